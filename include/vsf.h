@@ -1,0 +1,168 @@
+/*
+ * vsf.h -- C ABI of the MI355X (gfx950) stereo feature frontend.
+ *
+ * This is the drop-in seam for the two private methods of slam::Frontend that call into OpenCV in
+ * the reference (ut-amrl/vision_slam_frontend):
+ *
+ *   Frontend::ExtractFeatures  src/slam_frontend.cc:266-280  -> cv::Feature2D::detectAndCompute (ORB,
+ *                              parameters :205-213) or FastFeatureDetector::detect (:271, built :191)
+ *   Frontend::GetMatches       src/slam_frontend.cc:521-538  -> cv::BFMatcher(NORM_HAMMING)::knnMatch(k=2)
+ *                              (:525, matcher built :247) + the ratio test (:529-536)
+ *
+ * Plain pointers and sizes only; every function returns a vsf_status (never aborts, never throws;
+ * the reference's glog CHECK / cv::Exception / exit(1) paths become status codes).  A context owns one
+ * GPU's device memory and stream and is used by one host thread at a time.  Host-pointer entry points
+ * are synchronous; *_dev entry points take device pointers, are asynchronous on the context's stream and
+ * are what the batched / multi-GPU path uses.
+ *
+ * Output record layouts are the reference's: vsf_keypoint == cv::KeyPoint (28 B), vsf_dmatch ==
+ * cv::DMatch (16 B), descriptors are row-major N x 32 uint8 (cv::Mat CV_8U, 256 bit).
+ */
+#ifndef VSF_H_
+#define VSF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSF_VERSION 1
+#define VSF_DESC_BYTES 32
+#define VSF_MAX_LEVELS 64
+
+typedef enum {
+  VSF_OK = 0,
+  VSF_ERR_INVALID_ARG = 1, /* null pointer, bad size, image geometry != context geometry */
+  VSF_ERR_CAPACITY = 2,    /* an output or an internal segment overflowed; results are truncated */
+  VSF_ERR_HIP = 3,         /* a HIP runtime call failed (vsf_last_hip_error gives the code) */
+  VSF_ERR_UNSUPPORTED = 4, /* parameter combination outside the north-star path (e.g. WTA_K != 2) */
+  VSF_ERR_NO_DEVICE = 5    /* no usable gfx950 device */
+} vsf_status;
+
+/* cv::KeyPoint */
+typedef struct {
+  float x, y;      /* pt, level-0 pixel coordinates */
+  float size;      /* 31 * scale_l (ORB) / 7 (FAST) */
+  float angle;     /* degrees, [0,360) (ORB) / -1 (FAST) */
+  float response;  /* Harris response (ORB) / FAST score (FAST) */
+  int32_t octave;  /* pyramid level */
+  int32_t class_id;/* -1 */
+} vsf_keypoint;
+
+/* cv::DMatch */
+typedef struct {
+  int32_t queryIdx, trainIdx, imgIdx; /* imgIdx is always 0 */
+  float distance;                     /* (float) Hamming distance */
+} vsf_dmatch;
+
+typedef struct {
+  /* --- cv::ORB::create arguments (reference literals slam_frontend.cc:205-213) --- */
+  int32_t nfeatures;      /* 10000 in the reference; BASELINE configs use 2000 / 8000 */
+  float scale_factor;     /* 1.04f */
+  int32_t nlevels;        /* 50 (<= VSF_MAX_LEVELS) */
+  int32_t edge_threshold; /* 31 */
+  int32_t first_level;    /* 0 (only value supported) */
+  int32_t wta_k;          /* 2 (only value supported) */
+  int32_t score_type;     /* 0 = cv::ORB::HARRIS_SCORE (only value supported) */
+  int32_t patch_size;     /* 31 (only value supported) */
+  int32_t fast_threshold; /* 20 */
+  /* 1: GaussianBlur column pass rounds like OpenCV's SSE2 SymmColumnVec_32s8u (half-even) on columns
+   * [0, w - w%4) and like the scalar tail (half-up) beyond; 0: half-up everywhere (non-SSE2 build). */
+  int32_t blur_sse2;
+  /* --- cv::FastFeatureDetector::create(10, true) (slam_frontend.cc:191), FREAK branch only --- */
+  int32_t fast_detector_threshold; /* 10 */
+  int32_t fast_detector_nms;       /* 1 */
+  /* --- matcher: ratio test  dist1 < nn_match_ratio * dist2  with nn_match_ratio a double holding 0.6f
+   * (slam_frontend.cc:523,533,555)  ==  dist1 * 2^ratio_shift < ratio_num * dist2  exactly --- */
+  uint32_t ratio_num;   /* 10066330 */
+  uint32_t ratio_shift; /* 24 */
+  /* --- geometry and capacities (fixed per context) --- */
+  int32_t width, height;   /* image size in pixels */
+  int32_t max_images;      /* images per batch (2 per stereo frame) */
+  int32_t max_keypoints;   /* per-image capacity of keypoint/descriptor outputs; 0 = nfeatures + 256 */
+} vsf_params;
+
+typedef struct vsf_ctx vsf_ctx;
+
+/* Fills *p with the reference literals for the given image size and batch capacity. */
+vsf_status vsf_params_default(vsf_params* p, int width, int height, int max_images);
+/* ratio as the reference stores it: a float widened to double. Sets ratio_num / ratio_shift. */
+vsf_status vsf_params_set_ratio(vsf_params* p, float nn_match_ratio);
+
+vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out);
+void vsf_destroy(vsf_ctx* ctx);
+const char* vsf_status_string(vsf_status s);
+int vsf_last_hip_error(const vsf_ctx* ctx);
+vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream);
+/* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
+vsf_status vsf_sync(vsf_ctx* ctx);
+
+/* Pyramid geometry the context derived (cv::ORB layer sizes / scales / per-level feature budgets). */
+vsf_status vsf_level_info(const vsf_ctx* ctx, int level, int* w, int* h, float* scale, int* nfeatures);
+
+/* ---------------- host-pointer, synchronous: one call == one reference call ---------------- */
+
+/* detectAndCompute(image, noArray(), kps, desc)  (slam_frontend.cc:274-277).  kp_out/desc_out hold `cap`
+ * records; *n_out = number of keypoints found (<= cap written). */
+vsf_status vsf_extract(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, vsf_keypoint* kp_out,
+                       uint8_t* desc_out, int cap, int* n_out);
+/* fast_feature_detector_->detect(image, kps)  (slam_frontend.cc:271): FAST-9/16 + NMS on the full-resolution
+ * image, raster order.  threshold < 0 uses params.fast_detector_threshold. */
+vsf_status vsf_fast_detect(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int threshold, int nms,
+                           vsf_keypoint* kp_out, int cap, int* n_out);
+/* matcher_->knnMatch(q, t, matches, 2)  (slam_frontend.cc:525): idx2/dist2 are nq x 2, ordered by
+ * (distance, train index); absent neighbours are idx -1 / dist INT32_MAX. */
+vsf_status vsf_knn2_hamming(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,
+                            int32_t* dist2);
+/* Frontend::GetMatches(query, train, nn_match_ratio)  (slam_frontend.cc:521-538): matches in ascending
+ * queryIdx.  nt < 2 yields no matches (the reference reads out of bounds there). */
+vsf_status vsf_get_matches(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, vsf_dmatch* out,
+                           int cap, int* n_out);
+
+/* ---------------- device-pointer, asynchronous, batched ---------------- */
+
+/* detectAndCompute on n_images images resident in HBM.  d_imgs: image i starts at d_imgs + i*image_stride,
+ * rows `row_stride` bytes apart (both multiples of 16, base 16-byte aligned).  Outputs: d_kp
+ * [n_images][max_keypoints], d_desc [n_images][max_keypoints][32], d_counts [n_images]. */
+vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
+                                 size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts);
+/* knnMatch(k=2) + ratio test for n_pairs (query set, train set) pairs.  Set s of a descriptor array starts
+ * at base + s*set_stride bytes and holds d_n*[s] rows.  pair p matches query set q_set[p] against train set
+ * t_set[p] (device int32 arrays; NULL means q_set[p] = 2p, t_set[p] = 2p+1: left vs right of stereo frame p).
+ * Outputs per pair: d_idx2/d_dist2 [n_pairs][max_keypoints][2] (may be NULL), d_matches
+ * [n_pairs][max_keypoints], d_nmatches [n_pairs]. */
+vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
+                               const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs, int32_t* d_idx2,
+                               int32_t* d_dist2, vsf_dmatch* d_matches, int32_t* d_nmatches);
+/* The benchmarked hot path for a batch of stereo frames: extract(left) + extract(right) + GetMatches(left,
+ * right) (slam_frontend.cc:411-416).  d_imgs is [n_frames][2][h][w]-like with the strides above (image
+ * index 2f = left, 2f+1 = right). */
+vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frames, size_t image_stride,
+                                size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
+                                vsf_dmatch* d_matches, int32_t* d_nmatches);
+
+/* ---------------- introspection for kernel-level parity tests and the roofline model ---------------- */
+
+/* Copies level `level` of image `image` from the last extract to host (blurred: 0 = FAST/Harris/angle input,
+ * 1 = descriptor input).  out has `ostride` bytes per row. */
+vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t ostride);
+/* FAST+NMS candidates of (image, level) in raster order after the border filter (x, y, score) -> kp_out
+ * with size 7, angle -1, response = score.  */
+vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap,
+                                     int* n_out);
+/* Final per-level keypoints in level coordinates (after both retainBest cuts, with angle). */
+vsf_status vsf_debug_level_keypoints(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap,
+                                     int* n_out);
+/* Algorithmic HBM bytes of one extract of one image: SURVEY.md section 8(d) B_img for this geometry. */
+uint64_t vsf_algorithmic_bytes_per_image(const vsf_ctx* ctx);
+/* Total pyramid pixels P = sum_l w_l*h_l. */
+uint64_t vsf_pyramid_pixels(const vsf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSF_H_ */

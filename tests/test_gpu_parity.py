@@ -1,0 +1,138 @@
+"""GPU parity: every HIP kernel, through the C ABI (libvsf_hip.so), against the CPU oracle on the same seeded
+synthetic inputs.  Bit-exact for everything (integer / byte / index work; the few float outputs -- Harris
+response, angle, scaled coordinates -- are compared as raw bits as well)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from vision_slam_frontend_amd import capi
+    capi.lib()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ctx640(capi):
+    p = capi.default_params(640, 480, max_images=4, nfeatures=2000)
+    c = capi.Context(p)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def run640(ctx640, oracle, stereo640):
+    left, right = stereo640
+    o = oracle.Orb(nfeatures=2000)
+    o.run(left)
+    kp, desc = ctx640.extract(left)
+    return o, kp, desc
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_geometry_matches_oracle(ctx640, run640):
+    o = run640[0]
+    for l in range(50):
+        assert ctx640.level_info(l) == o.level_info(l)
+
+
+def test_pyramid_levels_bit_exact(ctx640, run640):
+    o = run640[0]
+    for l in range(50):
+        np.testing.assert_array_equal(ctx640.debug_level_image(0, l, False), o.level_image(l, False), err_msg="level %d" % l)
+
+
+def test_blurred_levels_bit_exact(ctx640, run640):
+    o = run640[0]
+    for l in range(50):
+        np.testing.assert_array_equal(ctx640.debug_level_image(0, l, True), o.level_image(l, True), err_msg="level %d" % l)
+
+
+def test_fast_candidates_raster_order(ctx640, run640):
+    o = run640[0]
+    total = 0
+    for l in range(50):
+        g = ctx640.debug_fast_candidates(0, l)
+        r = o.stage(0, l)
+        assert len(g) == len(r), "level %d" % l
+        for f in ("x", "y", "response"):
+            np.testing.assert_array_equal(g[f], r[f], err_msg="level %d %s" % (l, f))
+        total += len(r)
+    assert total > 10000
+
+
+def test_level_keypoints_order_response_angle(ctx640, run640):
+    o = run640[0]
+    for l in range(50):
+        g = ctx640.debug_level_keypoints(0, l)
+        r = o.stage(4, l)
+        assert len(g) == len(r), "level %d" % l
+        np.testing.assert_array_equal(g["x"], r["x"], err_msg="level %d x" % l)
+        np.testing.assert_array_equal(g["y"], r["y"], err_msg="level %d y" % l)
+        np.testing.assert_array_equal(_bits(g["response"]), _bits(r["response"]), err_msg="level %d harris" % l)
+        np.testing.assert_array_equal(_bits(g["angle"]), _bits(r["angle"]), err_msg="level %d angle" % l)
+
+
+def test_extract_keypoints_and_descriptors_bit_exact(run640):
+    o, kp, desc = run640
+    rk, rd = o.result()
+    assert len(kp) == len(rk) == 2000
+    assert kp.tobytes() == rk.tobytes()
+    np.testing.assert_array_equal(desc, rd)
+
+
+def test_knn2_and_matches(ctx640, oracle, stereo640, run640):
+    _, _, desc_l = run640
+    _, desc_r = ctx640.extract(stereo640[1])
+    gi, gd = ctx640.knn2_hamming(desc_l, desc_r)
+    ri, rd = oracle.knn2_hamming(desc_l, desc_r)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gd, rd)
+    gm = ctx640.get_matches(desc_l, desc_r)
+    rm = oracle.get_matches(desc_l, desc_r)
+    assert len(rm) > 50
+    assert gm.tobytes() == rm.tobytes()
+
+
+def test_knn2_tie_rule_adversarial(ctx640, oracle):
+    from vision_slam_frontend_amd import synth
+    q = synth.adversarial_descriptors(700, seed=1)
+    t = synth.adversarial_descriptors(900, seed=2)
+    gi, gd = ctx640.knn2_hamming(q, t)
+    ri, rd = oracle.knn2_hamming(q, t)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gd, rd)
+    assert ctx640.get_matches(q, t).tobytes() == oracle.get_matches(q, t).tobytes()
+
+
+@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (5, 1), (1, 2), (3, 3), (257, 255), (256, 513)])
+def test_matcher_edge_sizes(ctx640, oracle, nq, nt):
+    from vision_slam_frontend_amd import synth
+    q = synth.random_descriptors(max(nq, 1), seed=10)[:nq]
+    t = synth.random_descriptors(max(nt, 1), seed=11)[:nt]
+    gi, gd = ctx640.knn2_hamming(q, t)
+    ri, rd = oracle.knn2_hamming(q, t)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gd, rd)
+    assert ctx640.get_matches(q, t).tobytes() == oracle.get_matches(q, t).tobytes()
+
+
+def test_fast_detect_standalone(ctx640, oracle, stereo640):
+    left = stereo640[0]
+    for thr in (10, 20, 40):
+        g = ctx640.fast_detect(left, thr, True, cap=1 << 17)
+        r = oracle.fast9_16(left, thr, True)
+        assert len(r) > 100
+        assert g.tobytes() == r.tobytes(), "threshold %d" % thr
+
+
+def test_fast_detect_without_nms(ctx640, oracle, stereo640):
+    left = stereo640[0]
+    g = ctx640.fast_detect(left, 30, False, cap=1 << 18)
+    r = oracle.fast9_16(left, 30, False)
+    assert g.tobytes() == r.tobytes()

@@ -1,0 +1,260 @@
+"""ctypes binding of the C ABI in include/vsf.h (libvsf_hip.so, gfx950 HIP kernels).
+
+There is NO CPU fallback: if the shared library is missing or a GPU call fails this module raises.
+Host-side conveniences only (numpy in / numpy out for the host-pointer entry points, raw device pointers
+for the batched entry points, which callers fill from torch tensors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libvsf_hip.so"
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+DESC_BYTES = 32
+
+VSF_OK, VSF_ERR_INVALID_ARG, VSF_ERR_CAPACITY, VSF_ERR_HIP, VSF_ERR_UNSUPPORTED, VSF_ERR_NO_DEVICE = range(6)
+
+# Every symbol include/vsf.h declares (tests check that the library exports all of them).
+EXPORTS = [
+    "vsf_params_default", "vsf_params_set_ratio", "vsf_create", "vsf_destroy", "vsf_status_string",
+    "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
+    "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_batch_dev", "vsf_match_batch_dev",
+    "vsf_stereo_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
+    "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels",
+]
+
+
+class VsfParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+                ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32),
+                ("blur_sse2", C.c_int32), ("fast_detector_threshold", C.c_int32), ("fast_detector_nms", C.c_int32),
+                ("ratio_num", C.c_uint32), ("ratio_shift", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_images", C.c_int32), ("max_keypoints", C.c_int32)]
+
+
+class VsfError(RuntimeError):
+    def __init__(self, status: int, where: str, hip: int = 0):
+        self.status = status
+        msg = "%s: %s" % (where, lib().vsf_status_string(status).decode())
+        if status == VSF_ERR_HIP:
+            msg += " (hipError %d)" % hip
+        super().__init__(msg)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libvsf_hip.so; raises (loudly) if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). The product has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(str(LIB_PATH))
+        vp, i32, sz, pp = C.c_void_p, C.c_int, C.c_size_t, C.POINTER(VsfParams)
+        ip = C.POINTER(C.c_int)
+        L.vsf_params_default.argtypes = [pp, i32, i32, i32]
+        L.vsf_params_set_ratio.argtypes = [pp, C.c_float]
+        L.vsf_create.argtypes = [pp, i32, C.POINTER(vp)]
+        L.vsf_destroy.argtypes = [vp]
+        L.vsf_destroy.restype = None
+        L.vsf_status_string.argtypes = [i32]
+        L.vsf_status_string.restype = C.c_char_p
+        L.vsf_last_hip_error.argtypes = [vp]
+        L.vsf_get_params.argtypes = [vp, pp]
+        L.vsf_set_stream.argtypes = [vp, vp]
+        L.vsf_sync.argtypes = [vp]
+        L.vsf_level_info.argtypes = [vp, i32, ip, ip, C.POINTER(C.c_float), ip]
+        L.vsf_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, ip]
+        L.vsf_fast_detect.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, i32, ip]
+        L.vsf_knn2_hamming.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+        L.vsf_get_matches.argtypes = [vp, vp, i32, vp, i32, vp, i32, ip]
+        L.vsf_extract_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp]
+        L.vsf_match_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp, vp, vp]
+        L.vsf_stereo_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp, vp, vp]
+        L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
+        L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
+        L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
+        L.vsf_algorithmic_bytes_per_image.argtypes = [vp]
+        L.vsf_algorithmic_bytes_per_image.restype = C.c_uint64
+        L.vsf_pyramid_pixels.argtypes = [vp]
+        L.vsf_pyramid_pixels.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if isinstance(a, np.ndarray) else C.c_void_p(int(a) if a else 0)
+
+
+def default_params(width: int, height: int, max_images: int = 2, nfeatures: int = 10000, **over) -> VsfParams:
+    p = VsfParams()
+    st = lib().vsf_params_default(C.byref(p), width, height, max_images)
+    if st != VSF_OK:
+        raise VsfError(st, "vsf_params_default")
+    p.nfeatures = nfeatures
+    ratio = over.pop("nn_match_ratio", None)
+    if ratio is not None:
+        st = lib().vsf_params_set_ratio(C.byref(p), ratio)
+        if st != VSF_OK:
+            raise VsfError(st, "vsf_params_set_ratio")
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One GPU's vsf_ctx.  Not thread-safe (same contract as the C ABI)."""
+
+    def __init__(self, params: VsfParams, device: int = 0):
+        self._h = C.c_void_p()
+        st = lib().vsf_create(C.byref(params), device, C.byref(self._h))
+        if st != VSF_OK:
+            self._h = None
+            raise VsfError(st, "vsf_create")
+        self.params = VsfParams()
+        lib().vsf_get_params(self._h, C.byref(self.params))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vsf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st: int, where: str, allow_capacity: bool = False):
+        if st == VSF_OK or (allow_capacity and st == VSF_ERR_CAPACITY):
+            return st
+        raise VsfError(st, where, lib().vsf_last_hip_error(self._h))
+
+    # ---- geometry ----
+    @property
+    def nlevels(self) -> int:
+        return self.params.nlevels
+
+    def level_info(self, level: int):
+        w, h, n, s = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        self._check(lib().vsf_level_info(self._h, level, C.byref(w), C.byref(h), C.byref(s), C.byref(n)),
+                    "vsf_level_info")
+        return w.value, h.value, s.value, n.value
+
+    def algorithmic_bytes_per_image(self) -> int:
+        return int(lib().vsf_algorithmic_bytes_per_image(self._h))
+
+    def pyramid_pixels(self) -> int:
+        return int(lib().vsf_pyramid_pixels(self._h))
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(lib().vsf_set_stream(self._h, C.c_void_p(hip_stream or 0)), "vsf_set_stream")
+
+    def sync(self, allow_capacity: bool = False) -> int:
+        return self._check(lib().vsf_sync(self._h), "vsf_sync", allow_capacity)
+
+    # ---- host-pointer API (one call == one reference call) ----
+    def extract(self, img: np.ndarray, cap: int | None = None):
+        """detectAndCompute: returns (keypoints[KEYPOINT_DTYPE], descriptors[n,32] uint8)."""
+        img = _u8(img)
+        cap = self.params.max_keypoints if cap is None else cap
+        kp = np.zeros(max(cap, 1), KEYPOINT_DTYPE)
+        desc = np.zeros((max(cap, 1), DESC_BYTES), np.uint8)
+        n = C.c_int()
+        self._check(lib().vsf_extract(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kp), _p(desc),
+                                      cap, C.byref(n)), "vsf_extract")
+        return kp[:n.value], desc[:n.value]
+
+    def fast_detect(self, img: np.ndarray, threshold: int = -1, nms: bool = True, cap: int = 1 << 16):
+        img = _u8(img)
+        kp = np.zeros(max(cap, 1), KEYPOINT_DTYPE)
+        n = C.c_int()
+        self._check(lib().vsf_fast_detect(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], threshold,
+                                          int(nms), _p(kp), cap, C.byref(n)), "vsf_fast_detect")
+        return kp[:n.value]
+
+    def knn2_hamming(self, q: np.ndarray, t: np.ndarray):
+        q, t = _desc(q), _desc(t)
+        idx = np.full((max(len(q), 1), 2), -1, np.int32)
+        dist = np.full((max(len(q), 1), 2), np.iinfo(np.int32).max, np.int32)
+        self._check(lib().vsf_knn2_hamming(self._h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)),
+                    "vsf_knn2_hamming")
+        return idx[:len(q)], dist[:len(q)]
+
+    def get_matches(self, q: np.ndarray, t: np.ndarray) -> np.ndarray:
+        q, t = _desc(q), _desc(t)
+        out = np.zeros(max(len(q), 1), DMATCH_DTYPE)
+        n = C.c_int()
+        self._check(lib().vsf_get_matches(self._h, _p(q), len(q), _p(t), len(t), _p(out), len(q), C.byref(n)),
+                    "vsf_get_matches")
+        return out[:n.value]
+
+    # ---- device-pointer API (raw addresses, e.g. tensor.data_ptr()) ----
+    def extract_batch_dev(self, d_imgs: int, n_images: int, image_stride: int, row_stride: int, d_kp: int,
+                          d_desc: int, d_counts: int):
+        self._check(lib().vsf_extract_batch_dev(self._h, _p(d_imgs), n_images, image_stride, row_stride, _p(d_kp),
+                                                _p(d_desc), _p(d_counts)), "vsf_extract_batch_dev")
+
+    def match_batch_dev(self, d_desc: int, d_counts: int, set_stride: int, d_q_set: int, d_t_set: int, n_pairs: int,
+                        d_idx2: int, d_dist2: int, d_matches: int, d_nmatches: int):
+        self._check(lib().vsf_match_batch_dev(self._h, _p(d_desc), _p(d_counts), set_stride, _p(d_q_set),
+                                              _p(d_t_set), n_pairs, _p(d_idx2), _p(d_dist2), _p(d_matches),
+                                              _p(d_nmatches)), "vsf_match_batch_dev")
+
+    def stereo_batch_dev(self, d_imgs: int, n_frames: int, image_stride: int, row_stride: int, d_kp: int,
+                         d_desc: int, d_counts: int, d_matches: int, d_nmatches: int):
+        self._check(lib().vsf_stereo_batch_dev(self._h, _p(d_imgs), n_frames, image_stride, row_stride, _p(d_kp),
+                                               _p(d_desc), _p(d_counts), _p(d_matches), _p(d_nmatches)),
+                    "vsf_stereo_batch_dev")
+
+    # ---- introspection ----
+    def debug_level_image(self, image: int, level: int, blurred: bool = False) -> np.ndarray:
+        w, h, _, _ = self.level_info(level)
+        out = np.empty((h, w), np.uint8)
+        self._check(lib().vsf_debug_level_image(self._h, image, level, int(blurred), _p(out), w),
+                    "vsf_debug_level_image")
+        return out
+
+    def debug_fast_candidates(self, image: int, level: int, cap: int = 1 << 17) -> np.ndarray:
+        kp = np.zeros(cap, KEYPOINT_DTYPE)
+        n = C.c_int()
+        self._check(lib().vsf_debug_fast_candidates(self._h, image, level, _p(kp), cap, C.byref(n)),
+                    "vsf_debug_fast_candidates")
+        return kp[:min(n.value, cap)]
+
+    def debug_level_keypoints(self, image: int, level: int, cap: int = 1 << 15) -> np.ndarray:
+        kp = np.zeros(cap, KEYPOINT_DTYPE)
+        n = C.c_int()
+        self._check(lib().vsf_debug_level_keypoints(self._h, image, level, _p(kp), cap, C.byref(n)),
+                    "vsf_debug_level_keypoints")
+        return kp[:min(n.value, cap)]
+
+
+def _u8(img: np.ndarray) -> np.ndarray:
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise ValueError("expected a 2-D uint8 image")
+    if img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    return img
+
+
+def _desc(d: np.ndarray) -> np.ndarray:
+    d = np.ascontiguousarray(d, np.uint8)
+    return d.reshape(-1, DESC_BYTES)

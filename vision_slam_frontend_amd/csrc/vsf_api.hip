@@ -1,0 +1,806 @@
+// vsf_api.hip -- host side of the C ABI (include/vsf.h): context, pyramid geometry and coefficient tables,
+// HBM buffers, and the entry points that replace Frontend::ExtractFeatures (slam_frontend.cc:266-280) and
+// Frontend::GetMatches (slam_frontend.cc:521-538).  All arithmetic that OpenCV 3.2 does once per image size
+// on the host (layer sizes, layer scales, per-level feature budgets, resize coefficient tables, the fixed-point
+// Gaussian kernel; features2d/orb.cpp, imgproc/imgwarp.cpp, imgproc/smooth.cpp) is done here at vsf_create.
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vsf_internal.h"
+
+namespace {
+
+// ---- OpenCV scalar helpers (core/fast_math.hpp) ----
+inline int cvRoundD(double v) { return (int)std::nearbyint(v); }
+inline int cvRoundF(float v) { return (int)std::nearbyintf(v); }
+inline int cvFloorD(double v) {
+  const int i = cvRoundD(v);
+  return i - ((float)(v - i) < 0);
+}
+inline int cvCeilD(double v) {
+  const int i = cvRoundD(v);
+  return i + ((float)(i - v) < 0);
+}
+inline int16_t satShort(float v) { return (int16_t)std::min(std::max(cvRoundF(v), -32768), 32767); }
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct Geometry {
+  VsfGeom g{};
+  std::vector<VsfLevel> levels;
+  std::vector<uint32_t> strips;
+  std::vector<VsfTap> xt, yt;
+  std::vector<uint32_t> blur_tiles;
+  size_t fast_lds = 0;
+};
+
+// cv::resize(INTER_LINEAR, 8u) coefficient tables for one level (source sw x sh -> dw x dh).
+void build_taps(int sw, int sh, int dw, int dh, std::vector<VsfTap>* xt, std::vector<VsfTap>* yt) {
+  const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cvFloorD(fx);
+    fx -= sx;
+    if (sx < 0) fx = 0, sx = 0;
+    if (sx >= sw - 1) fx = 0, sx = sw - 1;  // (also the dx >= xmax single-tap case: weight 2048 on S[sx])
+    VsfTap t;
+    t.i0 = (uint16_t)sx;
+    t.i1 = (uint16_t)std::min(sx + 1, sw - 1);
+    t.c0 = satShort((1.f - fx) * 2048);
+    t.c1 = satShort(fx * 2048);
+    xt->push_back(t);
+  }
+  while (xt->size() % 4) xt->push_back(VsfTap{0, 0, 0, 0});
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = cvFloorD(fy);
+    fy -= sy;
+    VsfTap t;
+    t.i0 = (uint16_t)std::min(std::max(sy, 0), sh - 1);
+    t.i1 = (uint16_t)std::min(std::max(sy + 1, 0), sh - 1);
+    t.c0 = satShort((1.f - fy) * 2048);
+    t.c1 = satShort(fy * 2048);
+    yt->push_back(t);
+  }
+}
+
+// ORB umax table (features2d/orb.cpp computeKeyPoints) for the sanity check of the device constant.
+std::vector<int> orb_umax(int patch_size) {
+  const int half = patch_size / 2;
+  std::vector<int> umax(half + 2, 0);
+  int v, v0;
+  const int vmax = cvFloorD(half * std::sqrt(2.f) / 2 + 1);
+  const int vmin = cvCeilD(half * std::sqrt(2.f) / 2);
+  for (v = 0; v <= vmax; ++v) umax[v] = cvRoundD(std::sqrt((double)half * half - v * v));
+  for (v = half, v0 = 0; v >= vmin; --v) {
+    while (umax[v0] == umax[v0 + 1]) ++v0;
+    umax[v] = v0;
+    ++v0;
+  }
+  return umax;
+}
+
+// orb == true: the 50-level ORB pyramid with edge-threshold border; false: one full-resolution level with the
+// 3-pixel FAST rim (FastFeatureDetector::detect).
+bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
+  Geometry& G = *out;
+  const int nlevels = orb ? p.nlevels : 1;
+  const int border = orb ? std::max(p.edge_threshold, 3) : 3;
+  G.levels.assign(nlevels, VsfLevel{});
+  G.g.nlevels = nlevels;
+  G.g.width = p.width;
+  G.g.height = p.height;
+  const double scale_factor = (double)p.scale_factor;
+  // per-level budget
+  std::vector<int> nfeat(nlevels, 0);
+  if (orb) {
+    const float factor = (float)(1.0 / scale_factor);
+    float nd = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) {
+      nfeat[l] = cvRoundF(nd);
+      sum += nfeat[l];
+      nd *= factor;
+    }
+    nfeat[nlevels - 1] = std::max(p.nfeatures - sum, 0);
+  }
+  uint32_t offset = 0;
+  uint64_t pixels = 0;
+  int max_w = 0;
+  for (int l = 0; l < nlevels; l++) {
+    VsfLevel& L = G.levels[l];
+    L.scale = orb ? (float)std::pow(scale_factor, (double)(l - p.first_level)) : 1.f;
+    L.w = cvRoundF(p.width / L.scale);
+    L.h = cvRoundF(p.height / L.scale);
+    if (L.w < 1 || L.h < 1 || L.w > 4095 || L.h > 4095) return false;
+    L.pitch = align_up(L.w, 64);
+    L.offset = offset;
+    offset += (uint32_t)align_up(L.pitch * L.h, 256);
+    L.nfeatures = nfeat[l];
+    pixels += (uint64_t)L.w * L.h;
+    max_w = std::max(max_w, L.w);
+    if (L.w <= 2 * border || L.h <= 2 * border) {
+      L.x_lo = L.x_hi = L.y_lo = L.y_hi = border;  // runByImageBorder clears such a level
+    } else {
+      L.x_lo = border;
+      L.x_hi = L.w - border;
+      L.y_lo = border;
+      L.y_hi = L.h - border;
+    }
+    L.ncols = std::max(L.x_hi - L.x_lo + 2, 1);
+    L.ncols_magic = (uint32_t)((1ull << 32) / (uint32_t)L.ncols + 1);
+    L.blur_vec_end = p.blur_sse2 ? (L.w - L.w % 4) : 0;
+  }
+  G.g.pyr_bytes = offset;
+  G.g.pyramid_pixels = pixels;
+  // FAST strips: full-width bands of strip_rows rows
+  int max_tp = 16, max_sp = 16;
+  for (const VsfLevel& L : G.levels) {
+    const int cx0 = std::max(L.x_lo - 4, 0) & ~15;
+    max_tp = std::max(max_tp, align_up(L.x_hi + 4, 16) - cx0);
+    max_sp = std::max(max_sp, align_up(L.ncols, 16));
+  }
+  G.g.max_tile_pitch = max_tp;
+  G.g.max_score_pitch = max_sp;
+  int SR = 16;
+  auto lds_need = [&](int sr) { return (size_t)(sr + 8) * max_tp + (size_t)(sr + 2) * max_sp * 3 + 64; };
+  if (lds_need(SR) > 64 * 1024) SR = 8;
+  if (lds_need(SR) > 160 * 1024 - 1024) return false;
+  G.g.strip_rows = SR;
+  G.fast_lds = lds_need(SR);
+  uint32_t cand = 0;
+  int kp_off = 0;
+  for (int l = 0; l < nlevels; l++) {
+    VsfLevel& L = G.levels[l];
+    L.strip0 = (int)G.strips.size();
+    for (int y = L.y_lo; y < L.y_hi; y += SR) G.strips.push_back(((uint32_t)l << 16) | (uint32_t)y);
+    L.nstrips = (int)G.strips.size() - L.strip0;
+    if (L.nstrips > 512) return false;
+    const int vw = L.x_hi - L.x_lo;
+    L.seg_cap = nms ? ((vw + 1) / 2) * ((SR + 1) / 2) : vw * SR;
+    L.seg_cap = std::max(L.seg_cap, 1);
+    L.cand_offset = cand;
+    cand += (uint32_t)L.seg_cap * (uint32_t)L.nstrips;
+    L.kp_offset = kp_off;
+    L.kp_cap = 2 * L.nfeatures + 64;
+    kp_off += L.kp_cap;
+  }
+  G.g.cand_entries = std::max(cand, 1u);
+  G.g.nstrips = std::max((int)G.strips.size(), 1);
+  if (G.strips.empty()) G.strips.push_back(0);
+  G.g.lvlkp_entries = std::max(kp_off, 1);
+  // resize tables + blur tiles (ORB only)
+  if (orb) {
+    for (int l = 1; l < nlevels; l++) {
+      VsfLevel& L = G.levels[l];
+      const VsfLevel& P = G.levels[l - 1];
+      L.xtab = (uint32_t)G.xt.size();
+      L.ytab = (uint32_t)G.yt.size();
+      build_taps(P.w, P.h, L.w, L.h, &G.xt, &G.yt);
+    }
+    for (int l = 0; l < nlevels; l++) {
+      const VsfLevel& L = G.levels[l];
+      for (int ty = 0; ty * 16 < L.h; ty++)
+        for (int tx = 0; tx * 64 < L.w; tx++) G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)ty << 12) | tx);
+    }
+  }
+  if (G.xt.empty()) G.xt.push_back(VsfTap{0, 0, 0, 0});
+  if (G.yt.empty()) G.yt.push_back(VsfTap{0, 0, 0, 0});
+  if (G.blur_tiles.empty()) G.blur_tiles.push_back(0);
+  return true;
+}
+
+// getGaussianKernel(7, 2, CV_32F) scaled by 256 and rounded (createSeparableLinearFilter, 8u smooth kernels).
+void gaussian_taps(int k[4]) {
+  const int n = 7;
+  const double sigma = 2.0, scale2x = -0.5 / (sigma * sigma);
+  float cf[7];
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    const double x = i - (n - 1) * 0.5;
+    cf[i] = (float)std::exp(scale2x * x * x);
+    sum += cf[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < 4; i++) k[i] = cvRoundD((double)(float)(cf[i] * sum) * 256.0);
+}
+
+struct DevSet {  // device copies of one Geometry + its work buffers
+  VsfDev d{};
+  VsfLevel* levels = nullptr;
+  uint32_t* strips = nullptr;
+  VsfTap* xt = nullptr;
+  VsfTap* yt = nullptr;
+  uint32_t* blur_tiles = nullptr;
+  bool ready = false;
+};
+
+}  // namespace
+
+struct vsf_ctx {
+  vsf_params p{};
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int last_hip = 0;
+  Geometry orb, fast;
+  DevSet dorb, dfast;
+  int gauss[4] = {0, 0, 0, 0};
+  int32_t* d_status = nullptr;
+  int32_t* h_status = nullptr;  // pinned
+  // staging for the host-pointer entry points
+  uint8_t* st_img = nullptr;
+  size_t st_img_pitch = 0, st_img_stride = 0;
+  vsf_keypoint* st_kp = nullptr;
+  uint8_t* st_desc = nullptr;
+  int32_t* st_counts = nullptr;
+  // matcher work buffers
+  int32_t* m_idx2 = nullptr;
+  int32_t* m_dist2 = nullptr;
+  int m_pairs = 0, m_rows = 0;
+  uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
+  int32_t* mh_counts = nullptr;
+  vsf_dmatch* mh_matches = nullptr;
+  int32_t* mh_nmatches = nullptr;
+  int mh_rows = 0;
+  VsfImages last_images{};
+  bool last_valid = false;
+  bool fast_nms = true;  // NMS mode the standalone-FAST geometry was built for
+};
+
+namespace {
+
+#define VSF_HIP(call)                     \
+  do {                                    \
+    hipError_t e_ = (call);               \
+    if (e_ != hipSuccess) {               \
+      ctx->last_hip = (int)e_;            \
+      return VSF_ERR_HIP;                 \
+    }                                     \
+  } while (0)
+
+template <class T>
+hipError_t upload(T** dst, const std::vector<T>& v) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), v.size() * sizeof(T));
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, int n_images) {
+  VSF_HIP(upload(&ds->levels, G.levels));
+  VSF_HIP(upload(&ds->strips, G.strips));
+  VSF_HIP(upload(&ds->xt, G.xt));
+  VSF_HIP(upload(&ds->yt, G.yt));
+  VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
+  VsfDev& d = ds->d;
+  d.levels = ds->levels;
+  d.strips = ds->strips;
+  d.xtaps = ds->xt;
+  d.ytaps = ds->yt;
+  const size_t n = (size_t)n_images;
+  if (orb) {
+    VSF_HIP(hipMalloc((void**)&d.pyr, n * G.g.pyr_bytes));
+    VSF_HIP(hipMalloc((void**)&d.blur, n * G.g.pyr_bytes));
+    VSF_HIP(hipMalloc((void**)&d.scratch, n * 3 * G.g.cand_entries * sizeof(uint32_t)));
+    VSF_HIP(hipMalloc((void**)&d.lvlkp, n * G.g.lvlkp_entries * sizeof(VsfLevelKp)));
+    VSF_HIP(hipMalloc((void**)&d.lvl_count, n * G.g.nlevels * sizeof(int32_t)));
+    VSF_HIP(hipMemset(d.lvl_count, 0, n * G.g.nlevels * sizeof(int32_t)));
+  }
+  VSF_HIP(hipMalloc((void**)&d.cand, n * G.g.cand_entries * sizeof(uint32_t)));
+  VSF_HIP(hipMalloc((void**)&d.strip_count, n * G.g.nstrips * sizeof(int32_t)));
+  VSF_HIP(hipMemset(d.strip_count, 0, n * G.g.nstrips * sizeof(int32_t)));
+  d.status = ctx->d_status;
+  ds->ready = true;
+  return VSF_OK;
+}
+
+void free_devset(DevSet* ds) {
+  hipFree(ds->levels);
+  hipFree(ds->strips);
+  hipFree(ds->xt);
+  hipFree(ds->yt);
+  hipFree(ds->blur_tiles);
+  hipFree(ds->d.pyr);
+  hipFree(ds->d.blur);
+  hipFree(ds->d.scratch);
+  hipFree(ds->d.lvlkp);
+  hipFree(ds->d.lvl_count);
+  hipFree(ds->d.cand);
+  hipFree(ds->d.strip_count);
+  *ds = DevSet();
+}
+
+vsf_status ensure_match_buffers(vsf_ctx* ctx, int pairs, int rows) {
+  if (pairs <= ctx->m_pairs && rows <= ctx->m_rows) return VSF_OK;
+  pairs = std::max(pairs, ctx->m_pairs);
+  rows = std::max(rows, ctx->m_rows);
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(ctx->m_idx2);
+  hipFree(ctx->m_dist2);
+  ctx->m_idx2 = ctx->m_dist2 = nullptr;
+  VSF_HIP(hipMalloc((void**)&ctx->m_idx2, (size_t)pairs * rows * 2 * sizeof(int32_t)));
+  VSF_HIP(hipMalloc((void**)&ctx->m_dist2, (size_t)pairs * rows * 2 * sizeof(int32_t)));
+  ctx->m_pairs = pairs;
+  ctx->m_rows = rows;
+  return VSF_OK;
+}
+
+vsf_status ensure_match_host_staging(vsf_ctx* ctx, int rows) {
+  if (rows <= ctx->mh_rows) return VSF_OK;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(ctx->mh_desc);
+  hipFree(ctx->mh_matches);
+  ctx->mh_desc = nullptr;
+  ctx->mh_matches = nullptr;
+  VSF_HIP(hipMalloc((void**)&ctx->mh_desc, (size_t)2 * rows * VSF_DESC_BYTES));
+  VSF_HIP(hipMalloc((void**)&ctx->mh_matches, (size_t)rows * sizeof(vsf_dmatch)));
+  if (!ctx->mh_counts) VSF_HIP(hipMalloc((void**)&ctx->mh_counts, 2 * sizeof(int32_t)));
+  if (!ctx->mh_nmatches) VSF_HIP(hipMalloc((void**)&ctx->mh_nmatches, sizeof(int32_t)));
+  ctx->mh_rows = rows;
+  return VSF_OK;
+}
+
+vsf_status check_status_word(vsf_ctx* ctx) {
+  VSF_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VSF_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  return (*ctx->h_status & 1) ? VSF_ERR_CAPACITY : VSF_OK;
+}
+
+vsf_status validate_images(const vsf_ctx* ctx, const uint8_t* d_imgs, int n, size_t image_stride, size_t row_stride) {
+  if (!d_imgs || n < 1 || n > ctx->p.max_images) return VSF_ERR_INVALID_ARG;
+  if (((uintptr_t)d_imgs & 15) || (image_stride & 15) || (row_stride & 15)) return VSF_ERR_INVALID_ARG;
+  if (row_stride < (size_t)ctx->p.width || image_stride < row_stride * (size_t)ctx->p.height) return VSF_ERR_INVALID_ARG;
+  return VSF_OK;
+}
+
+vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
+  const VsfDev& d = ctx->dorb.d;
+  const VsfGeom& g = ctx->orb.g;
+  vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ctx->stream);
+  vsf_launch_fast(d, g, im, ctx->p.fast_threshold, ctx->stream);
+  vsf_launch_select(d, g, im, ctx->stream);
+  vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, ctx->stream);
+  vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp, d_desc, d_counts, ctx->stream);
+  ctx->last_images = im;
+  ctx->last_valid = true;
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+vsf_status vsf_params_default(vsf_params* p, int width, int height, int max_images) {
+  if (!p) return VSF_ERR_INVALID_ARG;
+  std::memset(p, 0, sizeof(*p));
+  p->nfeatures = 10000;
+  p->scale_factor = 1.04f;
+  p->nlevels = 50;
+  p->edge_threshold = 31;
+  p->first_level = 0;
+  p->wta_k = 2;
+  p->score_type = 0;
+  p->patch_size = 31;
+  p->fast_threshold = 20;
+  p->blur_sse2 = 1;
+  p->fast_detector_threshold = 10;
+  p->fast_detector_nms = 1;
+  p->width = width;
+  p->height = height;
+  p->max_images = max_images;
+  p->max_keypoints = 0;
+  return vsf_params_set_ratio(p, 0.6f);
+}
+
+vsf_status vsf_params_set_ratio(vsf_params* p, float nn_match_ratio) {
+  if (!p || !(nn_match_ratio > 0.f) || !(nn_match_ratio < 256.f)) return VSF_ERR_INVALID_ARG;
+  // nn_match_ratio widened to double (slam_frontend.cc:523) == num / 2^shift exactly.
+  double r = (double)nn_match_ratio;
+  uint32_t shift = 0;
+  while (r != std::floor(r) && shift < 31) {
+    r *= 2.0;
+    ++shift;
+  }
+  if (r != std::floor(r) || r >= 4294967296.0) return VSF_ERR_INVALID_ARG;
+  p->ratio_num = (uint32_t)r;
+  p->ratio_shift = shift;
+  return VSF_OK;
+}
+
+const char* vsf_status_string(vsf_status s) {
+  switch (s) {
+    case VSF_OK: return "ok";
+    case VSF_ERR_INVALID_ARG: return "invalid argument";
+    case VSF_ERR_CAPACITY: return "capacity exceeded (results truncated)";
+    case VSF_ERR_HIP: return "HIP runtime error";
+    case VSF_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case VSF_ERR_NO_DEVICE: return "no usable GPU";
+  }
+  return "unknown";
+}
+
+vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
+  if (!p || !out) return VSF_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (p->first_level != 0 || p->wta_k != 2 || p->score_type != 0 || p->patch_size != 31) return VSF_ERR_UNSUPPORTED;
+  if (p->nlevels < 1 || p->nlevels > VSF_MAX_LEVELS || p->width < 16 || p->height < 16 || p->max_images < 1 ||
+      p->nfeatures < 0 || p->edge_threshold < 0 || !(p->scale_factor > 1.0f))
+    return VSF_ERR_INVALID_ARG;
+  if (p->edge_threshold < 22) return VSF_ERR_UNSUPPORTED;  // borders are not materialised: needs reach 22 <= edge
+  {
+    const std::vector<int> um = orb_umax(31);
+    static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int i = 0; i < 16; i++)
+      if (um[i] != expect[i]) return VSF_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return VSF_ERR_NO_DEVICE;
+  vsf_ctx* ctx = new (std::nothrow) vsf_ctx();
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  ctx->p = *p;
+  if (ctx->p.max_keypoints <= 0) ctx->p.max_keypoints = ctx->p.nfeatures + 256;
+  ctx->device = device;
+  auto fail = [&](vsf_status s) {
+    vsf_destroy(ctx);
+    return s;
+  };
+  if (hipSetDevice(device) != hipSuccess) return fail(VSF_ERR_NO_DEVICE);
+  if (!build_geometry(ctx->p, true, true, &ctx->orb)) return fail(VSF_ERR_INVALID_ARG);
+  gaussian_taps(ctx->gauss);
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(VSF_ERR_HIP);
+  ctx->stream = ctx->own_stream;
+  if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipHostMalloc((void**)&ctx->h_status, sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+    return fail(VSF_ERR_HIP);
+  vsf_status st = alloc_devset(ctx, ctx->orb, &ctx->dorb, true, ctx->p.max_images);
+  if (st != VSF_OK) return fail(st);
+  // staging buffers of the host-pointer API (one image / one set of outputs per image slot)
+  ctx->st_img_pitch = (size_t)align_up(ctx->p.width, 64);
+  ctx->st_img_stride = ctx->st_img_pitch * (size_t)ctx->p.height;
+  const size_t n = (size_t)ctx->p.max_images, K = (size_t)ctx->p.max_keypoints;
+  if (hipMalloc((void**)&ctx->st_img, n * ctx->st_img_stride) != hipSuccess ||
+      hipMalloc((void**)&ctx->st_kp, n * K * sizeof(vsf_keypoint)) != hipSuccess ||
+      hipMalloc((void**)&ctx->st_desc, n * K * VSF_DESC_BYTES) != hipSuccess ||
+      hipMalloc((void**)&ctx->st_counts, n * sizeof(int32_t)) != hipSuccess)
+    return fail(VSF_ERR_HIP);
+  if (hipDeviceSynchronize() != hipSuccess) return fail(VSF_ERR_HIP);
+  *out = ctx;
+  return VSF_OK;
+}
+
+void vsf_destroy(vsf_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
+  free_devset(&ctx->dorb);
+  free_devset(&ctx->dfast);
+  hipFree(ctx->d_status);
+  if (ctx->h_status) hipHostFree(ctx->h_status);
+  hipFree(ctx->st_img);
+  hipFree(ctx->st_kp);
+  hipFree(ctx->st_desc);
+  hipFree(ctx->st_counts);
+  hipFree(ctx->m_idx2);
+  hipFree(ctx->m_dist2);
+  hipFree(ctx->mh_desc);
+  hipFree(ctx->mh_counts);
+  hipFree(ctx->mh_matches);
+  hipFree(ctx->mh_nmatches);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int vsf_last_hip_error(const vsf_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out) {
+  if (!ctx || !out) return VSF_ERR_INVALID_ARG;
+  *out = ctx->p;
+  return VSF_OK;
+}
+
+vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return VSF_OK;
+}
+
+vsf_status vsf_sync(vsf_ctx* ctx) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  return check_status_word(ctx);
+}
+
+vsf_status vsf_level_info(const vsf_ctx* ctx, int level, int* w, int* h, float* scale, int* nfeatures) {
+  if (!ctx || level < 0 || level >= ctx->orb.g.nlevels) return VSF_ERR_INVALID_ARG;
+  const VsfLevel& L = ctx->orb.levels[level];
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  if (scale) *scale = L.scale;
+  if (nfeatures) *nfeatures = L.nfeatures;
+  return VSF_OK;
+}
+
+uint64_t vsf_pyramid_pixels(const vsf_ctx* ctx) { return ctx ? ctx->orb.g.pyramid_pixels : 0; }
+
+uint64_t vsf_algorithmic_bytes_per_image(const vsf_ctx* ctx) {
+  if (!ctx) return 0;
+  // resize reads + resize writes + FAST read + blur read/write + outputs.
+  const auto& Ls = ctx->orb.levels;
+  uint64_t P = 0, rd = 0, wr = 0;
+  for (size_t l = 0; l < Ls.size(); l++) {
+    const uint64_t px = (uint64_t)Ls[l].w * Ls[l].h;
+    P += px;
+    if (l + 1 < Ls.size()) rd += px;
+    if (l >= 1) wr += px;
+  }
+  return rd + wr + P + 2 * P + (uint64_t)ctx->p.nfeatures * (sizeof(vsf_keypoint) + VSF_DESC_BYTES);
+}
+
+vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
+                                 size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
+  if (!ctx || !d_kp || !d_desc || !d_counts) return VSF_ERR_INVALID_ARG;
+  vsf_status st = validate_images(ctx, d_imgs, n_images, image_stride, row_stride);
+  if (st != VSF_OK) return st;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VsfImages im{d_imgs, image_stride, row_stride, n_images};
+  return extract_async(ctx, im, d_kp, d_desc, d_counts);
+}
+
+vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
+                               const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs, int32_t* d_idx2,
+                               int32_t* d_dist2, vsf_dmatch* d_matches, int32_t* d_nmatches) {
+  if (!ctx || !d_desc || !d_counts || n_pairs < 1 || !d_matches || !d_nmatches || (set_stride & 15))
+    return VSF_ERR_INVALID_ARG;
+  if ((d_idx2 == nullptr) != (d_dist2 == nullptr)) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  const int rows = ctx->p.max_keypoints;
+  if (!d_idx2) {
+    vsf_status st = ensure_match_buffers(ctx, n_pairs, rows);
+    if (st != VSF_OK) return st;
+    d_idx2 = ctx->m_idx2;
+    d_dist2 = ctx->m_dist2;
+  }
+  vsf_launch_knn2(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->stream);
+  vsf_launch_ratio_compact(d_counts, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->p.ratio_num,
+                           ctx->p.ratio_shift, d_matches, d_nmatches, ctx->d_status, ctx->stream);
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frames, size_t image_stride,
+                                size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
+                                vsf_dmatch* d_matches, int32_t* d_nmatches) {
+  if (!ctx || n_frames < 1) return VSF_ERR_INVALID_ARG;
+  vsf_status st = vsf_extract_batch_dev(ctx, d_imgs, 2 * n_frames, image_stride, row_stride, d_kp, d_desc, d_counts);
+  if (st != VSF_OK) return st;
+  return vsf_match_batch_dev(ctx, d_desc, d_counts, (size_t)ctx->p.max_keypoints * VSF_DESC_BYTES, nullptr, nullptr,
+                             n_frames, nullptr, nullptr, d_matches, d_nmatches);
+}
+
+// ---------------- host-pointer entry points ----------------
+
+static vsf_status upload_image(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int slot) {
+  if (!img || w != ctx->p.width || h != ctx->p.height || stride < (size_t)w) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipMemcpy2DAsync(ctx->st_img + (size_t)slot * ctx->st_img_stride, ctx->st_img_pitch, img, stride, (size_t)w,
+                           (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+  return VSF_OK;
+}
+
+vsf_status vsf_extract(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, vsf_keypoint* kp_out,
+                       uint8_t* desc_out, int cap, int* n_out) {
+  if (!ctx || !n_out || cap < 0 || (cap > 0 && (!kp_out || !desc_out))) return VSF_ERR_INVALID_ARG;
+  *n_out = 0;
+  VSF_HIP(hipSetDevice(ctx->device));
+  vsf_status st = upload_image(ctx, img, w, h, stride, 0);
+  if (st != VSF_OK) return st;
+  VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 1};
+  st = extract_async(ctx, im, ctx->st_kp, ctx->st_desc, ctx->st_counts);
+  if (st != VSF_OK) return st;
+  int32_t n = 0;
+  VSF_HIP(hipMemcpyAsync(&n, ctx->st_counts, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  st = check_status_word(ctx);  // synchronises
+  *n_out = n;
+  const int m = std::min(std::min((int)n, cap), ctx->p.max_keypoints);
+  if (m > 0) {
+    VSF_HIP(hipMemcpy(kp_out, ctx->st_kp, (size_t)m * sizeof(vsf_keypoint), hipMemcpyDeviceToHost));
+    VSF_HIP(hipMemcpy(desc_out, ctx->st_desc, (size_t)m * VSF_DESC_BYTES, hipMemcpyDeviceToHost));
+  }
+  if (st == VSF_OK && n > m) st = VSF_ERR_CAPACITY;
+  return st;
+}
+
+vsf_status vsf_fast_detect(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int threshold, int nms,
+                           vsf_keypoint* kp_out, int cap, int* n_out) {
+  if (!ctx || !n_out || cap < 0 || (cap > 0 && !kp_out)) return VSF_ERR_INVALID_ARG;
+  *n_out = 0;
+  VSF_HIP(hipSetDevice(ctx->device));
+  if (threshold < 0) {
+    threshold = ctx->p.fast_detector_threshold;
+  }
+  threshold = std::min(std::max(threshold, 0), 255);
+  const bool want_nms = nms != 0;
+  // The candidate segments are sized for the NMS case (no two 8-adjacent keypoints); without NMS every pixel
+  // may be a corner, so that geometry is (re)built with full-density segments.
+  if (!ctx->dfast.ready || ctx->fast_nms != want_nms) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    free_devset(&ctx->dfast);
+    ctx->fast = Geometry();
+    if (!build_geometry(ctx->p, false, want_nms, &ctx->fast)) return VSF_ERR_INVALID_ARG;
+    vsf_status st0 = alloc_devset(ctx, ctx->fast, &ctx->dfast, false, 1);
+    if (st0 != VSF_OK) return st0;
+    ctx->fast_nms = want_nms;
+  }
+  vsf_status st = upload_image(ctx, img, w, h, stride, 0);
+  if (st != VSF_OK) return st;
+  VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 1};
+  // Output capacity: grow a private buffer if the caller's cap exceeds the extract staging.
+  const int kcap = ctx->p.max_keypoints;
+  vsf_launch_fast(ctx->dfast.d, ctx->fast.g, im, threshold | (want_nms ? 0 : (1 << 16)), ctx->stream);
+  vsf_keypoint* d_out = ctx->st_kp;
+  vsf_keypoint* big = nullptr;
+  int outcap = kcap;
+  if (cap > kcap) {
+    VSF_HIP(hipMalloc((void**)&big, (size_t)cap * sizeof(vsf_keypoint)));
+    d_out = big;
+    outcap = cap;
+  }
+  vsf_launch_fast_emit(ctx->dfast.d, ctx->fast.g, 1, outcap, d_out, ctx->st_counts, ctx->stream);
+  int32_t n = 0;
+  hipError_t e = hipMemcpyAsync(&n, ctx->st_counts, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) {
+    st = check_status_word(ctx);
+    if (st == VSF_ERR_HIP) e = (hipError_t)ctx->last_hip;
+  }
+  if (e == hipSuccess) {
+    *n_out = n;
+    const int m = std::min(std::min((int)n, cap), outcap);
+    if (m > 0) e = hipMemcpy(kp_out, d_out, (size_t)m * sizeof(vsf_keypoint), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) st = n > m ? VSF_ERR_CAPACITY : VSF_OK;  // the status word only reflects `outcap`
+  }
+  if (big) hipFree(big);
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    return VSF_ERR_HIP;
+  }
+  return st;
+}
+
+static vsf_status match_host(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,
+                             int32_t* dist2, vsf_dmatch* out, int cap, int* n_out) {
+  if (nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || nt >= (1 << 20)) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  if (n_out) *n_out = 0;
+  if (nq == 0) return VSF_OK;
+  const int rows = std::max(std::max(nq, nt), 1);
+  vsf_status st = ensure_match_host_staging(ctx, rows);
+  if (st != VSF_OK) return st;
+  st = ensure_match_buffers(ctx, 1, ctx->mh_rows);
+  if (st != VSF_OK) return st;
+  const int R = ctx->mh_rows;
+  const size_t set_stride = (size_t)R * VSF_DESC_BYTES;
+  const int32_t counts[2] = {nq, nt};
+  VSF_HIP(hipMemcpyAsync(ctx->mh_counts, counts, sizeof(counts), hipMemcpyHostToDevice, ctx->stream));
+  VSF_HIP(hipMemcpyAsync(ctx->mh_desc, q, (size_t)nq * VSF_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+  if (nt > 0)
+    VSF_HIP(hipMemcpyAsync(ctx->mh_desc + set_stride, t, (size_t)nt * VSF_DESC_BYTES, hipMemcpyHostToDevice,
+                           ctx->stream));
+  // m_idx2/m_dist2 are laid out [pair][m_rows][2]; the kernels are given the same row capacity.
+  vsf_launch_knn2(ctx->mh_desc, ctx->mh_counts, set_stride, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2,
+                  ctx->stream);
+  if (out) {
+    vsf_launch_ratio_compact(ctx->mh_counts, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
+                             ctx->p.ratio_shift, ctx->mh_matches, ctx->mh_nmatches, ctx->d_status, ctx->stream);
+  }
+  VSF_HIP(hipGetLastError());
+  if (idx2) {
+    VSF_HIP(hipMemcpyAsync(idx2, ctx->m_idx2, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VSF_HIP(hipMemcpyAsync(dist2, ctx->m_dist2, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  int32_t nm = 0;
+  if (out) VSF_HIP(hipMemcpyAsync(&nm, ctx->mh_nmatches, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  if (out) {
+    if (n_out) *n_out = nm;
+    const int m = std::min((int)nm, cap);
+    if (m > 0) VSF_HIP(hipMemcpy(out, ctx->mh_matches, (size_t)m * sizeof(vsf_dmatch), hipMemcpyDeviceToHost));
+    if (nm > cap) return VSF_ERR_CAPACITY;
+  }
+  return VSF_OK;
+}
+
+vsf_status vsf_knn2_hamming(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,
+                            int32_t* dist2) {
+  if (!ctx || (nq > 0 && (!idx2 || !dist2))) return VSF_ERR_INVALID_ARG;
+  return match_host(ctx, q, nq, t, nt, idx2, dist2, nullptr, 0, nullptr);
+}
+
+vsf_status vsf_get_matches(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, vsf_dmatch* out,
+                           int cap, int* n_out) {
+  if (!ctx || !n_out || cap < 0 || (cap > 0 && !out)) return VSF_ERR_INVALID_ARG;
+  vsf_dmatch dummy;
+  return match_host(ctx, q, nq, t, nt, nullptr, nullptr, out ? out : &dummy, cap, n_out);
+}
+
+// ---------------- introspection ----------------
+
+vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t ostride) {
+  if (!ctx || !out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
+      level >= ctx->orb.g.nlevels)
+    return VSF_ERR_INVALID_ARG;
+  const VsfLevel& L = ctx->orb.levels[level];
+  if (ostride < (size_t)L.w) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  const uint8_t* src;
+  size_t pitch;
+  if (!blurred && level == 0) {
+    src = ctx->last_images.base + (size_t)image * ctx->last_images.image_stride;
+    pitch = ctx->last_images.row_stride;
+  } else {
+    src = (blurred ? ctx->dorb.d.blur : ctx->dorb.d.pyr) + (size_t)image * ctx->orb.g.pyr_bytes + L.offset;
+    pitch = (size_t)L.pitch;
+  }
+  VSF_HIP(hipMemcpy2D(out, ostride, src, pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+  return VSF_OK;
+}
+
+vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap, int* n_out) {
+  if (!ctx || !n_out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
+      level >= ctx->orb.g.nlevels)
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  const VsfLevel& L = ctx->orb.levels[level];
+  const VsfGeom& g = ctx->orb.g;
+  std::vector<int32_t> sc(std::max(L.nstrips, 1));
+  if (L.nstrips)
+    VSF_HIP(hipMemcpy(sc.data(), ctx->dorb.d.strip_count + (size_t)image * g.nstrips + L.strip0,
+                      (size_t)L.nstrips * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int n = 0;
+  std::vector<uint32_t> seg(L.seg_cap);
+  for (int s = 0; s < L.nstrips; s++) {
+    if (sc[s] <= 0) continue;
+    VSF_HIP(hipMemcpy(seg.data(),
+                      ctx->dorb.d.cand + (size_t)image * g.cand_entries + L.cand_offset + (size_t)s * L.seg_cap,
+                      (size_t)sc[s] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < sc[s]; i++, n++) {
+      if (n < cap && kp_out) {
+        const uint32_t cd = seg[i];
+        kp_out[n] = vsf_keypoint{(float)VSF_CAND_X(cd), (float)VSF_CAND_Y(cd), 7.f, -1.f, (float)VSF_CAND_SCORE(cd), 0, -1};
+      }
+    }
+  }
+  *n_out = n;
+  return VSF_OK;
+}
+
+vsf_status vsf_debug_level_keypoints(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap, int* n_out) {
+  if (!ctx || !n_out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
+      level >= ctx->orb.g.nlevels)
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  const VsfLevel& L = ctx->orb.levels[level];
+  const VsfGeom& g = ctx->orb.g;
+  int32_t n = 0;
+  VSF_HIP(hipMemcpy(&n, ctx->dorb.d.lvl_count + (size_t)image * g.nlevels + level, sizeof(int32_t),
+                    hipMemcpyDeviceToHost));
+  std::vector<VsfLevelKp> v(std::max(n, 1));
+  if (n > 0)
+    VSF_HIP(hipMemcpy(v.data(), ctx->dorb.d.lvlkp + (size_t)image * g.lvlkp_entries + L.kp_offset,
+                      (size_t)n * sizeof(VsfLevelKp), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < cap && kp_out; i++)
+    kp_out[i] = vsf_keypoint{(float)(v[i].xy & 0xFFFu), (float)(v[i].xy >> 12), 31 * L.scale, v[i].angle,
+                             v[i].response, level, -1};
+  *n_out = n;
+  return VSF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// vsf_internal.h -- structures shared by the host side of the C ABI and the gfx950 kernels.
+#ifndef VSF_INTERNAL_H_
+#define VSF_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vsf.h"
+
+// ---- pyramid level descriptor (device-resident table, read through scalar loads) ----
+struct VsfLevel {
+  int32_t w, h;            // level size (cv::ORB layer size)
+  int32_t pitch;           // bytes per row in the pyramid buffers (multiple of 64)
+  uint32_t offset;         // byte offset of row 0 inside one image's pyramid block
+  float scale;             // layerScale[level]
+  int32_t nfeatures;       // per-level budget n_l
+  int32_t x_lo, x_hi;      // keypoints may sit at x_lo <= x < x_hi  (runByImageBorder / FAST rim)
+  int32_t y_lo, y_hi;
+  int32_t strip0, nstrips; // this level's strips in the strip table
+  uint32_t cand_offset;    // u32 index of this level's first candidate segment (per image)
+  int32_t seg_cap;         // capacity of one strip's candidate segment
+  int32_t kp_offset;       // index of this level's final-keypoint segment (per image)
+  int32_t kp_cap;          // its capacity
+  int32_t blur_vec_end;    // columns [0, blur_vec_end) round half-even (SSE2 path), the rest half-up
+  uint32_t xtab, ytab;     // entry offsets of this level's resize tables (level >= 1)
+  int32_t ncols;           // x_hi - x_lo + 2: width of the FAST score region
+  uint32_t ncols_magic;    // floor(2^32 / ncols) + 1: idx / ncols == umulhi(idx, magic) for idx < 2^16
+  int32_t pad0, pad1;
+};
+
+// Resize coefficient table entry (cv::resize INTER_LINEAR 8u: xofs/ialpha resp. yofs/ibeta with the
+// out-of-range taps already clamped, weights kept).
+struct VsfTap {
+  uint16_t i0, i1;  // source indices of the two taps
+  int16_t c0, c1;   // 11-bit fixed-point weights
+};
+
+// Candidate keypoint, 32 bit: score << 24 | y << 12 | x   (level coordinates, x,y < 4096)
+#define VSF_CAND_PACK(x, y, s) (((uint32_t)(s) << 24) | ((uint32_t)(y) << 12) | (uint32_t)(x))
+#define VSF_CAND_X(c) ((int)((c)&0xFFFu))
+#define VSF_CAND_Y(c) ((int)(((c) >> 12) & 0xFFFu))
+#define VSF_CAND_SCORE(c) ((int)((c) >> 24))
+
+// Final per-level keypoint record (level coordinates).
+struct VsfLevelKp {
+  uint32_t xy;  // y << 12 | x
+  float response;
+  float angle;
+};
+
+#define VSF_FAST_THREADS 256
+#define VSF_SELECT_THREADS 256
+#define VSF_SELECT_LDS_ENTRIES 16384  // stage-1 array (u32) kept in LDS when the candidate count fits
+#define VSF_SELECT_LDS_STAGE2 2048    // stage-2 (response, xy) pairs kept in LDS when they fit
+
+struct VsfGeom {
+  int nlevels;
+  int width, height;
+  uint32_t pyr_bytes;       // one image's pyramid block
+  uint32_t cand_entries;    // one image's candidate buffer (u32 entries)
+  int nstrips;              // strips per image
+  int lvlkp_entries;        // one image's level-keypoint buffer (VsfLevelKp entries)
+  int max_tile_pitch;       // widest FAST LDS image tile row
+  int max_score_pitch;
+  int strip_rows;           // rows per FAST strip (16, or 8 when the LDS tile of a wide image would not fit)
+  uint64_t pyramid_pixels;
+};
+
+// Kernel launchers (implemented in the k_*.hip files). All asynchronous on `s`.
+struct VsfDev {
+  const VsfLevel* levels;   // [nlevels]
+  const uint32_t* strips;   // [nstrips]: level << 16 | y0
+  const VsfTap* xtaps;      // resize tables
+  const VsfTap* ytaps;
+  uint8_t* pyr;             // [max_images][pyr_bytes]   unblurred levels 1..L-1 (level 0 is the input)
+  uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
+  uint32_t* cand;           // [max_images][cand_entries]
+  int32_t* strip_count;     // [max_images][nstrips]
+  uint32_t* scratch;        // [max_images][cand_entries]   selection fallback when LDS is too small
+  VsfLevelKp* lvlkp;        // [max_images][lvlkp_entries]
+  int32_t* lvl_count;       // [max_images][nlevels]
+  int32_t* status;          // device status word (bit 0: capacity overflow)
+};
+
+struct VsfImages {
+  const uint8_t* base;      // level-0 images
+  size_t image_stride;
+  size_t row_stride;
+  int n;
+};
+
+void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
+                        hipStream_t s);
+void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, hipStream_t s);
+void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfImages& im, hipStream_t s);
+void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_tiles, int ntiles,
+                     const int k[4], hipStream_t s);
+void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int max_keypoints,
+                         vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts, hipStream_t s);
+void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int max_keypoints, vsf_keypoint* d_kp,
+                          int32_t* d_counts, hipStream_t s);
+void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
+                     const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
+                     hipStream_t s);
+void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
+                              int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
+                              uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
+                              hipStream_t s);
+
+#endif  // VSF_INTERNAL_H_
