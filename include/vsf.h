@@ -157,6 +157,16 @@ vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_key
 /* Final per-level keypoints in level coordinates (after both retainBest cuts, with angle). */
 vsf_status vsf_debug_level_keypoints(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap,
                                      int* n_out);
+/* Per-stage device timing (hipEvents recorded on the context's stream around every stage of the batched entry
+ * points).  vsf_profile_read synchronises the stream, adds the elapsed milliseconds and launch counts of every
+ * stage executed since the last reset into ms_total[] / launches[] (VSF_STAGE_COUNT entries each). */
+#define VSF_STAGE_COUNT 7
+enum { VSF_STAGE_PYRAMID = 0, VSF_STAGE_FAST, VSF_STAGE_SELECT, VSF_STAGE_BLUR, VSF_STAGE_DESCRIBE, VSF_STAGE_KNN2,
+       VSF_STAGE_RATIO };
+vsf_status vsf_profile_enable(vsf_ctx* ctx, int on);
+vsf_status vsf_profile_read(vsf_ctx* ctx, double* ms_total, int64_t* launches, int reset);
+const char* vsf_stage_name(int stage);
+
 /* Algorithmic HBM bytes of one extract of one image: SURVEY.md section 8(d) B_img for this geometry. */
 uint64_t vsf_algorithmic_bytes_per_image(const vsf_ctx* ctx);
 /* Total pyramid pixels P = sum_l w_l*h_l. */

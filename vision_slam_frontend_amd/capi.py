@@ -27,8 +27,10 @@ EXPORTS = [
     "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_batch_dev", "vsf_match_batch_dev",
     "vsf_stereo_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
-    "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels",
+    "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
+    "vsf_stage_name",
 ]
+STAGE_COUNT = 7
 
 
 class VsfParams(C.Structure):
@@ -88,6 +90,10 @@ def lib() -> C.CDLL:
         L.vsf_algorithmic_bytes_per_image.restype = C.c_uint64
         L.vsf_pyramid_pixels.argtypes = [vp]
         L.vsf_pyramid_pixels.restype = C.c_uint64
+        L.vsf_profile_enable.argtypes = [vp, i32]
+        L.vsf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+        L.vsf_stage_name.argtypes = [i32]
+        L.vsf_stage_name.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -222,6 +228,17 @@ class Context:
         self._check(lib().vsf_stereo_batch_dev(self._h, _p(d_imgs), n_frames, image_stride, row_stride, _p(d_kp),
                                                _p(d_desc), _p(d_counts), _p(d_matches), _p(d_nmatches)),
                     "vsf_stereo_batch_dev")
+
+    # ---- per-stage device timing ----
+    def profile_enable(self, on: bool = True):
+        self._check(lib().vsf_profile_enable(self._h, int(on)), "vsf_profile_enable")
+
+    def profile_read(self, reset: bool = True) -> dict:
+        """{stage name: (total ms, launches)} since the last reset (synchronises the stream)."""
+        ms = (C.c_double * STAGE_COUNT)()
+        n = (C.c_int64 * STAGE_COUNT)()
+        self._check(lib().vsf_profile_read(self._h, ms, n, int(reset)), "vsf_profile_read")
+        return {lib().vsf_stage_name(i).decode(): (ms[i], int(n[i])) for i in range(STAGE_COUNT)}
 
     # ---- introspection ----
     def debug_level_image(self, image: int, level: int, blurred: bool = False) -> np.ndarray:

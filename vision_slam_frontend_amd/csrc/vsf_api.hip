@@ -250,6 +250,14 @@ struct vsf_ctx {
   VsfImages last_images{};
   bool last_valid = false;
   bool fast_nms = true;  // NMS mode the standalone-FAST geometry was built for
+  // per-stage hipEvent profiling
+  bool prof_on = false;
+  std::vector<hipEvent_t> ev_pool;  // pairs
+  std::vector<int> ev_stage;        // stage of pair i
+  std::vector<int> ev_launches;
+  size_t ev_used = 0;               // pairs in flight
+  double prof_ms[VSF_STAGE_COUNT] = {0};
+  int64_t prof_launches[VSF_STAGE_COUNT] = {0};
 };
 
 namespace {
@@ -358,14 +366,69 @@ vsf_status validate_images(const vsf_ctx* ctx, const uint8_t* d_imgs, int n, siz
   return VSF_OK;
 }
 
+void prof_fold(vsf_ctx* ctx) {  // stream must be idle
+  for (size_t i = 0; i < ctx->ev_used; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess) {
+      ctx->prof_ms[ctx->ev_stage[i]] += ms;
+      ctx->prof_launches[ctx->ev_stage[i]] += ctx->ev_launches[i];
+    }
+  }
+  ctx->ev_used = 0;
+}
+
+struct StageTimer {  // records an event pair around one stage when profiling is on
+  vsf_ctx* ctx;
+  size_t slot = 0;
+  bool on;
+  StageTimer(vsf_ctx* c, int stage, int launches) : ctx(c), on(c->prof_on) {
+    if (!on) return;
+    if (ctx->ev_used >= 2048) {
+      (void)hipStreamSynchronize(ctx->stream);
+      prof_fold(ctx);
+    }
+    slot = ctx->ev_used++;
+    while (ctx->ev_pool.size() < 2 * (slot + 1)) {
+      hipEvent_t e = nullptr;
+      (void)hipEventCreate(&e);
+      ctx->ev_pool.push_back(e);
+    }
+    if (ctx->ev_stage.size() <= slot) {
+      ctx->ev_stage.resize(slot + 1);
+      ctx->ev_launches.resize(slot + 1);
+    }
+    ctx->ev_stage[slot] = stage;
+    ctx->ev_launches[slot] = launches;
+    (void)hipEventRecord(ctx->ev_pool[2 * slot], ctx->stream);
+  }
+  ~StageTimer() {
+    if (on) (void)hipEventRecord(ctx->ev_pool[2 * slot + 1], ctx->stream);
+  }
+};
+
 vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
   const VsfDev& d = ctx->dorb.d;
   const VsfGeom& g = ctx->orb.g;
-  vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ctx->stream);
-  vsf_launch_fast(d, g, im, ctx->p.fast_threshold, ctx->stream);
-  vsf_launch_select(d, g, im, ctx->stream);
-  vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, ctx->stream);
-  vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp, d_desc, d_counts, ctx->stream);
+  {
+    StageTimer t(ctx, VSF_STAGE_PYRAMID, g.nlevels - 1);
+    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ctx->stream);
+  }
+  {
+    StageTimer t(ctx, VSF_STAGE_FAST, 1);
+    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, ctx->stream);
+  }
+  {
+    StageTimer t(ctx, VSF_STAGE_SELECT, 1);
+    vsf_launch_select(d, g, im, ctx->stream);
+  }
+  {
+    StageTimer t(ctx, VSF_STAGE_BLUR, 1);
+    vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, ctx->stream);
+  }
+  {
+    StageTimer t(ctx, VSF_STAGE_DESCRIBE, 1);
+    vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp, d_desc, d_counts, ctx->stream);
+  }
   ctx->last_images = im;
   ctx->last_valid = true;
   VSF_HIP(hipGetLastError());
@@ -493,6 +556,7 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->mh_counts);
   hipFree(ctx->mh_matches);
   hipFree(ctx->mh_nmatches);
+  for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -508,6 +572,7 @@ vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out) {
 vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
+  prof_fold(ctx);
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return VSF_OK;
 }
@@ -567,11 +632,46 @@ vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_
     d_idx2 = ctx->m_idx2;
     d_dist2 = ctx->m_dist2;
   }
-  vsf_launch_knn2(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->stream);
-  vsf_launch_ratio_compact(d_counts, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->p.ratio_num,
-                           ctx->p.ratio_shift, d_matches, d_nmatches, ctx->d_status, ctx->stream);
+  {
+    StageTimer t(ctx, VSF_STAGE_KNN2, 1);
+    vsf_launch_knn2(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->stream);
+  }
+  {
+    StageTimer t(ctx, VSF_STAGE_RATIO, 1);
+    vsf_launch_ratio_compact(d_counts, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->p.ratio_num,
+                             ctx->p.ratio_shift, d_matches, d_nmatches, ctx->d_status, ctx->stream);
+  }
   VSF_HIP(hipGetLastError());
   return VSF_OK;
+}
+
+vsf_status vsf_profile_enable(vsf_ctx* ctx, int on) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  prof_fold(ctx);
+  ctx->prof_on = on != 0;
+  return VSF_OK;
+}
+
+vsf_status vsf_profile_read(vsf_ctx* ctx, double* ms_total, int64_t* launches, int reset) {
+  if (!ctx || !ms_total || !launches) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  prof_fold(ctx);
+  for (int i = 0; i < VSF_STAGE_COUNT; i++) {
+    ms_total[i] = ctx->prof_ms[i];
+    launches[i] = ctx->prof_launches[i];
+    if (reset) {
+      ctx->prof_ms[i] = 0;
+      ctx->prof_launches[i] = 0;
+    }
+  }
+  return VSF_OK;
+}
+
+const char* vsf_stage_name(int stage) {
+  static const char* names[VSF_STAGE_COUNT] = {"pyramid_resize", "fast_score_nms", "select_harris_angle", "gauss_blur7",
+                                               "orb_describe",   "hamming_knn2",   "ratio_compact"};
+  return (stage >= 0 && stage < VSF_STAGE_COUNT) ? names[stage] : "?";
 }
 
 vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frames, size_t image_stride,

@@ -75,6 +75,16 @@ class Scene:
 
     def render(self, frame_idx: int = 0, eye: int = 0) -> np.ndarray:
         """eye 0 = left, 1 = right.  Returns a C-contiguous (h, w) uint8 image (stride == w)."""
+        img = self.render_clean(frame_idx, eye)
+        return self.add_noise(img, frame_idx, eye)
+
+    def add_noise(self, clean: np.ndarray, frame_idx: int, eye: int, salt: int = 0) -> np.ndarray:
+        nrng = np.random.Generator(np.random.PCG64([self.seed, int(frame_idx), int(eye), 0x5EED + int(salt)]))
+        img = clean + nrng.integers(-3, 4, size=clean.shape)
+        return np.ascontiguousarray(np.clip(img, 0, 255).astype(np.uint8))
+
+    def render_clean(self, frame_idx: int = 0, eye: int = 0) -> np.ndarray:
+        """Noise-free int64 rendering (values may leave [0,255]; add_noise clips)."""
         f = int(frame_idx)
         sx, sy = 3 * f, 1 * f
         base = self._background(sx + (2 if eye else 0), sy)
@@ -100,9 +110,7 @@ class Scene:
             tex = self.tex[i][np.mod(u // cs, 8), np.mod(v // cs, 8)]
             win = img[y0:y1, x0:x1]
             win[m] = base[y0:y1, x0:x1][m] + int(self.delta[i]) + tex[m]
-        nrng = np.random.Generator(np.random.PCG64([self.seed, f, eye, 0x5EED]))
-        img += nrng.integers(-3, 4, size=img.shape)
-        return np.ascontiguousarray(np.clip(img, 0, 255).astype(np.uint8))
+        return img
 
 
 def stereo_pair(width: int = 640, height: int = 480, frame_idx: int = 0, seed: int = BASE_SEED,
@@ -121,6 +129,24 @@ def stereo_stream(n_frames: int, width: int = 640, height: int = 480, seed: int 
         s = Scene(width, height, n_objects, seed + f) if distinct_scenes else sc
         out[f, 0] = s.render(0 if distinct_scenes else f, 0)
         out[f, 1] = s.render(0 if distinct_scenes else f, 1)
+    return out
+
+
+def bench_batch(n_frames: int, width: int = 640, height: int = 480, seed: int = BASE_SEED, n_scenes: int = 8,
+                n_objects: int | None = None) -> np.ndarray:
+    """(n_frames, 2, h, w) uint8 for the throughput bench: `n_scenes` independently rendered stereo scenes,
+    each reused with a different circular shift and fresh noise (every frame is a distinct image with the
+    keypoint statistics of a rendered one, at a fraction of the rendering cost)."""
+    n_scenes = max(1, min(n_scenes, n_frames))
+    scenes = [Scene(width, height, n_objects, seed + 7919 * i) for i in range(n_scenes)]
+    clean = [(sc.render_clean(0, 0), sc.render_clean(0, 1)) for sc in scenes]
+    out = np.empty((n_frames, 2, height, width), dtype=np.uint8)
+    for f in range(n_frames):
+        s, k = f % n_scenes, f // n_scenes
+        dx, dy = 17 * k, 5 * k
+        for eye in (0, 1):
+            img = np.roll(clean[s][eye], (dy, dx), axis=(0, 1)) if k else clean[s][eye]
+            out[f, eye] = scenes[s].add_noise(img, 0, eye, salt=k)
     return out
 
 
