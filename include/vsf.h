@@ -157,6 +157,13 @@ vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_key
 /* Final per-level keypoints in level coordinates (after both retainBest cuts, with angle). */
 vsf_status vsf_debug_level_keypoints(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap,
                                      int* n_out);
+/* Test hook of the order-exact selection (cv::KeyPointsFilter::retainBest as left by libstdc++'s nth_element +
+ * partition): applies retainBest(n_points) on the GPU to n (key, id) pairs given as two host arrays, in place.
+ * mode 0: keys are float bit patterns compared as floats; mode 1: only the top byte of the key is compared
+ * (packed FAST candidates).  use_lds: run on an LDS copy when n <= 4096.  *n_out = surviving count. */
+vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids, int n, int n_points, int use_lds,
+                                 int mode, int* n_out);
+
 /* Per-stage device timing (hipEvents recorded on the context's stream around every stage of the batched entry
  * points).  vsf_profile_read synchronises the stream, adds the elapsed milliseconds and launch counts of every
  * stage executed since the last reset into ms_total[] / launches[] (VSF_STAGE_COUNT entries each). */

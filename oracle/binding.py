@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
         L.vsfo_orb_level_image.argtypes = [vp, i32, i32, vp, sz]
         L.vsfo_orb_stage_keypoints.argtypes = [vp, i32, i32, vp, i32]
         L.vsfo_orb_result.argtypes = [vp, vp, vp, i32]
+        L.vsfo_retain_best.argtypes = [vp, vp, i32, i32]
         L.vsfo_knn2_hamming.argtypes = [vp, i32, vp, i32, vp, vp]
         L.vsfo_get_matches.argtypes = [vp, i32, vp, i32, C.c_double, vp, i32]
         L.vsfo_get_matches_mt.argtypes = [vp, i32, vp, i32, C.c_double, vp, i32, i32]
@@ -145,6 +146,14 @@ def fast_atan2(y: float, x: float) -> float:
 
 def orb_pattern31() -> np.ndarray:
     return np.ctypeslib.as_array(lib().vsfo_orb_pattern31(), shape=(256, 4)).copy()
+
+
+def retain_best(keys: np.ndarray, n_points: int):
+    """cv::KeyPointsFilter::retainBest on float responses; returns (responses, ids) in libstdc++'s order."""
+    r = np.ascontiguousarray(keys, np.float32).copy()
+    ids = np.arange(len(r), dtype=np.uint32)
+    n = lib().vsfo_retain_best(_p(r), _p(ids), len(r), n_points)
+    return r[:n], ids[:n]
 
 
 class Orb:

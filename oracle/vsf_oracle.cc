@@ -698,6 +698,19 @@ float vsfo_fast_atan2(float y, float x) { return FastAtan2(y, x); }
 
 const int8_t* vsfo_orb_pattern31(void) { return kPattern31; }
 
+int vsfo_retain_best(float* response, uint32_t* id, int n, int n_points) {
+  std::vector<vsfo_keypoint> kps((size_t)std::max(n, 0));
+  for (int i = 0; i < n; i++) {
+    kps[i] = vsfo_keypoint{0.f, 0.f, 0.f, 0.f, response[i], 0, (int32_t)id[i]};
+  }
+  RetainBest(&kps, n_points);
+  for (size_t i = 0; i < kps.size(); i++) {
+    response[i] = kps[i].response;
+    id[i] = (uint32_t)kps[i].class_id;
+  }
+  return (int)kps.size();
+}
+
 vsfo_orb* vsfo_orb_create(const vsfo_orb_params* p) {
   vsfo_orb* o = new vsfo_orb();
   o->p = *p;

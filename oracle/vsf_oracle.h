@@ -79,6 +79,10 @@ float vsfo_fast_atan2(float y, float x);
 /* The rBRIEF pattern (256 x 4 int8). */
 const int8_t* vsfo_orb_pattern31(void);
 
+/* cv::KeyPointsFilter::retainBest on n (response, id) pairs with the host libstdc++ (std::nth_element +
+ * std::partition), in place; returns the surviving count. */
+int vsfo_retain_best(float* response, uint32_t* id, int n, int n_points);
+
 /* ---- ORB detectAndCompute with every intermediate kept for kernel-level parity ---- */
 typedef struct vsfo_orb vsfo_orb;
 vsfo_orb* vsfo_orb_create(const vsfo_orb_params* p);

@@ -136,3 +136,46 @@ def test_fast_detect_without_nms(ctx640, oracle, stereo640):
     g = ctx640.fast_detect(left, 30, False, cap=1 << 18)
     r = oracle.fast9_16(left, 30, False)
     assert g.tobytes() == r.tobytes()
+
+
+def _selection_inputs():
+    rng = np.random.default_rng(99)
+    cases = []
+    for n in (1, 2, 3, 5, 48, 49, 50, 100, 257, 1000, 4096, 4097, 8525, 20000, 70000):
+        cases.append(("uniform", rng.uniform(-1, 1, n).astype(np.float32)))
+        cases.append(("ties", rng.integers(20, 60, n).astype(np.float32)))
+        cases.append(("heavy_ties", rng.integers(20, 23, n).astype(np.float32)))
+    cases.append(("sorted", np.arange(5000, dtype=np.float32)))
+    cases.append(("reverse", np.arange(5000, dtype=np.float32)[::-1].copy()))
+    cases.append(("equal", np.full(3000, 7, np.float32)))
+    cases.append(("organ", np.minimum(np.arange(6000), 5999 - np.arange(6000)).astype(np.float32)))
+    return cases
+
+
+@pytest.mark.parametrize("use_lds", [False, True])
+def test_parallel_retain_best_matches_libstdcxx(ctx640, oracle, use_lds):
+    """The GPU's parallel Hoare passes must leave exactly libstdc++'s nth_element + partition permutation."""
+    checked = 0
+    for name, keys in _selection_inputs():
+        n = len(keys)
+        for k in sorted({0, 1, 2, n // 50, n // 7, n // 2, n - 1, n, n + 5}):
+            if k < 0:
+                continue
+            rk, rid = oracle.retain_best(keys, k)
+            gk, gid = ctx640.debug_retain_best(keys, k, use_lds=use_lds, mode=0)
+            assert len(gid) == len(rid), (name, n, k)
+            np.testing.assert_array_equal(gid, rid, err_msg="%s n=%d k=%d" % (name, n, k))
+            np.testing.assert_array_equal(gk, rk.view(np.uint32))
+            checked += 1
+    assert checked > 200
+
+
+def test_parallel_retain_best_packed_scores(ctx640, oracle):
+    rng = np.random.default_rng(5)
+    for n in (300, 5000, 30000):
+        score = rng.integers(20, 90, n)
+        packed = ((score.astype(np.uint32) << 24) | rng.integers(0, 1 << 24, n).astype(np.uint32))
+        for k in (10, n // 20, n // 3):
+            rk, rid = oracle.retain_best(score.astype(np.float32), k)
+            gk, gid = ctx640.debug_retain_best(packed.view(np.float32), k, mode=1)
+            np.testing.assert_array_equal(gid, rid, err_msg="n=%d k=%d" % (n, k))

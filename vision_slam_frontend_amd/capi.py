@@ -28,7 +28,7 @@ EXPORTS = [
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_batch_dev", "vsf_match_batch_dev",
     "vsf_stereo_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
-    "vsf_stage_name",
+    "vsf_stage_name", "vsf_debug_retain_best",
 ]
 STAGE_COUNT = 7
 
@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         L.vsf_algorithmic_bytes_per_image.restype = C.c_uint64
         L.vsf_pyramid_pixels.argtypes = [vp]
         L.vsf_pyramid_pixels.restype = C.c_uint64
+        L.vsf_debug_retain_best.argtypes = [vp, vp, vp, i32, i32, i32, i32, ip]
         L.vsf_profile_enable.argtypes = [vp, i32]
         L.vsf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
         L.vsf_stage_name.argtypes = [i32]
@@ -228,6 +229,15 @@ class Context:
         self._check(lib().vsf_stereo_batch_dev(self._h, _p(d_imgs), n_frames, image_stride, row_stride, _p(d_kp),
                                                _p(d_desc), _p(d_counts), _p(d_matches), _p(d_nmatches)),
                     "vsf_stereo_batch_dev")
+
+    def debug_retain_best(self, keys: np.ndarray, n_points: int, use_lds: bool = False, mode: int = 0):
+        """retainBest on the GPU; returns (keys, ids) of the survivors in the order the GPU left them."""
+        kb = np.ascontiguousarray(keys).view(np.uint32).copy()
+        ids = np.arange(len(kb), dtype=np.uint32)
+        n = C.c_int()
+        self._check(lib().vsf_debug_retain_best(self._h, _p(kb), _p(ids), len(kb), n_points, int(use_lds), mode,
+                                                C.byref(n)), "vsf_debug_retain_best")
+        return kb[:n.value], ids[:n.value]
 
     # ---- per-stage device timing ----
     def profile_enable(self, on: bool = True):

@@ -2,14 +2,23 @@
 // slam_frontend.cc:274), one workgroup per (image, level):
 //
 //   gather   the level's FAST candidates (raster order) from the strip segments
-//   K3       KeyPointsFilter::retainBest(2 * n_l) on the FAST score           (order-exact, vsf_select.h)
+//   K3       KeyPointsFilter::retainBest(2 * n_l) on the FAST score           (order-exact)
 //   K4       HarrisResponses(blockSize 7, k 0.04f) for the survivors           (int32 sums, 6 float ops, no FMA)
 //   K5       KeyPointsFilter::retainBest(n_l) on the Harris response          (order-exact)
 //   K6       ICAngles (intensity-centroid moments over the radius-15 disc, one wave per keypoint) + fastAtan2
 //
-// The arrays being permuted live in LDS when they fit (16 K candidates / 2 K survivors) and in an HBM scratch
-// area otherwise.  The permutation must equal libstdc++'s, so the selection itself is the
-// sequential restatement in vsf_select.h executed by one lane; everything around it is data-parallel.
+// Order-exact selection.  retainBest leaves libstdc++'s std::nth_element + std::partition
+// permutation, which later stages turn into keypoint indices, so it has to be reproduced exactly.  Both are
+// built from Hoare-style passes ("the k-th stopper from the left swaps with the k-th stopper from the right
+// until they cross"), and such a pass IS data-parallel:
+//   * flag every element as left-stopper / right-stopper against the pivot with wave ballots (bit masks),
+//   * prefix-popcount the masks (one block scan),
+//   * element i, the k-th left-stopper, takes part iff at least k right-stoppers lie to its right; it finds its
+//     partner (k-th right-stopper from the right) by rank -> position select on the mask and swaps,
+//   * the split point follows from the first non-participating stoppers.
+// Pivot choice (median of first+1 / mid / last-1), the depth limit, the heap-select fallback and the final
+// insertion sort are the sequential restatement of vsf_select.h, run by one lane on ranges <= 48 elements.
+// The arrays live in LDS when they fit and in an HBM scratch area otherwise.
 #include "vsf_internal.h"
 #include "vsf_select.h"
 
@@ -33,6 +42,7 @@ struct SelectArgs {
   int lvlkp_entries;
   int32_t* lvl_count;
   int nlevels;
+  int level0;  // first level handled by this launch
   int32_t* status;
 };
 
@@ -52,6 +62,242 @@ struct RespGe {
     return __uint_as_float(a.x) >= __uint_as_float(b.x);
   }
 };
+
+constexpr int kThreads = VSF_SELECT_THREADS;
+constexpr int kSerialCutoff = 48;
+
+// LDS scratch of the parallel passes. MAXW mask words cover MAXW * 64 elements.
+template <int MAXW>
+struct PassScratch {
+  unsigned long long maskL[MAXW];
+  unsigned long long maskR[MAXW];
+  int preL[MAXW];
+  int preR[MAXW];
+  unsigned long long wsum[8];
+  int st[8];  // 0 first, 1 last, 2 depth, 3 K, 4 cut, 5 totalL, 6 totalR
+};
+
+__device__ __forceinline__ int select64(unsigned long long x, int r) {
+  // position of the r-th (0-based) set bit of x
+  int pos = 0;
+  uint32_t v = (uint32_t)x;
+  int c = __popc(v);
+  if (r >= c) {
+    r -= c;
+    pos = 32;
+    v = (uint32_t)(x >> 32);
+  }
+  c = __popc(v & 0xFFFFu);
+  if (r >= c) {
+    r -= c;
+    pos += 16;
+    v >>= 16;
+  }
+  c = __popc(v & 0xFFu);
+  if (r >= c) {
+    r -= c;
+    pos += 8;
+    v >>= 8;
+  }
+  c = __popc(v & 0xFu);
+  if (r >= c) {
+    r -= c;
+    pos += 4;
+    v >>= 4;
+  }
+  c = __popc(v & 0x3u);
+  if (r >= c) {
+    r -= c;
+    pos += 2;
+    v >>= 2;
+  }
+  if (r >= (int)(v & 1u)) pos += 1;
+  return pos;
+}
+
+// index (0-based, relative to the pass range) of the t-th (0-based) set bit over the whole mask array
+__device__ __forceinline__ int select_rank(const unsigned long long* mask, const int* pre, int nw, int t) {
+  int lo = 0, hi = nw - 1;  // largest w with pre[w] <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pre[mid] <= t)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo * 64 + select64(mask[lo], t - pre[lo]);
+}
+
+// One Hoare pass over A[lo, hi): left-stoppers are elements with FL(x), right-stoppers those with FR(x).
+// Swaps the k-th left-stopper (from the left) with the k-th right-stopper (from the right) for every k with
+// left position < right position.  On return (all threads, after a barrier) s.st[3] = K (number of swaps),
+// s.st[5] / s.st[6] = stopper totals, s.st[4] = where a sequential scan would have stopped
+// (__unguarded_partition's return value when at least one stopper of each kind exists).
+template <int MAXW, class T, class FL, class FR>
+__device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>& s) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = hi - lo;
+  const int nw = (m + 63) >> 6;
+  for (int base = 0; base < m; base += kThreads) {
+    const int i = base + tid;
+    bool l = false, r = false;
+    if (i < m) {
+      const T x = A[lo + i];
+      l = fl(x);
+      r = fr(x);
+    }
+    const unsigned long long bl = __ballot(l), br = __ballot(r);
+    if (lane == 0 && (base >> 6) + wave < nw) {
+      s.maskL[(base >> 6) + wave] = bl;
+      s.maskR[(base >> 6) + wave] = br;
+    }
+  }
+  __syncthreads();
+  // exclusive prefix popcounts, words [t*wpt, (t+1)*wpt) per thread
+  const int wpt = (nw + kThreads - 1) / kThreads;
+  const int w0 = tid * wpt;
+  unsigned long long mine = 0;  // low 32: left count, high 32: right count
+  for (int j = 0; j < wpt; j++) {
+    const int w = w0 + j;
+    if (w < nw) mine += (unsigned long long)__popcll(s.maskL[w]) | ((unsigned long long)__popcll(s.maskR[w]) << 32);
+  }
+  unsigned long long inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s.wsum[wave] = inc;
+  __syncthreads();
+  unsigned long long base_sum = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    if (w < wave) base_sum += s.wsum[w];
+    total += s.wsum[w];
+  }
+  unsigned long long run = base_sum + inc - mine;
+  for (int j = 0; j < wpt; j++) {
+    const int w = w0 + j;
+    if (w < nw) {
+      s.preL[w] = (int)(uint32_t)run;
+      s.preR[w] = (int)(uint32_t)(run >> 32);
+      run += (unsigned long long)__popcll(s.maskL[w]) | ((unsigned long long)__popcll(s.maskR[w]) << 32);
+    }
+  }
+  const int totalL = (int)(uint32_t)total, totalR = (int)(uint32_t)(total >> 32);
+  __syncthreads();
+  // participating left-stoppers swap with their partners
+  int nswap = 0;
+  for (int base = 0; base < m; base += kThreads) {
+    const int i = base + tid;
+    if (i < m) {
+      const int w = i >> 6, b = i & 63;
+      const unsigned long long ml = s.maskL[w];
+      if ((ml >> b) & 1ull) {
+        const int k = s.preL[w] + __popcll(ml & ((1ull << b) - 1ull)) + 1;              // 1-based rank from the left
+        const int r_le = s.preR[w] + __popcll(s.maskR[w] & ((2ull << b) - 1ull));       // right-stoppers at <= i
+        if (totalR - r_le >= k) {
+          const int j = select_rank(s.maskR, s.preR, nw, totalR - k);
+          const T xi = A[lo + i], xj = A[lo + j];
+          A[lo + i] = xj;
+          A[lo + j] = xi;
+          ++nswap;
+        }
+      }
+    }
+  }
+  // K = total swaps
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nswap += __shfl_xor(nswap, o, 64);
+  if (lane == 0) s.wsum[wave] = (unsigned long long)nswap;
+  __syncthreads();
+  if (tid == 0) {
+    int K = 0;
+    for (int w = 0; w < kThreads / 64; w++) K += (int)s.wsum[w];
+    s.st[3] = K;
+    s.st[5] = totalL;
+    s.st[6] = totalR;
+    // where the left scan stops after K swaps: the (K+1)-th left-stopper if it lies before the K-th right-stopper
+    // (or no swap happened), else the K-th right-stopper's position (now holding a left-stopper).
+    int cut = lo;
+    const int aK1 = K < totalL ? select_rank(s.maskL, s.preL, nw, K) : 0x7FFFFFFF;
+    const int bK = K > 0 ? select_rank(s.maskR, s.preR, nw, totalR - K) : 0x7FFFFFFF;
+    if (K < totalL && (K == 0 || aK1 < bK))
+      cut = lo + aK1;
+    else
+      cut = lo + bK;
+    s.st[4] = cut;
+  }
+  __syncthreads();
+}
+
+// std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
+template <int MAXW, class T, class Greater>
+__device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScratch<MAXW>& s) {
+  if (n == 0 || nth == n) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s.st[0] = 0;
+    s.st[1] = n;
+    s.st[2] = vsf_sel::lg_(n) * 2;
+  }
+  __syncthreads();
+  while (true) {
+    const int first = s.st[0], last = s.st[1], depth = s.st[2];
+    if (last - first <= kSerialCutoff || depth == 0 || last - first - 1 > MAXW * 64) break;
+    if (tid == 0) {
+      const int mid = first + (last - first) / 2;
+      vsf_sel::move_median_to_first_(A, first, first + 1, mid, last - 1, greater);
+    }
+    __syncthreads();
+    const T pivot = A[first];
+    hoare_pass<MAXW>(
+        A, first + 1, last, [&](const T& x) { return !greater(x, pivot); },
+        [&](const T& x) { return !greater(pivot, x); }, s);
+    if (tid == 0) {
+      const int cut = s.st[4];
+      s.st[2] = depth - 1;
+      if (cut <= nth)
+        s.st[0] = cut;
+      else
+        s.st[1] = cut;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) vsf_sel::introselect_from_(A, s.st[0], s.st[1], nth, s.st[2], greater);
+  __syncthreads();
+}
+
+// std::partition(A + lo, A + hi, pred); returns the split point -- all threads call this.
+template <int MAXW, class T, class Pred>
+__device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>& s) {
+  const int tid = threadIdx.x;
+  if (hi - lo <= kSerialCutoff || hi - lo > MAXW * 64) {
+    if (tid == 0) s.st[4] = vsf_sel::partition_(A, lo, hi, pred);
+    __syncthreads();
+    const int r = s.st[4];
+    __syncthreads();
+    return r;
+  }
+  hoare_pass<MAXW>(
+      A, lo, hi, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, s);
+  const int r = lo + s.st[6];
+  __syncthreads();
+  return r;
+}
+
+// cv::KeyPointsFilter::retainBest(A[0..n), n_points); returns the new size -- all threads call this.
+template <int MAXW, class T, class Greater, class GreaterEq>
+__device__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, PassScratch<MAXW>& s) {
+  if (n_points >= 0 && n > n_points) {
+    if (n_points == 0) return 0;
+    par_nth_element<MAXW>(A, n, n_points, greater, s);
+    const T ambiguous = A[n_points - 1];
+    return par_partition<MAXW>(
+        A, n_points, n, [&](const T& x) { return ge(x, ambiguous); }, s);
+  }
+  return n;
+}
 
 // cv::fastAtan2 (core/mathfuncs.cpp), degrees.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -108,13 +354,15 @@ __device__ __forceinline__ int umax31(int v) {
   return v < 9 ? (int)((lo >> (4 * v)) & 15) : (int)((hi >> (4 * (v - 9))) & 15);
 }
 
-__global__ __launch_bounds__(VSF_SELECT_THREADS) void orb_select_kernel(SelectArgs a) {
-  __shared__ uint32_t sA[VSF_SELECT_LDS_ENTRIES];
-  __shared__ uint2 sB[VSF_SELECT_LDS_STAGE2];
+// ENTRIES: stage-1 candidates kept in LDS; STAGE2: stage-2 pairs kept in LDS; MAXW: mask words of a parallel pass.
+template <int ENTRIES, int STAGE2, int MAXW>
+__global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
+  __shared__ uint32_t sA[ENTRIES];
+  __shared__ uint2 sB[STAGE2];
+  __shared__ PassScratch<MAXW> ps;
   __shared__ int soff[520];
-  __shared__ int misc[8];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int level = blockIdx.x, image = blockIdx.y;
+  const int level = a.level0 + blockIdx.x, image = blockIdx.y;
   const VsfLevel L = a.levels[level];
   const uint8_t* img;
   int pitch;
@@ -139,60 +387,55 @@ __global__ __launch_bounds__(VSF_SELECT_THREADS) void orb_select_kernel(SelectAr
   __syncthreads();
   const int n = soff[L.nstrips];
   uint32_t* gscratch = a.scratch + (size_t)image * 3 * a.cand_entries;
-  const bool a_in_lds = n <= VSF_SELECT_LDS_ENTRIES;
-  uint32_t* A = a_in_lds ? sA : gscratch + L.cand_offset;
+  uint32_t* gA = gscratch + L.cand_offset;
+  uint2* gB = reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
+  const bool a_in_lds = n <= ENTRIES;
   const uint32_t* segs = a.cand + (size_t)image * a.cand_entries + L.cand_offset;
   for (int s = 0; s < L.nstrips; s++) {
     const int cnt = soff[s + 1] - soff[s];
     const uint32_t* seg = segs + (size_t)s * L.seg_cap;
-    for (int i = tid; i < cnt; i += VSF_SELECT_THREADS) A[soff[s] + i] = seg[i];
+    if (a_in_lds) {
+      for (int i = tid; i < cnt; i += kThreads) sA[soff[s] + i] = seg[i];
+    } else {
+      for (int i = tid; i < cnt; i += kThreads) gA[soff[s] + i] = seg[i];
+    }
   }
-  __threadfence_block();
   __syncthreads();
 
   // ---- K3: retainBest(2 * n_l) on the FAST score ----
-  if (tid == 0) {
-    int m1;
-    if (a_in_lds)
-      m1 = vsf_sel::retain_best_(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe());
-    else
-      m1 = vsf_sel::retain_best_(gscratch + L.cand_offset, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe());
-    misc[0] = m1;
-  }
-  __threadfence_block();
+  int m1;
+  if (a_in_lds)
+    m1 = par_retain_best<MAXW>(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
+  else
+    m1 = par_retain_best<MAXW>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
   __syncthreads();
-  const int m1 = misc[0];
 
   // ---- K4: Harris responses (one lane per keypoint) ----
-  const bool b_in_lds = m1 <= VSF_SELECT_LDS_STAGE2;
-  uint2* B = b_in_lds ? sB : reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
-  for (int i = tid; i < m1; i += VSF_SELECT_THREADS) {
-    const uint32_t cd = A[i];
+  const bool b_in_lds = m1 <= STAGE2;
+  for (int i = tid; i < m1; i += kThreads) {
+    const uint32_t cd = a_in_lds ? sA[i] : gA[i];
     const float r = harris_response(img, pitch, VSF_CAND_X(cd), VSF_CAND_Y(cd));
-    B[i] = make_uint2(__float_as_uint(r), cd & 0xFFFFFFu);
+    const uint2 e = make_uint2(__float_as_uint(r), cd & 0xFFFFFFu);
+    if (b_in_lds)
+      sB[i] = e;
+    else
+      gB[i] = e;
   }
-  __threadfence_block();
   __syncthreads();
 
   // ---- K5: retainBest(n_l) on the Harris response ----
-  if (tid == 0) {
-    int m2;
-    if (b_in_lds)
-      m2 = vsf_sel::retain_best_(sB, m1, L.nfeatures, RespGreater(), RespGe());
-    else
-      m2 = vsf_sel::retain_best_(reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset, m1,
-                                 L.nfeatures, RespGreater(), RespGe());
-    misc[1] = m2;
-  }
-  __threadfence_block();
+  int m2;
+  if (b_in_lds)
+    m2 = par_retain_best<MAXW>(sB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
+  else
+    m2 = par_retain_best<MAXW>(gB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
   __syncthreads();
-  const int m2 = misc[1];
 
   // ---- K6: IC angle, one wave per keypoint, two disc rows per step (32 lanes each) ----
   VsfLevelKp* out = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
   const int m_out = min(m2, L.kp_cap);
-  for (int i = wid; i < m_out; i += VSF_SELECT_THREADS / 64) {
-    const uint2 e = B[i];
+  for (int i = wid; i < m_out; i += kThreads / 64) {
+    const uint2 e = b_in_lds ? sB[i] : gB[i];
     const int x0 = (int)(e.y & 0xFFFu), y0 = (int)(e.y >> 12);
     const uint8_t* center = img + (size_t)y0 * pitch + x0;
     const int u = (lane & 31) - 15;
@@ -228,9 +471,39 @@ __global__ __launch_bounds__(VSF_SELECT_THREADS) void orb_select_kernel(SelectAr
   }
 }
 
+// Test hook: retainBest on (float key, id) pairs, one workgroup, arrays in HBM or LDS.
+template <int MAXW>
+__global__ __launch_bounds__(kThreads) void retain_best_test_kernel(uint2* data, int n, int n_points, int use_lds,
+                                                                    int mode, int* out_n) {
+  __shared__ PassScratch<MAXW> ps;
+  __shared__ uint2 buf[4096];
+  int m;
+  if (mode == 0) {  // float keys
+    if (use_lds && n <= 4096) {
+      for (int i = threadIdx.x; i < n; i += kThreads) buf[i] = data[i];
+      __syncthreads();
+      m = par_retain_best<MAXW>(buf, n, n_points, RespGreater(), RespGe(), ps);
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += kThreads) data[i] = buf[i];
+    } else {
+      m = par_retain_best<MAXW>(data, n, n_points, RespGreater(), RespGe(), ps);
+    }
+  } else {  // packed candidates: compare the top byte of .x only
+    struct G {
+      __device__ bool operator()(const uint2& a, const uint2& b) const { return (a.x >> 24) > (b.x >> 24); }
+    };
+    struct GE {
+      __device__ bool operator()(const uint2& a, const uint2& b) const { return (a.x >> 24) >= (b.x >> 24); }
+    };
+    m = par_retain_best<MAXW>(data, n, n_points, G(), GE(), ps);
+  }
+  if (threadIdx.x == 0) *out_n = m;
+}
+
 }  // namespace
 
-void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfImages& im, hipStream_t s) {
+void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
+                       hipStream_t s) {
   SelectArgs a;
   a.levels = d.levels;
   a.img0 = im.base;
@@ -248,5 +521,28 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfImages& im, h
   a.lvl_count = d.lvl_count;
   a.nlevels = g.nlevels;
   a.status = d.status;
-  hipLaunchKernelGGL(orb_select_kernel, dim3(g.nlevels, im.n), dim3(VSF_SELECT_THREADS), 0, s, a);
+  // Levels are split into a "large" class (big LDS arrays, one workgroup per CU) and a "small" class (several
+  // workgroups per CU) by the area in which keypoints may sit; either class falls back to HBM scratch when a
+  // level has more candidates than its LDS array holds, so the split only affects speed.
+  int nbig = 0;
+  while (nbig < g.nlevels) {
+    const VsfLevel& L = h_levels[nbig];
+    const long area = (long)(L.x_hi - L.x_lo) * (L.y_hi - L.y_lo);
+    if (area < 100000) break;
+    ++nbig;
+  }
+  if (nbig > 0) {
+    a.level0 = 0;
+    hipLaunchKernelGGL((orb_select_kernel<16384, 2048, 1024>), dim3(nbig, im.n), dim3(kThreads), 0, s, a);
+  }
+  if (nbig < g.nlevels) {
+    a.level0 = nbig;
+    hipLaunchKernelGGL((orb_select_kernel<4096, 1024, 256>), dim3(g.nlevels - nbig, im.n), dim3(kThreads), 0, s, a);
+  }
+}
+
+void vsf_launch_retain_best_test(uint2* d_data, int n, int n_points, int use_lds, int mode, int* d_out_n,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL((retain_best_test_kernel<1024>), dim3(1), dim3(kThreads), 0, s, d_data, n, n_points, use_lds,
+                     mode, d_out_n);
 }

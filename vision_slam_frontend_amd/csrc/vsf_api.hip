@@ -419,7 +419,7 @@ vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, 
   }
   {
     StageTimer t(ctx, VSF_STAGE_SELECT, 1);
-    vsf_launch_select(d, g, im, ctx->stream);
+    vsf_launch_select(d, g, ctx->orb.levels.data(), im, ctx->stream);
   }
   {
     StageTimer t(ctx, VSF_STAGE_BLUR, 1);
@@ -829,6 +829,34 @@ vsf_status vsf_get_matches(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t
 }
 
 // ---------------- introspection ----------------
+
+vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids, int n, int n_points, int use_lds,
+                                 int mode, int* n_out) {
+  if (!ctx || !n_out || n < 0 || (n > 0 && (!key_bits || !ids))) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  std::vector<uint2> h((size_t)std::max(n, 1));
+  for (int i = 0; i < n; i++) h[i] = make_uint2(key_bits[i], ids[i]);
+  uint2* d = nullptr;
+  int* dn = nullptr;
+  VSF_HIP(hipMalloc((void**)&d, h.size() * sizeof(uint2)));
+  VSF_HIP(hipMalloc((void**)&dn, sizeof(int)));
+  VSF_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(uint2), hipMemcpyHostToDevice));
+  vsf_launch_retain_best_test(d, n, n_points, use_lds, mode, dn, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(uint2), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(n_out, dn, sizeof(int), hipMemcpyDeviceToHost);
+  hipFree(d);
+  hipFree(dn);
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    return VSF_ERR_HIP;
+  }
+  for (int i = 0; i < n; i++) {
+    key_bits[i] = h[i].x;
+    ids[i] = h[i].y;
+  }
+  return VSF_OK;
+}
 
 vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t ostride) {
   if (!ctx || !out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||

@@ -92,7 +92,10 @@ struct VsfImages {
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                         hipStream_t s);
 void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, hipStream_t s);
-void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfImages& im, hipStream_t s);
+void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
+                       hipStream_t s);
+void vsf_launch_retain_best_test(uint2* d_data, int n, int n_points, int use_lds, int mode, int* d_out_n,
+                                 hipStream_t s);
 void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_tiles, int ntiles,
                      const int k[4], hipStream_t s);
 void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int max_keypoints,

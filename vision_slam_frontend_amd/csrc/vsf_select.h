@@ -180,6 +180,26 @@ VSF_HD int unguarded_partition_pivot_(T* a, int first, int last, Comp comp) {
   return unguarded_partition_(a, first + 1, last, first, comp);
 }
 
+// ---- std::__introselect continued from a given (first, last, depth_limit) state ----
+template <class T, class Comp>
+VSF_HD void introselect_from_(T* a, int first, int last, int nth, int depth, Comp comp) {
+  while (last - first > 3) {
+    if (depth == 0) {
+      VSF_SEL_TRACE_FALLBACK();
+      heap_select_(a, first, nth + 1, last, comp);
+      swap_(a[first], a[nth]);
+      return;
+    }
+    --depth;
+    const int cut = unguarded_partition_pivot_(a, first, last, comp);
+    if (cut <= nth)
+      first = cut;
+    else
+      last = cut;
+  }
+  insertion_sort_(a, first, last, comp);
+}
+
 // ---- std::nth_element(a, a + nth, a + n, comp) ----
 template <class T, class Comp>
 VSF_HD void nth_element_(T* a, int n, int nth, Comp comp) {
