@@ -93,6 +93,7 @@ def main() -> int:
     import torch.distributed as dist
 
     from vision_slam_frontend_amd import capi, synth
+    from vision_slam_frontend_amd import distributed as vd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,10 +140,8 @@ def main() -> int:
         if world > 1:
             # VisionFeature (left keypoints) / FeatureMatch payloads of this rank's frames -> rank 0 over RCCL.
             left_kp = d_kp.view(B, 2, K, 28)[:, 0].contiguous()
-            dist.gather(left_kp, gather_bufs["kp"] if rank == 0 else None, dst=0)
-            dist.gather(d_counts, gather_bufs["counts"] if rank == 0 else None, dst=0)
-            dist.gather(d_matches, gather_bufs["matches"] if rank == 0 else None, dst=0)
-            dist.gather(d_nmatches, gather_bufs["nmatches"] if rank == 0 else None, dst=0)
+            vd.gather_to_root({"kp": left_kp, "counts": d_counts, "matches": d_matches, "nmatches": d_nmatches},
+                              dst=0, bufs=gather_bufs)
 
     for _ in range(args.warmup):
         step()

@@ -76,8 +76,8 @@ typedef struct {
   int32_t fast_detector_nms;       /* 1 */
   /* --- matcher: ratio test  dist1 < nn_match_ratio * dist2  with nn_match_ratio a double holding 0.6f
    * (slam_frontend.cc:523,533,555)  ==  dist1 * 2^ratio_shift < ratio_num * dist2  exactly --- */
-  uint32_t ratio_num;   /* 10066330 */
-  uint32_t ratio_shift; /* 24 */
+  uint32_t ratio_num;   /* 5033165  (0.6f == 10066330 / 2^24, kept in lowest terms) */
+  uint32_t ratio_shift; /* 23 */
   /* --- geometry and capacities (fixed per context) --- */
   int32_t width, height;   /* image size in pixels */
   int32_t max_images;      /* images per batch (2 per stereo frame) */
@@ -96,7 +96,7 @@ void vsf_destroy(vsf_ctx* ctx);
 const char* vsf_status_string(vsf_status s);
 int vsf_last_hip_error(const vsf_ctx* ctx);
 vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out);
-/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+/* Use an existing hipStream_t (e.g. the caller's framework stream) instead of the context's own. NULL restores it. */
 vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);

@@ -1,0 +1,91 @@
+"""CPU-side checks of the product's host logic: the order-exact selection restatement against libstdc++, the
+C-ABI library (loads, exports every symbol include/vsf.h declares, parameter helpers), the synthetic generator."""
+import ctypes
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_select_restatement_equals_libstdcxx(tmp_path):
+    exe = tmp_path / "test_select"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "cpp" / "test_select.cc")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "failures=0" in out.stdout
+    assert int(re.search(r"heap_fallbacks_on_killers=(\d+)", out.stdout).group(1)) > 0
+
+
+@pytest.fixture(scope="module")
+def capi():
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as g
+    from vision_slam_frontend_amd import capi
+    if not capi.LIB_PATH.exists():
+        g.build()
+    return capi
+
+
+def test_library_exports_every_declared_symbol(capi):
+    header = (ROOT / "include" / "vsf.h").read_text()
+    declared = set(re.findall(r"\b(vsf_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vsf_status"}
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    lib = ctypes.CDLL(str(capi.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
+def test_no_torch_types_and_no_oracle_in_product():
+    # the boundary is a plain C ABI; the product never touches the oracle
+    header = (ROOT / "include" / "vsf.h").read_text()
+    assert "torch" not in header and "at::" not in header
+    for path in (ROOT / "vision_slam_frontend_amd").rglob("*"):
+        if path.suffix in {".py", ".hip", ".h", ".cc", ".cpp"}:
+            text = path.read_text()
+            assert "oracle" not in text.lower(), path
+
+
+def test_params_default_and_ratio(capi):
+    p = capi.default_params(640, 480, max_images=4)
+    assert (p.nfeatures, p.nlevels, p.edge_threshold, p.first_level, p.wta_k, p.score_type, p.patch_size,
+            p.fast_threshold) == (10000, 50, 31, 0, 2, 0, 31, 20)  # slam_frontend.cc:205-213
+    assert np.float32(p.scale_factor) == np.float32(1.04)
+    assert (p.fast_detector_threshold, p.fast_detector_nms) == (10, 1)  # slam_frontend.cc:191
+    # 0.6f widened to double (slam_frontend.cc:555) == 10066330 / 2^24, stored in lowest terms
+    assert p.ratio_num * 2 ** (24 - p.ratio_shift) == 10066330 and p.ratio_num / 2 ** p.ratio_shift == float(np.float32(0.6))
+    q = capi.default_params(640, 480, nn_match_ratio=0.75)
+    assert (q.ratio_num, q.ratio_shift) == (3, 2)
+    assert capi.lib().vsf_params_set_ratio(ctypes.byref(q), ctypes.c_float(0.0)) == capi.VSF_ERR_INVALID_ARG
+    assert capi.lib().vsf_status_string(capi.VSF_ERR_CAPACITY).decode().startswith("capacity")
+    assert capi.lib().vsf_stage_name(1).decode() == "fast_score_nms"
+
+
+def test_create_without_gpu_fails_loudly(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.VsfError):
+        capi.Context(capi.default_params(640, 480))
+    bad = capi.default_params(640, 480, wta_k=3)
+    h = ctypes.c_void_p()
+    assert capi.lib().vsf_create(ctypes.byref(bad), 0, ctypes.byref(h)) == capi.VSF_ERR_UNSUPPORTED
+
+
+def test_synthetic_generator_is_deterministic():
+    from vision_slam_frontend_amd import synth
+    left, right = synth.stereo_pair(640, 480, 0)
+    assert left.shape == (480, 640) and left.dtype == np.uint8 and left.flags.c_contiguous
+    assert synth.sha256(left).startswith("0427f20208354c21") and synth.sha256(right).startswith("cb1a0507eddcfc6a")
+    b = synth.bench_batch(10, 320, 240, n_scenes=4, n_objects=100)
+    assert b.shape == (10, 2, 240, 320)
+    assert len({synth.sha256(b[i, 0]) for i in range(10)}) == 10  # every frame is a distinct image
+    d = synth.random_descriptors(100)
+    assert d.shape == (100, 32) and synth.sha256(d) == synth.sha256(synth.random_descriptors(100))
+    a = synth.adversarial_descriptors(500)
+    assert len(np.unique(a, axis=0)) < 450  # many exact duplicates
