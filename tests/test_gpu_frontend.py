@@ -1,0 +1,100 @@
+"""slam::Frontend (C++ host class over the HIP C ABI) against a model of the reference's ObserveImage
+(slam_frontend.cc:400-472) assembled from the CPU oracle's pieces: extraction, stereo GetMatches,
+RemoveAmbigStereo re-indexing and threshold chain, temporal GetFeatureMatches (std::sort + best 30 %)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NF = 1000
+F_RECT = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # l^T F r = y_r - y_l: rectified synthetic pair
+
+
+def _model(oracle, frames, frame_life, best_percent=np.float32(0.3)):
+    thr = np.float32(10000.0)
+    frame_list, factors, kept_frames = [], [], []
+    for fid, (left, right) in enumerate(frames):
+        ol, orr = oracle.Orb(nfeatures=NF), oracle.Orb(nfeatures=NF)
+        ol.run(left)
+        orr.run(right)
+        kl, dl = ol.result()
+        kr, dr = orr.result()
+        m = oracle.get_matches(dl, dr)
+        keep, _, thr_new, _ = oracle.remove_ambig_stereo(kl, kr, m, F_RECT, float(thr))
+        thr = np.float32(thr_new)
+        kl2, dl2 = kl[m["queryIdx"][keep]], dl[m["queryIdx"][keep]]
+        for pid, _, pd in frame_list:
+            mm = oracle.sort_and_trim(oracle.get_matches(pd, dl2), float(best_percent))
+            factors.append((pid, fid, np.stack([mm["queryIdx"], mm["trainIdx"]], 1).astype(np.uint64)))
+        if len(frame_list) >= frame_life:
+            frame_list.pop(0)
+        frame_list.append((fid, kl2, dl2))
+        kept_frames.append((kl2, dl2, float(thr)))
+    return factors, frame_list, kept_frames
+
+
+def test_frontend_matches_reference_model(oracle):
+    from vision_slam_frontend_amd import frontend, synth
+    sc = synth.Scene(640, 480)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(4)]
+    fe = frontend.Frontend(640, 480, nfeatures=NF, fundamental=F_RECT, frame_life=3)
+    q = np.array([1, 0, 0, 0], np.float32)
+    # no odometry yet -> no node
+    assert fe.observe_image(*frames[0]) is False
+    fe.observe_odometry([0, 0, 0], q, 1.0)
+    assert fe.observe_image(*frames[0]) is False  # has not moved since the first odometry sample (quirk Q11 fix)
+    thr_seen = []
+    for f in range(4):
+        fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 10.0 + f)
+        assert fe.observe_image(*frames[f], time=99.0) is True
+        assert fe.observe_image(*frames[f]) is False  # same pose again: gated by OdomCheck (cc:175-186)
+        thr_seen.append(fe.stereo_ambig_constraint)
+    assert fe.num_poses == 4
+    factors, frame_list, kept = _model(oracle, frames, frame_life=3)
+    # thresholds: mean residual + 2 chain (cc:392-394)
+    assert thr_seen == [k[2] for k in kept]
+    # vision factors: ids and pairs, in order (cc:424-434)
+    got = fe.vision_factors()
+    assert len(got) == len(factors) == 0 + 1 + 2 + 3
+    for (ga, gb, gp), (ea, eb, ep) in zip(got, factors):
+        assert (ga, gb) == (ea, eb)
+        np.testing.assert_array_equal(gp, ep)
+        assert len(ep) > 3
+    # retained frames (after RemoveAmbigStereo re-indexing), sliding window of frame_life
+    for i, (fid, kl2, dl2) in enumerate(frame_list):
+        gid, gk, gd = fe.frame(i)
+        assert gid == fid and gk.tobytes() == kl2.tobytes()
+        np.testing.assert_array_equal(gd, dl2)
+    # nodes: one feature per surviving left keypoint, pixel = undistorted keypoint position, timestamp = odometry's
+    nodes = fe.nodes()
+    for f, node in enumerate(nodes):
+        kl2 = kept[f][0]
+        assert node["node_idx"] == f and node["timestamp"] == 10.0 + f
+        feat = node["features"]
+        assert len(feat) == len(kl2)
+        np.testing.assert_array_equal(feat[:, 0], np.arange(len(kl2), dtype=np.float32))
+        assert np.abs(feat[:, 1] - kl2["x"]).max() < 40 and np.isfinite(feat).all()
+        np.testing.assert_allclose(node["pose"], [0.3 * (f + 1), 0, 0, 1, 0, 0, 0], atol=1e-6)
+    # odometry factors between consecutive nodes (cc:311-321)
+    of = fe.odometry_factors()
+    assert [(a, b) for a, b, _ in of] == [(0, 1), (1, 2), (2, 3)]
+    for _, _, tq in of:
+        np.testing.assert_allclose(tq, [0.3, 0, 0, 1, 0, 0, 0], atol=1e-6)
+    fe.close()
+
+
+def test_frontend_rotation_gate_and_default_fundamental():
+    from vision_slam_frontend_amd import frontend, synth
+    left, right = synth.stereo_pair(320, 240, 0, n_objects=300)
+    fe = frontend.Frontend(320, 240, nfeatures=300)
+    F = fe.fundamental
+    assert np.isfinite(F).all() and np.abs(F).max() > 0
+    fe.observe_odometry([0, 0, 0], [1, 0, 0, 0], 0.0)
+    half = np.deg2rad(11.0) / 2
+    fe.observe_odometry([0, 0, 0], [np.cos(half), 0, 0, np.sin(half)], 1.0)  # 11 degrees > 10 degrees
+    assert fe.observe_image(left, right) is True
+    half = np.deg2rad(15.0) / 2
+    fe.observe_odometry([0, 0, 0], [np.cos(half), 0, 0, np.sin(half)], 2.0)  # only 4 degrees more
+    assert fe.observe_image(left, right) is False
+    assert fe.num_poses == 1
+    fe.close()

@@ -1,0 +1,131 @@
+"""ctypes view of the C++ host class slam::Frontend (vision_slam_frontend_amd/host/, libvsf_frontend.so), the
+mirror of the reference's Frontend::ObserveImage / ObserveOdometry / GetSLAMProblem API on top of the HIP C ABI.
+Used by tests and examples; the class itself is C++ because the reference's is."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import capi
+
+LIB_PATH = Path(__file__).resolve().parent / "libvsf_frontend.so"
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        capi.lib()  # libvsf_hip.so first (fails loudly if it was not built)
+        if not LIB_PATH.exists():
+            raise ImportError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+        L = C.CDLL(str(LIB_PATH))
+        vp, i32, f32, sz, dbl = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
+        L.vsfh_frontend_create.argtypes = [i32, i32, i32, i32, vp, f32, i32]
+        L.vsfh_frontend_create.restype = vp
+        L.vsfh_frontend_destroy.argtypes = [vp]
+        L.vsfh_observe_odometry.argtypes = [vp, vp, vp, dbl]
+        L.vsfh_observe_image.argtypes = [vp, vp, vp, i32, i32, sz, dbl]
+        L.vsfh_last_status.argtypes = [vp]
+        L.vsfh_num_poses.argtypes = [vp]
+        L.vsfh_stereo_ambig_constraint.argtypes = [vp]
+        L.vsfh_stereo_ambig_constraint.restype = f32
+        L.vsfh_get_fundamental.argtypes = [vp, vp]
+        L.vsfh_num_vision_factors.argtypes = [vp]
+        L.vsfh_vision_factor.argtypes = [vp, i32, vp, vp, vp, i32]
+        L.vsfh_node.argtypes = [vp, i32, vp, vp, vp, vp, i32]
+        L.vsfh_num_odometry_factors.argtypes = [vp]
+        L.vsfh_odometry_factor.argtypes = [vp, i32, vp, vp]
+        L.vsfh_frame.argtypes = [vp, i32, vp, vp, vp, i32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Frontend:
+    def __init__(self, width: int, height: int, nfeatures: int = 10000, device: int = 0, fundamental=None,
+                 best_percent: float = 0.0, frame_life: int = 0):
+        F = None if fundamental is None else np.ascontiguousarray(fundamental, np.float32).reshape(9)
+        self._h = lib().vsfh_frontend_create(nfeatures, width, height, device, _p(F), best_percent, frame_life)
+        self.cap = nfeatures + 256
+        st = lib().vsfh_last_status(self._h)
+        if st != capi.VSF_OK:
+            raise capi.VsfError(st, "Frontend")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vsfh_frontend_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def observe_odometry(self, translation, rotation_wxyz, timestamp: float):
+        t = np.ascontiguousarray(translation, np.float32)
+        q = np.ascontiguousarray(rotation_wxyz, np.float32)
+        lib().vsfh_observe_odometry(self._h, _p(t), _p(q), timestamp)
+
+    def observe_image(self, left: np.ndarray, right: np.ndarray, time: float = 0.0) -> bool:
+        left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        assert left.shape == right.shape and left.ndim == 2
+        added = bool(lib().vsfh_observe_image(self._h, _p(left), _p(right), left.shape[1], left.shape[0],
+                                              left.strides[0], time))
+        st = lib().vsfh_last_status(self._h)
+        if st != capi.VSF_OK:
+            raise capi.VsfError(st, "Frontend::ObserveImage")
+        return added
+
+    @property
+    def num_poses(self) -> int:
+        return lib().vsfh_num_poses(self._h)
+
+    @property
+    def stereo_ambig_constraint(self) -> float:
+        return float(lib().vsfh_stereo_ambig_constraint(self._h))
+
+    @property
+    def fundamental(self) -> np.ndarray:
+        F = np.zeros(9, np.float32)
+        lib().vsfh_get_fundamental(self._h, _p(F))
+        return F.reshape(3, 3)
+
+    def vision_factors(self):
+        out = []
+        for i in range(lib().vsfh_num_vision_factors(self._h)):
+            a, b = C.c_uint64(), C.c_uint64()
+            pairs = np.zeros((self.cap, 2), np.uint64)
+            n = lib().vsfh_vision_factor(self._h, i, C.byref(a), C.byref(b), _p(pairs), self.cap)
+            out.append((a.value, b.value, pairs[:n].copy()))
+        return out
+
+    def nodes(self):
+        out = []
+        for i in range(self.num_poses):
+            idx, ts = C.c_uint64(), C.c_double()
+            pose = np.zeros(7, np.float32)
+            feat = np.zeros((self.cap, 6), np.float32)
+            n = lib().vsfh_node(self._h, i, C.byref(idx), C.byref(ts), _p(pose), _p(feat), self.cap)
+            out.append({"node_idx": idx.value, "timestamp": ts.value, "pose": pose, "features": feat[:n].copy()})
+        return out
+
+    def odometry_factors(self):
+        out = []
+        for i in range(lib().vsfh_num_odometry_factors(self._h)):
+            ij = np.zeros(2, np.uint64)
+            tq = np.zeros(7, np.float32)
+            lib().vsfh_odometry_factor(self._h, i, _p(ij), _p(tq))
+            out.append((int(ij[0]), int(ij[1]), tq))
+        return out
+
+    def frame(self, i: int):
+        fid = C.c_uint64()
+        kp = np.zeros(self.cap, capi.KEYPOINT_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = lib().vsfh_frame(self._h, i, C.byref(fid), _p(kp), _p(desc), self.cap)
+        if n < 0:
+            raise IndexError(i)
+        return fid.value, kp[:n].copy(), desc[:n].copy()

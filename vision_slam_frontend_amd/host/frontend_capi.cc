@@ -1,0 +1,110 @@
+// frontend_capi.cc -- flat C view of slam::Frontend so tests (ctypes) and foreign callers can drive the host
+// class: same call sequence as the reference's driver (slam_frontend_main.cc:132,147,321).
+#include <cstring>
+
+#include "slam_frontend.h"
+
+using slam::Frontend;
+using slam::FrontendConfig;
+
+extern "C" {
+
+void* vsfh_frontend_create(int nfeatures, int width, int height, int device, const float* fundamental9,
+                           float best_percent, int frame_life) {
+  FrontendConfig cfg;
+  cfg.orb_nfeatures = nfeatures;
+  cfg.image_width = width;
+  cfg.image_height = height;
+  if (fundamental9) std::memcpy(cfg.fundamental.m, fundamental9, 9 * sizeof(float));
+  if (best_percent > 0) cfg.best_percent_ = best_percent;
+  if (frame_life > 0) cfg.frame_life_ = (uint32_t)frame_life;
+  return new Frontend("", cfg, device);
+}
+
+void vsfh_frontend_destroy(void* f) { delete static_cast<Frontend*>(f); }
+
+void vsfh_observe_odometry(void* f, const float t[3], const float q_wxyz[4], double ts) {
+  static_cast<Frontend*>(f)->ObserveOdometry(slam::Vector3f(t[0], t[1], t[2]),
+                                             slam::Quaternionf(q_wxyz[0], q_wxyz[1], q_wxyz[2], q_wxyz[3]), ts);
+}
+
+int vsfh_observe_image(void* f, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride, double time) {
+  return static_cast<Frontend*>(f)->ObserveImage(slam::Image(left, h, w, stride), slam::Image(right, h, w, stride), time)
+             ? 1
+             : 0;
+}
+
+int vsfh_last_status(void* f) { return (int)static_cast<Frontend*>(f)->last_status(); }
+int vsfh_num_poses(void* f) { return static_cast<Frontend*>(f)->GetNumPoses(); }
+float vsfh_stereo_ambig_constraint(void* f) { return static_cast<Frontend*>(f)->stereo_ambig_constraint(); }
+
+void vsfh_get_fundamental(void* f, float out9[9]) {
+  const FrontendConfig c = static_cast<Frontend*>(f)->GetConfig();
+  std::memcpy(out9, c.fundamental.m, 9 * sizeof(float));
+}
+
+int vsfh_num_vision_factors(void* f) {
+  slam_types::SLAMProblem p;
+  static_cast<Frontend*>(f)->GetSLAMProblem(&p);
+  return (int)p.vision_factors.size();
+}
+
+int vsfh_vision_factor(void* f, int i, uint64_t* pose_initial, uint64_t* pose_current, uint64_t* pairs, int cap) {
+  const auto& vf = static_cast<Frontend*>(f)->vision_factors();
+  if (i < 0 || i >= (int)vf.size()) return -1;
+  *pose_initial = vf[i].pose_idx_initial;
+  *pose_current = vf[i].pose_idx_current;
+  const int n = (int)vf[i].feature_matches.size();
+  for (int k = 0; k < n && k < cap; k++) {
+    pairs[2 * k] = vf[i].feature_matches[k].feature_idx_initial;
+    pairs[2 * k + 1] = vf[i].feature_matches[k].feature_idx_current;
+  }
+  return n;
+}
+
+// pose7 = loc xyz + angle wxyz; feat = cap x 6: feature_idx, pixel x, pixel y, point3d xyz
+int vsfh_node(void* f, int i, uint64_t* node_idx, double* timestamp, float pose7[7], float* feat, int cap) {
+  const auto& nodes = static_cast<Frontend*>(f)->nodes();
+  if (i < 0 || i >= (int)nodes.size()) return -1;
+  const slam_types::SLAMNode& n = nodes[i];
+  *node_idx = n.node_idx;
+  *timestamp = n.timestamp;
+  const float p[7] = {n.pose.loc.x(),   n.pose.loc.y(),   n.pose.loc.z(),  n.pose.angle.w(),
+                      n.pose.angle.x(), n.pose.angle.y(), n.pose.angle.z()};
+  std::memcpy(pose7, p, sizeof(p));
+  const int m = (int)n.features.size();
+  for (int k = 0; k < m && k < cap; k++) {
+    const slam_types::VisionFeature& v = n.features[k];
+    const float r[6] = {(float)v.feature_idx, v.pixel.x(), v.pixel.y(), v.point3d.x(), v.point3d.y(), v.point3d.z()};
+    std::memcpy(feat + 6 * k, r, sizeof(r));
+  }
+  return m;
+}
+
+int vsfh_num_odometry_factors(void* f) { return (int)static_cast<Frontend*>(f)->odometry_factors().size(); }
+
+int vsfh_odometry_factor(void* f, int i, uint64_t ij[2], float tq[7]) {
+  const auto& of = static_cast<Frontend*>(f)->odometry_factors();
+  if (i < 0 || i >= (int)of.size()) return -1;
+  ij[0] = of[i].pose_i;
+  ij[1] = of[i].pose_j;
+  const float r[7] = {of[i].translation.x(), of[i].translation.y(), of[i].translation.z(), of[i].rotation.w(),
+                      of[i].rotation.x(),    of[i].rotation.y(),    of[i].rotation.z()};
+  std::memcpy(tq, r, sizeof(r));
+  return 0;
+}
+
+// Keypoints / descriptors of the i-th retained frame (after RemoveAmbigStereo re-indexing).
+int vsfh_frame(void* f, int i, uint64_t* frame_id, vsf_keypoint* kp, uint8_t* desc, int cap) {
+  const auto& fl = static_cast<Frontend*>(f)->frame_list();
+  if (i < 0 || i >= (int)fl.size()) return -1;
+  *frame_id = fl[i].frame_ID_;
+  const int n = (int)fl[i].keypoints_.size();
+  const int m = n < cap ? n : cap;
+  if (m > 0 && kp) std::memcpy(kp, fl[i].keypoints_.data(), (size_t)m * sizeof(vsf_keypoint));
+  if (m > 0 && desc && fl[i].descriptors_.size() >= (size_t)m * VSF_DESC_BYTES)
+    std::memcpy(desc, fl[i].descriptors_.data(), (size_t)m * VSF_DESC_BYTES);
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// slam_frontend.cc -- host orchestration of one stereo frame, mirroring the reference's
+// src/slam_frontend.cc:117-538 with the OpenCV calls replaced by the C ABI (include/vsf.h).
+#include "slam_frontend.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace slam {
+
+using slam_types::FeatureMatch;
+using slam_types::OdometryFactor;
+using slam_types::RobotPose;
+using slam_types::SLAMNode;
+using slam_types::SLAMProblem;
+using slam_types::VisionFactor;
+using slam_types::VisionFeature;
+
+namespace {
+
+Matrix3f Mul(const Matrix3f& a, const Matrix3f& b) {
+  Matrix3f r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r(i, j) = (a(i, 0) * b(0, j) + a(i, 1) * b(1, j)) + a(i, 2) * b(2, j);
+  return r;
+}
+
+Matrix3f Transpose(const Matrix3f& a) {
+  Matrix3f r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r(i, j) = a(j, i);
+  return r;
+}
+
+Matrix3f Inverse(const Matrix3f& a) {
+  Matrix3f r;
+  const float c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1), c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2),
+              c02 = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  const float det = a(0, 0) * c00 + a(0, 1) * c01 + a(0, 2) * c02;
+  const float id = 1.0f / det;
+  r(0, 0) = c00 * id;
+  r(0, 1) = (a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2)) * id;
+  r(0, 2) = (a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1)) * id;
+  r(1, 0) = c01 * id;
+  r(1, 1) = (a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0)) * id;
+  r(1, 2) = (a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2)) * id;
+  r(2, 0) = c02 * id;
+  r(2, 1) = (a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1)) * id;
+  r(2, 2) = (a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0)) * id;
+  return r;
+}
+
+Matrix3f CameraMatrix(const CameraIntrinsics& I) {  // cc:542-548
+  Matrix3f M;
+  const float v[9] = {I.fx, 0, I.cx, 0, I.fy, I.cy, 0, 0, 1};
+  std::memcpy(M.m, v, sizeof(v));
+  return M;
+}
+
+// Smallest-eigenvalue eigenvector of the symmetric 4x4 matrix S (cyclic Jacobi, double).
+void SmallestEigenvector4(double S[4][4], double out[4]) {
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 4; p++)
+      for (int q = p + 1; q < 4; q++) off += S[p][q] * S[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 4; p++)
+      for (int q = p + 1; q < 4; q++) {
+        if (S[p][q] == 0.0) continue;
+        const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; k++) {
+          const double skp = S[k][p], skq = S[k][q];
+          S[k][p] = c * skp - s * skq;
+          S[k][q] = s * skp + c * skq;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double spk = S[p][k], sqk = S[q][k];
+          S[p][k] = c * spk - s * sqk;
+          S[q][k] = s * spk + c * sqk;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 4; i++)
+    if (S[i][i] < S[best][best]) best = i;
+  for (int k = 0; k < 4; k++) out[k] = V[k][best];
+}
+
+}  // namespace
+
+// ---- configuration: the reference's hard-coded defaults (cc:550-652) ----
+FrontendConfig::FrontendConfig() {
+  debug_images_ = false;  // reference: true (quirk Q10: retains every image forever); rendering is out of scope
+  // reference: AKAZE (cc:553, quirk Q1); ORB is the north-star path and the only extractor built here
+  descriptor_extract_type_ = DescriptorExtractorType::ORB;
+  best_percent_ = 0.3f;
+  nn_match_ratio_ = 0.6f;
+  frame_life_ = 10;
+  min_odom_rotation = (float)(10.0 / 180.0 * M_PI);
+  min_odom_translation = 0.2f;
+  min_vision_matches = 10;
+  orb_nfeatures = 10000;  // cc:205
+  image_width = 0;        // 0: taken from the first observed image
+  image_height = 0;
+
+  intrinsics_left.fx = 527.873518f;
+  intrinsics_left.cx = 482.823413f;
+  intrinsics_left.fy = 527.276819f;
+  intrinsics_left.cy = 298.033945f;
+  intrinsics_left.k1 = -0.153137f;
+  intrinsics_left.k2 = 0.075666f;
+  intrinsics_left.p1 = -0.000227f;
+  intrinsics_left.p2 = -0.000320f;
+  intrinsics_left.k3 = 0;
+  intrinsics_right.fx = 530.158021f;
+  intrinsics_right.cx = 475.540633f;
+  intrinsics_right.fy = 529.682234f;
+  intrinsics_right.cy = 299.995465f;
+  intrinsics_right.k1 = -0.156833f;
+  intrinsics_right.k2 = 0.081841f;
+  intrinsics_right.p1 = -0.000779f;
+  intrinsics_right.p2 = -0.000356f;
+  intrinsics_right.k3 = -0.000779f;
+
+  const Matrix3f K_left = CameraMatrix(intrinsics_left), K_right = CameraMatrix(intrinsics_right);
+  const float A_right[12] = {0.999593617649873f,  0.021411909431148f,  -0.018818333830411f, -0.131707087331978f,
+                             -0.021140534893290f, 0.999671312094879f,  0.014503294761121f,  0.003232397463343f,
+                             0.019122691705565f,  -0.014099571235136f, 0.999717722536176f,  -0.001146108483477f};
+  const float A_left[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) {
+      float l = 0, r = 0;
+      for (int k = 0; k < 3; k++) {
+        l += K_left(i, k) * A_left[4 * k + j];
+        r += K_right(i, k) * A_right[4 * k + j];
+      }
+      projection_left[4 * i + j] = l;
+      projection_right[4 * i + j] = r;
+    }
+  // Fundamental matrix (cc:635-644).  The reference builds the cross-product matrix from A[1], A[2], A[3] of a
+  // 3-vector (out-of-range read, quirk Q2); the well-formed skew matrix of A is used here instead.
+  Matrix3f rotation;
+  float translation[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) rotation(i, j) = A_right[4 * i + j];
+    translation[i] = A_right[4 * i + 3];
+  }
+  const Matrix3f KRt = Mul(K_left, Transpose(rotation));
+  float A[3];
+  for (int i = 0; i < 3; i++) A[i] = (KRt(i, 0) * translation[0] + KRt(i, 1) * translation[1]) + KRt(i, 2) * translation[2];
+  Matrix3f C;
+  const float c[9] = {0.0f, -A[2], A[1], A[2], 0.0f, -A[0], -A[1], A[0], 0.0f};
+  std::memcpy(C.m, c, sizeof(c));
+  fundamental = Mul(Mul(Mul(Transpose(Inverse(K_right)), rotation), Transpose(K_left)), C);
+}
+
+// ---- Frame (cc:511-519) ----
+Frame::Frame(const std::vector<vsf_keypoint>& keypoints, const std::vector<uint8_t>& descriptors, uint64_t frame_ID) {
+  keypoints_ = keypoints;
+  descriptors_ = descriptors;
+  frame_ID_ = frame_ID;
+  is_initial_ = std::vector<bool>(keypoints_.size(), true);
+  initial_ids_ = std::vector<int64_t>(keypoints_.size(), -1);
+}
+
+// ---- Frontend ----
+Frontend::Frontend(const std::string& config_path) : Frontend(config_path, FrontendConfig(), 0) {}
+
+Frontend::Frontend(const std::string& /*config_path*/, const FrontendConfig& config, int device)
+    : odom_initialized_(false),
+      odom_timestamp_(0),
+      config_(config),
+      curr_frame_ID_(0),
+      stereo_ambig_constraint_(10000),  // cc:353
+      ctx_(nullptr),
+      device_(device),
+      last_status_(VSF_OK) {
+  if (config_.descriptor_extract_type_ != FrontendConfig::DescriptorExtractorType::ORB &&
+      config_.descriptor_extract_type_ != FrontendConfig::DescriptorExtractorType::FREAK)
+    last_status_ = VSF_ERR_UNSUPPORTED;  // the reference would build AKAZE / BRISK / SURF / SIFT here (cc:193-232)
+  if (config_.image_width > 0 && config_.image_height > 0) EnsureContext(config_.image_width, config_.image_height);
+}
+
+Frontend::~Frontend() { vsf_destroy(ctx_); }
+
+bool Frontend::EnsureContext(int width, int height) {
+  if (ctx_) {
+    vsf_params p;
+    vsf_get_params(ctx_, &p);
+    if (p.width == width && p.height == height) return true;
+    vsf_destroy(ctx_);
+    ctx_ = nullptr;
+  }
+  vsf_params p;
+  vsf_params_default(&p, width, height, 2);
+  p.nfeatures = config_.orb_nfeatures;
+  last_status_ = vsf_params_set_ratio(&p, config_.nn_match_ratio_);
+  if (last_status_ != VSF_OK) return false;
+  last_status_ = vsf_create(&p, device_, &ctx_);
+  return last_status_ == VSF_OK;
+}
+
+// cc:250-263.  The reference copies the still-uninitialised odom_*_ into prev_odom_*_ on the first call (quirk
+// Q11); here prev_* starts at the first observed pose.
+void Frontend::ObserveOdometry(const Vector3f& translation, const Quaternionf& rotation, double timestamp) {
+  if (!odom_initialized_) {
+    init_odom_rotation_ = rotation;
+    init_odom_translation_ = translation;
+    prev_odom_rotation_ = rotation;
+    prev_odom_translation_ = translation;
+    odom_initialized_ = true;
+  }
+  odom_translation_ = translation;
+  odom_rotation_ = rotation;
+  odom_timestamp_ = timestamp;
+}
+
+// cc:175-186
+bool Frontend::OdomCheck() {
+  if (!odom_initialized_) return false;
+  if ((prev_odom_translation_ - odom_translation_).norm() > config_.min_odom_translation) return true;
+  if (prev_odom_rotation_.angularDistance(odom_rotation_) > config_.min_odom_rotation) return true;
+  return false;
+}
+
+// cc:266-280: detectAndCompute (ORB) or FAST detect (+ FREAK compute, which is not built: keypoints only).
+bool Frontend::ExtractFeatures(const Image& image, Frame* frame) {
+  if (image.empty() || !EnsureContext(image.cols, image.rows)) {
+    if (last_status_ == VSF_OK) last_status_ = VSF_ERR_INVALID_ARG;
+    return false;
+  }
+  vsf_params p;
+  vsf_get_params(ctx_, &p);
+  int n = 0;
+  std::vector<vsf_keypoint> kps;
+  std::vector<uint8_t> desc;
+  if (config_.descriptor_extract_type_ == FrontendConfig::DescriptorExtractorType::FREAK) {
+    int cap = 1 << 16;
+    kps.resize(cap);
+    last_status_ = vsf_fast_detect(ctx_, image.data, image.cols, image.rows, image.step, -1, 1, kps.data(), cap, &n);
+    if (last_status_ == VSF_ERR_CAPACITY) {
+      cap = n;
+      kps.resize(cap);
+      last_status_ = vsf_fast_detect(ctx_, image.data, image.cols, image.rows, image.step, -1, 1, kps.data(), cap, &n);
+    }
+    if (last_status_ != VSF_OK) return false;
+    kps.resize(n);
+  } else {
+    const int cap = p.max_keypoints;
+    kps.resize(cap);
+    desc.resize((size_t)cap * VSF_DESC_BYTES);
+    last_status_ = vsf_extract(ctx_, image.data, image.cols, image.rows, image.step, kps.data(), desc.data(), cap, &n);
+    if (last_status_ != VSF_OK) return false;
+    kps.resize(n);
+    desc.resize((size_t)n * VSF_DESC_BYTES);
+  }
+  *frame = Frame(kps, desc, curr_frame_ID_);
+  return true;
+}
+
+// cc:521-538
+std::vector<vsf_dmatch> Frontend::GetMatches(const Frame& frame_query, const Frame& frame_train, double nn_match_ratio) {
+  std::vector<vsf_dmatch> best_matches;
+  if (nn_match_ratio != (double)config_.nn_match_ratio_ || !ctx_) {
+    last_status_ = VSF_ERR_UNSUPPORTED;  // the context carries the configured ratio
+    return best_matches;
+  }
+  const int nq = (int)frame_query.keypoints_.size(), nt = (int)frame_train.keypoints_.size();
+  if (frame_query.descriptors_.size() != (size_t)nq * VSF_DESC_BYTES ||
+      frame_train.descriptors_.size() != (size_t)nt * VSF_DESC_BYTES)
+    return best_matches;  // no descriptors (FREAK branch)
+  best_matches.resize(nq);
+  int n = 0;
+  last_status_ = vsf_get_matches(ctx_, frame_query.descriptors_.data(), nq, frame_train.descriptors_.data(), nt,
+                                 best_matches.data(), nq, &n);
+  best_matches.resize(last_status_ == VSF_OK ? n : 0);
+  return best_matches;
+}
+
+// cc:282-309
+VisionFactor Frontend::GetFeatureMatches(Frame* past_frame_ptr, Frame* curr_frame_ptr) {
+  Frame& past_frame = *past_frame_ptr;
+  Frame& curr_frame = *curr_frame_ptr;
+  std::vector<FeatureMatch> pairs;
+  std::vector<vsf_dmatch> matches = GetMatches(past_frame, curr_frame, config_.nn_match_ratio_);
+  // cv::DMatch::operator< compares distance only; std::sort is unstable and its tie order decides who survives.
+  std::sort(matches.begin(), matches.end(),
+            [](const vsf_dmatch& a, const vsf_dmatch& b) { return a.distance < b.distance; });
+  const int num_good_matches = (int)(matches.size() * config_.best_percent_);  // size_t * float -> float -> int
+  matches.erase(matches.begin() + std::min<size_t>(std::max(num_good_matches, 0), matches.size()), matches.end());
+  for (const vsf_dmatch& match : matches) {
+    pairs.push_back(FeatureMatch(match.queryIdx, match.trainIdx));
+    if (curr_frame.is_initial_[match.trainIdx]) {
+      curr_frame.is_initial_[match.trainIdx] = false;
+      curr_frame.initial_ids_[match.trainIdx] = past_frame.is_initial_[match.queryIdx]
+                                                    ? (int64_t)past_frame.frame_ID_
+                                                    : past_frame.initial_ids_[match.queryIdx];
+    }
+  }
+  return VisionFactor(past_frame.frame_ID_, curr_frame.frame_ID_, pairs);
+}
+
+// cc:311-321
+void Frontend::AddOdometryFactor() {
+  const Vector3f translation = prev_odom_rotation_.inverse() * (odom_translation_ - prev_odom_translation_);
+  const Quaternionf rotation(odom_rotation_ * prev_odom_rotation_.inverse());
+  odometry_factors_.push_back(OdometryFactor(curr_frame_ID_ - 1, curr_frame_ID_, translation, rotation));
+}
+
+// cc:353-398.  |l^T F r| per stereo match (float, products accumulated left to right); survivors re-index both
+// frames; the next frame's threshold is this frame's mean residual + 2.
+void Frontend::RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vsf_dmatch>& stereo_matches) {
+  std::vector<vsf_keypoint> left_keypoints, right_keypoints;
+  std::vector<uint8_t> left_descs, right_descs;
+  const Matrix3f& F = config_.fundamental;
+  float avg_constraint = 0.0f;
+  for (size_t m = 0; m < stereo_matches.size(); m++) {
+    const vsf_dmatch& match = stereo_matches[m];
+    const vsf_keypoint& lk = left->keypoints_[match.queryIdx];
+    const vsf_keypoint& rk = right->keypoints_[match.trainIdx];
+    const float l[3] = {lk.x, lk.y, 1.0f}, r[3] = {rk.x, rk.y, 1.0f};
+    float t[3];
+    for (int j = 0; j < 3; j++) t[j] = (l[0] * F(0, j) + l[1] * F(1, j)) + l[2] * F(2, j);
+    const float constraint = std::fabs((t[0] * r[0] + t[1] * r[1]) + t[2] * r[2]);
+    avg_constraint += constraint;
+    if (constraint <= stereo_ambig_constraint_) {
+      left_keypoints.push_back(lk);
+      right_keypoints.push_back(rk);
+      const uint8_t* ld = left->descriptors_.data() + (size_t)match.queryIdx * VSF_DESC_BYTES;
+      const uint8_t* rd = right->descriptors_.data() + (size_t)match.trainIdx * VSF_DESC_BYTES;
+      left_descs.insert(left_descs.end(), ld, ld + VSF_DESC_BYTES);
+      right_descs.insert(right_descs.end(), rd, rd + VSF_DESC_BYTES);
+    }
+  }
+  // The reference divides by zero when there is no match and poisons the static with NaN forever (quirk Q3);
+  // here the threshold is left unchanged in that case.
+  if (!stereo_matches.empty()) stereo_ambig_constraint_ = avg_constraint / (float)stereo_matches.size() + 2.0f;
+  *left = Frame(left_keypoints, left_descs, left->frame_ID_);
+  *right = Frame(right_keypoints, right_descs, right->frame_ID_);
+}
+
+// cc:117-173: right->left matches with best_percent forced to 1, then DLT triangulation (cv::triangulatePoints:
+// per point the null vector of the 4x4 system, double) and the homogeneous divide.  SURVEY section 8(f) row f2: the
+// null vector is found by a Jacobi eigen-solve of A^T A, so values agree with OpenCV's SVD to rounding, not
+// bit for bit.
+void Frontend::Calculate3DPoints(Frame* left_frame, Frame* right_frame, std::vector<Vector3f>* points) {
+  const float best_percent = config_.best_percent_;
+  config_.best_percent_ = 1.0f;
+  const VisionFactor matches = GetFeatureMatches(right_frame, left_frame);
+  config_.best_percent_ = best_percent;
+  if (matches.feature_matches.empty()) return;
+  const float* P[2] = {config_.projection_left, config_.projection_right};
+  for (const FeatureMatch& match : matches.feature_matches) {
+    const vsf_keypoint& left_pt = left_frame->keypoints_[match.feature_idx_current];
+    const vsf_keypoint& right_pt = right_frame->keypoints_[match.feature_idx_initial];
+    const double xy[2][2] = {{left_pt.x, left_pt.y}, {right_pt.x, right_pt.y}};
+    double A[4][4];
+    for (int j = 0; j < 2; j++)
+      for (int k = 0; k < 4; k++) {
+        A[2 * j + 0][k] = xy[j][0] * P[j][8 + k] - P[j][0 + k];
+        A[2 * j + 1][k] = xy[j][1] * P[j][8 + k] - P[j][4 + k];
+      }
+    double S[4][4];
+    for (int a = 0; a < 4; a++)
+      for (int b = 0; b < 4; b++) {
+        double s = 0;
+        for (int k = 0; k < 4; k++) s += A[k][a] * A[k][b];
+        S[a][b] = s;
+      }
+    double X[4];
+    SmallestEigenvector4(S, X);
+    const float xf = (float)X[0], yf = (float)X[1], zf = (float)X[2], wf = (float)X[3];
+    points->push_back(Vector3f(xf, yf, zf) / wf);
+  }
+}
+
+// cc:323-351: cv::undistortPoints(distorted, out, K_left, dist_left, noArray(), K_left): 5 fixed-point
+// iterations in double per point, then re-projection with the same camera matrix (row f2 of SURVEY section 8(f)).
+void Frontend::UndistortFeaturePoints(std::vector<VisionFeature>* features_ptr) {
+  std::vector<VisionFeature>& features = *features_ptr;
+  const CameraIntrinsics& I = config_.intrinsics_left;
+  const double k[5] = {I.k1, I.k2, I.p1, I.p2, I.k3};
+  const double fx = I.fx, fy = I.fy, cx = I.cx, cy = I.cy, ifx = 1. / fx, ify = 1. / fy;
+  for (VisionFeature& f : features) {
+    double x = (f.pixel.x() - cx) * ifx, y = (f.pixel.y() - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    f.pixel = Vector2f((float)(x * fx + cx), (float)(y * fy + cy));
+  }
+}
+
+// cc:400-472
+bool Frontend::ObserveImage(const Image& left_image, const Image& right_image, double /*time*/) {
+  if (!OdomCheck()) return false;
+  Frame curr_frame, right_temp_frame;
+  if (!ExtractFeatures(left_image, &curr_frame)) return false;
+  if (!ExtractFeatures(right_image, &right_temp_frame)) return false;
+  const std::vector<vsf_dmatch> stereo_matches = GetMatches(curr_frame, right_temp_frame, config_.nn_match_ratio_);
+  RemoveAmbigStereo(&curr_frame, &right_temp_frame, stereo_matches);
+  for (Frame& past_frame : frame_list_) vision_factors_.push_back(GetFeatureMatches(&past_frame, &curr_frame));
+  std::vector<Vector3f> points;
+  Calculate3DPoints(&curr_frame, &right_temp_frame, &points);
+  std::vector<VisionFeature> features;
+  for (uint64_t i = 0; i < curr_frame.keypoints_.size(); i++) {
+    // The reference indexes points[i] by keypoint although `points` is in sorted-match order and may be shorter
+    // (quirk Q5, out-of-range read); the same index is used where it exists, a zero point otherwise.
+    const Vector3f p3 = i < points.size() ? points[i] : Vector3f();
+    features.push_back(VisionFeature(i, Vector2f(curr_frame.keypoints_[i].x, curr_frame.keypoints_[i].y), p3));
+  }
+  UndistortFeaturePoints(&features);
+  const Vector3f loc = init_odom_rotation_.inverse() * (odom_translation_ - init_odom_translation_);
+  const Quaternionf angle = odom_rotation_ * init_odom_rotation_.inverse();
+  nodes_.push_back(SLAMNode(curr_frame_ID_, odom_timestamp_, RobotPose(loc, angle), features));
+  if (curr_frame_ID_ > 0) AddOdometryFactor();
+  prev_odom_rotation_ = odom_rotation_;
+  prev_odom_translation_ = odom_translation_;
+  curr_frame_ID_++;
+  if (frame_list_.size() >= config_.frame_life_) frame_list_.erase(frame_list_.begin());
+  frame_list_.push_back(curr_frame);
+  return true;
+}
+
+void Frontend::GetSLAMProblem(SLAMProblem* problem) const {
+  *problem = SLAMProblem(nodes_, vision_factors_, odometry_factors_);
+}
+
+int Frontend::GetNumPoses() { return (int)nodes_.size(); }
+
+}  // namespace slam

@@ -1,0 +1,145 @@
+// slam_frontend.h -- host-side mirror of the reference's slam::Frontend (src/slam_frontend.h:117-142) on top of
+// the C ABI of include/vsf.h.  Same public method names and semantics:
+//   ObserveImage (cc:400-472), ObserveOdometry (cc:250-263), GetSLAMProblem (cc:498-503), GetNumPoses (cc:505),
+//   GetConfig (h:142), debug-image getters (cc:474-495, return empty: debug rendering is out of scope).
+// cv::Mat is replaced by slam::Image (a non-owning view) and Eigen types by the PODs of slam_types.h; both swaps
+// are mechanical for a maintainer who has OpenCV / Eigen.  The two private methods that call
+// OpenCV in the reference -- ExtractFeatures (cc:266) and GetMatches (cc:521) -- call vsf_extract /
+// vsf_get_matches here; everything else is the reference's own host logic restated.
+#ifndef VSF_HOST_SLAM_FRONTEND_H_
+#define VSF_HOST_SLAM_FRONTEND_H_
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/vsf.h"
+#include "slam_types.h"
+
+namespace slam {
+
+using slam_types::Quaternionf;
+using slam_types::Vector2f;
+using slam_types::Vector3f;
+
+// Non-owning 8-bit single-channel image view (stands in for `const cv::Mat&`).
+struct Image {
+  const uint8_t* data = nullptr;
+  int rows = 0, cols = 0;
+  size_t step = 0;
+  Image() {}
+  Image(const uint8_t* d, int r, int c, size_t s) : data(d), rows(r), cols(c), step(s) {}
+  bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+};
+
+// src/slam_frontend.h:42-56
+struct CameraIntrinsics {
+  float k1, k2, k3;
+  float p1, p2;
+  float fx, fy, cx, cy;
+};
+
+struct Matrix3f {
+  float m[9];  // row-major
+  float operator()(int r, int c) const { return m[3 * r + c]; }
+  float& operator()(int r, int c) { return m[3 * r + c]; }
+};
+
+// src/slam_frontend.h:58-97; defaults are the reference's (cc:550-652) except where noted in the .cc.
+struct FrontendConfig {
+  enum class DescriptorExtractorType { AKAZE, ORB, BRISK, SURF, SIFT, FREAK };
+  FrontendConfig();
+  bool debug_images_;
+  DescriptorExtractorType descriptor_extract_type_;
+  float best_percent_;
+  float nn_match_ratio_;
+  float min_odom_translation;
+  float min_odom_rotation;
+  uint32_t min_vision_matches;
+  uint32_t frame_life_;
+  CameraIntrinsics intrinsics_left, intrinsics_right;
+  float projection_left[12], projection_right[12];  // 3x4 row-major (cv::Mat CV_32F in the reference)
+  Matrix3f fundamental;
+  // ORB parameters the reference hard-codes in cv::ORB::create (cc:205-213); exposed so BASELINE configs can set
+  // nfeatures = 2000 / 8000.
+  int orb_nfeatures;
+  // Image geometry the GPU context is created for (the reference takes it from the first cv::Mat).
+  int image_width, image_height;
+};
+
+// src/slam_frontend.h:100-114
+class Frame {
+ public:
+  Frame(const std::vector<vsf_keypoint>& keypoints, const std::vector<uint8_t>& descriptors, uint64_t frame_ID);
+  Frame() : frame_ID_(0) {}
+  uint64_t frame_ID_;
+  std::vector<vsf_keypoint> keypoints_;
+  std::vector<bool> is_initial_;
+  std::vector<int64_t> initial_ids_;
+  std::vector<uint8_t> descriptors_;  // keypoints_.size() x 32, row-major (cv::Mat CV_8U in the reference)
+};
+
+class Frontend {
+ public:
+  // config_path is ignored exactly as in the reference (quirk Q1: FrontendConfig::Load is never defined).
+  explicit Frontend(const std::string& config_path);
+  Frontend(const std::string& config_path, const FrontendConfig& config, int device = 0);
+  ~Frontend();
+  Frontend(const Frontend&) = delete;
+  Frontend& operator=(const Frontend&) = delete;
+
+  // True iff a new SLAM node was added.  Never throws; a failing GPU call is reported by last_status().
+  bool ObserveImage(const Image& left_image, const Image& right_image, double time);
+  void ObserveOdometry(const Vector3f& translation, const Quaternionf& rotation, double timestamp);
+  void GetSLAMProblem(slam_types::SLAMProblem* problem) const;
+  int GetNumPoses();
+  FrontendConfig GetConfig() { return config_; }
+  std::vector<Image> getDebugImages() { return {}; }
+  Image GetLastDebugImage() { return Image(); }
+  Image GetLastDebugStereoImage() { return Image(); }
+  std::vector<Image> getDebugStereoImages() { return {}; }
+
+  // Additions (not in the reference): error reporting instead of abort, and read access for tests.
+  vsf_status last_status() const { return last_status_; }
+  float stereo_ambig_constraint() const { return stereo_ambig_constraint_; }
+  const std::vector<Frame>& frame_list() const { return frame_list_; }
+  const std::vector<slam_types::SLAMNode>& nodes() const { return nodes_; }
+  const std::vector<slam_types::VisionFactor>& vision_factors() const { return vision_factors_; }
+  const std::vector<slam_types::OdometryFactor>& odometry_factors() const { return odometry_factors_; }
+
+ private:
+  bool OdomCheck();
+  bool ExtractFeatures(const Image& image, Frame* curr_frame);
+  slam_types::VisionFactor GetFeatureMatches(Frame* past_frame_ptr, Frame* curr_frame_ptr);
+  std::vector<vsf_dmatch> GetMatches(const Frame& frame_query, const Frame& frame_train, double nn_match_ratio);
+  void RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vsf_dmatch>& stereo_matches);
+  void AddOdometryFactor();
+  void UndistortFeaturePoints(std::vector<slam_types::VisionFeature>* features);
+  void Calculate3DPoints(Frame* left_frame, Frame* right_frame, std::vector<Vector3f>* points);
+  bool EnsureContext(int width, int height);
+
+  bool odom_initialized_;
+  Vector3f init_odom_translation_;
+  Quaternionf init_odom_rotation_;
+  Vector3f prev_odom_translation_;
+  Quaternionf prev_odom_rotation_;
+  Vector3f odom_translation_;
+  Quaternionf odom_rotation_;
+  double odom_timestamp_;
+  FrontendConfig config_;
+  uint64_t curr_frame_ID_;
+  std::vector<Frame> frame_list_;
+  std::vector<slam_types::VisionFactor> vision_factors_;
+  std::vector<slam_types::SLAMNode> nodes_;
+  std::vector<slam_types::OdometryFactor> odometry_factors_;
+  // The reference keeps this in a file-static shared by all instances (cc:353, quirk Q3); here it is per object.
+  float stereo_ambig_constraint_;
+  vsf_ctx* ctx_;
+  int device_;
+  vsf_status last_status_;
+};
+
+}  // namespace slam
+
+#endif  // VSF_HOST_SLAM_FRONTEND_H_
