@@ -185,8 +185,10 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
     }
     for (int l = 0; l < nlevels; l++) {
       const VsfLevel& L = G.levels[l];
-      for (int ty = 0; ty * 16 < L.h; ty++)
-        for (int tx = 0; tx * 64 < L.w; tx++) G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)ty << 12) | tx);
+      // blur work units: (level, 248-column band, 64-row strip), one wave each
+      for (int st = 0; st * VSF_BLUR_STRIP_ROWS < L.h; st++)
+        for (int b = 0; b * VSF_BLUR_BAND_COLS < L.w; b++)
+          G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)st);
     }
   }
   if (G.xt.empty()) G.xt.push_back(VsfTap{0, 0, 0, 0});

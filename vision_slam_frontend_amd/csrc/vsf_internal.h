@@ -48,6 +48,8 @@ struct VsfLevelKp {
   float angle;
 };
 
+#define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
+#define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
 #define VSF_FAST_THREADS 256
 #define VSF_SELECT_THREADS 256
 #define VSF_SELECT_LDS_ENTRIES 16384  // stage-1 array (u32) kept in LDS when the candidate count fits
