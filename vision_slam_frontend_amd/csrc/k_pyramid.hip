@@ -4,38 +4,93 @@
 // VResizeLinear<..., FixedPtCast<int,uchar,22>>) as reached from ORB_Impl::detectAndCompute
 // (features2d/orb.cpp), i.e. from slam_frontend.cc:274.  The coefficient tables (xofs/ialpha, yofs/ibeta) are
 // built once per context on the host exactly as cv::resize builds them, so the kernel is integer-only.
-// One thread produces four horizontally adjacent output pixels (one 32-bit store).
+//
+// Streaming march kernel (no LDS, no barriers): a wave owns 256 output columns (lane = 4 adjacent pixels) and walks
+// down a strip of output rows.  The lane's four x-taps are loop-invariant: they become four v_perm_b32 byte
+// selectors and four packed weight pairs, so one 8-byte load per source row + 4 x (v_perm + v_dot2_u32_u16) gives
+// the four horizontal sums; the vertical pass and a 32-bit store finish the row.  A wave handles 4 output rows and
+// issues all eight source-row loads before any arithmetic (rows shared between neighbouring output rows hit L1),
+// so the kernel is limited by memory-level parallelism across waves, not by a per-row dependency chain.
 #include "vsf_internal.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t* __restrict__ src_base, size_t src_img_stride,
-                                                           int src_pitch, uint8_t* __restrict__ dst_base,
-                                                           size_t dst_img_stride, int dst_pitch, int dw, int dh,
-                                                           const VsfTap* __restrict__ xt,
-                                                           const VsfTap* __restrict__ yt) {
-  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  if (x4 >= dw || y >= dh) return;
-  const uint8_t* S = src_base + (size_t)blockIdx.z * src_img_stride;
-  const VsfTap ty = yt[y];
-  const uint8_t* S0 = S + (size_t)ty.i0 * src_pitch;
-  const uint8_t* S1 = S + (size_t)ty.i1 * src_pitch;
-  const int b0 = ty.c0, b1 = ty.c1;
-  uint32_t out = 0;
+constexpr int kStripRows = 4;
+
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(1))) U8B {
+  uint32_t lo, hi;
+};
+
+struct ResizeArgs {
+  const uint8_t* src;
+  size_t src_img_stride;
+  int src_pitch, sw, sh;
+  uint8_t* dst;
+  size_t dst_img_stride;
+  int dst_pitch, dw, dh;
+  const VsfTap* xt;
+  const VsfTap* yt;
+  int nbands, nunits;
+};
+
+__global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= a.nunits) return;  // wave-uniform
+  const int band = unit % a.nbands, strip = unit / a.nbands;
+  const int x4 = band * 256 + lane * 4;
+  const bool active = x4 < a.dw;
+  // loop-invariant x taps of this lane's 4 pixels
+  VsfTap t0 = a.xt[min(x4 + 0, a.dw - 1)], t1 = a.xt[min(x4 + 1, a.dw - 1)], t2 = a.xt[min(x4 + 2, a.dw - 1)],
+         t3 = a.xt[min(x4 + 3, a.dw - 1)];
+  const int base = min((int)t0.i0, a.sw - 8);  // 8-byte window [base, base+8) covers all eight taps, inside the row
+  auto selector = [&](const VsfTap& t) -> uint32_t {
+    return (uint32_t)(t.i0 - base) | 0x0C000C00u | ((uint32_t)(t.i1 - base) << 16);
+  };
+  auto weights = [](const VsfTap& t) -> uint32_t { return (uint32_t)(uint16_t)t.c0 | ((uint32_t)(uint16_t)t.c1 << 16); };
+  const uint32_t s0 = selector(t0), s1 = selector(t1), s2 = selector(t2), s3 = selector(t3);
+  const uint32_t q0 = weights(t0), q1 = weights(t1), q2 = weights(t2), q3 = weights(t3);
+  const uint8_t* S = a.src + (size_t)blockIdx.y * a.src_img_stride + base;
+  uint8_t* D = a.dst + (size_t)blockIdx.y * a.dst_img_stride + x4;
+
+  struct H4 {
+    uint32_t a, b, c, d;
+  };
+  auto hpass = [&](const U8B& v) -> H4 {
+    H4 h;
+    h.a = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(v.hi, v.lo, s0)),
+                                 __builtin_bit_cast(v2u16, q0), 0u, false);
+    h.b = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(v.hi, v.lo, s1)),
+                                 __builtin_bit_cast(v2u16, q1), 0u, false);
+    h.c = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(v.hi, v.lo, s2)),
+                                 __builtin_bit_cast(v2u16, q2), 0u, false);
+    h.d = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(v.hi, v.lo, s3)),
+                                 __builtin_bit_cast(v2u16, q3), 0u, false);
+    return h;
+  };
+  // Every output row issues its two source-row loads unconditionally (rows shared with the neighbouring output row
+  // hit L1): no loop-carried state, so all 2 * kStripRows loads of the strip are in flight together.
+  const int ys = strip * kStripRows;
+  VsfTap ty[kStripRows];
+  U8B v0[kStripRows], v1[kStripRows];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int x = x4 + k;
-    if (x < dw) {
-      const VsfTap tx = xt[x];
-      const int r0 = S0[tx.i0] * tx.c0 + S0[tx.i1] * tx.c1;
-      const int r1 = S1[tx.i0] * tx.c0 + S1[tx.i1] * tx.c1;
-      const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 255) << (8 * k);
-    }
+  for (int r = 0; r < kStripRows; r++) {
+    ty[r] = a.yt[min(ys + r, a.dh - 1)];  // wave-uniform
+    v0[r] = *reinterpret_cast<const U8B*>(S + (size_t)ty[r].i0 * a.src_pitch);
+    v1[r] = *reinterpret_cast<const U8B*>(S + (size_t)ty[r].i1 * a.src_pitch);
   }
-  uint8_t* D = dst_base + (size_t)blockIdx.z * dst_img_stride + (size_t)y * dst_pitch + x4;
-  *reinterpret_cast<uint32_t*>(D) = out;
+#pragma unroll
+  for (int r = 0; r < kStripRows; r++) {
+    const H4 h0 = hpass(v0[r]), h1 = hpass(v1[r]);
+    const int b0 = ty[r].c0, b1 = ty[r].c1;
+    auto vpass = [&](uint32_t u0, uint32_t u1) -> uint32_t {
+      return (uint32_t)((((b0 * (int)(u0 >> 4)) >> 16) + ((b1 * (int)(u1 >> 4)) >> 16) + 2) >> 2) & 255u;
+    };
+    const uint32_t out = vpass(h0.a, h1.a) | (vpass(h0.b, h1.b) << 8) | (vpass(h0.c, h1.c) << 16) |
+                         (vpass(h0.d, h1.d) << 24);
+    if (active && ys + r < a.dh) *reinterpret_cast<uint32_t*>(D + (size_t)(ys + r) * a.dst_pitch) = out;
+  }
 }
 
 }  // namespace
@@ -45,12 +100,21 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   for (int l = 1; l < g.nlevels; l++) {
     const VsfLevel& L = h_levels[l];
     const VsfLevel& P = h_levels[l - 1];
-    const uint8_t* src = (l == 1) ? im.base : d.pyr + P.offset;
-    const size_t src_img_stride = (l == 1) ? im.image_stride : (size_t)g.pyr_bytes;
-    const int src_pitch = (l == 1) ? (int)im.row_stride : P.pitch;
-    dim3 block(64, 4, 1);
-    dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, im.n);
-    hipLaunchKernelGGL(resize_level_kernel, grid, block, 0, s, src, src_img_stride, src_pitch, d.pyr + L.offset,
-                       (size_t)g.pyr_bytes, L.pitch, L.w, L.h, d.xtaps + L.xtab, d.ytaps + L.ytab);
+    ResizeArgs a;
+    a.src = (l == 1) ? im.base : d.pyr + P.offset;
+    a.src_img_stride = (l == 1) ? im.image_stride : (size_t)g.pyr_bytes;
+    a.src_pitch = (l == 1) ? (int)im.row_stride : P.pitch;
+    a.sw = P.w;
+    a.sh = P.h;
+    a.dst = d.pyr + L.offset;
+    a.dst_img_stride = (size_t)g.pyr_bytes;
+    a.dst_pitch = L.pitch;
+    a.dw = L.w;
+    a.dh = L.h;
+    a.xt = d.xtaps + L.xtab;
+    a.yt = d.ytaps + L.ytab;
+    a.nbands = (L.w + 255) / 256;
+    a.nunits = a.nbands * ((L.h + kStripRows - 1) / kStripRows);
+    hipLaunchKernelGGL(resize_march_kernel, dim3((a.nunits + 3) / 4, im.n), dim3(256), 0, s, a);
   }
 }

@@ -182,6 +182,15 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
       L.xtab = (uint32_t)G.xt.size();
       L.ytab = (uint32_t)G.yt.size();
       build_taps(P.w, P.h, L.w, L.h, &G.xt, &G.yt);
+      // resize_march_kernel reads one 8-byte source window per lane (4 output pixels): all eight taps must fit.
+      if (P.w < 8) return false;
+      for (int x4 = 0; x4 < L.w; x4 += 4) {
+        const int base = std::min((int)G.xt[L.xtab + x4].i0, P.w - 8);
+        for (int j = 0; j < 4 && x4 + j < L.w; j++) {
+          const VsfTap& t = G.xt[L.xtab + x4 + j];
+          if (t.i0 < base || t.i1 - base > 7) return false;
+        }
+      }
     }
     for (int l = 0; l < nlevels; l++) {
       const VsfLevel& L = G.levels[l];
