@@ -6,21 +6,31 @@
 // FastFeatureDetector::detect (threshold 10, slam_frontend.cc:191,271), plus
 // KeyPointsFilter::runByImageBorder(31) which is folded into the evaluated rectangle.
 //
-// Work decomposition: one workgroup owns a full-width strip of `strip_rows` rows of one level of one image.
-//   phase 0  coalesced 16-byte loads of the strip (+4 halo rows) into an LDS image tile
-//   phase A  every pixel: high-speed reject on the 2 vertical circle pixels, then the 16-pixel segment
-//            test on bit masks; corners are appended to an LDS list (dense work for phase B)
-//   phase B  one lane per listed corner: score = max(t, max_arc min(v-p), max_arc min(p-v)) - 1 -> LDS score tile
-//   phase C  strict 8-neighbour NMS on the score tile and an order-preserving compaction (each lane owns a
-//            contiguous raster run; block-wide exclusive scan) into the strip's candidate segment in HBM.
-// Strips of a level are ordered by y, so concatenating the segments gives OpenCV's raster order.
+// Streaming march kernel -- no LDS, no barriers, no divergent corner/score phases:
+//  * a wave owns a band of 240 keypoint columns x a strip of 32 rows of one level of one image and walks down the
+//    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window and
+//    gets its neighbours' dwords by DPP wave shifts;
+//  * corner test and score are ONE dense computation: with d_k = p_k - v on the 16-pixel circle,
+//      A = max over the 16 arcs of min(d over the 9-arc),  B = -min over arcs of max(d over the arc),
+//    the pixel is a FAST-9 corner iff max(A, B) > t and cornerScore is max(A, B) - 1.  Two pixels are processed per
+//    VALU lane-op with packed 16-bit min/max (v_pk_min_i16 / v_pk_max_i16), circle bytes are pulled out of the
+//    window with v_perm_b32; there is no data-dependent branch except a wave-wide early-out for flat rows;
+//  * scores stay in registers (3-row rolling window, 4 score bytes per lane); the strict 8-neighbour NMS reads the
+//    neighbours by DPP, and survivors are appended in raster order with ballot prefix ranks.
+// Output per unit: a candidate segment in unit-local raster order + the start offset of every row, which
+// vsf_gather.h merges into the level's global raster order.
+#include "vsf_gather.h"
 #include "vsf_internal.h"
 
 namespace {
 
+typedef short v2s __attribute__((ext_vector_type(2)));
+constexpr int SR = VSF_FAST_STRIP_ROWS;
+
 struct FastArgs {
   const VsfLevel* levels;
-  const uint32_t* strips;
+  const uint32_t* units;
+  int nunits;
   const uint8_t* img0;
   size_t img0_stride;
   int img0_pitch;
@@ -28,56 +38,132 @@ struct FastArgs {
   uint32_t pyr_bytes;
   uint32_t* cand;
   uint32_t cand_entries;
-  int32_t* strip_count;
-  int nstrips;
+  uint16_t* rowstart;
   int threshold;
   int nms;
-  int strip_rows;
-  int tile_pitch_max;
-  int score_pitch_max;
 };
 
-__device__ __forceinline__ bool has9(uint32_t m) {
-  // m: 16 circle flags; true iff 9 circularly contiguous bits are set.
-  m |= m << 16;
-  uint32_t a = m & (m >> 1);
-  a &= a >> 2;
-  a &= a >> 4;
-  a &= m >> 8;
-  return (a & 0xFFFFu) != 0;
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i-1
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {  // lane i <- lane i+1
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
 }
 
-// Block-wide exclusive scan over 256 threads (4 waves of 64).
-__device__ __forceinline__ int block_excl_scan_256(int v, int* lds4, int* total) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
+// One image row as seen by a lane: its own 4 pixels (d) and the neighbouring lanes' (p = left, n = right).
+struct Row3 {
+  uint32_t p, d, n;
+};
+
+// Bytes B and B+1 of the 12-byte run {p, d, n}, zero-extended into the two 16-bit halves.
+template <int B>
+__device__ __forceinline__ v2s pick2(const Row3& r) {
+  static_assert(B >= 0 && B + 1 <= 11, "byte range");
+  if constexpr (B + 1 <= 7) {
+    constexpr uint32_t sel = (uint32_t)B | 0x0C000C00u | ((uint32_t)(B + 1) << 16);
+    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.d, r.p, sel));
+  } else {
+    constexpr uint32_t sel = (uint32_t)(B - 4) | 0x0C000C00u | ((uint32_t)(B - 3) << 16);
+    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.n, r.d, sel));
   }
-  if (lane == 63) lds4[wid] = inc;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wid; w++) base += lds4[w];
-  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-  __syncthreads();
-  return base + inc - v;
 }
 
-#define VSF_CIRCLE16(F)                                                                                        \
-  F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3) F(8, 0, -3)        \
-      F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
+__device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 
-__global__ __launch_bounds__(VSF_FAST_THREADS) void fast_strip_kernel(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int tid = threadIdx.x;
-  const uint32_t sdesc = a.strips[blockIdx.x];
-  const int level = (int)(sdesc >> 16), ys = (int)(sdesc & 0xFFFFu);
+// Scores of the two pixels at bytes 4+J0, 5+J0 of the centre row (W[3]); W[0..6] are rows y-3..y+3.
+// Returns the two 8-bit scores (0 = not a corner) in bits 0..7 and 8..15.
+template <int J0>
+__device__ __forceinline__ uint32_t score_pair(const Row3 (&W)[7], int t, int nms) {
+  const v2s v = pick2<4 + J0>(W[3]);
+  v2s d[16];
+  // Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
+  // (-3,0)(-3,1)(-2,2)(-1,3); window row index = 3 + dy.
+  d[0] = pick2<4 + J0 + 0>(W[6]) - v;
+  d[1] = pick2<4 + J0 + 1>(W[6]) - v;
+  d[2] = pick2<4 + J0 + 2>(W[5]) - v;
+  d[3] = pick2<4 + J0 + 3>(W[4]) - v;
+  d[4] = pick2<4 + J0 + 3>(W[3]) - v;
+  d[5] = pick2<4 + J0 + 3>(W[2]) - v;
+  d[6] = pick2<4 + J0 + 2>(W[1]) - v;
+  d[7] = pick2<4 + J0 + 1>(W[0]) - v;
+  d[8] = pick2<4 + J0 + 0>(W[0]) - v;
+  d[9] = pick2<4 + J0 - 1>(W[0]) - v;
+  d[10] = pick2<4 + J0 - 2>(W[1]) - v;
+  d[11] = pick2<4 + J0 - 3>(W[2]) - v;
+  d[12] = pick2<4 + J0 - 3>(W[3]) - v;
+  d[13] = pick2<4 + J0 - 3>(W[4]) - v;
+  d[14] = pick2<4 + J0 - 2>(W[5]) - v;
+  d[15] = pick2<4 + J0 - 1>(W[6]) - v;
+  v2s n1[16], x1[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    n1[k] = vmin(d[k], d[(k + 1) & 15]);
+    x1[k] = vmax(d[k], d[(k + 1) & 15]);
+  }
+  v2s n2[16], x2[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    n2[k] = vmin(n1[k], n1[(k + 2) & 15]);
+    x2[k] = vmax(x1[k], x1[(k + 2) & 15]);
+  }
+  v2s A = {-32768, -32768}, Bm = {32767, 32767};
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const v2s n9 = vmin(vmin(n2[k], n2[(k + 4) & 15]), d[(k + 8) & 15]);
+    const v2s x9 = vmax(vmax(x2[k], x2[(k + 4) & 15]), d[(k + 8) & 15]);
+    A = vmax(A, n9);
+    Bm = vmin(Bm, x9);
+  }
+  // cornerScore<16>: max(t, A, -Bm) - 1; a corner iff that maximum exceeds t.  With NMS a corner of score 0 can
+  // never win (cv::FAST_t compares strictly against neighbours >= 0); without NMS only a corner marker is kept
+  // (cv::FAST_t leaves the response at 0 then).
+  const int a0 = A.x, a1 = A.y, b0 = -(int)Bm.x, b1 = -(int)Bm.y;
+  const int s0 = max(a0, b0), s1 = max(a1, b1);
+  const uint32_t r0 = s0 > t ? (nms ? (uint32_t)(s0 - 1) : 1u) : 0u, r1 = s1 > t ? (nms ? (uint32_t)(s1 - 1) : 1u) : 0u;
+  return r0 | (r1 << 8);
+}
+
+// True if some pixel of the lane's four could be a corner: a 9-arc always contains circle pixel 0 or 8.
+__device__ __forceinline__ bool maybe_corner(const Row3 (&W)[7], int t) {
+  const uint32_t c = W[3].d, up = W[0].d, dn = W[6].d;
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int v = (c >> (8 * j)) & 255, a = (up >> (8 * j)) & 255, b = (dn >> (8 * j)) & 255;
+    any |= (abs(a - v) > t) | (abs(b - v) > t);
+  }
+  return any;
+}
+
+template <int B>
+__device__ __forceinline__ int byte_of(const Row3& r) {
+  if constexpr (B < 4) {
+    return (int)((r.p >> (8 * B)) & 255u);
+  } else if constexpr (B < 8) {
+    return (int)((r.d >> (8 * (B - 4))) & 255u);
+  } else {
+    return (int)((r.n >> (8 * (B - 8))) & 255u);
+  }
+}
+
+template <int J>
+__device__ __forceinline__ bool nms_keep(const Row3& up, const Row3& mid, const Row3& dn, int nms) {
+  const int s = byte_of<4 + J>(mid);
+  if (s == 0) return false;
+  if (!nms) return true;
+  return s > byte_of<3 + J>(mid) && s > byte_of<5 + J>(mid) && s > byte_of<3 + J>(up) && s > byte_of<4 + J>(up) &&
+         s > byte_of<5 + J>(up) && s > byte_of<3 + J>(dn) && s > byte_of<4 + J>(dn) && s > byte_of<5 + J>(dn);
+}
+
+__global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= a.nunits) return;  // wave-uniform
+  const uint32_t ud = a.units[unit];
+  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip = (int)(ud & 0xFFFF);
   const VsfLevel L = a.levels[level];
   const int image = blockIdx.y;
-  const int SR = a.strip_rows;
-  const int ye = min(ys + SR, L.y_hi);
   const uint8_t* src;
   int pitch;
   if (level == 0) {
@@ -87,205 +173,134 @@ __global__ __launch_bounds__(VSF_FAST_THREADS) void fast_strip_kernel(FastArgs a
     src = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
     pitch = L.pitch;
   }
-  uint8_t* tile = smem;
-  uint8_t* score = tile + (SR + 8) * a.tile_pitch_max;
-  uint16_t* list = reinterpret_cast<uint16_t*>(score + (SR + 2) * a.score_pitch_max);
-  int* misc = reinterpret_cast<int*>(list + (SR + 2) * a.score_pitch_max);
-
-  const int cx0 = max(L.x_lo - 4, 0) & ~15;
-  const int cx1 = min((L.x_hi + 4 + 15) & ~15, pitch);
-  const int tp = cx1 - cx0;
-  const int ry0 = max(ys - 4, 0), ry1 = min(ye + 4, L.h);
-  const int nrows = ry1 - ry0;
-  const int sp = (L.ncols + 15) & ~15;
-  const int nsr = ye - ys + 2;
-
-  // phase 0: image tile + zeroed score tile
-  {
-    const int cpr = tp >> 4;
-    const int nchunks = nrows * cpr;
-    for (int i = tid; i < nchunks; i += VSF_FAST_THREADS) {
-      const int r = i / cpr, c = i - r * cpr;
-      const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(ry0 + r) * pitch + cx0 + c * 16);
-      *reinterpret_cast<uint4*>(tile + r * tp + c * 16) = v;
-    }
-    const int nz = (nsr * sp) >> 4;
-    for (int i = tid; i < nz; i += VSF_FAST_THREADS) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) misc[4] = 0;
-  }
-  __syncthreads();
-
-  // phase A: segment test
-  const int ncols = L.ncols;
-  const int total = nsr * ncols;
-  const int t = a.threshold;
-  for (int idx = tid; idx < total; idx += VSF_FAST_THREADS) {
-    const int r = (int)__umulhi((uint32_t)idx, L.ncols_magic);
-    const int c = idx - r * ncols;
-    const int y = ys - 1 + r, x = L.x_lo - 1 + c;
-    bool corner = false;
-    if (y >= 3 && y < L.h - 3 && x >= 3 && x < L.w - 3) {
-      const uint8_t* p = tile + (y - ry0) * tp + (x - cx0);
-      const int v = p[0];
-      const int lo = v - t, hi = v + t;
-      const int p0 = p[3 * tp], p8 = p[-3 * tp];
-      // A 9-arc of the 16-circle always contains pixel 0 or pixel 8.
-      if ((p0 < lo) | (p8 < lo) | (p0 > hi) | (p8 > hi)) {
-        uint32_t dark = 0, bright = 0;
-#define VSF_F(k, dx, dy)                     \
-  {                                          \
-    const int pk = p[(dy)*tp + (dx)];        \
-    dark |= (uint32_t)(pk < lo) << (k);      \
-    bright |= (uint32_t)(pk > hi) << (k);    \
-  }
-        VSF_CIRCLE16(VSF_F)
-#undef VSF_F
-        corner = has9(dark) || has9(bright);
-      }
-    }
-    if (corner) {
-      const int pos = atomicAdd(&misc[4], 1);
-      list[pos] = (uint16_t)idx;
-    }
-  }
-  __syncthreads();
-
-  // phase B: corner score
-  const int nlist = misc[4];
-  for (int i = tid; i < nlist; i += VSF_FAST_THREADS) {
-    const int idx = list[i];
-    const int r = (int)__umulhi((uint32_t)idx, L.ncols_magic);
-    const int c = idx - r * ncols;
-    const int y = ys - 1 + r, x = L.x_lo - 1 + c;
-    int s = 1;  // marker when NMS is off (OpenCV then leaves the response at 0)
-    if (a.nms) {
-      const uint8_t* p = tile + (y - ry0) * tp + (x - cx0);
-      const int v = p[0];
-      int d[16];
-#define VSF_F(k, dx, dy) d[k] = v - (int)p[(dy)*tp + (dx)];
-      VSF_CIRCLE16(VSF_F)
-#undef VSF_F
-      int mn[16], mx[16];
+  const int t = a.threshold, nms = a.nms;
+  const int bx0 = L.fast_a0 + VSF_FAST_BAND_COLS * band;
+  const int c0 = bx0 - 8 + 4 * lane;  // first column of this lane's 4 pixels
+  const bool loadable = c0 >= 0 && c0 + 3 < pitch;
+  const int ys = L.y_lo + strip * SR, ye = min(ys + SR, L.y_hi);
+  // Pixels that may carry a score: FAST's 3-pixel rim and one column beyond the keypoint rectangle (for the NMS).
+  const int sx_lo = max(L.x_lo - 1, 3), sx_hi = min(L.x_hi + 1, L.w - 3);
+  uint32_t smask = 0, emask = 0;  // per-pixel byte masks: may be scored / may be emitted
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        mn[k] = min(d[k], d[(k + 1) & 15]);
-        mx[k] = max(d[k], d[(k + 1) & 15]);
-      }
-      int mn2[16], mx2[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        mn2[k] = min(mn[k], mn[(k + 2) & 15]);
-        mx2[k] = max(mx[k], mx[(k + 2) & 15]);
-      }
-      int a0 = t, b0 = -t;
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int m9 = min(min(mn2[k], mn2[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int x9 = max(max(mx2[k], mx2[(k + 4) & 15]), d[(k + 8) & 15]);
-        a0 = max(a0, m9);
-        b0 = min(b0, x9);
-      }
-      // cornerScore<16>: a0 = max(t, max_arc min d); b0 = min(-a0, min_arc max d); result -b0 - 1.
-      b0 = min(b0, -a0);
-      s = -b0 - 1;
-    }
-    score[r * sp + c] = (uint8_t)s;
+  for (int j = 0; j < 4; j++) {
+    const int x = c0 + j;
+    if (lane >= 1 && lane <= 62 && x >= sx_lo && x < sx_hi) smask |= 0xFFu << (8 * j);
+    if (lane >= 2 && lane <= 61 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS) emask |= 0xFFu << (8 * j);
   }
-  __syncthreads();
+  const int unit_local = strip * L.nbands + band;
+  uint32_t* seg = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)unit_local * L.seg_cap;
+  uint16_t* rs = a.rowstart + ((size_t)image * a.nunits + L.unit0 + unit_local) * VSF_FAST_RS_STRIDE;
 
-  // phase C: NMS + raster-order compaction over rows [ys, ye) x cols [x_lo, x_hi)
-  const int vw = L.x_hi - L.x_lo;
-  const int npx = (ye - ys) * vw;
-  const int chunk = (npx + VSF_FAST_THREADS - 1) / VSF_FAST_THREADS;
-  const int beg = min(tid * chunk, npx), end = min(beg + chunk, npx);
-  const int r_beg = beg / vw, c_beg = beg - r_beg * vw;
-  auto is_kp = [&](int r, int c) -> int {
-    const uint8_t* q = score + (r + 1) * sp + (c + 1);
-    const int s = q[0];
-    if (s == 0) return -1;
-    if (!a.nms) return 0;
-    const bool keep = s > q[-1] && s > q[1] && s > q[-sp - 1] && s > q[-sp] && s > q[-sp + 1] && s > q[sp - 1] &&
-                      s > q[sp] && s > q[sp + 1];
-    return keep ? s : -1;
+  auto load_row = [&](int y) -> Row3 {
+    Row3 r;
+    const int yc = min(max(y, 0), L.h - 1);
+    r.d = loadable ? *reinterpret_cast<const uint32_t*>(src + (size_t)yc * pitch + c0) : 0u;
+    r.p = wave_shr1(r.d);
+    r.n = wave_shl1(r.d);
+    return r;
   };
-  int count = 0;
-  {
-    int r = r_beg, c = c_beg;
-    for (int i = beg; i < end; i++) {
-      count += is_kp(r, c) >= 0;
-      if (++c == vw) c = 0, ++r;
+
+  Row3 W[7];  // rows sy-3 .. sy+3 around the score row sy
+  int sy = ys - 1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) W[i + 1] = load_row(sy - 3 + i);
+  Row3 next = load_row(sy + 3);
+  Row3 S_up = {0, 0, 0}, S_mid = {0, 0, 0};  // score rows sy-2, sy-1 (4 score bytes per lane + neighbours)
+  int count = 0;   // candidates emitted so far (wave-uniform)
+  int my_rs = 0;   // lane l keeps rowstart[l]
+  for (; sy <= ye; sy++) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) W[i] = W[i + 1];
+    W[6] = next;
+    next = load_row(sy + 4);  // prefetch the next iteration's new row
+    // ---- scores of row sy ----
+    uint32_t S = 0;
+    const bool row_ok = sy >= 3 && sy < L.h - 3;  // wave-uniform
+    if (row_ok && __any(smask != 0 && maybe_corner(W, t))) {
+      S = score_pair<0>(W, t, nms) | (score_pair<2>(W, t, nms) << 16);
+      S &= smask;
     }
-  }
-  int total_kp;
-  int pos = block_excl_scan_256(count, misc, &total_kp);
-  const int strip_local = (int)blockIdx.x - L.strip0;
-  uint32_t* seg = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)strip_local * L.seg_cap;
-  if (count) {
-    int r = r_beg, c = c_beg;
-    for (int i = beg; i < end; i++) {
-      const int s = is_kp(r, c);
-      if (s >= 0) {
-        if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(L.x_lo + c, ys + r, s);
-        ++pos;
+    Row3 S_dn;
+    S_dn.d = S;
+    S_dn.p = wave_shr1(S);
+    S_dn.n = wave_shl1(S);
+    // ---- NMS + emission of row sy-1 ----
+    const int y = sy - 1;
+    if (y >= ys && y < ye) {
+      if (__any((S_mid.d & emask) != 0)) {
+        const bool k0 = (emask & 0xFFu) && nms_keep<0>(S_up, S_mid, S_dn, nms);
+        const bool k1 = (emask & 0xFF00u) && nms_keep<1>(S_up, S_mid, S_dn, nms);
+        const bool k2 = (emask & 0xFF0000u) && nms_keep<2>(S_up, S_mid, S_dn, nms);
+        const bool k3 = (emask & 0xFF000000u) && nms_keep<3>(S_up, S_mid, S_dn, nms);
+        const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int pos = count + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+        const uint32_t sc = nms ? S_mid.d : 0u;
+        if (k0) {
+          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 0, y, sc & 255u);
+          ++pos;
+        }
+        if (k1) {
+          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 1, y, (sc >> 8) & 255u);
+          ++pos;
+        }
+        if (k2) {
+          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 2, y, (sc >> 16) & 255u);
+          ++pos;
+        }
+        if (k3) {
+          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 3, y, sc >> 24);
+        }
+        count += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
       }
-      if (++c == vw) c = 0, ++r;
+      if (lane > y - ys) my_rs = min(count, L.seg_cap);
     }
+    S_up = S_mid;
+    S_mid = S_dn;
   }
-  if (tid == 0) a.strip_count[(size_t)image * a.nstrips + blockIdx.x] = min(total_kp, L.seg_cap);
+  if (lane <= SR) rs[lane] = (uint16_t)my_rs;
 }
 
-// Standalone FAST detect: candidate segments -> contiguous cv::KeyPoint list (raster order).
+// Standalone FAST detect: unit segments -> contiguous cv::KeyPoint list in raster order.
 __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restrict__ levels,
                                                         const uint32_t* __restrict__ cand, uint32_t cand_entries,
-                                                        const int32_t* __restrict__ strip_count, int nstrips,
+                                                        const uint16_t* __restrict__ rowstart, int nunits,
                                                         int max_keypoints, vsf_keypoint* __restrict__ out,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ status) {
-  __shared__ int lds4[8];
-  __shared__ int s_base;
+  __shared__ int cellpre[2048 + 8];
+  __shared__ int lds4[4];
   const int image = blockIdx.x;
   const VsfLevel L = levels[0];
-  const int32_t* sc = strip_count + (size_t)image * nstrips;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for (int s0 = 0; s0 < L.nstrips; s0 += 256) {
-    const int s = s0 + threadIdx.x;
-    const int n = s < L.nstrips ? sc[L.strip0 + s] : 0;
-    int tot;
-    const int off = block_excl_scan_256(n, lds4, &tot) + s_base;
-    if (s < L.nstrips) {
-      const uint32_t* seg = cand + (size_t)image * cand_entries + L.cand_offset + (size_t)s * L.seg_cap;
-      for (int i = 0; i < n; i++) {
-        const int o = off + i;
-        if (o < max_keypoints) {
-          const uint32_t cd = seg[i];
-          vsf_keypoint kp;
-          kp.x = (float)VSF_CAND_X(cd);
-          kp.y = (float)VSF_CAND_Y(cd);
-          kp.size = 7.f;
-          kp.angle = -1.f;
-          kp.response = (float)VSF_CAND_SCORE(cd);
-          kp.octave = 0;
-          kp.class_id = -1;
-          out[(size_t)image * max_keypoints + o] = kp;
-        }
-      }
+  const uint16_t* rs_img = rowstart + (size_t)image * nunits * VSF_FAST_RS_STRIDE;
+  const uint32_t* cand_img = cand + (size_t)image * cand_entries;
+  const int n = vsf_level_candidate_count(L, rs_img, lds4);
+  vsf_keypoint* o = out + (size_t)image * max_keypoints;
+  vsf_gather_level(L, cand_img, rs_img, cellpre, 2048, lds4, [&](int dst, uint32_t cd) {
+    if (dst < max_keypoints) {
+      vsf_keypoint kp;
+      kp.x = (float)VSF_CAND_X(cd);
+      kp.y = (float)VSF_CAND_Y(cd);
+      kp.size = 7.f;
+      kp.angle = -1.f;
+      kp.response = (float)VSF_CAND_SCORE(cd);
+      kp.octave = 0;
+      kp.class_id = -1;
+      o[dst] = kp;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) s_base += tot;
-    __syncthreads();
-  }
+  });
   if (threadIdx.x == 0) {
-    counts[image] = s_base;  // true count; the caller clamps to its capacity
-    if (s_base > max_keypoints) atomicOr(status, 1);
+    counts[image] = n;  // true count; the caller clamps to its capacity
+    if (n > max_keypoints) atomicOr(status, 1);
   }
 }
 
 }  // namespace
 
-void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, hipStream_t s) {
+void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s) {
   FastArgs a;
   a.levels = d.levels;
-  a.strips = d.strips;
+  a.units = d.units;
+  a.nunits = g.nunits;
   a.img0 = im.base;
   a.img0_stride = im.image_stride;
   a.img0_pitch = (int)im.row_stride;
@@ -293,24 +308,14 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.pyr_bytes = g.pyr_bytes;
   a.cand = d.cand;
   a.cand_entries = g.cand_entries;
-  a.strip_count = d.strip_count;
-  a.nstrips = g.nstrips;
-  a.threshold = threshold & 0xFFFF;
-  a.nms = (threshold >> 16) ? 0 : 1;  // bit 16 of `threshold` disables NMS (standalone FAST only)
-  a.strip_rows = g.strip_rows;
-  a.tile_pitch_max = g.max_tile_pitch;
-  a.score_pitch_max = g.max_score_pitch;
-  const size_t lds = (size_t)(g.strip_rows + 8) * g.max_tile_pitch +
-                     (size_t)(g.strip_rows + 2) * g.max_score_pitch * 3 + 64;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fast_strip_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid(g.nstrips, im.n, 1);
-  hipLaunchKernelGGL(fast_strip_kernel, grid, dim3(VSF_FAST_THREADS), lds, s, a);
+  a.rowstart = d.rowstart;
+  a.threshold = threshold;
+  a.nms = nms;
+  hipLaunchKernelGGL(fast_march_kernel, dim3((g.nunits + 3) / 4, im.n), dim3(256), 0, s, a);
 }
 
 void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int max_keypoints, vsf_keypoint* d_kp,
                           int32_t* d_counts, hipStream_t s) {
-  hipLaunchKernelGGL(fast_emit_kernel, dim3(n_images), dim3(256), 0, s, d.levels, d.cand, g.cand_entries,
-                     d.strip_count, g.nstrips, max_keypoints, d_kp, d_counts, d.status);
+  hipLaunchKernelGGL(fast_emit_kernel, dim3(n_images), dim3(256), 0, s, d.levels, d.cand, g.cand_entries, d.rowstart,
+                     g.nunits, max_keypoints, d_kp, d_counts, d.status);
 }

@@ -19,6 +19,7 @@
 // Pivot choice (median of first+1 / mid / last-1), the depth limit, the heap-select fallback and the final
 // insertion sort are the sequential restatement of vsf_select.h, run by one lane on ranges <= 48 elements.
 // The arrays live in LDS when they fit and in an HBM scratch area otherwise.
+#include "vsf_gather.h"
 #include "vsf_internal.h"
 #include "vsf_select.h"
 
@@ -35,8 +36,8 @@ struct SelectArgs {
   uint32_t pyr_bytes;
   const uint32_t* cand;
   uint32_t cand_entries;
-  const int32_t* strip_count;
-  int nstrips;
+  const uint16_t* rowstart;
+  int nunits;
   uint32_t* scratch;  // [image][3 * cand_entries]
   VsfLevelKp* lvlkp;
   int lvlkp_entries;
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
   __shared__ uint32_t sA[ENTRIES];
   __shared__ uint2 sB[STAGE2];
   __shared__ PassScratch<MAXW> ps;
-  __shared__ int soff[520];
+  constexpr int kCellCap = 1025;
+  __shared__ int cellpre[kCellCap];
+  __shared__ int lds4[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int level = a.level0 + blockIdx.x, image = blockIdx.y;
   const VsfLevel L = a.levels[level];
@@ -374,31 +377,19 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
     pitch = L.pitch;
   }
 
-  // ---- gather: exclusive scan of the strip counts, then a coalesced copy of every segment ----
-  const int32_t* sc = a.strip_count + (size_t)image * a.nstrips + L.strip0;
-  if (tid == 0) {
-    int acc = 0;
-    for (int s = 0; s < L.nstrips; s++) {
-      soff[s] = acc;
-      acc += sc[s];
-    }
-    soff[L.nstrips] = acc;
-  }
-  __syncthreads();
-  const int n = soff[L.nstrips];
+  // ---- gather: merge the FAST units' segments into the level's raster order (vsf_gather.h) ----
+  const uint16_t* rs_img = a.rowstart + (size_t)image * a.nunits * VSF_FAST_RS_STRIDE;
+  const int n = vsf_level_candidate_count(L, rs_img, lds4);
   uint32_t* gscratch = a.scratch + (size_t)image * 3 * a.cand_entries;
   uint32_t* gA = gscratch + L.cand_offset;
   uint2* gB = reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
   const bool a_in_lds = n <= ENTRIES;
-  const uint32_t* segs = a.cand + (size_t)image * a.cand_entries + L.cand_offset;
-  for (int s = 0; s < L.nstrips; s++) {
-    const int cnt = soff[s + 1] - soff[s];
-    const uint32_t* seg = segs + (size_t)s * L.seg_cap;
-    if (a_in_lds) {
-      for (int i = tid; i < cnt; i += kThreads) sA[soff[s] + i] = seg[i];
-    } else {
-      for (int i = tid; i < cnt; i += kThreads) gA[soff[s] + i] = seg[i];
-    }
+  {
+    const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
+    if (a_in_lds)
+      vsf_gather_level(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { sA[dst] = cd; });
+    else
+      vsf_gather_level(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { gA[dst] = cd; });
   }
   __syncthreads();
 
@@ -513,8 +504,8 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   a.pyr_bytes = g.pyr_bytes;
   a.cand = d.cand;
   a.cand_entries = g.cand_entries;
-  a.strip_count = d.strip_count;
-  a.nstrips = g.nstrips;
+  a.rowstart = d.rowstart;
+  a.nunits = g.nunits;
   a.scratch = d.scratch;
   a.lvlkp = d.lvlkp;
   a.lvlkp_entries = g.lvlkp_entries;

@@ -33,10 +33,9 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 struct Geometry {
   VsfGeom g{};
   std::vector<VsfLevel> levels;
-  std::vector<uint32_t> strips;
+  std::vector<uint32_t> units;
   std::vector<VsfTap> xt, yt;
   std::vector<uint32_t> blur_tiles;
-  size_t fast_lds = 0;
 };
 
 // cv::resize(INTER_LINEAR, 8u) coefficient tables for one level (source sw x sh -> dw x dh).
@@ -132,47 +131,36 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
       L.y_lo = border;
       L.y_hi = L.h - border;
     }
-    L.ncols = std::max(L.x_hi - L.x_lo + 2, 1);
-    L.ncols_magic = (uint32_t)((1ull << 32) / (uint32_t)L.ncols + 1);
     L.blur_vec_end = p.blur_sse2 ? (L.w - L.w % 4) : 0;
   }
   G.g.pyr_bytes = offset;
   G.g.pyramid_pixels = pixels;
-  // FAST strips: full-width bands of strip_rows rows
-  int max_tp = 16, max_sp = 16;
-  for (const VsfLevel& L : G.levels) {
-    const int cx0 = std::max(L.x_lo - 4, 0) & ~15;
-    max_tp = std::max(max_tp, align_up(L.x_hi + 4, 16) - cx0);
-    max_sp = std::max(max_sp, align_up(L.ncols, 16));
-  }
-  G.g.max_tile_pitch = max_tp;
-  G.g.max_score_pitch = max_sp;
-  int SR = 16;
-  auto lds_need = [&](int sr) { return (size_t)(sr + 8) * max_tp + (size_t)(sr + 2) * max_sp * 3 + 64; };
-  if (lds_need(SR) > 64 * 1024) SR = 8;
-  if (lds_need(SR) > 160 * 1024 - 1024) return false;
-  G.g.strip_rows = SR;
-  G.fast_lds = lds_need(SR);
+  // FAST units: (240-column band) x (32-row strip) of the keypoint rectangle, one wave each (k_fast.hip)
   uint32_t cand = 0;
   int kp_off = 0;
   for (int l = 0; l < nlevels; l++) {
     VsfLevel& L = G.levels[l];
-    L.strip0 = (int)G.strips.size();
-    for (int y = L.y_lo; y < L.y_hi; y += SR) G.strips.push_back(((uint32_t)l << 16) | (uint32_t)y);
-    L.nstrips = (int)G.strips.size() - L.strip0;
-    if (L.nstrips > 512) return false;
-    const int vw = L.x_hi - L.x_lo;
-    L.seg_cap = nms ? ((vw + 1) / 2) * ((SR + 1) / 2) : vw * SR;
+    const int vw = L.x_hi - L.x_lo, vh = L.y_hi - L.y_lo;
+    L.fast_a0 = L.x_lo & ~3;
+    L.nbands = vw > 0 ? (L.x_hi - L.fast_a0 + VSF_FAST_BAND_COLS - 1) / VSF_FAST_BAND_COLS : 0;
+    L.nstrips = vh > 0 && vw > 0 ? (vh + VSF_FAST_STRIP_ROWS - 1) / VSF_FAST_STRIP_ROWS : 0;
+    if (L.nbands > 255 || L.nstrips > 65535) return false;
+    L.unit0 = (int)G.units.size();
+    for (int s = 0; s < L.nstrips; s++)
+      for (int b = 0; b < L.nbands; b++) G.units.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)s);
+    // Strict 8-neighbour NMS leaves at most one keypoint per 2x2 block, so a segment of that size cannot overflow.
+    const int bw = std::min(VSF_FAST_BAND_COLS, std::max(vw, 1)), bh = std::min(VSF_FAST_STRIP_ROWS, std::max(vh, 1));
+    L.seg_cap = nms ? ((bw + 1) / 2) * ((bh + 1) / 2) : bw * bh;
     L.seg_cap = std::max(L.seg_cap, 1);
     L.cand_offset = cand;
-    cand += (uint32_t)L.seg_cap * (uint32_t)L.nstrips;
+    cand += (uint32_t)L.seg_cap * (uint32_t)(L.nstrips * L.nbands);
     L.kp_offset = kp_off;
     L.kp_cap = 2 * L.nfeatures + 64;
     kp_off += L.kp_cap;
   }
   G.g.cand_entries = std::max(cand, 1u);
-  G.g.nstrips = std::max((int)G.strips.size(), 1);
-  if (G.strips.empty()) G.strips.push_back(0);
+  G.g.nunits = (int)G.units.size();
+  if (G.units.empty()) G.units.push_back(0);
   G.g.lvlkp_entries = std::max(kp_off, 1);
   // resize tables + blur tiles (ORB only)
   if (orb) {
@@ -224,7 +212,7 @@ void gaussian_taps(int k[4]) {
 struct DevSet {  // device copies of one Geometry + its work buffers
   VsfDev d{};
   VsfLevel* levels = nullptr;
-  uint32_t* strips = nullptr;
+  uint32_t* units = nullptr;
   VsfTap* xt = nullptr;
   VsfTap* yt = nullptr;
   uint32_t* blur_tiles = nullptr;
@@ -291,13 +279,13 @@ hipError_t upload(T** dst, const std::vector<T>& v) {
 
 vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, int n_images) {
   VSF_HIP(upload(&ds->levels, G.levels));
-  VSF_HIP(upload(&ds->strips, G.strips));
+  VSF_HIP(upload(&ds->units, G.units));
   VSF_HIP(upload(&ds->xt, G.xt));
   VSF_HIP(upload(&ds->yt, G.yt));
   VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
   VsfDev& d = ds->d;
   d.levels = ds->levels;
-  d.strips = ds->strips;
+  d.units = ds->units;
   d.xtaps = ds->xt;
   d.ytaps = ds->yt;
   const size_t n = (size_t)n_images;
@@ -310,8 +298,9 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
     VSF_HIP(hipMemset(d.lvl_count, 0, n * G.g.nlevels * sizeof(int32_t)));
   }
   VSF_HIP(hipMalloc((void**)&d.cand, n * G.g.cand_entries * sizeof(uint32_t)));
-  VSF_HIP(hipMalloc((void**)&d.strip_count, n * G.g.nstrips * sizeof(int32_t)));
-  VSF_HIP(hipMemset(d.strip_count, 0, n * G.g.nstrips * sizeof(int32_t)));
+  const size_t rs_bytes = n * (size_t)std::max(G.g.nunits, 1) * VSF_FAST_RS_STRIDE * sizeof(uint16_t);
+  VSF_HIP(hipMalloc((void**)&d.rowstart, rs_bytes));
+  VSF_HIP(hipMemset(d.rowstart, 0, rs_bytes));
   d.status = ctx->d_status;
   ds->ready = true;
   return VSF_OK;
@@ -319,7 +308,7 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
 
 void free_devset(DevSet* ds) {
   hipFree(ds->levels);
-  hipFree(ds->strips);
+  hipFree(ds->units);
   hipFree(ds->xt);
   hipFree(ds->yt);
   hipFree(ds->blur_tiles);
@@ -329,7 +318,7 @@ void free_devset(DevSet* ds) {
   hipFree(ds->d.lvlkp);
   hipFree(ds->d.lvl_count);
   hipFree(ds->d.cand);
-  hipFree(ds->d.strip_count);
+  hipFree(ds->d.rowstart);
   *ds = DevSet();
 }
 
@@ -426,7 +415,7 @@ vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, 
   }
   {
     StageTimer t(ctx, VSF_STAGE_FAST, 1);
-    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, ctx->stream);
+    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, ctx->stream);
   }
   {
     StageTimer t(ctx, VSF_STAGE_SELECT, 1);
@@ -753,7 +742,7 @@ vsf_status vsf_fast_detect(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_
   VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 1};
   // Output capacity: grow a private buffer if the caller's cap exceeds the extract staging.
   const int kcap = ctx->p.max_keypoints;
-  vsf_launch_fast(ctx->dfast.d, ctx->fast.g, im, threshold | (want_nms ? 0 : (1 << 16)), ctx->stream);
+  vsf_launch_fast(ctx->dfast.d, ctx->fast.g, im, threshold, want_nms ? 1 : 0, ctx->stream);
   vsf_keypoint* d_out = ctx->st_kp;
   vsf_keypoint* big = nullptr;
   int outcap = kcap;
@@ -898,21 +887,28 @@ vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_key
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   const VsfLevel& L = ctx->orb.levels[level];
   const VsfGeom& g = ctx->orb.g;
-  std::vector<int32_t> sc(std::max(L.nstrips, 1));
-  if (L.nstrips)
-    VSF_HIP(hipMemcpy(sc.data(), ctx->dorb.d.strip_count + (size_t)image * g.nstrips + L.strip0,
-                      (size_t)L.nstrips * sizeof(int32_t), hipMemcpyDeviceToHost));
+  // Merge the unit segments (unit-local raster order + per-row starts) into the level's raster order.
+  const int nu = L.nstrips * L.nbands;
   int n = 0;
-  std::vector<uint32_t> seg(L.seg_cap);
-  for (int s = 0; s < L.nstrips; s++) {
-    if (sc[s] <= 0) continue;
-    VSF_HIP(hipMemcpy(seg.data(),
-                      ctx->dorb.d.cand + (size_t)image * g.cand_entries + L.cand_offset + (size_t)s * L.seg_cap,
-                      (size_t)sc[s] * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (int i = 0; i < sc[s]; i++, n++) {
-      if (n < cap && kp_out) {
-        const uint32_t cd = seg[i];
-        kp_out[n] = vsf_keypoint{(float)VSF_CAND_X(cd), (float)VSF_CAND_Y(cd), 7.f, -1.f, (float)VSF_CAND_SCORE(cd), 0, -1};
+  if (nu > 0) {
+    std::vector<uint16_t> rs((size_t)nu * VSF_FAST_RS_STRIDE);
+    VSF_HIP(hipMemcpy(rs.data(), ctx->dorb.d.rowstart + ((size_t)image * g.nunits + L.unit0) * VSF_FAST_RS_STRIDE,
+                      rs.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> seg((size_t)nu * L.seg_cap);
+    VSF_HIP(hipMemcpy(seg.data(), ctx->dorb.d.cand + (size_t)image * g.cand_entries + L.cand_offset,
+                      seg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int row = 0; row < L.y_hi - L.y_lo; row++) {
+      const int s = row / VSF_FAST_STRIP_ROWS, r = row % VSF_FAST_STRIP_ROWS;
+      for (int b = 0; b < L.nbands; b++) {
+        const int u = s * L.nbands + b;
+        const uint16_t* urs = rs.data() + (size_t)u * VSF_FAST_RS_STRIDE;
+        for (int e = urs[r]; e < urs[r + 1]; e++, n++) {
+          if (n < cap && kp_out) {
+            const uint32_t cd = seg[(size_t)u * L.seg_cap + e];
+            kp_out[n] =
+                vsf_keypoint{(float)VSF_CAND_X(cd), (float)VSF_CAND_Y(cd), 7.f, -1.f, (float)VSF_CAND_SCORE(cd), 0, -1};
+          }
+        }
       }
     }
   }

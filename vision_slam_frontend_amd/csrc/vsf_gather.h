@@ -1,0 +1,99 @@
+// vsf_gather.h -- device helpers shared by k_fast.hip and k_select.hip: block scan and the merge of the FAST march
+// kernel's per-unit candidate segments into ONE raster-ordered list per (image, level).
+//
+// cv::FAST emits keypoints in raster order (y, then x) and everything downstream (retainBest's permutation)
+// depends on that order.  The march kernel works on units = (240-column band) x (32-row strip); a unit's segment
+// is in raster order inside the unit and carries the start offset of each of its rows (rowstart[0..32]).  The global
+// order interleaves the bands row by row, so the destination of a segment element is
+//   prefix[cell(row, band)] + (index inside its row),   cell order = row-major, band-minor,
+// with the prefix obtained by a block-wide exclusive scan over the cell counts.
+#ifndef VSF_GATHER_H_
+#define VSF_GATHER_H_
+
+#include "vsf_internal.h"
+
+// Block-wide exclusive scan over 256 threads (4 waves of 64). lds4 needs 4 ints.
+__device__ __forceinline__ int vsf_block_excl_scan_256(int v, int* lds4, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds4[wid] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wid; w++) base += lds4[w];
+  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+// Number of candidates of level L of one image (all 256 threads call; same value returned to all).
+__device__ __forceinline__ int vsf_level_candidate_count(const VsfLevel& L, const uint16_t* __restrict__ rs_img,
+                                                         int* lds4) {
+  const int nu = L.nbands * L.nstrips;
+  int s = 0;
+  for (int u = threadIdx.x; u < nu; u += 256)
+    s += rs_img[(size_t)(L.unit0 + u) * VSF_FAST_RS_STRIDE + VSF_FAST_STRIP_ROWS];
+  int total;
+  vsf_block_excl_scan_256(s, lds4, &total);
+  return total;
+}
+
+// Merges the level's unit segments into raster order; store(dst_index, entry) receives every candidate once.
+// cellpre: LDS int array with cellcap >= VSF_FAST_STRIP_ROWS * nbands + 1 entries.  All 256 threads call.
+template <class Store>
+__device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32_t* __restrict__ cand_img,
+                                                 const uint16_t* __restrict__ rs_img, int* cellpre, int cellcap,
+                                                 int* lds4, Store store) {
+  constexpr int SR = VSF_FAST_STRIP_ROWS;
+  const int tid = threadIdx.x;
+  const int nrows = L.y_hi - L.y_lo, nb = L.nbands;
+  if (nrows <= 0 || nb <= 0) return;
+  int rows_per_chunk = ((cellcap - 1) / nb) / SR * SR;
+  if (rows_per_chunk < SR) rows_per_chunk = SR;
+  int base = 0;
+  for (int row0 = 0; row0 < nrows; row0 += rows_per_chunk) {
+    const int nr = min(rows_per_chunk, nrows - row0);
+    const int nc = nr * nb;
+    const int cpt = (nc + 255) / 256;
+    const int c_beg = min(tid * cpt, nc), c_end = min(c_beg + cpt, nc);
+    int local = 0;
+    {
+      int row = row0 + c_beg / nb, b = c_beg % nb;
+      for (int c = c_beg; c < c_end; c++) {
+        const int s = row / SR, r = row - s * SR;
+        const uint16_t* rs = rs_img + (size_t)(L.unit0 + s * nb + b) * VSF_FAST_RS_STRIDE;
+        cellpre[c] = local;
+        local += (int)rs[r + 1] - (int)rs[r];
+        if (++b == nb) b = 0, ++row;
+      }
+    }
+    int total;
+    const int excl = vsf_block_excl_scan_256(local, lds4, &total);
+    for (int c = c_beg; c < c_end; c++) cellpre[c] += excl;
+    __syncthreads();
+    const int s0 = row0 / SR, s1 = (row0 + nr + SR - 1) / SR;
+    for (int s = s0; s < s1; s++) {
+      for (int b = 0; b < nb; b++) {
+        const int u = s * nb + b;
+        const uint16_t* rs = rs_img + (size_t)(L.unit0 + u) * VSF_FAST_RS_STRIDE;
+        const int tot = rs[SR];
+        const uint32_t* seg = cand_img + L.cand_offset + (size_t)u * L.seg_cap;
+        for (int e = tid; e < tot; e += 256) {
+          const uint32_t entry = seg[e];
+          const int row = VSF_CAND_Y(entry) - L.y_lo;
+          const int r = row - s * SR;
+          const int c = (row - row0) * nb + b;
+          store(base + cellpre[c] + (e - (int)rs[r]), entry);
+        }
+      }
+    }
+    base += total;
+    __syncthreads();
+  }
+}
+
+#endif  // VSF_GATHER_H_

@@ -7,6 +7,15 @@
 
 #include "../../include/vsf.h"
 
+// FAST march kernel: a wave owns a band of 240 keypoint columns (lanes 2..61 x 4 px; lanes 1 and 62 add one
+// scored column block each side for the NMS, lanes 0 and 63 carry raw halo pixels) x a strip of 32 rows.
+#define VSF_FAST_BAND_COLS 240
+#define VSF_FAST_STRIP_ROWS 32
+#define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
+#define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
+#define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
+#define VSF_SELECT_THREADS 256
+
 // ---- pyramid level descriptor (device-resident table, read through scalar loads) ----
 struct VsfLevel {
   int32_t w, h;            // level size (cv::ORB layer size)
@@ -16,16 +25,16 @@ struct VsfLevel {
   int32_t nfeatures;       // per-level budget n_l
   int32_t x_lo, x_hi;      // keypoints may sit at x_lo <= x < x_hi  (runByImageBorder / FAST rim)
   int32_t y_lo, y_hi;
-  int32_t strip0, nstrips; // this level's strips in the strip table
+  int32_t fast_a0;         // x_lo rounded down to a multiple of 4: column origin of band 0
+  int32_t nbands, nstrips; // FAST units of this level: unit = strip * nbands + band
+  int32_t unit0;           // index of this level's first unit (per image)
   uint32_t cand_offset;    // u32 index of this level's first candidate segment (per image)
-  int32_t seg_cap;         // capacity of one strip's candidate segment
+  int32_t seg_cap;         // capacity of one unit's candidate segment
   int32_t kp_offset;       // index of this level's final-keypoint segment (per image)
   int32_t kp_cap;          // its capacity
   int32_t blur_vec_end;    // columns [0, blur_vec_end) round half-even (SSE2 path), the rest half-up
   uint32_t xtab, ytab;     // entry offsets of this level's resize tables (level >= 1)
-  int32_t ncols;           // x_hi - x_lo + 2: width of the FAST score region
-  uint32_t ncols_magic;    // floor(2^32 / ncols) + 1: idx / ncols == umulhi(idx, magic) for idx < 2^16
-  int32_t pad0, pad1;
+  int32_t pad0;
 };
 
 // Resize coefficient table entry (cv::resize INTER_LINEAR 8u: xofs/ialpha resp. yofs/ibeta with the
@@ -48,37 +57,27 @@ struct VsfLevelKp {
   float angle;
 };
 
-#define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
-#define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
-#define VSF_FAST_THREADS 256
-#define VSF_SELECT_THREADS 256
-#define VSF_SELECT_LDS_ENTRIES 16384  // stage-1 array (u32) kept in LDS when the candidate count fits
-#define VSF_SELECT_LDS_STAGE2 2048    // stage-2 (response, xy) pairs kept in LDS when they fit
-
 struct VsfGeom {
   int nlevels;
   int width, height;
   uint32_t pyr_bytes;       // one image's pyramid block
   uint32_t cand_entries;    // one image's candidate buffer (u32 entries)
-  int nstrips;              // strips per image
+  int nunits;               // FAST units per image
   int lvlkp_entries;        // one image's level-keypoint buffer (VsfLevelKp entries)
-  int max_tile_pitch;       // widest FAST LDS image tile row
-  int max_score_pitch;
-  int strip_rows;           // rows per FAST strip (16, or 8 when the LDS tile of a wide image would not fit)
   uint64_t pyramid_pixels;
 };
 
 // Kernel launchers (implemented in the k_*.hip files). All asynchronous on `s`.
 struct VsfDev {
   const VsfLevel* levels;   // [nlevels]
-  const uint32_t* strips;   // [nstrips]: level << 16 | y0
+  const uint32_t* units;    // [nunits]: level << 24 | band << 16 | strip
   const VsfTap* xtaps;      // resize tables
   const VsfTap* ytaps;
   uint8_t* pyr;             // [max_images][pyr_bytes]   unblurred levels 1..L-1 (level 0 is the input)
   uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
-  uint32_t* cand;           // [max_images][cand_entries]
-  int32_t* strip_count;     // [max_images][nstrips]
-  uint32_t* scratch;        // [max_images][cand_entries]   selection fallback when LDS is too small
+  uint32_t* cand;           // [max_images][cand_entries]  per-unit candidate segments (unit-local raster order)
+  uint16_t* rowstart;       // [max_images][nunits][VSF_FAST_RS_STRIDE]  start of each row inside its segment
+  uint32_t* scratch;        // [max_images][3 * cand_entries]   selection arrays when LDS is too small
   VsfLevelKp* lvlkp;        // [max_images][lvlkp_entries]
   int32_t* lvl_count;       // [max_images][nlevels]
   int32_t* status;          // device status word (bit 0: capacity overflow)
@@ -93,7 +92,8 @@ struct VsfImages {
 
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                         hipStream_t s);
-void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, hipStream_t s);
+// threshold: FAST threshold; nms == 0 keeps every corner (standalone FAST only).
+void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s);
 void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                        hipStream_t s);
 void vsf_launch_retain_best_test(uint2* d_data, int n, int n_points, int use_lds, int mode, int* d_out_n,
