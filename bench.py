@@ -53,7 +53,7 @@ def cpu_baseline(width, height, nfeatures, seed):
     ob.build()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))
-    n = 2 * cores
+    n = 6 * cores  # ~20 s of CPU work (about 0.2 s per stereo frame and thread)
     frames = synth.bench_batch(n, width, height, seed=seed, n_scenes=min(4, n))
 
     def one(i):
