@@ -1,12 +1,18 @@
-// k_describe.hip -- K8: computeOrbDescriptors (WTA_K = 2, 256-bit rotated BRIEF) and assembly of the final
-// cv::KeyPoint / descriptor arrays (features2d/orb.cpp; reached from slam_frontend.cc:274).
+// k_describe.hip -- K6 + K8 and assembly of the final cv::KeyPoint / descriptor arrays (features2d/orb.cpp,
+// reached from slam_frontend.cc:274), ONE WAVE PER KEYPOINT:
 //
-// One workgroup per (image, level); its four waves walk the level's keypoints, one wave per keypoint.
-// Lane l evaluates pattern pairs l, l+64, l+128, l+192, so each 64-lane ballot IS eight consecutive
-// descriptor bytes (bit i of byte k = pair 8k+i, LSB first, exactly OpenCV's packing) -- no shuffles, no LDS.
-// Per sample: x = px*a - py*b, y = px*b + py*a as separately rounded float ops (no FMA), cvRound
-// (round-half-even), one byte load from the blurred level (L2-resident 39x39 neighbourhood).
-// The level's slot in the image's level-major output is the sum of the preceding levels' counts.
+//   K6  ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (749 px, rows |v| <= 15 with half-width
+//       umax[|v|]) of the UNBLURRED level, angle = fastAtan2(m01, m10).  The disc is cut into 31 rows x 9 aligned
+//       dwords = 279 (row, dword) items, 5 per lane; an item's four byte weights come from a table indexed by the
+//       byte phase of x0 - 15 (built on the host: vsf_api.hip build_ic_table), so one item costs one 4-byte pixel
+//       load, one 8-byte table load and two v_dot4_u32_u8 (sum (u+16)*I and sum I over the in-disc bytes).  Integer
+//       sums are order-free, so the wave reduction gives exactly OpenCV's m10 / m01.
+//   K8  computeOrbDescriptors (WTA_K = 2, 256-bit rotated BRIEF) on the BLURRED level: lane l evaluates pattern
+//       pairs l, l+64, l+128, l+192, so each 64-lane ballot IS eight consecutive descriptor bytes (bit i of byte k
+//       = pair 8k+i, LSB first, exactly OpenCV's packing).  Per sample: x = px*a - py*b, y = px*b + py*a as
+//       separately rounded float ops (no FMA), cvRound (round-half-even), one byte load.
+// A level's keypoints are dealt round-robin to kSplit workgroups x 4 waves; the level's slot in the image's
+// level-major output is the sum of the preceding levels' counts.
 #include "vsf_internal.h"
 
 #pragma clang fp contract(off)
@@ -17,11 +23,18 @@ __constant__ int8_t c_pattern31[256 * 4] = {
 #include "orb_pattern31.inc"
 };
 
+constexpr int kSplit = 4;  // workgroups per (image, level)
+
 struct DescribeArgs {
   const VsfLevel* levels;
+  const uint8_t* img0;  // unblurred level 0 = the caller's images
+  size_t img0_stride;
+  int img0_pitch;
+  const uint8_t* pyr;   // unblurred levels >= 1
   const uint8_t* blur;
   uint32_t pyr_bytes;
-  const VsfLevelKp* lvlkp;
+  const uint2* ic_table;  // [4][VSF_IC_ITEMS]: .x = (u + 16) byte weights, .y = 0/1 byte mask
+  VsfLevelKp* lvlkp;
   int lvlkp_entries;
   const int32_t* lvl_count;
   int nlevels;
@@ -32,8 +45,31 @@ struct DescribeArgs {
   int32_t* status;
 };
 
+// cv::fastAtan2 (core/mathfuncs.cpp), degrees.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
 __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
-  const int level = blockIdx.x, image = blockIdx.y;
+  const int level = blockIdx.x / kSplit, part = blockIdx.x - level * kSplit, image = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int32_t* lc = a.lvl_count + (size_t)image * a.nlevels;
   // base = sum of counts of the levels before this one; total = all levels (wave-parallel, nlevels <= 64)
@@ -44,7 +80,7 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
     before += __shfl_xor(before, o, 64);
     total += __shfl_xor(total, o, 64);
   }
-  if (level == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.counts[image] = total;
     if (total > a.max_keypoints) atomicOr(a.status, 1);
   }
@@ -52,16 +88,57 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
   const int n = lc[level];
   const uint8_t* img = a.blur + (size_t)image * a.pyr_bytes + L.offset;
   const int pitch = L.pitch;
-  const VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
+  const uint8_t* raw;
+  int rpitch;
+  if (level == 0) {
+    raw = a.img0 + (size_t)image * a.img0_stride;
+    rpitch = a.img0_pitch;
+  } else {
+    raw = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
+    rpitch = L.pitch;
+  }
+  VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
   const float lscale = L.scale;
   const float inv = 1.f / lscale;
-  for (int i = wid; i < n; i += 4) {
+  // this lane's five disc items: row index (0..30 <-> v = -15..15) and dword index (0..8); items >= 279 carry
+  // zero weights and are pointed at row 30 so that they stay inside the image
+  int item_off[5], item_v[5];
+#pragma unroll
+  for (int it = 0; it < 5; it++) {
+    const int item = it * 64 + lane;
+    const int r = min(item / 9, 30), j = item - (item / 9) * 9;
+    item_off[it] = r * rpitch + 4 * j;
+    item_v[it] = r - 15;
+  }
+  for (int i = part * 4 + wid; i < n; i += 4 * kSplit) {
     const int o = before + i;
     if (o >= a.max_keypoints) break;
     const VsfLevelKp k = kps[i];
-    const float fx = (float)(int)(k.xy & 0xFFFu) * lscale;  // KeyPoint::pt *= scale
-    const float fy = (float)(int)(k.xy >> 12) * lscale;
-    float angle = k.angle;
+    const int x0 = (int)(k.xy & 0xFFFu), y0 = (int)(k.xy >> 12);
+    // ---- K6: intensity-centroid angle on the unblurred level ----
+    const int xs = x0 - 15;
+    const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
+    const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS + lane;
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+      const uint32_t px = *reinterpret_cast<const uint32_t*>(abase + item_off[it]);
+      const uint2 t = tab[it * 64];
+      const int sw = (int)__builtin_amdgcn_udot4(px, t.x, 0u, false);
+      const int sm = (int)__builtin_amdgcn_udot4(px, t.y, 0u, false);
+      m10 += sw - 16 * sm;
+      m01 += item_v[it] * sm;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      m10 += __shfl_xor(m10, off, 64);
+      m01 += __shfl_xor(m01, off, 64);
+    }
+    const float kp_angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- K8: rotated BRIEF on the blurred level ----
+    const float fx = (float)x0 * lscale;  // KeyPoint::pt *= scale
+    const float fy = (float)y0 * lscale;
+    float angle = kp_angle;
     angle *= (float)(3.14159265358979323846 / 180.f);
     // cos/sin of the float angle taken as the correctly rounded float (double evaluation).
     const float ca = (float)cos((double)angle), sb = (float)sin((double)angle);
@@ -71,10 +148,10 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int pair = lane + 64 * j;
-      const float x0 = (float)c_pattern31[4 * pair + 0], y0 = (float)c_pattern31[4 * pair + 1];
-      const float x1 = (float)c_pattern31[4 * pair + 2], y1 = (float)c_pattern31[4 * pair + 3];
-      const int ix0 = __float2int_rn(x0 * ca - y0 * sb), iy0 = __float2int_rn(x0 * sb + y0 * ca);
-      const int ix1 = __float2int_rn(x1 * ca - y1 * sb), iy1 = __float2int_rn(x1 * sb + y1 * ca);
+      const float x0f = (float)c_pattern31[4 * pair + 0], y0f = (float)c_pattern31[4 * pair + 1];
+      const float x1f = (float)c_pattern31[4 * pair + 2], y1f = (float)c_pattern31[4 * pair + 3];
+      const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
+      const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
       const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
       w[j] = __ballot(t0 < t1);
     }
@@ -87,12 +164,13 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
       kp.x = fx;
       kp.y = fy;
       kp.size = 31 * lscale;
-      kp.angle = k.angle;
+      kp.angle = kp_angle;
       kp.response = k.response;
       kp.octave = level;
       kp.class_id = -1;
       a.kp_out[(size_t)image * a.max_keypoints + o] = kp;
     }
+    if (lane == 5) kps[i].angle = kp_angle;  // kept for vsf_debug_level_keypoints
   }
 }
 
@@ -102,6 +180,11 @@ void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
                          vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts, hipStream_t s) {
   DescribeArgs a;
   a.levels = d.levels;
+  a.img0 = im.base;
+  a.img0_stride = im.image_stride;
+  a.img0_pitch = (int)im.row_stride;
+  a.pyr = d.pyr;
+  a.ic_table = d.ic_table;
   a.blur = d.blur;
   a.pyr_bytes = g.pyr_bytes;
   a.lvlkp = d.lvlkp;
@@ -113,5 +196,5 @@ void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
   a.desc_out = d_desc;
   a.counts = d_counts;
   a.status = d.status;
-  hipLaunchKernelGGL(orb_describe_kernel, dim3(g.nlevels, im.n), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(orb_describe_kernel, dim3(g.nlevels * kSplit, im.n), dim3(256), 0, s, a);
 }

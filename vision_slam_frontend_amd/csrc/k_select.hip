@@ -5,7 +5,7 @@
 //   K3       KeyPointsFilter::retainBest(2 * n_l) on the FAST score           (order-exact)
 //   K4       HarrisResponses(blockSize 7, k 0.04f) for the survivors           (int32 sums, 6 float ops, no FMA)
 //   K5       KeyPointsFilter::retainBest(n_l) on the Harris response          (order-exact)
-//   K6       ICAngles (intensity-centroid moments over the radius-15 disc, one wave per keypoint) + fastAtan2
+//   (K6, ICAngles + fastAtan2, runs per keypoint in k_describe.hip)
 //
 // Order-exact selection.  retainBest leaves libstdc++'s std::nth_element + std::partition
 // permutation, which later stages turn into keypoint indices, so it has to be reproduced exactly.  Both are
@@ -64,7 +64,6 @@ struct RespGe {
   }
 };
 
-constexpr int kThreads = VSF_SELECT_THREADS;
 constexpr int kSerialCutoff = 48;
 
 // LDS scratch of the parallel passes. MAXW mask words cover MAXW * 64 elements.
@@ -74,7 +73,7 @@ struct PassScratch {
   unsigned long long maskR[MAXW];
   int preL[MAXW];
   int preR[MAXW];
-  unsigned long long wsum[8];
+  unsigned long long wsum[16];
   int st[8];  // 0 first, 1 last, 2 depth, 3 K, 4 cut, 5 totalL, 6 totalR
 };
 
@@ -134,12 +133,12 @@ __device__ __forceinline__ int select_rank(const unsigned long long* mask, const
 // left position < right position.  On return (all threads, after a barrier) s.st[3] = K (number of swaps),
 // s.st[5] / s.st[6] = stopper totals, s.st[4] = where a sequential scan would have stopped
 // (__unguarded_partition's return value when at least one stopper of each kind exists).
-template <int MAXW, class T, class FL, class FR>
+template <int NT, int MAXW, class T, class FL, class FR>
 __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>& s) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = hi - lo;
   const int nw = (m + 63) >> 6;
-  for (int base = 0; base < m; base += kThreads) {
+  for (int base = 0; base < m; base += NT) {
     const int i = base + tid;
     bool l = false, r = false;
     if (i < m) {
@@ -155,7 +154,7 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
   }
   __syncthreads();
   // exclusive prefix popcounts, words [t*wpt, (t+1)*wpt) per thread
-  const int wpt = (nw + kThreads - 1) / kThreads;
+  const int wpt = (nw + NT - 1) / NT;
   const int w0 = tid * wpt;
   unsigned long long mine = 0;  // low 32: left count, high 32: right count
   for (int j = 0; j < wpt; j++) {
@@ -172,7 +171,7 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
   __syncthreads();
   unsigned long long base_sum = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < kThreads / 64; w++) {
+  for (int w = 0; w < NT / 64; w++) {
     if (w < wave) base_sum += s.wsum[w];
     total += s.wsum[w];
   }
@@ -189,7 +188,7 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
   __syncthreads();
   // participating left-stoppers swap with their partners
   int nswap = 0;
-  for (int base = 0; base < m; base += kThreads) {
+  for (int base = 0; base < m; base += NT) {
     const int i = base + tid;
     if (i < m) {
       const int w = i >> 6, b = i & 63;
@@ -214,7 +213,7 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
   __syncthreads();
   if (tid == 0) {
     int K = 0;
-    for (int w = 0; w < kThreads / 64; w++) K += (int)s.wsum[w];
+    for (int w = 0; w < NT / 64; w++) K += (int)s.wsum[w];
     s.st[3] = K;
     s.st[5] = totalL;
     s.st[6] = totalR;
@@ -233,7 +232,7 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
 }
 
 // std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
-template <int MAXW, class T, class Greater>
+template <int NT, int MAXW, class T, class Greater>
 __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScratch<MAXW>& s) {
   if (n == 0 || nth == n) return;
   const int tid = threadIdx.x;
@@ -252,7 +251,7 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
     }
     __syncthreads();
     const T pivot = A[first];
-    hoare_pass<MAXW>(
+    hoare_pass<NT, MAXW>(
         A, first + 1, last, [&](const T& x) { return !greater(x, pivot); },
         [&](const T& x) { return !greater(pivot, x); }, s);
     if (tid == 0) {
@@ -270,7 +269,7 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
 }
 
 // std::partition(A + lo, A + hi, pred); returns the split point -- all threads call this.
-template <int MAXW, class T, class Pred>
+template <int NT, int MAXW, class T, class Pred>
 __device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>& s) {
   const int tid = threadIdx.x;
   if (hi - lo <= kSerialCutoff || hi - lo > MAXW * 64) {
@@ -280,7 +279,7 @@ __device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>&
     __syncthreads();
     return r;
   }
-  hoare_pass<MAXW>(
+  hoare_pass<NT, MAXW>(
       A, lo, hi, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, s);
   const int r = lo + s.st[6];
   __syncthreads();
@@ -288,39 +287,16 @@ __device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>&
 }
 
 // cv::KeyPointsFilter::retainBest(A[0..n), n_points); returns the new size -- all threads call this.
-template <int MAXW, class T, class Greater, class GreaterEq>
+template <int NT, int MAXW, class T, class Greater, class GreaterEq>
 __device__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, PassScratch<MAXW>& s) {
   if (n_points >= 0 && n > n_points) {
     if (n_points == 0) return 0;
-    par_nth_element<MAXW>(A, n, n_points, greater, s);
+    par_nth_element<NT, MAXW>(A, n, n_points, greater, s);
     const T ambiguous = A[n_points - 1];
-    return par_partition<MAXW>(
+    return par_partition<NT, MAXW>(
         A, n_points, n, [&](const T& x) { return ge(x, ambiguous); }, s);
   }
   return n;
-}
-
-// cv::fastAtan2 (core/mathfuncs.cpp), degrees.
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
-  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
-  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
-  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
-  const float eps = (float)2.2204460492503131e-16;
-  const float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = ay / (ax + eps);
-    c2 = c * c;
-    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  } else {
-    c = ax / (ay + eps);
-    c2 = c * c;
-    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  }
-  if (x < 0) a = 180.f - a;
-  if (y < 0) a = 360.f - a;
-  return a;
 }
 
 // HarrisResponses for one keypoint at integer (x0, y0).
@@ -348,23 +324,16 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
   return (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
 }
 
-__device__ __forceinline__ int umax31(int v) {
-  // ORB's umax table for patchSize 31 (rows of the radius-15 disc): checked against the formula on the host.
-  const uint64_t lo = 0xDDEEEFFFFull;  // v = 0..8 : 15,15,15,15,14,14,14,13,13 (4 bits each)
-  const uint64_t hi = 0x3689ABCull;    // v = 9..15: 12,11,10,9,8,6,3
-  return v < 9 ? (int)((lo >> (4 * v)) & 15) : (int)((hi >> (4 * (v - 9))) & 15);
-}
-
 // ENTRIES: stage-1 candidates kept in LDS; STAGE2: stage-2 pairs kept in LDS; MAXW: mask words of a parallel pass.
-template <int ENTRIES, int STAGE2, int MAXW>
-__global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
+template <int NT, int ENTRIES, int STAGE2, int MAXW>
+__global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   __shared__ uint32_t sA[ENTRIES];
   __shared__ uint2 sB[STAGE2];
   __shared__ PassScratch<MAXW> ps;
   constexpr int kCellCap = 1025;
   __shared__ int cellpre[kCellCap];
-  __shared__ int lds4[4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ int lds4[16];
+  const int tid = threadIdx.x;
   const int level = a.level0 + blockIdx.x, image = blockIdx.y;
   const VsfLevel L = a.levels[level];
   const uint8_t* img;
@@ -379,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
 
   // ---- gather: merge the FAST units' segments into the level's raster order (vsf_gather.h) ----
   const uint16_t* rs_img = a.rowstart + (size_t)image * a.nunits * VSF_FAST_RS_STRIDE;
-  const int n = vsf_level_candidate_count(L, rs_img, lds4);
+  const int n = vsf_level_candidate_count<NT>(L, rs_img, lds4);
   uint32_t* gscratch = a.scratch + (size_t)image * 3 * a.cand_entries;
   uint32_t* gA = gscratch + L.cand_offset;
   uint2* gB = reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
@@ -387,23 +356,23 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
   {
     const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
     if (a_in_lds)
-      vsf_gather_level(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { sA[dst] = cd; });
+      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { sA[dst] = cd; });
     else
-      vsf_gather_level(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { gA[dst] = cd; });
+      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { gA[dst] = cd; });
   }
   __syncthreads();
 
   // ---- K3: retainBest(2 * n_l) on the FAST score ----
   int m1;
   if (a_in_lds)
-    m1 = par_retain_best<MAXW>(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
+    m1 = par_retain_best<NT, MAXW>(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
   else
-    m1 = par_retain_best<MAXW>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
+    m1 = par_retain_best<NT, MAXW>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
   __syncthreads();
 
   // ---- K4: Harris responses (one lane per keypoint) ----
   const bool b_in_lds = m1 <= STAGE2;
-  for (int i = tid; i < m1; i += kThreads) {
+  for (int i = tid; i < m1; i += NT) {
     const uint32_t cd = a_in_lds ? sA[i] : gA[i];
     const float r = harris_response(img, pitch, VSF_CAND_X(cd), VSF_CAND_Y(cd));
     const uint2 e = make_uint2(__float_as_uint(r), cd & 0xFFFFFFu);
@@ -417,44 +386,21 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
   // ---- K5: retainBest(n_l) on the Harris response ----
   int m2;
   if (b_in_lds)
-    m2 = par_retain_best<MAXW>(sB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
+    m2 = par_retain_best<NT, MAXW>(sB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
   else
-    m2 = par_retain_best<MAXW>(gB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
+    m2 = par_retain_best<NT, MAXW>(gB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
   __syncthreads();
 
-  // ---- K6: IC angle, one wave per keypoint, two disc rows per step (32 lanes each) ----
+  // ---- survivors in retainBest order; K6 (ICAngles) runs in k_describe.hip, one wave per keypoint ----
   VsfLevelKp* out = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
   const int m_out = min(m2, L.kp_cap);
-  for (int i = wid; i < m_out; i += kThreads / 64) {
+  for (int i = tid; i < m_out; i += NT) {
     const uint2 e = b_in_lds ? sB[i] : gB[i];
-    const int x0 = (int)(e.y & 0xFFFu), y0 = (int)(e.y >> 12);
-    const uint8_t* center = img + (size_t)y0 * pitch + x0;
-    const int u = (lane & 31) - 15;
-    int m10 = 0, m01 = 0;
-    for (int v0 = -15; v0 <= 15; v0 += 2) {
-      const int v = v0 + (lane >> 5);
-      const int av = v < 0 ? -v : v;
-      if (v <= 15 && u <= 15) {
-        const int d = umax31(av);
-        if (u >= -d && u <= d) {
-          const int val = center[v * pitch + u];
-          m10 += u * val;
-          m01 += v * val;
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      m10 += __shfl_xor(m10, o, 64);
-      m01 += __shfl_xor(m01, o, 64);
-    }
-    if (lane == 0) {
-      VsfLevelKp kp;
-      kp.xy = e.y;
-      kp.response = __uint_as_float(e.x);
-      kp.angle = fast_atan2_deg((float)m01, (float)m10);
-      out[i] = kp;
-    }
+    VsfLevelKp kp;
+    kp.xy = e.y;
+    kp.response = __uint_as_float(e.x);
+    kp.angle = -1.f;
+    out[i] = kp;
   }
   if (tid == 0) {
     a.lvl_count[(size_t)image * a.nlevels + level] = m_out;
@@ -463,21 +409,21 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(SelectArgs a) {
 }
 
 // Test hook: retainBest on (float key, id) pairs, one workgroup, arrays in HBM or LDS.
-template <int MAXW>
-__global__ __launch_bounds__(kThreads) void retain_best_test_kernel(uint2* data, int n, int n_points, int use_lds,
+template <int NT, int MAXW>
+__global__ __launch_bounds__(NT) void retain_best_test_kernel(uint2* data, int n, int n_points, int use_lds,
                                                                     int mode, int* out_n) {
   __shared__ PassScratch<MAXW> ps;
   __shared__ uint2 buf[4096];
   int m;
   if (mode == 0) {  // float keys
     if (use_lds && n <= 4096) {
-      for (int i = threadIdx.x; i < n; i += kThreads) buf[i] = data[i];
+      for (int i = threadIdx.x; i < n; i += NT) buf[i] = data[i];
       __syncthreads();
-      m = par_retain_best<MAXW>(buf, n, n_points, RespGreater(), RespGe(), ps);
+      m = par_retain_best<NT, MAXW>(buf, n, n_points, RespGreater(), RespGe(), ps);
       __syncthreads();
-      for (int i = threadIdx.x; i < n; i += kThreads) data[i] = buf[i];
+      for (int i = threadIdx.x; i < n; i += NT) data[i] = buf[i];
     } else {
-      m = par_retain_best<MAXW>(data, n, n_points, RespGreater(), RespGe(), ps);
+      m = par_retain_best<NT, MAXW>(data, n, n_points, RespGreater(), RespGe(), ps);
     }
   } else {  // packed candidates: compare the top byte of .x only
     struct G {
@@ -486,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void retain_best_test_kernel(uint2* data,
     struct GE {
       __device__ bool operator()(const uint2& a, const uint2& b) const { return (a.x >> 24) >= (b.x >> 24); }
     };
-    m = par_retain_best<MAXW>(data, n, n_points, G(), GE(), ps);
+    m = par_retain_best<NT, MAXW>(data, n, n_points, G(), GE(), ps);
   }
   if (threadIdx.x == 0) *out_n = m;
 }
@@ -524,16 +470,16 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   }
   if (nbig > 0) {
     a.level0 = 0;
-    hipLaunchKernelGGL((orb_select_kernel<16384, 2048, 1024>), dim3(nbig, im.n), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<1024, 16384, 2048, 1024>), dim3(nbig, im.n), dim3(1024), 0, s, a);
   }
   if (nbig < g.nlevels) {
     a.level0 = nbig;
-    hipLaunchKernelGGL((orb_select_kernel<4096, 1024, 256>), dim3(g.nlevels - nbig, im.n), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<256, 4096, 1024, 256>), dim3(g.nlevels - nbig, im.n), dim3(256), 0, s, a);
   }
 }
 
 void vsf_launch_retain_best_test(uint2* d_data, int n, int n_points, int use_lds, int mode, int* d_out_n,
                                  hipStream_t s) {
-  hipLaunchKernelGGL((retain_best_test_kernel<1024>), dim3(1), dim3(kThreads), 0, s, d_data, n, n_points, use_lds,
+  hipLaunchKernelGGL((retain_best_test_kernel<256, 1024>), dim3(1), dim3(256), 0, s, d_data, n, n_points, use_lds,
                      mode, d_out_n);
 }

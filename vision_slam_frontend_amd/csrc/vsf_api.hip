@@ -194,6 +194,28 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
   return true;
 }
 
+// ICAngles disc (patch 31) as byte weights for k_describe.hip: for byte phase s = (x0 - 15) & 3 the item (row r,
+// dword j) covers u = 4j + b - s - 15, b = 0..3, on row v = r - 15; .x holds u + 16 and .y holds 1 for the bytes
+// inside the disc (|u| <= umax[|v|]), 0 elsewhere.
+std::vector<uint2> build_ic_table() {
+  const std::vector<int> um = orb_umax(31);
+  std::vector<uint2> t(4 * VSF_IC_ITEMS, make_uint2(0, 0));
+  for (int s = 0; s < 4; s++)
+    for (int item = 0; item < 31 * 9; item++) {
+      const int r = item / 9, j = item % 9, v = r - 15, d = um[std::abs(v)];
+      uint32_t wx = 0, wm = 0;
+      for (int b = 0; b < 4; b++) {
+        const int u = 4 * j + b - s - 15;
+        if (std::abs(u) <= d) {
+          wx |= (uint32_t)(u + 16) << (8 * b);
+          wm |= 1u << (8 * b);
+        }
+      }
+      t[(size_t)s * VSF_IC_ITEMS + item] = make_uint2(wx, wm);
+    }
+  return t;
+}
+
 // getGaussianKernel(7, 2, CV_32F) scaled by 256 and rounded (createSeparableLinearFilter, 8u smooth kernels).
 void gaussian_taps(int k[4]) {
   const int n = 7;
@@ -216,6 +238,7 @@ struct DevSet {  // device copies of one Geometry + its work buffers
   VsfTap* xt = nullptr;
   VsfTap* yt = nullptr;
   uint32_t* blur_tiles = nullptr;
+  uint2* ic_table = nullptr;
   bool ready = false;
 };
 
@@ -283,7 +306,9 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   VSF_HIP(upload(&ds->xt, G.xt));
   VSF_HIP(upload(&ds->yt, G.yt));
   VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
+  VSF_HIP(upload(&ds->ic_table, build_ic_table()));
   VsfDev& d = ds->d;
+  d.ic_table = ds->ic_table;
   d.levels = ds->levels;
   d.units = ds->units;
   d.xtaps = ds->xt;
@@ -312,6 +337,7 @@ void free_devset(DevSet* ds) {
   hipFree(ds->xt);
   hipFree(ds->yt);
   hipFree(ds->blur_tiles);
+  hipFree(ds->ic_table);
   hipFree(ds->d.pyr);
   hipFree(ds->d.blur);
   hipFree(ds->d.scratch);

@@ -12,8 +12,9 @@
 
 #include "vsf_internal.h"
 
-// Block-wide exclusive scan over 256 threads (4 waves of 64). lds4 needs 4 ints.
-__device__ __forceinline__ int vsf_block_excl_scan_256(int v, int* lds4, int* total) {
+// Block-wide exclusive scan over NT threads (NT / 64 waves). lds4 needs NT / 64 ints.
+template <int NT>
+__device__ __forceinline__ int vsf_block_excl_scan(int v, int* lds4, int* total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -23,28 +24,34 @@ __device__ __forceinline__ int vsf_block_excl_scan_256(int v, int* lds4, int* to
   }
   if (lane == 63) lds4[wid] = inc;
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wid; w++) base += lds4[w];
-  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) {
+    const int c = lds4[w];
+    if (w < wid) base += c;
+    tot += c;
+  }
+  *total = tot;
   __syncthreads();
   return base + inc - v;
 }
 
-// Number of candidates of level L of one image (all 256 threads call; same value returned to all).
+// Number of candidates of level L of one image (all NT threads call; same value returned to all).
+template <int NT>
 __device__ __forceinline__ int vsf_level_candidate_count(const VsfLevel& L, const uint16_t* __restrict__ rs_img,
                                                          int* lds4) {
   const int nu = L.nbands * L.nstrips;
   int s = 0;
-  for (int u = threadIdx.x; u < nu; u += 256)
+  for (int u = threadIdx.x; u < nu; u += NT)
     s += rs_img[(size_t)(L.unit0 + u) * VSF_FAST_RS_STRIDE + VSF_FAST_STRIP_ROWS];
   int total;
-  vsf_block_excl_scan_256(s, lds4, &total);
+  vsf_block_excl_scan<NT>(s, lds4, &total);
   return total;
 }
 
 // Merges the level's unit segments into raster order; store(dst_index, entry) receives every candidate once.
-// cellpre: LDS int array with cellcap >= VSF_FAST_STRIP_ROWS * nbands + 1 entries.  All 256 threads call.
-template <class Store>
+// cellpre: LDS int array with cellcap >= VSF_FAST_STRIP_ROWS * nbands + 1 entries.  All NT threads call.
+template <int NT, class Store>
 __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32_t* __restrict__ cand_img,
                                                  const uint16_t* __restrict__ rs_img, int* cellpre, int cellcap,
                                                  int* lds4, Store store) {
@@ -58,7 +65,7 @@ __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32
   for (int row0 = 0; row0 < nrows; row0 += rows_per_chunk) {
     const int nr = min(rows_per_chunk, nrows - row0);
     const int nc = nr * nb;
-    const int cpt = (nc + 255) / 256;
+    const int cpt = (nc + NT - 1) / NT;
     const int c_beg = min(tid * cpt, nc), c_end = min(c_beg + cpt, nc);
     int local = 0;
     {
@@ -72,23 +79,22 @@ __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32
       }
     }
     int total;
-    const int excl = vsf_block_excl_scan_256(local, lds4, &total);
+    const int excl = vsf_block_excl_scan<NT>(local, lds4, &total);
     for (int c = c_beg; c < c_end; c++) cellpre[c] += excl;
     __syncthreads();
     const int s0 = row0 / SR, s1 = (row0 + nr + SR - 1) / SR;
-    for (int s = s0; s < s1; s++) {
-      for (int b = 0; b < nb; b++) {
-        const int u = s * nb + b;
-        const uint16_t* rs = rs_img + (size_t)(L.unit0 + u) * VSF_FAST_RS_STRIDE;
-        const int tot = rs[SR];
-        const uint32_t* seg = cand_img + L.cand_offset + (size_t)u * L.seg_cap;
-        for (int e = tid; e < tot; e += 256) {
-          const uint32_t entry = seg[e];
-          const int row = VSF_CAND_Y(entry) - L.y_lo;
-          const int r = row - s * SR;
-          const int c = (row - row0) * nb + b;
-          store(base + cellpre[c] + (e - (int)rs[r]), entry);
-        }
+    // one wave per unit (round robin): independent load chains instead of one long dependent loop
+    for (int u = s0 * nb + (tid >> 6); u < s1 * nb; u += NT / 64) {
+      const int s = u / nb, b = u - s * nb;
+      const uint16_t* rs = rs_img + (size_t)(L.unit0 + u) * VSF_FAST_RS_STRIDE;
+      const int tot = rs[SR];
+      const uint32_t* seg = cand_img + L.cand_offset + (size_t)u * L.seg_cap;
+      for (int e = tid & 63; e < tot; e += 64) {
+        const uint32_t entry = seg[e];
+        const int row = VSF_CAND_Y(entry) - L.y_lo;
+        const int r = row - s * SR;
+        const int c = (row - row0) * nb + b;
+        store(base + cellpre[c] + (e - (int)rs[r]), entry);
       }
     }
     base += total;

@@ -14,7 +14,7 @@
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
 #define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
-#define VSF_SELECT_THREADS 256
+#define VSF_IC_ITEMS 320         // ICAngles disc items per byte phase: 31 rows x 9 dwords = 279, padded to 5 x 64
 
 // ---- pyramid level descriptor (device-resident table, read through scalar loads) ----
 struct VsfLevel {
@@ -79,6 +79,7 @@ struct VsfDev {
   uint16_t* rowstart;       // [max_images][nunits][VSF_FAST_RS_STRIDE]  start of each row inside its segment
   uint32_t* scratch;        // [max_images][3 * cand_entries]   selection arrays when LDS is too small
   VsfLevelKp* lvlkp;        // [max_images][lvlkp_entries]
+  const uint2* ic_table;    // [4][VSF_IC_ITEMS] ICAngles byte weights (k_describe.hip)
   int32_t* lvl_count;       // [max_images][nlevels]
   int32_t* status;          // device status word (bit 0: capacity overflow)
 };
