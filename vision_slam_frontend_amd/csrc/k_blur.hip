@@ -8,10 +8,13 @@
 // SSE2 SymmColumnVec_32s8u handles ([0, w - w%4)) and half-up on the scalar tail, saturated to 255.
 //
 // Streaming "march" kernel, no LDS and no barriers: a wave owns a band of 248 columns (62 lanes x 4 pixels; lanes
-// 0 and 63 only carry the 4-pixel halo) and walks down a strip of rows.  Per row each lane issues ONE coalesced
-// 32-bit load, gets its neighbours' dwords with two DPP wave shifts, does the horizontal pass for its 4 pixels and
-// pushes the 4 sums into a 7-row register window; the vertical pass reads that window and the lane stores one
-// 32-bit word.  HBM traffic is the compulsory P read + P write (plus 6 halo rows per 64-row strip).
+// 0 and 63 only carry the 4-pixel halo) and walks down a strip of rows; per row each lane issues ONE coalesced
+// 32-bit load and ONE 32-bit store.  The two passes commute (exact integer sums, one rounding at the end), so the
+// kernel runs the COLUMN pass first, on bytes widened to packed 16 bit (two pixels per v_pk_add/v_pk_mad_u16; the
+// 7-tap sum is <= 255 * 257 = 65535, it just fits), over a 7-row register window, and then the ROW pass on those
+// 16-bit sums with v_dot2_u32_u16 (two taps per instruction, 32-bit accumulator): a pixel's seven taps are four
+// dot2 on the lane's own and its neighbours' packed pairs (4 DPP wave shifts per row).
+// HBM traffic is the compulsory P read + P write (plus 6 halo rows per 64-row strip).
 #include "vsf_internal.h"
 
 namespace {
@@ -32,8 +35,11 @@ struct BlurArgs {
   int k0, k1, k2, k3;  // fixed-point kernel taps (k[3-i] == k[3+i])
 };
 
-struct R4 {
-  int a, b, c, d;
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+typedef short v2s_ __attribute__((ext_vector_type(2)));
+
+struct Px4 {  // one row's 4 pixels as two packed pairs of 16-bit values: lo = (x, x+1), hi = (x+2, x+3)
+  v2u lo, hi;
 };
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -49,40 +55,26 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {  // lane i <- lane i
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
 }
 
-// Loads the lane's 4 pixels of one row (columns c0..c0+3), reflecting columns outside [0, w).
-__device__ __forceinline__ uint32_t load_row_dword(const uint8_t* __restrict__ rowp, int c0, int w, bool interior) {
-  if (interior) return *reinterpret_cast<const uint32_t*>(rowp + c0);
-  uint32_t v = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) v |= (uint32_t)rowp[reflect101(c0 + j, w)] << (8 * j);
-  return v;
-}
-
-__device__ __forceinline__ R4 row_pass(uint32_t dp, uint32_t d, uint32_t dn, int k0, int k1, int k2, int k3) {
-  const int b1 = (dp >> 8) & 255, b2 = (dp >> 16) & 255, b3 = dp >> 24;
-  const int b4 = d & 255, b5 = (d >> 8) & 255, b6 = (d >> 16) & 255, b7 = d >> 24;
-  const int b8 = dn & 255, b9 = (dn >> 8) & 255, b10 = (dn >> 16) & 255;
-  R4 r;
-  r.a = k0 * (b1 + b7) + k1 * (b2 + b6) + k2 * (b3 + b5) + k3 * b4;
-  r.b = k0 * (b2 + b8) + k1 * (b3 + b7) + k2 * (b4 + b6) + k3 * b5;
-  r.c = k0 * (b3 + b9) + k1 * (b4 + b8) + k2 * (b5 + b7) + k3 * b6;
-  r.d = k0 * (b4 + b10) + k1 * (b5 + b9) + k2 * (b6 + b8) + k3 * b7;
+__device__ __forceinline__ Px4 widen(uint32_t d) {
+  Px4 r;
+  r.lo = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, d, 0x0C010C00u));
+  r.hi = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, d, 0x0C030C02u));
   return r;
 }
 
-__device__ __forceinline__ int round_px(int n, bool half_even) {
-  int v;
-  if (half_even) {
-    v = n >> 16;
-    const int rem = n & 0xFFFF;
-    v += (rem > 0x8000) | ((rem == 0x8000) & (v & 1));
-  } else {
-    v = (n + 0x8000) >> 16;
-  }
-  return min(v, 255);
+__device__ __forceinline__ uint32_t dot2(v2u a, uint32_t kpair, uint32_t acc) {
+  return __builtin_amdgcn_udot2(a, __builtin_bit_cast(v2u, kpair), acc, false);
 }
 
-#define VSF_COL(f) (k0 * (w0.f + w6.f) + k1 * (w1.f + w5.f) + k2 * (w2.f + w4.f) + k3 * w3.f)
+__device__ __forceinline__ v2u dpp_shr1(v2u v) { return __builtin_bit_cast(v2u, wave_shr1(__builtin_bit_cast(uint32_t, v))); }
+__device__ __forceinline__ v2u dpp_shl1(v2u v) { return __builtin_bit_cast(v2u, wave_shl1(__builtin_bit_cast(uint32_t, v))); }
+
+// N / 65536 with OpenCV's rounding, left in bits 16..23 (saturated): tie_up = 1 rounds half-up (scalar tail),
+// tie_up = 0 rounds half-to-even (SSE2 cvtps2dq columns).
+__device__ __forceinline__ uint32_t round_fix16(uint32_t n, uint32_t tie_up) {
+  const uint32_t b = ((n >> 16) & 1u) | tie_up;
+  return min(n + 0x7FFFu + b, 0x00FFFFFFu);
+}
 
 __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
   const int lane = threadIdx.x & 63;
@@ -102,40 +94,94 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
     pitch = L.pitch;
   }
   uint8_t* dst = a.blur + (size_t)image * a.pyr_bytes + L.offset;
-  const int k0 = a.k0, k1 = a.k1, k2 = a.k2, k3 = a.k3;
+  const uint32_t k0 = (uint32_t)a.k0, k1 = (uint32_t)a.k1, k2 = (uint32_t)a.k2, k3 = (uint32_t)a.k3;
+  const v2u K0 = {(unsigned short)k0, (unsigned short)k0}, K1 = {(unsigned short)k1, (unsigned short)k1},
+            K2 = {(unsigned short)k2, (unsigned short)k2}, K3 = {(unsigned short)k3, (unsigned short)k3};
+  // tap pairs (low half, high half) of the row pass
+  const uint32_t p_0k0 = k0 << 16, p_k0_0 = k0, p_k1k2 = k1 | (k2 << 16), p_k3k2 = k3 | (k2 << 16),
+                 p_k1k0 = k1 | (k0 << 16), p_k0k1 = k0 | (k1 << 16), p_k2k3 = k2 | (k3 << 16),
+                 p_k2k1 = k2 | (k1 << 16);
   const int w = L.w, h = L.h;
   const int c0 = band * kBandCols - 4 + 4 * lane;  // first column of this lane's dword
+  // BORDER_REFLECT_101 columns without a divergent slow path: every column a lane can need lies in an aligned
+  // 8-byte window [a0, a0 + 8) of the row (a0 = c0 inside the image, 0 left of it, (w - 4) & ~3 at the right edge;
+  // level widths are >= 8), so a lane loads that window's two dwords and picks its 4 bytes with one v_perm_b32.
   const bool interior = c0 >= 0 && c0 + 3 < w;
+  const int a0 = interior ? c0 : (c0 < 0 ? 0 : ((w - 4) & ~3));
+  const int a1 = min(a0 + 4, pitch - 4);
+  uint32_t bsel = 0x03020100u;
+  if (!interior) {
+    bsel = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int sidx = reflect101(c0 + j, w) - a0;  // columns beyond w + 2 are never used: any in-window byte will do
+      sidx = min(max(sidx, 0), 7);
+      if (sidx >= 4 && a1 != a0 + 4) sidx = 3;  // (window clipped at the end of the row: only reachable there)
+      bsel |= (uint32_t)sidx << (8 * j);
+    }
+  }
+  const bool all_interior = __all(interior);
   const bool writer = lane >= 1 && lane <= 62 && c0 < w;
   const int ys = strip * kStripRows, ye = min(ys + kStripRows, h);
-  const bool he0 = c0 + 0 < L.blur_vec_end, he1 = c0 + 1 < L.blur_vec_end, he2 = c0 + 2 < L.blur_vec_end,
-             he3 = c0 + 3 < L.blur_vec_end;
+  const uint32_t t0 = c0 + 0 < L.blur_vec_end ? 0u : 1u, t1 = c0 + 1 < L.blur_vec_end ? 0u : 1u,
+                 t2 = c0 + 2 < L.blur_vec_end ? 0u : 1u, t3 = c0 + 3 < L.blur_vec_end ? 0u : 1u;
 
-  R4 w0, w1, w2, w3, w4, w5, w6;
-  auto fetch = [&](int y) -> R4 {
+  auto fetch = [&](int y) -> Px4 {
     const uint8_t* rowp = src + (size_t)reflect101(y, h) * pitch;
-    const uint32_t d = load_row_dword(rowp, c0, w, interior);
-    return row_pass(wave_shr1(d), d, wave_shl1(d), k0, k1, k2, k3);
+    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rowp + a0);
+    if (all_interior) return widen(d0);  // wave-uniform
+    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rowp + a1);
+    return widen(__builtin_amdgcn_perm(d1, d0, bsel));
   };
-  w1 = fetch(ys - 3);
-  w2 = fetch(ys - 2);
-  w3 = fetch(ys - 1);
-  w4 = fetch(ys);
-  w5 = fetch(ys + 1);
-  w6 = fetch(ys + 2);
-  for (int y = ys; y < ye; y++) {
-    w0 = w1;
-    w1 = w2;
-    w2 = w3;
-    w3 = w4;
-    w4 = w5;
-    w5 = w6;
-    w6 = fetch(y + 3);
+  // One output row: column pass over the 7-row window (r0 = row y-3 ... r6 = row y+3), then the row pass.
+  auto emit = [&](int y, const Px4& r0, const Px4& r1, const Px4& r2, const Px4& r3, const Px4& r4, const Px4& r5,
+                  const Px4& r6) {
+    const v2u clo = K3 * r3.lo + (K2 * (r2.lo + r4.lo) + (K1 * (r1.lo + r5.lo) + K0 * (r0.lo + r6.lo)));
+    const v2u chi = K3 * r3.hi + (K2 * (r2.hi + r4.hi) + (K1 * (r1.hi + r5.hi) + K0 * (r0.hi + r6.hi)));
+    const v2u llo = dpp_shr1(clo), lhi = dpp_shr1(chi), rlo = dpp_shl1(clo), rhi = dpp_shl1(chi);
+    // pixel x = c0 + j sees C[x-3 .. x+3]; lanes hold C as (lo.x, lo.y, hi.x, hi.y) = columns c0 .. c0+3
+    const uint32_t n0 = dot2(chi, p_k1k0, dot2(clo, p_k3k2, dot2(lhi, p_k1k2, dot2(llo, p_0k0, 0u))));
+    const uint32_t n1 = dot2(rlo, p_k0_0, dot2(chi, p_k2k1, dot2(clo, p_k2k3, dot2(lhi, p_k0k1, 0u))));
+    const uint32_t n2 = dot2(rlo, p_k1k0, dot2(chi, p_k3k2, dot2(clo, p_k1k2, dot2(lhi, p_0k0, 0u))));
+    const uint32_t n3 = dot2(rhi, p_k0_0, dot2(rlo, p_k2k1, dot2(chi, p_k2k3, dot2(clo, p_k0k1, 0u))));
     if (writer) {
-      const uint32_t o = (uint32_t)round_px(VSF_COL(a), he0) | ((uint32_t)round_px(VSF_COL(b), he1) << 8) |
-                         ((uint32_t)round_px(VSF_COL(c), he2) << 16) | ((uint32_t)round_px(VSF_COL(d), he3) << 24);
-      *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch + c0) = o;
+      const uint32_t v0 = round_fix16(n0, t0), v1 = round_fix16(n1, t1), v2 = round_fix16(n2, t2),
+                     v3 = round_fix16(n3, t3);
+      // byte 2 of each value -> bytes 0..3
+      const uint32_t lo2 = __builtin_amdgcn_perm(v1, v0, 0x0C0C0602u), hi2 = __builtin_amdgcn_perm(v3, v2, 0x06020C0Cu);
+      *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch + c0) = lo2 | hi2;
     }
+  };
+
+  Px4 W0, W1, W2, W3, W4, W5, W6;
+  W0 = fetch(ys - 3);
+  W1 = fetch(ys - 2);
+  W2 = fetch(ys - 1);
+  W3 = fetch(ys);
+  W4 = fetch(ys + 1);
+  W5 = fetch(ys + 2);
+  // The window rotates through seven register sets: row y uses (Wq .. Wq+6 mod 7) and refills the oldest one.
+  for (int y = ys; y < ye; y += 7) {
+    W6 = fetch(y + 3);
+    emit(y, W0, W1, W2, W3, W4, W5, W6);
+    if (y + 1 >= ye) break;
+    W0 = fetch(y + 4);
+    emit(y + 1, W1, W2, W3, W4, W5, W6, W0);
+    if (y + 2 >= ye) break;
+    W1 = fetch(y + 5);
+    emit(y + 2, W2, W3, W4, W5, W6, W0, W1);
+    if (y + 3 >= ye) break;
+    W2 = fetch(y + 6);
+    emit(y + 3, W3, W4, W5, W6, W0, W1, W2);
+    if (y + 4 >= ye) break;
+    W3 = fetch(y + 7);
+    emit(y + 4, W4, W5, W6, W0, W1, W2, W3);
+    if (y + 5 >= ye) break;
+    W4 = fetch(y + 8);
+    emit(y + 5, W5, W6, W0, W1, W2, W3, W4);
+    if (y + 6 >= ye) break;
+    W5 = fetch(y + 9);
+    emit(y + 6, W6, W0, W1, W2, W3, W4, W5);
   }
 }
 

@@ -116,7 +116,7 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
     L.scale = orb ? (float)std::pow(scale_factor, (double)(l - p.first_level)) : 1.f;
     L.w = cvRoundF(p.width / L.scale);
     L.h = cvRoundF(p.height / L.scale);
-    if (L.w < 1 || L.h < 1 || L.w > 4095 || L.h > 4095) return false;
+    if (L.w < 8 || L.h < 1 || L.w > 4095 || L.h > 4095) return false;  // (blur border window needs w >= 8)
     L.pitch = align_up(L.w, 64);
     L.offset = offset;
     offset += (uint32_t)align_up(L.pitch * L.h, 256);
