@@ -8,15 +8,18 @@
 //
 // Streaming march kernel -- no LDS, no barriers, no divergent corner/score phases:
 //  * a wave owns a band of 240 keypoint columns x a strip of 32 rows of one level of one image and walks down the
-//    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window and
-//    gets its neighbours' dwords by DPP wave shifts;
+//    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window (seven
+//    rotating register sets, no copies) and gets its neighbours' dwords by DPP wave shifts;
 //  * corner test and score are ONE dense computation: with d_k = p_k - v on the 16-pixel circle,
 //      A = max over the 16 arcs of min(d over the 9-arc),  B = -min over arcs of max(d over the arc),
 //    the pixel is a FAST-9 corner iff max(A, B) > t and cornerScore is max(A, B) - 1.  Two pixels are processed per
-//    VALU lane-op with packed 16-bit min/max (v_pk_min_i16 / v_pk_max_i16), circle bytes are pulled out of the
-//    window with v_perm_b32; there is no data-dependent branch except a wave-wide early-out for flat rows;
-//  * scores stay in registers (3-row rolling window, 4 score bytes per lane); the strict 8-neighbour NMS reads the
-//    neighbours by DPP, and survivors are appended in raster order with ballot prefix ranks.
+//    VALU lane-op with packed 16-bit min/max (v_pk_min_i16 / v_pk_max_i16); circle bytes are pulled out of the
+//    window with v_perm_b32.  The 16 arc minima come from prefix/suffix minima of the two circle halves (an arc
+//    of 9 = a suffix of one half + a prefix of the other): 59 instead of 80 packed ops per polarity;
+//  * the only branch is wave-wide: a row is skipped when v_sad_u8 of every lane's 4 pixels against the rows 3 above
+//    and 3 below stays <= t (circle pixels 0 and 8: every 9-arc contains one of them);
+//  * scores stay in registers; the strict 8-neighbour NMS is packed too (row-wise 3-maxima shared between the rows
+//    above and below), and survivors are appended in raster order with ballot prefix ranks.
 // Output per unit: a candidate segment in unit-local raster order + the start offset of every row, which
 // vsf_gather.h merges into the level's global raster order.
 #include "vsf_gather.h"
@@ -71,89 +74,92 @@ __device__ __forceinline__ v2s pick2(const Row3& r) {
 __device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 
-// Scores of the two pixels at bytes 4+J0, 5+J0 of the centre row (W[3]); W[0..6] are rows y-3..y+3.
-// Returns the two 8-bit scores (0 = not a corner) in bits 0..7 and 8..15.
+// Scores of the two pixels at bytes 4+J0, 5+J0 of the centre row R3; R0..R6 are rows y-3..y+3.
+// Returns the two scores (0 = not a corner; a marker 1 when nms == 0) in the two 16-bit halves.
 template <int J0>
-__device__ __forceinline__ uint32_t score_pair(const Row3 (&W)[7], int t, int nms) {
-  const v2s v = pick2<4 + J0>(W[3]);
+__device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3,
+                                          const Row3& R4, const Row3& R5, const Row3& R6, v2s tt, int nms) {
+  const v2s v = pick2<4 + J0>(R3);
   v2s d[16];
   // Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
-  // (-3,0)(-3,1)(-2,2)(-1,3); window row index = 3 + dy.
-  d[0] = pick2<4 + J0 + 0>(W[6]) - v;
-  d[1] = pick2<4 + J0 + 1>(W[6]) - v;
-  d[2] = pick2<4 + J0 + 2>(W[5]) - v;
-  d[3] = pick2<4 + J0 + 3>(W[4]) - v;
-  d[4] = pick2<4 + J0 + 3>(W[3]) - v;
-  d[5] = pick2<4 + J0 + 3>(W[2]) - v;
-  d[6] = pick2<4 + J0 + 2>(W[1]) - v;
-  d[7] = pick2<4 + J0 + 1>(W[0]) - v;
-  d[8] = pick2<4 + J0 + 0>(W[0]) - v;
-  d[9] = pick2<4 + J0 - 1>(W[0]) - v;
-  d[10] = pick2<4 + J0 - 2>(W[1]) - v;
-  d[11] = pick2<4 + J0 - 3>(W[2]) - v;
-  d[12] = pick2<4 + J0 - 3>(W[3]) - v;
-  d[13] = pick2<4 + J0 - 3>(W[4]) - v;
-  d[14] = pick2<4 + J0 - 2>(W[5]) - v;
-  d[15] = pick2<4 + J0 - 1>(W[6]) - v;
-  v2s n1[16], x1[16];
+  // (-3,0)(-3,1)(-2,2)(-1,3); window row = R[3 + dy].
+  d[0] = pick2<4 + J0 + 0>(R6) - v;
+  d[1] = pick2<4 + J0 + 1>(R6) - v;
+  d[2] = pick2<4 + J0 + 2>(R5) - v;
+  d[3] = pick2<4 + J0 + 3>(R4) - v;
+  d[4] = pick2<4 + J0 + 3>(R3) - v;
+  d[5] = pick2<4 + J0 + 3>(R2) - v;
+  d[6] = pick2<4 + J0 + 2>(R1) - v;
+  d[7] = pick2<4 + J0 + 1>(R0) - v;
+  d[8] = pick2<4 + J0 + 0>(R0) - v;
+  d[9] = pick2<4 + J0 - 1>(R0) - v;
+  d[10] = pick2<4 + J0 - 2>(R1) - v;
+  d[11] = pick2<4 + J0 - 3>(R2) - v;
+  d[12] = pick2<4 + J0 - 3>(R3) - v;
+  d[13] = pick2<4 + J0 - 3>(R4) - v;
+  d[14] = pick2<4 + J0 - 2>(R5) - v;
+  d[15] = pick2<4 + J0 - 1>(R6) - v;
+  // Arc k = d[k .. k+8] (indices mod 16).  With halves H0 = d[0..7], H1 = d[8..15]:
+  //   arc k     (k < 8) = suffix of H0 from k  +  prefix of H1 up to k
+  //   arc 8 + k         = suffix of H1 from k  +  prefix of H0 up to k
+  v2s ps0[8], ps1[8], sf0[8], sf1[8], px0[8], px1[8], sx0[8], sx1[8];
+  ps0[0] = px0[0] = d[0];
+  ps1[0] = px1[0] = d[8];
+  sf0[7] = sx0[7] = d[7];
+  sf1[7] = sx1[7] = d[15];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    n1[k] = vmin(d[k], d[(k + 1) & 15]);
-    x1[k] = vmax(d[k], d[(k + 1) & 15]);
+  for (int k = 1; k < 8; k++) {
+    ps0[k] = vmin(ps0[k - 1], d[k]);
+    px0[k] = vmax(px0[k - 1], d[k]);
+    ps1[k] = vmin(ps1[k - 1], d[8 + k]);
+    px1[k] = vmax(px1[k - 1], d[8 + k]);
+    sf0[7 - k] = vmin(sf0[8 - k], d[7 - k]);
+    sx0[7 - k] = vmax(sx0[8 - k], d[7 - k]);
+    sf1[7 - k] = vmin(sf1[8 - k], d[15 - k]);
+    sx1[7 - k] = vmax(sx1[8 - k], d[15 - k]);
   }
-  v2s n2[16], x2[16];
+  v2s A = vmin(sf0[0], ps1[0]), Bm = vmax(sx0[0], px1[0]);
+  A = vmax(A, vmin(sf1[0], ps0[0]));
+  Bm = vmin(Bm, vmax(sx1[0], px0[0]));
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    n2[k] = vmin(n1[k], n1[(k + 2) & 15]);
-    x2[k] = vmax(x1[k], x1[(k + 2) & 15]);
+  for (int k = 1; k < 8; k++) {
+    A = vmax(A, vmin(sf0[k], ps1[k]));
+    A = vmax(A, vmin(sf1[k], ps0[k]));
+    Bm = vmin(Bm, vmax(sx0[k], px1[k]));
+    Bm = vmin(Bm, vmax(sx1[k], px0[k]));
   }
-  v2s A = {-32768, -32768}, Bm = {32767, 32767};
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const v2s n9 = vmin(vmin(n2[k], n2[(k + 4) & 15]), d[(k + 8) & 15]);
-    const v2s x9 = vmax(vmax(x2[k], x2[(k + 4) & 15]), d[(k + 8) & 15]);
-    A = vmax(A, n9);
-    Bm = vmin(Bm, x9);
-  }
-  // cornerScore<16>: max(t, A, -Bm) - 1; a corner iff that maximum exceeds t.  With NMS a corner of score 0 can
+  // cornerScore<16> = max(t, A, -Bm) - 1; a corner iff that maximum exceeds t.  With NMS a corner of score 0 can
   // never win (cv::FAST_t compares strictly against neighbours >= 0); without NMS only a corner marker is kept
   // (cv::FAST_t leaves the response at 0 then).
-  const int a0 = A.x, a1 = A.y, b0 = -(int)Bm.x, b1 = -(int)Bm.y;
-  const int s0 = max(a0, b0), s1 = max(a1, b1);
-  const uint32_t r0 = s0 > t ? (nms ? (uint32_t)(s0 - 1) : 1u) : 0u, r1 = s1 > t ? (nms ? (uint32_t)(s1 - 1) : 1u) : 0u;
-  return r0 | (r1 << 8);
+  const v2s zero = {0, 0}, one = {1, 1};
+  const v2s sc = vmax(A, zero - Bm);
+  const v2s m = (tt - sc) >> 15;  // all ones where sc > t
+  return nms ? ((sc - one) & m) : (m & one);
 }
 
-// True if some pixel of the lane's four could be a corner: a 9-arc always contains circle pixel 0 or 8.
-__device__ __forceinline__ bool maybe_corner(const Row3 (&W)[7], int t) {
-  const uint32_t c = W[3].d, up = W[0].d, dn = W[6].d;
-  bool any = false;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int v = (c >> (8 * j)) & 255, a = (up >> (8 * j)) & 255, b = (dn >> (8 * j)) & 255;
-    any |= (abs(a - v) > t) | (abs(b - v) > t);
-  }
-  return any;
-}
+// One score row as the NMS needs it: the 4 score bytes, the centre pairs, and the horizontal maxima.
+struct ScoreRow {
+  uint32_t s;       // score bytes of the lane's 4 pixels
+  v2s c01, c23;     // the same as 16-bit pairs
+  v2s h3a, h3b;     // max(s[x-1], s[x], s[x+1]) for pixel pairs (0,1) and (2,3)
+  v2s h2a, h2b;     // max(s[x-1], s[x+1])
+};
 
-template <int B>
-__device__ __forceinline__ int byte_of(const Row3& r) {
-  if constexpr (B < 4) {
-    return (int)((r.p >> (8 * B)) & 255u);
-  } else if constexpr (B < 8) {
-    return (int)((r.d >> (8 * (B - 4))) & 255u);
-  } else {
-    return (int)((r.n >> (8 * (B - 8))) & 255u);
-  }
-}
-
-template <int J>
-__device__ __forceinline__ bool nms_keep(const Row3& up, const Row3& mid, const Row3& dn, int nms) {
-  const int s = byte_of<4 + J>(mid);
-  if (s == 0) return false;
-  if (!nms) return true;
-  return s > byte_of<3 + J>(mid) && s > byte_of<5 + J>(mid) && s > byte_of<3 + J>(up) && s > byte_of<4 + J>(up) &&
-         s > byte_of<5 + J>(up) && s > byte_of<3 + J>(dn) && s > byte_of<4 + J>(dn) && s > byte_of<5 + J>(dn);
+__device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
+  Row3 r;
+  r.d = S;
+  r.p = wave_shr1(S);
+  r.n = wave_shl1(S);
+  ScoreRow o;
+  o.s = S;
+  const v2s b3 = pick2<3>(r), b5 = pick2<5>(r), b7 = pick2<7>(r);
+  o.c01 = pick2<4>(r);
+  o.c23 = pick2<6>(r);
+  o.h2a = vmax(b3, b5);
+  o.h2b = vmax(b5, b7);
+  o.h3a = vmax(o.h2a, o.c01);
+  o.h3b = vmax(o.h2b, o.c23);
+  return o;
 }
 
 __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
     pitch = L.pitch;
   }
   const int t = a.threshold, nms = a.nms;
+  const v2s tt = {(short)t, (short)t};
   const int bx0 = L.fast_a0 + VSF_FAST_BAND_COLS * band;
   const int c0 = bx0 - 8 + 4 * lane;  // first column of this lane's 4 pixels
   const bool loadable = c0 >= 0 && c0 + 3 < pitch;
@@ -187,76 +194,115 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
     if (lane >= 1 && lane <= 62 && x >= sx_lo && x < sx_hi) smask |= 0xFFu << (8 * j);
     if (lane >= 2 && lane <= 61 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS) emask |= 0xFFu << (8 * j);
   }
+  const v2s em01 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, emask, 0x0C010C00u));
+  const v2s em23 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, emask, 0x0C030C02u));
   const int unit_local = strip * L.nbands + band;
   uint32_t* seg = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)unit_local * L.seg_cap;
   uint16_t* rs = a.rowstart + ((size_t)image * a.nunits + L.unit0 + unit_local) * VSF_FAST_RS_STRIDE;
+  const int seg_cap = L.seg_cap, hrow = L.h;
+  const unsigned long long lt = (1ull << lane) - 1ull;
 
   auto load_row = [&](int y) -> Row3 {
     Row3 r;
-    const int yc = min(max(y, 0), L.h - 1);
+    const int yc = min(max(y, 0), hrow - 1);
     r.d = loadable ? *reinterpret_cast<const uint32_t*>(src + (size_t)yc * pitch + c0) : 0u;
     r.p = wave_shr1(r.d);
     r.n = wave_shl1(r.d);
     return r;
   };
 
-  Row3 W[7];  // rows sy-3 .. sy+3 around the score row sy
-  int sy = ys - 1;
-#pragma unroll
-  for (int i = 0; i < 6; i++) W[i + 1] = load_row(sy - 3 + i);
-  Row3 next = load_row(sy + 3);
-  Row3 S_up = {0, 0, 0}, S_mid = {0, 0, 0};  // score rows sy-2, sy-1 (4 score bytes per lane + neighbours)
+  ScoreRow S_up = make_score_row(0u), S_mid = S_up;  // score rows sy-2, sy-1
   int count = 0;   // candidates emitted so far (wave-uniform)
   int my_rs = 0;   // lane l keeps rowstart[l]
-  for (; sy <= ye; sy++) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) W[i] = W[i + 1];
-    W[6] = next;
-    next = load_row(sy + 4);  // prefetch the next iteration's new row
-    // ---- scores of row sy ----
+
+  // One step: scores of row sy from the window R0..R6 = rows sy-3..sy+3, then NMS + emission of row sy-1.
+  auto step = [&](int sy, const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3, const Row3& R4,
+                  const Row3& R5, const Row3& R6) {
     uint32_t S = 0;
-    const bool row_ok = sy >= 3 && sy < L.h - 3;  // wave-uniform
-    if (row_ok && __any(smask != 0 && maybe_corner(W, t))) {
-      S = score_pair<0>(W, t, nms) | (score_pair<2>(W, t, nms) << 16);
+    const bool row_ok = sy >= 3 && sy < hrow - 3;  // wave-uniform
+    // a 9-arc contains circle pixel 0 (row sy+3) or 8 (row sy-3), both in the centre pixel's column
+    const uint32_t far = max(__builtin_amdgcn_sad_u8(R0.d, R3.d, 0u), __builtin_amdgcn_sad_u8(R6.d, R3.d, 0u));
+    if (row_ok && __any(smask != 0 && far > (uint32_t)t)) {
+      const v2s r01 = score_pair<0>(R0, R1, R2, R3, R4, R5, R6, tt, nms);
+      const v2s r23 = score_pair<2>(R0, R1, R2, R3, R4, R5, R6, tt, nms);
+      S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r23), __builtin_bit_cast(uint32_t, r01), 0x06040200u);
       S &= smask;
     }
-    Row3 S_dn;
-    S_dn.d = S;
-    S_dn.p = wave_shr1(S);
-    S_dn.n = wave_shl1(S);
-    // ---- NMS + emission of row sy-1 ----
+    const ScoreRow S_dn = make_score_row(S);
     const int y = sy - 1;
     if (y >= ys && y < ye) {
-      if (__any((S_mid.d & emask) != 0)) {
-        const bool k0 = (emask & 0xFFu) && nms_keep<0>(S_up, S_mid, S_dn, nms);
-        const bool k1 = (emask & 0xFF00u) && nms_keep<1>(S_up, S_mid, S_dn, nms);
-        const bool k2 = (emask & 0xFF0000u) && nms_keep<2>(S_up, S_mid, S_dn, nms);
-        const bool k3 = (emask & 0xFF000000u) && nms_keep<3>(S_up, S_mid, S_dn, nms);
+      if (__any((S_mid.s & emask) != 0)) {
+        // keep iff score > every 8-neighbour (strict); without NMS every marked corner is kept
+        const v2s zero = {0, 0};
+        const v2s nb01 = nms ? vmax(vmax(S_up.h3a, S_dn.h3a), S_mid.h2a) : zero;
+        const v2s nb23 = nms ? vmax(vmax(S_up.h3b, S_dn.h3b), S_mid.h2b) : zero;
+        const uint32_t k01 = __builtin_bit_cast(uint32_t, ((nb01 - S_mid.c01) >> 15) & em01);
+        const uint32_t k23 = __builtin_bit_cast(uint32_t, ((nb23 - S_mid.c23) >> 15) & em23);
+        const bool k0 = (k01 & 0xFFFFu) != 0, k1 = (k01 >> 16) != 0, k2 = (k23 & 0xFFFFu) != 0, k3 = (k23 >> 16) != 0;
         const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int pos = count + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
-        const uint32_t sc = nms ? S_mid.d : 0u;
-        if (k0) {
-          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 0, y, sc & 255u);
-          ++pos;
+        if ((b0 | b1 | b2 | b3) != 0ull) {  // wave-uniform
+          int pos = count + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+          const uint32_t sc = nms ? S_mid.s : 0u;
+          const uint32_t yx = ((uint32_t)y << 12) | (uint32_t)c0;
+          if (k0) {
+            if (pos < seg_cap) seg[pos] = ((sc & 255u) << 24) | yx;
+            ++pos;
+          }
+          if (k1) {
+            if (pos < seg_cap) seg[pos] = ((sc & 0xFF00u) << 16) | (yx + 1);
+            ++pos;
+          }
+          if (k2) {
+            if (pos < seg_cap) seg[pos] = ((sc & 0xFF0000u) << 8) | (yx + 2);
+            ++pos;
+          }
+          if (k3) {
+            if (pos < seg_cap) seg[pos] = (sc & 0xFF000000u) | (yx + 3);
+          }
+          count += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         }
-        if (k1) {
-          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 1, y, (sc >> 8) & 255u);
-          ++pos;
-        }
-        if (k2) {
-          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 2, y, (sc >> 16) & 255u);
-          ++pos;
-        }
-        if (k3) {
-          if (pos < L.seg_cap) seg[pos] = VSF_CAND_PACK(c0 + 3, y, sc >> 24);
-        }
-        count += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
       }
-      if (lane > y - ys) my_rs = min(count, L.seg_cap);
+      if (lane > y - ys) my_rs = min(count, seg_cap);
     }
     S_up = S_mid;
     S_mid = S_dn;
+  };
+
+  // Seven rotating register sets hold rows sy-3 .. sy+3; each step refills the oldest one two rows ahead.
+  const int sy0 = ys - 1;
+  Row3 W0 = load_row(sy0 - 3), W1 = load_row(sy0 - 2), W2 = load_row(sy0 - 1), W3 = load_row(sy0),
+       W4 = load_row(sy0 + 1), W5 = load_row(sy0 + 2), W6 = load_row(sy0 + 3);
+  Row3 nx = load_row(sy0 + 4);
+  for (int sy = sy0; sy <= ye; sy += 7) {
+    Row3 n2;
+    n2 = load_row(sy + 5);
+    step(sy, W0, W1, W2, W3, W4, W5, W6);
+    if (sy + 1 > ye) break;
+    W0 = nx;
+    nx = load_row(sy + 6);
+    step(sy + 1, W1, W2, W3, W4, W5, W6, W0);
+    if (sy + 2 > ye) break;
+    W1 = n2;
+    n2 = load_row(sy + 7);
+    step(sy + 2, W2, W3, W4, W5, W6, W0, W1);
+    if (sy + 3 > ye) break;
+    W2 = nx;
+    nx = load_row(sy + 8);
+    step(sy + 3, W3, W4, W5, W6, W0, W1, W2);
+    if (sy + 4 > ye) break;
+    W3 = n2;
+    n2 = load_row(sy + 9);
+    step(sy + 4, W4, W5, W6, W0, W1, W2, W3);
+    if (sy + 5 > ye) break;
+    W4 = nx;
+    nx = load_row(sy + 10);
+    step(sy + 5, W5, W6, W0, W1, W2, W3, W4);
+    if (sy + 6 > ye) break;
+    W5 = n2;
+    n2 = load_row(sy + 11);
+    step(sy + 6, W6, W0, W1, W2, W3, W4, W5);
+    W6 = nx;
+    nx = n2;
   }
   if (lane <= SR) rs[lane] = (uint16_t)my_rs;
 }
