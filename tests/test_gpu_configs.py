@@ -1,0 +1,181 @@
+"""GPU parity of BASELINE.json's configurations through the batched, device-pointer C ABI
+(vsf_extract_batch_dev / vsf_match_batch_dev / vsf_stereo_batch_dev), bit for bit against the CPU oracle:
+
+  configs[1]  640x480 stereo stream, 2000 kp/frame            -> test_stereo_batch_640
+  configs[2]  1920x1080 stereo, 8000 kp/frame                 -> test_config3_1080p_8000kp
+  configs[3]  frames sharded over ranks (one context per GPU) -> the sharding itself is covered on CPU by
+              tests/test_distributed_gloo.py; here: a batch processed as two half-batches gives identical results
+  configs[4]  temporal window of 8 frames, N x N multi-query   -> test_config5_temporal_window_multi_query
+  plus the size-independent properties of the matcher at full size (idempotence, self-match, symmetry of
+  distances) -> test_matcher_properties_full_size
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev_outputs(n_images, K, dev):
+    return (torch.zeros((n_images, K, 28), dtype=torch.uint8, device=dev),
+            torch.zeros((n_images, K, 32), dtype=torch.uint8, device=dev),
+            torch.zeros(n_images, dtype=torch.int32, device=dev))
+
+
+def _oracle_frame(oracle, left, right, nf):
+    a, b = oracle.Orb(nfeatures=nf), oracle.Orb(nfeatures=nf)
+    a.run(left)
+    b.run(right)
+    ka, da = a.result()
+    kb, db = b.result()
+    return ka, da, kb, db, oracle.get_matches(da, db)
+
+
+def _run_stereo_batch(capi, frames, nf):
+    """frames: (B, 2, h, w) uint8 -> per-image keypoints / descriptors and per-frame matches (numpy)."""
+    B, _, H, W = frames.shape
+    dev = torch.device("cuda", 0)
+    p = capi.default_params(W, H, max_images=2 * B, nfeatures=nf)
+    with capi.Context(p) as ctx:
+        K = ctx.params.max_keypoints
+        d_img = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+        d_kp, d_desc, d_counts = _dev_outputs(2 * B, K, dev)
+        d_m = torch.zeros((B, K, 16), dtype=torch.uint8, device=dev)
+        d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(),
+                             d_m.data_ptr(), d_nm.data_ptr())
+        assert ctx.sync() == capi.VSF_OK
+        kp, desc, counts = d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_counts.cpu().numpy()
+        m, nm = d_m.cpu().numpy(), d_nm.cpu().numpy()
+        ctx.set_stream(None)
+    return kp, desc, counts, m, nm
+
+
+def _check_frame(oracle, frames, f, nf, kp, desc, counts, m, nm):
+    ka, da, kb, db, rm = _oracle_frame(oracle, frames[f, 0], frames[f, 1], nf)
+    for img, (rk, rd) in ((2 * f, (ka, da)), (2 * f + 1, (kb, db))):
+        n = int(counts[img])
+        assert n == len(rk), "frame %d image %d: %d vs %d keypoints" % (f, img, n, len(rk))
+        assert kp[img, :n].tobytes() == rk.tobytes(), "frame %d image %d keypoints" % (f, img)
+        np.testing.assert_array_equal(desc[img, :n], rd, err_msg="frame %d image %d descriptors" % (f, img))
+    assert int(nm[f]) == len(rm)
+    assert m[f, :len(rm)].tobytes() == rm.tobytes(), "frame %d matches" % f
+    return len(rm)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from vision_slam_frontend_amd import capi
+    capi.lib()
+    return capi
+
+
+def test_stereo_batch_640(capi, oracle):
+    """configs[1]: the benchmarked entry point on a batch of distinct frames, every frame bit-exact."""
+    from vision_slam_frontend_amd import synth
+    frames = synth.bench_batch(6, 640, 480, seed=synth.BASE_SEED + 5, n_scenes=3)
+    out = _run_stereo_batch(capi, frames, 2000)
+    total = sum(_check_frame(oracle, frames, f, 2000, *out) for f in range(len(frames)))
+    assert total > 300
+
+
+def test_half_batches_equal_full_batch(capi):
+    """configs[3]: frames are independent, so sharding a batch (here: two half batches, as two ranks would see them)
+    changes nothing."""
+    from vision_slam_frontend_amd import synth
+    frames = synth.bench_batch(4, 640, 480, seed=synth.BASE_SEED + 9, n_scenes=2)
+    full = _run_stereo_batch(capi, frames, 2000)
+    lo = _run_stereo_batch(capi, frames[:2], 2000)
+    hi = _run_stereo_batch(capi, frames[2:], 2000)
+    for name, a, b, c in zip(("kp", "desc", "counts", "matches", "nmatches"), full, lo, hi):
+        np.testing.assert_array_equal(a, np.concatenate([b, c]), err_msg=name)
+
+
+def test_config3_1080p_8000kp(capi, oracle):
+    """configs[2]: 1920x1080, 8000 keypoints per image (wide levels: 8 FAST bands, HBM-scratch selection)."""
+    from vision_slam_frontend_amd import synth
+    left, right = synth.stereo_pair(1920, 1080, 0)
+    frames = np.stack([left, right])[None]
+    out = _run_stereo_batch(capi, frames, 8000)
+    assert int(out[2][0]) > 7000
+    n = _check_frame(oracle, frames, 0, 8000, *out)
+    assert n > 200
+
+
+def test_config5_temporal_window_multi_query(capi, oracle):
+    """configs[4]: a window of 8 frames; the newest frame's descriptors are the train set of seven query sets (the
+    reference's loop over frame_list_, slam_frontend.cc:424-434) in ONE matcher launch."""
+    from vision_slam_frontend_amd import synth
+    NF, Wn = 2000, 8
+    stream = synth.stereo_stream(Wn, 640, 480)
+    lefts = np.stack([np.asarray(f[0]) for f in stream])
+    dev = torch.device("cuda", 0)
+    p = capi.default_params(640, 480, max_images=Wn, nfeatures=NF)
+    with capi.Context(p) as ctx:
+        K = ctx.params.max_keypoints
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_img = torch.from_numpy(np.ascontiguousarray(lefts)).to(dev)
+        d_kp, d_desc, d_counts = _dev_outputs(Wn, K, dev)
+        ctx.extract_batch_dev(d_img.data_ptr(), Wn, 640 * 480, 640, d_kp.data_ptr(), d_desc.data_ptr(),
+                              d_counts.data_ptr())
+        npairs = Wn - 1
+        q_set = torch.arange(0, npairs, dtype=torch.int32, device=dev)
+        t_set = torch.full((npairs,), Wn - 1, dtype=torch.int32, device=dev)
+        d_idx = torch.zeros((npairs, K, 2), dtype=torch.int32, device=dev)
+        d_dist = torch.zeros((npairs, K, 2), dtype=torch.int32, device=dev)
+        d_m = torch.zeros((npairs, K, 16), dtype=torch.uint8, device=dev)
+        d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
+        ctx.match_batch_dev(d_desc.data_ptr(), d_counts.data_ptr(), K * 32, q_set.data_ptr(), t_set.data_ptr(), npairs,
+                            d_idx.data_ptr(), d_dist.data_ptr(), d_m.data_ptr(), d_nm.data_ptr())
+        assert ctx.sync() == capi.VSF_OK
+        desc, counts = d_desc.cpu().numpy(), d_counts.cpu().numpy()
+        idx, dist, m, nm = d_idx.cpu().numpy(), d_dist.cpu().numpy(), d_m.cpu().numpy(), d_nm.cpu().numpy()
+        ctx.set_stream(None)
+    sets = []
+    for i in range(Wn):
+        o = oracle.Orb(nfeatures=NF)
+        o.run(lefts[i])
+        _, rd = o.result()
+        n = int(counts[i])
+        assert n == len(rd)
+        np.testing.assert_array_equal(desc[i, :n], rd)
+        sets.append(rd)
+    total = 0
+    for pr in range(npairs):
+        ri, rdist = oracle.knn2_hamming(sets[pr], sets[Wn - 1])
+        nq = len(sets[pr])
+        np.testing.assert_array_equal(idx[pr, :nq], ri, err_msg="pair %d idx" % pr)
+        np.testing.assert_array_equal(dist[pr, :nq], rdist, err_msg="pair %d dist" % pr)
+        rm = oracle.get_matches(sets[pr], sets[Wn - 1])
+        assert int(nm[pr]) == len(rm)
+        assert m[pr, :len(rm)].tobytes() == rm.tobytes(), "pair %d matches" % pr
+        total += len(rm)
+    assert total > 500
+
+
+def test_matcher_properties_full_size(capi):
+    """Size-independent properties at the bench's full size (2000 x 2000, and 8000 x 8000 for configs[2]):
+    a set matched against itself finds itself at distance 0; distances are symmetric; rerunning is idempotent."""
+    from vision_slam_frontend_amd import synth
+    p = capi.default_params(640, 480, max_images=2, nfeatures=2000)
+    with capi.Context(p) as ctx:
+        for n in (2000, 8000):
+            a = synth.random_descriptors(n, seed=77)
+            b = synth.random_descriptors(n, seed=78)
+            i_self, d_self = ctx.knn2_hamming(a, a)
+            np.testing.assert_array_equal(i_self[:, 0], np.arange(n))
+            assert (d_self[:, 0] == 0).all() and (d_self[:, 1] > 0).all()
+            iab, dab = ctx.knn2_hamming(a, b)
+            iab2, dab2 = ctx.knn2_hamming(a, b)
+            np.testing.assert_array_equal(iab, iab2)
+            np.testing.assert_array_equal(dab, dab2)
+            # the reported distance is the true Hamming distance of the reported pair
+            x = np.unpackbits(a ^ b[iab[:, 0]], axis=1).sum(1)
+            np.testing.assert_array_equal(x, dab[:, 0])
+            # nobody is closer than the reported nearest neighbour (checked on a sample of rows)
+            for r in range(0, n, max(1, n // 16)):
+                dd = np.unpackbits(a[r][None] ^ b, axis=1).sum(1)
+                assert dd.min() == dab[r, 0] and np.sort(dd)[1] == dab[r, 1]
+                assert iab[r, 0] == int(np.flatnonzero(dd == dd.min())[0])
