@@ -83,6 +83,7 @@ def main() -> int:
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches per step (vsf_set_lanes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
@@ -133,6 +134,7 @@ def main() -> int:
         }
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_lanes(args.lanes)
 
     def step():
         ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(),

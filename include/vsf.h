@@ -98,6 +98,10 @@ int vsf_last_hip_error(const vsf_ctx* ctx);
 vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out);
 /* Use an existing hipStream_t (e.g. the caller's framework stream) instead of the context's own. NULL restores it. */
 vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream);
+/* Batched entry points split a batch in `lanes` halves (1 or 2, default 1) that run concurrently: one on the context's
+ * stream, one on an internal stream forked from / joined back into it with events, so the caller still sees ONE
+ * stream-ordered operation.  Frames are independent (slam_frontend.cc:411-416), results do not depend on it. */
+vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
 
@@ -132,7 +136,7 @@ vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_imag
                                  size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts);
 /* knnMatch(k=2) + ratio test for n_pairs (query set, train set) pairs.  Set s of a descriptor array starts
  * at base + s*set_stride bytes and holds d_n*[s] rows.  pair p matches query set q_set[p] against train set
- * t_set[p] (device int32 arrays; NULL means q_set[p] = 2p, t_set[p] = 2p+1: left vs right of stereo frame p).
+ * t_set[p] (device int32 arrays; both NULL means q_set[p] = 2p, t_set[p] = 2p+1: left vs right of stereo frame p).
  * Outputs per pair: d_idx2/d_dist2 [n_pairs][max_keypoints][2] (may be NULL), d_matches
  * [n_pairs][max_keypoints], d_nmatches [n_pairs]. */
 vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,

@@ -32,7 +32,7 @@ def _oracle_frame(oracle, left, right, nf):
     return ka, da, kb, db, oracle.get_matches(da, db)
 
 
-def _run_stereo_batch(capi, frames, nf):
+def _run_stereo_batch(capi, frames, nf, lanes=1):
     """frames: (B, 2, h, w) uint8 -> per-image keypoints / descriptors and per-frame matches (numpy)."""
     B, _, H, W = frames.shape
     dev = torch.device("cuda", 0)
@@ -44,6 +44,7 @@ def _run_stereo_batch(capi, frames, nf):
         d_m = torch.zeros((B, K, 16), dtype=torch.uint8, device=dev)
         d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_lanes(lanes)
         ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(),
                              d_m.data_ptr(), d_nm.data_ptr())
         assert ctx.sync() == capi.VSF_OK
@@ -91,6 +92,10 @@ def test_half_batches_equal_full_batch(capi):
     hi = _run_stereo_batch(capi, frames[2:], 2000)
     for name, a, b, c in zip(("kp", "desc", "counts", "matches", "nmatches"), full, lo, hi):
         np.testing.assert_array_equal(a, np.concatenate([b, c]), err_msg=name)
+    # ... and so does running the two halves concurrently on the context's two lanes (vsf_set_lanes)
+    two = _run_stereo_batch(capi, frames, 2000, lanes=2)
+    for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), full, two):
+        np.testing.assert_array_equal(a, b, err_msg="lanes=2 " + name)
 
 
 def test_config3_1080p_8000kp(capi, oracle):

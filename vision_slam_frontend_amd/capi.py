@@ -26,7 +26,7 @@ EXPORTS = [
     "vsf_params_default", "vsf_params_set_ratio", "vsf_create", "vsf_destroy", "vsf_status_string",
     "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_batch_dev", "vsf_match_batch_dev",
-    "vsf_stereo_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
+    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best",
 ]
@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
         L.vsf_extract_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp]
         L.vsf_match_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp, vp, vp]
         L.vsf_stereo_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp, vp, vp]
+        L.vsf_set_lanes.argtypes = [vp, i32]
         L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
         L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
         L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
@@ -172,6 +173,9 @@ class Context:
 
     def set_stream(self, hip_stream: int | None):
         self._check(lib().vsf_set_stream(self._h, C.c_void_p(hip_stream or 0)), "vsf_set_stream")
+
+    def set_lanes(self, lanes: int):
+        self._check(lib().vsf_set_lanes(self._h, lanes), "vsf_set_lanes")
 
     def sync(self, allow_capacity: bool = False) -> int:
         return self._check(lib().vsf_sync(self._h), "vsf_sync", allow_capacity)

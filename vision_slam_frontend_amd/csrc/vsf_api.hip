@@ -248,6 +248,11 @@ struct vsf_ctx {
   vsf_params p{};
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  // Second lane of the batched entry points: half of a batch runs on `stream`, the other half on `aux_stream`
+  // (frames are independent), so latency-bound stages of one half overlap VALU-bound stages of the other.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int last_hip = 0;
   Geometry orb, fast;
   DevSet dorb, dfast;
@@ -407,10 +412,12 @@ struct StageTimer {  // records an event pair around one stage when profiling is
   vsf_ctx* ctx;
   size_t slot = 0;
   bool on;
-  StageTimer(vsf_ctx* c, int stage, int launches) : ctx(c), on(c->prof_on) {
+  hipStream_t st;
+  StageTimer(vsf_ctx* c, hipStream_t stream, int stage, int launches) : ctx(c), on(c->prof_on), st(stream) {
     if (!on) return;
     if (ctx->ev_used >= 2048) {
       (void)hipStreamSynchronize(ctx->stream);
+      (void)hipStreamSynchronize(ctx->aux_stream);
       prof_fold(ctx);
     }
     slot = ctx->ev_used++;
@@ -425,36 +432,124 @@ struct StageTimer {  // records an event pair around one stage when profiling is
     }
     ctx->ev_stage[slot] = stage;
     ctx->ev_launches[slot] = launches;
-    (void)hipEventRecord(ctx->ev_pool[2 * slot], ctx->stream);
+    (void)hipEventRecord(ctx->ev_pool[2 * slot], st);
   }
   ~StageTimer() {
-    if (on) (void)hipEventRecord(ctx->ev_pool[2 * slot + 1], ctx->stream);
+    if (on) (void)hipEventRecord(ctx->ev_pool[2 * slot + 1], st);
   }
 };
 
-vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
-  const VsfDev& d = ctx->dorb.d;
+// The per-image work buffers of images [i0, i0 + n) seen as a batch of their own.
+VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
+  VsfDev o = d;
+  const size_t i = (size_t)i0;
+  if (o.pyr) o.pyr += i * g.pyr_bytes;
+  if (o.blur) o.blur += i * g.pyr_bytes;
+  o.cand += i * g.cand_entries;
+  o.rowstart += i * (size_t)g.nunits * VSF_FAST_RS_STRIDE;
+  if (o.scratch) o.scratch += i * 3 * g.cand_entries;
+  if (o.lvlkp) o.lvlkp += i * g.lvlkp_entries;
+  if (o.lvl_count) o.lvl_count += i * g.nlevels;
+  return o;
+}
+
+// detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.
+void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp,
+                uint8_t* d_desc, int32_t* d_counts) {
   const VsfGeom& g = ctx->orb.g;
+  const VsfDev d = shifted(ctx->dorb.d, g, i0);
+  VsfImages im = im_all;
+  im.base += (size_t)i0 * im.image_stride;
+  im.n = n;
+  const size_t K = (size_t)ctx->p.max_keypoints;
   {
-    StageTimer t(ctx, VSF_STAGE_PYRAMID, g.nlevels - 1);
-    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ctx->stream);
+    StageTimer t(ctx, st, VSF_STAGE_PYRAMID, g.nlevels - 1);
+    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st);
   }
   {
-    StageTimer t(ctx, VSF_STAGE_FAST, 1);
-    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, ctx->stream);
+    StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
+    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st);
   }
   {
-    StageTimer t(ctx, VSF_STAGE_SELECT, 1);
-    vsf_launch_select(d, g, ctx->orb.levels.data(), im, ctx->stream);
+    StageTimer t(ctx, st, VSF_STAGE_SELECT, 1);
+    vsf_launch_select(d, g, ctx->orb.levels.data(), im, st);
   }
   {
-    StageTimer t(ctx, VSF_STAGE_BLUR, 1);
-    vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, ctx->stream);
+    StageTimer t(ctx, st, VSF_STAGE_BLUR, 1);
+    vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, st);
   }
   {
-    StageTimer t(ctx, VSF_STAGE_DESCRIBE, 1);
-    vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp, d_desc, d_counts, ctx->stream);
+    StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);
+    vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp + i0 * K, d_desc + i0 * K * VSF_DESC_BYTES, d_counts + i0,
+                        st);
   }
+}
+
+// knnMatch(k = 2) + ratio test for pairs [p0, p0 + n) on stream `st`.
+void match_on(vsf_ctx* ctx, hipStream_t st, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
+              const int32_t* d_q_set, const int32_t* d_t_set, int p0, int n, int32_t* d_idx2, int32_t* d_dist2,
+              vsf_dmatch* d_matches, int32_t* d_nmatches) {
+  const int rows = ctx->p.max_keypoints;
+  const size_t R = (size_t)rows;
+  // implicit pairing (set 2p vs 2p + 1) is relative to the descriptor base: shift the base instead of the indices
+  const uint8_t* desc = d_desc;
+  const int32_t* counts = d_counts;
+  if (!d_q_set) {
+    desc += (size_t)(2 * p0) * set_stride;
+    counts += 2 * p0;
+  }
+  int32_t* idx2 = d_idx2 + (size_t)p0 * R * 2;
+  int32_t* dist2 = d_dist2 + (size_t)p0 * R * 2;
+  {
+    StageTimer t(ctx, st, VSF_STAGE_KNN2, 1);
+    vsf_launch_knn2(desc, counts, set_stride, d_q_set ? d_q_set + p0 : nullptr, d_t_set ? d_t_set + p0 : nullptr, n,
+                    rows, idx2, dist2, st);
+  }
+  {
+    StageTimer t(ctx, st, VSF_STAGE_RATIO, 1);
+    vsf_launch_ratio_compact(counts, d_q_set ? d_q_set + p0 : nullptr, d_t_set ? d_t_set + p0 : nullptr, n, rows, idx2,
+                             dist2, ctx->p.ratio_num, ctx->p.ratio_shift, d_matches + (size_t)p0 * R, d_nmatches + p0,
+                             ctx->d_status, st);
+  }
+}
+
+// Opens / closes the second lane: work queued on aux_stream between fork and join is ordered after everything
+// already on `stream` and before everything queued on it afterwards.
+vsf_status fork_lane(vsf_ctx* ctx) {
+  VSF_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  VSF_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+  return VSF_OK;
+}
+vsf_status join_lane(vsf_ctx* ctx) {
+  VSF_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+  VSF_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return VSF_OK;
+}
+
+// Runs body(stream, first, count) over `units` work items (images or stereo frames): all on the context's stream, or
+// (vsf_set_lanes(ctx, 2)) as two halves on the two lanes.  Measured on MI355X: the stages are either VALU-bound
+// (FAST, blur) or latency-bound, and a VALU-bound kernel at full occupancy leaves no registers for a second kernel's
+// waves, so the second lane only fills launch gaps and tails (+5 % frames/s) while every kernel's own duration
+// roughly doubles; one lane stays the default.
+template <class Body>
+vsf_status run_chunked(vsf_ctx* ctx, int units, Body body) {
+  if (ctx->lanes < 2 || units < 2) {
+    body(ctx->stream, 0, units);
+    return VSF_OK;
+  }
+  vsf_status st = fork_lane(ctx);
+  if (st != VSF_OK) return st;
+  const int n0 = (units + 1) / 2;
+  body(ctx->stream, 0, n0);
+  body(ctx->aux_stream, n0, units - n0);
+  return join_lane(ctx);
+}
+
+vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
+  vsf_status st = run_chunked(ctx, im.n, [&](hipStream_t s, int i0, int n) {
+    extract_on(ctx, s, im, i0, n, d_kp, d_desc, d_counts);
+  });
+  if (st != VSF_OK) return st;
   ctx->last_images = im;
   ctx->last_valid = true;
   VSF_HIP(hipGetLastError());
@@ -544,6 +639,10 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
   gaussian_taps(ctx->gauss);
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(VSF_ERR_HIP);
   ctx->stream = ctx->own_stream;
+  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+    return fail(VSF_ERR_HIP);
   if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipHostMalloc((void**)&ctx->h_status, sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
@@ -568,6 +667,7 @@ void vsf_destroy(vsf_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
+  if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
   free_devset(&ctx->dorb);
   free_devset(&ctx->dfast);
   hipFree(ctx->d_status);
@@ -583,6 +683,9 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->mh_matches);
   hipFree(ctx->mh_nmatches);
   for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -600,6 +703,13 @@ vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream) {
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   prof_fold(ctx);
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return VSF_OK;
+}
+
+vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes) {
+  if (!ctx || lanes < 1 || lanes > 2) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->lanes = lanes;
   return VSF_OK;
 }
 
@@ -649,7 +759,8 @@ vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_
                                int32_t* d_dist2, vsf_dmatch* d_matches, int32_t* d_nmatches) {
   if (!ctx || !d_desc || !d_counts || n_pairs < 1 || !d_matches || !d_nmatches || (set_stride & 15))
     return VSF_ERR_INVALID_ARG;
-  if ((d_idx2 == nullptr) != (d_dist2 == nullptr)) return VSF_ERR_INVALID_ARG;
+  if ((d_idx2 == nullptr) != (d_dist2 == nullptr) || (d_q_set == nullptr) != (d_t_set == nullptr))
+    return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   const int rows = ctx->p.max_keypoints;
   if (!d_idx2) {
@@ -658,15 +769,10 @@ vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_
     d_idx2 = ctx->m_idx2;
     d_dist2 = ctx->m_dist2;
   }
-  {
-    StageTimer t(ctx, VSF_STAGE_KNN2, 1);
-    vsf_launch_knn2(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->stream);
-  }
-  {
-    StageTimer t(ctx, VSF_STAGE_RATIO, 1);
-    vsf_launch_ratio_compact(d_counts, d_q_set, d_t_set, n_pairs, rows, d_idx2, d_dist2, ctx->p.ratio_num,
-                             ctx->p.ratio_shift, d_matches, d_nmatches, ctx->d_status, ctx->stream);
-  }
+  vsf_status st = run_chunked(ctx, n_pairs, [&](hipStream_t s, int p0, int n) {
+    match_on(ctx, s, d_desc, d_counts, set_stride, d_q_set, d_t_set, p0, n, d_idx2, d_dist2, d_matches, d_nmatches);
+  });
+  if (st != VSF_OK) return st;
   VSF_HIP(hipGetLastError());
   return VSF_OK;
 }
@@ -703,11 +809,24 @@ const char* vsf_stage_name(int stage) {
 vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frames, size_t image_stride,
                                 size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
                                 vsf_dmatch* d_matches, int32_t* d_nmatches) {
-  if (!ctx || n_frames < 1) return VSF_ERR_INVALID_ARG;
-  vsf_status st = vsf_extract_batch_dev(ctx, d_imgs, 2 * n_frames, image_stride, row_stride, d_kp, d_desc, d_counts);
+  if (!ctx || n_frames < 1 || !d_kp || !d_desc || !d_counts || !d_matches || !d_nmatches) return VSF_ERR_INVALID_ARG;
+  vsf_status st = validate_images(ctx, d_imgs, 2 * n_frames, image_stride, row_stride);
   if (st != VSF_OK) return st;
-  return vsf_match_batch_dev(ctx, d_desc, d_counts, (size_t)ctx->p.max_keypoints * VSF_DESC_BYTES, nullptr, nullptr,
-                             n_frames, nullptr, nullptr, d_matches, d_nmatches);
+  VSF_HIP(hipSetDevice(ctx->device));
+  st = ensure_match_buffers(ctx, n_frames, ctx->p.max_keypoints);
+  if (st != VSF_OK) return st;
+  const VsfImages im{d_imgs, image_stride, row_stride, 2 * n_frames};
+  const size_t set_stride = (size_t)ctx->p.max_keypoints * VSF_DESC_BYTES;
+  st = run_chunked(ctx, n_frames, [&](hipStream_t s, int fa, int nf) {
+    extract_on(ctx, s, im, 2 * fa, 2 * nf, d_kp, d_desc, d_counts);
+    match_on(ctx, s, d_desc, d_counts, set_stride, nullptr, nullptr, fa, nf, ctx->m_idx2, ctx->m_dist2, d_matches,
+             d_nmatches);
+  });
+  if (st != VSF_OK) return st;
+  ctx->last_images = im;
+  ctx->last_valid = true;
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
 }
 
 // ---------------- host-pointer entry points ----------------
