@@ -17,7 +17,8 @@
 //     partner (k-th right-stopper from the right) by rank -> position select on the mask and swaps,
 //   * the split point follows from the first non-participating stoppers.
 // Pivot choice (median of first+1 / mid / last-1), the depth limit, the heap-select fallback and the final
-// insertion sort are the sequential restatement of vsf_select.h, run by one lane on ranges <= 48 elements.
+// insertion sort are the sequential restatement of vsf_select.h; ranges <= 256 elements are finished by a single
+// wave (ballot masks in SGPRs, no workgroup barriers), the rare depth-limit / heap-select case by one lane.
 // The arrays live in LDS when they fit and in an HBM scratch area otherwise.
 #include "vsf_gather.h"
 #include "vsf_internal.h"
@@ -64,7 +65,7 @@ struct RespGe {
   }
 };
 
-constexpr int kSerialCutoff = 48;
+constexpr int kWaveCutoff = 256;  // ranges up to this size are finished by ONE wave without workgroup barriers
 
 // LDS scratch of the parallel passes. MAXW mask words cover MAXW * 64 elements.
 template <int MAXW>
@@ -231,6 +232,101 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
   __syncthreads();
 }
 
+// ---- single-wave versions for ranges of <= kWaveCutoff elements (4 per lane) ----
+// Same Hoare pass as above, but the stopper masks are four 64-bit ballots held in scalar registers, ranks are
+// v_mbcnt prefix counts and nothing needs a workgroup barrier.  All 64 lanes of ONE wave call these.
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int select_rank4(const unsigned long long (&m)[4], const int (&pre)[5], int t) {
+  const int w = (t >= pre[1]) + (t >= pre[2]) + (t >= pre[3]);
+  const unsigned long long mk = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+  const int p = w == 0 ? pre[0] : w == 1 ? pre[1] : w == 2 ? pre[2] : pre[3];
+  return w * 64 + select64(mk, t - p);
+}
+
+// One pass over A[lo, hi), hi - lo <= 256.  Returns (uniform) the swap count K, the stopper totals and `cut`.
+template <class T, class FL, class FR>
+__device__ __forceinline__ void wave_hoare_pass(T* A, int lo, int hi, FL fl, FR fr, int& totalR, int& cut) {
+  const int lane = threadIdx.x & 63;
+  const int m = hi - lo;
+  const unsigned long long lt = (1ull << lane) - 1ull, le = (2ull << lane) - 1ull;
+  unsigned long long mL[4], mR[4];
+  T x[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = e * 64 + lane;
+    bool l = false, r = false;
+    if (i < m) {
+      x[e] = A[lo + i];
+      l = fl(x[e]);
+      r = fr(x[e]);
+    }
+    mL[e] = __ballot(l);
+    mR[e] = __ballot(r);
+  }
+  int preL[5], preR[5];
+  preL[0] = preR[0] = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    preL[e + 1] = preL[e] + __popcll(mL[e]);
+    preR[e + 1] = preR[e] + __popcll(mR[e]);
+  }
+  const int totalL = preL[4];
+  totalR = preR[4];
+  int K = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool is_l = (mL[e] >> lane) & 1ull;
+    const int k = preL[e] + __popcll(mL[e] & lt) + 1;    // 1-based rank from the left
+    const int r_le = preR[e] + __popcll(mR[e] & le);     // right-stoppers at <= i
+    const bool part = is_l && (totalR - r_le >= k);
+    if (part) {
+      const int j = select_rank4(mR, preR, totalR - k);
+      const T xj = A[lo + j];
+      A[lo + e * 64 + lane] = xj;
+      A[lo + j] = x[e];
+    }
+    K += __popcll(__ballot(part));
+  }
+  const int aK1 = K < totalL ? select_rank4(mL, preL, K) : 0x7FFFFFFF;
+  const int bK = K > 0 ? select_rank4(mR, preR, totalR - K) : 0x7FFFFFFF;
+  cut = (K < totalL && (K == 0 || aK1 < bK)) ? lo + aK1 : lo + bK;
+  wave_fence();
+}
+
+// std::__introselect continued from (first, last, depth) on a range of <= kWaveCutoff elements.
+template <class T, class Greater>
+__device__ void wave_introselect(T* A, int first, int last, int nth, int depth, Greater greater) {
+  const int lane = threadIdx.x & 63;
+  while (last - first > 3) {
+    if (depth == 0) {
+      if (lane == 0) {
+        vsf_sel::heap_select_(A, first, nth + 1, last, greater);
+        vsf_sel::swap_(A[first], A[nth]);
+      }
+      wave_fence();
+      return;
+    }
+    --depth;
+    if (lane == 0) vsf_sel::move_median_to_first_(A, first, first + 1, first + (last - first) / 2, last - 1, greater);
+    wave_fence();
+    const T pivot = A[first];
+    int total_r, cut;
+    wave_hoare_pass(
+        A, first + 1, last, [&](const T& x) { return !greater(x, pivot); },
+        [&](const T& x) { return !greater(pivot, x); }, total_r, cut);
+    if (cut <= nth)
+      first = cut;
+    else
+      last = cut;
+  }
+  if (lane == 0) vsf_sel::insertion_sort_(A, first, last, greater);
+  wave_fence();
+}
+
 // std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
 template <int NT, int MAXW, class T, class Greater>
 __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScratch<MAXW>& s) {
@@ -244,7 +340,7 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
   __syncthreads();
   while (true) {
     const int first = s.st[0], last = s.st[1], depth = s.st[2];
-    if (last - first <= kSerialCutoff || depth == 0 || last - first - 1 > MAXW * 64) break;
+    if (last - first <= kWaveCutoff || depth == 0 || last - first - 1 > MAXW * 64) break;
     if (tid == 0) {
       const int mid = first + (last - first) / 2;
       vsf_sel::move_median_to_first_(A, first, first + 1, mid, last - 1, greater);
@@ -264,7 +360,13 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
     }
     __syncthreads();
   }
-  if (tid == 0) vsf_sel::introselect_from_(A, s.st[0], s.st[1], nth, s.st[2], greater);
+  if (tid < 64) {  // wave 0 finishes the range; the other waves wait at the barrier
+    const int first = s.st[0], last = s.st[1], depth = s.st[2];
+    if (last - first <= kWaveCutoff)
+      wave_introselect(A, first, last, nth, depth, greater);
+    else if (tid == 0)  // depth limit hit on a large range (heap select), or a range beyond the mask scratch
+      vsf_sel::introselect_from_(A, first, last, nth, depth, greater);
+  }
   __syncthreads();
 }
 
@@ -272,8 +374,18 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
 template <int NT, int MAXW, class T, class Pred>
 __device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>& s) {
   const int tid = threadIdx.x;
-  if (hi - lo <= kSerialCutoff || hi - lo > MAXW * 64) {
-    if (tid == 0) s.st[4] = vsf_sel::partition_(A, lo, hi, pred);
+  if (hi - lo <= kWaveCutoff || hi - lo > MAXW * 64) {
+    if (tid < 64) {
+      if (hi - lo <= kWaveCutoff) {
+        int total_r = 0, cut = 0;
+        if (hi > lo)
+          wave_hoare_pass(
+              A, lo, hi, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, total_r, cut);
+        if (tid == 0) s.st[4] = lo + total_r;
+      } else if (tid == 0) {
+        s.st[4] = vsf_sel::partition_(A, lo, hi, pred);
+      }
+    }
     __syncthreads();
     const int r = s.st[4];
     __syncthreads();
