@@ -11,7 +11,8 @@
 //    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window (seven
 //    rotating register sets, no copies) and gets its neighbours' dwords by DPP wave shifts;
 //  * corner test and score are ONE dense computation: with d_k = p_k - v on the 16-pixel circle,
-//      A = max over the 16 arcs of min(d over the 9-arc),  B = -min over arcs of max(d over the arc),
+//      A = max over the 16 arcs of min(d over the 9-arc),  B = -min over arcs of max(d over the arc)
+//    (computed on the p_k, v subtracted once at the end),
 //    the pixel is a FAST-9 corner iff max(A, B) > t and cornerScore is max(A, B) - 1.  Two pixels are processed per
 //    VALU lane-op with packed 16-bit min/max (v_pk_min_i16 / v_pk_max_i16); circle bytes are pulled out of the
 //    window with v_perm_b32.  The 16 arc minima come from prefix/suffix minima of the two circle halves (an arc
@@ -80,25 +81,25 @@ template <int J0>
 __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3,
                                           const Row3& R4, const Row3& R5, const Row3& R6, v2s tt, int nms) {
   const v2s v = pick2<4 + J0>(R3);
-  v2s d[16];
+  v2s d[16];  // circle pixels p_k; min / max commute with the subtraction of v, which is applied once at the end
   // Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
   // (-3,0)(-3,1)(-2,2)(-1,3); window row = R[3 + dy].
-  d[0] = pick2<4 + J0 + 0>(R6) - v;
-  d[1] = pick2<4 + J0 + 1>(R6) - v;
-  d[2] = pick2<4 + J0 + 2>(R5) - v;
-  d[3] = pick2<4 + J0 + 3>(R4) - v;
-  d[4] = pick2<4 + J0 + 3>(R3) - v;
-  d[5] = pick2<4 + J0 + 3>(R2) - v;
-  d[6] = pick2<4 + J0 + 2>(R1) - v;
-  d[7] = pick2<4 + J0 + 1>(R0) - v;
-  d[8] = pick2<4 + J0 + 0>(R0) - v;
-  d[9] = pick2<4 + J0 - 1>(R0) - v;
-  d[10] = pick2<4 + J0 - 2>(R1) - v;
-  d[11] = pick2<4 + J0 - 3>(R2) - v;
-  d[12] = pick2<4 + J0 - 3>(R3) - v;
-  d[13] = pick2<4 + J0 - 3>(R4) - v;
-  d[14] = pick2<4 + J0 - 2>(R5) - v;
-  d[15] = pick2<4 + J0 - 1>(R6) - v;
+  d[0] = pick2<4 + J0 + 0>(R6);
+  d[1] = pick2<4 + J0 + 1>(R6);
+  d[2] = pick2<4 + J0 + 2>(R5);
+  d[3] = pick2<4 + J0 + 3>(R4);
+  d[4] = pick2<4 + J0 + 3>(R3);
+  d[5] = pick2<4 + J0 + 3>(R2);
+  d[6] = pick2<4 + J0 + 2>(R1);
+  d[7] = pick2<4 + J0 + 1>(R0);
+  d[8] = pick2<4 + J0 + 0>(R0);
+  d[9] = pick2<4 + J0 - 1>(R0);
+  d[10] = pick2<4 + J0 - 2>(R1);
+  d[11] = pick2<4 + J0 - 3>(R2);
+  d[12] = pick2<4 + J0 - 3>(R3);
+  d[13] = pick2<4 + J0 - 3>(R4);
+  d[14] = pick2<4 + J0 - 2>(R5);
+  d[15] = pick2<4 + J0 - 1>(R6);
   // Arc k = d[k .. k+8] (indices mod 16).  With halves H0 = d[0..7], H1 = d[8..15]:
   //   arc k     (k < 8) = suffix of H0 from k  +  prefix of H1 up to k
   //   arc 8 + k         = suffix of H1 from k  +  prefix of H0 up to k
@@ -131,8 +132,8 @@ __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const 
   // cornerScore<16> = max(t, A, -Bm) - 1; a corner iff that maximum exceeds t.  With NMS a corner of score 0 can
   // never win (cv::FAST_t compares strictly against neighbours >= 0); without NMS only a corner marker is kept
   // (cv::FAST_t leaves the response at 0 then).
-  const v2s zero = {0, 0}, one = {1, 1};
-  const v2s sc = vmax(A, zero - Bm);
+  const v2s one = {1, 1};
+  const v2s sc = vmax(A - v, v - Bm);
   const v2s m = (tt - sc) >> 15;  // all ones where sc > t
   return nms ? ((sc - one) & m) : (m & one);
 }
