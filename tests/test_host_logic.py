@@ -31,6 +31,18 @@ def capi():
     return capi
 
 
+def test_describe_sincos_matches_libm(tmp_path):
+    """k_describe.hip's sincos_2pi (restated for the host, same arithmetic) against libm's cos/sin rounded to float
+    on a strided subset of all float angles in [0, 360]; stride 1 (every float, ~60 s) was run by hand: 0 mismatches
+    over 1 135 869 953 values."""
+    exe = tmp_path / "test_sincos"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe),
+                           str(ROOT / "tests" / "cpp" / "test_sincos_exhaustive.c"), "-lm"])
+    out = subprocess.run([str(exe), "257"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0" in out.stdout
+
+
 def test_library_exports_every_declared_symbol(capi):
     header = (ROOT / "include" / "vsf.h").read_text()
     declared = set(re.findall(r"\b(vsf_[a-z0-9_]+)\s*\(", header))

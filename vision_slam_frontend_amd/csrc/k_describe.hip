@@ -68,6 +68,36 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+// cos / sin of x in [0, 2 pi + eps] in double precision, error < 1 ulp(double) (the reference takes the libm value
+// and rounds it to float): Cody-Waite reduction by multiples of pi/2 (k <= 5, so two constant terms are
+// exact to ~1e-33 relative to k) and the fdlibm __kernel_sin / __kernel_cos minimax polynomials on [-pi/4, pi/4].
+// Hand-rolled instead of the device libm's sin()/cos() because those carry a Payne-Hanek path whose registers
+// (106 VGPRs for this kernel) halve the occupancy of a latency-bound kernel.
+__device__ __forceinline__ void sincos_2pi(double x, double* s_out, double* c_out) {
+  const double two_over_pi = 6.36619772367581382433e-01;
+  const double pio2_hi = 1.57079632679489655800e+00;  // first 53 bits of pi/2
+  const double pio2_lo = 6.12323399573676603587e-17;  // pi/2 - pio2_hi
+  const double kd = __builtin_rint(x * two_over_pi);
+  const int k = (int)kd;
+  const double r = __builtin_fma(-kd, pio2_lo, __builtin_fma(-kd, pio2_hi, x));
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2), S1);
+  const double sr = __builtin_fma(z * r, ps, r);
+  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+  // quadrant: x = r + k pi/2
+  const bool swap = k & 1;
+  const double sv = swap ? cr : sr, cv = swap ? sr : cr;
+  *s_out = (k & 2) ? -sv : sv;
+  *c_out = ((k + 1) & 2) ? -cv : cv;
+}
+
 __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
   const int level = blockIdx.x / kSplit, part = blockIdx.x - level * kSplit, image = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -110,67 +140,103 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
     item_off[it] = r * rpitch + 4 * j;
     item_v[it] = r - 15;
   }
-  for (int i = part * 4 + wid; i < n; i += 4 * kSplit) {
-    const int o = before + i;
-    if (o >= a.max_keypoints) break;
-    const VsfLevelKp k = kps[i];
-    const int x0 = (int)(k.xy & 0xFFFu), y0 = (int)(k.xy >> 12);
-    // ---- K6: intensity-centroid angle on the unblurred level ----
-    const int xs = x0 - 15;
-    const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
-    const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS + lane;
-    int m10 = 0, m01 = 0;
+  // A wave owns keypoints i = first + 4 * kSplit * k, k < 64 per round.  Round = three passes, so that the double
+  // precision cos / sin (the expensive, wave-uniform part of a keypoint) is evaluated ONCE per round with lane k
+  // working on keypoint k, instead of 64-fold redundantly once per keypoint:
+  //   pass 1  per keypoint: K6 moments + fastAtan2 (wave-wide reduction), lane k keeps angle / position
+  //   pass 2  lane k: cos / sin of keypoint k
+  //   pass 3  per keypoint: broadcast its cos / sin (v_readlane), K8 descriptor, outputs
+  // this lane's four pattern pairs (loop invariant)
+  float pat[4][4];
 #pragma unroll
-    for (int it = 0; it < 5; it++) {
-      const uint32_t px = *reinterpret_cast<const uint32_t*>(abase + item_off[it]);
-      const uint2 t = tab[it * 64];
-      const int sw = (int)__builtin_amdgcn_udot4(px, t.x, 0u, false);
-      const int sm = (int)__builtin_amdgcn_udot4(px, t.y, 0u, false);
-      m10 += sw - 16 * sm;
-      m01 += item_v[it] * sm;
-    }
+  for (int j = 0; j < 4; j++) {
+    const int pair = lane + 64 * j;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      m10 += __shfl_xor(m10, off, 64);
-      m01 += __shfl_xor(m01, off, 64);
+    for (int c = 0; c < 4; c++) pat[j][c] = (float)c_pattern31[4 * pair + c];
+  }
+  const int stride = 4 * kSplit;
+  for (int base = part * 4 + wid; base < n; base += 64 * stride) {
+    const int cnt = min(64, (n - base + stride - 1) / stride);  // keypoints of this round (wave-uniform)
+    float my_angle = 0.f;
+    uint32_t my_xy = 0;
+    float my_resp = 0.f;
+    for (int kk = 0; kk < cnt; kk++) {
+      const int i = base + kk * stride;
+      const VsfLevelKp k = kps[i];
+      const int x0 = (int)(k.xy & 0xFFFu), y0 = (int)(k.xy >> 12);
+      // ---- K6: intensity-centroid angle on the unblurred level ----
+      const int xs = x0 - 15;
+      const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
+      const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS + lane;
+      int m10 = 0, m01 = 0;
+#pragma unroll
+      for (int it = 0; it < 5; it++) {
+        const uint32_t px = *reinterpret_cast<const uint32_t*>(abase + item_off[it]);
+        const uint2 t = tab[it * 64];
+        const int sw = (int)__builtin_amdgcn_udot4(px, t.x, 0u, false);
+        const int sm = (int)__builtin_amdgcn_udot4(px, t.y, 0u, false);
+        m10 += sw - 16 * sm;
+        m01 += item_v[it] * sm;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off, 64);
+        m01 += __shfl_xor(m01, off, 64);
+      }
+      const float kp_angle = fast_atan2_deg((float)m01, (float)m10);
+      if (lane == kk) {
+        my_angle = kp_angle;
+        my_xy = k.xy;
+        my_resp = k.response;
+      }
     }
-    const float kp_angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- K8: rotated BRIEF on the blurred level ----
-    const float fx = (float)x0 * lscale;  // KeyPoint::pt *= scale
-    const float fy = (float)y0 * lscale;
-    float angle = kp_angle;
-    angle *= (float)(3.14159265358979323846 / 180.f);
+    // ---- cos / sin, one keypoint per lane ----
     // cos/sin of the float angle taken as the correctly rounded float (double evaluation).
-    const float ca = (float)cos((double)angle), sb = (float)sin((double)angle);
-    const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
-    const uint8_t* center = img + (size_t)cy * pitch + cx;
-    uint64_t w[4];
+    const float my_rad = my_angle * (float)(3.14159265358979323846 / 180.f);
+    double sd, cd;
+    sincos_2pi((double)my_rad, &sd, &cd);
+    const float my_ca = (float)cd, my_sb = (float)sd;
+    // ---- K8: rotated BRIEF on the blurred level ----
+    for (int kk = 0; kk < cnt; kk++) {
+      const int i = base + kk * stride;
+      const int o = before + i;
+      if (o >= a.max_keypoints) break;
+      const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), kk));
+      const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sb), kk));
+      const float kp_angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_angle), kk));
+      const float resp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_resp), kk));
+      const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)my_xy, kk);
+      const int x0 = (int)(xy & 0xFFFu), y0 = (int)(xy >> 12);
+      const float fx = (float)x0 * lscale;  // KeyPoint::pt *= scale
+      const float fy = (float)y0 * lscale;
+      const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
+      const uint8_t* center = img + (size_t)cy * pitch + cx;
+      uint64_t w[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int pair = lane + 64 * j;
-      const float x0f = (float)c_pattern31[4 * pair + 0], y0f = (float)c_pattern31[4 * pair + 1];
-      const float x1f = (float)c_pattern31[4 * pair + 2], y1f = (float)c_pattern31[4 * pair + 3];
-      const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
-      const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
-      const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
-      w[j] = __ballot(t0 < t1);
+      for (int j = 0; j < 4; j++) {
+        const float x0f = pat[j][0], y0f = pat[j][1], x1f = pat[j][2], y1f = pat[j][3];
+        const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
+        const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
+        const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
+        w[j] = __ballot(t0 < t1);
+      }
+      if (lane < 4) {
+        const uint64_t v = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
+        reinterpret_cast<uint64_t*>(a.desc_out + ((size_t)image * a.max_keypoints + o) * VSF_DESC_BYTES)[lane] = v;
+      }
+      if (lane == 4) {
+        vsf_keypoint kp;
+        kp.x = fx;
+        kp.y = fy;
+        kp.size = 31 * lscale;
+        kp.angle = kp_angle;
+        kp.response = resp;
+        kp.octave = level;
+        kp.class_id = -1;
+        a.kp_out[(size_t)image * a.max_keypoints + o] = kp;
+      }
+      if (lane == 5) kps[i].angle = kp_angle;  // kept for vsf_debug_level_keypoints
     }
-    if (lane < 4) {
-      const uint64_t v = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
-      reinterpret_cast<uint64_t*>(a.desc_out + ((size_t)image * a.max_keypoints + o) * VSF_DESC_BYTES)[lane] = v;
-    }
-    if (lane == 4) {
-      vsf_keypoint kp;
-      kp.x = fx;
-      kp.y = fy;
-      kp.size = 31 * lscale;
-      kp.angle = kp_angle;
-      kp.response = k.response;
-      kp.octave = level;
-      kp.class_id = -1;
-      a.kp_out[(size_t)image * a.max_keypoints + o] = kp;
-    }
-    if (lane == 5) kps[i].angle = kp_angle;  // kept for vsf_debug_level_keypoints
   }
 }
 
