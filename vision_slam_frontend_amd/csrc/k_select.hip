@@ -39,7 +39,7 @@ struct SelectArgs {
   uint32_t cand_entries;
   const uint16_t* rowstart;
   int nunits;
-  uint32_t* scratch;  // [image][3 * cand_entries]
+  uint32_t* scratch;  // [image][6 * cand_entries]: stage-1 array, stage-2 pairs (x2), rank tables (x2), masks
   VsfLevelKp* lvlkp;
   int lvlkp_entries;
   int32_t* lvl_count;
@@ -67,15 +67,22 @@ struct RespGe {
 
 constexpr int kWaveCutoff = 256;  // ranges up to this size are finished by ONE wave without workgroup barriers
 
-// LDS scratch of the parallel passes. MAXW mask words cover MAXW * 64 elements.
-template <int MAXW>
-struct PassScratch {
-  unsigned long long maskL[MAXW];
-  unsigned long long maskR[MAXW];
-  int preL[MAXW];
-  int preR[MAXW];
+// Scratch of the parallel passes.  Masks / prefix counts cover maxw * 64 elements; Lp / Rp are the rank -> position
+// tables of the left- and right-stoppers (P = uint16_t in LDS, uint32_t in HBM scratch).
+struct PassCtl {
   unsigned long long wsum[16];
   int st[8];  // 0 first, 1 last, 2 depth, 3 K, 4 cut, 5 totalL, 6 totalR
+};
+template <class P>
+struct PassMem {
+  unsigned long long* maskL;
+  unsigned long long* maskR;
+  int* preL;
+  int* preR;
+  P* Lp;
+  P* Rp;
+  int maxw;
+  PassCtl* c;
 };
 
 __device__ __forceinline__ int select64(unsigned long long x, int r) {
@@ -131,26 +138,40 @@ __device__ __forceinline__ int select_rank(const unsigned long long* mask, const
 
 // One Hoare pass over A[lo, hi): left-stoppers are elements with FL(x), right-stoppers those with FR(x).
 // Swaps the k-th left-stopper (from the left) with the k-th right-stopper (from the right) for every k with
-// left position < right position.  On return (all threads, after a barrier) s.st[3] = K (number of swaps),
-// s.st[5] / s.st[6] = stopper totals, s.st[4] = where a sequential scan would have stopped
+// left position < right position.  Steps (a workgroup barrier between them):
+//   1  flags -> ballot masks (loads batched four deep);  2  block scan of the mask popcounts;
+//   3  every stopper writes its position at its rank: Lp[rank from the left], Rp[rank from the left];
+//   4  thread k swaps A[Lp[k]] <-> A[Rp[totalR - 1 - k]] while Lp[k] < Rp[...] (no searching);
+//   5  K = number of swaps, cut = where a sequential scan would have stopped.
+// On return (all threads, after a barrier) c.st[3] = K, c.st[5] / c.st[6] = stopper totals, c.st[4] = cut
 // (__unguarded_partition's return value when at least one stopper of each kind exists).
-template <int NT, int MAXW, class T, class FL, class FR>
-__device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>& s) {
+template <int NT, class T, class FL, class FR, class PM>
+__device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, const PM& s) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = hi - lo;
   const int nw = (m + 63) >> 6;
-  for (int base = 0; base < m; base += NT) {
-    const int i = base + tid;
-    bool l = false, r = false;
-    if (i < m) {
-      const T x = A[lo + i];
-      l = fl(x);
-      r = fr(x);
+  constexpr int U = 4;
+  for (int base = 0; base < m; base += NT * U) {
+    T x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + u * NT + tid;
+      if (i < m) x[u] = A[lo + i];
     }
-    const unsigned long long bl = __ballot(l), br = __ballot(r);
-    if (lane == 0 && (base >> 6) + wave < nw) {
-      s.maskL[(base >> 6) + wave] = bl;
-      s.maskR[(base >> 6) + wave] = br;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + u * NT + tid;
+      bool l = false, r = false;
+      if (i < m) {
+        l = fl(x[u]);
+        r = fr(x[u]);
+      }
+      const unsigned long long bl = __ballot(l), br = __ballot(r);
+      const int w = ((base + u * NT) >> 6) + wave;
+      if (lane == 0 && w < nw) {
+        s.maskL[w] = bl;
+        s.maskR[w] = br;
+      }
     }
   }
   __syncthreads();
@@ -168,13 +189,13 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
     const unsigned long long t = __shfl_up(inc, o, 64);
     if (lane >= o) inc += t;
   }
-  if (lane == 63) s.wsum[wave] = inc;
+  if (lane == 63) s.c->wsum[wave] = inc;
   __syncthreads();
   unsigned long long base_sum = 0, total = 0;
 #pragma unroll
   for (int w = 0; w < NT / 64; w++) {
-    if (w < wave) base_sum += s.wsum[w];
-    total += s.wsum[w];
+    if (w < wave) base_sum += s.c->wsum[w];
+    total += s.c->wsum[w];
   }
   unsigned long long run = base_sum + inc - mine;
   for (int j = 0; j < wpt; j++) {
@@ -187,47 +208,64 @@ __device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, PassScratch<MAXW>
   }
   const int totalL = (int)(uint32_t)total, totalR = (int)(uint32_t)(total >> 32);
   __syncthreads();
-  // participating left-stoppers swap with their partners
-  int nswap = 0;
+  // rank -> position tables
+  typedef decltype(s.Lp[0] + 0) PosInt;  // (promoted) element type of the tables
   for (int base = 0; base < m; base += NT) {
     const int i = base + tid;
     if (i < m) {
       const int w = i >> 6, b = i & 63;
-      const unsigned long long ml = s.maskL[w];
-      if ((ml >> b) & 1ull) {
-        const int k = s.preL[w] + __popcll(ml & ((1ull << b) - 1ull)) + 1;              // 1-based rank from the left
-        const int r_le = s.preR[w] + __popcll(s.maskR[w] & ((2ull << b) - 1ull));       // right-stoppers at <= i
-        if (totalR - r_le >= k) {
-          const int j = select_rank(s.maskR, s.preR, nw, totalR - k);
-          const T xi = A[lo + i], xj = A[lo + j];
-          A[lo + i] = xj;
-          A[lo + j] = xi;
-          ++nswap;
-        }
+      const unsigned long long ml = s.maskL[w], mr = s.maskR[w], below = (1ull << b) - 1ull;
+      if ((ml >> b) & 1ull) s.Lp[s.preL[w] + __popcll(ml & below)] = (PosInt)i;
+      if ((mr >> b) & 1ull) s.Rp[s.preR[w] + __popcll(mr & below)] = (PosInt)i;
+    }
+  }
+  __syncthreads();
+  // swaps: the k-th left-stopper with the k-th right-stopper from the right, while they have not crossed
+  const int kmax = min(totalL, totalR);
+  int nswap = 0;
+  for (int base = 0; base < kmax; base += NT * U) {
+    int pi[U], pj[U];
+    T xi[U], xj[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = base + u * NT + tid;
+      pi[u] = 0;
+      pj[u] = 0;
+      if (k < kmax) {
+        pi[u] = (int)s.Lp[k];
+        pj[u] = (int)s.Rp[totalR - 1 - k];
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (pi[u] < pj[u]) {
+        xi[u] = A[lo + pi[u]];
+        xj[u] = A[lo + pj[u]];
+      }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (pi[u] < pj[u]) {
+        A[lo + pi[u]] = xj[u];
+        A[lo + pj[u]] = xi[u];
+        ++nswap;
+      }
   }
   // K = total swaps
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nswap += __shfl_xor(nswap, o, 64);
-  if (lane == 0) s.wsum[wave] = (unsigned long long)nswap;
+  if (lane == 0) s.c->wsum[wave] = (unsigned long long)nswap;
   __syncthreads();
   if (tid == 0) {
     int K = 0;
-    for (int w = 0; w < NT / 64; w++) K += (int)s.wsum[w];
-    s.st[3] = K;
-    s.st[5] = totalL;
-    s.st[6] = totalR;
+    for (int w = 0; w < NT / 64; w++) K += (int)s.c->wsum[w];
+    s.c->st[3] = K;
+    s.c->st[5] = totalL;
+    s.c->st[6] = totalR;
     // where the left scan stops after K swaps: the (K+1)-th left-stopper if it lies before the K-th right-stopper
-    // (or no swap happened), else the K-th right-stopper's position (now holding a left-stopper).
-    int cut = lo;
-    const int aK1 = K < totalL ? select_rank(s.maskL, s.preL, nw, K) : 0x7FFFFFFF;
-    const int bK = K > 0 ? select_rank(s.maskR, s.preR, nw, totalR - K) : 0x7FFFFFFF;
-    if (K < totalL && (K == 0 || aK1 < bK))
-      cut = lo + aK1;
-    else
-      cut = lo + bK;
-    s.st[4] = cut;
+    // from the right (or no swap happened), else that right-stopper's position (now holding a left-stopper).
+    const int aK1 = K < totalL ? (int)s.Lp[K] : 0x7FFFFFFF;
+    const int bK = K > 0 ? (int)s.Rp[totalR - K] : 0x7FFFFFFF;
+    s.c->st[4] = (K < totalL && (K == 0 || aK1 < bK)) ? lo + aK1 : lo + bK;
   }
   __syncthreads();
 }
@@ -328,8 +366,9 @@ __device__ void wave_introselect(T* A, int first, int last, int nth, int depth, 
 }
 
 // std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
-template <int NT, int MAXW, class T, class Greater>
-__device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScratch<MAXW>& s) {
+template <int NT, class T, class Greater, class PM>
+__device__ void par_nth_element(T* A, int n, int nth, Greater greater, const PM& pm) {
+  PassCtl& s = *pm.c;
   if (n == 0 || nth == n) return;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -340,16 +379,16 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
   __syncthreads();
   while (true) {
     const int first = s.st[0], last = s.st[1], depth = s.st[2];
-    if (last - first <= kWaveCutoff || depth == 0 || last - first - 1 > MAXW * 64) break;
+    if (last - first <= kWaveCutoff || depth == 0 || last - first - 1 > pm.maxw * 64) break;
     if (tid == 0) {
       const int mid = first + (last - first) / 2;
       vsf_sel::move_median_to_first_(A, first, first + 1, mid, last - 1, greater);
     }
     __syncthreads();
     const T pivot = A[first];
-    hoare_pass<NT, MAXW>(
+    hoare_pass<NT>(
         A, first + 1, last, [&](const T& x) { return !greater(x, pivot); },
-        [&](const T& x) { return !greater(pivot, x); }, s);
+        [&](const T& x) { return !greater(pivot, x); }, pm);
     if (tid == 0) {
       const int cut = s.st[4];
       s.st[2] = depth - 1;
@@ -371,10 +410,11 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, PassScrat
 }
 
 // std::partition(A + lo, A + hi, pred); returns the split point -- all threads call this.
-template <int NT, int MAXW, class T, class Pred>
-__device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>& s) {
+template <int NT, class T, class Pred, class PM>
+__device__ int par_partition(T* A, int lo, int hi, Pred pred, const PM& pm) {
+  PassCtl& s = *pm.c;
   const int tid = threadIdx.x;
-  if (hi - lo <= kWaveCutoff || hi - lo > MAXW * 64) {
+  if (hi - lo <= kWaveCutoff || hi - lo > pm.maxw * 64) {
     if (tid < 64) {
       if (hi - lo <= kWaveCutoff) {
         int total_r = 0, cut = 0;
@@ -391,21 +431,21 @@ __device__ int par_partition(T* A, int lo, int hi, Pred pred, PassScratch<MAXW>&
     __syncthreads();
     return r;
   }
-  hoare_pass<NT, MAXW>(
-      A, lo, hi, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, s);
+  hoare_pass<NT>(
+      A, lo, hi, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, pm);
   const int r = lo + s.st[6];
   __syncthreads();
   return r;
 }
 
 // cv::KeyPointsFilter::retainBest(A[0..n), n_points); returns the new size -- all threads call this.
-template <int NT, int MAXW, class T, class Greater, class GreaterEq>
-__device__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, PassScratch<MAXW>& s) {
+template <int NT, class T, class Greater, class GreaterEq, class PM>
+__device__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, const PM& s) {
   if (n_points >= 0 && n > n_points) {
     if (n_points == 0) return 0;
-    par_nth_element<NT, MAXW>(A, n, n_points, greater, s);
+    par_nth_element<NT>(A, n, n_points, greater, s);
     const T ambiguous = A[n_points - 1];
-    return par_partition<NT, MAXW>(
+    return par_partition<NT>(
         A, n_points, n, [&](const T& x) { return ge(x, ambiguous); }, s);
   }
   return n;
@@ -440,11 +480,15 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
 template <int NT, int ENTRIES, int STAGE2, int MAXW>
 __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   __shared__ uint32_t sA[ENTRIES];
+  __shared__ uint16_t sPos[2 * ENTRIES];  // rank -> position tables of the LDS-resident passes
   __shared__ uint2 sB[STAGE2];
-  __shared__ PassScratch<MAXW> ps;
-  constexpr int kCellCap = 1025;
-  __shared__ int cellpre[kCellCap];
+  __shared__ unsigned long long sMask[2 * MAXW];
+  __shared__ int sPre[2 * MAXW];
+  __shared__ PassCtl ctl;
   __shared__ int lds4[16];
+  static_assert(ENTRIES <= 65536 && ENTRIES / 64 <= MAXW && STAGE2 <= ENTRIES && ENTRIES >= 1025, "scratch sizes");
+  constexpr int kCellCap = ENTRIES;            // the gather's cell prefix array borrows the position tables
+  int* cellpre = reinterpret_cast<int*>(sPos);
   const int tid = threadIdx.x;
   const int level = a.level0 + blockIdx.x, image = blockIdx.y;
   const VsfLevel L = a.levels[level];
@@ -461,9 +505,25 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   // ---- gather: merge the FAST units' segments into the level's raster order (vsf_gather.h) ----
   const uint16_t* rs_img = a.rowstart + (size_t)image * a.nunits * VSF_FAST_RS_STRIDE;
   const int n = vsf_level_candidate_count<NT>(L, rs_img, lds4);
-  uint32_t* gscratch = a.scratch + (size_t)image * 3 * a.cand_entries;
+  uint32_t* gscratch = a.scratch + (size_t)image * 6 * a.cand_entries;
   uint32_t* gA = gscratch + L.cand_offset;
   uint2* gB = reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
+  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + ENTRIES, ENTRIES / 64, &ctl};
+  // HBM-resident passes keep their masks in HBM as well (24 bytes per 64 elements, carved from the level's slice of
+  // the sixth scratch block), so a level of any candidate count runs the parallel passes
+  const int level_cap = L.seg_cap * L.nbands * L.nstrips, hbm_w = (level_cap + 63) / 64;
+  unsigned long long* gmask = reinterpret_cast<unsigned long long*>(
+      (reinterpret_cast<uintptr_t>(gscratch + 5 * a.cand_entries + L.cand_offset) + 7) & ~(uintptr_t)7);
+  int* gpre = reinterpret_cast<int*>(gmask + 2 * hbm_w);
+  const bool hbm_masks = 6 * hbm_w + 2 <= level_cap;  // (always true for real levels; else the LDS masks bound the range)
+  const PassMem<uint32_t> pm_hbm{hbm_masks ? gmask : sMask,
+                                 hbm_masks ? gmask + hbm_w : sMask + MAXW,
+                                 hbm_masks ? gpre : sPre,
+                                 hbm_masks ? gpre + hbm_w : sPre + MAXW,
+                                 gscratch + 3 * a.cand_entries + L.cand_offset,
+                                 gscratch + 4 * a.cand_entries + L.cand_offset,
+                                 hbm_masks ? hbm_w : MAXW,
+                                 &ctl};
   const bool a_in_lds = n <= ENTRIES;
   {
     const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
@@ -477,9 +537,9 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   // ---- K3: retainBest(2 * n_l) on the FAST score ----
   int m1;
   if (a_in_lds)
-    m1 = par_retain_best<NT, MAXW>(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
+    m1 = par_retain_best<NT>(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), pm_lds);
   else
-    m1 = par_retain_best<NT, MAXW>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), ps);
+    m1 = par_retain_best<NT>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), pm_hbm);
   __syncthreads();
 
   // ---- K4: Harris responses (one lane per keypoint) ----
@@ -498,9 +558,9 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   // ---- K5: retainBest(n_l) on the Harris response ----
   int m2;
   if (b_in_lds)
-    m2 = par_retain_best<NT, MAXW>(sB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
+    m2 = par_retain_best<NT>(sB, m1, L.nfeatures, RespGreater(), RespGe(), pm_lds);
   else
-    m2 = par_retain_best<NT, MAXW>(gB, m1, L.nfeatures, RespGreater(), RespGe(), ps);
+    m2 = par_retain_best<NT>(gB, m1, L.nfeatures, RespGreater(), RespGe(), pm_hbm);
   __syncthreads();
 
   // ---- survivors in retainBest order; K6 (ICAngles) runs in k_describe.hip, one wave per keypoint ----
@@ -522,20 +582,26 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
 
 // Test hook: retainBest on (float key, id) pairs, one workgroup, arrays in HBM or LDS.
 template <int NT, int MAXW>
-__global__ __launch_bounds__(NT) void retain_best_test_kernel(uint2* data, int n, int n_points, int use_lds,
-                                                                    int mode, int* out_n) {
-  __shared__ PassScratch<MAXW> ps;
-  __shared__ uint2 buf[4096];
+__global__ __launch_bounds__(NT) void retain_best_test_kernel(uint2* data, uint32_t* tables, int n, int n_points,
+                                                              int use_lds, int mode, int* out_n) {
+  constexpr int kBuf = 4096;
+  __shared__ uint2 buf[kBuf];
+  __shared__ uint16_t sPos[2 * kBuf];
+  __shared__ unsigned long long sMask[2 * MAXW];
+  __shared__ int sPre[2 * MAXW];
+  __shared__ PassCtl ctl;
+  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + kBuf, kBuf / 64, &ctl};
+  const PassMem<uint32_t> pm_hbm{sMask, sMask + MAXW, sPre, sPre + MAXW, tables, tables + n, MAXW, &ctl};
   int m;
   if (mode == 0) {  // float keys
-    if (use_lds && n <= 4096) {
+    if (use_lds && n <= kBuf) {
       for (int i = threadIdx.x; i < n; i += NT) buf[i] = data[i];
       __syncthreads();
-      m = par_retain_best<NT, MAXW>(buf, n, n_points, RespGreater(), RespGe(), ps);
+      m = par_retain_best<NT>(buf, n, n_points, RespGreater(), RespGe(), pm_lds);
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += NT) data[i] = buf[i];
     } else {
-      m = par_retain_best<NT, MAXW>(data, n, n_points, RespGreater(), RespGe(), ps);
+      m = par_retain_best<NT>(data, n, n_points, RespGreater(), RespGe(), pm_hbm);
     }
   } else {  // packed candidates: compare the top byte of .x only
     struct G {
@@ -544,7 +610,7 @@ __global__ __launch_bounds__(NT) void retain_best_test_kernel(uint2* data, int n
     struct GE {
       __device__ bool operator()(const uint2& a, const uint2& b) const { return (a.x >> 24) >= (b.x >> 24); }
     };
-    m = par_retain_best<NT, MAXW>(data, n, n_points, G(), GE(), ps);
+    m = par_retain_best<NT>(data, n, n_points, G(), GE(), pm_hbm);
   }
   if (threadIdx.x == 0) *out_n = m;
 }
@@ -582,16 +648,17 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   }
   if (nbig > 0) {
     a.level0 = 0;
-    hipLaunchKernelGGL((orb_select_kernel<1024, 16384, 2048, 1024>), dim3(nbig, im.n), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<1024, 15360, 1024, 256>), dim3(nbig, im.n), dim3(1024), 0, s, a);
   }
   if (nbig < g.nlevels) {
     a.level0 = nbig;
-    hipLaunchKernelGGL((orb_select_kernel<256, 4096, 1024, 256>), dim3(g.nlevels - nbig, im.n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<256, 3072, 1024, 256>), dim3(g.nlevels - nbig, im.n), dim3(256), 0, s, a);
   }
 }
 
-void vsf_launch_retain_best_test(uint2* d_data, int n, int n_points, int use_lds, int mode, int* d_out_n,
-                                 hipStream_t s) {
-  hipLaunchKernelGGL((retain_best_test_kernel<256, 1024>), dim3(1), dim3(256), 0, s, d_data, n, n_points, use_lds,
-                     mode, d_out_n);
+void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n_points, int use_lds, int mode,
+                                 int* d_out_n, hipStream_t s) {
+  // d_tables: 2 * n uint32 of scratch (rank -> position tables of the HBM-resident passes)
+  hipLaunchKernelGGL((retain_best_test_kernel<256, 1024>), dim3(1), dim3(256), 0, s, d_data, d_tables, n, n_points,
+                     use_lds, mode, d_out_n);
 }

@@ -322,7 +322,7 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   if (orb) {
     VSF_HIP(hipMalloc((void**)&d.pyr, n * G.g.pyr_bytes));
     VSF_HIP(hipMalloc((void**)&d.blur, n * G.g.pyr_bytes));
-    VSF_HIP(hipMalloc((void**)&d.scratch, n * 3 * G.g.cand_entries * sizeof(uint32_t)));
+    VSF_HIP(hipMalloc((void**)&d.scratch, n * 6 * G.g.cand_entries * sizeof(uint32_t)));
     VSF_HIP(hipMalloc((void**)&d.lvlkp, n * G.g.lvlkp_entries * sizeof(VsfLevelKp)));
     VSF_HIP(hipMalloc((void**)&d.lvl_count, n * G.g.nlevels * sizeof(int32_t)));
     VSF_HIP(hipMemset(d.lvl_count, 0, n * G.g.nlevels * sizeof(int32_t)));
@@ -447,7 +447,7 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
   if (o.blur) o.blur += i * g.pyr_bytes;
   o.cand += i * g.cand_entries;
   o.rowstart += i * (size_t)g.nunits * VSF_FAST_RS_STRIDE;
-  if (o.scratch) o.scratch += i * 3 * g.cand_entries;
+  if (o.scratch) o.scratch += i * 6 * g.cand_entries;
   if (o.lvlkp) o.lvlkp += i * g.lvlkp_entries;
   if (o.lvl_count) o.lvl_count += i * g.nlevels;
   return o;
@@ -982,15 +982,18 @@ vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids
   std::vector<uint2> h((size_t)std::max(n, 1));
   for (int i = 0; i < n; i++) h[i] = make_uint2(key_bits[i], ids[i]);
   uint2* d = nullptr;
+  uint32_t* dt = nullptr;
   int* dn = nullptr;
   VSF_HIP(hipMalloc((void**)&d, h.size() * sizeof(uint2)));
+  VSF_HIP(hipMalloc((void**)&dt, 2 * h.size() * sizeof(uint32_t)));
   VSF_HIP(hipMalloc((void**)&dn, sizeof(int)));
   VSF_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(uint2), hipMemcpyHostToDevice));
-  vsf_launch_retain_best_test(d, n, n_points, use_lds, mode, dn, ctx->stream);
+  vsf_launch_retain_best_test(d, dt, n, n_points, use_lds, mode, dn, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(uint2), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(n_out, dn, sizeof(int), hipMemcpyDeviceToHost);
   hipFree(d);
+  hipFree(dt);
   hipFree(dn);
   if (e != hipSuccess) {
     ctx->last_hip = (int)e;

@@ -77,7 +77,7 @@ struct VsfDev {
   uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
   uint32_t* cand;           // [max_images][cand_entries]  per-unit candidate segments (unit-local raster order)
   uint16_t* rowstart;       // [max_images][nunits][VSF_FAST_RS_STRIDE]  start of each row inside its segment
-  uint32_t* scratch;        // [max_images][3 * cand_entries]   selection arrays when LDS is too small
+  uint32_t* scratch;        // [max_images][6 * cand_entries]   selection arrays, rank tables, masks when LDS is too small
   VsfLevelKp* lvlkp;        // [max_images][lvlkp_entries]
   const uint2* ic_table;    // [4][VSF_IC_ITEMS] ICAngles byte weights (k_describe.hip)
   int32_t* lvl_count;       // [max_images][nlevels]
@@ -97,8 +97,8 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
 void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s);
 void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                        hipStream_t s);
-void vsf_launch_retain_best_test(uint2* d_data, int n, int n_points, int use_lds, int mode, int* d_out_n,
-                                 hipStream_t s);
+void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n_points, int use_lds, int mode,
+                                 int* d_out_n, hipStream_t s);
 void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_tiles, int ntiles,
                      const int k[4], hipStream_t s);
 void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int max_keypoints,
