@@ -11,11 +11,11 @@
 // the four horizontal sums; the vertical pass and a 32-bit store finish the row.  A wave handles 4 output rows and
 // issues all eight source-row loads before any arithmetic (rows shared between neighbouring output rows hit L1),
 // so the kernel is limited by memory-level parallelism across waves, not by a per-row dependency chain.
+#pragma clang fp contract(off)
 #include "vsf_internal.h"
 
 namespace {
 
-constexpr int kStripRows = 4;
 
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(1))) U8B {
@@ -29,11 +29,11 @@ struct ResizeArgs {
   uint8_t* dst;
   size_t dst_img_stride;
   int dst_pitch, dw, dh;
-  const VsfTap* xt;
-  const VsfTap* yt;
+  double scale_x, scale_y;  // cv::resize: 1. / ((double)dw / sw), 1. / ((double)dh / sh)
   int nbands, nunits;
 };
 
+template <int kStripRows>
 __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
   const int lane = threadIdx.x & 63;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -41,9 +41,36 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
   const int band = unit % a.nbands, strip = unit / a.nbands;
   const int x4 = band * 256 + lane * 4;
   const bool active = x4 < a.dw;
+  // cv::resize's coefficient tables (xofs / ialpha, yofs / ibeta) evaluated in place with the same double / float
+  // steps as the host (vsf_api.hip build_taps; no FMA contraction in this file): no table load sits in front of the
+  // source-row loads, the wave's dependency chain is  rows -> arithmetic -> store.
+  auto xtap = [&](int dx) -> VsfTap {
+    float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) fx = 0, sx = 0;
+    if (sx >= a.sw - 1) fx = 0, sx = a.sw - 1;
+    VsfTap t;
+    t.i0 = (uint16_t)sx;
+    t.i1 = (uint16_t)min(sx + 1, a.sw - 1);
+    t.c0 = (int16_t)min(max(__float2int_rn((1.f - fx) * 2048), -32768), 32767);
+    t.c1 = (int16_t)min(max(__float2int_rn(fx * 2048), -32768), 32767);
+    return t;
+  };
+  auto ytap = [&](int dy) -> VsfTap {
+    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    VsfTap t;
+    t.i0 = (uint16_t)min(max(sy, 0), a.sh - 1);
+    t.i1 = (uint16_t)min(max(sy + 1, 0), a.sh - 1);
+    t.c0 = (int16_t)min(max(__float2int_rn((1.f - fy) * 2048), -32768), 32767);
+    t.c1 = (int16_t)min(max(__float2int_rn(fy * 2048), -32768), 32767);
+    return t;
+  };
   // loop-invariant x taps of this lane's 4 pixels
-  VsfTap t0 = a.xt[min(x4 + 0, a.dw - 1)], t1 = a.xt[min(x4 + 1, a.dw - 1)], t2 = a.xt[min(x4 + 2, a.dw - 1)],
-         t3 = a.xt[min(x4 + 3, a.dw - 1)];
+  const VsfTap t0 = xtap(min(x4 + 0, a.dw - 1)), t1 = xtap(min(x4 + 1, a.dw - 1)), t2 = xtap(min(x4 + 2, a.dw - 1)),
+               t3 = xtap(min(x4 + 3, a.dw - 1));
   const int base = min((int)t0.i0, a.sw - 8);  // 8-byte window [base, base+8) covers all eight taps, inside the row
   auto selector = [&](const VsfTap& t) -> uint32_t {
     return (uint32_t)(t.i0 - base) | 0x0C000C00u | ((uint32_t)(t.i1 - base) << 16);
@@ -76,7 +103,7 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
   U8B v0[kStripRows], v1[kStripRows];
 #pragma unroll
   for (int r = 0; r < kStripRows; r++) {
-    ty[r] = a.yt[min(ys + r, a.dh - 1)];  // wave-uniform
+    ty[r] = ytap(min(ys + r, a.dh - 1));  // wave-uniform
     v0[r] = *reinterpret_cast<const U8B*>(S + (size_t)ty[r].i0 * a.src_pitch);
     v1[r] = *reinterpret_cast<const U8B*>(S + (size_t)ty[r].i1 * a.src_pitch);
   }
@@ -96,25 +123,47 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
 }  // namespace
 
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
-                        hipStream_t s) {
+                        hipStream_t s, const VsfSideStream* side) {
+  // Level l depends on level l - 1 of the same image only, so the chain of 49 small dependent launches is issued
+  // twice, for the two halves of the batch, on two streams: the small levels are bound by the latency of a launch's
+  // dependency chain (~5 us each), not by throughput, and two chains run in the time of one.
+  const bool split = side && side->stream && im.n >= 2;
+  const int n0 = split ? (im.n + 1) / 2 : im.n;
+  if (split) {
+    (void)hipEventRecord(side->fork, s);
+    (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+  }
   for (int l = 1; l < g.nlevels; l++) {
     const VsfLevel& L = h_levels[l];
     const VsfLevel& P = h_levels[l - 1];
-    ResizeArgs a;
-    a.src = (l == 1) ? im.base : d.pyr + P.offset;
-    a.src_img_stride = (l == 1) ? im.image_stride : (size_t)g.pyr_bytes;
-    a.src_pitch = (l == 1) ? (int)im.row_stride : P.pitch;
-    a.sw = P.w;
-    a.sh = P.h;
-    a.dst = d.pyr + L.offset;
-    a.dst_img_stride = (size_t)g.pyr_bytes;
-    a.dst_pitch = L.pitch;
-    a.dw = L.w;
-    a.dh = L.h;
-    a.xt = d.xtaps + L.xtab;
-    a.yt = d.ytaps + L.ytab;
-    a.nbands = (L.w + 255) / 256;
-    a.nunits = a.nbands * ((L.h + kStripRows - 1) / kStripRows);
-    hipLaunchKernelGGL(resize_march_kernel, dim3((a.nunits + 3) / 4, im.n), dim3(256), 0, s, a);
+    for (int half = 0; half < (split ? 2 : 1); half++) {  // interleaved issue: both chains advance together
+      const int i0 = half ? n0 : 0, n = half ? im.n - n0 : n0;
+      ResizeArgs a;
+      a.src = (l == 1) ? im.base + (size_t)i0 * im.image_stride : d.pyr + (size_t)i0 * g.pyr_bytes + P.offset;
+      a.src_img_stride = (l == 1) ? im.image_stride : (size_t)g.pyr_bytes;
+      a.src_pitch = (l == 1) ? (int)im.row_stride : P.pitch;
+      a.sw = P.w;
+      a.sh = P.h;
+      a.dst = d.pyr + (size_t)i0 * g.pyr_bytes + L.offset;
+      a.dst_img_stride = (size_t)g.pyr_bytes;
+      a.dst_pitch = L.pitch;
+      a.dw = L.w;
+      a.dh = L.h;
+      a.scale_x = 1. / ((double)L.w / P.w);
+      a.scale_y = 1. / ((double)L.h / P.h);
+      a.nbands = (L.w + 255) / 256;
+      // rows per wave: more bytes in flight per wave on the large levels, more waves on the small ones
+      const bool large = (long)L.w * L.h * n >= 4000000;
+      const int rows = large ? 8 : 4;
+      a.nunits = a.nbands * ((L.h + rows - 1) / rows);
+      if (large)
+        hipLaunchKernelGGL(resize_march_kernel<8>, dim3((a.nunits + 3) / 4, n), dim3(256), 0, half ? side->stream : s, a);
+      else
+        hipLaunchKernelGGL(resize_march_kernel<4>, dim3((a.nunits + 3) / 4, n), dim3(256), 0, half ? side->stream : s, a);
+    }
+  }
+  if (split) {
+    (void)hipEventRecord(side->join, side->stream);
+    (void)hipStreamWaitEvent(s, side->join, 0);
   }
 }

@@ -251,7 +251,7 @@ struct vsf_ctx {
   // Second lane of the batched entry points: half of a batch runs on `stream`, the other half on `aux_stream`
   // (frames are independent), so latency-bound stages of one half overlap VALU-bound stages of the other.
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side_fork = nullptr, ev_side_join = nullptr;
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int last_hip = 0;
   Geometry orb, fast;
@@ -464,7 +464,9 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   const size_t K = (size_t)ctx->p.max_keypoints;
   {
     StageTimer t(ctx, st, VSF_STAGE_PYRAMID, g.nlevels - 1);
-    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st);
+    // one lane: the aux stream is idle, the pyramid chain of the second half of the images runs on it
+    const VsfSideStream side{ctx->aux_stream, ctx->ev_side_fork, ctx->ev_side_join};
+    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, ctx->lanes == 1 ? &side : nullptr);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
@@ -641,7 +643,9 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
   ctx->stream = ctx->own_stream;
   if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_side_join, hipEventDisableTiming) != hipSuccess)
     return fail(VSF_ERR_HIP);
   if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
@@ -685,6 +689,8 @@ void vsf_destroy(vsf_ctx* ctx) {
   for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_side_fork) hipEventDestroy(ctx->ev_side_fork);
+  if (ctx->ev_side_join) hipEventDestroy(ctx->ev_side_join);
   if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -91,8 +91,13 @@ struct VsfImages {
   int n;
 };
 
+// Optional second stream a launcher may fork independent kernels onto (joined back before it returns).
+struct VsfSideStream {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
-                        hipStream_t s);
+                        hipStream_t s, const VsfSideStream* side);
 // threshold: FAST threshold; nms == 0 keeps every corner (standalone FAST only).
 void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s);
 void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
