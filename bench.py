@@ -43,6 +43,21 @@ def stage_algorithmic_bytes(ctx, n_images: int, n_pairs: int, nfeatures: int) ->
     }
 
 
+def measured_traffic(stage: str, width: int, height: int, nfeatures: int, batch: int):
+    """HBM bytes per step of `stage` from the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in their own runs, gfx950 FETCH_SIZE correction applied), if they were taken on this
+    configuration; None otherwise.  PMC counters cannot be collected inside the timed run."""
+    try:
+        t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    except (OSError, ValueError):
+        return None
+    c = t.get("config", {})
+    if (c.get("width"), c.get("height"), c.get("nfeatures"), c.get("batch")) != (width, height, nfeatures, batch):
+        return None
+    st = t.get("stages", {}).get(stage)
+    return None if st is None else float(st["hbm_bytes_per_step"])
+
+
 def cpu_baseline(width, height, nfeatures, seed):
     """The CPU oracle (a scalar C++ restatement, kind "port") timed on this box's host cores."""
     from concurrent.futures import ThreadPoolExecutor
@@ -178,6 +193,11 @@ def main() -> int:
         per_launch_bytes = alg[dom] * args.steps / max(dom_launches, 1)
         per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9
+        traffic = args.traffic
+        if traffic is None:
+            t_step = measured_traffic(dom, W, H, NF, B)
+            if t_step is not None:
+                traffic = t_step * args.steps / max(dom_launches, 1)
         device_ms = sum(v[0] for v in stages.values())
         out = {
             "metric": "stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
@@ -194,9 +214,12 @@ def main() -> int:
                        "mean_keypoints_per_image": float(counts.mean()), "mean_stereo_matches": float(nm.mean()),
                        "capacity_overflow": bool(status == capi.VSF_ERR_CAPACITY)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "launches": dom_launches},
+            # every streaming stage against the same roofline (algorithmic bytes / measured stage time)
+            "streaming_stages_gbs": {k: alg[k] * args.steps / (stages[k][0] * 1e-3) / 1e9
+                                     for k in ("pyramid_resize", "fast_score_nms", "gauss_blur7") if stages[k][0] > 0},
             "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
             "device_ms_per_step": device_ms / args.steps,
         }
