@@ -162,7 +162,8 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
   G.g.nunits = (int)G.units.size();
   if (G.units.empty()) G.units.push_back(0);
   G.g.lvlkp_entries = std::max(kp_off, 1);
-  // resize tables + blur tiles (ORB only)
+  // resize coefficient tables (host only: the kernel evaluates the same arithmetic in place; built here to check
+  // that a lane's eight x taps fit the 8-byte source window it loads) + blur tiles (ORB only)
   if (orb) {
     for (int l = 1; l < nlevels; l++) {
       VsfLevel& L = G.levels[l];
@@ -235,8 +236,6 @@ struct DevSet {  // device copies of one Geometry + its work buffers
   VsfDev d{};
   VsfLevel* levels = nullptr;
   uint32_t* units = nullptr;
-  VsfTap* xt = nullptr;
-  VsfTap* yt = nullptr;
   uint32_t* blur_tiles = nullptr;
   uint2* ic_table = nullptr;
   bool ready = false;
@@ -308,16 +307,12 @@ hipError_t upload(T** dst, const std::vector<T>& v) {
 vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, int n_images) {
   VSF_HIP(upload(&ds->levels, G.levels));
   VSF_HIP(upload(&ds->units, G.units));
-  VSF_HIP(upload(&ds->xt, G.xt));
-  VSF_HIP(upload(&ds->yt, G.yt));
   VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
   VSF_HIP(upload(&ds->ic_table, build_ic_table()));
   VsfDev& d = ds->d;
   d.ic_table = ds->ic_table;
   d.levels = ds->levels;
   d.units = ds->units;
-  d.xtaps = ds->xt;
-  d.ytaps = ds->yt;
   const size_t n = (size_t)n_images;
   if (orb) {
     VSF_HIP(hipMalloc((void**)&d.pyr, n * G.g.pyr_bytes));
@@ -339,8 +334,6 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
 void free_devset(DevSet* ds) {
   hipFree(ds->levels);
   hipFree(ds->units);
-  hipFree(ds->xt);
-  hipFree(ds->yt);
   hipFree(ds->blur_tiles);
   hipFree(ds->ic_table);
   hipFree(ds->d.pyr);

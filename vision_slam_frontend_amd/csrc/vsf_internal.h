@@ -33,12 +33,12 @@ struct VsfLevel {
   int32_t kp_offset;       // index of this level's final-keypoint segment (per image)
   int32_t kp_cap;          // its capacity
   int32_t blur_vec_end;    // columns [0, blur_vec_end) round half-even (SSE2 path), the rest half-up
-  uint32_t xtab, ytab;     // entry offsets of this level's resize tables (level >= 1)
+  uint32_t xtab, ytab;     // entry offsets of this level's resize tables in the host-side Geometry (level >= 1)
   int32_t pad0;
 };
 
-// Resize coefficient table entry (cv::resize INTER_LINEAR 8u: xofs/ialpha resp. yofs/ibeta with the
-// out-of-range taps already clamped, weights kept).
+// Resize coefficients of one output column / row (cv::resize INTER_LINEAR 8u: xofs/ialpha resp. yofs/ibeta with the
+// out-of-range taps already clamped, weights kept); evaluated in place by k_pyramid.hip, tabulated on the host.
 struct VsfTap {
   uint16_t i0, i1;  // source indices of the two taps
   int16_t c0, c1;   // 11-bit fixed-point weights
@@ -71,8 +71,6 @@ struct VsfGeom {
 struct VsfDev {
   const VsfLevel* levels;   // [nlevels]
   const uint32_t* units;    // [nunits]: level << 24 | band << 16 | strip
-  const VsfTap* xtaps;      // resize tables
-  const VsfTap* ytaps;
   uint8_t* pyr;             // [max_images][pyr_bytes]   unblurred levels 1..L-1 (level 0 is the input)
   uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
   uint32_t* cand;           // [max_images][cand_entries]  per-unit candidate segments (unit-local raster order)
