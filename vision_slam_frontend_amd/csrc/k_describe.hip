@@ -98,6 +98,76 @@ __device__ __forceinline__ void sincos_2pi(double x, double* s_out, double* c_ou
   *c_out = ((k + 1) & 2) ? -cv : cv;
 }
 
+// K6: one wave per keypoint (rounds of up to 64 keypoints per wave, lane k <-> keypoint k of the round).
+__global__ __launch_bounds__(256) void orb_angle_kernel(DescribeArgs a) {
+  const int level = blockIdx.x / kSplit, part = blockIdx.x - level * kSplit, image = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const VsfLevel L = a.levels[level];
+  const int n = a.lvl_count[(size_t)image * a.nlevels + level];
+  const uint8_t* raw;
+  int rpitch;
+  if (level == 0) {
+    raw = a.img0 + (size_t)image * a.img0_stride;
+    rpitch = a.img0_pitch;
+  } else {
+    raw = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
+    rpitch = L.pitch;
+  }
+  VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
+  // this lane's five disc items: row index (0..30 <-> v = -15..15) and dword index (0..8); items >= 279 carry
+  // zero weights and are pointed at row 30 so that they stay inside the image
+  int item_off[5], item_v[5];
+#pragma unroll
+  for (int it = 0; it < 5; it++) {
+    const int item = it * 64 + lane;
+    const int r = min(item / 9, 30), j = item - (item / 9) * 9;
+    item_off[it] = r * rpitch + 4 * j;
+    item_v[it] = r - 15;
+  }
+  const int stride = 4 * kSplit;
+  for (int base = part * 4 + wid; base < n; base += 64 * stride) {
+    const int cnt = min(64, (n - base + stride - 1) / stride);  // keypoints of this round (wave-uniform)
+    uint32_t my_xy = 0;  // lane k holds keypoint k: one load for all records of the round
+    if (lane < cnt) my_xy = kps[base + lane * stride].xy;
+    float my_angle = 0.f;
+    for (int kk = 0; kk < cnt; kk++) {
+      const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)my_xy, kk);
+      const int x0 = (int)(xy & 0xFFFu), y0 = (int)(xy >> 12);
+      const int xs = x0 - 15;
+      const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
+      const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS;
+      int m10 = 0, m01 = 0;
+#pragma unroll
+      for (int it = 0; it < 5; it++) {
+        const uint32_t px = *reinterpret_cast<const uint32_t*>(abase + (uint32_t)item_off[it]);
+        const uint2 t = tab[(uint32_t)(it * 64 + lane)];
+        const int sw = (int)__builtin_amdgcn_udot4(px, t.x, 0u, false);
+        const int sm = (int)__builtin_amdgcn_udot4(px, t.y, 0u, false);
+        m10 += sw - 16 * sm;
+        m01 += item_v[it] * sm;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off, 64);
+        m01 += __shfl_xor(m01, off, 64);
+      }
+      const float kp_angle = fast_atan2_deg((float)m01, (float)m10);
+      if (lane == kk) my_angle = kp_angle;
+    }
+    // cos / sin, one keypoint per lane (the float nearest to the double-precision value)
+    const float my_rad = my_angle * (float)(3.14159265358979323846 / 180.f);
+    double sd, cd;
+    sincos_2pi((double)my_rad, &sd, &cd);
+    if (lane < cnt) {
+      VsfLevelKp* k = kps + base + lane * stride;
+      k->angle = my_angle;
+      k->ca = (float)cd;
+      k->sb = (float)sd;
+    }
+  }
+}
+
+// K8 + output assembly: one wave per keypoint.
 __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
   const int level = blockIdx.x / kSplit, part = blockIdx.x - level * kSplit, image = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -118,34 +188,9 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
   const int n = lc[level];
   const uint8_t* img = a.blur + (size_t)image * a.pyr_bytes + L.offset;
   const int pitch = L.pitch;
-  const uint8_t* raw;
-  int rpitch;
-  if (level == 0) {
-    raw = a.img0 + (size_t)image * a.img0_stride;
-    rpitch = a.img0_pitch;
-  } else {
-    raw = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
-    rpitch = L.pitch;
-  }
-  VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
+  const VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
   const float lscale = L.scale;
   const float inv = 1.f / lscale;
-  // this lane's five disc items: row index (0..30 <-> v = -15..15) and dword index (0..8); items >= 279 carry
-  // zero weights and are pointed at row 30 so that they stay inside the image
-  int item_off[5], item_v[5];
-#pragma unroll
-  for (int it = 0; it < 5; it++) {
-    const int item = it * 64 + lane;
-    const int r = min(item / 9, 30), j = item - (item / 9) * 9;
-    item_off[it] = r * rpitch + 4 * j;
-    item_v[it] = r - 15;
-  }
-  // A wave owns keypoints i = first + 4 * kSplit * k, k < 64 per round.  Round = three passes, so that the double
-  // precision cos / sin (the expensive, wave-uniform part of a keypoint) is evaluated ONCE per round with lane k
-  // working on keypoint k, instead of 64-fold redundantly once per keypoint:
-  //   pass 1  per keypoint: K6 moments + fastAtan2 (wave-wide reduction), lane k keeps angle / position
-  //   pass 2  lane k: cos / sin of keypoint k
-  //   pass 3  per keypoint: broadcast its cos / sin (v_readlane), K8 descriptor, outputs
   // this lane's four pattern pairs (loop invariant)
   float pat[4][4];
 #pragma unroll
@@ -157,85 +202,45 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
   const int stride = 4 * kSplit;
   for (int base = part * 4 + wid; base < n; base += 64 * stride) {
     const int cnt = min(64, (n - base + stride - 1) / stride);  // keypoints of this round (wave-uniform)
-    float my_angle = 0.f;
-    uint32_t my_xy = 0;
-    float my_resp = 0.f;
-    for (int kk = 0; kk < cnt; kk++) {
-      const int i = base + kk * stride;
-      const VsfLevelKp k = kps[i];
-      const int x0 = (int)(k.xy & 0xFFFu), y0 = (int)(k.xy >> 12);
-      // ---- K6: intensity-centroid angle on the unblurred level ----
-      const int xs = x0 - 15;
-      const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
-      const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS + lane;
-      int m10 = 0, m01 = 0;
-#pragma unroll
-      for (int it = 0; it < 5; it++) {
-        const uint32_t px = *reinterpret_cast<const uint32_t*>(abase + item_off[it]);
-        const uint2 t = tab[it * 64];
-        const int sw = (int)__builtin_amdgcn_udot4(px, t.x, 0u, false);
-        const int sm = (int)__builtin_amdgcn_udot4(px, t.y, 0u, false);
-        m10 += sw - 16 * sm;
-        m01 += item_v[it] * sm;
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off, 64);
-        m01 += __shfl_xor(m01, off, 64);
-      }
-      const float kp_angle = fast_atan2_deg((float)m01, (float)m10);
-      if (lane == kk) {
-        my_angle = kp_angle;
-        my_xy = k.xy;
-        my_resp = k.response;
-      }
-    }
-    // ---- cos / sin, one keypoint per lane ----
-    // cos/sin of the float angle taken as the correctly rounded float (double evaluation).
-    const float my_rad = my_angle * (float)(3.14159265358979323846 / 180.f);
-    double sd, cd;
-    sincos_2pi((double)my_rad, &sd, &cd);
-    const float my_ca = (float)cd, my_sb = (float)sd;
-    // ---- K8: rotated BRIEF on the blurred level ----
-    for (int kk = 0; kk < cnt; kk++) {
-      const int i = base + kk * stride;
-      const int o = before + i;
-      if (o >= a.max_keypoints) break;
-      const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), kk));
-      const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sb), kk));
-      const float kp_angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_angle), kk));
-      const float resp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_resp), kk));
-      const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)my_xy, kk);
-      const int x0 = (int)(xy & 0xFFFu), y0 = (int)(xy >> 12);
-      const float fx = (float)x0 * lscale;  // KeyPoint::pt *= scale
-      const float fy = (float)y0 * lscale;
+    const int cnt_out = min(cnt, (a.max_keypoints - (before + base) + stride - 1) / stride);  // that fit the output
+    if (cnt_out <= 0) break;
+    VsfLevelKp mine_kp{0u, 0.f, 0.f, 1.f, 0.f};  // lane k holds keypoint k: one load for all records of the round
+    if (lane < cnt_out) mine_kp = kps[base + lane * stride];
+    for (int kk = 0; kk < cnt_out; kk++) {
+      const int o = before + base + kk * stride;
+      const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_kp.ca), kk));
+      const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_kp.sb), kk));
+      const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)mine_kp.xy, kk);
+      const float fx = (float)(int)(xy & 0xFFFu) * lscale, fy = (float)(int)(xy >> 12) * lscale;
       const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
-      const uint8_t* center = img + (size_t)cy * pitch + cx;
+      // patch origin (centre - 19 rows - 19 columns; |rotated pattern| <= 18.4): lane offsets are non-negative
+      const uint8_t* corner = img + (size_t)(cy - 19) * pitch + (cx - 19);
       uint64_t w[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const float x0f = pat[j][0], y0f = pat[j][1], x1f = pat[j][2], y1f = pat[j][3];
         const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
         const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
-        const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
+        const int t0 = corner[(uint32_t)((iy0 + 19) * pitch + ix0 + 19)];
+        const int t1 = corner[(uint32_t)((iy1 + 19) * pitch + ix1 + 19)];
         w[j] = __ballot(t0 < t1);
       }
       if (lane < 4) {
         const uint64_t v = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
         reinterpret_cast<uint64_t*>(a.desc_out + ((size_t)image * a.max_keypoints + o) * VSF_DESC_BYTES)[lane] = v;
       }
-      if (lane == 4) {
-        vsf_keypoint kp;
-        kp.x = fx;
-        kp.y = fy;
-        kp.size = 31 * lscale;
-        kp.angle = kp_angle;
-        kp.response = resp;
-        kp.octave = level;
-        kp.class_id = -1;
-        a.kp_out[(size_t)image * a.max_keypoints + o] = kp;
-      }
-      if (lane == 5) kps[i].angle = kp_angle;  // kept for vsf_debug_level_keypoints
+    }
+    // the round's cv::KeyPoint records, one per lane
+    if (lane < cnt_out) {
+      vsf_keypoint kp;
+      kp.x = (float)(int)(mine_kp.xy & 0xFFFu) * lscale;  // KeyPoint::pt *= scale
+      kp.y = (float)(int)(mine_kp.xy >> 12) * lscale;
+      kp.size = 31 * lscale;
+      kp.angle = mine_kp.angle;
+      kp.response = mine_kp.response;
+      kp.octave = level;
+      kp.class_id = -1;
+      a.kp_out[(size_t)image * a.max_keypoints + before + base + lane * stride] = kp;
     }
   }
 }
@@ -262,5 +267,6 @@ void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
   a.desc_out = d_desc;
   a.counts = d_counts;
   a.status = d.status;
+  hipLaunchKernelGGL(orb_angle_kernel, dim3(g.nlevels * kSplit, im.n), dim3(256), 0, s, a);
   hipLaunchKernelGGL(orb_describe_kernel, dim3(g.nlevels * kSplit, im.n), dim3(256), 0, s, a);
 }

@@ -572,6 +572,8 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
     kp.xy = e.y;
     kp.response = __uint_as_float(e.x);
     kp.angle = -1.f;
+    kp.ca = 1.f;
+    kp.sb = 0.f;
     out[i] = kp;
   }
   if (tid == 0) {

@@ -54,7 +54,8 @@ struct VsfTap {
 struct VsfLevelKp {
   uint32_t xy;  // y << 12 | x
   float response;
-  float angle;
+  float angle;     // degrees (k_describe.hip orb_angle_kernel)
+  float ca, sb;    // cos / sin of the angle as computeOrbDescriptors takes them
 };
 
 struct VsfGeom {
