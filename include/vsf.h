@@ -149,6 +149,32 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
                                 size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
                                 vsf_dmatch* d_matches, int32_t* d_nmatches);
 
+/* ---------------- the reference's own steps between matcher and outputs, on the device ---------------- */
+
+/* Frontend::RemoveAmbigStereo (slam_frontend.cc:353-398) for n_frames stereo frames in time order, applied to the
+ * outputs of vsf_stereo_batch_dev (same layouts: image 2f = left, 2f+1 = right of frame f).  F: the fundamental
+ * matrix, 9 floats row major (HOST pointer).  thr_in: the threshold in force before frame 0 (the reference's static
+ * starts at 10000, cc:353).  d_thr_override: NULL, or a DEVICE array of n_frames thresholds applied as they are
+ * (multi-GPU: every rank derives them from all ranks' means, vision_slam_frontend_amd/distributed.py).
+ * Outputs (device): d_means [n_frames]: mean residual over ALL matches of the frame, summed in match order (NaN for
+ * a frame without matches: the reference divides 0/0 there, here the threshold is left unchanged); d_thr
+ * [n_frames + 1]: threshold applied to each frame and the one in force after the batch (written without override);
+ * d_kp_out / d_desc_out / d_counts_out: both frames rebuilt from the surviving pairs in match order (row i of the
+ * left frame matches row i of the right frame, cc:396-397), layouts as the inputs. */
+vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const uint8_t* d_desc,
+                                             const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_frames,
+                                             const float* F, float thr_in, const float* d_thr_override,
+                                             float* d_means, float* d_thr, vsf_keypoint* d_kp_out,
+                                             uint8_t* d_desc_out, int32_t* d_counts_out);
+/* Frontend::GetFeatureMatches (slam_frontend.cc:282-309) for n_pairs (past set, current set) pairs: GetMatches, then
+ * std::sort by DMatch::operator< (distance only; the permutation is libstdc++'s), then the cut to
+ * int(size * best_percent).  Set addressing as vsf_match_batch_dev.  d_pairs: [n_pairs][max_keypoints][2] uint64
+ * (FeatureMatch::feature_idx_initial = index in the past set, feature_idx_current = index in the current set),
+ * d_npairs [n_pairs].  Needs max_keypoints < 65536. */
+vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
+                                         size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
+                                         int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs);
+
 /* ---------------- introspection for kernel-level parity tests and the roofline model ---------------- */
 
 /* Copies level `level` of image `image` from the last extract to host (blurred: 0 = FAST/Harris/angle input,

@@ -1,0 +1,143 @@
+"""SURVEY 8(f) row f1 on the device: Frontend::RemoveAmbigStereo (slam_frontend.cc:353-398: residuals, ordered mean,
+threshold chain, re-indexing) and Frontend::GetFeatureMatches (cc:282-309: GetMatches + std::sort + best-percent cut)
+through vsf_remove_ambig_stereo_batch_dev / vsf_feature_matches_batch_dev, bit for bit against the CPU oracle's
+restatement of the same reference code (which uses the host libstdc++ std::sort)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+NF = 1500
+F_RECT = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # l^T F r = y_r - y_l on a rectified pair
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from vision_slam_frontend_amd import capi
+    capi.lib()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def batch(capi):
+    """Four time-ordered stereo frames through the benchmarked entry point; everything stays on the device."""
+    from vision_slam_frontend_amd import synth
+    frames = synth.stereo_stream(4, 640, 480)
+    # frame 2 gets a blank right image: no stereo matches there (quirk Q3: the threshold must carry over)
+    frames[2, 1] = 128
+    B = len(frames)
+    dev = torch.device("cuda", 0)
+    p = capi.default_params(640, 480, max_images=2 * B, nfeatures=NF)
+    ctx = capi.Context(p)
+    K = ctx.params.max_keypoints
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    t = dict(
+        img=torch.from_numpy(np.ascontiguousarray(frames)).to(dev),
+        kp=torch.zeros((2 * B, K, 28), dtype=torch.uint8, device=dev),
+        desc=torch.zeros((2 * B, K, 32), dtype=torch.uint8, device=dev),
+        counts=torch.zeros(2 * B, dtype=torch.int32, device=dev),
+        m=torch.zeros((B, K, 16), dtype=torch.uint8, device=dev),
+        nm=torch.zeros(B, dtype=torch.int32, device=dev),
+        means=torch.zeros(B, dtype=torch.float32, device=dev),
+        thr=torch.zeros(B + 1, dtype=torch.float32, device=dev),
+        kp2=torch.zeros((2 * B, K, 28), dtype=torch.uint8, device=dev),
+        desc2=torch.zeros((2 * B, K, 32), dtype=torch.uint8, device=dev),
+        counts2=torch.zeros(2 * B, dtype=torch.int32, device=dev),
+    )
+    ctx.stereo_batch_dev(t["img"].data_ptr(), B, 640 * 480, 640, t["kp"].data_ptr(), t["desc"].data_ptr(),
+                         t["counts"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr())
+    ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
+                                      F_RECT, 10000.0, 0, t["means"].data_ptr(), t["thr"].data_ptr(),
+                                      t["kp2"].data_ptr(), t["desc2"].data_ptr(), t["counts2"].data_ptr())
+    assert ctx.sync() == capi.VSF_OK
+    yield ctx, t, B, K
+    ctx.set_stream(None)
+    ctx.close()
+
+
+def _np(t, dtype=None):
+    a = t.cpu().numpy()
+    return a if dtype is None else a.view(dtype)
+
+
+def test_remove_ambig_stereo_chain(batch, oracle):
+    ctx, t, B, K = batch
+    kp = _np(t["kp"]).reshape(2 * B, K * 28).view(oracle.KEYPOINT_DTYPE)
+    desc, counts = _np(t["desc"]), _np(t["counts"])
+    m = _np(t["m"]).reshape(B, K * 16).view(oracle.DMATCH_DTYPE)
+    nm = _np(t["nm"])
+    kp2 = _np(t["kp2"]).reshape(2 * B, K * 28).view(oracle.KEYPOINT_DTYPE)
+    desc2, counts2 = _np(t["desc2"]), _np(t["counts2"])
+    means, thr = _np(t["means"]), _np(t["thr"])
+    cur = np.float32(10000.0)
+    assert nm[2] == 0 and nm[0] > 50
+    for f in range(B):
+        kl, kr = kp[2 * f, :counts[2 * f]], kp[2 * f + 1, :counts[2 * f + 1]]
+        mm = m[f, :nm[f]]
+        assert thr[f] == cur, "threshold applied to frame %d" % f
+        keep, res, thr_new, kept = oracle.remove_ambig_stereo(kl, kr, mm, F_RECT, float(cur))
+        if nm[f] == 0:
+            assert np.isnan(means[f]) and np.float32(thr_new) == cur  # unchanged (quirk Q3)
+        else:
+            assert np.float32(means[f] + np.float32(2.0)) == np.float32(thr_new), "ordered mean of frame %d" % f
+        cur = np.float32(thr_new)
+        assert counts2[2 * f] == counts2[2 * f + 1] == kept
+        q, tr = mm["queryIdx"][keep], mm["trainIdx"][keep]
+        assert kp2[2 * f, :kept].tobytes() == kl[q].tobytes()
+        assert kp2[2 * f + 1, :kept].tobytes() == kr[tr].tobytes()
+        np.testing.assert_array_equal(desc2[2 * f, :kept], desc[2 * f][q])
+        np.testing.assert_array_equal(desc2[2 * f + 1, :kept], desc[2 * f + 1][tr])
+    assert thr[B] == cur
+    # the first frame passes everything (threshold 10000), later frames are filtered by mean + 2
+    assert counts2[0] == nm[0] and 0 < counts2[2] < nm[1]
+
+
+def test_threshold_override(batch, capi):
+    ctx, t, B, K = batch
+    dev = t["kp"].device
+    over = torch.tensor([0.5, 1e9, 0.0, 3.0], dtype=torch.float32, device=dev)
+    counts3 = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    means3 = torch.zeros(B, dtype=torch.float32, device=dev)
+    ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
+                                      F_RECT, 10000.0, over.data_ptr(), means3.data_ptr(), 0, t["kp2"].data_ptr(),
+                                      t["desc2"].data_ptr(), counts3.data_ptr())
+    assert ctx.sync() == capi.VSF_OK
+    c3, nm = counts3.cpu().numpy(), t["nm"].cpu().numpy()
+    assert c3[2] == nm[1] and c3[0] < nm[0]
+    np.testing.assert_array_equal(means3.cpu().numpy().view(np.uint32), t["means"].cpu().numpy().view(np.uint32))
+    # restore the chained result for the tests below
+    ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
+                                      F_RECT, 10000.0, 0, t["means"].data_ptr(), t["thr"].data_ptr(),
+                                      t["kp2"].data_ptr(), t["desc2"].data_ptr(), t["counts2"].data_ptr())
+    assert ctx.sync() == capi.VSF_OK
+
+
+@pytest.mark.parametrize("best_percent", [0.3, 1.0])
+def test_feature_matches_sorted_and_trimmed(batch, oracle, capi, best_percent):
+    """Temporal factors (cc:424-434): every earlier filtered left frame against the newest one, one call."""
+    ctx, t, B, K = batch
+    dev = t["kp"].device
+    past = [0, 1]  # frames with survivors (frame 2 is empty)
+    q_set = torch.tensor([2 * f for f in past] + [4], dtype=torch.int32, device=dev)  # incl. the empty frame 2
+    t_set = torch.tensor([6] * 3, dtype=torch.int32, device=dev)
+    npairs = 3
+    d_pairs = torch.zeros((npairs, K, 2), dtype=torch.int64, device=dev)
+    d_np = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    bp = float(np.float32(best_percent))
+    ctx.feature_matches_batch_dev(t["desc2"].data_ptr(), t["counts2"].data_ptr(), K * 32, q_set.data_ptr(),
+                                  t_set.data_ptr(), npairs, bp, d_pairs.data_ptr(), d_np.data_ptr())
+    assert ctx.sync() == capi.VSF_OK
+    desc2, counts2 = t["desc2"].cpu().numpy(), t["counts2"].cpu().numpy()
+    pairs, npr = d_pairs.cpu().numpy(), d_np.cpu().numpy()
+    cur = desc2[6, :counts2[6]]
+    total = 0
+    for i, s in enumerate([0, 2, 4]):
+        pd = desc2[s, :counts2[s]]
+        mm = oracle.sort_and_trim(oracle.get_matches(pd, cur), bp)
+        assert npr[i] == len(mm), "pair %d" % i
+        np.testing.assert_array_equal(pairs[i, :len(mm), 0], mm["queryIdx"], err_msg="pair %d initial idx" % i)
+        np.testing.assert_array_equal(pairs[i, :len(mm), 1], mm["trainIdx"], err_msg="pair %d current idx" % i)
+        total += len(mm)
+    assert npr[2] == 0 and total > 20

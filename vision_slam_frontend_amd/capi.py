@@ -26,7 +26,7 @@ EXPORTS = [
     "vsf_params_default", "vsf_params_set_ratio", "vsf_create", "vsf_destroy", "vsf_status_string",
     "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_batch_dev", "vsf_match_batch_dev",
-    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
+    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best",
 ]
@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         L.vsf_match_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp, vp, vp]
         L.vsf_stereo_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp, vp, vp]
         L.vsf_set_lanes.argtypes = [vp, i32]
+        L.vsf_remove_ambig_stereo_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.c_float, vp, vp, vp, vp, vp, vp]
+        L.vsf_feature_matches_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, C.c_float, vp, vp]
         L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
         L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
         L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
@@ -233,6 +235,21 @@ class Context:
         self._check(lib().vsf_stereo_batch_dev(self._h, _p(d_imgs), n_frames, image_stride, row_stride, _p(d_kp),
                                                _p(d_desc), _p(d_counts), _p(d_matches), _p(d_nmatches)),
                     "vsf_stereo_batch_dev")
+
+    def remove_ambig_stereo_batch_dev(self, d_kp: int, d_desc: int, d_matches: int, d_nmatches: int, n_frames: int,
+                                      F: np.ndarray, thr_in: float, d_thr_override: int, d_means: int, d_thr: int,
+                                      d_kp_out: int, d_desc_out: int, d_counts_out: int):
+        Fh = np.ascontiguousarray(F, np.float32).reshape(9)
+        self._check(lib().vsf_remove_ambig_stereo_batch_dev(self._h, _p(d_kp), _p(d_desc), _p(d_matches), _p(d_nmatches),
+                                                            n_frames, _p(Fh), thr_in, _p(d_thr_override), _p(d_means),
+                                                            _p(d_thr), _p(d_kp_out), _p(d_desc_out), _p(d_counts_out)),
+                    "vsf_remove_ambig_stereo_batch_dev")
+
+    def feature_matches_batch_dev(self, d_desc: int, d_counts: int, set_stride: int, d_q_set: int, d_t_set: int,
+                                  n_pairs: int, best_percent: float, d_pairs: int, d_npairs: int):
+        self._check(lib().vsf_feature_matches_batch_dev(self._h, _p(d_desc), _p(d_counts), set_stride, _p(d_q_set),
+                                                        _p(d_t_set), n_pairs, best_percent, _p(d_pairs), _p(d_npairs)),
+                    "vsf_feature_matches_batch_dev")
 
     def debug_retain_best(self, keys: np.ndarray, n_points: int, use_lds: bool = False, mode: int = 0):
         """retainBest on the GPU; returns (keys, ids) of the survivors in the order the GPU left them."""

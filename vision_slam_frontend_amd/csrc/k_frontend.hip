@@ -1,0 +1,186 @@
+// k_frontend.hip -- SURVEY.md section 8(f) row f1: the two reference-code steps between the matcher and the outputs,
+// on the device, for batches of frames resident in HBM:
+//
+//   Frontend::RemoveAmbigStereo  (slam_frontend.cc:353-398): epipolar residual |l^T F r| of every stereo match
+//       (float, products accumulated left to right as Eigen's 1x3 * 3x3 * 3x1 does), its mean over ALL matches of
+//       the frame summed sequentially in match order (float addition is not associative), the threshold chain
+//       thr[k] = mean[k-1] + 2 (static stereo_ambig_constraint, cc:353, :392-394; a frame without matches leaves the
+//       threshold unchanged where the reference divides by zero), and the rebuild of both frames
+//       from the surviving pairs in match order (cc:396-397).
+//   Frontend::GetFeatureMatches  (slam_frontend.cc:282-309): std::sort of the ratio-tested matches by
+//       DMatch::operator< (distance only; unstable, so the permutation is libstdc++'s introsort + insertion sort,
+//       restated in vsf_select.h) and the cut to  int(size * best_percent)  pairs (float product, cc:290).
+//
+// The residual kernel is embarrassingly parallel except for the ordered sum (one lane, 4 values per LDS read); the
+// sort runs the sequential restatement on one lane per (query set, train set) pair with the keys in LDS -- pairs are
+// independent, a batch sorts them all concurrently.
+#include "vsf_internal.h"
+#include "vsf_select.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ---- RemoveAmbigStereo, step 1: residuals + ordered mean per frame ----
+__global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint* __restrict__ kp,
+                                                              const vsf_dmatch* __restrict__ matches,
+                                                              const int32_t* __restrict__ nmatches, int max_rows,
+                                                              const float* __restrict__ F,  // 9 floats, row major
+                                                              float* __restrict__ residual,  // [frames][max_rows]
+                                                              float* __restrict__ mean) {    // [frames], NaN if empty
+  const int f = blockIdx.x;
+  const int n = min(nmatches[f], max_rows);
+  const vsf_keypoint* left = kp + (size_t)(2 * f) * max_rows;
+  const vsf_keypoint* right = kp + (size_t)(2 * f + 1) * max_rows;
+  const vsf_dmatch* m = matches + (size_t)f * max_rows;
+  float* res = residual + (size_t)f * max_rows;
+  float Fm[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Fm[i] = F[i];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const vsf_dmatch dm = m[i];
+    const float lx = left[dm.queryIdx].x, ly = left[dm.queryIdx].y;
+    const float rx = right[dm.trainIdx].x, ry = right[dm.trainIdx].y;
+    float t[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[j] = (lx * Fm[0 * 3 + j] + ly * Fm[1 * 3 + j]) + 1.0f * Fm[2 * 3 + j];
+    res[i] = fabsf((t[0] * rx + t[1] * ry) + t[2] * 1.0f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float avg = 0.0f;  // avg_constraint += constraint, in match order
+    for (int i = 0; i < n; i++) avg += res[i];
+    mean[f] = n > 0 ? avg / (float)n : __builtin_nanf("");
+  }
+}
+
+// ---- step 2: thr[0] = thr_in, thr[k] = mean[k-1] + 2 unless frame k-1 had no match; thr[n] = value after the batch ----
+__global__ void stereo_threshold_chain_kernel(const float* __restrict__ mean, int n, float thr_in,
+                                              float* __restrict__ thr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float cur = thr_in;
+  for (int k = 0; k < n; k++) {
+    thr[k] = cur;
+    const float m = mean[k];
+    if (m == m) cur = m + 2.0f;  // padding_from_average, cc:392
+  }
+  thr[n] = cur;
+}
+
+// ---- step 3: keep residual <= thr, rebuild both frames in match order ----
+__global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* __restrict__ kp,
+                                                            const uint8_t* __restrict__ desc,
+                                                            const vsf_dmatch* __restrict__ matches,
+                                                            const int32_t* __restrict__ nmatches, int max_rows,
+                                                            const float* __restrict__ residual,
+                                                            const float* __restrict__ thr,
+                                                            vsf_keypoint* __restrict__ kp_out,   // [2*frames][max_rows]
+                                                            uint8_t* __restrict__ desc_out,      // [2*frames][max_rows][32]
+                                                            int32_t* __restrict__ counts_out) {  // [2*frames]
+  __shared__ int wsum[4];
+  __shared__ int s_base;
+  const int f = blockIdx.x;
+  const int n = min(nmatches[f], max_rows);
+  const float th = thr[f];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const size_t L = (size_t)(2 * f) * max_rows, R = (size_t)(2 * f + 1) * max_rows;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    bool keep = false;
+    vsf_dmatch dm{0, 0, 0, 0.f};
+    if (i < n) {
+      dm = matches[(size_t)f * max_rows + i];
+      keep = residual[(size_t)f * max_rows + i] <= th;
+    }
+    const uint64_t b = __ballot(keep);
+    const int within = __popcll(b & ((1ull << lane) - 1));
+    if (lane == 0) wsum[wid] = __popcll(b);
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wid; w++) base += wsum[w];
+    if (keep) {
+      const int o = base + within;
+      kp_out[L + o] = kp[L + dm.queryIdx];
+      kp_out[R + o] = kp[R + dm.trainIdx];
+      const uint4* ls = reinterpret_cast<const uint4*>(desc + (L + dm.queryIdx) * VSF_DESC_BYTES);
+      const uint4* rs = reinterpret_cast<const uint4*>(desc + (R + dm.trainIdx) * VSF_DESC_BYTES);
+      uint4* ld = reinterpret_cast<uint4*>(desc_out + (L + o) * VSF_DESC_BYTES);
+      uint4* rd = reinterpret_cast<uint4*>(desc_out + (R + o) * VSF_DESC_BYTES);
+      ld[0] = ls[0];
+      ld[1] = ls[1];
+      rd[0] = rs[0];
+      rd[1] = rs[1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counts_out[2 * f] = s_base;
+    counts_out[2 * f + 1] = s_base;
+  }
+}
+
+// ---- GetFeatureMatches: std::sort by distance + cut to int(n * best_percent) ----
+struct SortKey {
+  uint32_t dist;  // Hamming distance (DMatch::distance is (float)int, so the order is the integers')
+  uint32_t qt;    // queryIdx | trainIdx << 16
+};
+struct SortLess {
+  __device__ bool operator()(const SortKey& a, const SortKey& b) const { return a.dist < b.dist; }
+};
+
+__global__ __launch_bounds__(64) void sort_trim_kernel(const vsf_dmatch* __restrict__ matches,
+                                                       const int32_t* __restrict__ nmatches, int max_rows,
+                                                       float best_percent, SortKey* __restrict__ scratch,
+                                                       uint64_t* __restrict__ pairs,  // [pairs][max_rows][2]
+                                                       int32_t* __restrict__ npairs) {
+  extern __shared__ SortKey keys[];  // lds_rows entries, or unused when the pair does not fit
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int n = min(nmatches[p], max_rows);
+  const vsf_dmatch* m = matches + (size_t)p * max_rows;
+  SortKey* a = scratch + (size_t)p * max_rows;  // HBM copy (only used when n exceeds the LDS array)
+  const bool in_lds = n <= (int)(VSF_SORT_LDS_ROWS);
+  SortKey* arr = in_lds ? keys : a;
+  for (int i = lane; i < n; i += 64) {
+    const vsf_dmatch dm = m[i];
+    arr[i] = SortKey{(uint32_t)(int)dm.distance, (uint32_t)dm.queryIdx | ((uint32_t)dm.trainIdx << 16)};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) vsf_sel::sort_(arr, n, SortLess());
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // const int num_good_matches = matches.size() * config_.best_percent_;   (size_t -> float, float product, -> int)
+  int good = (int)((float)(size_t)n * best_percent);
+  good = min(max(good, 0), n);
+  uint64_t* out = pairs + (size_t)p * max_rows * 2;
+  for (int i = lane; i < good; i += 64) {
+    const SortKey k = arr[i];
+    out[2 * i] = (uint64_t)(k.qt & 0xFFFFu);      // FeatureMatch::feature_idx_initial  = queryIdx (cc:295)
+    out[2 * i + 1] = (uint64_t)(k.qt >> 16);      // FeatureMatch::feature_idx_current  = trainIdx (cc:296)
+  }
+  if (lane == 0) npairs[p] = good;
+}
+
+}  // namespace
+
+void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
+                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F,
+                              const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
+                              vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s) {
+  hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_matches, d_nmatches, max_rows,
+                     d_F, d_residual, d_mean);
+  if (!d_thr_override)
+    hipLaunchKernelGGL(stereo_threshold_chain_kernel, dim3(1), dim3(64), 0, s, d_mean, n_frames, thr_in, d_thr);
+  hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_desc, d_matches, d_nmatches,
+                     max_rows, d_residual, d_thr_override ? d_thr_override : d_thr, d_kp_out, d_desc_out, d_counts_out);
+}
+
+void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
+                          float best_percent, void* d_scratch, uint64_t* d_pairs, int32_t* d_npairs, hipStream_t s) {
+  hipLaunchKernelGGL(sort_trim_kernel, dim3(n_pairs), dim3(64), VSF_SORT_LDS_ROWS * sizeof(SortKey), s, d_matches,
+                     d_nmatches, max_rows, best_percent, reinterpret_cast<SortKey*>(d_scratch), d_pairs, d_npairs);
+}

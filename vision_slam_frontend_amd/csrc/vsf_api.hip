@@ -268,6 +268,14 @@ struct vsf_ctx {
   int32_t* m_idx2 = nullptr;
   int32_t* m_dist2 = nullptr;
   int m_pairs = 0, m_rows = 0;
+  // f1 work buffers: residuals [frames][rows], F (9 floats), matches / counts / sort keys of the temporal pairs
+  float* f_residual = nullptr;
+  float* f_F = nullptr;
+  int f_frames = 0;
+  vsf_dmatch* t_matches = nullptr;
+  int32_t* t_nmatches = nullptr;
+  void* t_sortkeys = nullptr;
+  int t_pairs = 0;
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -675,6 +683,11 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->st_counts);
   hipFree(ctx->m_idx2);
   hipFree(ctx->m_dist2);
+  hipFree(ctx->f_residual);
+  hipFree(ctx->f_F);
+  hipFree(ctx->t_matches);
+  hipFree(ctx->t_nmatches);
+  hipFree(ctx->t_sortkeys);
   hipFree(ctx->mh_desc);
   hipFree(ctx->mh_counts);
   hipFree(ctx->mh_matches);
@@ -824,6 +837,62 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
   if (st != VSF_OK) return st;
   ctx->last_images = im;
   ctx->last_valid = true;
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+// ---------------- reference steps between matcher and outputs ----------------
+
+vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const uint8_t* d_desc,
+                                             const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_frames,
+                                             const float* F, float thr_in, const float* d_thr_override,
+                                             float* d_means, float* d_thr, vsf_keypoint* d_kp_out,
+                                             uint8_t* d_desc_out, int32_t* d_counts_out) {
+  if (!ctx || !d_kp || !d_desc || !d_matches || !d_nmatches || n_frames < 1 || !F || !d_means || !d_kp_out ||
+      !d_desc_out || !d_counts_out || (!d_thr_override && !d_thr))
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_frames > ctx->f_frames) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->f_residual);
+    ctx->f_residual = nullptr;
+    VSF_HIP(hipMalloc((void**)&ctx->f_residual, (size_t)n_frames * K * sizeof(float)));
+    ctx->f_frames = n_frames;
+  }
+  if (!ctx->f_F) VSF_HIP(hipMalloc((void**)&ctx->f_F, 9 * sizeof(float)));
+  VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, ctx->f_F, d_thr_override, thr_in,
+                           ctx->f_residual, d_means, d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
+                                         size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
+                                         int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs) {
+  if (!ctx || !d_pairs || !d_npairs || n_pairs < 1 || !(best_percent >= 0.f)) return VSF_ERR_INVALID_ARG;
+  if (ctx->p.max_keypoints >= 65536) return VSF_ERR_UNSUPPORTED;  // (query, train) indices are packed 16 + 16 bit
+  VSF_HIP(hipSetDevice(ctx->device));
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_pairs > ctx->t_pairs) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->t_matches);
+    hipFree(ctx->t_nmatches);
+    hipFree(ctx->t_sortkeys);
+    ctx->t_matches = nullptr;
+    ctx->t_nmatches = nullptr;
+    ctx->t_sortkeys = nullptr;
+    VSF_HIP(hipMalloc((void**)&ctx->t_matches, (size_t)n_pairs * K * sizeof(vsf_dmatch)));
+    VSF_HIP(hipMalloc((void**)&ctx->t_nmatches, (size_t)n_pairs * sizeof(int32_t)));
+    VSF_HIP(hipMalloc(&ctx->t_sortkeys, (size_t)n_pairs * K * 8));
+    ctx->t_pairs = n_pairs;
+  }
+  vsf_status st = vsf_match_batch_dev(ctx, d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, nullptr, nullptr,
+                                      ctx->t_matches, ctx->t_nmatches);
+  if (st != VSF_OK) return st;
+  vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, ctx->t_sortkeys, d_pairs,
+                       d_npairs, ctx->stream);
   VSF_HIP(hipGetLastError());
   return VSF_OK;
 }

@@ -14,6 +14,7 @@
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
 #define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
+#define VSF_SORT_LDS_ROWS 4096   // matches of one pair sorted in LDS (8 B each); larger pairs sort in HBM scratch
 #define VSF_IC_ITEMS 320         // ICAngles disc items per byte phase: 31 rows x 9 dwords = 279, padded to 5 x 64
 
 // ---- pyramid level descriptor (device-resident table, read through scalar loads) ----
@@ -116,5 +117,13 @@ void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, c
                               int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
                               hipStream_t s);
+
+// k_frontend.hip
+void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
+                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F,
+                              const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
+                              vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s);
+void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
+                          float best_percent, void* d_scratch, uint64_t* d_pairs, int32_t* d_npairs, hipStream_t s);
 
 #endif  // VSF_INTERNAL_H_
