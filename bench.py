@@ -129,6 +129,11 @@ def main() -> int:
         dist.init_process_group("nccl", device_id=dev)
 
     B, W, H, NF = args.batch, args.width, args.height, args.nfeatures
+    # One explicit (non-default) stream carries everything: buffer initialisation, the HIP kernels (vsf_set_stream),
+    # the per-stage hipEvents and, for N > 1, the RCCL gather.  (torch's default stream has handle 0, which
+    # vsf_set_stream reads as "use the context's own stream".)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     p = capi.default_params(W, H, max_images=2 * B, nfeatures=NF)
     ctx = capi.Context(p, device=local_rank)
     K = ctx.params.max_keypoints
@@ -147,9 +152,10 @@ def main() -> int:
             "matches": [torch.empty_like(d_matches) for _ in range(world)],
             "nmatches": [torch.empty_like(d_nmatches) for _ in range(world)],
         }
-    stream = torch.cuda.current_stream()
+    assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_lanes(args.lanes)
+    torch.cuda.synchronize()
 
     def step():
         ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(),

@@ -43,14 +43,14 @@ def _run_stereo_batch(capi, frames, nf, lanes=1):
         d_kp, d_desc, d_counts = _dev_outputs(2 * B, K, dev)
         d_m = torch.zeros((B, K, 16), dtype=torch.uint8, device=dev)
         d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()  # torch's fills are done before the context's stream touches the buffers
         ctx.set_lanes(lanes)
+        torch.cuda.synchronize()
         ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(),
                              d_m.data_ptr(), d_nm.data_ptr())
         assert ctx.sync() == capi.VSF_OK
         kp, desc, counts = d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_counts.cpu().numpy()
         m, nm = d_m.cpu().numpy(), d_nm.cpu().numpy()
-        ctx.set_stream(None)
     return kp, desc, counts, m, nm
 
 
@@ -120,9 +120,10 @@ def test_config5_temporal_window_multi_query(capi, oracle):
     p = capi.default_params(640, 480, max_images=Wn, nfeatures=NF)
     with capi.Context(p) as ctx:
         K = ctx.params.max_keypoints
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()  # torch's fills are done before the context's stream touches the buffers
         d_img = torch.from_numpy(np.ascontiguousarray(lefts)).to(dev)
         d_kp, d_desc, d_counts = _dev_outputs(Wn, K, dev)
+        torch.cuda.synchronize()
         ctx.extract_batch_dev(d_img.data_ptr(), Wn, 640 * 480, 640, d_kp.data_ptr(), d_desc.data_ptr(),
                               d_counts.data_ptr())
         npairs = Wn - 1
@@ -132,12 +133,12 @@ def test_config5_temporal_window_multi_query(capi, oracle):
         d_dist = torch.zeros((npairs, K, 2), dtype=torch.int32, device=dev)
         d_m = torch.zeros((npairs, K, 16), dtype=torch.uint8, device=dev)
         d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         ctx.match_batch_dev(d_desc.data_ptr(), d_counts.data_ptr(), K * 32, q_set.data_ptr(), t_set.data_ptr(), npairs,
                             d_idx.data_ptr(), d_dist.data_ptr(), d_m.data_ptr(), d_nm.data_ptr())
         assert ctx.sync() == capi.VSF_OK
         desc, counts = d_desc.cpu().numpy(), d_counts.cpu().numpy()
         idx, dist, m, nm = d_idx.cpu().numpy(), d_dist.cpu().numpy(), d_m.cpu().numpy(), d_nm.cpu().numpy()
-        ctx.set_stream(None)
     sets = []
     for i in range(Wn):
         o = oracle.Orb(nfeatures=NF)

@@ -32,7 +32,7 @@ def batch(capi):
     p = capi.default_params(640, 480, max_images=2 * B, nfeatures=NF)
     ctx = capi.Context(p)
     K = ctx.params.max_keypoints
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()  # torch's fills are done before the context's stream touches the buffers
     t = dict(
         img=torch.from_numpy(np.ascontiguousarray(frames)).to(dev),
         kp=torch.zeros((2 * B, K, 28), dtype=torch.uint8, device=dev),
@@ -46,6 +46,7 @@ def batch(capi):
         desc2=torch.zeros((2 * B, K, 32), dtype=torch.uint8, device=dev),
         counts2=torch.zeros(2 * B, dtype=torch.int32, device=dev),
     )
+    torch.cuda.synchronize()
     ctx.stereo_batch_dev(t["img"].data_ptr(), B, 640 * 480, 640, t["kp"].data_ptr(), t["desc"].data_ptr(),
                          t["counts"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr())
     ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
@@ -53,7 +54,6 @@ def batch(capi):
                                       t["kp2"].data_ptr(), t["desc2"].data_ptr(), t["counts2"].data_ptr())
     assert ctx.sync() == capi.VSF_OK
     yield ctx, t, B, K
-    ctx.set_stream(None)
     ctx.close()
 
 
@@ -100,6 +100,7 @@ def test_threshold_override(batch, capi):
     over = torch.tensor([0.5, 1e9, 0.0, 3.0], dtype=torch.float32, device=dev)
     counts3 = torch.zeros(2 * B, dtype=torch.int32, device=dev)
     means3 = torch.zeros(B, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
     ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
                                       F_RECT, 10000.0, over.data_ptr(), means3.data_ptr(), 0, t["kp2"].data_ptr(),
                                       t["desc2"].data_ptr(), counts3.data_ptr())
@@ -126,6 +127,7 @@ def test_feature_matches_sorted_and_trimmed(batch, oracle, capi, best_percent):
     d_pairs = torch.zeros((npairs, K, 2), dtype=torch.int64, device=dev)
     d_np = torch.zeros(npairs, dtype=torch.int32, device=dev)
     bp = float(np.float32(best_percent))
+    torch.cuda.synchronize()
     ctx.feature_matches_batch_dev(t["desc2"].data_ptr(), t["counts2"].data_ptr(), K * 32, q_set.data_ptr(),
                                   t_set.data_ptr(), npairs, bp, d_pairs.data_ptr(), d_np.data_ptr())
     assert ctx.sync() == capi.VSF_OK
