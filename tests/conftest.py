@@ -4,6 +4,11 @@ from pathlib import Path
 
 import pytest
 
+try:  # load torch's HIP runtime before libvsf_hip.so pulls in /opt/rocm's: the other order leaves torch without GPUs
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

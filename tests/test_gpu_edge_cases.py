@@ -1,0 +1,127 @@
+"""Edge cases of the hot path on the GPU, bit for bit against the oracle: images without or with very few corners,
+odd image sizes whose top pyramid levels are too small for the 31-pixel border (cv::KeyPointsFilter::runByImageBorder
+clears them), other ORB parameter sets (the reference's nfeatures = 10000 literal, a classic 8-level / 1.2 pyramid, a
+lower FAST threshold), padded row strides on the device API, and the capacity status."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from vision_slam_frontend_amd import capi
+    capi.lib()
+    return capi
+
+
+def _both(capi, oracle, img, nfeatures, **kw):
+    h, w = img.shape
+    okw = {k: v for k, v in kw.items() if k in ("fast_threshold", "nlevels", "scale_factor")}
+    o = oracle.Orb(nfeatures=nfeatures, **okw)
+    o.run(img)
+    rk, rd = o.result()
+    p = capi.default_params(w, h, max_images=1, nfeatures=nfeatures, **kw)
+    with capi.Context(p) as ctx:
+        for l in range(ctx.nlevels):
+            assert ctx.level_info(l) == o.level_info(l)
+        kp, desc = ctx.extract(img)
+    assert len(kp) == len(rk)
+    assert kp.tobytes() == rk.tobytes()
+    np.testing.assert_array_equal(desc, rd)
+    return kp, desc
+
+
+def test_flat_image_has_no_keypoints(capi, oracle):
+    img = np.full((240, 320), 97, np.uint8)
+    kp, desc = _both(capi, oracle, img, 500)
+    assert len(kp) == 0
+    with capi.Context(capi.default_params(320, 240, max_images=1, nfeatures=500)) as ctx:
+        assert len(ctx.get_matches(desc, desc)) == 0
+        i2, d2 = ctx.knn2_hamming(np.zeros((3, 32), np.uint8), desc)
+        assert (i2 == -1).all()
+
+
+def test_single_square_few_keypoints(capi, oracle):
+    """Far fewer corners than the budget: every level keeps everything it finds (retainBest is a no-op)."""
+    img = np.full((240, 320), 60, np.uint8)
+    img[100:140, 150:200] = 200
+    kp, _ = _both(capi, oracle, img, 500)
+    assert 0 < len(kp) < 500
+
+
+@pytest.mark.parametrize("w,h", [(333, 257), (161, 131), (100, 75), (64, 64)])
+def test_odd_and_small_sizes(capi, oracle, w, h):
+    """Widths that are no multiple of 4 / 64, and sizes whose upper levels (or all levels) fall under the border."""
+    from vision_slam_frontend_amd import synth
+    img = synth.stereo_pair(w, h, 0, n_objects=max(40, w * h // 200))[0]
+    kp, _ = _both(capi, oracle, img, 700)
+    if w >= 161:
+        assert len(kp) > 50
+
+
+def test_reference_literal_nfeatures_10000(capi, oracle, stereo640):
+    kp, _ = _both(capi, oracle, stereo640[0], 10000)  # cv::ORB::create(10000, ...) slam_frontend.cc:205
+    assert len(kp) > 8000
+
+
+def test_classic_orb_pyramid_and_low_threshold(capi, oracle, stereo640):
+    kp, _ = _both(capi, oracle, stereo640[0], 1000, nlevels=8, scale_factor=1.2, fast_threshold=7)
+    assert len(kp) == 1000
+
+
+def test_single_level(capi, oracle, stereo640):
+    kp, _ = _both(capi, oracle, stereo640[0], 300, nlevels=1)
+    assert len(kp) >= 300
+
+
+def test_padded_row_stride_device_api(capi, oracle, stereo640):
+    torch = pytest.importorskip("torch")
+    left = stereo640[0]
+    h, w = left.shape
+    pitch = 704  # rows 64 bytes longer than the image
+    buf = np.random.default_rng(3).integers(0, 255, (2, h, pitch), dtype=np.uint8)  # garbage in the padding
+    buf[:, :, :w] = left
+    dev = torch.device("cuda", 0)
+    p = capi.default_params(w, h, max_images=2, nfeatures=2000)
+    with capi.Context(p) as ctx:
+        K = ctx.params.max_keypoints
+        d_img = torch.from_numpy(buf).to(dev)
+        d_kp = torch.zeros((2, K, 28), dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros((2, K, 32), dtype=torch.uint8, device=dev)
+        d_counts = torch.zeros(2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.extract_batch_dev(d_img.data_ptr(), 2, h * pitch, pitch, d_kp.data_ptr(), d_desc.data_ptr(),
+                              d_counts.data_ptr())
+        assert ctx.sync() == capi.VSF_OK
+        o = oracle.Orb(nfeatures=2000)
+        o.run(left)
+        rk, rd = o.result()
+        for i in range(2):
+            n = int(d_counts[i])
+            assert n == len(rk)
+            assert d_kp[i, :n].cpu().numpy().tobytes() == rk.tobytes()
+            np.testing.assert_array_equal(d_desc[i, :n].cpu().numpy(), rd)
+
+
+def test_capacity_status_and_truncation(capi, oracle, stereo640):
+    """An output capacity below the keypoint count reports VSF_ERR_CAPACITY and fills exactly the capacity with the
+    first keypoints of the level-major order."""
+    left = stereo640[0]
+    o = oracle.Orb(nfeatures=2000)
+    o.run(left)
+    rk, rd = o.result()
+    p = capi.default_params(640, 480, max_images=1, nfeatures=2000, max_keypoints=777)
+    with capi.Context(p) as ctx:
+        with pytest.raises(capi.VsfError) as e:
+            ctx.extract(left)
+        assert e.value.status == capi.VSF_ERR_CAPACITY
+        kp = np.zeros(777, capi.KEYPOINT_DTYPE)
+        desc = np.zeros((777, 32), np.uint8)
+        import ctypes as C
+        n = C.c_int()
+        st = capi.lib().vsf_extract(ctx._h, left.ctypes.data_as(C.c_void_p), 640, 480, 640, kp.ctypes.data_as(C.c_void_p),
+                                    desc.ctypes.data_as(C.c_void_p), 777, C.byref(n))
+        assert st == capi.VSF_ERR_CAPACITY and n.value == len(rk)
+        assert kp.tobytes() == rk[:777].tobytes()
+        np.testing.assert_array_equal(desc, rd[:777])
