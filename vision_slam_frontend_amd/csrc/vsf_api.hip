@@ -250,7 +250,8 @@ struct vsf_ctx {
   // Second lane of the batched entry points: half of a batch runs on `stream`, the other half on `aux_stream`
   // (frames are independent), so latency-bound stages of one half overlap VALU-bound stages of the other.
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side_fork = nullptr, ev_side_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  VsfSideStream side{};  // aux_stream, for the pyramid's second launch chain
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int last_hip = 0;
   Geometry orb, fast;
@@ -465,9 +466,8 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   const size_t K = (size_t)ctx->p.max_keypoints;
   {
     StageTimer t(ctx, st, VSF_STAGE_PYRAMID, g.nlevels - 1);
-    // one lane: the aux stream is idle, the pyramid chain of the second half of the images runs on it
-    const VsfSideStream side{ctx->aux_stream, ctx->ev_side_fork, ctx->ev_side_join};
-    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, ctx->lanes == 1 ? &side : nullptr);
+    // one lane: the aux stream is idle, the pyramid chain of the second half of the batch runs on it
+    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, ctx->lanes == 1 ? &ctx->side : nullptr);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
@@ -645,9 +645,15 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
   if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_side_join, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming) != hipSuccess)
     return fail(VSF_ERR_HIP);
+  ctx->side.stream[0] = ctx->aux_stream;
+  for (int i = 0; i < VSF_SIDE_STREAMS; i++) {
+    if (i > 0 && hipStreamCreateWithFlags(&ctx->side.stream[i], hipStreamNonBlocking) != hipSuccess)
+      return fail(VSF_ERR_HIP);
+    if (hipEventCreateWithFlags(&ctx->side.join[i], hipEventDisableTiming) != hipSuccess) return fail(VSF_ERR_HIP);
+    ctx->side.n = i + 1;
+  }
   if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipHostMalloc((void**)&ctx->h_status, sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
@@ -695,8 +701,14 @@ void vsf_destroy(vsf_ctx* ctx) {
   for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-  if (ctx->ev_side_fork) hipEventDestroy(ctx->ev_side_fork);
-  if (ctx->ev_side_join) hipEventDestroy(ctx->ev_side_join);
+  if (ctx->side.fork) hipEventDestroy(ctx->side.fork);
+  for (int i = 0; i < VSF_SIDE_STREAMS; i++) {
+    if (ctx->side.join[i]) hipEventDestroy(ctx->side.join[i]);
+    if (i > 0 && ctx->side.stream[i]) {
+      hipStreamSynchronize(ctx->side.stream[i]);
+      hipStreamDestroy(ctx->side.stream[i]);
+    }
+  }
   if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -91,10 +91,12 @@ struct VsfImages {
   int n;
 };
 
-// Optional second stream a launcher may fork independent kernels onto (joined back before it returns).
+// Optional extra streams a launcher may fork independent kernel chains onto (joined back before it returns).
+#define VSF_SIDE_STREAMS 1
 struct VsfSideStream {
-  hipStream_t stream;
-  hipEvent_t fork, join;
+  hipStream_t stream[VSF_SIDE_STREAMS];
+  hipEvent_t fork, join[VSF_SIDE_STREAMS];
+  int n;
 };
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                         hipStream_t s, const VsfSideStream* side);
