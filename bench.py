@@ -122,11 +122,17 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
+    rehearsal = bool(os.environ.get("VSF_BENCH_ONE_GPU"))  # N > 1 control flow on a one-GPU box: ranks share device 0
+    if rehearsal:                                          # and talk over gloo (RCCL refuses two ranks on one GPU)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     B, W, H, NF = args.batch, args.width, args.height, args.nfeatures
     # One explicit (non-default) stream carries everything: buffer initialisation, the HIP kernels (vsf_set_stream),
@@ -146,12 +152,8 @@ def main() -> int:
     d_nmatches = torch.zeros(B, dtype=torch.int32, device=dev)
     gather_bufs = None
     if world > 1 and rank == 0:
-        gather_bufs = {
-            "kp": [torch.empty((B, K, 28), dtype=torch.uint8, device=dev) for _ in range(world)],
-            "counts": [torch.empty(2 * B, dtype=torch.int32, device=dev) for _ in range(world)],
-            "matches": [torch.empty_like(d_matches) for _ in range(world)],
-            "nmatches": [torch.empty_like(d_nmatches) for _ in range(world)],
-        }
+        payload_bytes = B * K * 28 + 2 * B * 4 + B * K * 16 + B * 4
+        gather_bufs = [torch.empty(payload_bytes, dtype=torch.uint8, device=dev) for _ in range(world)]
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_lanes(args.lanes)
@@ -163,8 +165,8 @@ def main() -> int:
         if world > 1:
             # VisionFeature (left keypoints) / FeatureMatch payloads of this rank's frames -> rank 0 over RCCL.
             left_kp = d_kp.view(B, 2, K, 28)[:, 0].contiguous()
-            vd.gather_to_root({"kp": left_kp, "counts": d_counts, "matches": d_matches, "nmatches": d_nmatches},
-                              dst=0, bufs=gather_bufs)
+            vd.gather_packed_to_root({"kp": left_kp, "counts": d_counts, "matches": d_matches,
+                                      "nmatches": d_nmatches}, dst=0, bufs=gather_bufs)
 
     for _ in range(args.warmup):
         step()
@@ -184,7 +186,7 @@ def main() -> int:
     ctx.profile_enable(False)
     status = ctx.sync(allow_capacity=True)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -48,7 +48,14 @@ def _worker(rank: int, world: int, port: int, results):
             expect = np.array([_fake_outputs(f)[4] for r in range(world) for f in vd.frame_block(step, B, world, r)],
                               np.float32)
             all_ok &= bool(np.array_equal(flat, expect, equal_nan=True))
+            gp = vd.gather_packed_to_root(t, dst=0)  # one collective; must equal the per-tensor gather
             g = vd.gather_to_root(t, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    for k in t:
+                        all_ok &= bool(torch.equal(gp[r][k], g[k][r]))
+            else:
+                all_ok &= gp is None
             if rank == 0:
                 for r in range(world):
                     for i, f in enumerate(vd.frame_block(step, B, world, r)):
