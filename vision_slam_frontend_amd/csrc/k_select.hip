@@ -451,20 +451,43 @@ __device__ int par_retain_best(T* A, int n, int n_points, Greater greater, Great
   return n;
 }
 
-// HarrisResponses for one keypoint at integer (x0, y0).
+// HarrisResponses for one keypoint at integer (x0, y0): the 9x9 patch (7x7 block + Sobel reach) is fetched first as
+// 9 x 3 aligned dwords -- 27 independent loads in flight, one memory round trip -- and shifted into place with
+// v_alignbyte; the arithmetic then runs from registers.
 __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x0, int y0) {
-  const uint8_t* base = img + (size_t)(y0 - 3) * pitch + (x0 - 3);
-  int a = 0, b = 0, c = 0;
-  for (int i = 0; i < 7; i++) {
-    const uint8_t* pm = base + (i - 1) * pitch;
-    const uint8_t* p0 = base + i * pitch;
-    const uint8_t* pp = base + (i + 1) * pitch;
+  const int xs = x0 - 4;
+  const uint8_t* base = img + (size_t)(y0 - 4) * pitch + (xs & ~3);
+  const uint32_t sh = (uint32_t)(xs & 3);
+  uint32_t lo[9], mid[9], hi[9];
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-      const int Ix = ((int)p0[j + 1] - (int)p0[j - 1]) * 2 + ((int)pm[j + 1] - (int)pm[j - 1]) +
-                     ((int)pp[j + 1] - (int)pp[j - 1]);
-      const int Iy = ((int)pp[j] - (int)pm[j]) * 2 + ((int)pp[j - 1] - (int)pm[j - 1]) +
-                     ((int)pp[j + 1] - (int)pm[j + 1]);
+  for (int r = 0; r < 9; r++) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch);
+    lo[r] = p[0];
+    mid[r] = p[1];
+    hi[r] = p[2];
+  }
+  int px[9][9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(mid[r], lo[r], sh);  // patch columns 0..3
+    const uint32_t a1 = __builtin_amdgcn_alignbyte(hi[r], mid[r], sh);  // 4..7
+    const uint32_t a2 = __builtin_amdgcn_alignbyte(0u, hi[r], sh);      // 8
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      px[r][c] = (int)((a0 >> (8 * c)) & 255u);
+      px[r][4 + c] = (int)((a1 >> (8 * c)) & 255u);
+    }
+    px[r][8] = (int)(a2 & 255u);
+  }
+  int a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int i = 1; i <= 7; i++) {
+#pragma unroll
+    for (int j = 1; j <= 7; j++) {
+      const int Ix = (px[i][j + 1] - px[i][j - 1]) * 2 + (px[i - 1][j + 1] - px[i - 1][j - 1]) +
+                     (px[i + 1][j + 1] - px[i + 1][j - 1]);
+      const int Iy = (px[i + 1][j] - px[i - 1][j]) * 2 + (px[i + 1][j - 1] - px[i - 1][j - 1]) +
+                     (px[i + 1][j + 1] - px[i - 1][j + 1]);
       a += Ix * Ix;
       b += Iy * Iy;
       c += Ix * Iy;
@@ -648,13 +671,26 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
     if (area < 100000) break;
     ++nbig;
   }
+  // ... and a "tiny" class (single-wave workgroups: a barrier is one s_barrier of one wave, a dozen workgroups
+  // share a CU) for the many small top levels, where the selection is pure latency
+  int ntiny0 = nbig;
+  while (ntiny0 < g.nlevels) {
+    const VsfLevel& L = h_levels[ntiny0];
+    const long area = (long)(L.x_hi - L.x_lo) * (L.y_hi - L.y_lo);
+    if (area < 20000) break;
+    ++ntiny0;
+  }
   if (nbig > 0) {
     a.level0 = 0;
     hipLaunchKernelGGL((orb_select_kernel<1024, 15360, 1024, 256>), dim3(nbig, im.n), dim3(1024), 0, s, a);
   }
-  if (nbig < g.nlevels) {
+  if (ntiny0 > nbig) {
     a.level0 = nbig;
-    hipLaunchKernelGGL((orb_select_kernel<256, 3072, 1024, 256>), dim3(g.nlevels - nbig, im.n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<256, 3072, 1024, 256>), dim3(ntiny0 - nbig, im.n), dim3(256), 0, s, a);
+  }
+  if (ntiny0 < g.nlevels) {
+    a.level0 = ntiny0;
+    hipLaunchKernelGGL((orb_select_kernel<64, 1536, 512, 64>), dim3(g.nlevels - ntiny0, im.n), dim3(64), 0, s, a);
   }
 }
 
