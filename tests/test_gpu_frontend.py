@@ -80,6 +80,46 @@ def test_frontend_matches_reference_model(oracle):
     assert [(a, b) for a, b, _ in of] == [(0, 1), (1, 2), (2, 3)]
     for _, _, tq in of:
         np.testing.assert_allclose(tq, [0.3, 0, 0, 1, 0, 0, 0], atol=1e-6)
+    # ROS-1 wire bytes of the SLAMProblem (row f3): decode them again and compare with the getters
+    import struct
+    wire = fe.serialize_problem()
+    off = 0
+
+    def rd(fmt):
+        nonlocal off
+        v = struct.unpack_from("<" + fmt, wire, off)
+        off += struct.calcsize("<" + fmt)
+        return v
+
+    (n_nodes,) = rd("I")
+    assert n_nodes == len(nodes)
+    for node in nodes:
+        idx, ts = rd("Qd")
+        assert idx == node["node_idx"] and ts == node["timestamp"]
+        loc_q = rd("7d")  # loc xyz, quaternion xyzw
+        np.testing.assert_array_equal(np.float32(loc_q[:3]), node["pose"][:3])
+        np.testing.assert_array_equal(np.float32([loc_q[6], loc_q[3], loc_q[4], loc_q[5]]), node["pose"][3:])
+        (nf,) = rd("I")
+        assert nf == len(node["features"])
+        for f in node["features"]:
+            fid, px, py, pz, x, y, z = rd("Q6d")
+            assert fid == int(f[0]) and pz == 0.0
+            np.testing.assert_array_equal(np.float32([px, py, x, y, z]), f[1:6])
+    (n_vf,) = rd("I")
+    assert n_vf == len(got)
+    for a, b, pairs in got:
+        pa, pb, npairs = rd("QQI")
+        assert (pa, pb, npairs) == (a, b, len(pairs))
+        flat = rd("%dQ" % (2 * npairs))
+        np.testing.assert_array_equal(np.array(flat, np.uint64).reshape(-1, 2), pairs)
+    (n_of,) = rd("I")
+    assert n_of == len(of)
+    for a, b, tq in of:
+        vals = rd("QQ7d")
+        assert vals[:2] == (a, b)
+        np.testing.assert_array_equal(np.float32(vals[2:5]), tq[:3])
+        np.testing.assert_array_equal(np.float32([vals[8], vals[5], vals[6], vals[7]]), tq[3:])
+    assert off == len(wire)
     fe.close()
 
 

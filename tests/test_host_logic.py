@@ -43,6 +43,14 @@ def test_describe_sincos_matches_libm(tmp_path):
     assert "mismatches 0" in out.stdout
 
 
+def test_ros_wire_format_known_answer(tmp_path):
+    """host/slam_to_ros.h against bytes assembled field by field from msg/*.msg."""
+    exe = tmp_path / "test_ros_wire"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "cpp" / "test_ros_wire.cc")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
 def test_library_exports_every_declared_symbol(capi):
     header = (ROOT / "include" / "vsf.h").read_text()
     declared = set(re.findall(r"\b(vsf_[a-z0-9_]+)\s*\(", header))

@@ -38,6 +38,8 @@ def lib() -> C.CDLL:
         L.vsfh_num_odometry_factors.argtypes = [vp]
         L.vsfh_odometry_factor.argtypes = [vp, i32, vp, vp]
         L.vsfh_frame.argtypes = [vp, i32, vp, vp, vp, i32]
+        L.vsfh_serialize_problem.argtypes = [vp, vp, sz]
+        L.vsfh_serialize_problem.restype = sz
         _lib = L
     return _lib
 
@@ -120,6 +122,13 @@ class Frontend:
             lib().vsfh_odometry_factor(self._h, i, _p(ij), _p(tq))
             out.append((int(ij[0]), int(ij[1]), tq))
         return out
+
+    def serialize_problem(self) -> bytes:
+        """ROS-1 wire bytes of vision_slam_frontend/SLAMProblem for everything observed so far (host/slam_to_ros.h)."""
+        n = lib().vsfh_serialize_problem(self._h, None, 0)
+        buf = np.zeros(max(n, 1), np.uint8)
+        lib().vsfh_serialize_problem(self._h, _p(buf), n)
+        return buf[:n].tobytes()
 
     def frame(self, i: int):
         fid = C.c_uint64()

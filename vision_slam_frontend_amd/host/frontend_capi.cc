@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "slam_frontend.h"
+#include "slam_to_ros.h"
 
 using slam::Frontend;
 using slam::FrontendConfig;
@@ -105,6 +106,18 @@ int vsfh_frame(void* f, int i, uint64_t* frame_id, vsf_keypoint* kp, uint8_t* de
   if (m > 0 && desc && fl[i].descriptors_.size() >= (size_t)m * VSF_DESC_BYTES)
     std::memcpy(desc, fl[i].descriptors_.data(), (size_t)m * VSF_DESC_BYTES);
   return n;
+}
+
+
+// ROS-1 wire bytes of the current SLAMProblem (slam_to_ros.h; what the reference writes into its output bag,
+// slam_frontend_main.cc:341-374).  Returns the payload size; copies min(size, cap) bytes.
+size_t vsfh_serialize_problem(void* f, uint8_t* out, size_t cap) {
+  slam_types::SLAMProblem p;
+  static_cast<Frontend*>(f)->GetSLAMProblem(&p);
+  std::vector<uint8_t> bytes;
+  slam_to_ros::SerializeSLAMProblem(p, &bytes);
+  if (out && cap) std::memcpy(out, bytes.data(), bytes.size() < cap ? bytes.size() : cap);
+  return bytes.size();
 }
 
 }  // extern "C"
