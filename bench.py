@@ -99,6 +99,9 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches per step (vsf_set_lanes)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap a step's pyramid with the previous step's latency-bound tail (vsf_set_pipeline): "
+                         "+3.5 %% frames/s, but the per-stage timers then overlap; off for the reported line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
@@ -157,6 +160,7 @@ def main() -> int:
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_lanes(args.lanes)
+    ctx.set_pipeline(args.pipeline)  # (legal here: the synthetic stream is resident in HBM before every call)
     torch.cuda.synchronize()
 
     def step():

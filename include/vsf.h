@@ -102,6 +102,12 @@ vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream);
  * stream, one on an internal stream forked from / joined back into it with events, so the caller still sees ONE
  * stream-ordered operation.  Frames are independent (slam_frontend.cc:411-416), results do not depend on it. */
 vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes);
+/* Cross-call pipelining for streams of batches (off by default).  With it on, the caller promises that the input
+ * images of every *_batch_dev call are COMPLETE in device memory when the call is made (not merely ordered before it
+ * on the stream).  The scale pyramid of a call -- which depends on nothing else -- is then built on internal streams
+ * into the second of two pyramid buffers while the previous call's later stages are still running; all other stages
+ * and all outputs stay ordered on the context's stream as before. */
+vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
 

@@ -32,7 +32,7 @@ def _oracle_frame(oracle, left, right, nf):
     return ka, da, kb, db, oracle.get_matches(da, db)
 
 
-def _run_stereo_batch(capi, frames, nf, lanes=1):
+def _run_stereo_batch(capi, frames, nf, lanes=1, pipeline=False, repeats=1):
     """frames: (B, 2, h, w) uint8 -> per-image keypoints / descriptors and per-frame matches (numpy)."""
     B, _, H, W = frames.shape
     dev = torch.device("cuda", 0)
@@ -45,9 +45,11 @@ def _run_stereo_batch(capi, frames, nf, lanes=1):
         d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()  # torch's fills are done before the context's stream touches the buffers
         ctx.set_lanes(lanes)
+        ctx.set_pipeline(pipeline)
         torch.cuda.synchronize()
-        ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(),
-                             d_m.data_ptr(), d_nm.data_ptr())
+        for _ in range(repeats):
+            ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(),
+                                 d_m.data_ptr(), d_nm.data_ptr())
         assert ctx.sync() == capi.VSF_OK
         kp, desc, counts = d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_counts.cpu().numpy()
         m, nm = d_m.cpu().numpy(), d_nm.cpu().numpy()
@@ -96,6 +98,11 @@ def test_half_batches_equal_full_batch(capi):
     two = _run_stereo_batch(capi, frames, 2000, lanes=2)
     for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), full, two):
         np.testing.assert_array_equal(a, b, err_msg="lanes=2 " + name)
+    # ... and so does cross-call pipelining (vsf_set_pipeline: the next call's pyramid is built in the second pyramid
+    # buffer beside the previous call's tail); three back-to-back calls exercise both buffers and the release events
+    piped = _run_stereo_batch(capi, frames, 2000, pipeline=True, repeats=3)
+    for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), full, piped):
+        np.testing.assert_array_equal(a, b, err_msg="pipeline " + name)
 
 
 def test_config3_1080p_8000kp(capi, oracle):

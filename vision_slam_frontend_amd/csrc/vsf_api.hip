@@ -252,6 +252,16 @@ struct vsf_ctx {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   VsfSideStream side{};  // aux_stream, for the pyramid's second launch chain
+  // Cross-call pipelining (vsf_set_pipeline): the pyramid of call k + 1 is built on side streams, into the other of
+  // two pyramid buffers, while call k's later stages still run.
+  bool pipeline = false;
+  uint8_t* pyr_alt = nullptr;
+  int pyr_flip = 0;
+  hipStream_t pipe_stream = nullptr;
+  VsfSideStream pipe_side{};
+  hipEvent_t ev_pyr_done = nullptr, ev_pyr_free[2] = {nullptr, nullptr}, ev_fast_done = nullptr;
+  bool pyr_free_valid[2] = {false, false}, fast_done_valid = false;
+  const uint8_t* last_pyr = nullptr;
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int last_hip = 0;
   Geometry orb, fast;
@@ -457,21 +467,47 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
 
 // detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.
 void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp,
-                uint8_t* d_desc, int32_t* d_counts) {
+                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete = false) {
   const VsfGeom& g = ctx->orb.g;
-  const VsfDev d = shifted(ctx->dorb.d, g, i0);
+  VsfDev d = shifted(ctx->dorb.d, g, i0);
   VsfImages im = im_all;
   im.base += (size_t)i0 * im.image_stride;
   im.n = n;
   const size_t K = (size_t)ctx->p.max_keypoints;
-  {
+  const bool pipe = ctx->pipeline && inputs_complete && ctx->lanes == 1 && st == ctx->stream && i0 == 0;
+  if (pipe) {
+    // The pyramid depends on the input images only.  The caller promised they are complete (vsf_set_pipeline), so the
+    // chain goes onto the pipe streams WITHOUT being ordered after this stream's earlier work and overlaps the previous
+    // call's later stages; it writes the pyramid buffer the previous call does not use, once the call before that has
+    // released it.
+    const int buf = ctx->pyr_flip;
+    d.pyr = buf ? ctx->pyr_alt : ctx->dorb.d.pyr;
+    // (ROCm multiplexes streams onto a few hardware queues; the context's aux stream is known to run beside the
+    // main one, so the chain goes there, as a single chain)
+    hipStream_t ps = ctx->aux_stream;
+    if (ctx->pyr_free_valid[buf]) (void)hipStreamWaitEvent(ps, ctx->ev_pyr_free[buf], 0);
+    // ... and not before the previous call's FAST kernel has finished: FAST fills every register of the chip, the
+    // stages after it (selection, descriptors, matcher) are latency-bound and leave room for the resize chain
+    if (ctx->fast_done_valid) (void)hipStreamWaitEvent(ps, ctx->ev_fast_done, 0);
+    {
+      StageTimer t(ctx, ps, VSF_STAGE_PYRAMID, g.nlevels - 1);
+      vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ps, nullptr);
+    }
+    (void)hipEventRecord(ctx->ev_pyr_done, ps);
+    (void)hipStreamWaitEvent(st, ctx->ev_pyr_done, 0);
+  } else {
     StageTimer t(ctx, st, VSF_STAGE_PYRAMID, g.nlevels - 1);
     // one lane: the aux stream is idle, the pyramid chain of the second half of the batch runs on it
     vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, ctx->lanes == 1 ? &ctx->side : nullptr);
   }
+  ctx->last_pyr = d.pyr - (size_t)i0 * g.pyr_bytes;
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
     vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st);
+  }
+  if (pipe) {
+    (void)hipEventRecord(ctx->ev_fast_done, st);
+    ctx->fast_done_valid = true;
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_SELECT, 1);
@@ -485,6 +521,12 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);
     vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp + i0 * K, d_desc + i0 * K * VSF_DESC_BYTES, d_counts + i0,
                         st);
+  }
+  if (pipe) {  // every reader of this pyramid buffer is queued: the call after the next may overwrite it
+    const int buf = ctx->pyr_flip;
+    (void)hipEventRecord(ctx->ev_pyr_free[buf], st);
+    ctx->pyr_free_valid[buf] = true;
+    ctx->pyr_flip ^= 1;
   }
 }
 
@@ -548,9 +590,10 @@ vsf_status run_chunked(vsf_ctx* ctx, int units, Body body) {
   return join_lane(ctx);
 }
 
-vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
+vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
+                         bool inputs_complete = false) {
   vsf_status st = run_chunked(ctx, im.n, [&](hipStream_t s, int i0, int n) {
-    extract_on(ctx, s, im, i0, n, d_kp, d_desc, d_counts);
+    extract_on(ctx, s, im, i0, n, d_kp, d_desc, d_counts, inputs_complete);
   });
   if (st != VSF_OK) return st;
   ctx->last_images = im;
@@ -679,6 +722,18 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
   if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
+  if (ctx->pipe_stream) {
+    hipStreamSynchronize(ctx->pipe_stream);
+    hipStreamSynchronize(ctx->pipe_side.stream[0]);
+    hipStreamDestroy(ctx->pipe_stream);
+    hipStreamDestroy(ctx->pipe_side.stream[0]);
+    hipEventDestroy(ctx->pipe_side.fork);
+    hipEventDestroy(ctx->pipe_side.join[0]);
+    hipEventDestroy(ctx->ev_pyr_done);
+    hipEventDestroy(ctx->ev_fast_done);
+    for (hipEvent_t e : ctx->ev_pyr_free) hipEventDestroy(e);
+  }
+  hipFree(ctx->pyr_alt);
   free_devset(&ctx->dorb);
   free_devset(&ctx->dfast);
   hipFree(ctx->d_status);
@@ -737,6 +792,28 @@ vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes) {
   return VSF_OK;
 }
 
+vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->pipe_stream) VSF_HIP(hipStreamSynchronize(ctx->pipe_stream));
+  if (on && !ctx->pyr_alt) {
+    VSF_HIP(hipMalloc((void**)&ctx->pyr_alt, (size_t)ctx->p.max_images * ctx->orb.g.pyr_bytes));
+    VSF_HIP(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
+    VSF_HIP(hipStreamCreateWithFlags(&ctx->pipe_side.stream[0], hipStreamNonBlocking));
+    VSF_HIP(hipEventCreateWithFlags(&ctx->pipe_side.fork, hipEventDisableTiming));
+    VSF_HIP(hipEventCreateWithFlags(&ctx->pipe_side.join[0], hipEventDisableTiming));
+    ctx->pipe_side.n = 1;
+    VSF_HIP(hipEventCreateWithFlags(&ctx->ev_pyr_done, hipEventDisableTiming));
+    VSF_HIP(hipEventCreateWithFlags(&ctx->ev_fast_done, hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->ev_pyr_free) VSF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  ctx->pipeline = on != 0;
+  ctx->pyr_free_valid[0] = ctx->pyr_free_valid[1] = false;
+  ctx->fast_done_valid = false;
+  return VSF_OK;
+}
+
 vsf_status vsf_sync(vsf_ctx* ctx) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   return check_status_word(ctx);
@@ -775,7 +852,7 @@ vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_imag
   if (st != VSF_OK) return st;
   VSF_HIP(hipSetDevice(ctx->device));
   VsfImages im{d_imgs, image_stride, row_stride, n_images};
-  return extract_async(ctx, im, d_kp, d_desc, d_counts);
+  return extract_async(ctx, im, d_kp, d_desc, d_counts, true);
 }
 
 vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
@@ -842,7 +919,7 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
   const VsfImages im{d_imgs, image_stride, row_stride, 2 * n_frames};
   const size_t set_stride = (size_t)ctx->p.max_keypoints * VSF_DESC_BYTES;
   st = run_chunked(ctx, n_frames, [&](hipStream_t s, int fa, int nf) {
-    extract_on(ctx, s, im, 2 * fa, 2 * nf, d_kp, d_desc, d_counts);
+    extract_on(ctx, s, im, 2 * fa, 2 * nf, d_kp, d_desc, d_counts, true);
     match_on(ctx, s, d_desc, d_counts, set_stride, nullptr, nullptr, fa, nf, ctx->m_idx2, ctx->m_dist2, d_matches,
              d_nmatches);
   });
@@ -1100,7 +1177,8 @@ vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred
     src = ctx->last_images.base + (size_t)image * ctx->last_images.image_stride;
     pitch = ctx->last_images.row_stride;
   } else {
-    src = (blurred ? ctx->dorb.d.blur : ctx->dorb.d.pyr) + (size_t)image * ctx->orb.g.pyr_bytes + L.offset;
+    src = (blurred ? ctx->dorb.d.blur : (ctx->last_pyr ? ctx->last_pyr : ctx->dorb.d.pyr)) +
+          (size_t)image * ctx->orb.g.pyr_bytes + L.offset;
     pitch = (size_t)L.pitch;
   }
   VSF_HIP(hipMemcpy2D(out, ostride, src, pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
