@@ -34,7 +34,7 @@ constexpr int SR = VSF_FAST_STRIP_ROWS;
 struct FastArgs {
   const VsfLevel* levels;
   const uint32_t* units;
-  int nunits;
+  int nunits;  // cells (strip x band) per image: stride of the row-start tables
   const uint8_t* img0;
   size_t img0_stride;
   int img0_pitch;
@@ -163,12 +163,18 @@ __device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
   return o;
 }
 
-__global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
+// HALF = false: the wave is one unit (cell) of 240 keypoint columns x 32 rows.
+// HALF = true : the two 32-lane halves of the wave are two cells of the level's LAST, narrow band (<= 112 keypoint
+//               columns = 28 lanes + 2 x 2 halo lanes) in two consecutive strips; each half keeps its own candidate
+//               segment, row-start table and counter, so downstream nothing changes.  (The pyramid's 50 levels leave a
+//               narrow remainder band almost everywhere: 510 -> 446 waves per 640x480 image.)
+template <bool HALF>
+__global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, int nwork) {
   const int lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (unit >= a.nunits) return;  // wave-uniform
-  const uint32_t ud = a.units[unit];
-  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip = (int)(ud & 0xFFFF);
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= nwork) return;  // wave-uniform
+  const uint32_t ud = a.units[work0 + item];
+  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip0 = (int)(ud & 0x7FFF);
   const VsfLevel L = a.levels[level];
   const int image = blockIdx.y;
   const uint8_t* src;
@@ -182,69 +188,82 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
   }
   const int t = a.threshold, nms = a.nms;
   const v2s tt = {(short)t, (short)t};
+  constexpr int HL = HALF ? 32 : 64;                        // lanes per cell
+  const int half = HALF ? (lane >> 5) : 0, hl = lane & (HL - 1);
+  const int strip = strip0 + half;
+  const bool valid = strip < L.nstrips;                     // (the second half of the last odd strip has no cell)
   const int bx0 = L.fast_a0 + VSF_FAST_BAND_COLS * band;
-  const int c0 = bx0 - 8 + 4 * lane;  // first column of this lane's 4 pixels
+  const int c0 = bx0 - 8 + 4 * hl;  // first column of this lane's 4 pixels
   const bool loadable = c0 >= 0 && c0 + 3 < pitch;
-  const int ys = L.y_lo + strip * SR, ye = min(ys + SR, L.y_hi);
+  const int ys = L.y_lo + strip * SR;                       // per lane when HALF
+  const int nrows = valid ? min(SR, L.y_hi - ys) : 0;       // rows of this lane's cell
+  const int nrows0 = min(SR, L.y_hi - (L.y_lo + strip0 * SR));  // rows of the first cell (>= the second's): uniform
   // Pixels that may carry a score: FAST's 3-pixel rim and one column beyond the keypoint rectangle (for the NMS).
   const int sx_lo = max(L.x_lo - 1, 3), sx_hi = min(L.x_hi + 1, L.w - 3);
   uint32_t smask = 0, emask = 0;  // per-pixel byte masks: may be scored / may be emitted
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int x = c0 + j;
-    if (lane >= 1 && lane <= 62 && x >= sx_lo && x < sx_hi) smask |= 0xFFu << (8 * j);
-    if (lane >= 2 && lane <= 61 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS) emask |= 0xFFu << (8 * j);
+    if (hl >= 1 && hl <= HL - 2 && x >= sx_lo && x < sx_hi) smask |= 0xFFu << (8 * j);
+    if (hl >= 2 && hl <= HL - 3 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS) emask |= 0xFFu << (8 * j);
   }
+  if (!valid) smask = emask = 0;
   const v2s em01 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, emask, 0x0C010C00u));
   const v2s em23 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, emask, 0x0C030C02u));
-  const int unit_local = strip * L.nbands + band;
+  const int unit_local = (valid ? strip : strip0) * L.nbands + band;
   uint32_t* seg = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)unit_local * L.seg_cap;
   uint16_t* rs = a.rowstart + ((size_t)image * a.nunits + L.unit0 + unit_local) * VSF_FAST_RS_STRIDE;
   const int seg_cap = L.seg_cap, hrow = L.h;
-  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long hmask = HALF ? (half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull) : ~0ull;
+  const unsigned long long lt = ((1ull << lane) - 1ull) & hmask;  // lanes of my cell before me
 
-  auto load_row = [&](int y) -> Row3 {
+  auto load_row = [&](int q) -> Row3 {  // row ys - 1 + q of this lane's cell
     Row3 r;
-    const int yc = min(max(y, 0), hrow - 1);
+    const int yc = min(max(ys - 1 + q, 0), hrow - 1);
     r.d = loadable ? *reinterpret_cast<const uint32_t*>(src + (size_t)yc * pitch + c0) : 0u;
     r.p = wave_shr1(r.d);
     r.n = wave_shl1(r.d);
     return r;
   };
 
-  ScoreRow S_up = make_score_row(0u), S_mid = S_up;  // score rows sy-2, sy-1
-  int count = 0;   // candidates emitted so far (wave-uniform)
-  int my_rs = 0;   // lane l keeps rowstart[l]
+  ScoreRow S_up = make_score_row(0u), S_mid = S_up;  // score rows q-2, q-1
+  int count_lo = 0, count_hi = 0;  // candidates emitted so far by the cell(s) (wave-uniform)
+  int my_rs = 0;                   // lane hl keeps rowstart[hl] of its cell
 
-  // One step: scores of row sy from the window R0..R6 = rows sy-3..sy+3, then NMS + emission of row sy-1.
-  auto step = [&](int sy, const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3, const Row3& R4,
+  // One step: scores of cell row q - 1 (image row ys - 1 + q) from the window R0..R6 = image rows ys - 4 + q .. ys + 2 + q,
+  // then NMS + emission of cell row q - 2.
+  auto step = [&](int q, const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3, const Row3& R4,
                   const Row3& R5, const Row3& R6) {
     uint32_t S = 0;
-    const bool row_ok = sy >= 3 && sy < hrow - 3;  // wave-uniform
+    const int sy = ys - 1 + q;
+    const bool row_ok = sy >= 3 && sy < hrow - 3;  // (wave-uniform unless HALF)
     // a 9-arc contains circle pixel 0 (row sy+3) or 8 (row sy-3), both in the centre pixel's column
     const uint32_t far = max(__builtin_amdgcn_sad_u8(R0.d, R3.d, 0u), __builtin_amdgcn_sad_u8(R6.d, R3.d, 0u));
-    if (row_ok && __any(smask != 0 && far > (uint32_t)t)) {
+    if (__any(row_ok && smask != 0 && far > (uint32_t)t)) {
       const v2s r01 = score_pair<0>(R0, R1, R2, R3, R4, R5, R6, tt, nms);
       const v2s r23 = score_pair<2>(R0, R1, R2, R3, R4, R5, R6, tt, nms);
       S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r23), __builtin_bit_cast(uint32_t, r01), 0x06040200u);
-      S &= smask;
+      S &= row_ok ? smask : 0u;
     }
     const ScoreRow S_dn = make_score_row(S);
-    const int y = sy - 1;
-    if (y >= ys && y < ye) {
-      if (__any((S_mid.s & emask) != 0)) {
+    const int r = q - 2;  // cell row to emit
+    if (r >= 0 && r < nrows0) {
+      const uint32_t em = r < nrows ? emask : 0u;  // (the second cell may have fewer rows)
+      if (__any((S_mid.s & em) != 0)) {
         // keep iff score > every 8-neighbour (strict); without NMS every marked corner is kept
         const v2s zero = {0, 0};
         const v2s nb01 = nms ? vmax(vmax(S_up.h3a, S_dn.h3a), S_mid.h2a) : zero;
         const v2s nb23 = nms ? vmax(vmax(S_up.h3b, S_dn.h3b), S_mid.h2b) : zero;
-        const uint32_t k01 = __builtin_bit_cast(uint32_t, ((nb01 - S_mid.c01) >> 15) & em01);
-        const uint32_t k23 = __builtin_bit_cast(uint32_t, ((nb23 - S_mid.c23) >> 15) & em23);
+        uint32_t k01 = __builtin_bit_cast(uint32_t, ((nb01 - S_mid.c01) >> 15) & em01);
+        uint32_t k23 = __builtin_bit_cast(uint32_t, ((nb23 - S_mid.c23) >> 15) & em23);
+        if (r >= nrows) k01 = k23 = 0;
         const bool k0 = (k01 & 0xFFFFu) != 0, k1 = (k01 >> 16) != 0, k2 = (k23 & 0xFFFFu) != 0, k3 = (k23 >> 16) != 0;
         const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
         if ((b0 | b1 | b2 | b3) != 0ull) {  // wave-uniform
+          const int count = half ? count_hi : count_lo;
           int pos = count + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
           const uint32_t sc = nms ? S_mid.s : 0u;
-          const uint32_t yx = ((uint32_t)y << 12) | (uint32_t)c0;
+          const uint32_t yx = ((uint32_t)(ys + r) << 12) | (uint32_t)c0;
           if (k0) {
             if (pos < seg_cap) seg[pos] = ((sc & 255u) << 24) | yx;
             ++pos;
@@ -260,52 +279,62 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a) {
           if (k3) {
             if (pos < seg_cap) seg[pos] = (sc & 0xFF000000u) | (yx + 3);
           }
-          count += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+          if (HALF) {
+            count_lo += __popcll(b0 & 0xFFFFFFFFull) + __popcll(b1 & 0xFFFFFFFFull) + __popcll(b2 & 0xFFFFFFFFull) +
+                        __popcll(b3 & 0xFFFFFFFFull);
+            count_hi += __popcll(b0 >> 32) + __popcll(b1 >> 32) + __popcll(b2 >> 32) + __popcll(b3 >> 32);
+          } else {
+            count_lo += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+          }
         }
       }
-      if (lane > y - ys) my_rs = min(count, seg_cap);
+      if (hl > r) my_rs = min(half ? count_hi : count_lo, seg_cap);
     }
     S_up = S_mid;
     S_mid = S_dn;
   };
 
-  // Seven rotating register sets hold rows sy-3 .. sy+3; each step refills the oldest one two rows ahead.
-  const int sy0 = ys - 1;
-  Row3 W0 = load_row(sy0 - 3), W1 = load_row(sy0 - 2), W2 = load_row(sy0 - 1), W3 = load_row(sy0),
-       W4 = load_row(sy0 + 1), W5 = load_row(sy0 + 2), W6 = load_row(sy0 + 3);
-  Row3 nx = load_row(sy0 + 4);
-  for (int sy = sy0; sy <= ye; sy += 7) {
+  // Seven rotating register sets hold image rows (ys - 1 + q) - 3 .. + 3; each step refills the oldest one two rows
+  // ahead.  q runs over 0 .. nrows0 + 1 (score rows ys - 1 .. ys + nrows0).
+  Row3 W0 = load_row(-3), W1 = load_row(-2), W2 = load_row(-1), W3 = load_row(0), W4 = load_row(1), W5 = load_row(2),
+       W6 = load_row(3);
+  Row3 nx = load_row(4);
+  const int qe = nrows0 + 1;
+  for (int q = 0; q <= qe; q += 7) {
     Row3 n2;
-    n2 = load_row(sy + 5);
-    step(sy, W0, W1, W2, W3, W4, W5, W6);
-    if (sy + 1 > ye) break;
+    n2 = load_row(q + 5);
+    step(q, W0, W1, W2, W3, W4, W5, W6);
+    if (q + 1 > qe) break;
     W0 = nx;
-    nx = load_row(sy + 6);
-    step(sy + 1, W1, W2, W3, W4, W5, W6, W0);
-    if (sy + 2 > ye) break;
+    nx = load_row(q + 6);
+    step(q + 1, W1, W2, W3, W4, W5, W6, W0);
+    if (q + 2 > qe) break;
     W1 = n2;
-    n2 = load_row(sy + 7);
-    step(sy + 2, W2, W3, W4, W5, W6, W0, W1);
-    if (sy + 3 > ye) break;
+    n2 = load_row(q + 7);
+    step(q + 2, W2, W3, W4, W5, W6, W0, W1);
+    if (q + 3 > qe) break;
     W2 = nx;
-    nx = load_row(sy + 8);
-    step(sy + 3, W3, W4, W5, W6, W0, W1, W2);
-    if (sy + 4 > ye) break;
+    nx = load_row(q + 8);
+    step(q + 3, W3, W4, W5, W6, W0, W1, W2);
+    if (q + 4 > qe) break;
     W3 = n2;
-    n2 = load_row(sy + 9);
-    step(sy + 4, W4, W5, W6, W0, W1, W2, W3);
-    if (sy + 5 > ye) break;
+    n2 = load_row(q + 9);
+    step(q + 4, W4, W5, W6, W0, W1, W2, W3);
+    if (q + 5 > qe) break;
     W4 = nx;
-    nx = load_row(sy + 10);
-    step(sy + 5, W5, W6, W0, W1, W2, W3, W4);
-    if (sy + 6 > ye) break;
+    nx = load_row(q + 10);
+    step(q + 5, W5, W6, W0, W1, W2, W3, W4);
+    if (q + 6 > qe) break;
     W5 = n2;
-    n2 = load_row(sy + 11);
-    step(sy + 6, W6, W0, W1, W2, W3, W4, W5);
+    n2 = load_row(q + 11);
+    step(q + 6, W6, W0, W1, W2, W3, W4, W5);
     W6 = nx;
     nx = n2;
   }
-  if (lane <= SR) rs[lane] = (uint16_t)my_rs;
+  if (valid) {
+    if (hl < SR) rs[hl] = (uint16_t)my_rs;                                          // rowstart[0 .. SR-1]
+    if (hl == 0) rs[SR] = (uint16_t)min(half ? count_hi : count_lo, seg_cap);       // rowstart[SR] = cell total
+  }
 }
 
 // Standalone FAST detect: unit segments -> contiguous cv::KeyPoint list in raster order.
@@ -358,7 +387,11 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.rowstart = d.rowstart;
   a.threshold = threshold;
   a.nms = nms;
-  hipLaunchKernelGGL(fast_march_kernel, dim3((g.nunits + 3) / 4, im.n), dim3(256), 0, s, a);
+  if (g.nwork_full > 0)
+    hipLaunchKernelGGL(fast_march_kernel<false>, dim3((g.nwork_full + 3) / 4, im.n), dim3(256), 0, s, a, 0, g.nwork_full);
+  if (g.nwork_half > 0)
+    hipLaunchKernelGGL(fast_march_kernel<true>, dim3((g.nwork_half + 3) / 4, im.n), dim3(256), 0, s, a, g.nwork_full,
+                       g.nwork_half);
 }
 
 void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int max_keypoints, vsf_keypoint* d_kp,

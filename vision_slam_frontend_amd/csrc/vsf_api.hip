@@ -137,17 +137,29 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
   G.g.pyramid_pixels = pixels;
   // FAST units: (240-column band) x (32-row strip) of the keypoint rectangle, one wave each (k_fast.hip)
   uint32_t cand = 0;
-  int kp_off = 0;
+  int kp_off = 0, ncells = 0;
+  std::vector<uint32_t> half_items;
   for (int l = 0; l < nlevels; l++) {
     VsfLevel& L = G.levels[l];
     const int vw = L.x_hi - L.x_lo, vh = L.y_hi - L.y_lo;
     L.fast_a0 = L.x_lo & ~3;
     L.nbands = vw > 0 ? (L.x_hi - L.fast_a0 + VSF_FAST_BAND_COLS - 1) / VSF_FAST_BAND_COLS : 0;
     L.nstrips = vh > 0 && vw > 0 ? (vh + VSF_FAST_STRIP_ROWS - 1) / VSF_FAST_STRIP_ROWS : 0;
-    if (L.nbands > 255 || L.nstrips > 65535) return false;
-    L.unit0 = (int)G.units.size();
+    if (L.nbands > 255 || L.nstrips > 32767) return false;
+    L.unit0 = ncells;
+    ncells += L.nstrips * L.nbands;
+    // work items: one wave per cell, except that a narrow last band is walked two strips per wave (k_fast.hip)
+    const int last_w = L.nbands > 0 ? L.x_hi - (L.fast_a0 + VSF_FAST_BAND_COLS * (L.nbands - 1)) : 0;
+    const bool half_last = L.nbands > 0 && L.nstrips >= 2 && last_w <= VSF_FAST_HALF_COLS;
     for (int s = 0; s < L.nstrips; s++)
-      for (int b = 0; b < L.nbands; b++) G.units.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)s);
+      for (int b = 0; b < L.nbands; b++) {
+        const uint32_t item = ((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)s;
+        if (half_last && b == L.nbands - 1) {
+          if ((s & 1) == 0) half_items.push_back(item);
+        } else {
+          G.units.push_back(item);
+        }
+      }
     // Strict 8-neighbour NMS leaves at most one keypoint per 2x2 block, so a segment of that size cannot overflow.
     const int bw = std::min(VSF_FAST_BAND_COLS, std::max(vw, 1)), bh = std::min(VSF_FAST_STRIP_ROWS, std::max(vh, 1));
     L.seg_cap = nms ? ((bw + 1) / 2) * ((bh + 1) / 2) : bw * bh;
@@ -159,7 +171,10 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
     kp_off += L.kp_cap;
   }
   G.g.cand_entries = std::max(cand, 1u);
-  G.g.nunits = (int)G.units.size();
+  G.g.nunits = ncells;
+  G.g.nwork_full = (int)G.units.size();
+  G.g.nwork_half = (int)half_items.size();
+  G.units.insert(G.units.end(), half_items.begin(), half_items.end());
   if (G.units.empty()) G.units.push_back(0);
   G.g.lvlkp_entries = std::max(kp_off, 1);
   // resize coefficient tables (host only: the kernel evaluates the same arithmetic in place; built here to check

@@ -10,6 +10,7 @@
 // FAST march kernel: a wave owns a band of 240 keypoint columns (lanes 2..61 x 4 px; lanes 1 and 62 add one
 // scored column block each side for the NMS, lanes 0 and 63 carry raw halo pixels) x a strip of 32 rows.
 #define VSF_FAST_BAND_COLS 240
+#define VSF_FAST_HALF_COLS 112   // a last band of at most this many columns is walked two strips per wave
 #define VSF_FAST_STRIP_ROWS 32
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
@@ -64,7 +65,8 @@ struct VsfGeom {
   int width, height;
   uint32_t pyr_bytes;       // one image's pyramid block
   uint32_t cand_entries;    // one image's candidate buffer (u32 entries)
-  int nunits;               // FAST units per image
+  int nunits;               // FAST cells (32-row strip x 240-column band) per image
+  int nwork_full, nwork_half;  // FAST work items: waves covering one cell / two cells of a narrow last band
   int lvlkp_entries;        // one image's level-keypoint buffer (VsfLevelKp entries)
   uint64_t pyramid_pixels;
 };
@@ -72,7 +74,7 @@ struct VsfGeom {
 // Kernel launchers (implemented in the k_*.hip files). All asynchronous on `s`.
 struct VsfDev {
   const VsfLevel* levels;   // [nlevels]
-  const uint32_t* units;    // [nunits]: level << 24 | band << 16 | strip
+  const uint32_t* units;    // [nwork_full + nwork_half]: level << 24 | band << 16 | (first) strip
   uint8_t* pyr;             // [max_images][pyr_bytes]   unblurred levels 1..L-1 (level 0 is the input)
   uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
   uint32_t* cand;           // [max_images][cand_entries]  per-unit candidate segments (unit-local raster order)
