@@ -1,7 +1,7 @@
-// k_select.hip -- K3 + K4 + K5 + K6 of ORB's computeKeyPoints (features2d/orb.cpp, reached from
+// k_select.hip -- K3 + K4 + K5 of ORB's computeKeyPoints (features2d/orb.cpp, reached from
 // slam_frontend.cc:274), one workgroup per (image, level):
 //
-//   gather   the level's FAST candidates (raster order) from the strip segments
+//   gather   the level's FAST candidates (raster order) from the FAST cells' segments (vsf_gather.h)
 //   K3       KeyPointsFilter::retainBest(2 * n_l) on the FAST score           (order-exact)
 //   K4       HarrisResponses(blockSize 7, k 0.04f) for the survivors           (int32 sums, 6 float ops, no FMA)
 //   K5       KeyPointsFilter::retainBest(n_l) on the Harris response          (order-exact)
@@ -13,9 +13,9 @@
 // until they cross"), and such a pass IS data-parallel:
 //   * flag every element as left-stopper / right-stopper against the pivot with wave ballots (bit masks),
 //   * prefix-popcount the masks (one block scan),
-//   * element i, the k-th left-stopper, takes part iff at least k right-stoppers lie to its right; it finds its
-//     partner (k-th right-stopper from the right) by rank -> position select on the mask and swaps,
-//   * the split point follows from the first non-participating stoppers.
+//   * every stopper writes its position at its rank (rank -> position tables), and thread k swaps the k-th
+//     left-stopper with the k-th right-stopper from the right while they have not crossed (no searching),
+//   * the split point follows from the table entries next to the last swap.
 // Pivot choice (median of first+1 / mid / last-1), the depth limit, the heap-select fallback and the final
 // insertion sort are the sequential restatement of vsf_select.h; ranges <= 256 elements are finished by a single
 // wave (ballot masks in SGPRs, no workgroup barriers), the rare depth-limit / heap-select case by one lane.
@@ -121,19 +121,6 @@ __device__ __forceinline__ int select64(unsigned long long x, int r) {
   }
   if (r >= (int)(v & 1u)) pos += 1;
   return pos;
-}
-
-// index (0-based, relative to the pass range) of the t-th (0-based) set bit over the whole mask array
-__device__ __forceinline__ int select_rank(const unsigned long long* mask, const int* pre, int nw, int t) {
-  int lo = 0, hi = nw - 1;  // largest w with pre[w] <= t
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (pre[mid] <= t)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  return lo * 64 + select64(mask[lo], t - pre[lo]);
 }
 
 // One Hoare pass over A[lo, hi): left-stoppers are elements with FL(x), right-stoppers those with FR(x).
