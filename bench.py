@@ -101,7 +101,7 @@ def main() -> int:
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches per step (vsf_set_lanes)")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap a step's pyramid with the previous step's latency-bound tail (vsf_set_pipeline): "
-                         "+3.5 %% frames/s, but the per-stage timers then overlap; off for the reported line")
+                         "+4.7 %% frames/s, but the per-stage timers then overlap; off for the reported line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
