@@ -120,6 +120,11 @@ vsf_status vsf_level_info(const vsf_ctx* ctx, int level, int* w, int* h, float* 
  * records; *n_out = number of keypoints found (<= cap written). */
 vsf_status vsf_extract(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, vsf_keypoint* kp_out,
                        uint8_t* desc_out, int cap, int* n_out);
+/* The two detectAndCompute calls of one stereo frame (slam_frontend.cc:411-412) as ONE batch of two images: one
+ * upload, one set of launches, one download.  Same results as two vsf_extract calls; needs max_images >= 2. */
+vsf_status vsf_extract_pair(vsf_ctx* ctx, const uint8_t* img0, const uint8_t* img1, int w, int h, size_t stride,
+                            vsf_keypoint* kp0, uint8_t* desc0, int* n0, vsf_keypoint* kp1, uint8_t* desc1, int* n1,
+                            int cap);
 /* fast_feature_detector_->detect(image, kps)  (slam_frontend.cc:271): FAST-9/16 + NMS on the full-resolution
  * image, raster order.  threshold < 0 uses params.fast_detector_threshold. */
 vsf_status vsf_fast_detect(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int threshold, int nms,
@@ -132,6 +137,12 @@ vsf_status vsf_knn2_hamming(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_
  * queryIdx.  nt < 2 yields no matches (the reference reads out of bounds there). */
 vsf_status vsf_get_matches(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, vsf_dmatch* out,
                            int cap, int* n_out);
+
+/* GetMatches of n_sets query sets against ONE train set -- the temporal loop of slam_frontend.cc:424-434, every past
+ * frame against the new one -- in one upload / launch / download.  q[s] points at nq[s] rows; the matches of set s
+ * are written at out + s * cap_per_set, their number to n_out[s].  Same results as n_sets vsf_get_matches calls. */
+vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const int* nq, int n_sets, const uint8_t* t,
+                                 int nt, vsf_dmatch* out, int cap_per_set, int* n_out);
 
 /* ---------------- device-pointer, asynchronous, batched ---------------- */
 

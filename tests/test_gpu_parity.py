@@ -99,6 +99,24 @@ def test_knn2_and_matches(ctx640, oracle, stereo640, run640):
     assert gm.tobytes() == rm.tobytes()
 
 
+def test_extract_pair_and_matches_multi_equal_single_calls(ctx640, oracle, stereo640, run640):
+    """The batched host-pointer entry points (one stereo frame's two extractions; one train set against many query
+    sets) return exactly what the one-at-a-time calls return."""
+    from vision_slam_frontend_amd import synth
+    _, kp_l, desc_l = run640
+    kp_r, desc_r = ctx640.extract(stereo640[1])
+    (pk_l, pd_l), (pk_r, pd_r) = ctx640.extract_pair(stereo640[0], stereo640[1])
+    assert pk_l.tobytes() == kp_l.tobytes() and pk_r.tobytes() == kp_r.tobytes()
+    np.testing.assert_array_equal(pd_l, desc_l)
+    np.testing.assert_array_equal(pd_r, desc_r)
+    q_sets = [desc_l, synth.random_descriptors(700, seed=3), desc_r[:5], desc_r[:0], synth.adversarial_descriptors(900, seed=4)]
+    got = ctx640.get_matches_multi(q_sets, desc_r)
+    assert len(got) == len(q_sets)
+    for q, g in zip(q_sets, got):
+        assert g.tobytes() == oracle.get_matches(q, desc_r).tobytes()
+    assert len(got[0]) > 50 and len(got[3]) == 0
+
+
 def test_knn2_tie_rule_adversarial(ctx640, oracle):
     from vision_slam_frontend_amd import synth
     q = synth.adversarial_descriptors(700, seed=1)

@@ -25,7 +25,7 @@ VSF_OK, VSF_ERR_INVALID_ARG, VSF_ERR_CAPACITY, VSF_ERR_HIP, VSF_ERR_UNSUPPORTED,
 EXPORTS = [
     "vsf_params_default", "vsf_params_set_ratio", "vsf_create", "vsf_destroy", "vsf_status_string",
     "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
-    "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_batch_dev", "vsf_match_batch_dev",
+    "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_pair", "vsf_get_matches_multi", "vsf_extract_batch_dev", "vsf_match_batch_dev",
     "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best",
@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.vsf_level_info.argtypes = [vp, i32, ip, ip, C.POINTER(C.c_float), ip]
         L.vsf_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, ip]
         L.vsf_fast_detect.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, i32, ip]
+        L.vsf_extract_pair.argtypes = [vp, vp, vp, i32, i32, sz, vp, vp, ip, vp, vp, ip, i32]
+        L.vsf_get_matches_multi.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, vp]
         L.vsf_knn2_hamming.argtypes = [vp, vp, i32, vp, i32, vp, vp]
         L.vsf_get_matches.argtypes = [vp, vp, i32, vp, i32, vp, i32, ip]
         L.vsf_extract_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp]
@@ -197,6 +199,33 @@ class Context:
         self._check(lib().vsf_extract(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kp), _p(desc),
                                       cap, C.byref(n)), "vsf_extract")
         return kp[:n.value], desc[:n.value]
+
+    def extract_pair(self, img0: np.ndarray, img1: np.ndarray, cap: int | None = None):
+        """Both detectAndCompute calls of a stereo frame in one batch: ((kp0, desc0), (kp1, desc1))."""
+        img0, img1 = _u8(img0), _u8(img1)
+        assert img0.shape == img1.shape and img0.strides == img1.strides
+        cap = self.params.max_keypoints if cap is None else cap
+        kp = [np.zeros(max(cap, 1), KEYPOINT_DTYPE) for _ in range(2)]
+        desc = [np.zeros((max(cap, 1), DESC_BYTES), np.uint8) for _ in range(2)]
+        n0, n1 = C.c_int(), C.c_int()
+        self._check(lib().vsf_extract_pair(self._h, _p(img0), _p(img1), img0.shape[1], img0.shape[0], img0.strides[0],
+                                           _p(kp[0]), _p(desc[0]), C.byref(n0), _p(kp[1]), _p(desc[1]), C.byref(n1), cap),
+                    "vsf_extract_pair")
+        return (kp[0][:n0.value], desc[0][:n0.value]), (kp[1][:n1.value], desc[1][:n1.value])
+
+    def get_matches_multi(self, q_sets, t: np.ndarray):
+        """GetMatches of every query set against one train set in one call: list of DMATCH arrays."""
+        q_sets = [_desc(q) for q in q_sets]
+        t = _desc(t)
+        S = len(q_sets)
+        cap = max(max((len(q) for q in q_sets), default=0), 1)
+        ptrs = (C.c_void_p * S)(*[q.ctypes.data if len(q) else None for q in q_sets])
+        nq = np.array([len(q) for q in q_sets], np.int32)
+        out = np.zeros((S, cap), DMATCH_DTYPE)
+        n_out = np.zeros(S, np.int32)
+        self._check(lib().vsf_get_matches_multi(self._h, C.cast(ptrs, C.c_void_p), _p(nq), S, _p(t), len(t), _p(out), cap,
+                                                _p(n_out)), "vsf_get_matches_multi")
+        return [out[s, :n_out[s]].copy() for s in range(S)]
 
     def fast_detect(self, img: np.ndarray, threshold: int = -1, nms: bool = True, cap: int = 1 << 16):
         img = _u8(img)

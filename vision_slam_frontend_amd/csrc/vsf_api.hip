@@ -307,6 +307,12 @@ struct vsf_ctx {
   vsf_dmatch* mh_matches = nullptr;
   int32_t* mh_nmatches = nullptr;
   int mh_rows = 0;
+  // vsf_get_matches_multi staging: sets x rows descriptors, per-set counts / set indices / matches
+  uint8_t* mm_desc = nullptr;
+  int32_t* mm_counts = nullptr;  // [sets + 1] counts, then [sets] q_set, [sets] t_set
+  vsf_dmatch* mm_matches = nullptr;
+  int32_t* mm_nmatches = nullptr;
+  int mm_sets = 0, mm_rows = 0;
   VsfImages last_images{};
   bool last_valid = false;
   bool fast_nms = true;  // NMS mode the standalone-FAST geometry was built for
@@ -764,6 +770,10 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_matches);
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
+  hipFree(ctx->mm_desc);
+  hipFree(ctx->mm_counts);
+  hipFree(ctx->mm_matches);
+  hipFree(ctx->mm_nmatches);
   hipFree(ctx->mh_desc);
   hipFree(ctx->mh_counts);
   hipFree(ctx->mh_matches);
@@ -1033,6 +1043,39 @@ vsf_status vsf_extract(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t st
   return st;
 }
 
+vsf_status vsf_extract_pair(vsf_ctx* ctx, const uint8_t* img0, const uint8_t* img1, int w, int h, size_t stride,
+                            vsf_keypoint* kp0, uint8_t* desc0, int* n0, vsf_keypoint* kp1, uint8_t* desc1, int* n1,
+                            int cap) {
+  if (!ctx || !n0 || !n1 || cap < 0 || (cap > 0 && (!kp0 || !desc0 || !kp1 || !desc1))) return VSF_ERR_INVALID_ARG;
+  *n0 = *n1 = 0;
+  if (ctx->p.max_images < 2) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  vsf_status st = upload_image(ctx, img0, w, h, stride, 0);
+  if (st == VSF_OK) st = upload_image(ctx, img1, w, h, stride, 1);
+  if (st != VSF_OK) return st;
+  VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
+  st = extract_async(ctx, im, ctx->st_kp, ctx->st_desc, ctx->st_counts);
+  if (st != VSF_OK) return st;
+  int32_t n[2] = {0, 0};
+  VSF_HIP(hipMemcpyAsync(n, ctx->st_counts, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  st = check_status_word(ctx);  // synchronises
+  *n0 = n[0];
+  *n1 = n[1];
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  vsf_keypoint* kps[2] = {kp0, kp1};
+  uint8_t* descs[2] = {desc0, desc1};
+  for (int i = 0; i < 2; i++) {
+    const int m = std::min(std::min((int)n[i], cap), ctx->p.max_keypoints);
+    if (m > 0) {
+      VSF_HIP(hipMemcpy(kps[i], ctx->st_kp + i * K, (size_t)m * sizeof(vsf_keypoint), hipMemcpyDeviceToHost));
+      VSF_HIP(hipMemcpy(descs[i], ctx->st_desc + i * K * VSF_DESC_BYTES, (size_t)m * VSF_DESC_BYTES,
+                        hipMemcpyDeviceToHost));
+    }
+    if (st == VSF_OK && n[i] > m) st = VSF_ERR_CAPACITY;
+  }
+  return st;
+}
+
 vsf_status vsf_fast_detect(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int threshold, int nms,
                            vsf_keypoint* kp_out, int cap, int* n_out) {
   if (!ctx || !n_out || cap < 0 || (cap > 0 && !kp_out)) return VSF_ERR_INVALID_ARG;
@@ -1130,6 +1173,80 @@ static vsf_status match_host(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8
     if (nm > cap) return VSF_ERR_CAPACITY;
   }
   return VSF_OK;
+}
+
+vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const int* nq, int n_sets, const uint8_t* t,
+                                 int nt, vsf_dmatch* out, int cap_per_set, int* n_out) {
+  if (!ctx || n_sets < 1 || !q || !nq || !n_out || cap_per_set < 0 || (cap_per_set > 0 && !out) || nt < 0 ||
+      (nt > 0 && !t) || nt >= (1 << 20))
+    return VSF_ERR_INVALID_ARG;
+  int rows = std::max(nt, 1);
+  for (int s = 0; s < n_sets; s++) {
+    if (nq[s] < 0 || (nq[s] > 0 && !q[s])) return VSF_ERR_INVALID_ARG;
+    rows = std::max(rows, nq[s]);
+    n_out[s] = 0;
+  }
+  VSF_HIP(hipSetDevice(ctx->device));
+  if (n_sets > ctx->mm_sets || rows > ctx->mm_rows) {
+    const int S = std::max(n_sets, ctx->mm_sets), R = std::max(rows, ctx->mm_rows);
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->mm_desc);
+    hipFree(ctx->mm_counts);
+    hipFree(ctx->mm_matches);
+    hipFree(ctx->mm_nmatches);
+    ctx->mm_desc = nullptr;
+    ctx->mm_counts = nullptr;
+    ctx->mm_matches = nullptr;
+    ctx->mm_nmatches = nullptr;
+    ctx->mm_sets = ctx->mm_rows = 0;
+    VSF_HIP(hipMalloc((void**)&ctx->mm_desc, (size_t)(S + 1) * R * VSF_DESC_BYTES));
+    VSF_HIP(hipMalloc((void**)&ctx->mm_counts, (size_t)(3 * S + 1) * sizeof(int32_t)));
+    VSF_HIP(hipMalloc((void**)&ctx->mm_matches, (size_t)S * R * sizeof(vsf_dmatch)));
+    VSF_HIP(hipMalloc((void**)&ctx->mm_nmatches, (size_t)S * sizeof(int32_t)));
+    ctx->mm_sets = S;
+    ctx->mm_rows = R;
+  }
+  const int S = n_sets, R = ctx->mm_rows;
+  vsf_status st = ensure_match_buffers(ctx, S, R);
+  if (st != VSF_OK) return st;
+  const size_t set_stride = (size_t)R * VSF_DESC_BYTES;
+  std::vector<int32_t> meta((size_t)3 * S + 1);
+  for (int s = 0; s < S; s++) {
+    meta[s] = nq[s];
+    meta[S + 1 + s] = s;      // q_set
+    meta[2 * S + 1 + s] = S;  // t_set: the one train set
+    if (nq[s] > 0)
+      VSF_HIP(hipMemcpyAsync(ctx->mm_desc + s * set_stride, q[s], (size_t)nq[s] * VSF_DESC_BYTES, hipMemcpyHostToDevice,
+                             ctx->stream));
+  }
+  meta[S] = nt;
+  if (nt > 0)
+    VSF_HIP(hipMemcpyAsync(ctx->mm_desc + S * set_stride, t, (size_t)nt * VSF_DESC_BYTES, hipMemcpyHostToDevice,
+                           ctx->stream));
+  VSF_HIP(hipMemcpyAsync(ctx->mm_counts, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  const int32_t* d_q = ctx->mm_counts + S + 1;
+  const int32_t* d_t = ctx->mm_counts + 2 * S + 1;
+  // every buffer of this call is laid out with row capacity R: m_idx2 / m_dist2 [S][R][2] (they hold at least
+  // m_pairs x m_rows >= S x R entries), mm_matches [S][R]
+  vsf_launch_knn2(ctx->mm_desc, ctx->mm_counts, set_stride, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2,
+                  ctx->stream);
+  vsf_launch_ratio_compact(ctx->mm_counts, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
+                           ctx->p.ratio_shift, ctx->mm_matches, ctx->mm_nmatches, ctx->d_status, ctx->stream);
+  VSF_HIP(hipGetLastError());
+  std::vector<int32_t> nm(S);
+  VSF_HIP(hipMemcpyAsync(nm.data(), ctx->mm_nmatches, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  st = VSF_OK;
+  for (int s = 0; s < S; s++) {
+    n_out[s] = nm[s];
+    const int m = std::min((int)nm[s], cap_per_set);
+    if (m > 0)
+      VSF_HIP(hipMemcpyAsync(out + (size_t)s * cap_per_set, ctx->mm_matches + (size_t)s * R,
+                             (size_t)m * sizeof(vsf_dmatch), hipMemcpyDeviceToHost, ctx->stream));
+    if (nm[s] > cap_per_set) st = VSF_ERR_CAPACITY;
+  }
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  return st;
 }
 
 vsf_status vsf_knn2_hamming(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,

@@ -266,6 +266,33 @@ bool Frontend::ExtractFeatures(const Image& image, Frame* frame) {
   return true;
 }
 
+bool Frontend::ExtractFeaturesPair(const Image& left, const Image& right, Frame* left_frame, Frame* right_frame) {
+  const bool orb = config_.descriptor_extract_type_ != FrontendConfig::DescriptorExtractorType::FREAK;
+  if (!orb || left.empty() || right.empty() || left.cols != right.cols || left.rows != right.rows ||
+      left.step != right.step)
+    return ExtractFeatures(left, left_frame) && ExtractFeatures(right, right_frame);
+  if (!EnsureContext(left.cols, left.rows)) {
+    if (last_status_ == VSF_OK) last_status_ = VSF_ERR_INVALID_ARG;
+    return false;
+  }
+  vsf_params p;
+  vsf_get_params(ctx_, &p);
+  const int cap = p.max_keypoints;
+  std::vector<vsf_keypoint> kl(cap), kr(cap);
+  std::vector<uint8_t> dl((size_t)cap * VSF_DESC_BYTES), dr((size_t)cap * VSF_DESC_BYTES);
+  int nl = 0, nr = 0;
+  last_status_ = vsf_extract_pair(ctx_, left.data, right.data, left.cols, left.rows, left.step, kl.data(), dl.data(), &nl,
+                                  kr.data(), dr.data(), &nr, cap);
+  if (last_status_ != VSF_OK) return false;
+  kl.resize(nl);
+  dl.resize((size_t)nl * VSF_DESC_BYTES);
+  kr.resize(nr);
+  dr.resize((size_t)nr * VSF_DESC_BYTES);
+  *left_frame = Frame(kl, dl, curr_frame_ID_);
+  *right_frame = Frame(kr, dr, curr_frame_ID_);
+  return true;
+}
+
 // cc:521-538
 std::vector<vsf_dmatch> Frontend::GetMatches(const Frame& frame_query, const Frame& frame_train, double nn_match_ratio) {
   std::vector<vsf_dmatch> best_matches;
@@ -306,6 +333,52 @@ VisionFactor Frontend::GetFeatureMatches(Frame* past_frame_ptr, Frame* curr_fram
     }
   }
   return VisionFactor(past_frame.frame_ID_, curr_frame.frame_ID_, pairs);
+}
+
+void Frontend::GetFeatureMatchesAll(std::vector<Frame>* past_frames, Frame* curr_frame_ptr,
+                                    std::vector<VisionFactor>* out) {
+  Frame& curr_frame = *curr_frame_ptr;
+  const int S = (int)past_frames->size();
+  if (S == 0) return;
+  const int nt = (int)curr_frame.keypoints_.size();
+  bool batched = ctx_ != nullptr && curr_frame.descriptors_.size() == (size_t)nt * VSF_DESC_BYTES;
+  std::vector<const uint8_t*> q(S);
+  std::vector<int> nq(S), nm(S, 0);
+  int cap = 1;
+  for (int s = 0; s < S && batched; s++) {
+    const Frame& f = (*past_frames)[s];
+    nq[s] = (int)f.keypoints_.size();
+    if (f.descriptors_.size() != (size_t)nq[s] * VSF_DESC_BYTES) batched = false;
+    q[s] = f.descriptors_.data();
+    cap = std::max(cap, nq[s]);
+  }
+  if (!batched) {  // (FREAK branch: no descriptors) one call per past frame, as the reference
+    for (Frame& past : *past_frames) out->push_back(GetFeatureMatches(&past, &curr_frame));
+    return;
+  }
+  std::vector<vsf_dmatch> all((size_t)S * cap);
+  last_status_ = vsf_get_matches_multi(ctx_, q.data(), nq.data(), S, curr_frame.descriptors_.data(), nt, all.data(), cap,
+                                       nm.data());
+  if (last_status_ != VSF_OK) std::fill(nm.begin(), nm.end(), 0);
+  for (int s = 0; s < S; s++) {  // cc:289-308 for every past frame, in list order
+    Frame& past_frame = (*past_frames)[s];
+    std::vector<vsf_dmatch> matches(all.begin() + (size_t)s * cap, all.begin() + (size_t)s * cap + nm[s]);
+    std::sort(matches.begin(), matches.end(),
+              [](const vsf_dmatch& a, const vsf_dmatch& b) { return a.distance < b.distance; });
+    const int num_good_matches = (int)(matches.size() * config_.best_percent_);
+    matches.erase(matches.begin() + std::min<size_t>(std::max(num_good_matches, 0), matches.size()), matches.end());
+    std::vector<FeatureMatch> pairs;
+    for (const vsf_dmatch& match : matches) {
+      pairs.push_back(FeatureMatch(match.queryIdx, match.trainIdx));
+      if (curr_frame.is_initial_[match.trainIdx]) {
+        curr_frame.is_initial_[match.trainIdx] = false;
+        curr_frame.initial_ids_[match.trainIdx] = past_frame.is_initial_[match.queryIdx]
+                                                      ? (int64_t)past_frame.frame_ID_
+                                                      : past_frame.initial_ids_[match.queryIdx];
+      }
+    }
+    out->push_back(VisionFactor(past_frame.frame_ID_, curr_frame.frame_ID_, pairs));
+  }
 }
 
 // cc:311-321
@@ -408,11 +481,10 @@ void Frontend::UndistortFeaturePoints(std::vector<VisionFeature>* features_ptr) 
 bool Frontend::ObserveImage(const Image& left_image, const Image& right_image, double /*time*/) {
   if (!OdomCheck()) return false;
   Frame curr_frame, right_temp_frame;
-  if (!ExtractFeatures(left_image, &curr_frame)) return false;
-  if (!ExtractFeatures(right_image, &right_temp_frame)) return false;
+  if (!ExtractFeaturesPair(left_image, right_image, &curr_frame, &right_temp_frame)) return false;
   const std::vector<vsf_dmatch> stereo_matches = GetMatches(curr_frame, right_temp_frame, config_.nn_match_ratio_);
   RemoveAmbigStereo(&curr_frame, &right_temp_frame, stereo_matches);
-  for (Frame& past_frame : frame_list_) vision_factors_.push_back(GetFeatureMatches(&past_frame, &curr_frame));
+  GetFeatureMatchesAll(&frame_list_, &curr_frame, &vision_factors_);
   std::vector<Vector3f> points;
   Calculate3DPoints(&curr_frame, &right_temp_frame, &points);
   std::vector<VisionFeature> features;

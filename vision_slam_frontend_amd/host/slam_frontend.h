@@ -111,6 +111,12 @@ class Frontend {
  private:
   bool OdomCheck();
   bool ExtractFeatures(const Image& image, Frame* curr_frame);
+  // The two ExtractFeatures calls of ObserveImage (cc:411-412) as one batch of two images (vsf_extract_pair).
+  bool ExtractFeaturesPair(const Image& left, const Image& right, Frame* left_frame, Frame* right_frame);
+  // The temporal loop of ObserveImage (cc:424-434): GetFeatureMatches of every past frame against the new one, with
+  // the matcher run once for all of them (vsf_get_matches_multi); same factors, same order, same bookkeeping.
+  void GetFeatureMatchesAll(std::vector<Frame>* past_frames, Frame* curr_frame,
+                            std::vector<slam_types::VisionFactor>* out);
   slam_types::VisionFactor GetFeatureMatches(Frame* past_frame_ptr, Frame* curr_frame_ptr);
   std::vector<vsf_dmatch> GetMatches(const Frame& frame_query, const Frame& frame_train, double nn_match_ratio);
   void RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vsf_dmatch>& stereo_matches);
