@@ -11,12 +11,21 @@
 // exact in integers) and compact the survivors in ascending query index.
 #include <limits.h>
 
+#include <algorithm>
+
 #include "vsf_internal.h"
 
 namespace {
 
 constexpr int kTrainTile = 256;
 
+// SPLIT = false: a workgroup walks the whole train set and writes idx2 / dist2.
+// SPLIT = true : gridDim.z workgroups share a query tile, each walks one chunk of the train set and merges its top-2 into
+//                the query's packed 64-bit key pair (best << 32 | second) kept in the dist2 slot, with a CAS loop (the
+//                merge  m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2))  is associative and commutative);
+//                knn2_finalize_kernel then unpacks.  Used when few pairs would leave most of the chip idle (one frame
+//                at a time: 10000 x 10000 rows are 40 query tiles).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ desc,
                                                    const int32_t* __restrict__ counts, size_t set_stride,
                                                    const int32_t* __restrict__ q_set,
@@ -36,8 +45,14 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
     qb = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[1];
   }
   uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
-  for (int t0 = 0; t0 < nt; t0 += kTrainTile) {
-    const int cnt = min(kTrainTile, nt - t0);
+  int t_begin = 0, t_end = nt;
+  if (SPLIT) {
+    const int chunk = ((nt + (int)gridDim.z - 1) / (int)gridDim.z + kTrainTile - 1) / kTrainTile * kTrainTile;
+    t_begin = min((int)blockIdx.z * chunk, nt);
+    t_end = min(t_begin + chunk, nt);
+  }
+  for (int t0 = t_begin; t0 < t_end; t0 += kTrainTile) {
+    const int cnt = min(kTrainTile, t_end - t0);
     __syncthreads();
     if ((int)threadIdx.x < cnt) {
       const uint4* src = reinterpret_cast<const uint4*>(T + (size_t)(t0 + threadIdx.x) * 32);
@@ -60,6 +75,22 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
       b1 = min(b1, key);
     }
   }
+  if (SPLIT) {
+    if (q < nq && t_begin < t_end) {
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(dist2) + (size_t)pair * max_rows + q;
+      unsigned long long seen = *slot;
+      while (true) {
+        const uint32_t a1 = (uint32_t)(seen >> 32), a2 = (uint32_t)seen;
+        const uint32_t m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2));
+        const unsigned long long merged = ((unsigned long long)m1 << 32) | m2;
+        if (merged == seen) break;
+        const unsigned long long prev = atomicCAS(slot, seen, merged);
+        if (prev == seen) break;
+        seen = prev;
+      }
+    }
+    return;
+  }
   if (q < nq) {
     const size_t o = ((size_t)pair * max_rows + q) * 2;
     idx2[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFFu);
@@ -67,6 +98,24 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
     dist2[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 20);
     dist2[o + 1] = b2 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b2 >> 20);
   }
+}
+
+// Unpacks the key pairs of the split path into idx2 / dist2 (in place: a thread reads its slot before writing it).
+__global__ __launch_bounds__(256) void knn2_finalize_kernel(const int32_t* __restrict__ counts,
+                                                            const int32_t* __restrict__ q_set, int max_rows,
+                                                            int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
+  const int pair = blockIdx.y;
+  const int qs = q_set ? q_set[pair] : 2 * pair;
+  const int nq = min(counts[qs], max_rows);
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const unsigned long long key = (reinterpret_cast<const unsigned long long*>(dist2))[(size_t)pair * max_rows + q];
+  const uint32_t b1 = (uint32_t)(key >> 32), b2 = (uint32_t)key;
+  const size_t o = ((size_t)pair * max_rows + q) * 2;
+  idx2[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFFu);
+  idx2[o + 1] = b2 == 0xFFFFFFFFu ? -1 : (int32_t)(b2 & 0xFFFFFu);
+  dist2[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 20);
+  dist2[o + 1] = b2 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b2 >> 20);
 }
 
 __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __restrict__ counts,
@@ -123,9 +172,21 @@ __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __res
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
                      hipStream_t s) {
-  dim3 grid((max_rows + 255) / 256, n_pairs, 1);
-  hipLaunchKernelGGL(knn2_kernel, grid, dim3(256), 0, s, d_desc, d_counts, set_stride, d_q_set, d_t_set, max_rows,
-                     d_idx2, d_dist2);
+  const int qtiles = (max_rows + 255) / 256;
+  // few (query tile, pair) workgroups: split the train sets so that about a thousand workgroups share the work
+  int nsplit = 1;
+  if ((long)qtiles * n_pairs < 256) nsplit = (int)std::min<long>(16, std::max<long>(1, 1024 / ((long)qtiles * n_pairs)));
+  nsplit = std::min(nsplit, std::max(1, max_rows / (2 * kTrainTile)));
+  if (nsplit <= 1) {
+    hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride, d_q_set,
+                       d_t_set, max_rows, d_idx2, d_dist2);
+    return;
+  }
+  (void)hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s);
+  hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
+                     d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+  hipLaunchKernelGGL(knn2_finalize_kernel, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set, max_rows, d_idx2,
+                     d_dist2);
 }
 
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
