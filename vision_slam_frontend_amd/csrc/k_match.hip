@@ -23,8 +23,7 @@ constexpr int kTrainTile = 256;
 // SPLIT = true : gridDim.z workgroups share a query tile, each walks one chunk of the train set and merges its top-2 into
 //                the query's packed 64-bit key pair (best << 32 | second) kept in the dist2 slot, with a CAS loop (the
 //                merge  m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2))  is associative and commutative);
-//                knn2_finalize_kernel then unpacks.  Used when few pairs would leave most of the chip idle (one frame
-//                at a time: 10000 x 10000 rows are 40 query tiles).
+//                knn2_finalize_kernel then unpacks.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ desc,
                                                    const int32_t* __restrict__ counts, size_t set_stride,
@@ -173,9 +172,11 @@ void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
                      hipStream_t s) {
   const int qtiles = (max_rows + 255) / 256;
-  // few (query tile, pair) workgroups: split the train sets so that about a thousand workgroups share the work
+  // Aim at ~8000 workgroups: fewer (a single pair of one frame at a time, but also 128 stereo pairs = 1152 query tiles)
+  // leave SIMDs with one or two waves, too few to hide the LDS latency of the distance loop; the train sets are then
+  // split (at least two tiles per chunk) and merged through the packed key pairs.
   int nsplit = 1;
-  if ((long)qtiles * n_pairs < 256) nsplit = (int)std::min<long>(16, std::max<long>(1, 1024 / ((long)qtiles * n_pairs)));
+  if ((long)qtiles * n_pairs < 8192) nsplit = (int)std::min<long>(16, std::max<long>(1, 8192 / ((long)qtiles * n_pairs)));
   nsplit = std::min(nsplit, std::max(1, max_rows / (2 * kTrainTile)));
   if (nsplit <= 1) {
     hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride, d_q_set,
