@@ -23,7 +23,7 @@ __constant__ int8_t c_pattern31[256 * 4] = {
 #include "orb_pattern31.inc"
 };
 
-constexpr int kSplit = 4;  // workgroups per (image, level)
+constexpr int kSplit = 2;  // workgroups per (image, level)
 
 struct DescribeArgs {
   const VsfLevel* levels;
