@@ -32,15 +32,14 @@ struct ResizeArgs {
   size_t dst_img_stride;
   int dst_pitch, dw, dh;
   double scale_x, scale_y;  // cv::resize: 1. / ((double)dw / sw), 1. / ((double)dh / sh)
-  int nbands, nunits;
+  int nstrips;
 };
 
 template <int kStripRows>
 __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
   const int lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (unit >= a.nunits) return;  // wave-uniform
-  const int band = unit % a.nbands, strip = unit / a.nbands;
+  const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), band = blockIdx.z;
+  if (strip >= a.nstrips) return;  // wave-uniform
   const int x4 = band * 256 + lane * 4;
   const bool active = x4 < a.dw;
   // cv::resize's coefficient tables (xofs / ialpha, yofs / ibeta) evaluated in place with the same double / float
@@ -55,8 +54,8 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
     VsfTap t;
     t.i0 = (uint16_t)sx;
     t.i1 = (uint16_t)min(sx + 1, a.sw - 1);
-    t.c0 = (int16_t)min(max(__float2int_rn((1.f - fx) * 2048), -32768), 32767);
-    t.c1 = (int16_t)min(max(__float2int_rn(fx * 2048), -32768), 32767);
+    t.c0 = (int16_t)__float2int_rn((1.f - fx) * 2048);  // saturate_cast<short>: fx in [0, 1), no clamp can trigger
+    t.c1 = (int16_t)__float2int_rn(fx * 2048);
     return t;
   };
   auto ytap = [&](int dy) -> VsfTap {
@@ -66,22 +65,22 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
     VsfTap t;
     t.i0 = (uint16_t)min(max(sy, 0), a.sh - 1);
     t.i1 = (uint16_t)min(max(sy + 1, 0), a.sh - 1);
-    t.c0 = (int16_t)min(max(__float2int_rn((1.f - fy) * 2048), -32768), 32767);
-    t.c1 = (int16_t)min(max(__float2int_rn(fy * 2048), -32768), 32767);
+    t.c0 = (int16_t)__float2int_rn((1.f - fy) * 2048);
+    t.c1 = (int16_t)__float2int_rn(fy * 2048);
     return t;
   };
   // loop-invariant x taps of this lane's 4 pixels
   const VsfTap t0 = xtap(min(x4 + 0, a.dw - 1)), t1 = xtap(min(x4 + 1, a.dw - 1)), t2 = xtap(min(x4 + 2, a.dw - 1)),
                t3 = xtap(min(x4 + 3, a.dw - 1));
-  const int base = min((int)t0.i0, a.sw - 8);  // 8-byte window [base, base+8) covers all eight taps, inside the row
+  const uint32_t base = (uint32_t)min((int)t0.i0, a.sw - 8);  // 8-byte window [base, base+8) covers all eight taps
   auto selector = [&](const VsfTap& t) -> uint32_t {
-    return (uint32_t)(t.i0 - base) | 0x0C000C00u | ((uint32_t)(t.i1 - base) << 16);
+    return (t.i0 - base) | 0x0C000C00u | ((t.i1 - base) << 16);
   };
   auto weights = [](const VsfTap& t) -> uint32_t { return (uint32_t)(uint16_t)t.c0 | ((uint32_t)(uint16_t)t.c1 << 16); };
   const uint32_t s0 = selector(t0), s1 = selector(t1), s2 = selector(t2), s3 = selector(t3);
   const uint32_t q0 = weights(t0), q1 = weights(t1), q2 = weights(t2), q3 = weights(t3);
-  const uint8_t* S = a.src + (size_t)blockIdx.y * a.src_img_stride + base;
-  uint8_t* D = a.dst + (size_t)blockIdx.y * a.dst_img_stride + x4;
+  const uint8_t* S = a.src + (size_t)blockIdx.y * a.src_img_stride;  // wave-uniform; the lane adds `base`
+  uint8_t* D = a.dst + (size_t)blockIdx.y * a.dst_img_stride;
 
   struct H4 {
     uint32_t a, b, c, d;
@@ -98,27 +97,43 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
                                  __builtin_bit_cast(v2u16, q3), 0u, false);
     return h;
   };
+  // The y taps are wave-uniform: lane r evaluates output row ys + r once, v_readlane hands the result to the scalar
+  // unit, and row addresses / weights live in SGPRs from there on (one tap evaluation per wave instead of one per
+  // row, address arithmetic off the vector ALU).
+  const int ys = strip * kStripRows;
+  const VsfTap tyl = ytap(min(ys + (lane & (kStripRows - 1)), a.dh - 1));
+  const uint32_t ty_rows = (uint32_t)tyl.i0 | ((uint32_t)tyl.i1 << 16);
+  const uint32_t ty_wts = (uint32_t)(uint16_t)tyl.c0 | ((uint32_t)(uint16_t)tyl.c1 << 16);  // both in [0, 2048]
   // Every output row issues its two source-row loads unconditionally (rows shared with the neighbouring output row
   // hit L1): no loop-carried state, so all 2 * kStripRows loads of the strip are in flight together.
-  const int ys = strip * kStripRows;
-  VsfTap ty[kStripRows];
+  uint32_t wts[kStripRows];
   U8B v0[kStripRows], v1[kStripRows];
 #pragma unroll
   for (int r = 0; r < kStripRows; r++) {
-    ty[r] = ytap(min(ys + r, a.dh - 1));  // wave-uniform
-    v0[r] = *reinterpret_cast<const U8B*>(S + (size_t)ty[r].i0 * a.src_pitch);
-    v1[r] = *reinterpret_cast<const U8B*>(S + (size_t)ty[r].i1 * a.src_pitch);
+    const uint32_t rows = __builtin_amdgcn_readlane(ty_rows, r);
+    wts[r] = __builtin_amdgcn_readlane(ty_wts, r);
+    const uint8_t* r0 = S + (size_t)((rows & 0xFFFFu) * (uint32_t)a.src_pitch);  // scalar
+    const uint8_t* r1 = S + (size_t)((rows >> 16) * (uint32_t)a.src_pitch);
+    v0[r] = *reinterpret_cast<const U8B*>(r0 + base);
+    v1[r] = *reinterpret_cast<const U8B*>(r1 + base);
   }
 #pragma unroll
   for (int r = 0; r < kStripRows; r++) {
     const H4 h0 = hpass(v0[r]), h1 = hpass(v1[r]);
-    const int b0 = ty[r].c0, b1 = ty[r].c1;
+    // VResizeLinear:  ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.   b * (S >> 4) >> 16 is the high
+    // word of the 24 x 24-bit product (b << 12) * (S & ~15) (b <= 2^11, S <= 255 * 2048 < 2^19): one full-rate
+    // v_mul_hi_u32_u24 instead of shift + 32-bit multiply + shift.
+    const uint32_t b0 = (wts[r] & 0xFFFFu) << 12, b1 = (wts[r] >> 16) << 12;  // scalar
+    auto mulhi24 = [](uint32_t x, uint32_t y) -> uint32_t {
+      return (uint32_t)(((uint64_t)(x & 0xFFFFFFu) * (uint64_t)(y & 0xFFFFFFu)) >> 32);
+    };
     auto vpass = [&](uint32_t u0, uint32_t u1) -> uint32_t {
-      return (uint32_t)((((b0 * (int)(u0 >> 4)) >> 16) + ((b1 * (int)(u1 >> 4)) >> 16) + 2) >> 2) & 255u;
+      return (mulhi24(b0, u0 & 0xFFFFF0u) + mulhi24(b1, u1 & 0xFFFFF0u) + 2u) >> 2;  // <= 255
     };
     const uint32_t out = vpass(h0.a, h1.a) | (vpass(h0.b, h1.b) << 8) | (vpass(h0.c, h1.c) << 16) |
                          (vpass(h0.d, h1.d) << 24);
-    if (active && ys + r < a.dh) *reinterpret_cast<uint32_t*>(D + (size_t)(ys + r) * a.dst_pitch) = out;
+    uint8_t* drow = D + (size_t)((uint32_t)min(ys + r, a.dh - 1) * (uint32_t)a.dst_pitch);  // scalar; a row past the
+    if (active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)x4) = out;  // last one rewrites the last row's values
   }
 }
 
@@ -155,15 +170,15 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
       a.dh = L.h;
       a.scale_x = 1. / ((double)L.w / P.w);
       a.scale_y = 1. / ((double)L.h / P.h);
-      a.nbands = (L.w + 255) / 256;
+      const int nbands = (L.w + 255) / 256;
       // rows per wave: more bytes in flight per wave on the large levels, more waves on the small ones
       const bool large = (long)L.w * L.h * n >= 4000000;
       const int rows = large ? 8 : 4;
-      a.nunits = a.nbands * ((L.h + rows - 1) / rows);
+      a.nstrips = (L.h + rows - 1) / rows;
       if (large)
-        hipLaunchKernelGGL(resize_march_kernel<8>, dim3((a.nunits + 3) / 4, n), dim3(256), 0, st[c], a);
+        hipLaunchKernelGGL(resize_march_kernel<8>, dim3((a.nstrips + 3) / 4, n, nbands), dim3(256), 0, st[c], a);
       else
-        hipLaunchKernelGGL(resize_march_kernel<4>, dim3((a.nunits + 3) / 4, n), dim3(256), 0, st[c], a);
+        hipLaunchKernelGGL(resize_march_kernel<4>, dim3((a.nstrips + 3) / 4, n, nbands), dim3(256), 0, st[c], a);
     }
   }
   for (int c = 1; c < nchains; c++) {
