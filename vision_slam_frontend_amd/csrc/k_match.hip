@@ -17,85 +17,184 @@
 
 namespace {
 
-constexpr int kTrainTile = 256;
+constexpr int kTile = 32;          // train rows per MFMA tile
+constexpr int kTileStride = 272;   // bytes per expanded train row in LDS (256 + 16: conflict-free ds_read_b128)
+constexpr int kChunkRows = 8192;   // train rows per key range (13-bit relative index inside the accumulator)
+constexpr int kSplitAlign = 256;   // split chunks are multiples of this many train rows
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 16 descriptor bits -> 16 int8 values, `one` for a set bit and `zero` for a clear one (bytes 1 and 0 of `lut`).
+// nibble * 0x204081 puts bit i of the nibble at bit 8 i; v_perm picks lut byte 0 / 1 per output byte.
+__device__ inline v4i expand16(uint32_t bits, uint32_t lut) {
+  v4i r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t nib = (bits >> (4 * k)) & 15u;
+    const uint32_t t = __umul24(nib, 0x204081u) & 0x01010101u;
+    r[k] = (int)__builtin_amdgcn_perm(0u, lut, t);
+  }
+  return r;
+}
+
+// median of three; written as the pattern the backend selects v_med3_u32 for
+__device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return min(max(a, b), max(min(a, b), c)); }
+
+__device__ inline void merge_top2(uint32_t& m1, uint32_t& m2, uint32_t b1, uint32_t b2) {
+  const uint32_t lo = min(m1, b1), hi = max(m1, b1);
+  m2 = min(hi, min(m2, b2));
+  m1 = lo;
+}
+
+// Hamming distances as int8 matrix products on the matrix cores.  With train bits expanded to +64 / -64 and query bits
+// to -64 / +64, a train row and a query column at Hamming distance d multiply to  8192 d - 2^20,  so an accumulator
+// that starts at  2^20 + (train row index inside the chunk)  ends as the packed key  d << 13 | row : the matrix core
+// produces the sort key itself and the vector ALU only keeps the two smallest keys per query (v_min + v_med3 per
+// element).  One v_mfma_i32_32x32x32_i8 covers 32 train rows x 32 queries x 32 bits; a wave owns 64 queries (two
+// column tiles, expanded once into 64 VGPRs) and walks the train set 32 rows at a time; the workgroup's four waves
+// share each expanded train tile through LDS (double buffered, one barrier per tile).
+//   C/D layout (cdna guide): column = lane & 31 (a query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (a train row).
+//   A/B layout: lane (r, h) holds 16 of the 32 k-values of row / column r; which 16 does not matter here as long as
+//   both operands are expanded the same way (they are: expand16 of bits [16 h, 16 h + 16) of dword s for step s).
 // SPLIT = false: a workgroup walks the whole train set and writes idx2 / dist2.
 // SPLIT = true : gridDim.z workgroups share a query tile, each walks one chunk of the train set and merges its top-2 into
 //                the query's packed 64-bit key pair (best << 32 | second) kept in the dist2 slot, with a CAS loop (the
 //                merge  m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2))  is associative and commutative);
 //                knn2_finalize_kernel then unpacks.
+// Keys leave the kernel as  distance << 20 | train index  ("smaller distance first, ties to the lower train index",
+// batchDistance's insertion rule).
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ desc,
                                                    const int32_t* __restrict__ counts, size_t set_stride,
                                                    const int32_t* __restrict__ q_set,
                                                    const int32_t* __restrict__ t_set, int max_rows,
                                                    int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
-  __shared__ uint4 tile[kTrainTile * 2];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[2][kTile * kTileStride];
   const int pair = blockIdx.y;
   const int qs = q_set ? q_set[pair] : 2 * pair, ts = t_set ? t_set[pair] : 2 * pair + 1;
   const int nq = min(counts[qs], max_rows), nt = min(counts[ts], max_rows);
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= nq) return;  // whole block idle (uniform)
+  if ((int)blockIdx.x * 256 >= nq) return;  // whole block idle (uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
   const uint8_t* Q = desc + (size_t)qs * set_stride;
-  const uint8_t* T = desc + (size_t)ts * set_stride;
-  uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-  if (q < nq) {
-    qa = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[0];
-    qb = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[1];
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(desc + (size_t)ts * set_stride);
+  // query operands: column c of the wave's two tiles, bits [16 h, 16 h + 16) of each descriptor dword
+  const int qbase = blockIdx.x * 256 + wave * 64;
+  v4i qf[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int q = min(qbase + 32 * j + c, nq - 1);
+    const uint4 lo = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[0];
+    const uint4 hi = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int s = 0; s < 8; s++) qf[j][s] = expand16(w[s] >> (16 * h), 0x000040C0u);  // set bit -> -64, clear -> +64
   }
-  uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
   int t_begin = 0, t_end = nt;
   if (SPLIT) {
-    const int chunk = ((nt + (int)gridDim.z - 1) / (int)gridDim.z + kTrainTile - 1) / kTrainTile * kTrainTile;
+    const int chunk = ((nt + (int)gridDim.z - 1) / (int)gridDim.z + kSplitAlign - 1) / kSplitAlign * kSplitAlign;
     t_begin = min((int)blockIdx.z * chunk, nt);
     t_end = min(t_begin + chunk, nt);
   }
-  for (int t0 = t_begin; t0 < t_end; t0 += kTrainTile) {
-    const int cnt = min(kTrainTile, t_end - t0);
+  uint32_t g1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, g2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // distance << 20 | train index
+  // staging: thread tid expands dword (tid & 7) of train row (tid >> 3) of the tile: 32 bytes at row * 272 + 32 s
+  const int st_row = tid >> 3, st_s = tid & 7;
+  auto load_bits = [&](int t0) -> uint32_t {
+    return (t0 + st_row < t_end) ? T[(size_t)(t0 + st_row) * 8 + st_s] : 0u;
+  };
+  auto stage = [&](int buf, uint32_t bits) {
+    uint8_t* dst = &tile[buf][st_row * kTileStride + 32 * st_s];
+    *reinterpret_cast<v4i*>(dst) = expand16(bits, 0x0000C040u);             // set bit -> +64, clear -> -64
+    *reinterpret_cast<v4i*>(dst + 16) = expand16(bits >> 16, 0x0000C040u);
+  };
+  for (int c0 = t_begin; c0 < t_end; c0 += kChunkRows) {
+    const int c_end = min(c0 + kChunkRows, t_end);
+    uint32_t m1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, m2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // distance << 13 | row - c0
+    v16i base;  // 2^20 + (train row of accumulator register i) - c0, advanced by 32 per tile
+#pragma unroll
+    for (int i = 0; i < 16; i++) base[i] = (1 << 20) + (i & 3) + 8 * (i >> 2) + 4 * h;
+    __syncthreads();  // the previous chunk's last tile has been read
+    stage(0, load_bits(c0));
     __syncthreads();
-    if ((int)threadIdx.x < cnt) {
-      const uint4* src = reinterpret_cast<const uint4*>(T + (size_t)(t0 + threadIdx.x) * 32);
-      tile[2 * threadIdx.x] = src[0];
-      tile[2 * threadIdx.x + 1] = src[1];
+    int buf = 0;
+    for (int t0 = c0; t0 < c_end; t0 += kTile, buf ^= 1) {
+      const bool more = t0 + kTile < c_end;
+      uint32_t nxt = 0;
+      if (more) nxt = load_bits(t0 + kTile);
+      const uint8_t* rowp = &tile[buf][c * kTileStride + 16 * h];
+      v16i acc0 = base, acc1 = base;
+#pragma unroll
+      for (int s = 0; s < 8; s++) {
+        const v4i tf = *reinterpret_cast<const v4i*>(rowp + 32 * s);
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[1][s], acc1, 0, 0, 0);
+      }
+      if (t0 + kTile <= c_end) {  // full tile (uniform)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const uint32_t k0 = (uint32_t)acc0[i], k1 = (uint32_t)acc1[i];
+          m2[0] = umed3(m1[0], m2[0], k0);
+          m1[0] = min(m1[0], k0);
+          m2[1] = umed3(m1[1], m2[1], k1);
+          m1[1] = min(m1[1], k1);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const bool valid = t0 + (i & 3) + 8 * (i >> 2) + 4 * h < c_end;
+          const uint32_t k0 = valid ? (uint32_t)acc0[i] : 0xFFFFFFFFu, k1 = valid ? (uint32_t)acc1[i] : 0xFFFFFFFFu;
+          m2[0] = umed3(m1[0], m2[0], k0);
+          m1[0] = min(m1[0], k0);
+          m2[1] = umed3(m1[1], m2[1], k1);
+          m1[1] = min(m1[1], k1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) base[i] += kTile;
+      if (more) stage(buf ^ 1, nxt);
+      __syncthreads();
     }
-    __syncthreads();
-    for (int j = 0; j < cnt; j++) {
-      const uint4 ta = tile[2 * j], tb = tile[2 * j + 1];
-      uint32_t d = __popc(qa.x ^ ta.x);
-      d += __popc(qa.y ^ ta.y);
-      d += __popc(qa.z ^ ta.z);
-      d += __popc(qa.w ^ ta.w);
-      d += __popc(qb.x ^ tb.x);
-      d += __popc(qb.y ^ tb.y);
-      d += __popc(qb.z ^ tb.z);
-      d += __popc(qb.w ^ tb.w);
-      const uint32_t key = (d << 20) | (uint32_t)(t0 + j);
-      b2 = min(b2, max(b1, key));
-      b1 = min(b1, key);
+    // chunk keys -> global keys, merged into the running best two
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t a1 = m1[j] == 0xFFFFFFFFu ? m1[j] : ((m1[j] >> 13) << 20) | ((m1[j] & 8191u) + (uint32_t)c0);
+      const uint32_t a2 = m2[j] == 0xFFFFFFFFu ? m2[j] : ((m2[j] >> 13) << 20) | ((m2[j] & 8191u) + (uint32_t)c0);
+      merge_top2(g1[j], g2[j], a1, a2);
     }
   }
-  if (SPLIT) {
-    if (q < nq && t_begin < t_end) {
+  // the two lane halves hold the rows 4 h + ... of every tile: merge them
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const uint32_t o1 = __shfl_xor(g1[j], 32), o2 = __shfl_xor(g2[j], 32);
+    merge_top2(g1[j], g2[j], o1, o2);
+  }
+  if (h != 0) return;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int q = qbase + 32 * j + c;
+    if (q >= nq) continue;
+    const uint32_t b1 = g1[j], b2 = g2[j];
+    if (SPLIT) {
+      if (t_begin >= t_end) continue;
       unsigned long long* slot = reinterpret_cast<unsigned long long*>(dist2) + (size_t)pair * max_rows + q;
       unsigned long long seen = *slot;
       while (true) {
         const uint32_t a1 = (uint32_t)(seen >> 32), a2 = (uint32_t)seen;
-        const uint32_t m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2));
-        const unsigned long long merged = ((unsigned long long)m1 << 32) | m2;
+        const uint32_t n1 = min(a1, b1), n2 = min(max(a1, b1), min(a2, b2));
+        const unsigned long long merged = ((unsigned long long)n1 << 32) | n2;
         if (merged == seen) break;
         const unsigned long long prev = atomicCAS(slot, seen, merged);
         if (prev == seen) break;
         seen = prev;
       }
+    } else {
+      const size_t o = ((size_t)pair * max_rows + q) * 2;
+      idx2[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFFu);
+      idx2[o + 1] = b2 == 0xFFFFFFFFu ? -1 : (int32_t)(b2 & 0xFFFFFu);
+      dist2[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 20);
+      dist2[o + 1] = b2 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b2 >> 20);
     }
-    return;
-  }
-  if (q < nq) {
-    const size_t o = ((size_t)pair * max_rows + q) * 2;
-    idx2[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFFu);
-    idx2[o + 1] = b2 == 0xFFFFFFFFu ? -1 : (int32_t)(b2 & 0xFFFFFu);
-    dist2[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 20);
-    dist2[o + 1] = b2 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b2 >> 20);
   }
 }
 
@@ -177,7 +276,7 @@ void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_
   // split (at least two tiles per chunk) and merged through the packed key pairs.
   int nsplit = 1;
   if ((long)qtiles * n_pairs < 8192) nsplit = (int)std::min<long>(16, std::max<long>(1, 8192 / ((long)qtiles * n_pairs)));
-  nsplit = std::min(nsplit, std::max(1, max_rows / (2 * kTrainTile)));
+  nsplit = std::min(nsplit, std::max(1, max_rows / (2 * kSplitAlign)));
   if (nsplit <= 1) {
     hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride, d_q_set,
                        d_t_set, max_rows, d_idx2, d_dist2);

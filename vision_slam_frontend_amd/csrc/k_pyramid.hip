@@ -137,6 +137,104 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
   }
 }
 
+// Shared-row variant (levels whose y taps advance by 1 or 2 source rows per output row, VsfLevel::resize_rows): the
+// strip's R output rows touch at most R + 2 consecutive source rows, so each source row is loaded and pushed through
+// the horizontal pass ONCE (R + 2 row passes instead of 2 R) and an output row picks its two entries with a
+// wave-uniform branch.  The kernel is VALU-bound (two pyramid chains overlap), so instruction count is time.
+template <int R>
+__global__ __launch_bounds__(256) void resize_strip_kernel(ResizeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), band = blockIdx.z;
+  if (strip >= a.nstrips) return;  // wave-uniform
+  const int x4 = band * 256 + lane * 4;
+  const bool active = x4 < a.dw;
+  auto xtap = [&](int dx) -> VsfTap {
+    float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) fx = 0, sx = 0;
+    if (sx >= a.sw - 1) fx = 0, sx = a.sw - 1;
+    VsfTap t;
+    t.i0 = (uint16_t)sx;
+    t.i1 = (uint16_t)min(sx + 1, a.sw - 1);
+    t.c0 = (int16_t)__float2int_rn((1.f - fx) * 2048);
+    t.c1 = (int16_t)__float2int_rn(fx * 2048);
+    return t;
+  };
+  const VsfTap t0 = xtap(min(x4 + 0, a.dw - 1)), t1 = xtap(min(x4 + 1, a.dw - 1)), t2 = xtap(min(x4 + 2, a.dw - 1)),
+               t3 = xtap(min(x4 + 3, a.dw - 1));
+  const uint32_t base = (uint32_t)min((int)t0.i0, a.sw - 8);
+  auto selector = [&](const VsfTap& t) -> uint32_t {
+    return (t.i0 - base) | 0x0C000C00u | ((t.i1 - base) << 16);
+  };
+  auto weights = [](const VsfTap& t) -> uint32_t { return (uint32_t)(uint16_t)t.c0 | ((uint32_t)(uint16_t)t.c1 << 16); };
+  const uint32_t s0 = selector(t0), s1 = selector(t1), s2 = selector(t2), s3 = selector(t3);
+  const uint32_t q0 = weights(t0), q1 = weights(t1), q2 = weights(t2), q3 = weights(t3);
+  const uint8_t* S = a.src + (size_t)blockIdx.y * a.src_img_stride;
+  uint8_t* D = a.dst + (size_t)blockIdx.y * a.dst_img_stride;
+  // y taps: lane r evaluates output row ys + r (only row index i0 and the two weights are needed)
+  const int ys = strip * R;
+  uint32_t ty_i0, ty_wts;
+  {
+    const int dy = min(ys + (lane & (R - 1)), a.dh - 1);
+    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    ty_i0 = (uint32_t)min(max(sy, 0), a.sh - 1);
+    ty_wts = (uint32_t)__float2int_rn((1.f - fy) * 2048) | ((uint32_t)__float2int_rn(fy * 2048) << 16);
+  }
+  const uint32_t first = __builtin_amdgcn_readlane(ty_i0, 0);
+  struct H4 {
+    uint32_t a, b, c, d;
+  };
+  U8B v[R + 2];
+#pragma unroll
+  for (int k = 0; k < R + 2; k++) {
+    const uint8_t* row = S + (size_t)(min(first + (uint32_t)k, (uint32_t)(a.sh - 1)) * (uint32_t)a.src_pitch);  // scalar
+    v[k] = *reinterpret_cast<const U8B*>(row + base);
+  }
+  H4 H[R + 2];  // horizontal sums with the low 4 bits cleared (VResizeLinear uses S >> 4)
+#pragma unroll
+  for (int k = 0; k < R + 2; k++) {
+    auto hsum = [&](uint32_t sel, uint32_t q) -> uint32_t {
+      return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(v[k].hi, v[k].lo, sel)),
+                                    __builtin_bit_cast(v2u16, q), 0u, false) & 0xFFFFF0u;
+    };
+    H[k].a = hsum(s0, q0);
+    H[k].b = hsum(s1, q1);
+    H[k].c = hsum(s2, q2);
+    H[k].d = hsum(s3, q3);
+  }
+  auto mulhi24 = [](uint32_t x, uint32_t y) -> uint32_t {
+    return (uint32_t)(((uint64_t)(x & 0xFFFFFFu) * (uint64_t)(y & 0xFFFFFFu)) >> 32);
+  };
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (ys + r >= a.dh) break;  // wave-uniform
+    const uint32_t wts = __builtin_amdgcn_readlane(ty_wts, r);
+    const uint32_t b0 = (wts & 0xFFFFu) << 12, b1 = (wts >> 16) << 12;  // scalar, <= 2^23
+    const bool skip = __builtin_amdgcn_readlane(ty_i0, r) != first + (uint32_t)r;  // then it is first + r + 1
+    // ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 per pixel; the four 10-bit sums are shifted as
+    // two packed pairs and their low bytes gathered with one v_perm
+    auto vrow = [&](const H4& h0, const H4& h1) -> uint32_t {
+      const uint32_t ta = mulhi24(b0, h0.a) + mulhi24(b1, h1.a) + 2u, tb = mulhi24(b0, h0.b) + mulhi24(b1, h1.b) + 2u;
+      const uint32_t tc = mulhi24(b0, h0.c) + mulhi24(b1, h1.c) + 2u, td = mulhi24(b0, h0.d) + mulhi24(b1, h1.d) + 2u;
+      const v2u16 lo = __builtin_bit_cast(v2u16, ta | (tb << 16)) >> (v2u16){2, 2};
+      const v2u16 hi = __builtin_bit_cast(v2u16, tc | (td << 16)) >> (v2u16){2, 2};
+      return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+    };
+    uint8_t* drow = D + (size_t)((uint32_t)(ys + r) * (uint32_t)a.dst_pitch);  // scalar
+    if (skip) {
+      const uint32_t out = vrow(H[r + 1], H[r + 2]);
+      if (active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)x4) = out;
+      asm volatile("" ::: "memory");  // keeps the two arms distinct (no select of the eight operands)
+    } else {
+      const uint32_t out = vrow(H[r], H[r + 1]);
+      if (active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)x4) = out;
+    }
+  }
+}
+
 }  // namespace
 
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
@@ -173,6 +271,17 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
       const int nbands = (L.w + 255) / 256;
       // rows per wave: more bytes in flight per wave on the large levels, more waves on the small ones
       const bool large = (long)L.w * L.h * n >= 4000000;
+      const dim3 block(256);
+      if (L.resize_rows >= 8) {
+        const int R = (large && L.resize_rows >= 16) ? 16 : 8;
+        a.nstrips = (L.h + R - 1) / R;
+        const dim3 grid((a.nstrips + 3) / 4, n, nbands);
+        if (R == 16)
+          hipLaunchKernelGGL(resize_strip_kernel<16>, grid, block, 0, st[c], a);
+        else
+          hipLaunchKernelGGL(resize_strip_kernel<8>, grid, block, 0, st[c], a);
+        continue;
+      }
       const int rows = large ? 8 : 4;
       a.nstrips = (L.h + rows - 1) / rows;
       if (large)

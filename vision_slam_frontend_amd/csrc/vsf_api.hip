@@ -195,6 +195,25 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
           if (t.i0 < base || t.i1 - base > 7) return false;
         }
       }
+      // resize_strip_kernel<R> keeps the horizontal sums of R + 2 consecutive source rows (from the first output
+      // row's upper tap on) and takes output row r's taps from entries r + d, r + d + 1 with d in {0, 1}: true when
+      // the scale is below 1 + 1 / (R - 1) (all ORB levels at 1.04 qualify); checked here on the exact tables.
+      L.resize_rows = 0;
+      for (int R : {16, 8, 4}) {
+        bool ok = true;
+        for (int ys = 0; ys < L.h && ok; ys += R) {
+          const int f = G.yt[L.ytab + ys].i0;
+          for (int r = 0; r < R && ys + r < L.h && ok; r++) {
+            const VsfTap& t = G.yt[L.ytab + ys + r];
+            const int dlt = (int)t.i0 - f - r;
+            ok = (dlt == 0 || dlt == 1) && (int)t.i1 == std::min((int)t.i0 + 1, P.h - 1);
+          }
+        }
+        if (ok) {
+          L.resize_rows = R;
+          break;
+        }
+      }
     }
     for (int l = 0; l < nlevels; l++) {
       const VsfLevel& L = G.levels[l];

@@ -36,7 +36,7 @@ struct VsfLevel {
   int32_t kp_cap;          // its capacity
   int32_t blur_vec_end;    // columns [0, blur_vec_end) round half-even (SSE2 path), the rest half-up
   uint32_t xtab, ytab;     // entry offsets of this level's resize tables in the host-side Geometry (level >= 1)
-  int32_t pad0;
+  int32_t resize_rows;     // largest strip height (16, 8, 4) the shared-row resize kernel may use for this level, or 0
 };
 
 // Resize coefficients of one output column / row (cv::resize INTER_LINEAR 8u: xofs/ialpha resp. yofs/ibeta with the
