@@ -20,7 +20,7 @@ namespace {
 constexpr int kTile = 32;          // train rows per MFMA tile
 constexpr int kTileStride = 272;   // bytes per expanded train row in LDS (256 + 16: conflict-free ds_read_b128)
 constexpr int kChunkRows = 8192;   // train rows per key range (13-bit relative index inside the accumulator)
-constexpr int kSplitAlign = 256;   // split chunks are multiples of this many train rows
+constexpr int kSplitAlign = 128;   // split chunks are multiples of this many train rows (four tiles)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -98,11 +98,10 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
     t_end = min(t_begin + chunk, nt);
   }
   uint32_t g1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, g2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // distance << 20 | train index
-  // staging: thread tid expands dword (tid & 7) of train row (tid >> 3) of the tile: 32 bytes at row * 272 + 32 s
+  // staging: thread tid expands dword (tid & 7) of train row (tid >> 3) of the tile: 32 bytes at row * 272 + 32 s.
+  // Rows past the chunk's end are clamped to its last row (never folded: the last tile's fold checks the row index).
   const int st_row = tid >> 3, st_s = tid & 7;
-  auto load_bits = [&](int t0) -> uint32_t {
-    return (t0 + st_row < t_end) ? T[(size_t)(t0 + st_row) * 8 + st_s] : 0u;
-  };
+  auto load_bits = [&](int t0, int c_end) -> uint32_t { return T[(size_t)min(t0 + st_row, c_end - 1) * 8 + st_s]; };
   auto stage = [&](int buf, uint32_t bits) {
     uint8_t* dst = &tile[buf][st_row * kTileStride + 32 * st_s];
     *reinterpret_cast<v4i*>(dst) = expand16(bits, 0x0000C040u);             // set bit -> +64, clear -> -64
@@ -110,50 +109,73 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
   };
   for (int c0 = t_begin; c0 < t_end; c0 += kChunkRows) {
     const int c_end = min(c0 + kChunkRows, t_end);
+    const int ntiles = (c_end - c0 + kTile - 1) / kTile;
     uint32_t m1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, m2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // distance << 13 | row - c0
     v16i base;  // 2^20 + (train row of accumulator register i) - c0, advanced by 32 per tile
 #pragma unroll
     for (int i = 0; i < 16; i++) base[i] = (1 << 20) + (i & 3) + 8 * (i >> 2) + 4 * h;
-    __syncthreads();  // the previous chunk's last tile has been read
-    stage(0, load_bits(c0));
-    __syncthreads();
-    int buf = 0;
-    for (int t0 = c0; t0 < c_end; t0 += kTile, buf ^= 1) {
-      const bool more = t0 + kTile < c_end;
-      uint32_t nxt = 0;
-      if (more) nxt = load_bits(t0 + kTile);
+    auto fold = [&](const v16i& a0, const v16i& a1, int t0, bool check) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const bool valid = !check || t0 + (i & 3) + 8 * (i >> 2) + 4 * h < c_end;
+        const uint32_t k0 = valid ? (uint32_t)a0[i] : 0xFFFFFFFFu, k1 = valid ? (uint32_t)a1[i] : 0xFFFFFFFFu;
+        m2[0] = umed3(m1[0], m2[0], k0);
+        m1[0] = min(m1[0], k0);
+        m2[1] = umed3(m1[1], m2[1], k1);
+        m1[1] = min(m1[1], k1);
+      }
+    };
+    // One pipeline step = tile t: its sixteen MFMAs (into `n0`, `n1`) are issued one at a time with eight vector-ALU
+    // instructions behind each -- the fold of tile t - 1's keys (`p0`, `p1`), the row-index update and the expansion of
+    // tile t + 1 into the other LDS buffer -- so the matrix core and the vector ALU of a SIMD run side by side inside
+    // one wave (waves that alternate whole MFMA and VALU phases fall into step with each other and serialise).
+    constexpr int kAhead = 4;    // descriptor dwords are fetched this many tiles ahead (L2 latency ~ 2 steps)
+    uint32_t bits_next[kAhead];  // tiles t + 1 .. t + kAhead: this thread's descriptor dword of each
+    auto step = [&](int t, const v16i& p0, const v16i& p1, v16i& n0, v16i& n1, bool fold_prev) {
+      const int buf = t & 1;
+      const uint32_t bits_after = load_bits(c0 + (t + 1 + kAhead) * kTile, c_end);
       const uint8_t* rowp = &tile[buf][c * kTileStride + 16 * h];
-      v16i acc0 = base, acc1 = base;
+      v4i tf[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) tf[s] = *reinterpret_cast<const v4i*>(rowp + 32 * s);
+      n0 = base;
+      n1 = base;
 #pragma unroll
       for (int s = 0; s < 8; s++) {
-        const v4i tf = *reinterpret_cast<const v4i*>(rowp + 32 * s);
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[1][s], acc1, 0, 0, 0);
+        n0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf[s], qf[0][s], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf[s], qf[1][s], n1, 0, 0, 0);
       }
-      if (t0 + kTile <= c_end) {  // full tile (uniform)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const uint32_t k0 = (uint32_t)acc0[i], k1 = (uint32_t)acc1[i];
-          m2[0] = umed3(m1[0], m2[0], k0);
-          m1[0] = min(m1[0], k0);
-          m2[1] = umed3(m1[1], m2[1], k1);
-          m1[1] = min(m1[1], k1);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const bool valid = t0 + (i & 3) + 8 * (i >> 2) + 4 * h < c_end;
-          const uint32_t k0 = valid ? (uint32_t)acc0[i] : 0xFFFFFFFFu, k1 = valid ? (uint32_t)acc1[i] : 0xFFFFFFFFu;
-          m2[0] = umed3(m1[0], m2[0], k0);
-          m1[0] = min(m1[0], k0);
-          m2[1] = umed3(m1[1], m2[1], k1);
-          m1[1] = min(m1[1], k1);
-        }
-      }
+      if (fold_prev) fold(p0, p1, 0, false);  // (every tile but a chunk's last is full)
 #pragma unroll
       for (int i = 0; i < 16; i++) base[i] += kTile;
-      if (more) stage(buf ^ 1, nxt);
+      stage(buf ^ 1, bits_next[0]);
+#pragma unroll
+      for (int k = 0; k + 1 < kAhead; k++) bits_next[k] = bits_next[k + 1];
+      bits_next[kAhead - 1] = bits_after;
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // eight VALU
+      }
       __syncthreads();
+    };
+    __syncthreads();  // the previous chunk's last tile has been read
+    stage(0, load_bits(c0, c_end));
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) bits_next[k] = load_bits(c0 + (1 + k) * kTile, c_end);
+    __syncthreads();
+    v16i accA0, accA1, accB0, accB1;
+    step(0, accB0, accB1, accA0, accA1, false);
+    int t = 1;
+    for (; t + 1 < ntiles; t += 2) {
+      step(t, accA0, accA1, accB0, accB1, true);
+      step(t + 1, accB0, accB1, accA0, accA1, true);
+    }
+    if (t < ntiles) {  // uniform
+      step(t, accA0, accA1, accB0, accB1, true);
+      fold(accB0, accB1, c0 + t * kTile, true);
+    } else {
+      fold(accA0, accA1, c0 + (t - 1) * kTile, true);
     }
     // chunk keys -> global keys, merged into the running best two
 #pragma unroll
@@ -271,12 +293,12 @@ void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
                      hipStream_t s) {
   const int qtiles = (max_rows + 255) / 256;
-  // Aim at ~8000 workgroups: fewer (a single pair of one frame at a time, but also 128 stereo pairs = 1152 query tiles)
-  // leave SIMDs with one or two waves, too few to hide the LDS latency of the distance loop; the train sets are then
-  // split (at least two tiles per chunk) and merged through the packed key pairs.
+  // Two workgroups fit a CU (register-limited), 512 run at once.  A batch of 128 stereo pairs brings ~1000 query tiles,
+  // two full rounds, and runs unsplit; with fewer (one pair of one frame at a time) the train sets are split until about
+  // that many workgroups exist (each at least eight 32-row tiles) and merged through the packed key pairs.
   int nsplit = 1;
-  if ((long)qtiles * n_pairs < 8192) nsplit = (int)std::min<long>(16, std::max<long>(1, 8192 / ((long)qtiles * n_pairs)));
-  nsplit = std::min(nsplit, std::max(1, max_rows / (2 * kSplitAlign)));
+  if ((long)qtiles * n_pairs < 768) nsplit = (int)std::min<long>(32, 1024 / ((long)qtiles * n_pairs));
+  nsplit = std::max(1, std::min(nsplit, max_rows / (2 * kSplitAlign)));
   if (nsplit <= 1) {
     hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride, d_q_set,
                        d_t_set, max_rows, d_idx2, d_dist2);
