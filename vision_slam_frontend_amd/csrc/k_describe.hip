@@ -11,8 +11,10 @@
 //       pairs l, l+64, l+128, l+192, so each 64-lane ballot IS eight consecutive descriptor bytes (bit i of byte k
 //       = pair 8k+i, LSB first, exactly OpenCV's packing).  Per sample: x = px*a - py*b, y = px*b + py*a as
 //       separately rounded float ops (no FMA), cvRound (round-half-even), one byte load.
-// A level's keypoints are dealt round-robin to kSplit workgroups x 4 waves; the level's slot in the image's
-// level-major output is the sum of the preceding levels' counts.
+// Both run in one kernel over the image's keypoints in output order (level-major; a level's slot is the sum of the
+// preceding levels' counts), sixteen consecutive keypoints per wave.
+#include <algorithm>
+
 #include "vsf_internal.h"
 
 #pragma clang fp contract(off)
@@ -22,8 +24,6 @@ namespace {
 __constant__ int8_t c_pattern31[256 * 4] = {
 #include "orb_pattern31.inc"
 };
-
-constexpr int kSplit = 2;  // workgroups per (image, level)
 
 struct DescribeArgs {
   const VsfLevel* levels;
@@ -43,6 +43,7 @@ struct DescribeArgs {
   uint8_t* desc_out;
   int32_t* counts;
   int32_t* status;
+  int nblocks, nimages;  // workgroups per image, images
 };
 
 // cv::fastAtan2 (core/mathfuncs.cpp), degrees.
@@ -98,100 +99,132 @@ __device__ __forceinline__ void sincos_2pi(double x, double* s_out, double* c_ou
   *c_out = ((k + 1) & 2) ? -cv : cv;
 }
 
-// K6: one wave per keypoint (rounds of up to 64 keypoints per wave, lane k <-> keypoint k of the round).
-__global__ __launch_bounds__(256) void orb_angle_kernel(DescribeArgs a) {
-  const int level = blockIdx.x / kSplit, part = blockIdx.x - level * kSplit, image = blockIdx.y;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const VsfLevel L = a.levels[level];
-  const int n = a.lvl_count[(size_t)image * a.nlevels + level];
-  const uint8_t* raw;
-  int rpitch;
-  if (level == 0) {
-    raw = a.img0 + (size_t)image * a.img0_stride;
-    rpitch = a.img0_pitch;
-  } else {
-    raw = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
-    rpitch = L.pitch;
-  }
-  VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
-  // this lane's five disc items: row index (0..30 <-> v = -15..15) and dword index (0..8); items >= 279 carry
-  // zero weights and are pointed at row 30 so that they stay inside the image
-  int item_off[5], item_v[5];
-#pragma unroll
-  for (int it = 0; it < 5; it++) {
-    const int item = it * 64 + lane;
-    const int r = min(item / 9, 30), j = item - (item / 9) * 9;
-    item_off[it] = r * rpitch + 4 * j;
-    item_v[it] = r - 15;
-  }
-  const int stride = 4 * kSplit;
-  for (int base = part * 4 + wid; base < n; base += 64 * stride) {
-    const int cnt = min(64, (n - base + stride - 1) / stride);  // keypoints of this round (wave-uniform)
-    uint32_t my_xy = 0;  // lane k holds keypoint k: one load for all records of the round
-    if (lane < cnt) my_xy = kps[base + lane * stride].xy;
-    float my_angle = 0.f;
-    for (int kk = 0; kk < cnt; kk++) {
-      const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)my_xy, kk);
-      const int x0 = (int)(xy & 0xFFFu), y0 = (int)(xy >> 12);
-      const int xs = x0 - 15;
-      const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
-      const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS;
-      int m10 = 0, m01 = 0;
-#pragma unroll
-      for (int it = 0; it < 5; it++) {
-        const uint32_t px = *reinterpret_cast<const uint32_t*>(abase + (uint32_t)item_off[it]);
-        const uint2 t = tab[(uint32_t)(it * 64 + lane)];
-        const int sw = (int)__builtin_amdgcn_udot4(px, t.x, 0u, false);
-        const int sm = (int)__builtin_amdgcn_udot4(px, t.y, 0u, false);
-        m10 += sw - 16 * sm;
-        m01 += item_v[it] * sm;
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off, 64);
-        m01 += __shfl_xor(m01, off, 64);
-      }
-      const float kp_angle = fast_atan2_deg((float)m01, (float)m10);
-      if (lane == kk) my_angle = kp_angle;
-    }
-    // cos / sin, one keypoint per lane (the float nearest to the double-precision value)
-    const float my_rad = my_angle * (float)(3.14159265358979323846 / 180.f);
-    double sd, cd;
-    sincos_2pi((double)my_rad, &sd, &cd);
-    if (lane < cnt) {
-      VsfLevelKp* k = kps + base + lane * stride;
-      k->angle = my_angle;
-      k->ca = (float)cd;
-      k->sb = (float)sd;
-    }
-  }
-}
+constexpr int kKpPerWave = 16;  // consecutive output keypoints per wave
 
-// K8 + output assembly: one wave per keypoint.
-__global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
-  const int level = blockIdx.x / kSplit, part = blockIdx.x - level * kSplit, image = blockIdx.y;
+// K6 + K8 + output assembly.  The image's keypoints are numbered in output order (level-major, retainBest order
+// inside a level); wave w of the image takes numbers [16 w, 16 w + 16), whatever levels they belong to: lane k < 16
+// looks up keypoint k's level (binary search in the wave-scanned level counts), record and level geometry once, and
+// the wave then walks the 16 keypoints with v_readlane broadcasts.  (One workgroup per (level, image) left most waves
+// with two or three keypoints and a prologue longer than their work.)
+__global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a) {
+  constexpr int kWinRows = 39, kWinPitch = 48, kWinBytes = kWinRows * kWinPitch;
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][2][kWinBytes];
+  // Workgroups are dealt to the 8 XCDs round-robin by their linear id; all workgroups of an image are given ids of
+  // one residue class so that an image's pyramid levels are pulled into ONE XCD's L2 (speed only, not correctness).
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int image = xcd + 8 * (seq / a.nblocks), block = seq - (seq / a.nblocks) * a.nblocks;
+  if (image >= a.nimages) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int32_t* lc = a.lvl_count + (size_t)image * a.nlevels;
-  // base = sum of counts of the levels before this one; total = all levels (wave-parallel, nlevels <= 64)
+  // inclusive scan of the level counts over the lanes (nlevels <= 64)
   const int mine = lane < a.nlevels ? lc[lane] : 0;
-  int before = lane < level ? mine : 0, total = mine;
+  int incl = mine;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    before += __shfl_xor(before, o, 64);
-    total += __shfl_xor(total, o, 64);
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  const int total = __shfl(incl, 63, 64);
+  if (block == 0 && threadIdx.x == 0) {
     a.counts[image] = total;
     if (total > a.max_keypoints) atomicOr(a.status, 1);
   }
-  const VsfLevel L = a.levels[level];
-  const int n = lc[level];
-  const uint8_t* img = a.blur + (size_t)image * a.pyr_bytes + L.offset;
-  const int pitch = L.pitch;
-  const VsfLevelKp* kps = a.lvlkp + (size_t)image * a.lvlkp_entries + L.kp_offset;
-  const float lscale = L.scale;
-  const float inv = 1.f / lscale;
-  // this lane's four pattern pairs (loop invariant)
+  const int n_out = min(total, a.max_keypoints);
+  const int o_begin = (block * 4 + wid) * kKpPerWave;
+  if (o_begin >= n_out) return;  // wave-uniform
+  const int cnt = min(kKpPerWave, n_out - o_begin);
+
+  // ---- lane k <-> keypoint o_begin + k: level, record, level geometry ----
+  const int o_k = o_begin + min(lane, cnt - 1);
+  int level_k = 0;  // number of levels that end at or before o_k
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) {
+    const int t = level_k + step;
+    const int v = __shfl(incl, t - 1, 64);  // (lanes >= nlevels hold `total` > o_k)
+    if (v <= o_k) level_k = t;
+  }
+  const int idx_k = o_k - __shfl(incl - mine, level_k, 64);
+  const VsfLevel Lk = a.levels[level_k];
+  const VsfLevelKp* rec_p = a.lvlkp + (size_t)image * a.lvlkp_entries + Lk.kp_offset + idx_k;
+  const uint32_t xy_k = rec_p->xy;
+  const float resp_k = rec_p->response;
+  const float scale_k = Lk.scale, inv_k = 1.f / scale_k;
+  const uint32_t off_k = Lk.offset;
+  const int pitch_k = Lk.pitch;
+
+  // ---- K6: ICAngles on the unblurred level.  The lane's five disc items: row (0..30 <-> v = -15..15) and dword
+  // (0..8); items >= 279 carry zero weights and are pointed at row 30 so that they stay inside the image.
+  int item_r[5], item_j4[5];
+#pragma unroll
+  for (int it = 0; it < 5; it++) {
+    const int item = it * 64 + lane;
+    item_r[it] = min(item / 9, 30);
+    item_j4[it] = 4 * (item - (item / 9) * 9);
+  }
+  float my_angle = 0.f;
+  // The five pixel dwords and table entries of keypoint k + 1 are requested before keypoint k is reduced: the loop
+  // is a chain of memory round trips otherwise (the levels do not fit the caches).
+  uint32_t px[5];
+  uint2 tw[5];
+  auto request = [&](int kk) {
+    const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_k, kk);
+    const int lvl = __builtin_amdgcn_readlane(level_k, kk);
+    const uint8_t* raw;
+    int rpitch;
+    if (lvl == 0) {
+      raw = a.img0 + (size_t)image * a.img0_stride;
+      rpitch = a.img0_pitch;
+    } else {
+      raw = a.pyr + (size_t)image * a.pyr_bytes + (uint32_t)__builtin_amdgcn_readlane((int)off_k, kk);
+      rpitch = __builtin_amdgcn_readlane(pitch_k, kk);
+    }
+    const int xs = (int)(xy & 0xFFFu) - 15, y0 = (int)(xy >> 12);
+    const uint8_t* abase = raw + (size_t)(y0 - 15) * rpitch + (xs & ~3);
+    const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+      px[it] = *reinterpret_cast<const uint32_t*>(abase + (uint32_t)(item_r[it] * rpitch + item_j4[it]));
+      tw[it] = tab[(uint32_t)(it * 64 + lane)];
+    }
+  };
+  // sum over the 64 lanes without LDS: four DPP steps leave every lane of a 16-lane row with the row's sum, the four
+  // row sums meet on the scalar unit
+  auto wave_sum = [](int v) -> int {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+  };
+  request(0);
+  for (int kk = 0; kk < cnt; kk++) {
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+      const int sw = (int)__builtin_amdgcn_udot4(px[it], tw[it].x, 0u, false);
+      const int sm = (int)__builtin_amdgcn_udot4(px[it], tw[it].y, 0u, false);
+      m10 += sw - 16 * sm;
+      m01 += (item_r[it] - 15) * sm;
+    }
+    if (kk + 1 < cnt) request(kk + 1);
+    const float kp_angle = fast_atan2_deg((float)wave_sum(m01), (float)wave_sum(m10));
+    if (lane == kk) my_angle = kp_angle;
+  }
+  // cos / sin, one keypoint per lane (the float nearest to the double-precision value)
+  const float my_rad = my_angle * (float)(3.14159265358979323846 / 180.f);
+  double sd, cd;
+  sincos_2pi((double)my_rad, &sd, &cd);
+  const float ca_k = (float)cd, sb_k = (float)sd;
+  if (lane < cnt) {  // (kept in the level record for vsf_debug_level_keypoints)
+    VsfLevelKp* k = a.lvlkp + (size_t)image * a.lvlkp_entries + Lk.kp_offset + idx_k;
+    k->angle = my_angle;
+    k->ca = ca_k;
+    k->sb = sb_k;
+  }
+
+  // ---- K8: rotated BRIEF on the blurred level ----
+  // this lane's four pattern pairs
   float pat[4][4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -199,49 +232,75 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(DescribeArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; c++) pat[j][c] = (float)c_pattern31[4 * pair + c];
   }
-  const int stride = 4 * kSplit;
-  for (int base = part * 4 + wid; base < n; base += 64 * stride) {
-    const int cnt = min(64, (n - base + stride - 1) / stride);  // keypoints of this round (wave-uniform)
-    const int cnt_out = min(cnt, (a.max_keypoints - (before + base) + stride - 1) / stride);  // that fit the output
-    if (cnt_out <= 0) break;
-    VsfLevelKp mine_kp{0u, 0.f, 0.f, 1.f, 0.f};  // lane k holds keypoint k: one load for all records of the round
-    if (lane < cnt_out) mine_kp = kps[base + lane * stride];
-    for (int kk = 0; kk < cnt_out; kk++) {
-      const int o = before + base + kk * stride;
-      const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_kp.ca), kk));
-      const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_kp.sb), kk));
-      const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)mine_kp.xy, kk);
-      const float fx = (float)(int)(xy & 0xFFFu) * lscale, fy = (float)(int)(xy >> 12) * lscale;
-      const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
-      // patch origin (centre - 19 rows - 19 columns; |rotated pattern| <= 18.4): lane offsets are non-negative
-      const uint8_t* corner = img + (size_t)(cy - 19) * pitch + (cx - 19);
-      uint64_t w[4];
+  // A keypoint's 512 pattern points fall in the 39 x 39 window around it (|rotated pattern| <= 18.4).  Gathering them
+  // straight from memory costs the L1 one tag lookup per distinct cache line per load instruction (~40 lines x 8
+  // loads per keypoint: the kernel ran at that rate); instead the window is copied once, row-contiguously (39 rows x
+  // 48 bytes from a 4-byte aligned column: 117 16-byte loads, two per lane), into a wave-private LDS tile and the
+  // points are gathered from LDS.  The copy of keypoint k + 1 is in flight while keypoint k is gathered (two tiles).
+  // the lane's two 16-byte pieces of a window: piece p = lane + 64 r -> row p / 3, segment p % 3
+  const int p0 = lane, p1 = lane + 64;
+  const int r0 = p0 / 3, g0 = p0 - 3 * r0, r1 = p1 / 3, g1 = p1 - 3 * r1;
+  const bool has1 = p1 < kWinRows * 3;
+  const int dst0 = r0 * kWinPitch + 16 * g0, dst1 = r1 * kWinPitch + 16 * g1;
+  auto centre = [&](int kk, int* cx, int* cy) {
+    const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_k, kk);
+    const float lscale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scale_k), kk));
+    const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_k), kk));
+    const float fx = (float)(int)(xy & 0xFFFu) * lscale, fy = (float)(int)(xy >> 12) * lscale;
+    *cx = __float2int_rn(fx * inv);
+    *cy = __float2int_rn(fy * inv);
+  };
+  uint4 q0, q1 = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](int kk) {
+    int cx, cy;
+    centre(kk, &cx, &cy);
+    const int pitch = __builtin_amdgcn_readlane(pitch_k, kk);
+    const uint8_t* org = a.blur + (size_t)image * a.pyr_bytes + (uint32_t)__builtin_amdgcn_readlane((int)off_k, kk) +
+                         (size_t)(cy - 19) * pitch + ((cx - 19) & ~3);  // wave-uniform
+    q0 = *reinterpret_cast<const uint4*>(org + (uint32_t)(r0 * pitch + 16 * g0));
+    if (has1) q1 = *reinterpret_cast<const uint4*>(org + (uint32_t)(r1 * pitch + 16 * g1));
+  };
+  fetch(0);
+  for (int kk = 0; kk < cnt; kk++) {
+    uint8_t* win = s_win[wid][kk & 1];
+    *reinterpret_cast<uint4*>(win + dst0) = q0;
+    if (has1) *reinterpret_cast<uint4*>(win + dst1) = q1;
+    if (kk + 1 < cnt) fetch(kk + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_k), kk));
+    const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sb_k), kk));
+    int cx, cy;
+    centre(kk, &cx, &cy);
+    // tile origin = (centre - 19 rows, (centre - 19 columns) rounded down to 4): lane offsets are non-negative
+    const uint8_t* corner = win + 19 * kWinPitch + 19 + ((cx - 19) & 3);
+    uint64_t w[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float x0f = pat[j][0], y0f = pat[j][1], x1f = pat[j][2], y1f = pat[j][3];
-        const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
-        const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
-        const int t0 = corner[(uint32_t)((iy0 + 19) * pitch + ix0 + 19)];
-        const int t1 = corner[(uint32_t)((iy1 + 19) * pitch + ix1 + 19)];
-        w[j] = __ballot(t0 < t1);
-      }
-      if (lane < 4) {
-        const uint64_t v = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
-        reinterpret_cast<uint64_t*>(a.desc_out + ((size_t)image * a.max_keypoints + o) * VSF_DESC_BYTES)[lane] = v;
-      }
+    for (int j = 0; j < 4; j++) {
+      const float x0f = pat[j][0], y0f = pat[j][1], x1f = pat[j][2], y1f = pat[j][3];
+      const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
+      const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
+      const int t0 = corner[iy0 * kWinPitch + ix0];
+      const int t1 = corner[iy1 * kWinPitch + ix1];
+      w[j] = __ballot(t0 < t1);
     }
-    // the round's cv::KeyPoint records, one per lane
-    if (lane < cnt_out) {
-      vsf_keypoint kp;
-      kp.x = (float)(int)(mine_kp.xy & 0xFFFu) * lscale;  // KeyPoint::pt *= scale
-      kp.y = (float)(int)(mine_kp.xy >> 12) * lscale;
-      kp.size = 31 * lscale;
-      kp.angle = mine_kp.angle;
-      kp.response = mine_kp.response;
-      kp.octave = level;
-      kp.class_id = -1;
-      a.kp_out[(size_t)image * a.max_keypoints + before + base + lane * stride] = kp;
+    if (lane < 4) {
+      const uint64_t v = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
+      reinterpret_cast<uint64_t*>(a.desc_out + ((size_t)image * a.max_keypoints + o_begin + kk) * VSF_DESC_BYTES)[lane] = v;
     }
+  }
+  // the cv::KeyPoint records, one per lane
+  if (lane < cnt) {
+    vsf_keypoint kp;
+    kp.x = (float)(int)(xy_k & 0xFFFu) * scale_k;  // KeyPoint::pt *= scale
+    kp.y = (float)(int)(xy_k >> 12) * scale_k;
+    kp.size = 31 * scale_k;
+    kp.angle = my_angle;
+    kp.response = resp_k;
+    kp.octave = level_k;
+    kp.class_id = -1;
+    a.kp_out[(size_t)image * a.max_keypoints + o_begin + lane] = kp;
   }
 }
 
@@ -267,6 +326,7 @@ void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
   a.desc_out = d_desc;
   a.counts = d_counts;
   a.status = d.status;
-  hipLaunchKernelGGL(orb_angle_kernel, dim3(g.nlevels * kSplit, im.n), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(orb_describe_kernel, dim3(g.nlevels * kSplit, im.n), dim3(256), 0, s, a);
+  a.nblocks = std::max((max_keypoints + 4 * kKpPerWave - 1) / (4 * kKpPerWave), 1);
+  a.nimages = im.n;
+  hipLaunchKernelGGL(orb_orient_describe_kernel, dim3(a.nblocks * ((im.n + 7) / 8 * 8)), dim3(256), 0, s, a);
 }
