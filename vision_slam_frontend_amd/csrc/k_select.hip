@@ -45,6 +45,7 @@ struct SelectArgs {
   int32_t* lvl_count;
   int nlevels;
   int level0;  // first level handled by this launch
+  int nlv, nimages;  // levels of this launch, images
   int32_t* status;
 };
 
@@ -500,7 +501,11 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   constexpr int kCellCap = ENTRIES;            // the gather's cell prefix array borrows the position tables
   int* cellpre = reinterpret_cast<int*>(sPos);
   const int tid = threadIdx.x;
-  const int level = a.level0 + blockIdx.x, image = blockIdx.y;
+  // image -> XCD affinity (workgroups go to the 8 XCDs round-robin by linear id): an image's candidates, pixels and
+  // scratch stay in one L2 (speed only)
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int image = xcd + 8 * (seq / a.nlv), level = a.level0 + seq - (seq / a.nlv) * a.nlv;
+  if (image >= a.nimages) return;
   const VsfLevel L = a.levels[level];
   const uint8_t* img;
   int pitch;
@@ -669,13 +674,17 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   // Large and mid levels share one launch of 256-thread workgroups with a 5120-entry LDS array (50 KB: three per
   // CU): levels with more candidates run their passes on HBM-resident arrays, which costs a workgroup ~1.3x the time
   // of the LDS path but beats one 1024-thread / 134 KB workgroup per CU (1.13 -> 0.81 ms per 128-frame step).
+  a.nimages = im.n;
+  const int n8 = (im.n + 7) / 8 * 8;
   if (ntiny0 > 0) {
     a.level0 = 0;
-    hipLaunchKernelGGL((orb_select_kernel<256, 5120, 512, 128>), dim3(ntiny0, im.n), dim3(256), 0, s, a);
+    a.nlv = ntiny0;
+    hipLaunchKernelGGL((orb_select_kernel<256, 5120, 512, 128>), dim3(a.nlv * n8), dim3(256), 0, s, a);
   }
   if (ntiny0 < g.nlevels) {
     a.level0 = ntiny0;
-    hipLaunchKernelGGL((orb_select_kernel<64, 1536, 512, 64>), dim3(g.nlevels - ntiny0, im.n), dim3(64), 0, s, a);
+    a.nlv = g.nlevels - ntiny0;
+    hipLaunchKernelGGL((orb_select_kernel<64, 1536, 512, 64>), dim3(a.nlv * n8), dim3(64), 0, s, a);
   }
 }
 
