@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
                      v3 = round_fix16(n3, t3);
       // byte 2 of each value -> bytes 0..3
       const uint32_t lo2 = __builtin_amdgcn_perm(v1, v0, 0x0C0C0602u), hi2 = __builtin_amdgcn_perm(v3, v2, 0x06020C0Cu);
-      *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch + c0) = lo2 | hi2;
+      *reinterpret_cast<uint32_t*>(dst + VSF_BLUR_TILE_OFFSET(L.pitch, c0, y)) = lo2 | hi2;  // (c0 % 4 == 0)
     }
   };
 

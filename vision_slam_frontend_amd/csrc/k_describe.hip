@@ -107,7 +107,7 @@ constexpr int kKpPerWave = 16;  // consecutive output keypoints per wave
 // the wave then walks the 16 keypoints with v_readlane broadcasts.  (One workgroup per (level, image) left most waves
 // with two or three keypoints and a prologue longer than their work.)
 __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a) {
-  constexpr int kWinRows = 39, kWinPitch = 48, kWinBytes = kWinRows * kWinPitch;
+  constexpr int kWinRows = 39, kWinPitch = 64, kWinBytes = kWinRows * kWinPitch;
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][2][kWinBytes];
   // Workgroups are dealt to the 8 XCDs round-robin by their linear id; all workgroups of an image are given ids of
   // one residue class so that an image's pyramid levels are pulled into ONE XCD's L2 (speed only, not correctness).
@@ -234,14 +234,16 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
   }
   // A keypoint's 512 pattern points fall in the 39 x 39 window around it (|rotated pattern| <= 18.4).  Gathering them
   // straight from memory costs the L1 one tag lookup per distinct cache line per load instruction (~40 lines x 8
-  // loads per keypoint: the kernel ran at that rate); instead the window is copied once, row-contiguously (39 rows x
-  // 48 bytes from a 4-byte aligned column: 117 16-byte loads, two per lane), into a wave-private LDS tile and the
-  // points are gathered from LDS.  The copy of keypoint k + 1 is in flight while keypoint k is gathered (two tiles).
-  // the lane's two 16-byte pieces of a window: piece p = lane + 64 r -> row p / 3, segment p % 3
-  const int p0 = lane, p1 = lane + 64;
-  const int r0 = p0 / 3, g0 = p0 - 3 * r0, r1 = p1 / 3, g1 = p1 - 3 * r1;
-  const bool has1 = p1 < kWinRows * 3;
-  const int dst0 = r0 * kWinPitch + 16 * g0, dst1 = r1 * kWinPitch + 16 * g1;
+  // loads per keypoint: the kernel ran at that rate); instead the window is copied once (39 rows x 64 bytes from a
+  // 16-byte aligned column: 156 16-byte pieces, three per lane) into a wave-private LDS tile and the points are
+  // gathered from LDS.  The blurred levels are stored in 4 x 32 tiles (k_blur.hip), so the window is ~24 cache lines.
+  // The copy of keypoint k + 1 is in flight while keypoint k is gathered (two tiles).
+  // the lane's 16-byte pieces of a window: piece p = lane + 64 r -> row p / 4, segment p % 4
+  const int pc0 = lane, pc1 = lane + 64, pc2 = min(lane + 128, kWinRows * 4 - 1);  // (spare lanes repeat the last piece)
+  const int prow0 = pc0 >> 2, prow1 = pc1 >> 2, prow2 = pc2 >> 2;
+  const int pseg0 = pc0 & 3, pseg1 = pc1 & 3, pseg2 = pc2 & 3;
+  const int pdst0 = prow0 * kWinPitch + 16 * pseg0, pdst1 = prow1 * kWinPitch + 16 * pseg1,
+            pdst2 = prow2 * kWinPitch + 16 * pseg2;
   auto centre = [&](int kk, int* cx, int* cy) {
     const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_k, kk);
     const float lscale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scale_k), kk));
@@ -250,21 +252,27 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
     *cx = __float2int_rn(fx * inv);
     *cy = __float2int_rn(fy * inv);
   };
-  uint4 q0, q1 = make_uint4(0, 0, 0, 0);
+  uint4 q0, q1, q2;
   auto fetch = [&](int kk) {
     int cx, cy;
     centre(kk, &cx, &cy);
     const int pitch = __builtin_amdgcn_readlane(pitch_k, kk);
-    const uint8_t* org = a.blur + (size_t)image * a.pyr_bytes + (uint32_t)__builtin_amdgcn_readlane((int)off_k, kk) +
-                         (size_t)(cy - 19) * pitch + ((cx - 19) & ~3);  // wave-uniform
-    q0 = *reinterpret_cast<const uint4*>(org + (uint32_t)(r0 * pitch + 16 * g0));
-    if (has1) q1 = *reinterpret_cast<const uint4*>(org + (uint32_t)(r1 * pitch + 16 * g1));
+    const uint8_t* lvl = a.blur + (size_t)image * a.pyr_bytes + (uint32_t)__builtin_amdgcn_readlane((int)off_k, kk);
+    const int ya = cy - 19, tx = (cx - 19) >> 4, tx_max = (pitch >> 4) - 1;  // wave-uniform (16-byte segments)
+    auto piece = [&](int prow, int pseg) -> uint4 {
+      const int y = ya + prow, t = min(tx + pseg, tx_max);  // (a segment past the row end is never gathered)
+      return *reinterpret_cast<const uint4*>(lvl + VSF_BLUR_TILE_OFFSET(pitch, t << 4, y));
+    };
+    q0 = piece(prow0, pseg0);
+    q1 = piece(prow1, pseg1);
+    q2 = piece(prow2, pseg2);
   };
   fetch(0);
   for (int kk = 0; kk < cnt; kk++) {
     uint8_t* win = s_win[wid][kk & 1];
-    *reinterpret_cast<uint4*>(win + dst0) = q0;
-    if (has1) *reinterpret_cast<uint4*>(win + dst1) = q1;
+    *reinterpret_cast<uint4*>(win + pdst0) = q0;
+    *reinterpret_cast<uint4*>(win + pdst1) = q1;
+    *reinterpret_cast<uint4*>(win + pdst2) = q2;
     if (kk + 1 < cnt) fetch(kk + 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
     const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sb_k), kk));
     int cx, cy;
     centre(kk, &cx, &cy);
-    // tile origin = (centre - 19 rows, (centre - 19 columns) rounded down to 4): lane offsets are non-negative
-    const uint8_t* corner = win + 19 * kWinPitch + 19 + ((cx - 19) & 3);
+    // tile origin = (centre - 19 rows, (centre - 19 columns) rounded down to 16): lane offsets are non-negative
+    const uint8_t* corner = win + 19 * kWinPitch + 19 + ((cx - 19) & 15);
     uint64_t w[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
 #pragma unroll
     for (int k = 0; k < kAhead; k++) bits_next[k] = load_bits(c0 + (1 + k) * kTile, c_end);
     __syncthreads();
-    v16i accA0, accA1, accB0, accB1;
+    v16i accA0, accA1, accB0 = base, accB1 = base;  // (B is not folded before it is written)
     step(0, accB0, accB1, accA0, accA1, false);
     int t = 1;
     for (; t + 1 < ntiles; t += 2) {

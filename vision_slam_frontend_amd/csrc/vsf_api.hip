@@ -119,7 +119,7 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
     if (L.w < 8 || L.h < 1 || L.w > 4095 || L.h > 4095) return false;  // (blur border window needs w >= 8)
     L.pitch = align_up(L.w, 64);
     L.offset = offset;
-    offset += (uint32_t)align_up(L.pitch * L.h, 256);
+    offset += (uint32_t)align_up(L.pitch * align_up(L.h, 8), 256);  // (rows padded for the tiled blurred copy)
     L.nfeatures = nfeat[l];
     pixels += (uint64_t)L.w * L.h;
     max_w = std::max(max_w, L.w);
@@ -1331,6 +1331,13 @@ vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred
     src = (blurred ? ctx->dorb.d.blur : (ctx->last_pyr ? ctx->last_pyr : ctx->dorb.d.pyr)) +
           (size_t)image * ctx->orb.g.pyr_bytes + L.offset;
     pitch = (size_t)L.pitch;
+  }
+  if (blurred) {  // stored in tiles (VSF_BLUR_TILE_OFFSET)
+    std::vector<uint8_t> tiled((size_t)L.pitch * align_up(L.h, 8));
+    VSF_HIP(hipMemcpy(tiled.data(), src, tiled.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; y++)
+      for (int x = 0; x < L.w; x++) out[(size_t)y * ostride + x] = tiled[VSF_BLUR_TILE_OFFSET(L.pitch, x, y)];
+    return VSF_OK;
   }
   VSF_HIP(hipMemcpy2D(out, ostride, src, pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
   return VSF_OK;

@@ -15,6 +15,12 @@
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
 #define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
+// The blurred levels are stored in tiles of 4 rows x 32 bytes (= one 128-byte cache line), tiles in row-major order:
+// the descriptor kernel gathers 39 x 39 windows from them and a window then touches ~24 lines instead of 39..78,
+// while the blur kernel still writes whole 32-byte sectors (8 lanes x 4 bytes).
+// Byte offset of pixel (x, y) inside a level of row pitch `pitch` (a multiple of 64; rows padded to a multiple of 8):
+#define VSF_BLUR_TILE_OFFSET(pitch, x, y) \
+  ((uint32_t)((y) >> 2) * (uint32_t)((pitch) * 4) + ((uint32_t)((x) >> 5) << 7) + ((uint32_t)((y) & 3) << 5) + (uint32_t)((x) & 31))
 #define VSF_SORT_LDS_ROWS 4096   // matches of one pair sorted in LDS (8 B each); larger pairs sort in HBM scratch
 #define VSF_IC_ITEMS 320         // ICAngles disc items per byte phase: 31 rows x 9 dwords = 279, padded to 5 x 64
 
