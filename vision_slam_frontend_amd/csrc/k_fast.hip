@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restri
                                                         int max_keypoints, vsf_keypoint* __restrict__ out,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ status) {
   __shared__ int cellpre[2048 + 8];
+  __shared__ __attribute__((aligned(4))) uint16_t rs_lds[64 * VSF_FAST_RS_STRIDE];
   __shared__ int lds4[4];
   const int image = blockIdx.x;
   const VsfLevel L = levels[0];
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restri
   const uint32_t* cand_img = cand + (size_t)image * cand_entries;
   const int n = vsf_level_candidate_count<256>(L, rs_img, lds4);
   vsf_keypoint* o = out + (size_t)image * max_keypoints;
-  vsf_gather_level<256>(L, cand_img, rs_img, cellpre, 2048, lds4, [&](int dst, uint32_t cd) {
+  vsf_gather_level<256>(L, cand_img, rs_img, cellpre, 2048, rs_lds, 64, lds4, [&](int dst, uint32_t cd) {
     if (dst < max_keypoints) {
       vsf_keypoint kp;
       kp.x = (float)VSF_CAND_X(cd);

@@ -498,8 +498,10 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   __shared__ PassCtl ctl;
   __shared__ int lds4[16];
   static_assert(ENTRIES <= 65536 && ENTRIES / 64 <= MAXW && STAGE2 <= ENTRIES && ENTRIES >= 1025, "scratch sizes");
-  constexpr int kCellCap = ENTRIES;            // the gather's cell prefix array borrows the position tables
+  // the gather borrows the position tables: three quarters for the cell prefix array, one for the row-start tables
+  constexpr int kCellCap = ENTRIES * 3 / 4, kRsUnits = (ENTRIES / 4) * 2 / VSF_FAST_RS_STRIDE;
   int* cellpre = reinterpret_cast<int*>(sPos);
+  uint16_t* rs_lds = reinterpret_cast<uint16_t*>(cellpre + kCellCap);
   const int tid = threadIdx.x;
   // image -> XCD affinity (workgroups go to the 8 XCDs round-robin by linear id): an image's candidates, pixels and
   // scratch stay in one L2 (speed only)
@@ -543,9 +545,11 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   {
     const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
     if (a_in_lds)
-      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { sA[dst] = cd; });
+      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, rs_lds, kRsUnits, lds4,
+                           [&](int dst, uint32_t cd) { sA[dst] = cd; });
     else
-      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, lds4, [&](int dst, uint32_t cd) { gA[dst] = cd; });
+      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, rs_lds, kRsUnits, lds4,
+                           [&](int dst, uint32_t cd) { gA[dst] = cd; });
   }
   __syncthreads();
 

@@ -50,43 +50,59 @@ __device__ __forceinline__ int vsf_level_candidate_count(const VsfLevel& L, cons
 }
 
 // Merges the level's unit segments into raster order; store(dst_index, entry) receives every candidate once.
-// cellpre: LDS int array with cellcap >= VSF_FAST_STRIP_ROWS * nbands + 1 entries.  All NT threads call.
+// cellpre: LDS int array with cellcap >= VSF_FAST_STRIP_ROWS * nbands + 1 entries; rs_lds: LDS copy of the row-start
+// tables of the units of one chunk, room for rs_units >= nbands tables.  All NT threads call.
+// The level is walked in chunks of whole strips.  Per chunk the units' row-start tables come into LDS with one
+// coalesced read, the per-cell counts and their prefix sums are formed from LDS, and the segments are copied one unit
+// per wave: the only dependent global read left in front of the copy is the segment itself.
 template <int NT, class Store>
 __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32_t* __restrict__ cand_img,
                                                  const uint16_t* __restrict__ rs_img, int* cellpre, int cellcap,
-                                                 int* lds4, Store store) {
-  constexpr int SR = VSF_FAST_STRIP_ROWS;
+                                                 uint16_t* rs_lds, int rs_units, int* lds4, Store store) {
+  constexpr int SR = VSF_FAST_STRIP_ROWS, RS = VSF_FAST_RS_STRIDE;
   const int tid = threadIdx.x;
   const int nrows = L.y_hi - L.y_lo, nb = L.nbands;
   if (nrows <= 0 || nb <= 0) return;
-  int rows_per_chunk = ((cellcap - 1) / nb) / SR * SR;
-  if (rows_per_chunk < SR) rows_per_chunk = SR;
+  int strips_per_chunk = min(((cellcap - 1) / nb) / SR, rs_units / nb);
+  if (strips_per_chunk < 1) strips_per_chunk = 1;  // (capacities are sized so that this cannot happen)
+  const int rows_per_chunk = strips_per_chunk * SR;
   int base = 0;
   for (int row0 = 0; row0 < nrows; row0 += rows_per_chunk) {
     const int nr = min(rows_per_chunk, nrows - row0);
     const int nc = nr * nb;
+    const int s0 = row0 / SR, s1 = (row0 + nr + SR - 1) / SR;
+    const int nu = (s1 - s0) * nb;
+    // the chunk's row-start tables (contiguous in memory: units s0 * nb .. s1 * nb - 1), as dwords
+    {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(rs_img + (size_t)(L.unit0 + s0 * nb) * RS);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(rs_lds);
+      for (int i = tid; i < nu * (RS / 2); i += NT) dst[i] = src[i];
+    }
+    __syncthreads();
+    // cell (row, band) -> number of candidates, then exclusive prefix sums over the cells
+    for (int c = tid; c < nc; c += NT) {
+      const int row = row0 + c / nb, b = c - (c / nb) * nb;
+      const int s = row / SR, r = row - s * SR;
+      const uint16_t* rs = rs_lds + ((s - s0) * nb + b) * RS;
+      cellpre[c] = (int)rs[r + 1] - (int)rs[r];
+    }
+    __syncthreads();
     const int cpt = (nc + NT - 1) / NT;
     const int c_beg = min(tid * cpt, nc), c_end = min(c_beg + cpt, nc);
     int local = 0;
-    {
-      int row = row0 + c_beg / nb, b = c_beg % nb;
-      for (int c = c_beg; c < c_end; c++) {
-        const int s = row / SR, r = row - s * SR;
-        const uint16_t* rs = rs_img + (size_t)(L.unit0 + s * nb + b) * VSF_FAST_RS_STRIDE;
-        cellpre[c] = local;
-        local += (int)rs[r + 1] - (int)rs[r];
-        if (++b == nb) b = 0, ++row;
-      }
-    }
+    for (int c = c_beg; c < c_end; c++) local += cellpre[c];
     int total;
-    const int excl = vsf_block_excl_scan<NT>(local, lds4, &total);
-    for (int c = c_beg; c < c_end; c++) cellpre[c] += excl;
+    int run = vsf_block_excl_scan<NT>(local, lds4, &total);
+    for (int c = c_beg; c < c_end; c++) {
+      const int v = cellpre[c];
+      cellpre[c] = run;
+      run += v;
+    }
     __syncthreads();
-    const int s0 = row0 / SR, s1 = (row0 + nr + SR - 1) / SR;
-    // one wave per unit (round robin): independent load chains instead of one long dependent loop
+    // one wave per unit (round robin)
     for (int u = s0 * nb + (tid >> 6); u < s1 * nb; u += NT / 64) {
       const int s = u / nb, b = u - s * nb;
-      const uint16_t* rs = rs_img + (size_t)(L.unit0 + u) * VSF_FAST_RS_STRIDE;
+      const uint16_t* rs = rs_lds + (u - s0 * nb) * RS;
       const int tot = rs[SR];
       const uint32_t* seg = cand_img + L.cand_offset + (size_t)u * L.seg_cap;
       for (int e = tid & 63; e < tot; e += 64) {
