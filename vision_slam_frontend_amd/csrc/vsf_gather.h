@@ -105,12 +105,21 @@ __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32
       const uint16_t* rs = rs_lds + (u - s0 * nb) * RS;
       const int tot = rs[SR];
       const uint32_t* seg = cand_img + L.cand_offset + (size_t)u * L.seg_cap;
-      for (int e = tid & 63; e < tot; e += 64) {
-        const uint32_t entry = seg[e];
-        const int row = VSF_CAND_Y(entry) - L.y_lo;
-        const int r = row - s * SR;
-        const int c = (row - row0) * nb + b;
-        store(base + cellpre[c] + (e - (int)rs[r]), entry);
+      // four segment reads in flight per lane (a unit rarely holds more than 256 candidates)
+      for (int e0 = tid & 63; e0 < tot; e0 += 256) {
+        uint32_t entry[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) entry[k] = e0 + 64 * k < tot ? seg[e0 + 64 * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int e = e0 + 64 * k;
+          if (e < tot) {
+            const int row = VSF_CAND_Y(entry[k]) - L.y_lo;
+            const int r = row - s * SR;
+            const int c = (row - row0) * nb + b;
+            store(base + cellpre[c] + (e - (int)rs[r]), entry[k]);
+          }
+        }
       }
     }
     base += total;
