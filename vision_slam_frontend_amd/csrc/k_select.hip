@@ -84,7 +84,10 @@ struct PassMem {
   P* Rp;
   int maxw;
   PassCtl* c;
+  uint8_t* wbuf;  // LDS scratch of the single-wave passes: kWaveScratch bytes (rank table + staging of an HBM range)
 };
+constexpr int kWaveTable = 2 * kWaveCutoff;               // u16 rank -> position table
+constexpr int kWaveScratch = kWaveTable + 8 * kWaveCutoff;  // + up to 256 staged 8-byte elements
 
 __device__ __forceinline__ int select64(unsigned long long x, int r) {
   // position of the r-th (0-based) set bit of x
@@ -266,66 +269,104 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ int select_rank4(const unsigned long long (&m)[4], const int (&pre)[5], int t) {
-  const int w = (t >= pre[1]) + (t >= pre[2]) + (t >= pre[3]);
-  const unsigned long long mk = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
-  const int p = w == 0 ? pre[0] : w == 1 ? pre[1] : w == 2 ? pre[2] : pre[3];
+template <int E>
+__device__ __forceinline__ int select_rank(const unsigned long long (&m)[E], const int (&pre)[E + 1], int t) {
+  int w = 0;
+#pragma unroll
+  for (int e = 1; e < E; e++) w += (t >= pre[e]);
+  unsigned long long mk = m[0];
+  int p = pre[0];
+#pragma unroll
+  for (int e = 1; e < E; e++)
+    if (w == e) mk = m[e], p = pre[e];
   return w * 64 + select64(mk, t - p);
 }
 
-// One pass over A[lo, hi), hi - lo <= 256.  Returns (uniform) the swap count K, the stopper totals and `cut`.
-template <class T, class FL, class FR>
-__device__ __forceinline__ void wave_hoare_pass(T* A, int lo, int hi, FL fl, FR fr, int& totalR, int& cut) {
+// One pass over A[lo, hi), hi - lo <= 64 E, A in LDS.  Returns (uniform) the right-stopper total and `cut`.
+// The right-stoppers publish their positions in a rank -> position table (rank counted from the right); a left-stopper
+// of rank k that takes part reads its partner's position there (two LDS round trips instead of a 64-bit rank-select per
+// element), then all partner elements are read before any is written (a position is touched by at most one swap).
+// E = elements per lane: a single wave works through these passes alone, so their cost is instruction latency, and
+// most passes of a selection run on the short ranges at its end.
+template <int E, class T, class FL, class FR>
+__device__ __forceinline__ void wave_hoare_pass_e(T* A, int lo, int hi, FL fl, FR fr, int& totalR, int& cut,
+                                                  uint16_t* wtab) {
   const int lane = threadIdx.x & 63;
   const int m = hi - lo;
   const unsigned long long lt = (1ull << lane) - 1ull, le = (2ull << lane) - 1ull;
-  unsigned long long mL[4], mR[4];
-  T x[4];
+  unsigned long long mL[E], mR[E];
+  T x[E];
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
+    const int i = e * 64 + lane;
+    if (i < m) x[e] = A[lo + i];
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
     const int i = e * 64 + lane;
     bool l = false, r = false;
     if (i < m) {
-      x[e] = A[lo + i];
       l = fl(x[e]);
       r = fr(x[e]);
     }
     mL[e] = __ballot(l);
     mR[e] = __ballot(r);
   }
-  int preL[5], preR[5];
+  int preL[E + 1], preR[E + 1];
   preL[0] = preR[0] = 0;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     preL[e + 1] = preL[e] + __popcll(mL[e]);
     preR[e + 1] = preR[e] + __popcll(mR[e]);
   }
-  const int totalL = preL[4];
-  totalR = preR[4];
-  int K = 0;
+  const int totalL = preL[E];
+  totalR = preR[E];
+  bool part[E];
+  int kk[E];
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const bool is_l = (mL[e] >> lane) & 1ull;
+  for (int e = 0; e < E; e++) {
+    const bool is_l = (mL[e] >> lane) & 1ull, is_r = (mR[e] >> lane) & 1ull;
     const int k = preL[e] + __popcll(mL[e] & lt) + 1;    // 1-based rank from the left
     const int r_le = preR[e] + __popcll(mR[e] & le);     // right-stoppers at <= i
-    const bool part = is_l && (totalR - r_le >= k);
-    if (part) {
-      const int j = select_rank4(mR, preR, totalR - k);
-      const T xj = A[lo + j];
-      A[lo + e * 64 + lane] = xj;
-      A[lo + j] = x[e];
-    }
-    K += __popcll(__ballot(part));
+    if (is_r) wtab[totalR - r_le] = (uint16_t)(e * 64 + lane);  // 0-based rank from the right
+    part[e] = is_l && (totalR - r_le >= k);
+    kk[e] = k;
   }
-  const int aK1 = K < totalL ? select_rank4(mL, preL, K) : 0x7FFFFFFF;
-  const int bK = K > 0 ? select_rank4(mR, preR, totalR - K) : 0x7FFFFFFF;
+  wave_fence();
+  int jj[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) jj[e] = part[e] ? (int)wtab[kk[e] - 1] : 0;
+  T xj[E];
+#pragma unroll
+  for (int e = 0; e < E; e++)
+    if (part[e]) xj[e] = A[lo + jj[e]];
+  int K = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    if (part[e]) {
+      A[lo + e * 64 + lane] = xj[e];
+      A[lo + jj[e]] = x[e];
+    }
+    K += __popcll(__ballot(part[e]));
+  }
+  const int aK1 = K < totalL ? select_rank<E>(mL, preL, K) : 0x7FFFFFFF;
+  const int bK = K > 0 ? select_rank<E>(mR, preR, totalR - K) : 0x7FFFFFFF;
   cut = (K < totalL && (K == 0 || aK1 < bK)) ? lo + aK1 : lo + bK;
   wave_fence();
 }
 
-// std::__introselect continued from (first, last, depth) on a range of <= kWaveCutoff elements.
+template <class T, class FL, class FR>
+__device__ __forceinline__ void wave_hoare_pass(T* A, int lo, int hi, FL fl, FR fr, int& totalR, int& cut,
+                                                uint16_t* wtab) {
+  if (hi - lo <= 64)  // wave-uniform
+    wave_hoare_pass_e<1>(A, lo, hi, fl, fr, totalR, cut, wtab);
+  else
+    wave_hoare_pass_e<4>(A, lo, hi, fl, fr, totalR, cut, wtab);
+}
+
+// std::__introselect continued from (first, last, depth) on a range of <= kWaveCutoff elements, A in LDS.
 template <class T, class Greater>
-__device__ void wave_introselect(T* A, int first, int last, int nth, int depth, Greater greater) {
+__device__ void wave_introselect(T* A, int first, int last, int nth, int depth, Greater greater, uint16_t* wtab) {
   const int lane = threadIdx.x & 63;
   while (last - first > 3) {
     if (depth == 0) {
@@ -337,13 +378,25 @@ __device__ void wave_introselect(T* A, int first, int last, int nth, int depth, 
       return;
     }
     --depth;
-    if (lane == 0) vsf_sel::move_median_to_first_(A, first, first + 1, first + (last - first) / 2, last - 1, greater);
+    // std::__move_median_to_first(first, first + 1, mid, last - 1): every lane reads the four elements (uniform
+    // addresses, one round trip) and takes the same decision; lane 0 stores the swap
+    const int pa = first + 1, pb = first + (last - first) / 2, pc = last - 1;
+    const T vf = A[first], va = A[pa], vb = A[pb], vc = A[pc];
+    int pm;
+    if (greater(va, vb))
+      pm = greater(vb, vc) ? pb : greater(va, vc) ? pc : pa;
+    else
+      pm = greater(va, vc) ? pa : greater(vb, vc) ? pc : pb;
+    const T pivot = pm == pa ? va : pm == pb ? vb : vc;
+    if (lane == 0) {
+      A[first] = pivot;
+      A[pm] = vf;
+    }
     wave_fence();
-    const T pivot = A[first];
     int total_r, cut;
     wave_hoare_pass(
         A, first + 1, last, [&](const T& x) { return !greater(x, pivot); },
-        [&](const T& x) { return !greater(pivot, x); }, total_r, cut);
+        [&](const T& x) { return !greater(pivot, x); }, total_r, cut, wtab);
     if (cut <= nth)
       first = cut;
     else
@@ -351,6 +404,23 @@ __device__ void wave_introselect(T* A, int first, int last, int nth, int depth, 
   }
   if (lane == 0) vsf_sel::insertion_sort_(A, first, last, greater);
   wave_fence();
+}
+
+// Runs f(B, off) on an LDS image B of A[lo, hi) (hi - lo <= kWaveCutoff), B[i - off] = A[i]: A itself when it lives in
+// LDS, else the range is staged through the wave scratch (an HBM-resident array pays a memory round trip per access).
+template <bool IN_LDS, class T, class F>
+__device__ __forceinline__ void with_lds_range(T* A, int lo, int hi, uint8_t* wbuf, F f) {
+  if constexpr (IN_LDS) {
+    f(A, 0);
+  } else {
+    const int lane = threadIdx.x & 63;
+    T* B = reinterpret_cast<T*>(wbuf + kWaveTable);
+    for (int i = lane; i < hi - lo; i += 64) B[i] = A[lo + i];
+    wave_fence();
+    f(B, lo);
+    for (int i = lane; i < hi - lo; i += 64) A[lo + i] = B[i];
+    wave_fence();
+  }
 }
 
 // std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
@@ -390,7 +460,9 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, const PM&
   if (tid < 64) {  // wave 0 finishes the range; the other waves wait at the barrier
     const int first = s.st[0], last = s.st[1], depth = s.st[2];
     if (last - first <= kWaveCutoff)
-      wave_introselect(A, first, last, nth, depth, greater);
+      with_lds_range<sizeof(*pm.Lp) == 2>(A, first, last, pm.wbuf, [&](T* B, int off) {
+        wave_introselect(B, first - off, last - off, nth - off, depth, greater, reinterpret_cast<uint16_t*>(pm.wbuf));
+      });
     else if (tid == 0)  // depth limit hit on a large range (heap select), or a range beyond the mask scratch
       vsf_sel::introselect_from_(A, first, last, nth, depth, greater);
   }
@@ -407,8 +479,11 @@ __device__ int par_partition(T* A, int lo, int hi, Pred pred, const PM& pm) {
       if (hi - lo <= kWaveCutoff) {
         int total_r = 0, cut = 0;
         if (hi > lo)
-          wave_hoare_pass(
-              A, lo, hi, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, total_r, cut);
+          with_lds_range<sizeof(*pm.Lp) == 2>(A, lo, hi, pm.wbuf, [&](T* B, int off) {
+            wave_hoare_pass(
+                B, lo - off, hi - off, [&](const T& x) { return !pred(x); }, [&](const T& x) { return pred(x); }, total_r,
+                cut, reinterpret_cast<uint16_t*>(pm.wbuf));
+          });
         if (tid == 0) s.st[4] = lo + total_r;
       } else if (tid == 0) {
         s.st[4] = vsf_sel::partition_(A, lo, hi, pred);
@@ -490,9 +565,9 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
 // ENTRIES: stage-1 candidates kept in LDS; STAGE2: stage-2 pairs kept in LDS; MAXW: mask words of a parallel pass.
 template <int NT, int ENTRIES, int STAGE2, int MAXW>
 __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
-  __shared__ uint32_t sA[ENTRIES];
+  __shared__ __attribute__((aligned(16))) uint32_t sA[ENTRIES];
   __shared__ uint16_t sPos[2 * ENTRIES];  // rank -> position tables of the LDS-resident passes
-  __shared__ uint2 sB[STAGE2];
+  __shared__ __attribute__((aligned(16))) uint2 sB[STAGE2];
   __shared__ unsigned long long sMask[2 * MAXW];
   __shared__ int sPre[2 * MAXW];
   __shared__ PassCtl ctl;
@@ -525,7 +600,11 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   uint32_t* gscratch = a.scratch + (size_t)image * 6 * a.cand_entries;
   uint32_t* gA = gscratch + L.cand_offset;
   uint2* gB = reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
-  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + ENTRIES, ENTRIES / 64, &ctl};
+  // wave scratch: stage 1 borrows the (still unused) stage-2 array, stage 2 the stage-1 array (consumed by then)
+  static_assert(sizeof(uint2) * STAGE2 >= kWaveScratch && sizeof(uint32_t) * ENTRIES >= kWaveScratch, "wave scratch");
+  uint8_t* wbuf1 = reinterpret_cast<uint8_t*>(sB);
+  uint8_t* wbuf2 = reinterpret_cast<uint8_t*>(sA);
+  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + ENTRIES, ENTRIES / 64, &ctl, wbuf1};
   // HBM-resident passes keep their masks in HBM as well (24 bytes per 64 elements, carved from the level's slice of
   // the sixth scratch block), so a level of any candidate count runs the parallel passes
   const int level_cap = L.seg_cap * L.nbands * L.nstrips, hbm_w = (level_cap + 63) / 64;
@@ -540,7 +619,11 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
                                  gscratch + 3 * a.cand_entries + L.cand_offset,
                                  gscratch + 4 * a.cand_entries + L.cand_offset,
                                  hbm_masks ? hbm_w : MAXW,
-                                 &ctl};
+                                 &ctl,
+                                 wbuf1};
+  PassMem<uint16_t> pm_lds2 = pm_lds;
+  PassMem<uint32_t> pm_hbm2 = pm_hbm;
+  pm_lds2.wbuf = pm_hbm2.wbuf = wbuf2;
   const bool a_in_lds = n <= ENTRIES;
   {
     const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
@@ -577,9 +660,9 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   // ---- K5: retainBest(n_l) on the Harris response ----
   int m2;
   if (b_in_lds)
-    m2 = par_retain_best<NT>(sB, m1, L.nfeatures, RespGreater(), RespGe(), pm_lds);
+    m2 = par_retain_best<NT>(sB, m1, L.nfeatures, RespGreater(), RespGe(), pm_lds2);
   else
-    m2 = par_retain_best<NT>(gB, m1, L.nfeatures, RespGreater(), RespGe(), pm_hbm);
+    m2 = par_retain_best<NT>(gB, m1, L.nfeatures, RespGreater(), RespGe(), pm_hbm2);
   __syncthreads();
 
   // ---- survivors in retainBest order; K6 (ICAngles) runs in k_describe.hip, one wave per keypoint ----
@@ -611,8 +694,9 @@ __global__ __launch_bounds__(NT) void retain_best_test_kernel(uint2* data, uint3
   __shared__ unsigned long long sMask[2 * MAXW];
   __shared__ int sPre[2 * MAXW];
   __shared__ PassCtl ctl;
-  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + kBuf, kBuf / 64, &ctl};
-  const PassMem<uint32_t> pm_hbm{sMask, sMask + MAXW, sPre, sPre + MAXW, tables, tables + n, MAXW, &ctl};
+  __shared__ __attribute__((aligned(8))) uint8_t wbuf[kWaveScratch];
+  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + kBuf, kBuf / 64, &ctl, wbuf};
+  const PassMem<uint32_t> pm_hbm{sMask, sMask + MAXW, sPre, sPre + MAXW, tables, tables + n, MAXW, &ctl, wbuf};
   int m;
   if (mode == 0) {  // float keys
     if (use_lds && n <= kBuf) {
