@@ -322,7 +322,7 @@ __device__ __forceinline__ void wave_hoare_pass_e(T* A, int lo, int hi, FL fl, F
   const int totalL = preL[E];
   totalR = preR[E];
   bool part[E];
-  int kk[E];
+  int kk[E], rr[E];
 #pragma unroll
   for (int e = 0; e < E; e++) {
     const bool is_l = (mL[e] >> lane) & 1ull, is_r = (mR[e] >> lane) & 1ull;
@@ -331,6 +331,7 @@ __device__ __forceinline__ void wave_hoare_pass_e(T* A, int lo, int hi, FL fl, F
     if (is_r) wtab[totalR - r_le] = (uint16_t)(e * 64 + lane);  // 0-based rank from the right
     part[e] = is_l && (totalR - r_le >= k);
     kk[e] = k;
+    rr[e] = totalR - r_le + 1;                           // 1-based rank from the right (when a right-stopper)
   }
   wave_fence();
   int jj[E];
@@ -349,8 +350,15 @@ __device__ __forceinline__ void wave_hoare_pass_e(T* A, int lo, int hi, FL fl, F
     }
     K += __popcll(__ballot(part[e]));
   }
-  const int aK1 = K < totalL ? select_rank<E>(mL, preL, K) : 0x7FFFFFFF;
-  const int bK = K > 0 ? select_rank<E>(mR, preR, totalR - K) : 0x7FFFFFFF;
+  // the (K+1)-th left-stopper and the K-th right-stopper from the right: the lane that holds it raises its hand
+  int aK1 = 0x7FFFFFFF, bK = 0x7FFFFFFF;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const unsigned long long ha = __ballot(((mL[e] >> lane) & 1ull) && kk[e] == K + 1);
+    const unsigned long long hb = __ballot(((mR[e] >> lane) & 1ull) && rr[e] == K);
+    if (ha) aK1 = e * 64 + (int)__builtin_ctzll(ha);
+    if (hb && K > 0) bK = e * 64 + (int)__builtin_ctzll(hb);
+  }
   cut = (K < totalL && (K == 0 || aK1 < bK)) ? lo + aK1 : lo + bK;
   wave_fence();
 }
@@ -506,6 +514,25 @@ template <int NT, class T, class Greater, class GreaterEq, class PM>
 __device__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, const PM& s) {
   if (n_points >= 0 && n > n_points) {
     if (n_points == 0) return 0;
+    if (n <= kWaveCutoff) {  // short array: wave 0 runs selection and partition back to back, one barrier at the end
+      PassCtl& c = *s.c;
+      if (threadIdx.x < 64) {
+        uint16_t* wtab = reinterpret_cast<uint16_t*>(s.wbuf);
+        with_lds_range<sizeof(*s.Lp) == 2>(A, 0, n, s.wbuf, [&](T* B, int) {
+          wave_introselect(B, 0, n, n_points, vsf_sel::lg_(n) * 2, greater, wtab);
+          const T ambiguous = B[n_points - 1];
+          int total_r = 0, cut = 0;
+          wave_hoare_pass(
+              B, n_points, n, [&](const T& x) { return !ge(x, ambiguous); },
+              [&](const T& x) { return ge(x, ambiguous); }, total_r, cut, wtab);
+          if (threadIdx.x == 0) c.st[4] = n_points + total_r;
+        });
+      }
+      __syncthreads();
+      const int r = c.st[4];
+      __syncthreads();
+      return r;
+    }
     par_nth_element<NT>(A, n, n_points, greater, s);
     const T ambiguous = A[n_points - 1];
     return par_partition<NT>(
