@@ -128,7 +128,11 @@ def test_knn2_tie_rule_adversarial(ctx640, oracle):
     assert ctx640.get_matches(q, t).tobytes() == oracle.get_matches(q, t).tobytes()
 
 
-@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (5, 1), (1, 2), (3, 3), (257, 255), (256, 513)])
+# sizes around the matcher's tiles: 32 train rows per MFMA tile, 64 queries per wave / 256 per workgroup, 128-row split
+# chunks, 8192 train rows per 13-bit key range (k_match.hip)
+@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (5, 1), (1, 2), (3, 3), (257, 255), (256, 513), (64, 31), (64, 32),
+                                   (65, 33), (63, 64), (129, 65), (33, 127), (33, 129), (10, 8191), (10, 8192),
+                                   (70, 8193), (300, 20000)])
 def test_matcher_edge_sizes(ctx640, oracle, nq, nt):
     from vision_slam_frontend_amd import synth
     q = synth.random_descriptors(max(nq, 1), seed=10)[:nq]
@@ -138,6 +142,17 @@ def test_matcher_edge_sizes(ctx640, oracle, nq, nt):
     np.testing.assert_array_equal(gi, ri)
     np.testing.assert_array_equal(gd, rd)
     assert ctx640.get_matches(q, t).tobytes() == oracle.get_matches(q, t).tobytes()
+
+
+def test_knn2_ties_across_key_ranges(ctx640, oracle):
+    """Equal distances in different 32-row tiles, split chunks and 8192-row key ranges resolve to the lower train index."""
+    from vision_slam_frontend_amd import synth
+    q = synth.adversarial_descriptors(300, seed=3)
+    t = np.concatenate([synth.adversarial_descriptors(4500, seed=4)] * 4)[:17000]  # every train row occurs 3-4 times
+    gi, gd = ctx640.knn2_hamming(q, t)
+    ri, rd = oracle.knn2_hamming(q, t)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gd, rd)
 
 
 def test_fast_detect_standalone(ctx640, oracle, stereo640):
