@@ -372,11 +372,130 @@ __device__ __forceinline__ void wave_hoare_pass(T* A, int lo, int hi, FL fl, FR 
     wave_hoare_pass_e<4>(A, lo, hi, fl, fr, totalR, cut, wtab);
 }
 
+// ---- register-resident passes for ranges of <= 64 elements (one per lane) ----
+// A selection spends most of its passes on the short ranges at its end, where a pass through LDS is a chain of seven
+// round trips for one wave.  Here the range lives in one VGPR (pair) per lane across all remaining passes: the median
+// of three comes from v_readlane, partners are found by pushing lane ids to their rank (ds_permute) and elements move
+// with ds_bpermute -- three crossbar hops per pass, no memory round trip.
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint2 lane_get(const uint2& v, int l) {
+  return make_uint2((uint32_t)__builtin_amdgcn_readlane((int)v.x, l), (uint32_t)__builtin_amdgcn_readlane((int)v.y, l));
+}
+__device__ __forceinline__ uint32_t lane_pull(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+}
+__device__ __forceinline__ uint2 lane_pull(const uint2& v, int src) {
+  return make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v.x),
+                    (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v.y));
+}
+
+// One Hoare pass on the lanes flagged l (left-stoppers) / r (right-stoppers); returns the new element of this lane.
+template <class T>
+__device__ __forceinline__ T reg_hoare_pass(const T& x, bool l, bool r, int& totalR, int& cut_lane) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull, le = (2ull << lane) - 1ull;
+  const unsigned long long mL = __ballot(l), mR = __ballot(r);
+  const int totalL = __popcll(mL);
+  totalR = __popcll(mR);
+  const int k = __popcll(mL & lt) + 1;                // 1-based rank from the left (when a left-stopper)
+  const int r_le = __popcll(mR & le);                 // right-stoppers at <= lane
+  const int rr = totalR - r_le + 1;                   // 1-based rank from the right (when a right-stopper)
+  const bool part_l = l && (totalR - r_le >= k);
+  const int K = __popcll(__ballot(part_l));
+  const bool part_r = r && rr <= K;
+  // rank -> lane tables, one entry per lane (entries beyond the stopper counts are never read)
+  const int l_of_rank = __builtin_amdgcn_ds_permute((l ? k - 1 : 63) << 2, lane);
+  const int r_of_rank = __builtin_amdgcn_ds_permute((r ? rr - 1 : 63) << 2, lane);
+  const int pl = __builtin_amdgcn_ds_bpermute((k - 1) << 2, r_of_rank);    // partner of a left-stopper of rank k
+  const int pr = __builtin_amdgcn_ds_bpermute((rr - 1) << 2, l_of_rank);   // partner of a right-stopper of rank rr
+  const int src = part_l ? pl : part_r ? pr : lane;
+  const T y = lane_pull(x, src);
+  const unsigned long long ha = __ballot(l && k == K + 1), hb = __ballot(r && rr == K);
+  const int aK1 = ha ? (int)__builtin_ctzll(ha) : 0x7FFFFFFF;
+  const int bK = (hb && K > 0) ? (int)__builtin_ctzll(hb) : 0x7FFFFFFF;
+  cut_lane = (K < totalL && (K == 0 || aK1 < bK)) ? aK1 : bK;
+  return y;
+}
+
+// std::__introselect continued from (first, last, depth), last - first <= 64, A in LDS; runs to the end (including the
+// final insertion sort).  Returns false (nothing done) when the depth limit is hit: the caller's LDS path handles that.
+template <class T, class Greater>
+__device__ __forceinline__ bool reg_introselect(T* A, int first, int last, int nth, int depth, Greater greater) {
+  const int lane = threadIdx.x & 63;
+  const int base = first, m0 = last - first;
+  T x = A[base + min(lane, m0 - 1)];
+  while (last - first > 3) {
+    if (depth == 0) {  // heap select on the array itself
+      if (lane < m0) A[base + lane] = x;
+      wave_fence();
+      if (lane == 0) {
+        vsf_sel::heap_select_(A, first, nth + 1, last, greater);
+        vsf_sel::swap_(A[first], A[nth]);
+      }
+      wave_fence();
+      return true;
+    }
+    --depth;
+    const int lf = first - base, la = lf + 1, lb = lf + (last - first) / 2, lc = last - 1 - base;
+    const T vf = lane_get(x, lf), va = lane_get(x, la), vb = lane_get(x, lb), vc = lane_get(x, lc);
+    int lm;
+    if (greater(va, vb))
+      lm = greater(vb, vc) ? lb : greater(va, vc) ? lc : la;
+    else
+      lm = greater(va, vc) ? la : greater(vb, vc) ? lc : lb;
+    const T pivot = lm == la ? va : lm == lb ? vb : vc;
+    if (lane == lf) x = pivot;
+    if (lane == lm) x = vf;
+    const bool in = lane > lf && lane <= lc;
+    int total_r, cut_lane;
+    x = reg_hoare_pass(x, in && !greater(x, pivot), in && !greater(pivot, x), total_r, cut_lane);
+    const int cut = base + cut_lane;
+    if (cut <= nth)
+      first = cut;
+    else
+      last = cut;
+  }
+  // std::__insertion_sort on the (<= 3) remaining elements, on uniform copies
+  const int n3 = last - first, l0 = first - base;
+  if (n3 >= 2) {
+    T t0 = lane_get(x, l0), t1 = lane_get(x, l0 + 1);
+    if (greater(t1, t0)) {
+      const T s = t0;
+      t0 = t1;
+      t1 = s;
+    }
+    T t2 = t1;
+    if (n3 == 3) {
+      const T v = lane_get(x, l0 + 2);
+      if (greater(v, t0)) {
+        t2 = t1;
+        t1 = t0;
+        t0 = v;
+      } else if (greater(v, t1)) {
+        t2 = t1;
+        t1 = v;
+      } else {
+        t2 = v;
+      }
+    }
+    if (lane == l0) x = t0;
+    if (lane == l0 + 1) x = t1;
+    if (n3 == 3 && lane == l0 + 2) x = t2;
+  }
+  if (lane < m0) A[base + lane] = x;
+  wave_fence();
+  return true;
+}
+
 // std::__introselect continued from (first, last, depth) on a range of <= kWaveCutoff elements, A in LDS.
 template <class T, class Greater>
 __device__ void wave_introselect(T* A, int first, int last, int nth, int depth, Greater greater, uint16_t* wtab) {
   const int lane = threadIdx.x & 63;
   while (last - first > 3) {
+    if (last - first <= 64) {  // the rest of the selection runs in registers
+      reg_introselect(A, first, last, nth, depth, greater);
+      return;
+    }
     if (depth == 0) {
       if (lane == 0) {
         vsf_sel::heap_select_(A, first, nth + 1, last, greater);
