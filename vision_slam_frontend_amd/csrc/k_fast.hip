@@ -350,9 +350,8 @@ __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restri
   const VsfLevel L = levels[0];
   const uint16_t* rs_img = rowstart + (size_t)image * nunits * VSF_FAST_RS_STRIDE;
   const uint32_t* cand_img = cand + (size_t)image * cand_entries;
-  const int n = vsf_level_candidate_count<256>(L, rs_img, lds4);
   vsf_keypoint* o = out + (size_t)image * max_keypoints;
-  vsf_gather_level<256>(L, cand_img, rs_img, cellpre, 2048, rs_lds, 64, lds4, [&](int dst, uint32_t cd) {
+  const int n = vsf_gather_level<256>(L, cand_img, rs_img, cellpre, 2048, rs_lds, 64, lds4, [](int) {}, [&](int dst, uint32_t cd) {
     if (dst < max_keypoints) {
       vsf_keypoint kp;
       kp.x = (float)VSF_CAND_X(cd);

@@ -742,7 +742,6 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
 
   // ---- gather: merge the FAST units' segments into the level's raster order (vsf_gather.h) ----
   const uint16_t* rs_img = a.rowstart + (size_t)image * a.nunits * VSF_FAST_RS_STRIDE;
-  const int n = vsf_level_candidate_count<NT>(L, rs_img, lds4);
   uint32_t* gscratch = a.scratch + (size_t)image * 6 * a.cand_entries;
   uint32_t* gA = gscratch + L.cand_offset;
   uint2* gB = reinterpret_cast<uint2*>(gscratch + a.cand_entries) + L.cand_offset;
@@ -770,16 +769,16 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   PassMem<uint16_t> pm_lds2 = pm_lds;
   PassMem<uint32_t> pm_hbm2 = pm_hbm;
   pm_lds2.wbuf = pm_hbm2.wbuf = wbuf2;
-  const bool a_in_lds = n <= ENTRIES;
-  {
-    const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
-    if (a_in_lds)
-      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, rs_lds, kRsUnits, lds4,
-                           [&](int dst, uint32_t cd) { sA[dst] = cd; });
-    else
-      vsf_gather_level<NT>(L, cand_img, rs_img, cellpre, kCellCap, rs_lds, kRsUnits, lds4,
-                           [&](int dst, uint32_t cd) { gA[dst] = cd; });
-  }
+  bool a_in_lds = true;
+  const uint32_t* cand_img = a.cand + (size_t)image * a.cand_entries;
+  const int n = vsf_gather_level<NT>(
+      L, cand_img, rs_img, cellpre, kCellCap, rs_lds, kRsUnits, lds4, [&](int total) { a_in_lds = total <= ENTRIES; },
+      [&](int dst, uint32_t cd) {
+        if (a_in_lds)  // (workgroup-uniform)
+          sA[dst] = cd;
+        else
+          gA[dst] = cd;
+      });
   __syncthreads();
 
   // ---- K3: retainBest(2 * n_l) on the FAST score ----

@@ -49,23 +49,36 @@ __device__ __forceinline__ int vsf_level_candidate_count(const VsfLevel& L, cons
   return total;
 }
 
-// Merges the level's unit segments into raster order; store(dst_index, entry) receives every candidate once.
+// Merges the level's unit segments into raster order; store(dst_index, entry) receives every candidate once, after
+// on_total(n) has told every thread the level's candidate count (returned as well).
 // cellpre: LDS int array with cellcap >= VSF_FAST_STRIP_ROWS * nbands + 1 entries; rs_lds: LDS copy of the row-start
 // tables of the units of one chunk, room for rs_units >= nbands tables.  All NT threads call.
 // The level is walked in chunks of whole strips.  Per chunk the units' row-start tables come into LDS with one
 // coalesced read, the per-cell counts and their prefix sums are formed from LDS, and the segments are copied one unit
 // per wave: the only dependent global read left in front of the copy is the segment itself.
-template <int NT, class Store>
-__device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32_t* __restrict__ cand_img,
-                                                 const uint16_t* __restrict__ rs_img, int* cellpre, int cellcap,
-                                                 uint16_t* rs_lds, int rs_units, int* lds4, Store store) {
+template <int NT, class OnTotal, class Store>
+__device__ __forceinline__ int vsf_gather_level(const VsfLevel& L, const uint32_t* __restrict__ cand_img,
+                                                const uint16_t* __restrict__ rs_img, int* cellpre, int cellcap,
+                                                uint16_t* rs_lds, int rs_units, int* lds4, OnTotal on_total,
+                                                Store store) {
   constexpr int SR = VSF_FAST_STRIP_ROWS, RS = VSF_FAST_RS_STRIDE;
   const int tid = threadIdx.x;
   const int nrows = L.y_hi - L.y_lo, nb = L.nbands;
-  if (nrows <= 0 || nb <= 0) return;
+  if (nrows <= 0 || nb <= 0) {
+    on_total(0);
+    return 0;
+  }
   int strips_per_chunk = min(((cellcap - 1) / nb) / SR, rs_units / nb);
   if (strips_per_chunk < 1) strips_per_chunk = 1;  // (capacities are sized so that this cannot happen)
   const int rows_per_chunk = strips_per_chunk * SR;
+  // A level that fits one chunk (all but the widest) learns its count from the chunk's own prefix sums; otherwise the
+  // count takes one more pass over the row-start tables in memory.
+  const bool one_chunk = rows_per_chunk >= nrows;
+  int n_level = 0;
+  if (!one_chunk) {
+    n_level = vsf_level_candidate_count<NT>(L, rs_img, lds4);
+    on_total(n_level);
+  }
   int base = 0;
   for (int row0 = 0; row0 < nrows; row0 += rows_per_chunk) {
     const int nr = min(rows_per_chunk, nrows - row0);
@@ -98,6 +111,10 @@ __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32
       cellpre[c] = run;
       run += v;
     }
+    if (one_chunk) {
+      n_level = total;
+      on_total(total);
+    }
     __syncthreads();
     // one wave per unit (round robin)
     for (int u = s0 * nb + (tid >> 6); u < s1 * nb; u += NT / 64) {
@@ -125,6 +142,7 @@ __device__ __forceinline__ void vsf_gather_level(const VsfLevel& L, const uint32
     base += total;
     __syncthreads();
   }
+  return n_level;
 }
 
 #endif  // VSF_GATHER_H_
