@@ -78,7 +78,8 @@ __device__ __forceinline__ uint32_t round_fix16(uint32_t n, uint32_t tie_up) {
 
 __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
   const int lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (readfirstlane: the unit and everything derived from it -- level, strip, row addresses -- stays on the scalar unit)
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (unit >= a.nunits) return;  // wave-uniform
   const uint32_t ud = a.units[unit];
   const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip = (int)(ud & 0xFFFF);
@@ -120,6 +121,12 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
       bsel |= (uint32_t)sidx << (8 * j);
     }
   }
+  const uint32_t tile_col = ((uint32_t)(max(c0, 0) >> 5) << 7) + (uint32_t)(max(c0, 0) & 31);
+  // buffer resources over the source level and the blurred level (raw buffers, 32-bit data format; reads past the end
+  // return 0, writes past the end are dropped)
+  const __amdgpu_buffer_rsrc_t src_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, pitch * L.h, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, L.pitch * ((L.h + 7) & ~7), 0x00020000);
   const bool all_interior = __all(interior);
   const bool writer = lane >= 1 && lane <= 62 && c0 < w;
   const int ys = strip * kStripRows, ye = min(ys + kStripRows, h);
@@ -127,10 +134,11 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
                  t2 = c0 + 2 < L.blur_vec_end ? 0u : 1u, t3 = c0 + 3 < L.blur_vec_end ? 0u : 1u;
 
   auto fetch = [&](int y) -> Px4 {
-    const uint8_t* rowp = src + (size_t)reflect101(y, h) * pitch;
-    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rowp + a0);
+    // buffer load: lane offset in a VGPR, row offset in an SGPR -- no vector address arithmetic per row
+    const uint32_t row_off = (uint32_t)reflect101(y, h) * (uint32_t)pitch;  // scalar
+    const uint32_t d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a0, row_off, 0);
     if (all_interior) return widen(d0);  // wave-uniform
-    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rowp + a1);
+    const uint32_t d1 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a1, row_off, 0);
     return widen(__builtin_amdgcn_perm(d1, d0, bsel));
   };
   // One output row: column pass over the 7-row window (r0 = row y-3 ... r6 = row y+3), then the row pass.
@@ -149,7 +157,9 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
                      v3 = round_fix16(n3, t3);
       // byte 2 of each value -> bytes 0..3
       const uint32_t lo2 = __builtin_amdgcn_perm(v1, v0, 0x0C0C0602u), hi2 = __builtin_amdgcn_perm(v3, v2, 0x06020C0Cu);
-      *reinterpret_cast<uint32_t*>(dst + VSF_BLUR_TILE_OFFSET(L.pitch, c0, y)) = lo2 | hi2;  // (c0 % 4 == 0)
+      // tiled store (VSF_BLUR_TILE_OFFSET): the row part is scalar, the lane part loop-invariant (c0 % 4 == 0)
+      const uint32_t drow = (uint32_t)(y >> 2) * (uint32_t)(L.pitch * 4) + (uint32_t)((y & 3) << 5);
+      __builtin_amdgcn_raw_buffer_store_b32(lo2 | hi2, dst_rsrc, tile_col, drow, 0);
     }
   };
 
