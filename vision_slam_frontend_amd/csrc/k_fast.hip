@@ -171,7 +171,8 @@ __device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
 template <bool HALF>
 __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, int nwork) {
   const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (readfirstlane: the work item and everything derived from it -- level, band, strip, row addresses -- is scalar)
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (item >= nwork) return;  // wave-uniform
   const uint32_t ud = a.units[work0 + item];
   const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip0 = (int)(ud & 0x7FFF);
@@ -217,10 +218,17 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
   const unsigned long long hmask = HALF ? (half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull) : ~0ull;
   const unsigned long long lt = ((1ull << lane) - 1ull) & hmask;  // lanes of my cell before me
 
+  // buffer loads: a lane's column offset sits in a VGPR, the row offset in an SGPR (per lane when HALF); reads outside
+  // the level return 0
+  const __amdgpu_buffer_rsrc_t src_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, pitch * hrow, 0x00020000);
   auto load_row = [&](int q) -> Row3 {  // row ys - 1 + q of this lane's cell
     Row3 r;
     const int yc = min(max(ys - 1 + q, 0), hrow - 1);
-    r.d = loadable ? *reinterpret_cast<const uint32_t*>(src + (size_t)yc * pitch + c0) : 0u;
+    if (HALF)
+      r.d = loadable ? __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, (uint32_t)(yc * pitch + c0), 0u, 0) : 0u;
+    else
+      r.d = loadable ? __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, (uint32_t)c0, (uint32_t)(yc * pitch), 0) : 0u;
     r.p = wave_shr1(r.d);
     r.n = wave_shl1(r.d);
     return r;
