@@ -137,7 +137,7 @@ __device__ __forceinline__ int select64(unsigned long long x, int r) {
 // On return (all threads, after a barrier) c.st[3] = K, c.st[5] / c.st[6] = stopper totals, c.st[4] = cut
 // (__unguarded_partition's return value when at least one stopper of each kind exists).
 template <int NT, class T, class FL, class FR, class PM>
-__device__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, const PM& s) {
+__device__ __forceinline__ void hoare_pass(T* A, int lo, int hi, FL fl, FR fr, const PM& s) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = hi - lo;
   const int nw = (m + 63) >> 6;
@@ -489,7 +489,7 @@ __device__ __forceinline__ bool reg_introselect(T* A, int first, int last, int n
 
 // std::__introselect continued from (first, last, depth) on a range of <= kWaveCutoff elements, A in LDS.
 template <class T, class Greater>
-__device__ void wave_introselect(T* A, int first, int last, int nth, int depth, Greater greater, uint16_t* wtab) {
+__device__ __forceinline__ void wave_introselect(T* A, int first, int last, int nth, int depth, Greater greater, uint16_t* wtab) {
   const int lane = threadIdx.x & 63;
   while (last - first > 3) {
     if (last - first <= 64) {  // the rest of the selection runs in registers
@@ -550,21 +550,40 @@ __device__ __forceinline__ void with_lds_range(T* A, int lo, int hi, uint8_t* wb
   }
 }
 
-// std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
+// Where an HBM-resident selection continues once its range fits: an LDS array of `cap` elements and the pass scratch
+// that goes with it (buf == nullptr: stay in HBM).
+template <class T>
+struct LdsStage {
+  T* buf;
+  int cap;
+  const PassMem<uint16_t>* pm;
+};
+
+// std::__introselect from the state (first, last, depth) kept in pm.c->st[0..2] -- all threads call this.
 template <int NT, class T, class Greater, class PM>
-__device__ void par_nth_element(T* A, int n, int nth, Greater greater, const PM& pm) {
+__device__ __forceinline__ void par_introselect(T* A, int nth, Greater greater, const PM& pm, const LdsStage<T>& stage) {
   PassCtl& s = *pm.c;
-  if (n == 0 || nth == n) return;
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    s.st[0] = 0;
-    s.st[1] = n;
-    s.st[2] = vsf_sel::lg_(n) * 2;
-  }
-  __syncthreads();
   while (true) {
     const int first = s.st[0], last = s.st[1], depth = s.st[2];
     if (last - first <= kWaveCutoff || depth == 0 || last - first - 1 > pm.maxw * 64) break;
+    if constexpr (sizeof(*pm.Lp) != 2) {
+      // An HBM-resident pass pays a memory round trip in each of its phases (~2.5x an LDS pass on the same range), and
+      // the range shrinks to a fraction after the first pass or two: the rest of the selection runs on an LDS copy.
+      if (stage.buf && last - first <= stage.cap) {
+        __syncthreads();
+        for (int i = tid; i < last - first; i += NT) stage.buf[i] = A[first + i];
+        if (tid == 0) {
+          s.st[0] = 0;
+          s.st[1] = last - first;
+        }
+        __syncthreads();
+        par_introselect<NT>(stage.buf, nth - first, greater, *stage.pm, LdsStage<T>{nullptr, 0, nullptr});
+        for (int i = tid; i < last - first; i += NT) A[first + i] = stage.buf[i];
+        __syncthreads();
+        return;
+      }
+    }
     if (tid == 0) {
       const int mid = first + (last - first) / 2;
       vsf_sel::move_median_to_first_(A, first, first + 1, mid, last - 1, greater);
@@ -596,9 +615,23 @@ __device__ void par_nth_element(T* A, int n, int nth, Greater greater, const PM&
   __syncthreads();
 }
 
+// std::nth_element(A, A + nth, A + n, greater) -- all threads of the workgroup call this.
+template <int NT, class T, class Greater, class PM>
+__device__ __forceinline__ void par_nth_element(T* A, int n, int nth, Greater greater, const PM& pm, const LdsStage<T>& stage) {
+  PassCtl& s = *pm.c;
+  if (n == 0 || nth == n) return;
+  if (threadIdx.x == 0) {
+    s.st[0] = 0;
+    s.st[1] = n;
+    s.st[2] = vsf_sel::lg_(n) * 2;
+  }
+  __syncthreads();
+  par_introselect<NT>(A, nth, greater, pm, stage);
+}
+
 // std::partition(A + lo, A + hi, pred); returns the split point -- all threads call this.
 template <int NT, class T, class Pred, class PM>
-__device__ int par_partition(T* A, int lo, int hi, Pred pred, const PM& pm) {
+__device__ __forceinline__ int par_partition(T* A, int lo, int hi, Pred pred, const PM& pm) {
   PassCtl& s = *pm.c;
   const int tid = threadIdx.x;
   if (hi - lo <= kWaveCutoff || hi - lo > pm.maxw * 64) {
@@ -630,7 +663,8 @@ __device__ int par_partition(T* A, int lo, int hi, Pred pred, const PM& pm) {
 
 // cv::KeyPointsFilter::retainBest(A[0..n), n_points); returns the new size -- all threads call this.
 template <int NT, class T, class Greater, class GreaterEq, class PM>
-__device__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, const PM& s) {
+__device__ __forceinline__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, const PM& s,
+                               const LdsStage<T>& stage = LdsStage<T>{nullptr, 0, nullptr}) {
   if (n_points >= 0 && n > n_points) {
     if (n_points == 0) return 0;
     if (n <= kWaveCutoff) {  // short array: wave 0 runs selection and partition back to back, one barrier at the end
@@ -652,7 +686,7 @@ __device__ int par_retain_best(T* A, int n, int n_points, Greater greater, Great
       __syncthreads();
       return r;
     }
-    par_nth_element<NT>(A, n, n_points, greater, s);
+    par_nth_element<NT>(A, n, n_points, greater, s, stage);
     const T ambiguous = A[n_points - 1];
     return par_partition<NT>(
         A, n_points, n, [&](const T& x) { return ge(x, ambiguous); }, s);
@@ -786,7 +820,8 @@ __global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
   if (a_in_lds)
     m1 = par_retain_best<NT>(sA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), pm_lds);
   else
-    m1 = par_retain_best<NT>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), pm_hbm);
+    m1 = par_retain_best<NT>(gA, n, 2 * L.nfeatures, ScoreGreater(), ScoreGe(), pm_hbm,
+                             LdsStage<uint32_t>{sA, ENTRIES, &pm_lds});  // (sA is idle while the array lives in HBM)
   __syncthreads();
 
   // ---- K4: Harris responses (one lane per keypoint) ----
