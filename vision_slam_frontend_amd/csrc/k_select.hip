@@ -939,15 +939,17 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
     if (area < 20000) break;
     ++ntiny0;
   }
-  // Large and mid levels share one launch of 256-thread workgroups with a 5120-entry LDS array (50 KB: three per
-  // CU): levels with more candidates run their passes on HBM-resident arrays, which costs a workgroup ~1.3x the time
-  // of the LDS path but beats one 1024-thread / 134 KB workgroup per CU (1.13 -> 0.81 ms per 128-frame step).
+  // Large and mid levels share one launch of 256-thread workgroups with a 4096-entry LDS array (39 KB and 128 VGPRs:
+  // FOUR workgroups per CU -- the kernel is a chain of short dependent phases, so resident workgroups are throughput).
+  // Levels with more candidates start on HBM-resident arrays and move to the LDS array once the selection range fits
+  // (par_introselect); that beats one 1024-thread / 134 KB workgroup per CU (1.13 ms) and 5120 entries at three per CU
+  // (0.58 ms) with 0.53 ms per 128-frame step.
   a.nimages = im.n;
   const int n8 = (im.n + 7) / 8 * 8;
   if (ntiny0 > 0) {
     a.level0 = 0;
     a.nlv = ntiny0;
-    hipLaunchKernelGGL((orb_select_kernel<256, 5120, 512, 128>), dim3(a.nlv * n8), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<256, 4096, 512, 64>), dim3(a.nlv * n8), dim3(256), 0, s, a);
   }
   if (ntiny0 < g.nlevels) {
     a.level0 = ntiny0;
