@@ -744,7 +744,7 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
 
 // ENTRIES: stage-1 candidates kept in LDS; STAGE2: stage-2 pairs kept in LDS; MAXW: mask words of a parallel pass.
 template <int NT, int ENTRIES, int STAGE2, int MAXW>
-__global__ __launch_bounds__(NT) void orb_select_kernel(SelectArgs a) {
+__global__ __launch_bounds__(NT, NT == 256 ? 5 : 1) void orb_select_kernel(SelectArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t sA[ENTRIES];
   __shared__ uint16_t sPos[2 * ENTRIES];  // rank -> position tables of the LDS-resident passes
   __shared__ __attribute__((aligned(16))) uint2 sB[STAGE2];
@@ -939,17 +939,17 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
     if (area < 20000) break;
     ++ntiny0;
   }
-  // Large and mid levels share one launch of 256-thread workgroups with a 4096-entry LDS array (39 KB and 128 VGPRs:
-  // FOUR workgroups per CU -- the kernel is a chain of short dependent phases, so resident workgroups are throughput).
-  // Levels with more candidates start on HBM-resident arrays and move to the LDS array once the selection range fits
-  // (par_introselect); that beats one 1024-thread / 134 KB workgroup per CU (1.13 ms) and 5120 entries at three per CU
-  // (0.58 ms) with 0.53 ms per 128-frame step.
+  // Large and mid levels share one launch of 256-thread workgroups with a 3072-entry LDS array (30 KB, and 96 VGPRs by
+  // launch bounds: FIVE workgroups per CU -- the kernel is a chain of short dependent phases, so resident workgroups
+  // are throughput).  Levels with more candidates start on HBM-resident arrays and move to the LDS array once the
+  // selection range fits (par_introselect).  Per 128-frame step: one 1024-thread / 134 KB workgroup per CU 1.13 ms;
+  // 5120 entries, three per CU 0.58 ms; 4096, four per CU 0.53 ms; 3072, five per CU 0.50 ms; 2560, six per CU 0.50 ms.
   a.nimages = im.n;
   const int n8 = (im.n + 7) / 8 * 8;
   if (ntiny0 > 0) {
     a.level0 = 0;
     a.nlv = ntiny0;
-    hipLaunchKernelGGL((orb_select_kernel<256, 4096, 512, 64>), dim3(a.nlv * n8), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((orb_select_kernel<256, 3072, 512, 64>), dim3(a.nlv * n8), dim3(256), 0, s, a);
   }
   if (ntiny0 < g.nlevels) {
     a.level0 = ntiny0;
