@@ -105,6 +105,23 @@ def test_half_batches_equal_full_batch(capi):
         np.testing.assert_array_equal(a, b, err_msg="pipeline " + name)
 
 
+@pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 96), (320, 240, 500, 100)])
+def test_large_batch_equals_small_batches(capi, oracle, w, h, nf, B):
+    """A batch that fills the CUs (>= 192 images on an MI355X) builds the one-band levels of its pyramids with the
+    image-major LDS kernel (k_pyramid.hip pyramid_image_kernel) instead of per-level launches: identical outputs, and the
+    oracle agrees on the first and the last frame."""
+    from vision_slam_frontend_amd import synth
+    frames = synth.bench_batch(B, w, h, seed=synth.BASE_SEED + 21, n_scenes=4)
+    big = _run_stereo_batch(capi, frames, nf)
+    for lo in (0, B // 2, B - 2):
+        small = _run_stereo_batch(capi, frames[lo:lo + 2], nf)
+        for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), big, small):
+            sl = slice(2 * lo, 2 * lo + 4) if name in ("kp", "desc", "counts") else slice(lo, lo + 2)
+            np.testing.assert_array_equal(a[sl], b, err_msg="%s of frames %d..%d" % (name, lo, lo + 1))
+    for f in (0, B - 1):
+        _check_frame(oracle, frames, f, nf, *big)
+
+
 def test_config3_1080p_8000kp(capi, oracle):
     """configs[2]: 1920x1080, 8000 keypoints per image (wide levels: 8 FAST bands, HBM-scratch selection)."""
     from vision_slam_frontend_amd import synth

@@ -141,13 +141,24 @@ __global__ __launch_bounds__(256) void resize_march_kernel(ResizeArgs a) {
 // strip's R output rows touch at most R + 2 consecutive source rows, so each source row is loaded and pushed through
 // the horizontal pass ONCE (R + 2 row passes instead of 2 R) and an output row picks its two entries with a
 // wave-uniform branch.  The kernel is VALU-bound (two pyramid chains overlap), so instruction count is time.
+// The strip computation in three steps so that a caller can keep one band's x taps across strips and have the next
+// strip's source rows in flight while the current one is computed (pyramid_image_kernel).
+struct StripX {      // per (level, band, lane): x taps as byte selectors + weight pairs, source window, output column
+  uint32_t s0, s1, s2, s3, q0, q1, q2, q3, base;
+  int x4;
+  bool active;
+};
 template <int R>
-__global__ __launch_bounds__(256) void resize_strip_kernel(ResizeArgs a) {
+struct StripRows {   // per strip: the R + 2 source-row windows and the lane-distributed y taps
+  U8B v[R + 2];
+  uint32_t ty_i0, ty_wts;
+};
+
+__device__ __forceinline__ StripX strip_setup(const ResizeArgs& a, int band) {
   const int lane = threadIdx.x & 63;
-  const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), band = blockIdx.z;
-  if (strip >= a.nstrips) return;  // wave-uniform
-  const int x4 = band * 256 + lane * 4;
-  const bool active = x4 < a.dw;
+  StripX c;
+  c.x4 = band * 256 + lane * 4;
+  c.active = c.x4 < a.dw;
   auto xtap = [&](int dx) -> VsfTap {
     float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
     int sx = (int)floorf(fx);
@@ -161,49 +172,76 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(ResizeArgs a) {
     t.c1 = (int16_t)__float2int_rn(fx * 2048);
     return t;
   };
-  const VsfTap t0 = xtap(min(x4 + 0, a.dw - 1)), t1 = xtap(min(x4 + 1, a.dw - 1)), t2 = xtap(min(x4 + 2, a.dw - 1)),
-               t3 = xtap(min(x4 + 3, a.dw - 1));
-  const uint32_t base = (uint32_t)min((int)t0.i0, a.sw - 8);
+  const VsfTap t0 = xtap(min(c.x4 + 0, a.dw - 1)), t1 = xtap(min(c.x4 + 1, a.dw - 1)),
+               t2 = xtap(min(c.x4 + 2, a.dw - 1)), t3 = xtap(min(c.x4 + 3, a.dw - 1));
+  c.base = (uint32_t)min((int)t0.i0, a.sw - 8);
+  const uint32_t base = c.base;
   auto selector = [&](const VsfTap& t) -> uint32_t {
     return (t.i0 - base) | 0x0C000C00u | ((t.i1 - base) << 16);
   };
   auto weights = [](const VsfTap& t) -> uint32_t { return (uint32_t)(uint16_t)t.c0 | ((uint32_t)(uint16_t)t.c1 << 16); };
-  const uint32_t s0 = selector(t0), s1 = selector(t1), s2 = selector(t2), s3 = selector(t3);
-  const uint32_t q0 = weights(t0), q1 = weights(t1), q2 = weights(t2), q3 = weights(t3);
-  const uint8_t* S = a.src + (size_t)blockIdx.y * a.src_img_stride;
-  uint8_t* D = a.dst + (size_t)blockIdx.y * a.dst_img_stride;
+  c.s0 = selector(t0), c.s1 = selector(t1), c.s2 = selector(t2), c.s3 = selector(t3);
+  c.q0 = weights(t0), c.q1 = weights(t1), c.q2 = weights(t2), c.q3 = weights(t3);
+  return c;
+}
+
+template <int R, bool ALIGNED = false>
+__device__ __forceinline__ void strip_issue_from(const ResizeArgs& a, const StripX& c, const uint8_t* S, int strip,
+                                                 StripRows<R>& o) {  // S = the source level of this image (HBM or LDS)
+  const int lane = threadIdx.x & 63;
   // y taps: lane r evaluates output row ys + r (only row index i0 and the two weights are needed)
   const int ys = strip * R;
-  uint32_t ty_i0, ty_wts;
   {
     const int dy = min(ys + (lane & (R - 1)), a.dh - 1);
     float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
     const int sy = (int)floorf(fy);
     fy -= sy;
-    ty_i0 = (uint32_t)min(max(sy, 0), a.sh - 1);
-    ty_wts = (uint32_t)__float2int_rn((1.f - fy) * 2048) | ((uint32_t)__float2int_rn(fy * 2048) << 16);
+    o.ty_i0 = (uint32_t)min(max(sy, 0), a.sh - 1);
+    o.ty_wts = (uint32_t)__float2int_rn((1.f - fy) * 2048) | ((uint32_t)__float2int_rn(fy * 2048) << 16);
   }
-  const uint32_t first = __builtin_amdgcn_readlane(ty_i0, 0);
-  struct H4 {
-    uint32_t a, b, c, d;
-  };
-  U8B v[R + 2];
+  const uint32_t first = __builtin_amdgcn_readlane(o.ty_i0, 0);
 #pragma unroll
   for (int k = 0; k < R + 2; k++) {
     const uint8_t* row = S + (size_t)(min(first + (uint32_t)k, (uint32_t)(a.sh - 1)) * (uint32_t)a.src_pitch);  // scalar
-    v[k] = *reinterpret_cast<const U8B*>(row + base);
+    if constexpr (ALIGNED) {
+      // LDS source: an unaligned 8-byte read is split by the hardware and stalls the LDS queue; three aligned dwords and
+      // two v_alignbyte give the same window (levels are padded to their 64-byte pitch, so the third dword exists)
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(row + (c.base & ~3u));
+      const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+      o.v[k].lo = __builtin_amdgcn_alignbyte(d1, d0, c.base & 3u);
+      o.v[k].hi = __builtin_amdgcn_alignbyte(d2, d1, c.base & 3u);
+    } else {
+      o.v[k] = *reinterpret_cast<const U8B*>(row + c.base);
+    }
   }
+}
+
+template <int R>
+__device__ __forceinline__ void strip_issue(const ResizeArgs& a, const StripX& c, int image, int strip, StripRows<R>& o) {
+  strip_issue_from<R>(a, c, a.src + (size_t)image * a.src_img_stride, strip, o);
+}
+
+// lcopy != nullptr: the output rows are also written to an LDS image of the level (same pitch as in HBM)
+template <int R>
+__device__ __forceinline__ void strip_finish(const ResizeArgs& a, const StripX& c, int image, int strip,
+                                             const StripRows<R>& in, uint8_t* lcopy = nullptr) {
+  uint8_t* D = a.dst + (size_t)image * a.dst_img_stride;
+  const int ys = strip * R;
+  const uint32_t first = __builtin_amdgcn_readlane(in.ty_i0, 0);
+  struct H4 {
+    uint32_t a, b, c, d;
+  };
   H4 H[R + 2];  // horizontal sums with the low 4 bits cleared (VResizeLinear uses S >> 4)
 #pragma unroll
   for (int k = 0; k < R + 2; k++) {
     auto hsum = [&](uint32_t sel, uint32_t q) -> uint32_t {
-      return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(v[k].hi, v[k].lo, sel)),
+      return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, __builtin_amdgcn_perm(in.v[k].hi, in.v[k].lo, sel)),
                                     __builtin_bit_cast(v2u16, q), 0u, false) & 0xFFFFF0u;
     };
-    H[k].a = hsum(s0, q0);
-    H[k].b = hsum(s1, q1);
-    H[k].c = hsum(s2, q2);
-    H[k].d = hsum(s3, q3);
+    H[k].a = hsum(c.s0, c.q0);
+    H[k].b = hsum(c.s1, c.q1);
+    H[k].c = hsum(c.s2, c.q2);
+    H[k].d = hsum(c.s3, c.q3);
   }
   auto mulhi24 = [](uint32_t x, uint32_t y) -> uint32_t {
     return (uint32_t)(((uint64_t)(x & 0xFFFFFFu) * (uint64_t)(y & 0xFFFFFFu)) >> 32);
@@ -211,9 +249,9 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(ResizeArgs a) {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     if (ys + r >= a.dh) break;  // wave-uniform
-    const uint32_t wts = __builtin_amdgcn_readlane(ty_wts, r);
+    const uint32_t wts = __builtin_amdgcn_readlane(in.ty_wts, r);
     const uint32_t b0 = (wts & 0xFFFFu) << 12, b1 = (wts >> 16) << 12;  // scalar, <= 2^23
-    const bool skip = __builtin_amdgcn_readlane(ty_i0, r) != first + (uint32_t)r;  // then it is first + r + 1
+    const bool skip = __builtin_amdgcn_readlane(in.ty_i0, r) != first + (uint32_t)r;  // then it is first + r + 1
     // ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 per pixel; the four 10-bit sums are shifted as
     // two packed pairs and their low bytes gathered with one v_perm
     auto vrow = [&](const H4& h0, const H4& h1) -> uint32_t {
@@ -224,14 +262,116 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(ResizeArgs a) {
       return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
     };
     uint8_t* drow = D + (size_t)((uint32_t)(ys + r) * (uint32_t)a.dst_pitch);  // scalar
+    uint8_t* lrow = lcopy + (uint32_t)(ys + r) * (uint32_t)a.dst_pitch;
     if (skip) {
       const uint32_t out = vrow(H[r + 1], H[r + 2]);
-      if (active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)x4) = out;
+      if (c.active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)c.x4) = out;
+      if (lcopy && c.active) *reinterpret_cast<uint32_t*>(lrow + (uint32_t)c.x4) = out;
       asm volatile("" ::: "memory");  // keeps the two arms distinct (no select of the eight operands)
     } else {
       const uint32_t out = vrow(H[r], H[r + 1]);
-      if (active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)x4) = out;
+      if (c.active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)c.x4) = out;
+      if (lcopy && c.active) *reinterpret_cast<uint32_t*>(lrow + (uint32_t)c.x4) = out;
     }
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void resize_strip_unit(const ResizeArgs& a, int image, int strip, int band) {
+  const StripX c = strip_setup(a, band);
+  StripRows<R> rows;
+  strip_issue<R>(a, c, image, strip, rows);
+  strip_finish<R>(a, c, image, strip, rows);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void resize_strip_kernel(ResizeArgs a) {
+  const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (strip >= a.nstrips) return;  // wave-uniform
+  resize_strip_unit<R>(a, blockIdx.y, strip, blockIdx.z);
+}
+
+// Image-major tail of the pyramid for large batches: the levels that are one band wide (w <= 256; 26 of the 49 at
+// 640x480) are a chain of ~8 us launch-to-launch latencies when launched one by one.  Here ONE launch walks them: a
+// 1024-thread workgroup per image; each level is produced into HBM (for the other stages) AND into one of two LDS
+// images, from which the next level is read -- between levels there is one workgroup barrier and no memory round trip.
+// 16 waves share a level's strips; the x taps (the same for every wave: one band) are evaluated by wave 0 for the NEXT
+// level while the others finish the current one.  (Walking ALL levels this way was no faster than the two chains of
+// launches: the large levels are throughput-bound and want the whole chip per level.)  Used when the batch fills the
+// CUs (vsf_launch_pyramid); every level of the tail must qualify for the shared-row strips and fit kTailLdsBytes.
+constexpr int kTailLdsBytes = 61440;
+
+struct PyramidArgs {
+  const VsfLevel* levels;
+  const uint8_t* img0;
+  size_t img0_stride;
+  int img0_pitch;
+  uint8_t* pyr;
+  uint32_t pyr_bytes;
+  int l_begin, nlevels;  // levels [l_begin, nlevels), l_begin >= 2
+};
+
+__device__ __forceinline__ ResizeArgs tail_level_args(const PyramidArgs& p, int l) {
+  const VsfLevel L = p.levels[l];
+  const VsfLevel P = p.levels[l - 1];
+  ResizeArgs a;
+  a.src = p.pyr + P.offset;
+  a.src_img_stride = (size_t)p.pyr_bytes;
+  a.src_pitch = P.pitch;
+  a.sw = P.w;
+  a.sh = P.h;
+  a.dst = p.pyr + L.offset;
+  a.dst_img_stride = (size_t)p.pyr_bytes;
+  a.dst_pitch = L.pitch;
+  a.dw = L.w;
+  a.dh = L.h;
+  a.scale_x = __builtin_bit_cast(double, ((unsigned long long)L.rscale_x[1] << 32) | L.rscale_x[0]);
+  a.scale_y = __builtin_bit_cast(double, ((unsigned long long)L.rscale_y[1] << 32) | L.rscale_y[0]);
+  a.nstrips = (L.h + 7) / 8;
+  return a;
+}
+
+__global__ __launch_bounds__(1024) void pyramid_image_kernel(PyramidArgs p) {
+  __shared__ __attribute__((aligned(16))) uint8_t lvl[2][kTailLdsBytes];
+  __shared__ uint32_t xs[2][10][64];  // StripX of a level, per lane (double buffered)
+  const int image = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto publish = [&](int l) {  // wave 0: the level's x taps -> xs[l & 1]
+    const ResizeArgs a = tail_level_args(p, l);
+    const StripX c = strip_setup(a, 0);
+    uint32_t(*o)[64] = xs[l & 1];
+    o[0][lane] = c.s0, o[1][lane] = c.s1, o[2][lane] = c.s2, o[3][lane] = c.s3;
+    o[4][lane] = c.q0, o[5][lane] = c.q1, o[6][lane] = c.q2, o[7][lane] = c.q3;
+    o[8][lane] = c.base;
+  };
+  if (wave == 0) publish(p.l_begin);
+  __syncthreads();
+  for (int l = p.l_begin; l < p.nlevels; l++) {
+    const ResizeArgs a = tail_level_args(p, l);
+    StripX c;
+    {
+      const uint32_t(*o)[64] = xs[l & 1];
+      c.s0 = o[0][lane], c.s1 = o[1][lane], c.s2 = o[2][lane], c.s3 = o[3][lane];
+      c.q0 = o[4][lane], c.q1 = o[5][lane], c.q2 = o[6][lane], c.q3 = o[7][lane];
+      c.base = o[8][lane];
+      c.x4 = lane * 4;
+      c.active = c.x4 < a.dw;
+    }
+    const bool from_lds = l > p.l_begin;
+    uint8_t* lcopy = (l + 1 < p.nlevels) ? lvl[(l - p.l_begin) & 1] : nullptr;
+    const uint8_t* lsrc = lvl[(l - p.l_begin + 1) & 1];
+    const uint8_t* gsrc = a.src + (size_t)image * a.src_img_stride;
+    for (int strip = wave; strip < a.nstrips; strip += 16) {
+      StripRows<8> rows;
+      if (from_lds)  // (workgroup-uniform; two inlined copies so that the LDS one reads with ds_read_b64)
+        strip_issue_from<8, true>(a, c, lsrc, strip, rows);
+      else
+        strip_issue_from<8>(a, c, gsrc, strip, rows);
+      strip_finish<8>(a, c, image, strip, rows, lcopy);
+    }
+    if (wave == 0 && l + 1 < p.nlevels) publish(l + 1);
+    __syncthreads();  // (waits for this wave's LDS writes; the HBM copy is not read in this kernel)
   }
 }
 
@@ -243,6 +383,26 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   // per half of the batch, on two streams, interleaved: the small levels are bound by the latency of a launch's
   // dependency chain (~5 us each), not by throughput, and two chains run in the time of one.
   // (two chains: with four the host's launch rate, ~4 us per launch, becomes the limit: 0.56 -> 0.94 ms measured)
+  // A batch that fills the CUs with one workgroup per image (last round at least three quarters full) hands its
+  // one-band levels to the image-major tail kernel; `side` doubles as the permission (the cross-call prefetch on the aux
+  // stream keeps the plain chain).
+  int l_tail = g.nlevels;
+  if (side && im.n >= 64) {
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 256;
+    }
+    const int rounds = (im.n + ncu - 1) / ncu;
+    if (4 * im.n >= 3 * rounds * ncu) {
+      while (l_tail > 2 && h_levels[l_tail - 1].w <= 256 && h_levels[l_tail - 1].resize_rows >= 8 &&
+             h_levels[l_tail - 1].pitch * h_levels[l_tail - 1].h + 16 <= kTailLdsBytes)
+        --l_tail;
+      if (g.nlevels - l_tail < 4) l_tail = g.nlevels;  // not worth a launch
+    }
+  }
   const int nchains = (side && side->n > 0 && im.n >= 2) ? 2 : 1;
   hipStream_t st[VSF_SIDE_STREAMS + 1] = {s};
   for (int c = 1; c < nchains; c++) st[c] = side->stream[c - 1];
@@ -250,7 +410,7 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
     (void)hipEventRecord(side->fork, s);
     for (int c = 1; c < nchains; c++) (void)hipStreamWaitEvent(st[c], side->fork, 0);
   }
-  for (int l = 1; l < g.nlevels; l++) {
+  for (int l = 1; l < l_tail; l++) {
     const VsfLevel& L = h_levels[l];
     const VsfLevel& P = h_levels[l - 1];
     for (int c = 0; c < nchains; c++) {  // interleaved issue: the chains advance together
@@ -293,5 +453,17 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   for (int c = 1; c < nchains; c++) {
     (void)hipEventRecord(side->join[c - 1], st[c]);
     (void)hipStreamWaitEvent(s, side->join[c - 1], 0);
+  }
+  if (l_tail < g.nlevels) {
+    PyramidArgs p;
+    p.levels = d.levels;
+    p.img0 = im.base;
+    p.img0_stride = im.image_stride;
+    p.img0_pitch = (int)im.row_stride;
+    p.pyr = d.pyr;
+    p.pyr_bytes = g.pyr_bytes;
+    p.l_begin = l_tail;
+    p.nlevels = g.nlevels;
+    hipLaunchKernelGGL(pyramid_image_kernel, dim3(im.n), dim3(1024), 0, s, p);
   }
 }

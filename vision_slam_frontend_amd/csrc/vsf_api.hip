@@ -186,6 +186,11 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
       L.xtab = (uint32_t)G.xt.size();
       L.ytab = (uint32_t)G.yt.size();
       build_taps(P.w, P.h, L.w, L.h, &G.xt, &G.yt);
+      {
+        const double sx = 1. / ((double)L.w / P.w), sy = 1. / ((double)L.h / P.h);
+        memcpy(L.rscale_x, &sx, 8);
+        memcpy(L.rscale_y, &sy, 8);
+      }
       // resize_march_kernel reads one 8-byte source window per lane (4 output pixels): all eight taps must fit.
       if (P.w < 8) return false;
       for (int x4 = 0; x4 < L.w; x4 += 4) {
