@@ -222,13 +222,16 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
   // the level return 0
   const __amdgpu_buffer_rsrc_t src_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, pitch * hrow, 0x00020000);
+  // (a lane outside the row gets an offset beyond the buffer instead of a branch around the load: no divergent control
+  // flow, so the row offset stays in an SGPR)
+  const uint32_t col_off = loadable ? (uint32_t)c0 : 0xFFFFFFF0u;
   auto load_row = [&](int q) -> Row3 {  // row ys - 1 + q of this lane's cell
     Row3 r;
     const int yc = min(max(ys - 1 + q, 0), hrow - 1);
     if (HALF)
-      r.d = loadable ? __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, (uint32_t)(yc * pitch + c0), 0u, 0) : 0u;
+      r.d = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, loadable ? (uint32_t)(yc * pitch + c0) : 0xFFFFFFF0u, 0u, 0);
     else
-      r.d = loadable ? __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, (uint32_t)c0, (uint32_t)(yc * pitch), 0) : 0u;
+      r.d = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, col_off, (uint32_t)(yc * pitch), 0);
     r.p = wave_shr1(r.d);
     r.n = wave_shl1(r.d);
     return r;
