@@ -11,7 +11,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 STAGE_OF = {"fast_march": "fast_score_nms", "blur_march": "gauss_blur7", "orb_orient_describe": "orb_describe",
             "knn2": "hamming_knn2", "ratio_compact": "ratio_compact", "orb_select": "select_harris_angle",
-            "resize_march": "pyramid_resize", "resize_strip": "pyramid_resize"}
+            "resize_march": "pyramid_resize", "resize_strip": "pyramid_resize", "pyramid_image": "pyramid_resize"}
 STEPS = 4  # 1 warm-up + 3 timed steps in each pmc run
 
 
