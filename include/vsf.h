@@ -192,6 +192,16 @@ vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, co
                                          size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
                                          int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs);
 
+/* SURVEY section 8(f) row f4, the part behind cv::imdecode: DecodeImage's cvtColor(COLOR_BayerBG2BGR) +
+ * cvtColor(COLOR_BGR2GRAY) (slam_frontend_main.cc:101-106) for n 8-bit mosaics of width x height resident in HBM, in
+ * one pass.  d_src / d_dst: image i at base + i * image_stride, rows row_stride bytes apart; bases and strides multiples
+ * of 4, dst_row_stride >= (width + 3) & ~3 (the padding bytes of a destination row up to that width are overwritten).
+ * The result is the input of vsf_extract_batch_dev / vsf_stereo_batch_dev (whose own alignment rules apply).
+ * Asynchronous on the context's stream. */
+vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, int n_images, int width, int height,
+                                          size_t src_image_stride, size_t src_row_stride, uint8_t* d_dst,
+                                          size_t dst_image_stride, size_t dst_row_stride);
+
 /* ---------------- introspection for kernel-level parity tests and the roofline model ---------------- */
 
 /* Copies level `level` of image `image` from the last extract to host (blurred: 0 = FAST/Harris/angle input,

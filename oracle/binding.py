@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
         L.vsfo_get_matches_mt.argtypes = [vp, i32, vp, i32, C.c_double, vp, i32, i32]
         L.vsfo_sort_and_trim.argtypes = [vp, i32, f32]
         L.vsfo_remove_ambig_stereo.argtypes = [vp, vp, vp, i32, vp, C.POINTER(f32), vp, vp]
+        L.vsfo_bayer_bg_to_gray.argtypes = [vp, i32, i32, sz, vp, sz]
         _lib = L
     return _lib
 
@@ -244,3 +245,12 @@ def remove_ambig_stereo(left: np.ndarray, right: np.ndarray, matches: np.ndarray
     kept = lib().vsfo_remove_ambig_stereo(_p(left), _p(right), _p(matches), len(matches), _p(F), C.byref(thr),
                                           _p(keep), _p(res))
     return keep[:len(matches)].astype(bool), res[:len(matches)], thr.value, kept
+
+
+def bayer_bg_to_gray(mosaic: np.ndarray) -> np.ndarray:
+    """cvtColor(COLOR_BayerBG2BGR) + cvtColor(COLOR_BGR2GRAY) of an 8-bit mosaic (slam_frontend_main.cc:101-106)."""
+    m = _u8img(mosaic)
+    out = np.zeros_like(m)
+    if lib().vsfo_bayer_bg_to_gray(_p(m), m.shape[1], m.shape[0], m.strides[0], _p(out), out.strides[0]) != 0:
+        raise ValueError("vsfo_bayer_bg_to_gray")
+    return out

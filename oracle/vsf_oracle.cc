@@ -813,4 +813,87 @@ int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* rig
   return kept;
 }
 
+int vsfo_bayer_bg_to_gray(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride) {
+  // demosaicing.cpp Bayer2RGB_<uchar, SIMDBayerInterpolator_8u> with code = CV_BayerBG2BGR, dcn = 3 (the SIMD
+  // interpolator computes the same integers as the scalar loops restated here), into a temporary BGR image ...
+  if (!src || !dst || w < 1 || h < 1) return -1;
+  const int dcn = 3;
+  std::vector<uint8_t> bgr((size_t)w * h * dcn, 0);
+  const int dst_step = w * dcn;
+  const int bayer_step = (int)sstride;
+  int blue = -1, start_with_green = 0;  // BayerBG
+  const int size_h = h - 2, size_w = w - 2;
+  if (size_h > 0) {
+    const uint8_t* bayer0 = src;
+    uint8_t* dst0 = bgr.data() + dst_step + dcn + 1;
+    for (int i = 0; i < size_h; bayer0 += bayer_step, dst0 += dst_step, ++i) {
+      int t0, t1;
+      const uint8_t* bayer = bayer0;
+      uint8_t* d = dst0;
+      const uint8_t* bayer_end = bayer + size_w;
+      if (size_w <= 0) {
+        d[-4] = d[-3] = d[-2] = d[size_w * dcn - 1] = d[size_w * dcn] = d[size_w * dcn + 1] = 0;
+        blue = -blue;  // (the reference `continue`s before the flips; nothing is computed on such images anyway)
+        start_with_green = !start_with_green;
+        continue;
+      }
+      if (start_with_green) {
+        t0 = (bayer[1] + bayer[bayer_step * 2 + 1] + 1) >> 1;
+        t1 = (bayer[bayer_step] + bayer[bayer_step + 2] + 1) >> 1;
+        d[-blue] = (uint8_t)t0;
+        d[0] = bayer[bayer_step + 1];
+        d[blue] = (uint8_t)t1;
+        bayer++;
+        d += dcn;
+      }
+      for (; bayer <= bayer_end - 2; bayer += 2, d += 2 * dcn) {
+        t0 = (bayer[0] + bayer[2] + bayer[bayer_step * 2] + bayer[bayer_step * 2 + 2] + 2) >> 2;
+        t1 = (bayer[1] + bayer[bayer_step] + bayer[bayer_step + 2] + bayer[bayer_step * 2 + 1] + 2) >> 2;
+        d[-blue] = (uint8_t)t0;
+        d[0] = (uint8_t)t1;
+        d[blue] = bayer[bayer_step + 1];
+        t0 = (bayer[2] + bayer[bayer_step * 2 + 2] + 1) >> 1;
+        t1 = (bayer[bayer_step + 1] + bayer[bayer_step + 3] + 1) >> 1;
+        d[3 - blue] = (uint8_t)t0;  // (blue > 0: dst[2] = t0, dst[4] = t1; blue < 0: dst[4] = t0, dst[2] = t1)
+        d[3] = bayer[bayer_step + 2];
+        d[3 + blue] = (uint8_t)t1;
+      }
+      if (bayer < bayer_end) {  // one pixel left at the end of the row
+        t0 = (bayer[0] + bayer[2] + bayer[bayer_step * 2] + bayer[bayer_step * 2 + 2] + 2) >> 2;
+        t1 = (bayer[1] + bayer[bayer_step] + bayer[bayer_step + 2] + bayer[bayer_step * 2 + 1] + 2) >> 2;
+        d[-blue] = (uint8_t)t0;
+        d[0] = (uint8_t)t1;
+        d[blue] = bayer[bayer_step + 1];
+        bayer++;
+        d += dcn;
+      }
+      // the first and the last pixel of the row
+      dst0[-4] = dst0[-1];
+      dst0[-3] = dst0[0];
+      dst0[-2] = dst0[1];
+      dst0[size_w * dcn - 1] = dst0[size_w * dcn - 4];
+      dst0[size_w * dcn] = dst0[size_w * dcn - 3];
+      dst0[size_w * dcn + 1] = dst0[size_w * dcn - 2];
+      blue = -blue;
+      start_with_green = !start_with_green;
+    }
+  }
+  // the first and the last row
+  if (h > 2) {
+    for (int i = 0; i < w * dcn; i++) {
+      bgr[i] = bgr[i + dst_step];
+      bgr[i + (size_t)(h - 1) * dst_step] = bgr[i + (size_t)(h - 2) * dst_step];
+    }
+  } else {
+    for (int i = 0; i < w * dcn; i++) bgr[i] = bgr[i + (size_t)(h - 1) * dst_step] = 0;
+  }
+  // ... then color.cpp RGB2Gray<uchar> (blueIdx = 0): tab-based  (b*B2Y + g*G2Y + r*R2Y + (1 << 13)) >> 14
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const uint8_t* p = &bgr[((size_t)y * w + x) * dcn];
+      dst[(size_t)y * dstride + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+    }
+  return 0;
+}
+
 }  // extern "C"

@@ -125,6 +125,13 @@ int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* rig
                              const vsfo_dmatch* matches, int n, const float F[9], float* threshold_io,
                              uint8_t* keep, float* residual);
 
+/* ---- image ingest (the part after cv::imdecode): slam_frontend_main.cc:101-106 ----
+ * cv::cvtColor(COLOR_BayerBG2BGR) (imgproc/demosaicing.cpp Bayer2RGB_<uchar>: bilinear, the one-pixel frame copied
+ * from its neighbours) followed by cv::cvtColor(COLOR_BGR2GRAY) (color.cpp RGB2Gray<uchar>: (1868 B + 9617 G + 4899 R +
+ * 8192) >> 14).  src: w x h mosaic, dst: w x h gray.  Images narrower or lower than 3 pixels come out zero, as OpenCV's
+ * loops leave them. */
+int vsfo_bayer_bg_to_gray(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,26 @@ def test_randomised_sizes_and_parameters():
     out = subprocess.run([sys.executable, str(root / "tools" / "stress_parity.py"), "10", "5"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "mismatches: 0 of 10" in out.stdout
+
+
+@pytest.mark.parametrize("w,h,n", [(640, 480, 3), (641, 479, 2), (9, 5, 2), (4, 3, 1), (3, 3, 1), (2, 7, 1), (5, 2, 1),
+                                   (1031, 67, 2), (257, 19, 2), (513, 33, 1), (258, 7, 1), (256, 17, 1), (5, 3, 1),
+                                   (6, 40, 1), (7, 3, 1), (8, 3, 1)])
+def test_bayer_bg_to_gray_batch(capi, oracle, w, h, n):
+    """Row f4 (behind imdecode): BayerBG2BGR + BGR2GRAY on the device, bit-exact vs the oracle incl. the copied frame,
+    ragged row ends, padded strides and degenerate sizes."""
+    import torch
+    rng = np.random.default_rng(w * 7 + h)
+    sp, dp = (w + 3) // 4 * 4 + 8, (w + 3) // 4 * 4 + 4  # padded row strides (multiples of 4)
+    src = rng.integers(0, 256, (n, h, sp), dtype=np.uint8)
+    dev = torch.device("cuda", 0)
+    p = capi.default_params(640, 480, max_images=2, nfeatures=500)
+    with capi.Context(p) as ctx:
+        d_src = torch.from_numpy(src).to(dev)
+        d_dst = torch.full((n, h, dp), 255, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.bayer_bg_to_gray_batch_dev(d_src.data_ptr(), n, w, h, h * sp, sp, d_dst.data_ptr(), h * dp, dp)
+        assert ctx.sync() == capi.VSF_OK
+        got = d_dst.cpu().numpy()
+    for i in range(n):
+        np.testing.assert_array_equal(got[i, :, :w], oracle.bayer_bg_to_gray(src[i, :, :w]), err_msg="image %d" % i)

@@ -303,3 +303,47 @@ def test_orb_end_to_end_invariants(oracle, stereo640):
         ix1, iy1 = int(np.rint(x1 * a - y1 * b)), int(np.rint(x1 * b + y1 * a))
         bits.append(int(blurred[cy + iy0, cx + ix0] < blurred[cy + iy1, cx + ix1]))
     assert sum(bit << i for i, bit in enumerate(bits)) == int(desc[j, 0])
+
+
+def _bayer_bg_gray_by_site(m):
+    """Independent formulation of BayerBG2BGR + BGR2GRAY: per-site bilinear formulas on the interior, frame replicated
+    (the oracle follows OpenCV's loop structure instead)."""
+    m = m.astype(np.int32)
+    h, w = m.shape
+    if w < 3 or h < 3:
+        return np.zeros((h, w), np.uint8)
+    U, D, L, R, C = m[:-2, 1:-1], m[2:, 1:-1], m[1:-1, :-2], m[1:-1, 2:], m[1:-1, 1:-1]
+    diag = (m[:-2, :-2] + m[:-2, 2:] + m[2:, :-2] + m[2:, 2:] + 2) >> 2
+    cross, hor, ver = (U + D + L + R + 2) >> 2, (L + R + 1) >> 1, (U + D + 1) >> 1
+    yy, xx = np.mgrid[1:h - 1, 1:w - 1]
+    ex, ey = xx & 1, yy & 1
+    G = np.where(ex == ey, cross, C)
+    B = np.where(ey == 1, np.where(ex == 1, C, hor), np.where(ex == 1, ver, diag))
+    Rr = np.where(ey == 1, np.where(ex == 1, diag, ver), np.where(ex == 1, hor, C))
+    out = np.zeros((h, w), np.int32)
+    out[1:-1, 1:-1] = (1868 * B + 9617 * G + 4899 * Rr + 8192) >> 14
+    out[1:-1, 0], out[1:-1, -1] = out[1:-1, 1], out[1:-1, -2]
+    out[0], out[-1] = out[1], out[-2]
+    return out.astype(np.uint8)
+
+
+def test_bayer_bg_to_gray_known_answers(oracle):
+    # a flat mosaic stays flat: (1868 + 9617 + 4899) * v + 8192 >> 14 == v
+    flat = np.full((6, 8), 77, np.uint8)
+    np.testing.assert_array_equal(oracle.bayer_bg_to_gray(flat), flat)
+    # a single bright blue site at (3, 3): B = 255 there, R / G zero -> gray (1868 * 255 + 8192) >> 14 = 29;
+    # its green neighbours see it as a horizontal / vertical blue average (128), its red diagonal neighbours as 64
+    m = np.zeros((7, 7), np.uint8)
+    m[3, 3] = 255
+    g = oracle.bayer_bg_to_gray(m)
+    assert g[3, 3] == (1868 * 255 + 8192) >> 14
+    assert g[3, 2] == g[3, 4] == g[2, 3] == g[4, 3] == (1868 * 128 + 8192) >> 14
+    assert g[2, 2] == g[4, 4] == (1868 * 64 + 8192) >> 14
+    assert g[0, 0] == g[1, 1] and g[6, 6] == g[5, 5]  # frame copies its inner neighbour
+
+
+@pytest.mark.parametrize("h,w", [(3, 3), (4, 4), (5, 7), (8, 9), (17, 16), (33, 40), (1, 5), (2, 9), (7, 2), (6, 1),
+                                 (480, 640), (101, 203)])
+def test_bayer_bg_to_gray_loop_restatement_equals_site_formulas(oracle, h, w):
+    m = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w), dtype=np.uint8)
+    np.testing.assert_array_equal(oracle.bayer_bg_to_gray(m), _bayer_bg_gray_by_site(m))

@@ -26,7 +26,7 @@ EXPORTS = [
     "vsf_params_default", "vsf_params_set_ratio", "vsf_create", "vsf_destroy", "vsf_status_string",
     "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_pair", "vsf_get_matches_multi", "vsf_extract_batch_dev", "vsf_match_batch_dev",
-    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
+    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_bayer_bg_to_gray_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best",
 ]
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         L.vsf_set_pipeline.argtypes = [vp, i32]
         L.vsf_remove_ambig_stereo_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.c_float, vp, vp, vp, vp, vp, vp]
         L.vsf_feature_matches_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, C.c_float, vp, vp]
+        L.vsf_bayer_bg_to_gray_batch_dev.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, sz, sz]
         L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
         L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
         L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
@@ -283,6 +284,13 @@ class Context:
         self._check(lib().vsf_feature_matches_batch_dev(self._h, _p(d_desc), _p(d_counts), set_stride, _p(d_q_set),
                                                         _p(d_t_set), n_pairs, best_percent, _p(d_pairs), _p(d_npairs)),
                     "vsf_feature_matches_batch_dev")
+
+    def bayer_bg_to_gray_batch_dev(self, d_src: int, n_images: int, width: int, height: int, src_image_stride: int,
+                                   src_row_stride: int, d_dst: int, dst_image_stride: int, dst_row_stride: int):
+        """DecodeImage's BayerBG2BGR + BGR2GRAY (slam_frontend_main.cc:101-106) on mosaics resident in HBM."""
+        self._check(lib().vsf_bayer_bg_to_gray_batch_dev(self._h, _p(d_src), n_images, width, height, src_image_stride,
+                                                         src_row_stride, _p(d_dst), dst_image_stride, dst_row_stride),
+                    "vsf_bayer_bg_to_gray_batch_dev")
 
     def debug_retain_best(self, keys: np.ndarray, n_points: int, use_lds: bool = False, mode: int = 0):
         """retainBest on the GPU; returns (keys, ids) of the survivors in the order the GPU left them."""

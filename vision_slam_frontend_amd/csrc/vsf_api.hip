@@ -1006,6 +1006,24 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
   return VSF_OK;
 }
 
+vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, int n_images, int width, int height,
+                                          size_t src_image_stride, size_t src_row_stride, uint8_t* d_dst,
+                                          size_t dst_image_stride, size_t dst_row_stride) {
+  if (!ctx || !d_src || !d_dst || n_images < 1 || width < 1 || height < 1 || width > 16384 || height > 65535 ||
+      n_images > 65535)
+    return VSF_ERR_INVALID_ARG;
+  if (((uintptr_t)d_src & 3) || ((uintptr_t)d_dst & 3) || (src_image_stride & 3) || (src_row_stride & 3) ||
+      (dst_image_stride & 3) || (dst_row_stride & 3) || src_row_stride < (size_t)width ||
+      dst_row_stride < (size_t)((width + 3) & ~3) || src_row_stride > 0x7FFFFFFF || dst_row_stride > 0x7FFFFFFF ||
+      src_image_stride < src_row_stride * (size_t)height || dst_image_stride < dst_row_stride * (size_t)height)
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  vsf_launch_bayer_bg_gray(d_src, n_images, width, height, src_image_stride, (int)src_row_stride, d_dst,
+                           dst_image_stride, (int)dst_row_stride, ctx->stream);
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
 vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
                                          size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
                                          int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs) {

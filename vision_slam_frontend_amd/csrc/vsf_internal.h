@@ -107,6 +107,8 @@ struct VsfSideStream {
   hipEvent_t fork, join[VSF_SIDE_STREAMS];
   int n;
 };
+void vsf_launch_bayer_bg_gray(const uint8_t* d_src, int n, int w, int h, size_t src_image_stride, int src_pitch,
+                              uint8_t* d_dst, size_t dst_image_stride, int dst_pitch, hipStream_t s);
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                         hipStream_t s, const VsfSideStream* side);
 // threshold: FAST threshold; nms == 0 keeps every corner (standalone FAST only).
