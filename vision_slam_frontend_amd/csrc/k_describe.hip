@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
     const uint2* tab = a.ic_table + (xs & 3) * VSF_IC_ITEMS;
 #pragma unroll
     for (int it = 0; it < 5; it++) {
-      px[it] = *reinterpret_cast<const uint32_t*>(abase + (uint32_t)(item_r[it] * rpitch + item_j4[it]));
+      px[it] = *reinterpret_cast<const uint32_t*>(abase + (__umul24((uint32_t)item_r[it], (uint32_t)rpitch) + (uint32_t)item_j4[it]));  // (24-bit multiply: full rate)
       tw[it] = tab[(uint32_t)(it * 64 + lane)];
     }
   };
@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
     const int ya = cy - 19, tx = (cx - 19) >> 4, tx_max = (pitch >> 4) - 1;  // wave-uniform (16-byte segments)
     auto piece = [&](int prow, int pseg) -> uint4 {
       const int y = ya + prow, t = min(tx + pseg, tx_max);  // (a segment past the row end is never gathered)
-      return *reinterpret_cast<const uint4*>(lvl + VSF_BLUR_TILE_OFFSET(pitch, t << 4, y));
+      // VSF_BLUR_TILE_OFFSET(pitch, 16 t, y) with a full-rate 24-bit multiply
+      const uint32_t off = __umul24((uint32_t)(y >> 2), (uint32_t)(pitch * 4)) + ((uint32_t)(t >> 1) << 7) +
+                           ((uint32_t)(y & 3) << 5) + ((uint32_t)(t & 1) << 4);
+      return *reinterpret_cast<const uint4*>(lvl + off);
     };
     q0 = piece(prow0, pseg0);
     q1 = piece(prow1, pseg1);
