@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
     Row3 r;
     const int yc = min(max(ys - 1 + q, 0), hrow - 1);
     if (HALF)
-      r.d = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, loadable ? (uint32_t)(yc * pitch + c0) : 0xFFFFFFF0u, 0u, 0);
+      r.d = __builtin_amdgcn_raw_buffer_load_b32(
+          src_rsrc, loadable ? __umul24((uint32_t)yc, (uint32_t)pitch) + (uint32_t)c0 : 0xFFFFFFF0u, 0u, 0);  // (full-rate multiply)
     else
       r.d = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, col_off, (uint32_t)(yc * pitch), 0);
     r.p = wave_shr1(r.d);
