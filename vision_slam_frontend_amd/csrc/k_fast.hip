@@ -8,8 +8,8 @@
 //
 // Streaming march kernel -- no LDS, no barriers, no divergent corner/score phases:
 //  * a wave owns a band of 240 keypoint columns x a strip of 32 rows of one level of one image and walks down the
-//    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window (seven
-//    rotating register sets, no copies) and gets its neighbours' dwords by DPP wave shifts;
+//    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window (nine
+//    rotating register sets incl. two rows of read-ahead, no copies) and gets its neighbours' dwords by DPP wave shifts;
 //  * corner test and score are ONE dense computation: with d_k = p_k - v on the 16-pixel circle,
 //      A = max over the 16 arcs of min(d over the 9-arc),  B = -min over arcs of max(d over the arc)
 //    (computed on the p_k, v subtracted once at the end),
@@ -215,8 +215,6 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
   uint32_t* seg = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)unit_local * L.seg_cap;
   uint16_t* rs = a.rowstart + ((size_t)image * a.nunits + L.unit0 + unit_local) * VSF_FAST_RS_STRIDE;
   const int seg_cap = L.seg_cap, hrow = L.h;
-  const unsigned long long hmask = HALF ? (half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull) : ~0ull;
-  const unsigned long long lt = ((1ull << lane) - 1ull) & hmask;  // lanes of my cell before me
 
   // buffer loads: a lane's column offset sits in a VGPR, the row offset in an SGPR (per lane when HALF); reads outside
   // the level return 0
@@ -238,14 +236,14 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
     return r;
   };
 
-  ScoreRow S_up = make_score_row(0u), S_mid = S_up;  // score rows q-2, q-1
+  ScoreRow S0 = make_score_row(0u), S1 = S0, S2 = S0;  // score rows rotate through three sets: q-2, q-1, q
   int count_lo = 0, count_hi = 0;  // candidates emitted so far by the cell(s) (wave-uniform)
   int my_rs = 0;                   // lane hl keeps rowstart[hl] of its cell
 
   // One step: scores of cell row q - 1 (image row ys - 1 + q) from the window R0..R6 = image rows ys - 4 + q .. ys + 2 + q,
   // then NMS + emission of cell row q - 2.
   auto step = [&](int q, const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3, const Row3& R4,
-                  const Row3& R5, const Row3& R6) {
+                  const Row3& R5, const Row3& R6, const ScoreRow& S_up, const ScoreRow& S_mid, ScoreRow& S_dn) {
     uint32_t S = 0;
     const int sy = ys - 1 + q;
     const bool row_ok = sy >= 3 && sy < hrow - 3;  // (wave-uniform unless HALF)
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
       S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r23), __builtin_bit_cast(uint32_t, r01), 0x06040200u);
       S &= row_ok ? smask : 0u;
     }
-    const ScoreRow S_dn = make_score_row(S);
+    S_dn = make_score_row(S);
     const int r = q - 2;  // cell row to emit
     if (r >= 0 && r < nrows0) {
       const uint32_t em = r < nrows ? emask : 0u;  // (the second cell may have fewer rows)
@@ -272,8 +270,16 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
         const bool k0 = (k01 & 0xFFFFu) != 0, k1 = (k01 >> 16) != 0, k2 = (k23 & 0xFFFFu) != 0, k3 = (k23 >> 16) != 0;
         const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
         if ((b0 | b1 | b2 | b3) != 0ull) {  // wave-uniform
-          const int count = half ? count_hi : count_lo;
-          int pos = count + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+          // rank among the cell's lanes: v_mbcnt counts the set bits below this lane (two instructions per ballot, chained
+          // through the accumulator); the upper cell of a half-wave pair subtracts the lower cell's bits (scalar)
+          auto below = [](unsigned long long b, int acc) -> int {
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)acc));
+          };
+          int pos = below(b3, below(b2, below(b1, below(b0, half ? count_hi : count_lo))));
+          if (HALF) {
+            const int lower = __popc((uint32_t)b0) + __popc((uint32_t)b1) + __popc((uint32_t)b2) + __popc((uint32_t)b3);
+            pos -= half ? lower : 0;
+          }
           const uint32_t sc = nms ? S_mid.s : 0u;
           const uint32_t yx = ((uint32_t)(ys + r) << 12) | (uint32_t)c0;
           if (k0) {
@@ -302,47 +308,32 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
       }
       if (hl > r) my_rs = min(half ? count_hi : count_lo, seg_cap);
     }
-    S_up = S_mid;
-    S_mid = S_dn;
   };
 
-  // Seven rotating register sets hold image rows (ys - 1 + q) - 3 .. + 3; each step refills the oldest one two rows
-  // ahead.  q runs over 0 .. nrows0 + 1 (score rows ys - 1 .. ys + nrows0).
-  Row3 W0 = load_row(-3), W1 = load_row(-2), W2 = load_row(-1), W3 = load_row(0), W4 = load_row(1), W5 = load_row(2),
-       W6 = load_row(3);
-  Row3 nx = load_row(4);
+  // NINE rotating register sets hold image rows: step q reads rows (ys - 4 + q) .. (ys + 2 + q) from sets q .. q + 6
+  // (mod 9), set q + 7 already holds the next row and the row after that is requested into set q + 8 -- the set whose row
+  // the previous step used last.  The loop body is nine steps, a multiple of the three score-row sets' period, so neither
+  // the image rows nor the score rows are ever copied between registers (a period of seven cost 17 v_mov per step).
+  // q runs over 0 .. nrows0 + 1 (score rows ys - 1 .. ys + nrows0).
+  Row3 A0 = load_row(-3), A1 = load_row(-2), A2 = load_row(-1), A3 = load_row(0), A4 = load_row(1), A5 = load_row(2),
+       A6 = load_row(3), A7 = load_row(4), A8;
   const int qe = nrows0 + 1;
-  for (int q = 0; q <= qe; q += 7) {
-    Row3 n2;
-    n2 = load_row(q + 5);
-    step(q, W0, W1, W2, W3, W4, W5, W6);
-    if (q + 1 > qe) break;
-    W0 = nx;
-    nx = load_row(q + 6);
-    step(q + 1, W1, W2, W3, W4, W5, W6, W0);
-    if (q + 2 > qe) break;
-    W1 = n2;
-    n2 = load_row(q + 7);
-    step(q + 2, W2, W3, W4, W5, W6, W0, W1);
-    if (q + 3 > qe) break;
-    W2 = nx;
-    nx = load_row(q + 8);
-    step(q + 3, W3, W4, W5, W6, W0, W1, W2);
-    if (q + 4 > qe) break;
-    W3 = n2;
-    n2 = load_row(q + 9);
-    step(q + 4, W4, W5, W6, W0, W1, W2, W3);
-    if (q + 5 > qe) break;
-    W4 = nx;
-    nx = load_row(q + 10);
-    step(q + 5, W5, W6, W0, W1, W2, W3, W4);
-    if (q + 6 > qe) break;
-    W5 = n2;
-    n2 = load_row(q + 11);
-    step(q + 6, W6, W0, W1, W2, W3, W4, W5);
-    W6 = nx;
-    nx = n2;
+#define VSF_FAST_STEP(j, r0, r1, r2, r3, r4, r5, r6, ld, su, sm, sd) \
+  if (q + (j) > qe) break;                                             \
+  ld = load_row(q + (j) + 5);                                          \
+  step(q + (j), r0, r1, r2, r3, r4, r5, r6, su, sm, sd);
+  for (int q = 0;; q += 9) {
+    VSF_FAST_STEP(0, A0, A1, A2, A3, A4, A5, A6, A8, S0, S1, S2)
+    VSF_FAST_STEP(1, A1, A2, A3, A4, A5, A6, A7, A0, S1, S2, S0)
+    VSF_FAST_STEP(2, A2, A3, A4, A5, A6, A7, A8, A1, S2, S0, S1)
+    VSF_FAST_STEP(3, A3, A4, A5, A6, A7, A8, A0, A2, S0, S1, S2)
+    VSF_FAST_STEP(4, A4, A5, A6, A7, A8, A0, A1, A3, S1, S2, S0)
+    VSF_FAST_STEP(5, A5, A6, A7, A8, A0, A1, A2, A4, S2, S0, S1)
+    VSF_FAST_STEP(6, A6, A7, A8, A0, A1, A2, A3, A5, S0, S1, S2)
+    VSF_FAST_STEP(7, A7, A8, A0, A1, A2, A3, A4, A6, S1, S2, S0)
+    VSF_FAST_STEP(8, A8, A0, A1, A2, A3, A4, A5, A7, S2, S0, S1)
   }
+#undef VSF_FAST_STEP
   if (valid) {
     if (hl < SR) rs[hl] = (uint16_t)my_rs;                                          // rowstart[0 .. SR-1]
     if (hl == 0) rs[SR] = (uint16_t)min(half ? count_hi : count_lo, seg_cap);       // rowstart[SR] = cell total
