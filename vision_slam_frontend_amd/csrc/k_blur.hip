@@ -49,10 +49,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i-1
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {  // lane i <- lane i+1
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
 }
 
 __device__ __forceinline__ Px4 widen(uint32_t d) {

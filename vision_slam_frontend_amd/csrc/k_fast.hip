@@ -48,10 +48,10 @@ struct FastArgs {
 };
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i-1
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {  // lane i <- lane i+1
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
 }
 
 // One image row as seen by a lane: its own 4 pixels (d) and the neighbouring lanes' (p = left, n = right).
