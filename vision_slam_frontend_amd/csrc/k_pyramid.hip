@@ -206,8 +206,10 @@ __device__ __forceinline__ void strip_issue_from(const ResizeArgs& a, const Stri
     if constexpr (ALIGNED) {
       // LDS source: an unaligned 8-byte read is split by the hardware and stalls the LDS queue; three aligned dwords and
       // two v_alignbyte give the same window (levels are padded to their 64-byte pitch, so the third dword exists)
-      const uint32_t* w = reinterpret_cast<const uint32_t*>(row + (c.base & ~3u));
-      const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+      const uint32_t b0 = c.base & ~3u;
+      // (the third dword is clamped into the row: when it would start past the pitch none of its bytes is needed)
+      const uint32_t d0 = *reinterpret_cast<const uint32_t*>(row + b0), d1 = *reinterpret_cast<const uint32_t*>(row + b0 + 4u),
+                     d2 = *reinterpret_cast<const uint32_t*>(row + min(b0 + 8u, (uint32_t)a.src_pitch - 4u));
       o.v[k].lo = __builtin_amdgcn_alignbyte(d1, d0, c.base & 3u);
       o.v[k].hi = __builtin_amdgcn_alignbyte(d2, d1, c.base & 3u);
     } else {
