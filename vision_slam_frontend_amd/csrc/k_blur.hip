@@ -133,14 +133,24 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
   const uint32_t t0 = c0 + 0 < L.blur_vec_end ? 0u : 1u, t1 = c0 + 1 < L.blur_vec_end ? 0u : 1u,
                  t2 = c0 + 2 < L.blur_vec_end ? 0u : 1u, t3 = c0 + 3 < L.blur_vec_end ? 0u : 1u;
 
-  auto fetch = [&](int y) -> Px4 {
+  // A row is requested two steps before the step that needs it (the raw dwords wait in registers): with the load
+  // issued right in front of its use the kernel depended on eight resident waves per SIMD to cover the latency.
+  struct Raw {
+    uint32_t d0, d1;
+  };
+  auto request = [&](int y) -> Raw {
     // buffer load: lane offset in a VGPR, row offset in an SGPR -- no vector address arithmetic per row
     const uint32_t row_off = (uint32_t)reflect101(y, h) * (uint32_t)pitch;  // scalar
-    const uint32_t d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a0, row_off, 0);
-    if (all_interior) return widen(d0);  // wave-uniform
-    const uint32_t d1 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a1, row_off, 0);
-    return widen(__builtin_amdgcn_perm(d1, d0, bsel));
+    Raw r;
+    r.d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a0, row_off, 0);
+    r.d1 = all_interior ? 0u : __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a1, row_off, 0);  // wave-uniform
+    return r;
   };
+  auto unpack = [&](const Raw& r) -> Px4 {
+    if (all_interior) return widen(r.d0);  // wave-uniform
+    return widen(__builtin_amdgcn_perm(r.d1, r.d0, bsel));
+  };
+  auto fetch = [&](int y) -> Px4 { return unpack(request(y)); };
   // One output row: column pass over the 7-row window (r0 = row y-3 ... r6 = row y+3), then the row pass.
   auto emit = [&](int y, const Px4& r0, const Px4& r1, const Px4& r2, const Px4& r3, const Px4& r4, const Px4& r5,
                   const Px4& r6) {
@@ -170,29 +180,25 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
   W3 = fetch(ys);
   W4 = fetch(ys + 1);
   W5 = fetch(ys + 2);
-  // The window rotates through seven register sets: row y uses (Wq .. Wq+6 mod 7) and refills the oldest one.
-  for (int y = ys; y < ye; y += 7) {
-    W6 = fetch(y + 3);
-    emit(y, W0, W1, W2, W3, W4, W5, W6);
-    if (y + 1 >= ye) break;
-    W0 = fetch(y + 4);
-    emit(y + 1, W1, W2, W3, W4, W5, W6, W0);
-    if (y + 2 >= ye) break;
-    W1 = fetch(y + 5);
-    emit(y + 2, W2, W3, W4, W5, W6, W0, W1);
-    if (y + 3 >= ye) break;
-    W2 = fetch(y + 6);
-    emit(y + 3, W3, W4, W5, W6, W0, W1, W2);
-    if (y + 4 >= ye) break;
-    W3 = fetch(y + 7);
-    emit(y + 4, W4, W5, W6, W0, W1, W2, W3);
-    if (y + 5 >= ye) break;
-    W4 = fetch(y + 8);
-    emit(y + 5, W5, W6, W0, W1, W2, W3, W4);
-    if (y + 6 >= ye) break;
-    W5 = fetch(y + 9);
-    emit(y + 6, W6, W0, W1, W2, W3, W4, W5);
+  // The window rotates through seven register sets: row y uses (Wq .. Wq+6 mod 7) and refills the oldest one from the
+  // raw row requested two steps earlier.
+  Raw ra = request(ys + 3), rb = request(ys + 4);
+#define VSF_BLUR_STEP(j, w0, w1, w2, w3, w4, w5, w6) \
+  if (y + (j) >= ye) break;                           \
+  w6 = unpack(ra);                                    \
+  ra = rb;                                            \
+  rb = request(y + (j) + 5);                          \
+  emit(y + (j), w0, w1, w2, w3, w4, w5, w6);
+  for (int y = ys;; y += 7) {
+    VSF_BLUR_STEP(0, W0, W1, W2, W3, W4, W5, W6)
+    VSF_BLUR_STEP(1, W1, W2, W3, W4, W5, W6, W0)
+    VSF_BLUR_STEP(2, W2, W3, W4, W5, W6, W0, W1)
+    VSF_BLUR_STEP(3, W3, W4, W5, W6, W0, W1, W2)
+    VSF_BLUR_STEP(4, W4, W5, W6, W0, W1, W2, W3)
+    VSF_BLUR_STEP(5, W5, W6, W0, W1, W2, W3, W4)
+    VSF_BLUR_STEP(6, W6, W0, W1, W2, W3, W4, W5)
   }
+#undef VSF_BLUR_STEP
 }
 
 }  // namespace
