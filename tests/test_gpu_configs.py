@@ -105,7 +105,7 @@ def test_half_batches_equal_full_batch(capi):
         np.testing.assert_array_equal(a, b, err_msg="pipeline " + name)
 
 
-@pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 96), (320, 240, 500, 100)])
+@pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 96), (320, 240, 500, 100), (1920, 1080, 8000, 96)])
 def test_large_batch_equals_small_batches(capi, oracle, w, h, nf, B):
     """A batch that fills the CUs (>= 192 images on an MI355X) builds the one-band levels of its pyramids with the
     image-major LDS kernel (k_pyramid.hip pyramid_image_kernel) instead of per-level launches: identical outputs, and the
