@@ -153,10 +153,12 @@ def main() -> int:
     d_counts = torch.zeros(2 * B, dtype=torch.int32, device=dev)
     d_matches = torch.empty((B, K, 16), dtype=torch.uint8, device=dev)
     d_nmatches = torch.zeros(B, dtype=torch.int32, device=dev)
-    gather_bufs = None
+    gather_bufs = [None, None]
     if world > 1 and rank == 0:
         payload_bytes = B * K * 28 + 2 * B * 4 + B * K * 16 + B * 4
-        gather_bufs = [torch.empty(payload_bytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+        gather_bufs = [[torch.empty(payload_bytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+                       for _ in range(2)]  # two sets: the gather of step i is in flight while step i + 1 is computed
+    pending = []  # (work, payload, recv) of the gathers in flight
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_lanes(args.lanes)
@@ -167,13 +169,26 @@ def main() -> int:
         ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(),
                              d_counts.data_ptr(), d_matches.data_ptr(), d_nmatches.data_ptr())
         if world > 1:
-            # VisionFeature (left keypoints) / FeatureMatch payloads of this rank's frames -> rank 0 over RCCL.
+            # VisionFeature (left keypoints) / FeatureMatch payloads of this rank's frames -> rank 0 over RCCL, as an
+            # asynchronous collective on the backend's stream: it overlaps the next step's kernels (the payload is a
+            # packed copy, so the next step may overwrite the output buffers; at most two gathers are in flight).
+            if len(pending) >= 2:
+                pending.pop(0)[0].wait()
             left_kp = d_kp.view(B, 2, K, 28)[:, 0].contiguous()
-            vd.gather_packed_to_root({"kp": left_kp, "counts": d_counts, "matches": d_matches,
-                                      "nmatches": d_nmatches}, dst=0, bufs=gather_bufs)
+            pending.append(vd.gather_packed_to_root_async(
+                {"kp": left_kp, "counts": d_counts, "matches": d_matches, "nmatches": d_nmatches}, dst=0,
+                bufs=gather_bufs[step.n & 1]))
+            step.n += 1
+
+    step.n = 0
+
+    def drain():
+        while pending:
+            pending.pop(0)[0].wait()
 
     for _ in range(args.warmup):
         step()
+    drain()
     ctx.sync(allow_capacity=True)
     ctx.profile_enable(True)
     if world > 1:
@@ -182,6 +197,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()  # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -49,7 +49,16 @@ def _worker(rank: int, world: int, port: int, results):
                               np.float32)
             all_ok &= bool(np.array_equal(flat, expect, equal_nan=True))
             gp = vd.gather_packed_to_root(t, dst=0)  # one collective; must equal the per-tensor gather
+            work, payload, recv = vd.gather_packed_to_root_async(t, dst=0)  # the overlapped form bench.py uses
             g = vd.gather_to_root(t, dst=0)
+            work.wait()
+            if rank == 0:
+                for r in range(world):
+                    got = vd.unpack(recv[r], t)
+                    for k in t:
+                        all_ok &= bool(torch.equal(got[k], gp[r][k]))
+            else:
+                all_ok &= recv is None
             if rank == 0:
                 for r in range(world):
                     for k in t:

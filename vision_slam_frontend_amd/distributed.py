@@ -79,6 +79,22 @@ def gather_packed_to_root(tensors: Dict[str, torch.Tensor], dst: int = 0,
     return None if rank != dst else [unpack(b, tensors) for b in recv]
 
 
+def gather_packed_to_root_async(tensors: Dict[str, torch.Tensor], dst: int = 0,
+                                bufs: Optional[List[torch.Tensor]] = None):
+    """gather_packed_to_root as an asynchronous collective: returns (work, payload, recv).  The collective runs on the
+    backend's own stream behind the producer of `tensors`; the caller keeps computing and calls work.wait() before it
+    reuses `bufs` (recv is None off the root).  A step's outputs then travel while the next step is computed."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    payload = pack(tensors)
+    if payload.is_cuda and dist.get_backend() == "gloo":  # rehearsal on CPU collectives: gloo gathers host tensors
+        payload, bufs = payload.cpu(), None
+    recv = None
+    if rank == dst:
+        recv = bufs if bufs is not None else [torch.empty_like(payload) for _ in range(world)]
+    work = dist.gather(payload, recv, dst=dst, async_op=True)
+    return work, payload, recv
+
+
 def allgather_frame_means(local_means: torch.Tensor) -> torch.Tensor:
     """All ranks receive every rank's per-frame mean residuals, shape (world, frames_per_rank), rank-major."""
     world = dist.get_world_size()
