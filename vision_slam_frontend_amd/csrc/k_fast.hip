@@ -267,42 +267,63 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
         uint32_t k01 = __builtin_bit_cast(uint32_t, ((nb01 - S_mid.c01) >> 15) & em01);
         uint32_t k23 = __builtin_bit_cast(uint32_t, ((nb23 - S_mid.c23) >> 15) & em23);
         if (r >= nrows) k01 = k23 = 0;
-        const bool k0 = (k01 & 0xFFFFu) != 0, k1 = (k01 >> 16) != 0, k2 = (k23 & 0xFFFFu) != 0, k3 = (k23 >> 16) != 0;
-        const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
-        if ((b0 | b1 | b2 | b3) != 0ull) {  // wave-uniform
-          // rank among the cell's lanes: v_mbcnt counts the set bits below this lane (two instructions per ballot, chained
-          // through the accumulator); the upper cell of a half-wave pair subtracts the lower cell's bits (scalar)
-          auto below = [](unsigned long long b, int acc) -> int {
-            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)acc));
-          };
-          int pos = below(b3, below(b2, below(b1, below(b0, half ? count_hi : count_lo))));
-          if (HALF) {
-            const int lower = __popc((uint32_t)b0) + __popc((uint32_t)b1) + __popc((uint32_t)b2) + __popc((uint32_t)b3);
-            pos -= half ? lower : 0;
+        // rank among the cell's lanes: v_mbcnt counts the set bits below this lane (two instructions per ballot, chained
+        // through the accumulator); the upper cell of a half-wave pair subtracts the lower cell's bits (scalar)
+        auto below = [](unsigned long long b, int acc) -> int {
+          return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)acc));
+        };
+        const uint32_t yx = ((uint32_t)(ys + r) << 12) | (uint32_t)c0;
+        if (nms) {
+          // Strict NMS: two neighbouring pixels cannot both survive, so a lane emits at most TWO of its four pixels --
+          // two ballots / ranks / stores instead of four.  m = survivor bits of the lane's pixels 0..3.
+          const uint32_t m = (k01 & 1u) | ((k01 >> 15) & 2u) | ((k23 & 1u) << 2) | ((k23 >> 13) & 8u);
+          const uint32_t m2 = m & (m - 1u);  // without its lowest bit
+          const unsigned long long bA = __ballot(m != 0u), bB = __ballot(m2 != 0u);
+          if (bA != 0ull) {  // wave-uniform
+            int pos = below(bB, below(bA, half ? count_hi : count_lo));
+            if (HALF) pos -= half ? __popc((uint32_t)bA) + __popc((uint32_t)bB) : 0;
+            const uint32_t j1 = (uint32_t)__builtin_ctz(m | 16u), j2 = (uint32_t)__builtin_ctz(m2 | 16u);
+            const uint32_t sc = S_mid.s;
+            if (m != 0u && pos < seg_cap) seg[pos] = (((sc >> (8u * j1)) & 255u) << 24) | (yx + j1);
+            if (m2 != 0u && pos + 1 < seg_cap) seg[pos + 1] = (((sc >> (8u * j2)) & 255u) << 24) | (yx + j2);
+            if (HALF) {
+              count_lo += __popc((uint32_t)bA) + __popc((uint32_t)bB);
+              count_hi += __popc((uint32_t)(bA >> 32)) + __popc((uint32_t)(bB >> 32));
+            } else {
+              count_lo += __popcll(bA) + __popcll(bB);
+            }
           }
-          const uint32_t sc = nms ? S_mid.s : 0u;
-          const uint32_t yx = ((uint32_t)(ys + r) << 12) | (uint32_t)c0;
-          if (k0) {
-            if (pos < seg_cap) seg[pos] = ((sc & 255u) << 24) | yx;
-            ++pos;
-          }
-          if (k1) {
-            if (pos < seg_cap) seg[pos] = ((sc & 0xFF00u) << 16) | (yx + 1);
-            ++pos;
-          }
-          if (k2) {
-            if (pos < seg_cap) seg[pos] = ((sc & 0xFF0000u) << 8) | (yx + 2);
-            ++pos;
-          }
-          if (k3) {
-            if (pos < seg_cap) seg[pos] = (sc & 0xFF000000u) | (yx + 3);
-          }
-          if (HALF) {
-            count_lo += __popcll(b0 & 0xFFFFFFFFull) + __popcll(b1 & 0xFFFFFFFFull) + __popcll(b2 & 0xFFFFFFFFull) +
-                        __popcll(b3 & 0xFFFFFFFFull);
-            count_hi += __popcll(b0 >> 32) + __popcll(b1 >> 32) + __popcll(b2 >> 32) + __popcll(b3 >> 32);
-          } else {
-            count_lo += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        } else {
+          const bool k0 = (k01 & 0xFFFFu) != 0, k1 = (k01 >> 16) != 0, k2 = (k23 & 0xFFFFu) != 0, k3 = (k23 >> 16) != 0;
+          const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
+          if ((b0 | b1 | b2 | b3) != 0ull) {  // wave-uniform
+            int pos = below(b3, below(b2, below(b1, below(b0, half ? count_hi : count_lo))));
+            if (HALF) {
+              const int lower = __popc((uint32_t)b0) + __popc((uint32_t)b1) + __popc((uint32_t)b2) + __popc((uint32_t)b3);
+              pos -= half ? lower : 0;
+            }
+            if (k0) {
+              if (pos < seg_cap) seg[pos] = yx;  // (without NMS cv::FAST_t leaves the response at 0)
+              ++pos;
+            }
+            if (k1) {
+              if (pos < seg_cap) seg[pos] = yx + 1;
+              ++pos;
+            }
+            if (k2) {
+              if (pos < seg_cap) seg[pos] = yx + 2;
+              ++pos;
+            }
+            if (k3) {
+              if (pos < seg_cap) seg[pos] = yx + 3;
+            }
+            if (HALF) {
+              count_lo += __popcll(b0 & 0xFFFFFFFFull) + __popcll(b1 & 0xFFFFFFFFull) + __popcll(b2 & 0xFFFFFFFFull) +
+                          __popcll(b3 & 0xFFFFFFFFull);
+              count_hi += __popcll(b0 >> 32) + __popcll(b1 >> 32) + __popcll(b2 >> 32) + __popcll(b3 >> 32);
+            } else {
+              count_lo += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+            }
           }
         }
       }
