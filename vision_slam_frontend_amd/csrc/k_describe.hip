@@ -12,7 +12,7 @@
 //       = pair 8k+i, LSB first, exactly OpenCV's packing).  Per sample: x = px*a - py*b, y = px*b + py*a as
 //       separately rounded float ops (no FMA), cvRound (round-half-even), one byte load.
 // Both run in one kernel over the image's keypoints in output order (level-major; a level's slot is the sum of the
-// preceding levels' counts), sixteen consecutive keypoints per wave.
+// preceding levels' counts), four consecutive keypoints per wave.
 #include <algorithm>
 
 #include "vsf_internal.h"
@@ -99,12 +99,13 @@ __device__ __forceinline__ void sincos_2pi(double x, double* s_out, double* c_ou
   *c_out = ((k + 1) & 2) ? -cv : cv;
 }
 
-constexpr int kKpPerWave = 16;  // consecutive output keypoints per wave
+constexpr int kKpPerWave = 4;  // consecutive output keypoints per wave (per 256-frame step: 2 -> 0.89 ms, 4 -> 0.83, 8 -> 0.85,
+                                // 16 -> 0.89, 32 -> 0.97: the kernel lives on waves in flight, not on amortised prologues)
 
 // K6 + K8 + output assembly.  The image's keypoints are numbered in output order (level-major, retainBest order
-// inside a level); wave w of the image takes numbers [16 w, 16 w + 16), whatever levels they belong to: lane k < 16
+// inside a level); wave w of the image takes numbers [4 w, 4 w + 4), whatever levels they belong to: lane k < 4
 // looks up keypoint k's level (binary search in the wave-scanned level counts), record and level geometry once, and
-// the wave then walks the 16 keypoints with v_readlane broadcasts.  (One workgroup per (level, image) left most waves
+// the wave then walks its keypoints with v_readlane broadcasts.  (One workgroup per (level, image) left most waves
 // with two or three keypoints and a prologue longer than their work.)
 __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a) {
   constexpr int kWinRows = 39, kWinPitch = 64, kWinBytes = kWinRows * kWinPitch;
