@@ -74,6 +74,17 @@ __device__ __forceinline__ v2s pick2(const Row3& r) {
 
 __device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+// Three-input packed minimum / maximum of values 0..255 held in 16-bit halves (see score_pair).
+__device__ __forceinline__ v2s vmin3(v2s a, v2s b, v2s c) {
+  v2s r;
+  asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ v2s vmax3(v2s a, v2s b, v2s c) {
+  v2s r;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 // Scores of the two pixels at bytes 4+J0, 5+J0 of the centre row R3; R0..R6 are rows y-3..y+3.
 // Returns the two scores (0 = not a corner; a marker 1 when nms == 0) in the two 16-bit halves.
@@ -100,35 +111,33 @@ __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const 
   d[13] = pick2<4 + J0 - 3>(R4);
   d[14] = pick2<4 + J0 - 2>(R5);
   d[15] = pick2<4 + J0 - 1>(R6);
-  // Arc k = d[k .. k+8] (indices mod 16).  With halves H0 = d[0..7], H1 = d[8..15]:
-  //   arc k     (k < 8) = suffix of H0 from k  +  prefix of H1 up to k
-  //   arc 8 + k         = suffix of H1 from k  +  prefix of H0 up to k
-  v2s ps0[8], ps1[8], sf0[8], sf1[8], px0[8], px1[8], sx0[8], sx1[8];
-  ps0[0] = px0[0] = d[0];
-  ps1[0] = px1[0] = d[8];
-  sf0[7] = sx0[7] = d[7];
-  sf1[7] = sx1[7] = d[15];
+  // Arc k = d[k .. k+8] (indices mod 16).  Arcs 2j and 2j+1 share the eight pixels C = d[2j+1 .. 2j+8]:
+  //   max(min(d[2j], C), min(C, d[2j+9])) = min(C, max(d[2j], d[2j+9]))                       (distributive lattice)
+  // and C is four pixel pairs E_i = min(d[2i+1], d[2i+2]), i = j .. j+3, i.e. two quads F_i = min(E_i, E_{i+1}):
+  //   A = max_j min3(F_j, F_{j+2}, max(d[2j], d[2j+9])),     Bm likewise with min and max exchanged.
+  // 8 + 8 + 8 two-input ops, 8 three-input ops and a 4-op reduction = 36 per polarity (59 with prefix / suffix minima of
+  // the two circle halves).  The three-input ops are gfx950's v_pk_minimum3_f16 / v_pk_maximum3_f16 on the pixel values
+  // as they sit in the 16-bit halves: 0..255 are f16 denormals, whose order is the integer order (f16 denormals are
+  // never flushed in the default mode; exhaustively checked on MI355X for all 2^24 triples, tools/exp/m3.hip).
+  v2s E[8], G[8], F[8], H[8];
 #pragma unroll
-  for (int k = 1; k < 8; k++) {
-    ps0[k] = vmin(ps0[k - 1], d[k]);
-    px0[k] = vmax(px0[k - 1], d[k]);
-    ps1[k] = vmin(ps1[k - 1], d[8 + k]);
-    px1[k] = vmax(px1[k - 1], d[8 + k]);
-    sf0[7 - k] = vmin(sf0[8 - k], d[7 - k]);
-    sx0[7 - k] = vmax(sx0[8 - k], d[7 - k]);
-    sf1[7 - k] = vmin(sf1[8 - k], d[15 - k]);
-    sx1[7 - k] = vmax(sx1[8 - k], d[15 - k]);
+  for (int j = 0; j < 8; j++) {
+    E[j] = vmin(d[2 * j + 1], d[(2 * j + 2) & 15]);
+    G[j] = vmax(d[2 * j + 1], d[(2 * j + 2) & 15]);
   }
-  v2s A = vmin(sf0[0], ps1[0]), Bm = vmax(sx0[0], px1[0]);
-  A = vmax(A, vmin(sf1[0], ps0[0]));
-  Bm = vmin(Bm, vmax(sx1[0], px0[0]));
 #pragma unroll
-  for (int k = 1; k < 8; k++) {
-    A = vmax(A, vmin(sf0[k], ps1[k]));
-    A = vmax(A, vmin(sf1[k], ps0[k]));
-    Bm = vmin(Bm, vmax(sx0[k], px1[k]));
-    Bm = vmin(Bm, vmax(sx1[k], px0[k]));
+  for (int j = 0; j < 8; j++) {
+    F[j] = vmin(E[j], E[(j + 1) & 7]);
+    H[j] = vmax(G[j], G[(j + 1) & 7]);
   }
+  v2s ta[8], tb[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    ta[j] = vmin3(F[j], F[(j + 2) & 7], vmax(d[2 * j], d[(2 * j + 9) & 15]));
+    tb[j] = vmax3(H[j], H[(j + 2) & 7], vmin(d[2 * j], d[(2 * j + 9) & 15]));
+  }
+  const v2s A = vmax(vmax3(vmax3(ta[0], ta[1], ta[2]), vmax3(ta[3], ta[4], ta[5]), ta[6]), ta[7]);
+  const v2s Bm = vmin(vmin3(vmin3(tb[0], tb[1], tb[2]), vmin3(tb[3], tb[4], tb[5]), tb[6]), tb[7]);
   // cornerScore<16> = max(t, A, -Bm) - 1; a corner iff that maximum exceeds t.  With NMS a corner of score 0 can
   // never win (cv::FAST_t compares strictly against neighbours >= 0); without NMS only a corner marker is kept
   // (cv::FAST_t leaves the response at 0 then).
