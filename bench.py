@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: stereo frames/s through extract(left) + extract(right) + GetMatches(left, right)
-(slam_frontend.cc:411-416) on synthetic 640x480 stereo pairs, 2000 keypoints per frame (BASELINE.json
-configs[1]), inputs resident in HBM, on N GPUs of one node (one process per GPU, frames sharded, outputs
-gathered to rank 0 over RCCL).
+"""Headline benchmark: stereo frames/s through the per-frame hot path of Frontend::ObserveImage
+(slam_frontend.cc:400-443) on synthetic 640x480 stereo pairs, 2000 keypoints per frame (BASELINE.json configs[1]),
+inputs resident in HBM, on N GPUs of one node: one process per GPU, frames sharded in blocks, the RemoveAmbigStereo
+means all-gathered, compact VisionFeature / FeatureMatch payloads gathered to rank 0 over RCCL (configs[3]).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --config 1080p            # BASELINE configs[2]: 1920x1080, 8000 keypoints
 
-A "step" is one pass of the hot path over one batch of `--batch` stereo frames per GPU.  Rank 0 prints ONE
-JSON line (schema: task contract + `roofline` and `cpu_baseline` objects).
+A "step" is one pass of the hot path over one batch of `--batch` stereo frames per GPU: extract(L) + extract(R) +
+GetMatches(L, R) -- the part BASELINE's metric names and >= 97 % of the step -- followed by the reference's own steps up
+to the output records (RemoveAmbigStereo, GetFeatureMatches against the previous frame, Calculate3DPoints,
+UndistortFeaturePoints) and the packing of the payload; the SAME per-GPU work at every N, plus the collectives for
+N > 1 (vision_slam_frontend_amd/distributed.py).  Rank 0 prints ONE JSON line (task contract + `roofline`,
+`roofline_valu`, `matcher` and `cpu_baseline` objects).
 """
 from __future__ import annotations
 
@@ -23,7 +28,14 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4  # 1024 SIMDs x 2.4 GHz, one wave64 VALU instruction per 4 cycles = 614.4 G wave-inst/s
+MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 = the fp8 rate (MI355X_MICROARCH.md: ~5 PFLOP/s fp8 dense)
+
+CONFIGS = {
+    "vga": dict(width=640, height=480, nfeatures=2000, batch=256, label="BASELINE configs[1]"),
+    "1080p": dict(width=1920, height=1080, nfeatures=8000, batch=32, label="BASELINE configs[2]"),
+}
 
 
 def stage_algorithmic_bytes(ctx, n_images: int, n_pairs: int, nfeatures: int) -> dict:
@@ -40,26 +52,27 @@ def stage_algorithmic_bytes(ctx, n_images: int, n_pairs: int, nfeatures: int) ->
         "orb_describe": n_images * nfeatures * rec,                # cv::KeyPoint + descriptor out
         "hamming_knn2": n_pairs * (32 * 2 * nfeatures + 16 * nfeatures),
         "ratio_compact": n_pairs * (16 * nfeatures + 16 * nfeatures),
+        "frontend_tail": n_pairs * nfeatures * (16 + 60 + 28),     # matches in, filtered frames + VisionFeature out
     }
 
 
-def measured_traffic(stage: str, width: int, height: int, nfeatures: int, batch: int):
-    """HBM bytes per step of `stage` from the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in their own runs, gfx950 FETCH_SIZE correction applied), if they were taken on this
-    configuration; None otherwise.  PMC counters cannot be collected inside the timed run."""
+def committed_counters(width: int, height: int, nfeatures: int, batch: int):
+    """Per-stage counters of the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE, WRITE_SIZE and
+    SQ_INSTS_VALU collected in their own runs), if they were taken on this configuration; {} otherwise.  PMC counters
+    cannot be collected inside the timed run."""
     try:
         t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
     except (OSError, ValueError):
-        return None
+        return {}
     c = t.get("config", {})
     if (c.get("width"), c.get("height"), c.get("nfeatures"), c.get("batch")) != (width, height, nfeatures, batch):
-        return None
-    st = t.get("stages", {}).get(stage)
-    return None if st is None else float(st["hbm_bytes_per_step"])
+        return {}
+    return t.get("stages", {})
 
 
 def cpu_baseline(width, height, nfeatures, seed):
-    """The CPU oracle (a scalar C++ restatement, kind "port") timed on this box's host cores."""
+    """The CPU oracle (a scalar C++ restatement of the OpenCV routines, kind "port": real OpenCV cannot be built here)
+    timed on ALL of this box's host cores, one stereo frame per thread at a time."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import binding as ob
@@ -67,14 +80,17 @@ def cpu_baseline(width, height, nfeatures, seed):
 
     ob.build()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))
-    n = 6 * cores  # ~20 s of CPU work (about 0.2 s per stereo frame and thread)
-    frames = synth.bench_batch(n, width, height, seed=seed, n_scenes=min(4, n))
+    cores = max(1, cores)
+    per_frame_s = 0.2 * (width * height) / (640 * 480)  # measured: ~0.2 s per VGA stereo frame and thread
+    rounds = max(1, int(round(15.0 / per_frame_s)))      # ~15 s of wall time ...
+    n = rounds * cores                                    # ... on every core
+    n_render = min(n, 4 * cores, 64)
+    frames = synth.bench_batch(n_render, width, height, seed=seed, n_scenes=min(4, n_render))
 
     def one(i):
         a, b = ob.Orb(nfeatures=nfeatures), ob.Orb(nfeatures=nfeatures)
-        a.run(frames[i, 0])
-        b.run(frames[i, 1])
+        a.run(frames[i % n_render, 0])
+        b.run(frames[i % n_render, 1])
         _, da = a.result()
         _, db = b.result()
         return len(ob.get_matches(da, db))
@@ -85,8 +101,9 @@ def cpu_baseline(width, height, nfeatures, seed):
         list(ex.map(one, range(n)))
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic %dx%d stereo frames (%d kp), oracle extract(L)+extract(R)+GetMatches, "
-                      "%d threads, %.1f s wall" % (n, width, height, nfeatures, cores, dt)}
+            "sample": "%d synthetic %dx%d stereo frames (%d kp) through the oracle port's extract(L)+extract(R)+GetMatches "
+                      "(scalar C++ restatement of OpenCV 3.2, not OpenCV itself), %d threads = all host cores, %.1f s wall"
+                      % (n, width, height, nfeatures, cores, dt)}
 
 
 def main() -> int:
@@ -94,24 +111,31 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="stereo frames per step per GPU")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="vga")
+    ap.add_argument("--batch", type=int, default=None, help="stereo frames per step per GPU")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--nfeatures", type=int, default=None)
+    ap.add_argument("--window", type=int, default=1, help="temporal GetFeatureMatches per frame (previous frames)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches per step (vsf_set_lanes)")
     ap.add_argument("--pipeline", action="store_true",
-                    help="overlap a step's pyramid with the previous step's latency-bound tail (vsf_set_pipeline): "
-                         "+4.7 %% frames/s, but the per-stage timers then overlap; off for the reported line")
+                    help="overlap a step's pyramid with the previous step's latency-bound tail (vsf_set_pipeline); "
+                         "the per-stage timers then overlap; off for the reported line")
+    ap.add_argument("--scene", choices=["bench", "sparse"], default="bench",
+                    help="sparse: few objects on a smooth background (~2 %% corner pixels) instead of SURVEY 8(d)'s stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W = args.width or cfg["width"]
+    H = args.height or cfg["height"]
+    NF = args.nfeatures or cfg["nfeatures"]
+    B = args.batch or cfg["batch"]
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
-    from vision_slam_frontend_amd import capi, synth
+    from vision_slam_frontend_amd import capi, frontend, synth
     from vision_slam_frontend_amd import distributed as vd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,58 +161,29 @@ def main() -> int:
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    B, W, H, NF = args.batch, args.width, args.height, args.nfeatures
-    # One explicit (non-default) stream carries everything: buffer initialisation, the HIP kernels (vsf_set_stream),
-    # the per-stage hipEvents and, for N > 1, the RCCL gather.  (torch's default stream has handle 0, which
-    # vsf_set_stream reads as "use the context's own stream".)
+    # One explicit (non-default) stream carries everything: the HIP kernels (vsf_set_stream), torch's copies, the
+    # per-stage hipEvents and, for N > 1, the RCCL collectives' dependencies.
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     p = capi.default_params(W, H, max_images=2 * B, nfeatures=NF)
     ctx = capi.Context(p, device=local_rank)
-    K = ctx.params.max_keypoints
-    frames = synth.bench_batch(B, W, H, seed=synth.BASE_SEED + 100003 * rank)
+    if args.scene == "sparse":
+        frames = synth.bench_batch(B, W, H, seed=synth.BASE_SEED + 100003 * rank, n_objects=max(8, W * H // 20000))
+    else:
+        frames = synth.bench_batch(B, W, H, seed=synth.BASE_SEED + 100003 * rank)
     d_img = torch.from_numpy(frames).to(dev)  # [B, 2, H, W] uint8, resident in HBM before timing
-    d_kp = torch.empty((2 * B, K, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.empty((2 * B, K, 32), dtype=torch.uint8, device=dev)
-    d_counts = torch.zeros(2 * B, dtype=torch.int32, device=dev)
-    d_matches = torch.empty((B, K, 16), dtype=torch.uint8, device=dev)
-    d_nmatches = torch.zeros(B, dtype=torch.int32, device=dev)
-    gather_bufs = [None, None]
-    if world > 1 and rank == 0:
-        payload_bytes = B * K * 28 + 2 * B * 4 + B * K * 16 + B * 4
-        gather_bufs = [[torch.empty(payload_bytes, dtype=torch.uint8, device=dev) for _ in range(world)]
-                       for _ in range(2)]  # two sets: the gather of step i is in flight while step i + 1 is computed
-    pending = []  # (work, payload, recv) of the gathers in flight
-    assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
+    calib = frontend.default_calibration()
+    # the synthetic pairs are rectified (pure horizontal disparity): l^T F r = y_r - y_l
+    calib.set("fundamental", [0, 0, 0, 0, 0, -1, 0, 1, 0])
+    sf = vd.ShardedStereoFrontend(ctx, B, W, H, calib, window=args.window, device=dev, stream=stream)
+    sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
     ctx.set_lanes(args.lanes)
     ctx.set_pipeline(args.pipeline)  # (legal here: the synthetic stream is resident in HBM before every call)
     torch.cuda.synchronize()
 
-    def step():
-        ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(),
-                             d_counts.data_ptr(), d_matches.data_ptr(), d_nmatches.data_ptr())
-        if world > 1:
-            # VisionFeature (left keypoints) / FeatureMatch payloads of this rank's frames -> rank 0 over RCCL, as an
-            # asynchronous collective on the backend's stream: it overlaps the next step's kernels (the payload is a
-            # packed copy, so the next step may overwrite the output buffers; at most two gathers are in flight).
-            if len(pending) >= 2:
-                pending.pop(0)[0].wait()
-            left_kp = d_kp.view(B, 2, K, 28)[:, 0].contiguous()
-            pending.append(vd.gather_packed_to_root_async(
-                {"kp": left_kp, "counts": d_counts, "matches": d_matches, "nmatches": d_nmatches}, dst=0,
-                bufs=gather_bufs[step.n & 1]))
-            step.n += 1
-
-    step.n = 0
-
-    def drain():
-        while pending:
-            pending.pop(0)[0].wait()
-
     for _ in range(args.warmup):
-        step()
-    drain()
+        sf.step(d_img)
+    sf.drain()
     ctx.sync(allow_capacity=True)
     ctx.profile_enable(True)
     if world > 1:
@@ -196,8 +191,8 @@ def main() -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    drain()  # every gather of the timed steps has completed inside the timed region
+        sf.step(d_img)
+    sf.drain()  # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -210,22 +205,46 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    counts = d_counts.cpu().numpy()
-    nm = d_nmatches.cpu().numpy()
+    counts = sf.counts.cpu().numpy()
+    nm = sf.nmatches.cpu().numpy()
+    nfeat = sf.nfeat.cpu().numpy()
+    payload_bytes = int(sf.local_payload(sf.step_idx - 1)[12:16].view(torch.int32).item())
     if rank == 0:
         total_frames = world * B * args.steps
         value = total_frames / elapsed
         alg = stage_algorithmic_bytes(ctx, 2 * B, B, NF)
+        pmc = committed_counters(W, H, NF, B)
         dom = max(stages, key=lambda k: stages[k][0])
         dom_ms, dom_launches = stages[dom]
         per_launch_bytes = alg[dom] * args.steps / max(dom_launches, 1)
         per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9
-        traffic = args.traffic
-        if traffic is None:
-            t_step = measured_traffic(dom, W, H, NF, B)
-            if t_step is not None:
-                traffic = t_step * args.steps / max(dom_launches, 1)
+        traffic = pmc.get(dom, {}).get("hbm_bytes_per_step")
+        if traffic is not None:
+            traffic = float(traffic) * args.steps / max(dom_launches, 1)
+        # VALU roofline of the same kernel: wave64 VALU instructions per step from the committed SQ_INSTS_VALU pass
+        # divided by the stage time measured in THIS run, against 1024 SIMDs x 2.4 GHz / 4 cycles per instruction
+        valu = None
+        insts = pmc.get(dom, {}).get("valu_wave_insts_per_step")
+        if insts:
+            a = float(insts) * args.steps / (dom_ms * 1e-3) / 1e9
+            valu = {"bound": "valu", "kernel": dom, "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
+                    "frac": a / VALU_PEAK_GINST, "valu_wave_insts_per_launch": float(insts) * args.steps / max(dom_launches, 1),
+                    "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass) / stage time of this run"}
+        hbm_frac = achieved / HBM_PEAK_GBS
+        bound = "valu" if valu and valu["frac"] > hbm_frac else "hbm"
+        # matcher (K9): pair distances per second of the stereo knn2 launches and the int8 matrix-core rate they imply
+        # (a 256-bit distance is 256 int8 multiply-adds on the MFMA pipe = 512 ops)
+        knn_ms, knn_launches = stages.get("hamming_knn2", (0.0, 0))
+        matcher = None
+        if knn_ms > 0:
+            mean_n = float(counts.mean())
+            pairs_per_step = B * mean_n * mean_n  # stereo L->R; the R'->L' and temporal launches are ~1 % of that
+            dps = pairs_per_step * args.steps / (knn_ms * 1e-3)
+            matcher = {"pair_distances_per_s": dps, "int8_mfma_tops": dps * 512 / 1e12,
+                       "frac_of_int8_mfma_peak": dps * 512 / 1e12 / MFMA_I8_PEAK_TOPS, "peak_tops": MFMA_I8_PEAK_TOPS,
+                       "ms_per_step": knn_ms / args.steps,
+                       "note": "all knn2 launches of a step (stereo + R'->L' + temporal) over the stereo pair count"}
         device_ms = sum(v[0] for v in stages.values())
         out = {
             "metric": "stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
@@ -233,18 +252,25 @@ def main() -> int:
             "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %dx%d stereo stream, nfeatures=%d, ORB(1.04, 50 levels, "
-                                   "edge 31, FAST 20, Harris) + Hamming 2-NN + ratio 0.6f; extract(L)+extract(R)+"
-                                   "GetMatches(L,R)" % (W, H, NF),
-                       "frames_per_step_per_gpu": B, "global_frames_per_step": world * B,
+            "config": {"workload": "%s: %dx%d stereo stream, nfeatures=%d, ORB(1.04, 50 levels, edge 31, FAST 20, Harris) + "
+                                   "Hamming 2-NN + ratio 0.6f; extract(L)+extract(R)+GetMatches(L,R), then RemoveAmbigStereo, "
+                                   "GetFeatureMatches x%d, Calculate3DPoints, packed VisionFeature/FeatureMatch payload"
+                                   % (cfg["label"] if (W, H, NF) == (cfg["width"], cfg["height"], cfg["nfeatures"])
+                                      else "custom", W, H, NF, args.window),
+                       "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "scene": args.scene,
                        "parallelism": "frames sharded over %d GPU(s)%s" %
-                                      (world, ", RCCL gather of keypoints+matches to rank 0" if world > 1 else ""),
+                                      (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
+                                              "(RCCL)" if world > 1 else ""),
                        "mean_keypoints_per_image": float(counts.mean()), "mean_stereo_matches": float(nm.mean()),
+                       "mean_features_per_frame": float(nfeat.mean()), "payload_bytes_per_step_per_gpu": payload_bytes,
+                       "parity": "bit-exact vs the in-repo oracle (a restatement of OpenCV 3.2; parity with OpenCV itself unpinned)",
                        "capacity_overflow": bool(status == capi.VSF_ERR_CAPACITY)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_frac, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "launches": dom_launches},
+            "roofline_valu": valu,
+            "matcher": matcher,
             # every streaming stage against the same roofline (algorithmic bytes / measured stage time)
             "streaming_stages_gbs": {k: alg[k] * args.steps / (stages[k][0] * 1e-3) / 1e9
                                      for k in ("pyramid_resize", "fast_score_nms", "gauss_blur7") if stages[k][0] > 0},

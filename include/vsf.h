@@ -174,7 +174,8 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
  * starts at 10000, cc:353).  d_thr_override: NULL, or a DEVICE array of n_frames thresholds applied as they are
  * (multi-GPU: every rank derives them from all ranks' means, vision_slam_frontend_amd/distributed.py).
  * Outputs (device): d_means [n_frames]: mean residual over ALL matches of the frame, summed in match order (NaN for
- * a frame without matches: the reference divides 0/0 there, here the threshold is left unchanged); d_thr
+ * a frame without matches: 0/0 as in the reference, whose static is then NaN for exactly the next frame -- that frame
+ * keeps nothing -- and finite again afterwards; reproduced); d_thr
  * [n_frames + 1]: threshold applied to each frame and the one in force after the batch (written without override);
  * d_kp_out / d_desc_out / d_counts_out: both frames rebuilt from the surviving pairs in match order (row i of the
  * left frame matches row i of the right frame, cc:396-397), layouts as the inputs. */
@@ -191,6 +192,68 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
 vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
                                          size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
                                          int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs);
+
+/* The three steps of vsf_remove_ambig_stereo_batch_dev as separate calls, for the multi-GPU path: a rank computes the
+ * residuals and per-frame means of ITS frames, all ranks exchange the means (one float per frame), every rank derives
+ * the thresholds of the whole time-ordered step and filters its own frames (slam_frontend.cc:353, 392-394).
+ * vsf_stereo_residuals_batch_dev keeps the residuals inside the context for the vsf_stereo_filter_batch_dev that follows. */
+vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const vsf_dmatch* d_matches,
+                                          const int32_t* d_nmatches, int n_frames, const float* F, float* d_means);
+/* d_means [n]: the means of n consecutive frames in time order (all ranks' frames of one step).  d_thr_state: ONE device
+ * float, the threshold in force before frame 0 (initialise it to 10000, cc:353); it is advanced to the value in force
+ * after frame n - 1.  d_thr [n]: thr[0] = state, thr[k] = means[k - 1] + 2. */
+vsf_status vsf_stereo_thresholds_dev(vsf_ctx* ctx, const float* d_means, int n, float* d_thr_state, float* d_thr);
+vsf_status vsf_stereo_filter_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const uint8_t* d_desc,
+                                       const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_frames,
+                                       const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
+                                       int32_t* d_counts_out);
+
+/* ---------------- VisionFeature on the device ---------------- */
+
+/* Stereo calibration as Frontend uses it (FrontendConfig, slam_frontend.cc:565-644); all row-major floats. */
+typedef struct {
+  float projection_left[12];   /* config_.projection_left  = K_left  * [I | 0]   (cc:595-600, 619-622) */
+  float projection_right[12];  /* config_.projection_right = K_right * A_right   (cc:602-611) */
+  float camera_matrix_left[9]; /* config_.camera_matrix_left (cc:575-578) */
+  float distortion_left[5];    /* k1 k2 p1 p2 k3 (cc:623-628) */
+  float fundamental[9];        /* config_.fundamental (cc:635-644) */
+  /* Rows of the DLT system cv::triangulatePoints solves per point: 6 = OpenCV <= 3.4.1 incl. the pinned 3.2.0
+   * (x*P2-P0, y*P2-P1, x*P1-y*P0 per view), 4 = OpenCV >= 3.4.2 (third row dropped).  0 means 6. */
+  int32_t triangulate_rows;
+} vsf_calibration;
+
+/* slam_types::VisionFeature (slam_types.h:60-75 / VisionFeature.msg) as a 28-byte record: uint64 feature_idx (two
+ * words, little endian), Vector2f pixel, Vector3f point3d. */
+typedef struct {
+  uint32_t feature_idx_lo, feature_idx_hi;
+  float pixel[2];
+  float point3d[3];
+} vsf_vision_feature;
+/* slam_types::FeatureMatch (slam_types.h:77-89 / FeatureMatch.msg). */
+typedef struct {
+  uint64_t feature_idx_initial, feature_idx_current;
+} vsf_feature_match;
+
+/* The tail of Frontend::ObserveImage (slam_frontend.cc:437-443) for n_frames frames whose left / right frames were
+ * rebuilt by RemoveAmbigStereo (layouts of vsf_remove_ambig_stereo_batch_dev's outputs: set 2f = left, 2f + 1 = right):
+ * Calculate3DPoints (GetFeatureMatches(right, left) with best_percent 1, cv::triangulatePoints in sorted-match order,
+ * (x,y,z)/w), VisionFeature(i, keypoint i, points[i]) -- a zero point where the reference's points[i] does not exist
+ * (its quirk Q5) -- and UndistortFeaturePoints (cv::undistortPoints with P = K_left).
+ * d_features [n_frames][max_keypoints], d_nfeatures [n_frames]; d_npoints [n_frames] (may be NULL): triangulated points
+ * per frame.  Floating point: agrees with OpenCV to rounding (1e-5 relative), not bit for bit. */
+vsf_status vsf_vision_features_batch_dev(vsf_ctx* ctx, const vsf_calibration* calib, const vsf_keypoint* d_kp,
+                                         const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
+                                         vsf_vision_feature* d_features, int32_t* d_nfeatures, int32_t* d_npoints);
+
+/* Compact output payload of a batch (what a rank sends to rank 0): counts first, then records sized by the counts.
+ *   u32 magic 'VSF1', n_frames, n_pairs, total_bytes | u32 nfeatures[n_frames] | u32 npairs[n_pairs] |
+ *   vsf_vision_feature x sum(nfeatures), frame after frame | vsf_feature_match x sum(npairs), pair after pair
+ * d_pairs / d_npairs: outputs of vsf_feature_matches_batch_dev ([n_pairs][max_keypoints][2] uint64); n_pairs may be 0.
+ * Needs payload_cap >= vsf_packed_outputs_capacity(ctx, n_frames, n_pairs) to be safe for any counts. */
+size_t vsf_packed_outputs_capacity(const vsf_ctx* ctx, int n_frames, int n_pairs);
+vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_features, const int32_t* d_nfeatures,
+                                int n_frames, const uint64_t* d_pairs, const int32_t* d_npairs, int n_pairs,
+                                uint8_t* d_payload, size_t payload_cap);
 
 /* SURVEY section 8(f) row f4, the part behind cv::imdecode: DecodeImage's cvtColor(COLOR_BayerBG2BGR) +
  * cvtColor(COLOR_BGR2GRAY) (slam_frontend_main.cc:101-106) for n 8-bit mosaics of width x height resident in HBM, in
@@ -224,9 +287,9 @@ vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids
 /* Per-stage device timing (hipEvents recorded on the context's stream around every stage of the batched entry
  * points).  vsf_profile_read synchronises the stream, adds the elapsed milliseconds and launch counts of every
  * stage executed since the last reset into ms_total[] / launches[] (VSF_STAGE_COUNT entries each). */
-#define VSF_STAGE_COUNT 7
+#define VSF_STAGE_COUNT 8
 enum { VSF_STAGE_PYRAMID = 0, VSF_STAGE_FAST, VSF_STAGE_SELECT, VSF_STAGE_BLUR, VSF_STAGE_DESCRIBE, VSF_STAGE_KNN2,
-       VSF_STAGE_RATIO };
+       VSF_STAGE_RATIO, VSF_STAGE_TAIL /* residuals, thresholds, filter, sort + trim, 3-D points, pack */ };
 vsf_status vsf_profile_enable(vsf_ctx* ctx, int on);
 vsf_status vsf_profile_read(vsf_ctx* ctx, double* ms_total, int64_t* launches, int reset);
 const char* vsf_stage_name(int stage);

@@ -19,7 +19,8 @@ _LIB_PATH = _DIR / "libvsf_oracle.so"
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                            ("octave", "<i4"), ("class_id", "<i4")])
 DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
-assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
+VISION_FEATURE_DTYPE = np.dtype([("feature_idx", "<u8"), ("pixel", "<f4", (2,)), ("point3d", "<f4", (3,))])
+assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and VISION_FEATURE_DTYPE.itemsize == 28
 
 
 class OrbParams(C.Structure):
@@ -73,6 +74,9 @@ def lib() -> C.CDLL:
         L.vsfo_sort_and_trim.argtypes = [vp, i32, f32]
         L.vsfo_remove_ambig_stereo.argtypes = [vp, vp, vp, i32, vp, C.POINTER(f32), vp, vp]
         L.vsfo_bayer_bg_to_gray.argtypes = [vp, i32, i32, sz, vp, sz]
+        L.vsfo_triangulate_points.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+        L.vsfo_undistort_points.argtypes = [vp, i32, vp, vp, vp]
+        L.vsfo_vision_features.argtypes = [vp, vp, vp, vp, i32, C.c_double, vp, vp, vp, vp, i32, vp, C.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -254,3 +258,48 @@ def bayer_bg_to_gray(mosaic: np.ndarray) -> np.ndarray:
     if lib().vsfo_bayer_bg_to_gray(_p(m), m.shape[1], m.shape[0], m.strides[0], _p(out), out.strides[0]) != 0:
         raise ValueError("vsfo_bayer_bg_to_gray")
     return out
+
+
+def triangulate_points(P1: np.ndarray, P2: np.ndarray, pts1: np.ndarray, pts2: np.ndarray, rows: int = 6) -> np.ndarray:
+    """cv::triangulatePoints for float32 inputs; returns (n, 4) float32 homogeneous points."""
+    P1 = np.ascontiguousarray(P1, np.float32).reshape(12)
+    P2 = np.ascontiguousarray(P2, np.float32).reshape(12)
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    out = np.zeros((max(len(a), 1), 4), np.float32)
+    if lib().vsfo_triangulate_points(_p(P1), _p(P2), _p(a), _p(b), len(a), rows, _p(out)) != 0:
+        raise ValueError("vsfo_triangulate_points")
+    return out[:len(a)]
+
+
+def undistort_points(pts: np.ndarray, K: np.ndarray, dist: np.ndarray) -> np.ndarray:
+    """cv::undistortPoints(pts, K, dist, noArray(), K); (n, 2) float32."""
+    a = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    d = np.ascontiguousarray(dist, np.float32).reshape(5)
+    out = np.zeros((max(len(a), 1), 2), np.float32)
+    if lib().vsfo_undistort_points(_p(a), len(a), _p(K), _p(d), _p(out)) != 0:
+        raise ValueError("vsfo_undistort_points")
+    return out[:len(a)]
+
+
+def vision_features(left: np.ndarray, left_desc: np.ndarray, right: np.ndarray, right_desc: np.ndarray, P_left, P_right,
+                    K_left, dist_left, ratio: float = float(np.float32(0.6)), rows: int = 6):
+    """slam_frontend.cc:437-443 on the two filtered frames; returns (VISION_FEATURE_DTYPE[n], n_points)."""
+    left = np.ascontiguousarray(left, KEYPOINT_DTYPE)
+    right = np.ascontiguousarray(right, KEYPOINT_DTYPE)
+    n = len(left)
+    assert len(right) == n
+    ld = np.ascontiguousarray(left_desc, np.uint8).reshape(-1, 32)
+    rd = np.ascontiguousarray(right_desc, np.uint8).reshape(-1, 32)
+    out = np.zeros(max(n, 1), VISION_FEATURE_DTYPE)
+    npts = C.c_int(0)
+    r = lib().vsfo_vision_features(_p(left), _p(ld), _p(right), _p(rd), n, ratio,
+                                   _p(np.ascontiguousarray(P_left, np.float32).reshape(12)),
+                                   _p(np.ascontiguousarray(P_right, np.float32).reshape(12)),
+                                   _p(np.ascontiguousarray(K_left, np.float32).reshape(9)),
+                                   _p(np.ascontiguousarray(dist_left, np.float32).reshape(5)), rows, _p(out),
+                                   C.byref(npts))
+    if r < 0:
+        raise ValueError("vsfo_vision_features")
+    return out[:n], npts.value

@@ -808,9 +808,216 @@ int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* rig
     if (keep) keep[m] = k;
     kept += k;
   }
-  // Quirk Q3: 0/0 when n == 0 poisons the static with NaN in the reference; the oracle keeps the old value.
-  if (n > 0) *threshold_io = avg / (float)(size_t)n + 2.0f;
+  // cc:392-394, unconditionally: with no match this is 0.0f / 0 + 2 = NaN (quirk Q3).  The NEXT frame is then filtered
+  // against NaN and loses every feature (`constraint <= NaN` is false), but its own mean runs over ALL its matches, so
+  // the frame after that is filtered with a finite threshold again: the NaN lives for exactly one frame.
+  *threshold_io = avg / (float)(size_t)n + 2.0f;
   return kept;
+}
+
+// ---- cv::triangulatePoints / cv::undistortPoints as Calculate3DPoints / UndistortFeaturePoints
+// call them (slam_frontend.cc:117-173, 323-351) ----
+namespace {
+
+// core/src/lapack.cpp: the file-local hypot template the Jacobi routines use (not ::hypot).
+inline double cvLapackHypot(double a, double b) {
+  a = std::abs(a);
+  b = std::abs(b);
+  if (a > b) {
+    b /= a;
+    return a * std::sqrt(1 + b * b);
+  }
+  if (b > 0) {
+    a /= b;
+    return b * std::sqrt(1 + a * a);
+  }
+  return 0;
+}
+
+// core/src/lapack.cpp JacobiSVDImpl_<double> as cv::SVD::compute reaches it for an m x n matrix with m >= n
+// (At = A transposed: row i of At is column i of A; eps = DBL_EPSILON * 10; one-sided Hestenes rotations, at most
+// max(m, 30) sweeps, singular values sorted descending with the rows of Vt swapped along).  U is not computed: only
+// W and Vt are read by cvTriangulatePoints.
+void JacobiSVD64(double* At, int astep, double* W, double* Vt, int vstep, int m, int n) {
+  const double eps = DBL_EPSILON * 10;
+  const int max_iter = std::max(m, 30);
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) {
+      const double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = sd;
+    for (int k = 0; k < n; k++) Vt[i * vstep + k] = 0;
+    Vt[i * vstep + i] = 1;
+  }
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (int i = 0; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        double *Ai = At + i * astep, *Aj = At + j * astep;
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+        if (std::abs(p) <= eps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = cvLapackHypot(p, beta);
+        double c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = std::sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = std::sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < m; k++) {
+          const double t0 = c * Ai[k] + s * Aj[k];
+          const double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+        double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
+        for (int k = 0; k < n; k++) {
+          const double t0 = c * Vi[k] + s * Vj[k];
+          const double t1 = -s * Vi[k] + c * Vj[k];
+          Vi[k] = t0;
+          Vj[k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) {
+      const double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = std::sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      std::swap(W[i], W[j]);
+      for (int k = 0; k < m; k++) std::swap(At[i * astep + k], At[j * astep + k]);
+      for (int k = 0; k < n; k++) std::swap(Vt[i * vstep + k], Vt[j * vstep + k]);
+    }
+  }
+}
+
+}  // namespace
+
+int vsfo_triangulate_points(const float P1[12], const float P2[12], const float* pts1, const float* pts2, int n,
+                            int rows, float* points4d) {
+  // calib3d/src/triangulate.cpp cvTriangulatePoints, reached through cv::triangulatePoints with CV_32F projection
+  // matrices and vector<Point2f> points (slam_frontend.cc:152): every cvmGet widens a float to double, the 4 x n
+  // output has the points' type (CV_32F), cvmSet narrows the double back to float.
+  // rows == 6: OpenCV <= 3.4.1 (incl. the pinned 3.2.0): per view  x*P[2]-P[0],  y*P[2]-P[1],  x*P[1]-y*P[0];
+  // rows == 4: OpenCV >= 3.4.2 / 4.x dropped the third (dependent) row.  SVD of the rows x 4 system, X = Vt row 3.
+  if (!P1 || !P2 || n < 0 || (n > 0 && (!pts1 || !pts2 || !points4d)) || (rows != 6 && rows != 4)) return -1;
+  const float* P[2] = {P1, P2};
+  const float* pts[2] = {pts1, pts2};
+  const int per = rows / 2;
+  for (int i = 0; i < n; i++) {
+    double At[4 * 6], W[4], Vt[16];  // At[k][r] = A[r][k]
+    for (int j = 0; j < 2; j++) {
+      const double x = pts[j][2 * i], y = pts[j][2 * i + 1];
+      for (int k = 0; k < 4; k++) {
+        const double p0 = P[j][k], p1 = P[j][4 + k], p2 = P[j][8 + k];
+        At[k * rows + j * per + 0] = x * p2 - p0;
+        At[k * rows + j * per + 1] = y * p2 - p1;
+        if (per == 3) At[k * rows + j * per + 2] = x * p1 - y * p0;
+      }
+    }
+    JacobiSVD64(At, rows, W, Vt, 4, rows, 4);
+    for (int k = 0; k < 4; k++) points4d[4 * i + k] = (float)Vt[3 * 4 + k];
+  }
+  return 0;
+}
+
+int vsfo_undistort_points(const float* src, int n, const float K[9], const float dist[5], float* dst) {
+  // imgproc/src/undistort.cpp cvUndistortPoints(src, dst, cameraMatrix, distCoeffs, R = NULL, P = cameraMatrix)
+  // (slam_frontend.cc:334-339): camera matrix and coefficients widened to double, 5 fixed-point iterations, then
+  // RR = P * I applied as (RR00*x + RR01*y + RR02) * (1 / (RR20*x + RR21*y + RR22)), result narrowed to float.
+  if (n < 0 || (n > 0 && (!src || !dst)) || !K || !dist) return -1;
+  double A[3][3], k[14] = {0};
+  for (int i = 0; i < 9; i++) A[i / 3][i % 3] = K[i];
+  for (int i = 0; i < 5; i++) k[i] = dist[i];
+  const double fx = A[0][0], fy = A[1][1], ifx = 1. / fx, ify = 1. / fy, cx = A[0][2], cy = A[1][2];
+  const double (*RR)[3] = A;  // matP * identity
+  for (int i = 0; i < n; i++) {
+    double x = src[2 * i], y = src[2 * i + 1];
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    // (k[12] = k[13] = 0: the tilt matrix is the identity; invProj = 1/1)
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+    const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+    const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+    dst[2 * i] = (float)(xx * ww);
+    dst[2 * i + 1] = (float)(yy * ww);
+  }
+  return 0;
+}
+
+int vsfo_vision_features(const vsfo_keypoint* left, const uint8_t* left_desc, const vsfo_keypoint* right,
+                         const uint8_t* right_desc, int n, double nn_match_ratio, const float P_left[12],
+                         const float P_right[12], const float K_left[9], const float dist_left[5], int rows,
+                         vsfo_vision_feature* out, int* n_points) {
+  // slam_frontend.cc:437-443 on the two frames RemoveAmbigStereo left behind (n rows each, row i <-> row i):
+  //   Calculate3DPoints (:117-173): GetFeatureMatches(right, left) with best_percent_ forced to 1.0 (:129-132) ->
+  //   points in SORTED-MATCH order, (x, y, z) / w in float (:159-165);
+  //   features[i] = VisionFeature(i, left.keypoints_[i].pt, points[i]) (:438-442) -- indexed by KEYPOINT although
+  //   `points` is in match order and may be shorter (quirk Q5: out-of-range read in the reference; a zero point here);
+  //   UndistortFeaturePoints (:323-351).
+  if (n < 0 || !out) return -1;
+  std::vector<vsfo_dmatch> m((size_t)std::max(n, 1));
+  int nm = n > 0 ? GetMatches(right_desc, n, left_desc, n, nn_match_ratio, m.data(), n, 1) : 0;
+  nm = vsfo_sort_and_trim(m.data(), nm, 1.0f);
+  std::vector<float> lp((size_t)2 * std::max(nm, 1)), rp((size_t)2 * std::max(nm, 1)), X((size_t)4 * std::max(nm, 1));
+  for (int i = 0; i < nm; i++) {
+    const vsfo_keypoint& l = left[m[i].trainIdx];   // match.feature_idx_current  (cc:137)
+    const vsfo_keypoint& r = right[m[i].queryIdx];  // match.feature_idx_initial  (cc:139)
+    lp[2 * i] = l.x, lp[2 * i + 1] = l.y;
+    rp[2 * i] = r.x, rp[2 * i + 1] = r.y;
+  }
+  if (nm > 0 && vsfo_triangulate_points(P_left, P_right, lp.data(), rp.data(), nm, rows, X.data()) != 0) return -1;
+  std::vector<float> px((size_t)2 * std::max(n, 1)), ux((size_t)2 * std::max(n, 1));
+  for (int i = 0; i < n; i++) px[2 * i] = left[i].x, px[2 * i + 1] = left[i].y;
+  if (vsfo_undistort_points(px.data(), n, K_left, dist_left, ux.data()) != 0) return -1;
+  for (int i = 0; i < n; i++) {
+    vsfo_vision_feature f;
+    f.feature_idx_lo = (uint32_t)i;
+    f.feature_idx_hi = 0;
+    f.pixel[0] = ux[2 * i];
+    f.pixel[1] = ux[2 * i + 1];
+    if (i < nm) {
+      const float w = X[4 * i + 3];
+      f.point3d[0] = X[4 * i] / w;
+      f.point3d[1] = X[4 * i + 1] / w;
+      f.point3d[2] = X[4 * i + 2] / w;
+    } else {
+      f.point3d[0] = f.point3d[1] = f.point3d[2] = 0.f;
+    }
+    out[i] = f;
+  }
+  if (n_points) *n_points = nm;
+  return n;
 }
 
 int vsfo_bayer_bg_to_gray(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride) {

@@ -125,6 +125,27 @@ int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* rig
                              const vsfo_dmatch* matches, int n, const float F[9], float* threshold_io,
                              uint8_t* keep, float* residual);
 
+/* ---- Calculate3DPoints / UndistortFeaturePoints (slam_frontend.cc:117-173, 323-351) ---- */
+/* slam_types::VisionFeature as it travels (slam_types.h:60-75; 28 bytes: u64 index, pixel, point3d). */
+typedef struct {
+  uint32_t feature_idx_lo, feature_idx_hi;
+  float pixel[2];
+  float point3d[3];
+} vsfo_vision_feature;
+/* cv::triangulatePoints(P1, P2, pts1, pts2) for CV_32F inputs (calib3d/src/triangulate.cpp cvTriangulatePoints +
+ * core/src/lapack.cpp JacobiSVDImpl_<double>): pts are n x 2, points4d is n x 4 (column i of OpenCV's 4 x n output).
+ * rows: 6 = OpenCV <= 3.4.1 (the pinned 3.2.0), 4 = later versions (third row of each view dropped). */
+int vsfo_triangulate_points(const float P1[12], const float P2[12], const float* pts1, const float* pts2, int n,
+                            int rows, float* points4d);
+/* cv::undistortPoints(src, dst, K, dist, noArray(), K) (imgproc/src/undistort.cpp cvUndistortPoints). */
+int vsfo_undistort_points(const float* src, int n, const float K[9], const float dist[5], float* dst);
+/* slam_frontend.cc:437-443: Calculate3DPoints + VisionFeature(i, pt_i, points[i]) + UndistortFeaturePoints on the
+ * two frames RemoveAmbigStereo rebuilt (n rows each).  Returns n; *n_points = number of triangulated points. */
+int vsfo_vision_features(const vsfo_keypoint* left, const uint8_t* left_desc, const vsfo_keypoint* right,
+                         const uint8_t* right_desc, int n, double nn_match_ratio, const float P_left[12],
+                         const float P_right[12], const float K_left[9], const float dist_left[5], int rows,
+                         vsfo_vision_feature* out, int* n_points);
+
 /* ---- image ingest (the part after cv::imdecode): slam_frontend_main.cc:101-106 ----
  * cv::cvtColor(COLOR_BayerBG2BGR) (imgproc/demosaicing.cpp Bayer2RGB_<uchar>: bilinear, the one-pixel frame copied
  * from its neighbours) followed by cv::cvtColor(COLOR_BGR2GRAY) (color.cpp RGB2Gray<uchar>: (1868 B + 9617 G + 4899 R +

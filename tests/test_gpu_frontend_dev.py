@@ -25,8 +25,9 @@ def batch(capi):
     """Four time-ordered stereo frames through the benchmarked entry point; everything stays on the device."""
     from vision_slam_frontend_amd import synth
     frames = synth.stereo_stream(4, 640, 480)
-    # frame 2 gets a blank right image: no stereo matches there (quirk Q3: the threshold must carry over)
-    frames[2, 1] = 128
+    # frame 1 gets a blank right image: no stereo matches there (quirk Q3: frame 2 is then filtered against NaN and keeps
+    # nothing, frame 3 is filtered normally again)
+    frames[1, 1] = 128
     B = len(frames)
     dev = torch.device("cuda", 0)
     p = capi.default_params(640, 480, max_images=2 * B, nfeatures=NF)
@@ -72,16 +73,20 @@ def test_remove_ambig_stereo_chain(batch, oracle):
     desc2, counts2 = _np(t["desc2"]), _np(t["counts2"])
     means, thr = _np(t["means"]), _np(t["thr"])
     cur = np.float32(10000.0)
-    assert nm[2] == 0 and nm[0] > 50
+    assert nm[1] == 0 and nm[0] > 50 and nm[2] > 50 and nm[3] > 50
     for f in range(B):
         kl, kr = kp[2 * f, :counts[2 * f]], kp[2 * f + 1, :counts[2 * f + 1]]
         mm = m[f, :nm[f]]
-        assert thr[f] == cur, "threshold applied to frame %d" % f
+        assert thr[f].tobytes() == cur.tobytes() or (np.isnan(thr[f]) and np.isnan(cur)), "threshold applied to frame %d" % f
         keep, res, thr_new, kept = oracle.remove_ambig_stereo(kl, kr, mm, F_RECT, float(cur))
         if nm[f] == 0:
-            assert np.isnan(means[f]) and np.float32(thr_new) == cur  # unchanged (quirk Q3)
+            assert np.isnan(means[f]) and np.isnan(thr_new)  # 0/0 + 2 (quirk Q3) ...
         else:
             assert np.float32(means[f] + np.float32(2.0)) == np.float32(thr_new), "ordered mean of frame %d" % f
+        if f == 2:
+            assert np.isnan(cur) and kept == 0 and counts2[4] == 0  # ... the frame after it keeps nothing ...
+        if f == 3:
+            assert np.isfinite(cur) and 0 < kept < nm[3]  # ... and the one after that is filtered normally again
         cur = np.float32(thr_new)
         assert counts2[2 * f] == counts2[2 * f + 1] == kept
         q, tr = mm["queryIdx"][keep], mm["trainIdx"][keep]
@@ -91,13 +96,13 @@ def test_remove_ambig_stereo_chain(batch, oracle):
         np.testing.assert_array_equal(desc2[2 * f + 1, :kept], desc[2 * f + 1][tr])
     assert thr[B] == cur
     # the first frame passes everything (threshold 10000), later frames are filtered by mean + 2
-    assert counts2[0] == nm[0] and 0 < counts2[2] < nm[1]
+    assert counts2[0] == nm[0] and 0 < counts2[6] < nm[3]
 
 
 def test_threshold_override(batch, capi):
     ctx, t, B, K = batch
     dev = t["kp"].device
-    over = torch.tensor([0.5, 1e9, 0.0, 3.0], dtype=torch.float32, device=dev)
+    over = torch.tensor([0.5, 0.0, 1e9, 3.0], dtype=torch.float32, device=dev)
     counts3 = torch.zeros(2 * B, dtype=torch.int32, device=dev)
     means3 = torch.zeros(B, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -106,7 +111,7 @@ def test_threshold_override(batch, capi):
                                       t["desc2"].data_ptr(), counts3.data_ptr())
     assert ctx.sync() == capi.VSF_OK
     c3, nm = counts3.cpu().numpy(), t["nm"].cpu().numpy()
-    assert c3[2] == nm[1] and c3[0] < nm[0]
+    assert c3[4] == nm[2] > 0 and c3[0] < nm[0]
     np.testing.assert_array_equal(means3.cpu().numpy().view(np.uint32), t["means"].cpu().numpy().view(np.uint32))
     # restore the chained result for the tests below
     ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
@@ -120,8 +125,8 @@ def test_feature_matches_sorted_and_trimmed(batch, oracle, capi, best_percent):
     """Temporal factors (cc:424-434): every earlier filtered left frame against the newest one, one call."""
     ctx, t, B, K = batch
     dev = t["kp"].device
-    past = [0, 1]  # frames with survivors (frame 2 is empty)
-    q_set = torch.tensor([2 * f for f in past] + [4], dtype=torch.int32, device=dev)  # incl. the empty frame 2
+    past = [0, 1]  # frame 0 has survivors; frames 1 (no stereo match) and 2 (NaN threshold) are empty
+    q_set = torch.tensor([2 * f for f in past] + [4], dtype=torch.int32, device=dev)
     t_set = torch.tensor([6] * 3, dtype=torch.int32, device=dev)
     npairs = 3
     d_pairs = torch.zeros((npairs, K, 2), dtype=torch.int64, device=dev)
@@ -142,4 +147,4 @@ def test_feature_matches_sorted_and_trimmed(batch, oracle, capi, best_percent):
         np.testing.assert_array_equal(pairs[i, :len(mm), 0], mm["queryIdx"], err_msg="pair %d initial idx" % i)
         np.testing.assert_array_equal(pairs[i, :len(mm), 1], mm["trainIdx"], err_msg="pair %d current idx" % i)
         total += len(mm)
-    assert npr[2] == 0 and total > 20
+    assert npr[2] == 0 and total > 10

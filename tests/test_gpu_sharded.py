@@ -1,0 +1,115 @@
+"""BASELINE configs[3] with real kernels: two ranks share ONE GPU (gloo between them -- RCCL refuses two ranks on one
+device) and run the sharded hot path of vision_slam_frontend_amd.distributed.ShardedStereoFrontend: all-gather of the
+per-frame means -> device thresholds -> RemoveAmbigStereo filter -> tail exchange for the temporal pairs ->
+Calculate3DPoints -> compact VisionFeature / FeatureMatch payload -> gather to rank 0.  Rank 0's gathered frames must
+be BYTE-IDENTICAL to a single-process run over the same frames -- including the RemoveAmbigStereo threshold that
+crosses the rank boundary (slam_frontend.cc:353, 392-398), its NaN case (quirk Q3) and the temporal predecessor that
+lives on the other rank."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = Path(__file__).resolve().parent.parent
+W_IMG, H_IMG, NF = 320, 240, 600
+B, STEPS, WORLD, WINDOW = 3, 3, 2, 2
+F_RECT = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # l^T F r = y_r - y_l on the rectified synthetic pair
+
+
+def _calibration():
+    from vision_slam_frontend_amd import frontend
+    return frontend.default_calibration().set("fundamental", F_RECT)
+
+
+def _run(frames, frames_per_rank, rank, world):
+    """All steps of one rank; returns the ShardedStereoFrontend (drained)."""
+    from vision_slam_frontend_amd import capi
+    from vision_slam_frontend_amd import distributed as vd
+    dev = torch.device("cuda", 0)
+    ctx = capi.Context(capi.default_params(W_IMG, H_IMG, max_images=2 * frames_per_rank, nfeatures=NF))
+    sf = vd.ShardedStereoFrontend(ctx, frames_per_rank, W_IMG, H_IMG, _calibration(), window=WINDOW, device=dev)
+    local = []
+    for s in range(STEPS):
+        idx = list(vd.frame_block(s, frames_per_rank, world, rank))
+        d_img = torch.from_numpy(np.ascontiguousarray(frames[idx])).to(dev)
+        sf.step(d_img)
+        if world == 1:
+            sf.stream.synchronize()
+            local.append((s, [sf.local_payload(s).cpu().clone()]))
+    sf.drain()
+    assert ctx.sync() == capi.VSF_OK
+    return sf, local, ctx
+
+
+def _worker(rank: int, world: int, port: int, frames_path: str, out_path: str):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        frames = np.load(frames_path)
+        sf, _, ctx = _run(frames, B, rank, world)
+        if rank == 0:
+            assert [c[0] for c in sf.completed] == list(range(STEPS))
+            np.savez(out_path, **{"s%d_r%d" % (st, r): pl.cpu().numpy() for st, per in sf.completed
+                                  for r, pl in enumerate(per)})
+        else:
+            assert not sf.completed
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_equal_one_process(tmp_path):
+    import torch.multiprocessing as mp
+
+    from vision_slam_frontend_amd import distributed as vd
+    from vision_slam_frontend_amd import synth
+
+    n = WORLD * B * STEPS
+    frames = synth.stereo_stream(n, W_IMG, H_IMG, n_objects=400)
+    frames[B - 1, 1] = 128  # rank 0's last frame of step 0 has no stereo match: rank 1's first frame gets the NaN threshold
+    frames_path, out_path = str(tmp_path / "frames.npy"), str(tmp_path / "gathered.npz")
+    np.save(frames_path, frames)
+
+    # single process: the same frames, world x B per step
+    sf1, local, ctx1 = _run(frames, WORLD * B, 0, 1)
+    want_f, want_m = vd.assemble_outputs(local, 1, WORLD * B, WINDOW)
+    ctx1.close()
+    assert sorted(want_f) == list(range(n))
+
+    mp.spawn(_worker, args=(WORLD, _free_port(), frames_path, out_path), nprocs=WORLD, join=True)
+    z = np.load(out_path)
+    completed = [(s, [z["s%d_r%d" % (s, r)] for r in range(WORLD)]) for s in range(STEPS)]
+    got_f, got_m = vd.assemble_outputs(completed, WORLD, B, WINDOW)
+
+    assert sorted(got_f) == sorted(want_f) and sorted(got_m) == sorted(want_m)
+    for g in range(n):
+        assert got_f[g].tobytes() == want_f[g].tobytes(), "VisionFeature records of global frame %d" % g
+    for key in want_m:
+        assert got_m[key].tobytes() == want_m[key].tobytes(), "FeatureMatch records of factor %s" % (key,)
+    # the cases this test exists for really occurred
+    sizes = [len(want_f[g]) for g in range(n)]
+    assert sizes[B - 1] == 0 and sizes[B] == 0, "empty-match frame, then the NaN-threshold frame on the OTHER rank"
+    assert sizes[B + 1] > 20 and sizes[0] > sizes[1] > 0, "filtering resumes; later frames are filtered by mean + 2"
+    cross = [k for k in want_m if k[0] // B != k[1] // B]  # predecessor on another rank (or the previous step)
+    assert len(cross) >= 2 * (WORLD * STEPS - 1) and sum(len(want_m[k]) for k in cross) > 20
+    assert sum(len(v) for v in want_m.values()) > 40
+    # and the payloads were compact: sized by the counts, not by the capacity
+    assert all(int(pl[:16].view(np.uint32)[3]) < sf1.cap // 4 for _, per in completed for pl in per)

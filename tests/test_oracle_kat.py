@@ -252,9 +252,15 @@ def test_remove_ambig_stereo(oracle):
     assert thr == np.float32(2.0 / 4 + 2.0)
     keep, res, thr2, kept = oracle.remove_ambig_stereo(left, right, m, F, 1.0)
     assert keep.tolist() == [True, True, False, True] and kept == 3 and thr2 == thr
-    # no matches: threshold unchanged (the reference would poison it with NaN, quirk Q3)
-    _, _, thr3, _ = oracle.remove_ambig_stereo(left, right, m[:0], F, 3.5)
-    assert thr3 == 3.5
+    # Quirk Q3 (slam_frontend.cc:392-394), frame by frame: frame A has no stereo match -> the static becomes 0/0 + 2 = NaN;
+    # frame B (the frame AFTER the empty one) is filtered against NaN and keeps nothing, but its mean is finite;
+    # frame C is filtered normally again.
+    _, _, thr_a, kept_a = oracle.remove_ambig_stereo(left, right, m[:0], F, 3.5)
+    assert np.isnan(thr_a) and kept_a == 0
+    keep_b, _, thr_b, kept_b = oracle.remove_ambig_stereo(left, right, m, F, thr_a)
+    assert kept_b == 0 and not keep_b.any() and thr_b == np.float32(2.0 / 4 + 2.0)
+    keep_c, _, _, kept_c = oracle.remove_ambig_stereo(left, right, m, F, thr_b)
+    assert kept_c == 4 and keep_c.all()
 
 
 def test_retain_best_keeps_boundary_ties(oracle):

@@ -17,7 +17,11 @@ LIB_PATH = _PKG / "libvsf_hip.so"
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                            ("octave", "<i4"), ("class_id", "<i4")])
 DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+VISION_FEATURE_DTYPE = np.dtype([("feature_idx", "<u8"), ("pixel", "<f4", (2,)), ("point3d", "<f4", (3,))])
+FEATURE_MATCH_DTYPE = np.dtype([("feature_idx_initial", "<u8"), ("feature_idx_current", "<u8")])
+assert VISION_FEATURE_DTYPE.itemsize == 28 and FEATURE_MATCH_DTYPE.itemsize == 16
 DESC_BYTES = 32
+PAYLOAD_MAGIC = 0x31465356  # "VSF1"
 
 VSF_OK, VSF_ERR_INVALID_ARG, VSF_ERR_CAPACITY, VSF_ERR_HIP, VSF_ERR_UNSUPPORTED, VSF_ERR_NO_DEVICE = range(6)
 
@@ -28,9 +32,11 @@ EXPORTS = [
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_pair", "vsf_get_matches_multi", "vsf_extract_batch_dev", "vsf_match_batch_dev",
     "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_bayer_bg_to_gray_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
-    "vsf_stage_name", "vsf_debug_retain_best",
+    "vsf_stage_name", "vsf_debug_retain_best", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
+    "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
+    "vsf_pack_outputs_dev",
 ]
-STAGE_COUNT = 7
+STAGE_COUNT = 8
 
 
 class VsfParams(C.Structure):
@@ -40,6 +46,24 @@ class VsfParams(C.Structure):
                 ("blur_sse2", C.c_int32), ("fast_detector_threshold", C.c_int32), ("fast_detector_nms", C.c_int32),
                 ("ratio_num", C.c_uint32), ("ratio_shift", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
                 ("max_images", C.c_int32), ("max_keypoints", C.c_int32)]
+
+
+class VsfCalibration(C.Structure):
+    """vsf_calibration: FrontendConfig's stereo calibration (slam_frontend.cc:565-644), row-major floats."""
+    _fields_ = [("projection_left", C.c_float * 12), ("projection_right", C.c_float * 12),
+                ("camera_matrix_left", C.c_float * 9), ("distortion_left", C.c_float * 5),
+                ("fundamental", C.c_float * 9), ("triangulate_rows", C.c_int32)]
+
+    def set(self, name: str, values) -> "VsfCalibration":
+        arr = getattr(self, name)
+        v = np.ascontiguousarray(values, np.float32).reshape(-1)
+        assert len(v) == len(arr), name
+        for i, x in enumerate(v):
+            arr[i] = float(x)
+        return self
+
+    def get(self, name: str) -> np.ndarray:
+        return np.array(list(getattr(self, name)), np.float32)
 
 
 class VsfError(RuntimeError):
@@ -90,6 +114,13 @@ def lib() -> C.CDLL:
         L.vsf_remove_ambig_stereo_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.c_float, vp, vp, vp, vp, vp, vp]
         L.vsf_feature_matches_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, C.c_float, vp, vp]
         L.vsf_bayer_bg_to_gray_batch_dev.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, sz, sz]
+        L.vsf_stereo_residuals_batch_dev.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+        L.vsf_stereo_thresholds_dev.argtypes = [vp, vp, i32, vp, vp]
+        L.vsf_stereo_filter_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+        L.vsf_vision_features_batch_dev.argtypes = [vp, C.POINTER(VsfCalibration), vp, vp, vp, i32, vp, vp, vp]
+        L.vsf_packed_outputs_capacity.argtypes = [vp, i32, i32]
+        L.vsf_packed_outputs_capacity.restype = sz
+        L.vsf_pack_outputs_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, sz]
         L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
         L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
         L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
@@ -285,6 +316,37 @@ class Context:
                                                         _p(d_t_set), n_pairs, best_percent, _p(d_pairs), _p(d_npairs)),
                     "vsf_feature_matches_batch_dev")
 
+    def stereo_residuals_batch_dev(self, d_kp: int, d_matches: int, d_nmatches: int, n_frames: int, F: np.ndarray,
+                                   d_means: int):
+        Fh = np.ascontiguousarray(F, np.float32).reshape(9)
+        self._check(lib().vsf_stereo_residuals_batch_dev(self._h, _p(d_kp), _p(d_matches), _p(d_nmatches), n_frames,
+                                                         _p(Fh), _p(d_means)), "vsf_stereo_residuals_batch_dev")
+
+    def stereo_thresholds_dev(self, d_means: int, n: int, d_thr_state: int, d_thr: int):
+        self._check(lib().vsf_stereo_thresholds_dev(self._h, _p(d_means), n, _p(d_thr_state), _p(d_thr)),
+                    "vsf_stereo_thresholds_dev")
+
+    def stereo_filter_batch_dev(self, d_kp: int, d_desc: int, d_matches: int, d_nmatches: int, n_frames: int,
+                                d_thr: int, d_kp_out: int, d_desc_out: int, d_counts_out: int):
+        self._check(lib().vsf_stereo_filter_batch_dev(self._h, _p(d_kp), _p(d_desc), _p(d_matches), _p(d_nmatches),
+                                                      n_frames, _p(d_thr), _p(d_kp_out), _p(d_desc_out),
+                                                      _p(d_counts_out)), "vsf_stereo_filter_batch_dev")
+
+    def vision_features_batch_dev(self, calib: VsfCalibration, d_kp: int, d_desc: int, d_counts: int, n_frames: int,
+                                  d_features: int, d_nfeatures: int, d_npoints: int = 0):
+        self._check(lib().vsf_vision_features_batch_dev(self._h, C.byref(calib), _p(d_kp), _p(d_desc), _p(d_counts),
+                                                        n_frames, _p(d_features), _p(d_nfeatures), _p(d_npoints)),
+                    "vsf_vision_features_batch_dev")
+
+    def packed_outputs_capacity(self, n_frames: int, n_pairs: int) -> int:
+        return int(lib().vsf_packed_outputs_capacity(self._h, n_frames, n_pairs))
+
+    def pack_outputs_dev(self, d_features: int, d_nfeatures: int, n_frames: int, d_pairs: int, d_npairs: int,
+                         n_pairs: int, d_payload: int, payload_cap: int):
+        self._check(lib().vsf_pack_outputs_dev(self._h, _p(d_features), _p(d_nfeatures), n_frames, _p(d_pairs),
+                                               _p(d_npairs), n_pairs, _p(d_payload), payload_cap),
+                    "vsf_pack_outputs_dev")
+
     def bayer_bg_to_gray_batch_dev(self, d_src: int, n_images: int, width: int, height: int, src_image_stride: int,
                                    src_row_stride: int, d_dst: int, dst_image_stride: int, dst_row_stride: int):
         """DecodeImage's BayerBG2BGR + BGR2GRAY (slam_frontend_main.cc:101-106) on mosaics resident in HBM."""
@@ -347,3 +409,28 @@ def _u8(img: np.ndarray) -> np.ndarray:
 def _desc(d: np.ndarray) -> np.ndarray:
     d = np.ascontiguousarray(d, np.uint8)
     return d.reshape(-1, DESC_BYTES)
+
+
+def unpack_outputs(payload: np.ndarray):
+    """Inverse of vsf_pack_outputs_dev: (list of VISION_FEATURE_DTYPE arrays per frame, list of FEATURE_MATCH_DTYPE
+    arrays per pair).  `payload`: uint8 array holding at least the packed bytes."""
+    b = np.ascontiguousarray(payload, np.uint8).reshape(-1)
+    hdr = b[:16].view(np.uint32)
+    if int(hdr[0]) != PAYLOAD_MAGIC:
+        raise ValueError("not a packed output payload")
+    nf, npairs, total = int(hdr[1]), int(hdr[2]), int(hdr[3])
+    if total > len(b):
+        raise ValueError("payload truncated: %d of %d bytes" % (len(b), total))
+    counts = b[16:16 + 4 * (nf + npairs)].view(np.uint32).astype(np.int64)
+    off = 16 + 4 * (nf + npairs)
+    feats, matches = [], []
+    for i in range(nf):
+        n = int(counts[i]) * 28
+        feats.append(b[off:off + n].view(VISION_FEATURE_DTYPE).copy())
+        off += n
+    for i in range(npairs):
+        n = int(counts[nf + i]) * 16
+        matches.append(b[off:off + n].view(FEATURE_MATCH_DTYPE).copy())
+        off += n
+    assert off == total
+    return feats, matches

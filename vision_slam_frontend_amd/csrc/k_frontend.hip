@@ -4,9 +4,9 @@
 //   Frontend::RemoveAmbigStereo  (slam_frontend.cc:353-398): epipolar residual |l^T F r| of every stereo match
 //       (float, products accumulated left to right as Eigen's 1x3 * 3x3 * 3x1 does), its mean over ALL matches of
 //       the frame summed sequentially in match order (float addition is not associative), the threshold chain
-//       thr[k] = mean[k-1] + 2 (static stereo_ambig_constraint, cc:353, :392-394; a frame without matches leaves the
-//       threshold unchanged where the reference divides by zero), and the rebuild of both frames
-//       from the surviving pairs in match order (cc:396-397).
+//       thr[k] = mean[k-1] + 2 (static stereo_ambig_constraint, cc:353, :392-394; a frame without matches makes it
+//       0/0 + 2 = NaN for exactly the next frame, which then keeps nothing -- SURVEY quirk Q3, reproduced), and the
+//       rebuild of both frames from the surviving pairs in match order (cc:396-397).
 //   Frontend::GetFeatureMatches  (slam_frontend.cc:282-309): std::sort of the ratio-tested matches by
 //       DMatch::operator< (distance only; unstable, so the permutation is libstdc++'s introsort + insertion sort,
 //       restated in vsf_select.h) and the cut to  int(size * best_percent)  pairs (float product, cc:290).
@@ -54,15 +54,15 @@ __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint
   }
 }
 
-// ---- step 2: thr[0] = thr_in, thr[k] = mean[k-1] + 2 unless frame k-1 had no match; thr[n] = value after the batch ----
+// ---- step 2: thr[0] = thr_in, thr[k] = mean[k-1] + 2 (NaN when frame k-1 had no match: frame k then keeps nothing, and
+// frame k+1 is back to a finite threshold, exactly as the reference's static behaves); thr[n] = value after the batch ----
 __global__ void stereo_threshold_chain_kernel(const float* __restrict__ mean, int n, float thr_in,
                                               float* __restrict__ thr) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float cur = thr_in;
   for (int k = 0; k < n; k++) {
     thr[k] = cur;
-    const float m = mean[k];
-    if (m == m) cur = m + 2.0f;  // padding_from_average, cc:392
+    cur = mean[k] + 2.0f;  // padding_from_average, cc:392-394; NaN after a frame without matches (quirk Q3)
   }
   thr[n] = cur;
 }
@@ -167,16 +167,30 @@ __global__ __launch_bounds__(64) void sort_trim_kernel(const vsf_dmatch* __restr
 
 }  // namespace
 
+void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
+                                 int n_frames, int max_rows, const float* d_F, float* d_residual, float* d_mean,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_matches, d_nmatches, max_rows,
+                     d_F, d_residual, d_mean);
+}
+
+void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
+                                   const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_residual,
+                                   const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
+                                   int32_t* d_counts_out, hipStream_t s) {
+  hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_desc, d_matches, d_nmatches,
+                     max_rows, d_residual, d_thr, d_kp_out, d_desc_out, d_counts_out);
+}
+
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
                               const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F,
                               const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
                               vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s) {
-  hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_matches, d_nmatches, max_rows,
-                     d_F, d_residual, d_mean);
+  vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, max_rows, d_F, d_residual, d_mean, s);
   if (!d_thr_override)
     hipLaunchKernelGGL(stereo_threshold_chain_kernel, dim3(1), dim3(64), 0, s, d_mean, n_frames, thr_in, d_thr);
-  hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_desc, d_matches, d_nmatches,
-                     max_rows, d_residual, d_thr_override ? d_thr_override : d_thr, d_kp_out, d_desc_out, d_counts_out);
+  vsf_launch_stereo_filter_only(d_kp, d_desc, d_matches, d_nmatches, n_frames, max_rows, d_residual,
+                                d_thr_override ? d_thr_override : d_thr, d_kp_out, d_desc_out, d_counts_out, s);
 }
 
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,

@@ -326,6 +326,13 @@ struct vsf_ctx {
   int32_t* t_nmatches = nullptr;
   void* t_sortkeys = nullptr;
   int t_pairs = 0;
+  // f2 work buffers: right->left pairs of every frame, their set indices, the pack kernel's offsets
+  uint64_t* v_pairs = nullptr;
+  int32_t* v_npairs = nullptr;
+  int32_t* v_sets = nullptr;   // [2][v_frames]: q_set = 2f + 1, t_set = 2f
+  int v_frames = 0;
+  uint32_t* pk_offsets = nullptr;
+  int pk_entries = 0;
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -437,6 +444,19 @@ vsf_status ensure_match_host_staging(vsf_ctx* ctx, int rows) {
   if (!ctx->mh_counts) VSF_HIP(hipMalloc((void**)&ctx->mh_counts, 2 * sizeof(int32_t)));
   if (!ctx->mh_nmatches) VSF_HIP(hipMalloc((void**)&ctx->mh_nmatches, sizeof(int32_t)));
   ctx->mh_rows = rows;
+  return VSF_OK;
+}
+
+vsf_status ensure_residual_buffers(vsf_ctx* ctx, int n_frames) {
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_frames > ctx->f_frames) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->f_residual);
+    ctx->f_residual = nullptr;
+    VSF_HIP(hipMalloc((void**)&ctx->f_residual, (size_t)n_frames * K * sizeof(float)));
+    ctx->f_frames = n_frames;
+  }
+  if (!ctx->f_F) VSF_HIP(hipMalloc((void**)&ctx->f_F, 9 * sizeof(float)));
   return VSF_OK;
 }
 
@@ -794,6 +814,10 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_matches);
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
+  hipFree(ctx->v_pairs);
+  hipFree(ctx->v_npairs);
+  hipFree(ctx->v_sets);
+  hipFree(ctx->pk_offsets);
   hipFree(ctx->mm_desc);
   hipFree(ctx->mm_counts);
   hipFree(ctx->mm_matches);
@@ -952,7 +976,7 @@ vsf_status vsf_profile_read(vsf_ctx* ctx, double* ms_total, int64_t* launches, i
 
 const char* vsf_stage_name(int stage) {
   static const char* names[VSF_STAGE_COUNT] = {"pyramid_resize", "fast_score_nms", "select_harris_angle", "gauss_blur7",
-                                               "orb_describe",   "hamming_knn2",   "ratio_compact"};
+                                               "orb_describe",   "hamming_knn2",   "ratio_compact", "frontend_tail"};
   return (stage >= 0 && stage < VSF_STAGE_COUNT) ? names[stage] : "?";
 }
 
@@ -991,17 +1015,133 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   const size_t K = (size_t)ctx->p.max_keypoints;
-  if (n_frames > ctx->f_frames) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->f_residual);
-    ctx->f_residual = nullptr;
-    VSF_HIP(hipMalloc((void**)&ctx->f_residual, (size_t)n_frames * K * sizeof(float)));
-    ctx->f_frames = n_frames;
+  {
+    vsf_status st = ensure_residual_buffers(ctx, n_frames);
+    if (st != VSF_OK) return st;
   }
-  if (!ctx->f_F) VSF_HIP(hipMalloc((void**)&ctx->f_F, 9 * sizeof(float)));
   VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, ctx->f_F, d_thr_override, thr_in,
                            ctx->f_residual, d_means, d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const vsf_dmatch* d_matches,
+                                          const int32_t* d_nmatches, int n_frames, const float* F, float* d_means) {
+  if (!ctx || !d_kp || !d_matches || !d_nmatches || n_frames < 1 || !F || !d_means) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  vsf_status st = ensure_residual_buffers(ctx, n_frames);
+  if (st != VSF_OK) return st;
+  VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  {
+    StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
+    vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_F, ctx->f_residual,
+                                d_means, ctx->stream);
+  }
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+vsf_status vsf_stereo_thresholds_dev(vsf_ctx* ctx, const float* d_means, int n, float* d_thr_state, float* d_thr) {
+  if (!ctx || !d_means || n < 1 || !d_thr_state || !d_thr) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  {
+    StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
+    vsf_launch_stereo_thresholds(d_means, n, d_thr_state, d_thr, ctx->stream);
+  }
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+vsf_status vsf_stereo_filter_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const uint8_t* d_desc,
+                                       const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_frames,
+                                       const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
+                                       int32_t* d_counts_out) {
+  if (!ctx || !d_kp || !d_desc || !d_matches || !d_nmatches || n_frames < 1 || !d_thr || !d_kp_out || !d_desc_out ||
+      !d_counts_out)
+    return VSF_ERR_INVALID_ARG;
+  if (n_frames > ctx->f_frames || !ctx->f_residual) return VSF_ERR_INVALID_ARG;  // no residuals of such a batch
+  VSF_HIP(hipSetDevice(ctx->device));
+  {
+    StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
+    vsf_launch_stereo_filter_only(d_kp, d_desc, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_residual,
+                                  d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
+  }
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+vsf_status vsf_vision_features_batch_dev(vsf_ctx* ctx, const vsf_calibration* calib, const vsf_keypoint* d_kp,
+                                         const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
+                                         vsf_vision_feature* d_features, int32_t* d_nfeatures, int32_t* d_npoints) {
+  if (!ctx || !calib || !d_kp || !d_desc || !d_counts || n_frames < 1 || !d_features || !d_nfeatures)
+    return VSF_ERR_INVALID_ARG;
+  if (calib->triangulate_rows != 0 && calib->triangulate_rows != 4 && calib->triangulate_rows != 6)
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_frames > ctx->v_frames) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->v_pairs);
+    hipFree(ctx->v_npairs);
+    hipFree(ctx->v_sets);
+    ctx->v_pairs = nullptr;
+    ctx->v_npairs = nullptr;
+    ctx->v_sets = nullptr;
+    ctx->v_frames = 0;
+    VSF_HIP(hipMalloc((void**)&ctx->v_pairs, (size_t)n_frames * K * 2 * sizeof(uint64_t)));
+    VSF_HIP(hipMalloc((void**)&ctx->v_npairs, (size_t)n_frames * sizeof(int32_t)));
+    VSF_HIP(hipMalloc((void**)&ctx->v_sets, (size_t)2 * n_frames * sizeof(int32_t)));
+    std::vector<int32_t> sets((size_t)2 * n_frames);
+    for (int f = 0; f < n_frames; f++) {
+      sets[f] = 2 * f + 1;         // query  = right frame ("initial", cc:131)
+      sets[n_frames + f] = 2 * f;  // train  = left frame  ("current")
+    }
+    VSF_HIP(hipMemcpy(ctx->v_sets, sets.data(), sets.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->v_frames = n_frames;
+  }
+  // Calculate3DPoints: best_percent_ forced to 1.0 (cc:129-132)
+  vsf_status st = vsf_feature_matches_batch_dev(ctx, d_desc, d_counts, K * VSF_DESC_BYTES, ctx->v_sets,
+                                                ctx->v_sets + ctx->v_frames, n_frames, 1.0f, ctx->v_pairs, ctx->v_npairs);
+  if (st != VSF_OK) return st;
+  {
+    StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
+    vsf_launch_vision_features(d_kp, d_counts, ctx->v_pairs, ctx->v_npairs, n_frames, (int)K, *calib, d_features,
+                               d_nfeatures, d_npoints, ctx->stream);
+  }
+  VSF_HIP(hipGetLastError());
+  return VSF_OK;
+}
+
+size_t vsf_packed_outputs_capacity(const vsf_ctx* ctx, int n_frames, int n_pairs) {
+  if (!ctx || n_frames < 0 || n_pairs < 0) return 0;
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  return 16 + 4 * ((size_t)n_frames + n_pairs) + (size_t)n_frames * K * sizeof(vsf_vision_feature) +
+         (size_t)n_pairs * K * sizeof(vsf_feature_match);
+}
+
+vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_features, const int32_t* d_nfeatures,
+                                int n_frames, const uint64_t* d_pairs, const int32_t* d_npairs, int n_pairs,
+                                uint8_t* d_payload, size_t payload_cap) {
+  if (!ctx || n_frames < 0 || n_pairs < 0 || n_frames + n_pairs < 1 || (n_frames > 0 && (!d_features || !d_nfeatures)) ||
+      (n_pairs > 0 && (!d_pairs || !d_npairs)) || !d_payload || ((uintptr_t)d_payload & 3) ||
+      payload_cap < 16 + 4 * ((size_t)n_frames + n_pairs))
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  const int n = n_frames + n_pairs;
+  if (n > ctx->pk_entries) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->pk_offsets);
+    ctx->pk_offsets = nullptr;
+    VSF_HIP(hipMalloc((void**)&ctx->pk_offsets, (size_t)n * sizeof(uint32_t)));
+    ctx->pk_entries = n;
+  }
+  const uint32_t cap = (uint32_t)std::min<size_t>(payload_cap, 0xFFFFFFFCu);
+  {
+    StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 2);
+    vsf_launch_pack_outputs(d_features, d_nfeatures, n_frames, d_pairs, d_npairs, n_pairs, ctx->p.max_keypoints,
+                            d_payload, cap, ctx->pk_offsets, ctx->d_status, ctx->stream);
+  }
   VSF_HIP(hipGetLastError());
   return VSF_OK;
 }
@@ -1047,8 +1187,11 @@ vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, co
   vsf_status st = vsf_match_batch_dev(ctx, d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, nullptr, nullptr,
                                       ctx->t_matches, ctx->t_nmatches);
   if (st != VSF_OK) return st;
-  vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, ctx->t_sortkeys, d_pairs,
-                       d_npairs, ctx->stream);
+  {
+    StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
+    vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, ctx->t_sortkeys, d_pairs,
+                         d_npairs, ctx->stream);
+  }
   VSF_HIP(hipGetLastError());
   return VSF_OK;
 }

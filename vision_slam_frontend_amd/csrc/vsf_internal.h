@@ -136,6 +136,22 @@ void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, c
                               const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F,
                               const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
                               vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s);
+void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
+                                 int n_frames, int max_rows, const float* d_F, float* d_residual, float* d_mean,
+                                 hipStream_t s);
+void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
+                                   const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_residual,
+                                   const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
+                                   int32_t* d_counts_out, hipStream_t s);
+// k_points.hip (SURVEY 8(f) row f2 + the compact gather payload)
+void vsf_launch_stereo_thresholds(const float* d_means, int n, float* d_state, float* d_thr, hipStream_t s);
+void vsf_launch_vision_features(const vsf_keypoint* d_kp, const int32_t* d_counts, const uint64_t* d_pairs,
+                                const int32_t* d_npairs, int n_frames, int max_rows, const vsf_calibration& c,
+                                vsf_vision_feature* d_out, int32_t* d_nfeatures, int32_t* d_npoints, hipStream_t s);
+void vsf_launch_pack_outputs(const vsf_vision_feature* d_features, const int32_t* d_nfeatures, int n_frames,
+                             const uint64_t* d_pairs, const int32_t* d_npairs, int n_pairs, int max_rows,
+                             uint8_t* d_payload, uint32_t cap_bytes, uint32_t* d_offsets, int32_t* d_status,
+                             hipStream_t s);
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
                           float best_percent, void* d_scratch, uint64_t* d_pairs, int32_t* d_npairs, hipStream_t s);
 

@@ -106,17 +106,247 @@ def allgather_frame_means(local_means: torch.Tensor) -> torch.Tensor:
 def stereo_thresholds(frame_means: Sequence[float], first: float = INITIAL_STEREO_AMBIG_CONSTRAINT) -> np.ndarray:
     """Threshold applied to each frame of a time-ordered sequence given every frame's mean residual:
     thr[0] = `first` (the static's value before the sequence), thr[k] = float32(mean[k-1] + 2.0f).
-    A frame without stereo matches (mean is NaN: 0/0 in the reference, quirk Q3) leaves the threshold unchanged."""
+    A frame without stereo matches has mean NaN (0/0 in the reference, quirk Q3): the frame after it is filtered against
+    NaN (keeps nothing), the one after that against a finite threshold again -- as the reference's static behaves."""
     m = np.asarray(frame_means, np.float32)
     thr = np.empty(len(m), np.float32)
-    cur = np.float32(first)
-    for k in range(len(m)):
-        thr[k] = cur
-        if not np.isnan(m[k]):
-            cur = np.float32(m[k] + np.float32(STEREO_AMBIG_PADDING))
+    if len(m):
+        thr[0] = np.float32(first)
+        thr[1:] = m[:-1] + np.float32(STEREO_AMBIG_PADDING)
     return thr
 
 
 def time_ordered(per_rank: torch.Tensor) -> torch.Tensor:
     """(world, frames_per_rank, ...) of ONE step -> (world * frames_per_rank, ...) in global frame order."""
     return per_rank.reshape((-1,) + tuple(per_rank.shape[2:]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The sharded hot path (BASELINE configs[3]; SURVEY.md section 8(e); slam_frontend.cc:400-443 per frame)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class ShardedStereoFrontend:
+    """One rank's share of a time-ordered stereo stream, one step = `frames_per_rank` frames on this GPU.
+
+    Global frame order is step-major, rank-major (frame_block()).  Per step, on the device and stream-ordered:
+
+      1. vsf_stereo_batch_dev                extract(L), extract(R), GetMatches(L, R)          (cc:411-416)   local
+      2. vsf_stereo_residuals_batch_dev      |l^T F r| and the per-frame mean                  (cc:369-383)   local
+      3. all-gather of the means             one float per frame                                              RCCL
+      4. vsf_stereo_thresholds_dev           thr[g] = mean[g-1] + 2 over the step's world x B frames (cc:392-394)
+      5. vsf_stereo_filter_batch_dev         RemoveAmbigStereo's re-indexing                   (cc:384-397)   local
+      6. all-gather of every rank's last `window` filtered left frames (descriptors + counts): the temporal
+         predecessors of the next rank's first frames (rank 0 uses the last rank's tail of the PREVIOUS step)      RCCL
+      7. vsf_feature_matches_batch_dev       GetFeatureMatches(past, current), `window` per frame (cc:424-434) local
+      8. vsf_vision_features_batch_dev       Calculate3DPoints + UndistortFeaturePoints         (cc:437-443)   local
+      9. vsf_pack_outputs_dev                compact VisionFeature / FeatureMatch payload, counts first
+     10. all-gather of the payload sizes (4 bytes per rank), then -- one step later, when the sizes have reached the
+         host without stalling it -- an asynchronous gather of the payloads to rank 0, sized by the counts        RCCL
+
+    With world == 1 the same kernels run and the collectives degenerate to local copies, so bench.py measures the same
+    per-GPU work at every N.  Works on "nccl" (RCCL, device tensors) and, for one-GPU rehearsals and the CPU-side
+    tests of the exchange logic, on "gloo" (tensors take a detour through the host).
+    """
+
+    PAYLOAD_SLOTS = 3
+
+    def __init__(self, ctx, frames_per_rank: int, width: int, height: int, calib, *, window: int = 1,
+                 best_percent: float = 0.3, device=None, stream=None):
+        from . import capi  # noqa: F401  (ctx is a capi.Context)
+
+        self.ctx, self.B, self.W = ctx, int(frames_per_rank), int(window)
+        self.width, self.height = int(width), int(height)
+        self.calib = calib
+        self.best_percent = float(np.float32(best_percent))
+        self.dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.dist_on else 1
+        self.rank = dist.get_rank() if self.dist_on else 0
+        self.host_detour = self.dist_on and dist.get_backend() == "gloo"
+        if not 0 <= self.W <= self.B:
+            raise ValueError("window must be in [0, frames_per_rank]")
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        B, W, world, K = self.B, self.W, self.world, ctx.params.max_keypoints
+        self.K = K
+        self.F = calib.get("fundamental")
+        u8 = torch.uint8
+        with torch.cuda.stream(self.stream):
+            z = lambda *shape, dtype=u8: torch.zeros(shape, dtype=dtype, device=dev)  # noqa: E731
+            self.kp, self.desc, self.counts = z(2 * B, K, 28), z(2 * B, K, 32), z(2 * B, dtype=torch.int32)
+            self.matches, self.nmatches = z(B, K, 16), z(B, dtype=torch.int32)
+            self.means = z(B, dtype=torch.float32)
+            self.means_all = z(world * B, dtype=torch.float32)
+            self.thr_all = z(world * B, dtype=torch.float32)
+            self.thr_state = torch.full((1,), INITIAL_STEREO_AMBIG_CONSTRAINT, dtype=torch.float32, device=dev)
+            # filtered frames: sets 0 .. 2B-1 (2f = left, 2f+1 = right of local frame f), then two regions (step
+            # parity) of world x W gathered tail sets, then one set that stays empty
+            self.tail0 = 2 * B
+            self.empty_set = 2 * B + 2 * world * W
+            nsets = self.empty_set + 1
+            self.kpf = z(2 * B, K, 28)
+            self.descf, self.countsf = z(nsets, K, 32), z(nsets, dtype=torch.int32)
+            self.feat, self.nfeat = z(B, K, 28), z(B, dtype=torch.int32)
+            self.NP = B * W
+            self.pairs = z(max(self.NP, 1), K, 2, dtype=torch.int64)
+            self.npairs = z(max(self.NP, 1), dtype=torch.int32)
+            self.cap = ctx.packed_outputs_capacity(B, self.NP)
+            self.payload = [z(self.cap) for _ in range(self.PAYLOAD_SLOTS)]
+            self.sizes_dev = [z(world, dtype=torch.int32) for _ in range(self.PAYLOAD_SLOTS)]
+            self.tail_idx = torch.tensor([2 * (B - W + j) for j in range(W)], dtype=torch.long, device=dev)
+            # (query set, train set) of temporal pair i*W + (W - w): frame i against the frame `w` before it
+            self.pair_sets = {key: self._pair_sets(*key) for key in ((0, True), (1, True), (0, False), (1, False))}
+        self.sizes_host = [torch.zeros(world, dtype=torch.int32).pin_memory() for _ in range(self.PAYLOAD_SLOTS)]
+        self.size_events = [torch.cuda.Event() for _ in range(self.PAYLOAD_SLOTS)]
+        self.recv = None
+        if self.rank == 0 and self.dist_on:
+            # receive buffers sized by the largest possible payload; each gather uses a prefix sized by the counts
+            rdev = "cpu" if self.host_detour else dev
+            self.recv = [[torch.empty(self.cap, dtype=u8, device=rdev) for _ in range(world)]
+                         for _ in range(self.PAYLOAD_SLOTS)]
+        self.step_idx = 0
+        self.next_gather = 0  # first step whose payload has not been handed to a gather yet
+        self.inflight = []   # (step, work, send tensor, receive views) of the gathers not yet waited for
+        self.completed = []  # on rank 0: (step, [uint8 tensor per rank]) in step order
+        self.keep_outputs = True
+        ctx.set_stream(self.stream.cuda_stream)
+        self.stream.synchronize()
+
+    # ---- static schedule of the temporal pairs ----
+    def _pair_sets(self, parity: int, first_step: bool):
+        B, W, world = self.B, self.W, self.world
+        q, t = [], []
+        for i in range(B):
+            for w in range(W, 0, -1):  # oldest first, the order of frame_list_ (cc:424)
+                past = i - w
+                if past >= 0:
+                    qs = 2 * past
+                elif self.rank > 0:
+                    qs = self.tail0 + parity * world * W + (self.rank - 1) * W + (W + past)
+                elif first_step:
+                    qs = self.empty_set  # the stream starts here: no predecessor
+                else:  # rank 0: the last rank's tail of the previous step
+                    qs = self.tail0 + (1 - parity) * world * W + (world - 1) * W + (W + past)
+                q.append(qs)
+                t.append(2 * i)
+        mk = lambda v: torch.tensor(v if v else [0], dtype=torch.int32, device=self.dev)  # noqa: E731
+        return mk(q), mk(t)
+
+    def pair_frames(self, step: int):
+        """(global past frame, global current frame) of each temporal pair of this rank's payload, -1 = none."""
+        out = []
+        for i in range(self.B):
+            g = (step * self.world + self.rank) * self.B + i
+            for w in range(self.W, 0, -1):
+                out.append((g - w if g - w >= 0 else -1, g))
+        return out
+
+    # ---- collectives (host detour on gloo) ----
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        """out: contiguous (world * inp.numel()) view; rank-major."""
+        if not self.dist_on:
+            out.view(-1).copy_(inp.reshape(-1))
+            return
+        if self.host_detour:
+            self.stream.synchronize()
+            h_in = inp.contiguous().cpu().reshape(-1)
+            parts = [torch.empty_like(h_in) for _ in range(self.world)]
+            dist.all_gather(parts, h_in)
+            out.view(-1).copy_(torch.cat(parts).to(out.device))
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().reshape(-1))
+
+    # ---- one step ----
+    def step(self, d_img: torch.Tensor):
+        """d_img: (B, 2, H, W) uint8 resident in HBM: this rank's frames of step `step_idx`, in time order."""
+        ctx, B, W, K, world = self.ctx, self.B, self.W, self.K, self.world
+        s = self.step_idx
+        parity, slot = s & 1, s % self.PAYLOAD_SLOTS
+        p = lambda t: t.data_ptr()  # noqa: E731
+        with torch.cuda.stream(self.stream):
+            if self.dist_on:  # payload slot `slot` (and the root's receive set) was last used by step s - PAYLOAD_SLOTS
+                self._retire_through(s - self.PAYLOAD_SLOTS)
+            ctx.stereo_batch_dev(p(d_img), B, self.width * self.height, self.width, p(self.kp), p(self.desc),
+                                 p(self.counts), p(self.matches), p(self.nmatches))
+            ctx.stereo_residuals_batch_dev(p(self.kp), p(self.matches), p(self.nmatches), B, self.F, p(self.means))
+            self._all_gather(self.means_all, self.means)
+            ctx.stereo_thresholds_dev(p(self.means_all), world * B, p(self.thr_state), p(self.thr_all))
+            ctx.stereo_filter_batch_dev(p(self.kp), p(self.desc), p(self.matches), p(self.nmatches), B,
+                                        p(self.thr_all) + 4 * self.rank * B, p(self.kpf), p(self.descf), p(self.countsf))
+            if W > 0:
+                r0 = self.tail0 + parity * world * W
+                self._all_gather(self.descf[r0:r0 + world * W], self.descf.index_select(0, self.tail_idx))
+                self._all_gather(self.countsf[r0:r0 + world * W], self.countsf.index_select(0, self.tail_idx))
+                q_set, t_set = self.pair_sets[(parity, s == 0)]
+                ctx.feature_matches_batch_dev(p(self.descf), p(self.countsf), K * 32, p(q_set), p(t_set), self.NP,
+                                              self.best_percent, p(self.pairs), p(self.npairs))
+            ctx.vision_features_batch_dev(self.calib, p(self.kpf), p(self.descf), p(self.countsf), B, p(self.feat),
+                                          p(self.nfeat), 0)
+            ctx.pack_outputs_dev(p(self.feat), p(self.nfeat), B, p(self.pairs), p(self.npairs), self.NP,
+                                 p(self.payload[slot]), self.cap)
+            if self.dist_on:
+                # sizes of every rank's payload -> host, without stalling it: read one step later
+                self._all_gather(self.sizes_dev[slot], self.payload[slot][12:16].view(torch.int32))
+                self.sizes_host[slot].copy_(self.sizes_dev[slot], non_blocking=True)
+                self.size_events[slot].record(self.stream)
+                while self.next_gather < s:
+                    self._issue_gather(self.next_gather)
+        self.step_idx += 1
+
+    def _issue_gather(self, step: int):
+        slot = step % self.PAYLOAD_SLOTS
+        self.size_events[slot].synchronize()  # (long done: the GPU is at least one step ahead of this point)
+        nbytes = int(self.sizes_host[slot].max())
+        nbytes = min((nbytes + 15) & ~15, self.cap)
+        send = self.payload[slot][:nbytes]
+        recv = None
+        if self.host_detour:
+            send = send.cpu()
+        if self.rank == 0:
+            recv = [b[:nbytes] for b in self.recv[slot]]
+        work = dist.gather(send, recv, dst=0, async_op=True)
+        self.inflight.append((step, work, send, recv))
+        self.next_gather = step + 1
+
+    def _retire_through(self, step: int):
+        """Waits (stream-ordered on RCCL, on the host with gloo) for the gathers of all steps <= `step`."""
+        while self.inflight and self.inflight[0][0] <= step:
+            st, work, _send, recv = self.inflight.pop(0)
+            work.wait()
+            if self.rank == 0 and self.keep_outputs:
+                self.completed.append((st, [r.clone() for r in recv]))
+
+    def drain(self):
+        """Issues and completes every outstanding gather (call inside the timed region), then waits for the stream."""
+        if self.dist_on:
+            with torch.cuda.stream(self.stream):
+                while self.next_gather < self.step_idx:
+                    self._issue_gather(self.next_gather)
+                self._retire_through(self.step_idx)
+        self.stream.synchronize()
+
+    def local_payload(self, step: int) -> torch.Tensor:
+        """This rank's packed payload of `step` (valid until PAYLOAD_SLOTS further steps have been issued)."""
+        return self.payload[step % self.PAYLOAD_SLOTS]
+
+
+def assemble_outputs(completed, world: int, frames_per_rank: int, window: int):
+    """Rank 0's view of the gathered payloads: ({global frame: VisionFeature records}, {(past frame, current frame):
+    FeatureMatch records}) from ShardedStereoFrontend.completed (or [(step, [payload])] of a single-process run)."""
+    from . import capi
+
+    feats, factors = {}, {}
+    for step, per_rank in completed:
+        for r, payload in enumerate(per_rank):
+            raw = payload.cpu().numpy() if isinstance(payload, torch.Tensor) else np.asarray(payload)
+            fl, ml = capi.unpack_outputs(raw)
+            assert len(fl) == frames_per_rank and len(ml) == frames_per_rank * window
+            base = (step * world + r) * frames_per_rank
+            for i in range(frames_per_rank):
+                feats[base + i] = fl[i]
+                for k, w in enumerate(range(window, 0, -1)):
+                    if base + i - w >= 0:
+                        factors[(base + i - w, base + i)] = ml[i * window + k]
+                    else:
+                        assert len(ml[i * window + k]) == 0
+    return feats, factors

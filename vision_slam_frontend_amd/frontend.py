@@ -40,12 +40,21 @@ def lib() -> C.CDLL:
         L.vsfh_frame.argtypes = [vp, i32, vp, vp, vp, i32]
         L.vsfh_serialize_problem.argtypes = [vp, vp, sz]
         L.vsfh_serialize_problem.restype = sz
+        L.vsfh_default_calibration.argtypes = [C.POINTER(capi.VsfCalibration)]
+        L.vsfh_default_calibration.restype = None
         _lib = L
     return _lib
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def default_calibration() -> capi.VsfCalibration:
+    """FrontendConfig()'s stereo calibration (the reference's hard-coded constants, slam_frontend.cc:565-644)."""
+    c = capi.VsfCalibration()
+    lib().vsfh_default_calibration(C.byref(c))
+    return c
 
 
 class Frontend:

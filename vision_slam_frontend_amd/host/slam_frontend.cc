@@ -162,6 +162,21 @@ FrontendConfig::FrontendConfig() {
   fundamental = Mul(Mul(Mul(Transpose(Inverse(K_right)), rotation), Transpose(K_left)), C);
 }
 
+vsf_calibration MakeCalibration(const FrontendConfig& config) {
+  vsf_calibration c;
+  std::memset(&c, 0, sizeof(c));
+  std::memcpy(c.projection_left, config.projection_left, sizeof(c.projection_left));
+  std::memcpy(c.projection_right, config.projection_right, sizeof(c.projection_right));
+  const Matrix3f K = CameraMatrix(config.intrinsics_left);  // camera_matrix_left, cc:575-578
+  std::memcpy(c.camera_matrix_left, K.m, sizeof(c.camera_matrix_left));
+  const CameraIntrinsics& I = config.intrinsics_left;       // distortion_coeffs_left, cc:623-628
+  const float d[5] = {I.k1, I.k2, I.p1, I.p2, I.k3};
+  std::memcpy(c.distortion_left, d, sizeof(d));
+  std::memcpy(c.fundamental, config.fundamental.m, sizeof(c.fundamental));
+  c.triangulate_rows = 6;  // OpenCV 3.2.0's cvTriangulatePoints (CMakeLists.txt:20 pins that version)
+  return c;
+}
+
 // ---- Frame (cc:511-519) ----
 Frame::Frame(const std::vector<vsf_keypoint>& keypoints, const std::vector<uint8_t>& descriptors, uint64_t frame_ID) {
   keypoints_ = keypoints;
@@ -413,9 +428,9 @@ void Frontend::RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vs
       right_descs.insert(right_descs.end(), rd, rd + VSF_DESC_BYTES);
     }
   }
-  // The reference divides by zero when there is no match and poisons the static with NaN forever (quirk Q3);
-  // here the threshold is left unchanged in that case.
-  if (!stereo_matches.empty()) stereo_ambig_constraint_ = avg_constraint / (float)stereo_matches.size() + 2.0f;
+  // cc:392-394.  Without a match this is 0/0 + 2 = NaN (quirk Q3): the next frame keeps no feature (`c <= NaN` is
+  // false) but updates the threshold from its own matches, so the frame after it is filtered normally again.
+  stereo_ambig_constraint_ = avg_constraint / (float)stereo_matches.size() + 2.0f;
   *left = Frame(left_keypoints, left_descs, left->frame_ID_);
   *right = Frame(right_keypoints, right_descs, right->frame_ID_);
 }

@@ -68,6 +68,9 @@ struct FrontendConfig {
   int image_width, image_height;
 };
 
+// FrontendConfig's stereo calibration in the layout of the C ABI (include/vsf.h vsf_calibration).
+vsf_calibration MakeCalibration(const FrontendConfig& config);
+
 // src/slam_frontend.h:100-114
 class Frame {
  public:
