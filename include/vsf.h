@@ -255,6 +255,30 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
                                 int n_frames, const uint64_t* d_pairs, const int32_t* d_npairs, int n_pairs,
                                 uint8_t* d_payload, size_t payload_cap);
 
+/* ---------------- one submission per Frontend::ObserveImage (slam_frontend.cc:400-472) ---------------- */
+
+/* Everything ObserveImage computes between OdomCheck and the node / factor bookkeeping, for ONE stereo frame given as
+ * host images, in one submission: upload (pinned staging), ExtractFeatures x 2 (cc:411-412), GetMatches (cc:414),
+ * RemoveAmbigStereo (cc:417, the threshold lives in the context like the reference's file-static), GetFeatureMatches
+ * against the <= frame_life frames kept from earlier calls (cc:424-434; their filtered descriptors stay resident in HBM),
+ * Calculate3DPoints (cc:437), VisionFeature assembly + UndistortFeaturePoints (cc:438-443), one compact result.  The
+ * frame then joins the window and the oldest leaves once frame_life are kept (cc:467-470).
+ * Result (little endian, *out_bytes bytes, at most vsf_observe_capacity()):
+ *   u32 magic 'VSFO', n_pairs, nfeat, total_bytes, n_left, n_right (raw keypoints), n_stereo_matches, n_points,
+ *   f32 mean residual, threshold applied, threshold in force afterwards, u32 overflow, 4 x u32 reserved     (64 bytes)
+ *   u32 npairs[n_pairs], padded to a multiple of 4 words
+ *   vsf_vision_feature x nfeat
+ *   vsf_feature_match x npairs[p], p = 0 .. n_pairs-1: the temporal factors, oldest kept frame first (the order of
+ *     frame_list_), and LAST the right->left matches of Calculate3DPoints in sorted order (n_pairs = kept frames + 1)
+ *   vsf_keypoint x nfeat, then 32-byte descriptors x nfeat: the left frame as RemoveAmbigStereo rebuilt it (cc:396)
+ * Same results as the separate calls (tests/test_gpu_observe.py).  vsf_observe_reset forgets the window and puts the
+ * threshold back to 10000 (cc:353). */
+size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life);
+vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                              const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
+                              size_t cap, size_t* out_bytes);
+vsf_status vsf_observe_reset(vsf_ctx* ctx);
+
 /* SURVEY section 8(f) row f4, the part behind cv::imdecode: DecodeImage's cvtColor(COLOR_BayerBG2BGR) +
  * cvtColor(COLOR_BGR2GRAY) (slam_frontend_main.cc:101-106) for n 8-bit mosaics of width x height resident in HBM, in
  * one pass.  d_src / d_dst: image i at base + i * image_stride, rows row_stride bytes apart; bases and strides multiples

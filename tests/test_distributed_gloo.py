@@ -111,3 +111,44 @@ def test_stereo_threshold_chain():
     # float32 arithmetic, like `avg_constraint / n + padding_from_average` in the reference
     m = np.float32(0.1)
     assert vd.stereo_thresholds([m, m])[1] == np.float32(m + np.float32(2.0))
+
+
+@pytest.mark.parametrize("world,B,W", [(1, 4, 2), (2, 3, 2), (3, 2, 2), (4, 5, 1), (2, 4, 4)])
+def test_temporal_pair_schedule_reaches_the_right_frames(world, B, W):
+    """The static (query set, train set) schedule of ShardedStereoFrontend resolves, on every rank and step, to the
+    global frames (g - w, g) of slam_frontend.cc:424-434 -- through local sets, the previous rank's tail of the same
+    step, or (rank 0) the last rank's tail of the previous step."""
+    steps = 4
+    empty = 2 * B + 2 * world * W
+    where = {}  # (step parity region, slot) -> global frame held there after that step's tail all-gather
+    seen = set()
+    for s in range(steps):
+        parity = s & 1
+        for r in range(world):  # what the all-gather of step s leaves in region `parity`
+            blk = list(vd.frame_block(s, B, world, r))
+            for j in range(W):
+                where[(parity, r * W + j)] = blk[B - W + j]
+        for r in range(world):
+            blk = list(vd.frame_block(s, B, world, r))
+            q, t = vd.temporal_pair_sets(B, W, world, r, parity, s == 0)
+            assert len(q) == len(t) == B * W
+            k = 0
+            for i in range(B):
+                for w in range(W, 0, -1):
+                    g = blk[i]
+                    assert t[k] == 2 * i
+                    if q[k] == empty:
+                        assert g - w < 0
+                    elif q[k] < 2 * B:
+                        assert q[k] % 2 == 0 and blk[q[k] // 2] == g - w
+                    else:
+                        reg = (q[k] - 2 * B) // (world * W)
+                        slot = (q[k] - 2 * B) % (world * W)
+                        # a same-step region must have been filled by a LOWER rank (its tail exists before ours is needed)
+                        assert reg == parity and slot // W < r or reg == 1 - parity and r == 0
+                        assert where[(reg, slot)] == g - w
+                    if g - w >= 0:
+                        seen.add((g - w, g))
+                    k += 1
+    n = world * B * steps
+    assert seen == {(g - w, g) for g in range(n) for w in range(1, W + 1) if g - w >= 0}

@@ -1,6 +1,7 @@
 """slam::Frontend (C++ host class over the HIP C ABI) against a model of the reference's ObserveImage
 (slam_frontend.cc:400-472) assembled from the CPU oracle's pieces: extraction, stereo GetMatches,
-RemoveAmbigStereo re-indexing and threshold chain, temporal GetFeatureMatches (std::sort + best 30 %)."""
+RemoveAmbigStereo re-indexing and threshold chain, temporal GetFeatureMatches (std::sort + best 30 %),
+Calculate3DPoints / UndistortFeaturePoints (cv::triangulatePoints, cv::undistortPoints restated)."""
 import numpy as np
 import pytest
 
@@ -10,7 +11,10 @@ NF = 1000
 F_RECT = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # l^T F r = y_r - y_l: rectified synthetic pair
 
 
-def _model(oracle, frames, frame_life, best_percent=np.float32(0.3)):
+POINT_RTOL, PIXEL_ATOL = 1e-5, 1e-4  # floating point: relative per coordinate of point3d; pixels
+
+
+def _model(oracle, frames, frame_life, best_percent=np.float32(0.3), calib=None):
     thr = np.float32(10000.0)
     frame_list, factors, kept_frames = [], [], []
     for fid, (left, right) in enumerate(frames):
@@ -23,13 +27,18 @@ def _model(oracle, frames, frame_life, best_percent=np.float32(0.3)):
         keep, _, thr_new, _ = oracle.remove_ambig_stereo(kl, kr, m, F_RECT, float(thr))
         thr = np.float32(thr_new)
         kl2, dl2 = kl[m["queryIdx"][keep]], dl[m["queryIdx"][keep]]
+        kr2, dr2 = kr[m["trainIdx"][keep]], dr[m["trainIdx"][keep]]
         for pid, _, pd in frame_list:
             mm = oracle.sort_and_trim(oracle.get_matches(pd, dl2), float(best_percent))
             factors.append((pid, fid, np.stack([mm["queryIdx"], mm["trainIdx"]], 1).astype(np.uint64)))
         if len(frame_list) >= frame_life:
             frame_list.pop(0)
         frame_list.append((fid, kl2, dl2))
-        kept_frames.append((kl2, dl2, float(thr)))
+        vf = None
+        if calib is not None:  # cc:437-443
+            vf, _ = oracle.vision_features(kl2, dl2, kr2, dr2, calib.get("projection_left"), calib.get("projection_right"),
+                                           calib.get("camera_matrix_left"), calib.get("distortion_left"))
+        kept_frames.append((kl2, dl2, float(thr), vf))
     return factors, frame_list, kept_frames
 
 
@@ -50,7 +59,7 @@ def test_frontend_matches_reference_model(oracle):
         assert fe.observe_image(*frames[f]) is False  # same pose again: gated by OdomCheck (cc:175-186)
         thr_seen.append(fe.stereo_ambig_constraint)
     assert fe.num_poses == 4
-    factors, frame_list, kept = _model(oracle, frames, frame_life=3)
+    factors, frame_list, kept = _model(oracle, frames, frame_life=3, calib=frontend.default_calibration())
     # thresholds: mean residual + 2 chain (cc:392-394)
     assert thr_seen == [k[2] for k in kept]
     # vision factors: ids and pairs, in order (cc:424-434)
@@ -73,7 +82,14 @@ def test_frontend_matches_reference_model(oracle):
         feat = node["features"]
         assert len(feat) == len(kl2)
         np.testing.assert_array_equal(feat[:, 0], np.arange(len(kl2), dtype=np.float32))
-        assert np.abs(feat[:, 1] - kl2["x"]).max() < 40 and np.isfinite(feat).all()
+        want = kept[f][3]
+        assert np.abs(feat[:, 1:3].astype(np.float64) - want["pixel"]).max() <= PIXEL_ATOL  # UndistortFeaturePoints
+        g, w = feat[:, 3:6].astype(np.float64), want["point3d"].astype(np.float64)     # Calculate3DPoints, (x,y,z)/w
+        assert np.array_equal(np.isfinite(g), np.isfinite(w)) and np.isfinite(w).mean() > 0.99
+        fin = np.isfinite(w)
+        rel = np.abs(g[fin] - w[fin]) / np.maximum(np.abs(w[fin]), 1e-30)
+        assert rel.max() <= POINT_RTOL, "frame %d: worst relative point3d error %.3g" % (f, rel.max())
+        assert np.abs(w[fin]).max() > 0
         np.testing.assert_allclose(node["pose"], [0.3 * (f + 1), 0, 0, 1, 0, 0, 0], atol=1e-6)
     # odometry factors between consecutive nodes (cc:311-321)
     of = fe.odometry_factors()
@@ -138,3 +154,43 @@ def test_frontend_rotation_gate_and_default_fundamental():
     assert fe.observe_image(left, right) is False
     assert fe.num_poses == 1
     fe.close()
+
+
+def test_fused_observe_equals_call_by_call():
+    """ObserveImage as ONE submission (vsf_observe_stereo: descriptors of the kept frames resident in HBM, device
+    RemoveAmbigStereo / GetFeatureMatches / Calculate3DPoints) against the same class making one C-ABI call per
+    reference call with the host steps in between: identical nodes, factors, frames, thresholds and wire bytes --
+    including a frame without stereo matches, the NaN threshold after it (quirk Q3) and the window sliding."""
+    from vision_slam_frontend_amd import frontend, synth
+    sc = synth.Scene(320, 240, n_objects=400)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(7)]
+    frames[2] = (frames[2][0], np.full_like(frames[2][1], 128))  # no stereo match in frame 2
+    q = np.array([1, 0, 0, 0], np.float32)
+    runs = []
+    for fused in (True, False):
+        fe = frontend.Frontend(320, 240, nfeatures=600, fundamental=F_RECT, frame_life=3)
+        fe.set_fused(fused)
+        fe.observe_odometry([0, 0, 0], q, 0.0)
+        thr = []
+        for f, (l, r) in enumerate(frames):
+            fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
+            assert fe.observe_image(l, r) is True
+            thr.append(fe.stereo_ambig_constraint)
+        runs.append(dict(thr=np.float32(thr), factors=fe.vision_factors(), nodes=fe.nodes(),
+                         frames=[fe.frame(i) for i in range(3)], wire=fe.serialize_problem()))
+        fe.close()
+    a, b = runs
+    assert a["thr"].tobytes() == b["thr"].tobytes() and np.isnan(a["thr"][2]) and np.isfinite(a["thr"][3])
+    assert len(a["factors"]) == len(b["factors"]) == 0 + 1 + 2 + 3 + 3 + 3 + 3
+    for (a0, a1, ap), (b0, b1, bp) in zip(a["factors"], b["factors"]):
+        assert (a0, a1) == (b0, b1)
+        np.testing.assert_array_equal(ap, bp)
+    for na, nb in zip(a["nodes"], b["nodes"]):
+        assert na["node_idx"] == nb["node_idx"] and na["timestamp"] == nb["timestamp"]
+        np.testing.assert_array_equal(na["pose"], nb["pose"])
+        assert na["features"].tobytes() == nb["features"].tobytes()  # same arithmetic on host and device
+    assert [len(n["features"]) for n in a["nodes"]][2:4] == [0, 0] and len(a["nodes"][4]["features"]) > 20
+    for (ia, ka, da), (ib, kb, db) in zip(a["frames"], b["frames"]):
+        assert ia == ib and ka.tobytes() == kb.tobytes()
+        np.testing.assert_array_equal(da, db)
+    assert a["wire"] == b["wire"]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Latency of the one-frame-at-a-time path (C++ slam::Frontend over the host-pointer C ABI): ObserveImage per stereo
-frame at 640x480 with the reference's literals (nfeatures 10000 -> ~6000 keypoints on the synthetic scene, window 10)."""
+"""Latency of the one-frame-at-a-time path (C++ slam::Frontend): ObserveImage per stereo frame at 640x480, window 10,
+as one GPU submission (vsf_observe_stereo) and call by call (one C-ABI call per reference call).
+    python tools/time_frontend.py [nfeatures ...]     (default 2000 10000)"""
 import sys
 import time
 from pathlib import Path
@@ -10,21 +11,31 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from vision_slam_frontend_amd import frontend, synth  # noqa: E402
 
-NF = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-sc = synth.Scene(640, 480)
-frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(14)]
-F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
-fe = frontend.Frontend(640, 480, nfeatures=NF, fundamental=F)
-q = np.array([1, 0, 0, 0], np.float32)
-fe.observe_odometry([0, 0, 0], q, 0.0)
-ts = []
-for f, (l, r) in enumerate(frames):
-    fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
-    t0 = time.perf_counter()
-    added = fe.observe_image(l, r)
-    ts.append(time.perf_counter() - t0)
-    assert added
-print("nfeatures %d: ObserveImage ms per frame: first %.1f, then %s (window fills up to 10 past frames)" %
-      (NF, 1e3 * ts[0], " ".join("%.1f" % (1e3 * t) for t in ts[1:])))
-print("poses %d, vision factors %d" % (fe.num_poses, len(fe.vision_factors())))
-fe.close()
+
+def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 24, width: int = 640, height: int = 480):
+    """Median ObserveImage time in ms once the window of 10 kept frames is full."""
+    sc = synth.Scene(width, height)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(n_frames)]
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    fe = frontend.Frontend(width, height, nfeatures=nfeatures, fundamental=F)
+    fe.set_fused(fused)
+    q = np.array([1, 0, 0, 0], np.float32)
+    fe.observe_odometry([0, 0, 0], q, 0.0)
+    ts = []
+    for f, (l, r) in enumerate(frames):
+        fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
+        t0 = time.perf_counter()
+        added = fe.observe_image(l, r)
+        ts.append(time.perf_counter() - t0)
+        assert added
+    feats = [len(n["features"]) for n in fe.nodes()]
+    fe.close()
+    return 1e3 * float(np.median(ts[11:])), ts, feats
+
+
+if __name__ == "__main__":
+    for nf in [int(a) for a in sys.argv[1:]] or [2000, 10000]:
+        for fused in (True, False):
+            ms, ts, feats = observe_image_ms(nf, fused)
+            print("nfeatures %5d %-12s ObserveImage median %.3f ms (window full); first %.1f ms; features/frame ~%d" %
+                  (nf, "fused" if fused else "call-by-call", ms, 1e3 * ts[0], int(np.median(feats))))

@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint
   if (threadIdx.x == 0) {
     float avg = 0.0f;  // avg_constraint += constraint, in match order
     for (int i = 0; i < n; i++) avg += res[i];
-    mean[f] = n > 0 ? avg / (float)n : __builtin_nanf("");
+    // 0.0f / 0 on the reference's x86 is the default ("real indefinite") NaN, sign bit set; the bits travel into the
+    // threshold and the gathered records, so they are reproduced rather than left to this GPU's own default NaN
+    mean[f] = n > 0 ? avg / (float)n : __uint_as_float(0xFFC00000u);
   }
 }
 
@@ -134,7 +136,9 @@ struct SortLess {
 
 __global__ __launch_bounds__(64) void sort_trim_kernel(const vsf_dmatch* __restrict__ matches,
                                                        const int32_t* __restrict__ nmatches, int max_rows,
-                                                       float best_percent, SortKey* __restrict__ scratch,
+                                                       float best_percent,
+                                                       const float* __restrict__ best_percent_of,  // per pair, or null
+                                                       SortKey* __restrict__ scratch,
                                                        uint64_t* __restrict__ pairs,  // [pairs][max_rows][2]
                                                        int32_t* __restrict__ npairs) {
   extern __shared__ SortKey keys[];  // lds_rows entries, or unused when the pair does not fit
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(64) void sort_trim_kernel(const vsf_dmatch* __restr
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // const int num_good_matches = matches.size() * config_.best_percent_;   (size_t -> float, float product, -> int)
+  if (best_percent_of) best_percent = best_percent_of[p];
   int good = (int)((float)(size_t)n * best_percent);
   good = min(max(good, 0), n);
   uint64_t* out = pairs + (size_t)p * max_rows * 2;
@@ -163,6 +168,78 @@ __global__ __launch_bounds__(64) void sort_trim_kernel(const vsf_dmatch* __restr
     out[2 * i + 1] = (uint64_t)(k.qt >> 16);      // FeatureMatch::feature_idx_current  = trainIdx (cc:296)
   }
   if (lane == 0) npairs[p] = good;
+}
+
+// ---- vsf_observe_stereo: everything one ObserveImage returns, compact, written straight into pinned host memory ----
+// header (16 words) | npairs[n_pairs] padded to 4 words | VisionFeature x nfeat | FeatureMatch x sum(npairs) |
+// cv::KeyPoint x nfeat (the filtered left frame) | descriptors x nfeat; also stores the filtered left frame into its
+// slot of the temporal ring (descriptors + count): the next calls match against it.
+__global__ __launch_bounds__(256) void observe_pack_kernel(VsfObserveArgs a) {
+  __shared__ uint32_t s_off[4 + VSF_OBSERVE_MAX_PAIRS];
+  const int K = a.max_rows;
+  const int nfeat = min(max(a.counts_f[0], 0), K);
+  if (threadIdx.x == 0) {
+    uint32_t off = 64u + 4u * (uint32_t)((a.n_pairs + 3) & ~3);
+    s_off[0] = off;  // features
+    off += (uint32_t)nfeat * 28u;
+    for (int p = 0; p < a.n_pairs; p++) {
+      s_off[3 + p] = off;
+      off += (uint32_t)min(max(a.npairs[p], 0), K) * 16u;
+    }
+    s_off[1] = off;  // keypoints
+    off += (uint32_t)nfeat * 28u;
+    s_off[2] = off;  // descriptors
+    off += (uint32_t)nfeat * 32u;
+    s_off[3 + a.n_pairs] = off;  // total
+  }
+  __syncthreads();
+  const uint32_t total = s_off[3 + a.n_pairs];
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.out);
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) {
+      out[0] = 0x4F465356u;  // "VSFO"
+      out[1] = (uint32_t)a.n_pairs;
+      out[2] = (uint32_t)nfeat;
+      out[3] = total;
+      out[4] = (uint32_t)a.counts_raw[0];
+      out[5] = (uint32_t)a.counts_raw[1];
+      out[6] = (uint32_t)a.nmatches[0];
+      out[7] = (uint32_t)a.npoints[0];
+      out[8] = __float_as_uint(a.means[0]);
+      out[9] = __float_as_uint(a.thr[0]);
+      out[10] = __float_as_uint(a.thr_state[0]);
+      out[11] = total > a.out_cap ? 1u : 0u;
+      out[12] = out[13] = out[14] = out[15] = 0u;
+    }
+    if ((int)threadIdx.x < ((a.n_pairs + 3) & ~3))
+      out[16 + threadIdx.x] = (int)threadIdx.x < a.n_pairs ? (uint32_t)min(max(a.npairs[threadIdx.x], 0), K) : 0u;
+    if (threadIdx.x == 0) a.ring_count[0] = nfeat;
+  }
+  if (total > a.out_cap) return;
+  const int sec = blockIdx.y;
+  const uint32_t* src;
+  uint32_t words;
+  if (sec == 0) {
+    src = reinterpret_cast<const uint32_t*>(a.features);
+    words = (uint32_t)nfeat * 7u;
+  } else if (sec == 1) {
+    src = reinterpret_cast<const uint32_t*>(a.kp_f);
+    words = (uint32_t)nfeat * 7u;
+  } else if (sec == 2) {
+    src = reinterpret_cast<const uint32_t*>(a.desc_f);
+    words = (uint32_t)nfeat * 8u;
+  } else {
+    const int p = sec - 3;
+    src = reinterpret_cast<const uint32_t*>(a.pairs + (size_t)p * K * 2);
+    words = (uint32_t)min(max(a.npairs[p], 0), K) * 4u;
+  }
+  uint32_t* dst = out + s_off[sec] / 4u;
+  uint32_t* ring = sec == 2 ? reinterpret_cast<uint32_t*>(a.ring_desc) : nullptr;
+  for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < words; w += gridDim.x * 256u) {
+    const uint32_t v = src[w];
+    dst[w] = v;
+    if (ring) ring[w] = v;
+  }
 }
 
 }  // namespace
@@ -194,7 +271,14 @@ void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, c
 }
 
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
-                          float best_percent, void* d_scratch, uint64_t* d_pairs, int32_t* d_npairs, hipStream_t s) {
+                          float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
+                          int32_t* d_npairs, hipStream_t s) {
   hipLaunchKernelGGL(sort_trim_kernel, dim3(n_pairs), dim3(64), VSF_SORT_LDS_ROWS * sizeof(SortKey), s, d_matches,
-                     d_nmatches, max_rows, best_percent, reinterpret_cast<SortKey*>(d_scratch), d_pairs, d_npairs);
+                     d_nmatches, max_rows, best_percent, d_best_percent_of, reinterpret_cast<SortKey*>(d_scratch), d_pairs,
+                     d_npairs);
+}
+
+void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s) {
+  // sections: 0 VisionFeature, 1 cv::KeyPoint, 2 descriptors, 3.. one per pair; up to 16 chunks of workgroups each
+  hipLaunchKernelGGL(observe_pack_kernel, dim3(16, 3 + a.n_pairs), dim3(256), 0, s, a);
 }

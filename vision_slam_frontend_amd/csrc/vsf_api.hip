@@ -333,6 +333,29 @@ struct vsf_ctx {
   int v_frames = 0;
   uint32_t* pk_offsets = nullptr;
   int pk_entries = 0;
+  // vsf_observe_stereo: temporal ring, per-call device scratch, pinned host staging
+  struct ObserveMeta {  // pinned, device-visible: read by the kernels over PCIe (a few words per call, no copy command)
+    float F[9];
+    float best_percent[VSF_OBSERVE_MAX_PAIRS];
+    int32_t q_set[VSF_OBSERVE_MAX_PAIRS], t_set[VSF_OBSERVE_MAX_PAIRS];
+  };
+  struct Observe {
+    int frame_life = 0;
+    uint8_t* ring = nullptr;        // [frame_life + 2][K][32]: kept frames, then the current left / right frame
+    int32_t* ring_counts = nullptr; // [frame_life + 2]
+    vsf_keypoint* kpf = nullptr;    // [2][K]
+    vsf_dmatch* matches = nullptr;  // [K] raw stereo matches
+    int32_t* ints = nullptr;        // nmatches, nfeat, npoints
+    float* floats = nullptr;        // mean, thr, thr_state
+    vsf_vision_feature* features = nullptr;
+    uint64_t* pairs = nullptr;      // [frame_life + 1][K][2]
+    int32_t* npairs = nullptr;
+    uint8_t* h_img = nullptr;       // pinned: both images at the staging pitch
+    uint8_t* h_out = nullptr;       // pinned, written by observe_pack_kernel
+    size_t out_cap = 0;
+    ObserveMeta* h_meta = nullptr;
+    std::vector<int> order;         // ring slots of the kept frames, oldest first
+  } ob;
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -457,6 +480,41 @@ vsf_status ensure_residual_buffers(vsf_ctx* ctx, int n_frames) {
     ctx->f_frames = n_frames;
   }
   if (!ctx->f_F) VSF_HIP(hipMalloc((void**)&ctx->f_F, 9 * sizeof(float)));
+  return VSF_OK;
+}
+
+void free_observe(vsf_ctx* ctx) {
+  vsf_ctx::Observe& o = ctx->ob;
+  hipFree(o.ring);
+  hipFree(o.ring_counts);
+  hipFree(o.kpf);
+  hipFree(o.matches);
+  hipFree(o.ints);
+  hipFree(o.floats);
+  hipFree(o.features);
+  hipFree(o.pairs);
+  hipFree(o.npairs);
+  if (o.h_img) hipHostFree(o.h_img);
+  if (o.h_out) hipHostFree(o.h_out);
+  if (o.h_meta) hipHostFree(o.h_meta);
+  o = vsf_ctx::Observe();
+}
+
+vsf_status ensure_temporal_buffers(vsf_ctx* ctx, int n_pairs) {
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_pairs <= ctx->t_pairs) return VSF_OK;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(ctx->t_matches);
+  hipFree(ctx->t_nmatches);
+  hipFree(ctx->t_sortkeys);
+  ctx->t_matches = nullptr;
+  ctx->t_nmatches = nullptr;
+  ctx->t_sortkeys = nullptr;
+  ctx->t_pairs = 0;
+  VSF_HIP(hipMalloc((void**)&ctx->t_matches, (size_t)n_pairs * K * sizeof(vsf_dmatch)));
+  VSF_HIP(hipMalloc((void**)&ctx->t_nmatches, (size_t)n_pairs * sizeof(int32_t)));
+  VSF_HIP(hipMalloc(&ctx->t_sortkeys, (size_t)n_pairs * K * 8));
+  ctx->t_pairs = n_pairs;
   return VSF_OK;
 }
 
@@ -814,6 +872,7 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_matches);
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
+  free_observe(ctx);
   hipFree(ctx->v_pairs);
   hipFree(ctx->v_npairs);
   hipFree(ctx->v_sets);
@@ -1171,29 +1230,196 @@ vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, co
   if (ctx->p.max_keypoints >= 65536) return VSF_ERR_UNSUPPORTED;  // (query, train) indices are packed 16 + 16 bit
   VSF_HIP(hipSetDevice(ctx->device));
   const size_t K = (size_t)ctx->p.max_keypoints;
-  if (n_pairs > ctx->t_pairs) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->t_matches);
-    hipFree(ctx->t_nmatches);
-    hipFree(ctx->t_sortkeys);
-    ctx->t_matches = nullptr;
-    ctx->t_nmatches = nullptr;
-    ctx->t_sortkeys = nullptr;
-    VSF_HIP(hipMalloc((void**)&ctx->t_matches, (size_t)n_pairs * K * sizeof(vsf_dmatch)));
-    VSF_HIP(hipMalloc((void**)&ctx->t_nmatches, (size_t)n_pairs * sizeof(int32_t)));
-    VSF_HIP(hipMalloc(&ctx->t_sortkeys, (size_t)n_pairs * K * 8));
-    ctx->t_pairs = n_pairs;
+  {
+    vsf_status st0 = ensure_temporal_buffers(ctx, n_pairs);
+    if (st0 != VSF_OK) return st0;
   }
   vsf_status st = vsf_match_batch_dev(ctx, d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, nullptr, nullptr,
                                       ctx->t_matches, ctx->t_nmatches);
   if (st != VSF_OK) return st;
   {
     StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
-    vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, ctx->t_sortkeys, d_pairs,
-                         d_npairs, ctx->stream);
+    vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, nullptr, ctx->t_sortkeys,
+                         d_pairs, d_npairs, ctx->stream);
   }
   VSF_HIP(hipGetLastError());
   return VSF_OK;
+}
+
+// ---------------- one submission per ObserveImage ----------------
+
+size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life) {
+  if (!ctx || frame_life < 0 || frame_life + 1 > VSF_OBSERVE_MAX_PAIRS) return 0;
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  return 64 + 4 * (size_t)((frame_life + 1 + 3) & ~3) + K * (28 + 28 + 32) + (size_t)(frame_life + 1) * K * 16;
+}
+
+static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
+  vsf_ctx::Observe& o = ctx->ob;
+  if (o.ring && o.frame_life == frame_life) return VSF_OK;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  float thr_state = 10000.0f;  // cc:353
+  const bool had = o.floats != nullptr;
+  if (had) VSF_HIP(hipMemcpy(&thr_state, o.floats + 2, sizeof(float), hipMemcpyDeviceToHost));
+  free_observe(ctx);
+  const size_t K = (size_t)ctx->p.max_keypoints, S = (size_t)frame_life + 2;
+  VSF_HIP(hipMalloc((void**)&o.ring, S * K * VSF_DESC_BYTES));
+  VSF_HIP(hipMalloc((void**)&o.ring_counts, S * sizeof(int32_t)));
+  VSF_HIP(hipMemset(o.ring_counts, 0, S * sizeof(int32_t)));
+  VSF_HIP(hipMalloc((void**)&o.kpf, 2 * K * sizeof(vsf_keypoint)));
+  VSF_HIP(hipMalloc((void**)&o.matches, K * sizeof(vsf_dmatch)));
+  VSF_HIP(hipMalloc((void**)&o.ints, 4 * sizeof(int32_t)));
+  VSF_HIP(hipMemset(o.ints, 0, 4 * sizeof(int32_t)));
+  VSF_HIP(hipMalloc((void**)&o.floats, 4 * sizeof(float)));
+  const float f4[4] = {0.f, 0.f, thr_state, 0.f};
+  VSF_HIP(hipMemcpy(o.floats, f4, sizeof(f4), hipMemcpyHostToDevice));
+  VSF_HIP(hipMalloc((void**)&o.features, K * sizeof(vsf_vision_feature)));
+  VSF_HIP(hipMalloc((void**)&o.pairs, (size_t)(frame_life + 1) * K * 2 * sizeof(uint64_t)));
+  VSF_HIP(hipMalloc((void**)&o.npairs, (size_t)(frame_life + 1) * sizeof(int32_t)));
+  VSF_HIP(hipHostMalloc((void**)&o.h_img, 2 * ctx->st_img_stride, hipHostMallocMapped));
+  o.out_cap = vsf_observe_capacity(ctx, frame_life);
+  VSF_HIP(hipHostMalloc((void**)&o.h_out, o.out_cap, hipHostMallocMapped));
+  VSF_HIP(hipHostMalloc((void**)&o.h_meta, sizeof(vsf_ctx::ObserveMeta), hipHostMallocMapped));
+  std::memset(o.h_meta, 0, sizeof(vsf_ctx::ObserveMeta));
+  o.frame_life = frame_life;
+  vsf_status st = ensure_match_buffers(ctx, frame_life + 1, (int)K);
+  if (st == VSF_OK) st = ensure_temporal_buffers(ctx, frame_life + 1);
+  if (st == VSF_OK) st = ensure_residual_buffers(ctx, 1);
+  return st;
+}
+
+vsf_status vsf_observe_reset(vsf_ctx* ctx) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  free_observe(ctx);
+  return VSF_OK;
+}
+
+vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                              const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
+                              size_t cap, size_t* out_bytes) {
+  if (!ctx || !left || !right || !calib || !out || !out_bytes || !(best_percent >= 0.f) || frame_life < 0 ||
+      frame_life + 1 > VSF_OBSERVE_MAX_PAIRS)
+    return VSF_ERR_INVALID_ARG;
+  *out_bytes = 0;
+  if (w != ctx->p.width || h != ctx->p.height || stride < (size_t)w || ctx->p.max_images < 2) return VSF_ERR_INVALID_ARG;
+  if (ctx->p.max_keypoints >= 65536) return VSF_ERR_UNSUPPORTED;
+  if (calib->triangulate_rows != 0 && calib->triangulate_rows != 4 && calib->triangulate_rows != 6)
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  vsf_status st = ensure_observe(ctx, frame_life);
+  if (st != VSF_OK) return st;
+  vsf_ctx::Observe& o = ctx->ob;
+  hipStream_t s = ctx->stream;
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  const int Kc = (int)K;
+  // ---- upload: rows into the pinned staging at the device pitch, ONE copy command for both images ----
+  const uint8_t* src[2] = {left, right};
+  for (int i = 0; i < 2; i++)
+    for (int y = 0; y < h; y++)
+      std::memcpy(o.h_img + (size_t)i * ctx->st_img_stride + (size_t)y * ctx->st_img_pitch, src[i] + (size_t)y * stride,
+                  (size_t)w);
+  VSF_HIP(hipMemcpyAsync(ctx->st_img, o.h_img, 2 * ctx->st_img_stride, hipMemcpyHostToDevice, s));
+  // ---- per-call parameters: written into pinned memory the kernels read directly ----
+  const int n_past = (int)o.order.size(), n_pairs = n_past + 1, S = frame_life;
+  vsf_ctx::ObserveMeta& M = *o.h_meta;
+  std::memcpy(M.F, calib->fundamental, sizeof(M.F));
+  for (int p = 0; p < n_past; p++) {
+    M.q_set[p] = o.order[p];  // oldest kept frame first: the order frame_list_ is walked in (cc:424)
+    M.t_set[p] = S;
+    M.best_percent[p] = best_percent;
+  }
+  M.q_set[n_past] = S + 1;  // Calculate3DPoints: GetFeatureMatches(right, left) with best_percent_ 1.0 (cc:129-132)
+  M.t_set[n_past] = S;
+  M.best_percent[n_past] = 1.0f;
+  // ---- ExtractFeatures x 2 + GetMatches (cc:411-416) ----
+  const VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
+  extract_on(ctx, s, im, 0, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts);
+  ctx->last_images = im;
+  ctx->last_valid = true;
+  int32_t* nmatches = o.ints;
+  match_on(ctx, s, ctx->st_desc, ctx->st_counts, K * VSF_DESC_BYTES, nullptr, nullptr, 0, 1, ctx->m_idx2, ctx->m_dist2,
+           o.matches, nmatches);
+  // ---- RemoveAmbigStereo (cc:417): the current frame lands in ring sets S (left) and S + 1 (right) ----
+  float *means = o.floats, *thr = o.floats + 1, *thr_state = o.floats + 2;
+  uint8_t* cur_desc = o.ring + (size_t)S * K * VSF_DESC_BYTES;
+  int32_t* cur_counts = o.ring_counts + S;
+  {
+    StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
+    vsf_launch_stereo_residuals(ctx->st_kp, o.matches, nmatches, 1, Kc, M.F, ctx->f_residual, means, s);
+    vsf_launch_stereo_thresholds(means, 1, thr_state, thr, s);
+    vsf_launch_stereo_filter_only(ctx->st_kp, ctx->st_desc, o.matches, nmatches, 1, Kc, ctx->f_residual, thr, o.kpf,
+                                  cur_desc, cur_counts, s);
+  }
+  // ---- GetFeatureMatches against every kept frame + the right->left matches of Calculate3DPoints: one matcher
+  // launch, one sort launch (per-pair best_percent) ----
+  {
+    StageTimer t(ctx, s, VSF_STAGE_KNN2, 1);
+    vsf_launch_knn2(o.ring, o.ring_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, s);
+  }
+  {
+    StageTimer t(ctx, s, VSF_STAGE_RATIO, 1);
+    vsf_launch_ratio_compact(o.ring_counts, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
+                             ctx->p.ratio_shift, ctx->t_matches, ctx->t_nmatches, ctx->d_status, s);
+  }
+  {
+    StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
+    vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, Kc, best_percent, M.best_percent, ctx->t_sortkeys,
+                         o.pairs, o.npairs, s);
+    // ---- Calculate3DPoints + VisionFeature + UndistortFeaturePoints (cc:437-443) ----
+    int32_t *nfeat = o.ints + 1, *npoints = o.ints + 2;
+    vsf_launch_vision_features(o.kpf, cur_counts, o.pairs + (size_t)n_past * K * 2, o.npairs + n_past, 1, Kc, *calib,
+                               o.features, nfeat, npoints, s);
+    // ---- the compact result into pinned memory; the filtered left frame into its ring slot (cc:467-470) ----
+    int slot;
+    if (frame_life == 0) {
+      slot = S + 1;  // nothing is kept: park it on the right frame's set
+    } else if (n_past >= frame_life) {
+      slot = o.order.front();
+    } else {
+      slot = n_past;
+      for (int c = 0; c < frame_life; c++)
+        if (std::find(o.order.begin(), o.order.end(), c) == o.order.end()) {
+          slot = c;
+          break;
+        }
+    }
+    VsfObserveArgs a;
+    a.n_pairs = n_pairs;
+    a.max_rows = Kc;
+    a.counts_raw = ctx->st_counts;
+    a.nmatches = nmatches;
+    a.counts_f = cur_counts;
+    a.npoints = npoints;
+    a.means = means;
+    a.thr = thr;
+    a.thr_state = thr_state;
+    a.features = o.features;
+    a.kp_f = o.kpf;
+    a.desc_f = cur_desc;
+    a.pairs = o.pairs;
+    a.npairs = o.npairs;
+    a.ring_desc = o.ring + (size_t)slot * K * VSF_DESC_BYTES;
+    a.ring_count = o.ring_counts + slot;
+    a.out = o.h_out;
+    a.out_cap = (uint32_t)std::min<size_t>(o.out_cap, 0xFFFFFFF0u);
+    vsf_launch_observe_pack(a, s);
+    if (frame_life > 0) {
+      if (n_past >= frame_life) o.order.erase(o.order.begin());
+      o.order.push_back(slot);
+    }
+  }
+  VSF_HIP(hipGetLastError());
+  st = check_status_word(ctx);  // synchronises
+  if (st == VSF_ERR_HIP) return st;
+  const uint32_t* hdr = reinterpret_cast<const uint32_t*>(o.h_out);
+  if (hdr[0] != 0x4F465356u) return VSF_ERR_HIP;
+  const size_t total = hdr[3];
+  *out_bytes = total;
+  if (hdr[11] != 0 || total > cap) return VSF_ERR_CAPACITY;
+  std::memcpy(out, o.h_out, total);
+  return st;
 }
 
 // ---------------- host-pointer entry points ----------------

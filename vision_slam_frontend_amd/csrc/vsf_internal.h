@@ -153,6 +153,29 @@ void vsf_launch_pack_outputs(const vsf_vision_feature* d_features, const int32_t
                              uint8_t* d_payload, uint32_t cap_bytes, uint32_t* d_offsets, int32_t* d_status,
                              hipStream_t s);
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
-                          float best_percent, void* d_scratch, uint64_t* d_pairs, int32_t* d_npairs, hipStream_t s);
+                          float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
+                          int32_t* d_npairs, hipStream_t s);
+// vsf_observe_stereo's output kernel (k_frontend.hip)
+#define VSF_OBSERVE_MAX_PAIRS 64
+struct VsfObserveArgs {
+  int n_pairs, max_rows;
+  const int32_t* counts_raw;          // [2] keypoints of the left / right image
+  const int32_t* nmatches;            // [1] raw stereo matches
+  const int32_t* counts_f;            // [1] features of the filtered left frame
+  const int32_t* npoints;             // [1] triangulated points
+  const float* means;                 // [1]
+  const float* thr;                   // [1] threshold applied
+  const float* thr_state;             // [1] threshold in force afterwards
+  const vsf_vision_feature* features; // [max_rows]
+  const vsf_keypoint* kp_f;           // [max_rows] filtered left keypoints
+  const uint8_t* desc_f;              // [max_rows][32] filtered left descriptors
+  const uint64_t* pairs;              // [n_pairs][max_rows][2]
+  const int32_t* npairs;              // [n_pairs]
+  uint8_t* ring_desc;                 // ring slot that receives the filtered left descriptors
+  int32_t* ring_count;                // ... and their number
+  uint8_t* out;                       // pinned host memory (device-visible)
+  uint32_t out_cap;
+};
+void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s);
 
 #endif  // VSF_INTERNAL_H_

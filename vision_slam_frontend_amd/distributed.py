@@ -125,6 +125,38 @@ def time_ordered(per_rank: torch.Tensor) -> torch.Tensor:
 # The sharded hot path (BASELINE configs[3]; slam_frontend.cc:400-443 per frame)
 # ---------------------------------------------------------------------------------------------------------------------
 
+def tail_region(frames_per_rank: int, window: int, world: int, parity: int) -> int:
+    """First set index of the gathered-tail region of step parity `parity` in ShardedStereoFrontend's set array:
+    sets 0 .. 2B-1 are the local filtered frames (2f = left, 2f+1 = right), then two regions of world x window tail
+    sets (rank-major; a rank's tail = its last `window` filtered LEFT frames in time order), then one empty set."""
+    return 2 * frames_per_rank + parity * world * window
+
+
+def temporal_pair_sets(frames_per_rank: int, window: int, world: int, rank: int, parity: int, first_step: bool):
+    """(query sets, train sets) of one rank's temporal GetFeatureMatches calls of one step (slam_frontend.cc:424-434):
+    pair i*window + k matches local frame i (train = set 2i) against the frame `window - k` before it, oldest first as
+    frame_list_ is walked.  A predecessor inside the rank's block is a local set; one before the block lives in the
+    previous rank's tail of the same step (region `parity`) -- for rank 0 in the LAST rank's tail of the previous step
+    (region 1 - parity), or nowhere when the stream starts (the empty set)."""
+    B, W = frames_per_rank, window
+    empty = 2 * B + 2 * world * W
+    q, t = [], []
+    for i in range(B):
+        for w in range(W, 0, -1):
+            past = i - w
+            if past >= 0:
+                qs = 2 * past
+            elif rank > 0:
+                qs = tail_region(B, W, world, parity) + (rank - 1) * W + (W + past)
+            elif first_step:
+                qs = empty
+            else:
+                qs = tail_region(B, W, world, 1 - parity) + (world - 1) * W + (W + past)
+            q.append(qs)
+            t.append(2 * i)
+    return q, t
+
+
 class ShardedStereoFrontend:
     """One rank's share of a time-ordered stereo stream, one step = `frames_per_rank` frames on this GPU.
 
@@ -214,21 +246,7 @@ class ShardedStereoFrontend:
 
     # ---- static schedule of the temporal pairs ----
     def _pair_sets(self, parity: int, first_step: bool):
-        B, W, world = self.B, self.W, self.world
-        q, t = [], []
-        for i in range(B):
-            for w in range(W, 0, -1):  # oldest first, the order of frame_list_ (cc:424)
-                past = i - w
-                if past >= 0:
-                    qs = 2 * past
-                elif self.rank > 0:
-                    qs = self.tail0 + parity * world * W + (self.rank - 1) * W + (W + past)
-                elif first_step:
-                    qs = self.empty_set  # the stream starts here: no predecessor
-                else:  # rank 0: the last rank's tail of the previous step
-                    qs = self.tail0 + (1 - parity) * world * W + (world - 1) * W + (W + past)
-                q.append(qs)
-                t.append(2 * i)
+        q, t = temporal_pair_sets(self.B, self.W, self.world, self.rank, parity, first_step)
         mk = lambda v: torch.tensor(v if v else [0], dtype=torch.int32, device=self.dev)  # noqa: E731
         return mk(q), mk(t)
 

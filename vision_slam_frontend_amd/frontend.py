@@ -42,6 +42,8 @@ def lib() -> C.CDLL:
         L.vsfh_serialize_problem.restype = sz
         L.vsfh_default_calibration.argtypes = [C.POINTER(capi.VsfCalibration)]
         L.vsfh_default_calibration.restype = None
+        L.vsfh_set_fused.argtypes = [vp, i32]
+        L.vsfh_set_fused.restype = None
         _lib = L
     return _lib
 
@@ -66,6 +68,11 @@ class Frontend:
         st = lib().vsfh_last_status(self._h)
         if st != capi.VSF_OK:
             raise capi.VsfError(st, "Frontend")
+
+    def set_fused(self, on: bool):
+        """True (default): ObserveImage is one GPU submission (vsf_observe_stereo); False: one C-ABI call per
+        reference call with the reference's host steps in between.  Choose before the first observe_image."""
+        lib().vsfh_set_fused(self._h, int(on))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -26,6 +26,8 @@ void* vsfh_frontend_create(int nfeatures, int width, int height, int device, con
 // slam_frontend.cc:565-644) in the layout the C ABI takes -- the one place tests, bench.py and the multi-GPU path get it.
 void vsfh_default_calibration(vsf_calibration* out) { *out = slam::MakeCalibration(FrontendConfig()); }
 
+void vsfh_set_fused(void* f, int on) { static_cast<Frontend*>(f)->set_fused(on != 0); }
+
 void vsfh_frontend_destroy(void* f) { delete static_cast<Frontend*>(f); }
 
 void vsfh_observe_odometry(void* f, const float t[3], const float q_wxyz[4], double ts) {

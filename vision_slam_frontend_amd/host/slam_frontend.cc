@@ -57,41 +57,61 @@ Matrix3f CameraMatrix(const CameraIntrinsics& I) {  // cc:542-548
   return M;
 }
 
-// Smallest-eigenvalue eigenvector of the symmetric 4x4 matrix S (cyclic Jacobi, double).
-void SmallestEigenvector4(double S[4][4], double out[4]) {
-  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-  for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
-    for (int p = 0; p < 4; p++)
-      for (int q = p + 1; q < 4; q++) off += S[p][q] * S[p][q];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 4; p++)
-      for (int q = p + 1; q < 4; q++) {
-        if (S[p][q] == 0.0) continue;
-        const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 4; k++) {
-          const double skp = S[k][p], skq = S[k][q];
-          S[k][p] = c * skp - s * skq;
-          S[k][q] = s * skp + c * skq;
+// Right singular vector of the smallest singular value of the M x 4 system whose columns are At[0..3] (M <= 6):
+// one-sided (Hestenes) Jacobi in double as cv::SVD::compute runs it for cv::triangulatePoints (core/src/lapack.cpp
+// JacobiSVDImpl_: rotate column pairs until every pair is orthogonal to 10 * DBL_EPSILON, at most 30 sweeps).
+void SmallestRightSingularVector(double At[4][6], int M, double out[4]) {
+  const double eps = 2.220446049250313e-16 * 10;
+  double W[4], Vt[4][4];
+  for (int i = 0; i < 4; i++) {
+    W[i] = 0;
+    for (int k = 0; k < M; k++) W[i] += At[i][k] * At[i][k];
+    for (int k = 0; k < 4; k++) Vt[i][k] = i == k;
+  }
+  auto hyp = [](double a, double b) {
+    a = std::fabs(a), b = std::fabs(b);
+    if (a > b) return a * std::sqrt(1 + (b / a) * (b / a));
+    return b > 0 ? b * std::sqrt(1 + (a / b) * (a / b)) : 0.0;
+  };
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 3; i++)
+      for (int j = i + 1; j < 4; j++) {
+        double a = W[i], b = W[j], p = 0;
+        for (int k = 0; k < M; k++) p += At[i][k] * At[j][k];
+        if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hyp(p, beta);
+        double c, s;
+        if (beta < 0) {
+          s = std::sqrt((gamma - beta) * 0.5 / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = std::sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
         }
-        for (int k = 0; k < 4; k++) {
-          const double spk = S[p][k], sqk = S[q][k];
-          S[p][k] = c * spk - s * sqk;
-          S[q][k] = s * spk + c * sqk;
+        a = b = 0;
+        for (int k = 0; k < M; k++) {
+          const double t0 = c * At[i][k] + s * At[j][k], t1 = -s * At[i][k] + c * At[j][k];
+          At[i][k] = t0, At[j][k] = t1;
+          a += t0 * t0, b += t1 * t1;
         }
+        W[i] = a, W[j] = b;
+        changed = true;
         for (int k = 0; k < 4; k++) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
+          const double t0 = c * Vt[i][k] + s * Vt[j][k], t1 = -s * Vt[i][k] + c * Vt[j][k];
+          Vt[i][k] = t0, Vt[j][k] = t1;
         }
       }
+    if (!changed) break;
   }
   int best = 0;
-  for (int i = 1; i < 4; i++)
-    if (S[i][i] < S[best][best]) best = i;
-  for (int k = 0; k < 4; k++) out[k] = V[k][best];
+  for (int i = 0; i < 4; i++) {
+    W[i] = 0;
+    for (int k = 0; k < M; k++) W[i] += At[i][k] * At[i][k];
+    if (W[i] < W[best]) best = i;
+  }
+  for (int k = 0; k < 4; k++) out[k] = Vt[best][k];
 }
 
 }  // namespace
@@ -195,6 +215,7 @@ Frontend::Frontend(const std::string& /*config_path*/, const FrontendConfig& con
       config_(config),
       curr_frame_ID_(0),
       stereo_ambig_constraint_(10000),  // cc:353
+      fused_(true),
       ctx_(nullptr),
       device_(device),
       last_status_(VSF_OK) {
@@ -435,10 +456,10 @@ void Frontend::RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vs
   *right = Frame(right_keypoints, right_descs, right->frame_ID_);
 }
 
-// cc:117-173: right->left matches with best_percent forced to 1, then DLT triangulation (cv::triangulatePoints:
-// per point the null vector of the 4x4 system, double) and the homogeneous divide.  SURVEY section 8(f) row f2: the
-// null vector is found by a Jacobi eigen-solve of A^T A, so values agree with OpenCV's SVD to rounding, not
-// bit for bit.
+// cc:117-173: right->left matches with best_percent forced to 1, then cv::triangulatePoints (per point the right
+// singular vector of the smallest singular value of the 6 x 4 system OpenCV 3.2 builds: x*P2-P0, y*P2-P1, x*P1-y*P0 per
+// view, in double) and the homogeneous divide in float.  Same arithmetic as the device kernel (csrc/k_points.hip);
+// against real OpenCV the values agree to rounding (its SVD may run through LAPACK), not bit for bit.
 void Frontend::Calculate3DPoints(Frame* left_frame, Frame* right_frame, std::vector<Vector3f>* points) {
   const float best_percent = config_.best_percent_;
   config_.best_percent_ = 1.0f;
@@ -450,21 +471,16 @@ void Frontend::Calculate3DPoints(Frame* left_frame, Frame* right_frame, std::vec
     const vsf_keypoint& left_pt = left_frame->keypoints_[match.feature_idx_current];
     const vsf_keypoint& right_pt = right_frame->keypoints_[match.feature_idx_initial];
     const double xy[2][2] = {{left_pt.x, left_pt.y}, {right_pt.x, right_pt.y}};
-    double A[4][4];
+    double At[4][6];
     for (int j = 0; j < 2; j++)
       for (int k = 0; k < 4; k++) {
-        A[2 * j + 0][k] = xy[j][0] * P[j][8 + k] - P[j][0 + k];
-        A[2 * j + 1][k] = xy[j][1] * P[j][8 + k] - P[j][4 + k];
-      }
-    double S[4][4];
-    for (int a = 0; a < 4; a++)
-      for (int b = 0; b < 4; b++) {
-        double s = 0;
-        for (int k = 0; k < 4; k++) s += A[k][a] * A[k][b];
-        S[a][b] = s;
+        const double p0 = P[j][k], p1 = P[j][4 + k], p2 = P[j][8 + k];
+        At[k][3 * j + 0] = xy[j][0] * p2 - p0;
+        At[k][3 * j + 1] = xy[j][1] * p2 - p1;
+        At[k][3 * j + 2] = xy[j][0] * p1 - xy[j][1] * p0;
       }
     double X[4];
-    SmallestEigenvector4(S, X);
+    SmallestRightSingularVector(At, 6, X);
     const float xf = (float)X[0], yf = (float)X[1], zf = (float)X[2], wf = (float)X[3];
     points->push_back(Vector3f(xf, yf, zf) / wf);
   }
@@ -492,9 +508,107 @@ void Frontend::UndistortFeaturePoints(std::vector<VisionFeature>* features_ptr) 
   }
 }
 
+// cc:400-472 through ONE submission to the GPU (vsf_observe_stereo): upload, both ExtractFeatures, GetMatches,
+// RemoveAmbigStereo, every GetFeatureMatches of the temporal loop, Calculate3DPoints, the VisionFeature records and
+// UndistortFeaturePoints run on the device back to back and come home in one compact buffer; the kept frames'
+// descriptors never leave HBM.  What stays here is the reference's bookkeeping (is_initial_ / initial_ids_, nodes,
+// factors, the sliding window), in the reference's order.
+bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_image) {
+  if (!EnsureContext(left_image.cols, left_image.rows)) {
+    if (last_status_ == VSF_OK) last_status_ = VSF_ERR_INVALID_ARG;
+    return false;
+  }
+  const vsf_calibration calib = MakeCalibration(config_);
+  const size_t cap = vsf_observe_capacity(ctx_, (int)config_.frame_life_);
+  if (observe_buf_.size() < cap) observe_buf_.resize(cap);
+  size_t bytes = 0;
+  last_status_ = vsf_observe_stereo(ctx_, left_image.data, right_image.data, left_image.cols, left_image.rows,
+                                    left_image.step, &calib, config_.best_percent_, (int)config_.frame_life_,
+                                    observe_buf_.data(), observe_buf_.size(), &bytes);
+  if (last_status_ != VSF_OK) return false;
+  const uint8_t* b = observe_buf_.data();
+  uint32_t hdr[16];
+  std::memcpy(hdr, b, sizeof(hdr));
+  const int n_pairs = (int)hdr[1], nfeat = (int)hdr[2];
+  std::memcpy(&stereo_ambig_constraint_, &hdr[10], sizeof(float));  // the static's value after this frame (cc:392-394)
+  if (n_pairs != (int)frame_list_.size() + 1) {  // the context's window and frame_list_ went out of step
+    last_status_ = VSF_ERR_INVALID_ARG;
+    return false;
+  }
+  std::vector<uint32_t> npairs((size_t)n_pairs);
+  std::memcpy(npairs.data(), b + 64, (size_t)n_pairs * 4);
+  size_t off = 64 + 4 * (size_t)((n_pairs + 3) & ~3);
+  const uint8_t* feat_bytes = b + off;
+  off += (size_t)nfeat * sizeof(vsf_vision_feature);
+  std::vector<const uint8_t*> pair_bytes((size_t)n_pairs);
+  for (int p = 0; p < n_pairs; p++) {
+    pair_bytes[p] = b + off;
+    off += (size_t)npairs[p] * sizeof(vsf_feature_match);
+  }
+  std::vector<vsf_keypoint> kps((size_t)nfeat);
+  std::vector<uint8_t> desc((size_t)nfeat * VSF_DESC_BYTES);
+  if (nfeat > 0) {
+    std::memcpy(kps.data(), b + off, (size_t)nfeat * sizeof(vsf_keypoint));
+    std::memcpy(desc.data(), b + off + (size_t)nfeat * sizeof(vsf_keypoint), desc.size());
+  }
+  Frame curr_frame(kps, desc, curr_frame_ID_);
+  auto book = [](const Frame& past_frame, Frame* curr, const uint8_t* bytes, uint32_t n, std::vector<FeatureMatch>* pairs) {
+    for (uint32_t k = 0; k < n; k++) {  // cc:294-306
+      vsf_feature_match m;
+      std::memcpy(&m, bytes + (size_t)k * sizeof(m), sizeof(m));
+      if (pairs) pairs->push_back(FeatureMatch(m.feature_idx_initial, m.feature_idx_current));
+      if (m.feature_idx_current < curr->is_initial_.size() && curr->is_initial_[m.feature_idx_current]) {
+        curr->is_initial_[m.feature_idx_current] = false;
+        curr->initial_ids_[m.feature_idx_current] =
+            m.feature_idx_initial < past_frame.is_initial_.size() && !past_frame.is_initial_[m.feature_idx_initial]
+                ? past_frame.initial_ids_[m.feature_idx_initial]
+                : (int64_t)past_frame.frame_ID_;
+      }
+    }
+  };
+  for (int p = 0; p + 1 < n_pairs; p++) {  // the temporal loop, cc:424-434
+    std::vector<FeatureMatch> pairs;
+    book(frame_list_[p], &curr_frame, pair_bytes[p], npairs[p], &pairs);
+    vision_factors_.push_back(VisionFactor(frame_list_[p].frame_ID_, curr_frame.frame_ID_, pairs));
+  }
+  {  // Calculate3DPoints' GetFeatureMatches(right, left) (cc:131): every row of the right frame is still `initial`
+    Frame right_temp_frame;
+    right_temp_frame.frame_ID_ = curr_frame_ID_;
+    book(right_temp_frame, &curr_frame, pair_bytes[n_pairs - 1], npairs[n_pairs - 1], nullptr);
+  }
+  std::vector<VisionFeature> features;
+  features.reserve((size_t)nfeat);
+  for (int i = 0; i < nfeat; i++) {  // cc:438-443, computed on the device
+    vsf_vision_feature f;
+    std::memcpy(&f, feat_bytes + (size_t)i * sizeof(f), sizeof(f));
+    features.push_back(VisionFeature((uint64_t)f.feature_idx_lo | ((uint64_t)f.feature_idx_hi << 32),
+                                     Vector2f(f.pixel[0], f.pixel[1]), Vector3f(f.point3d[0], f.point3d[1], f.point3d[2])));
+  }
+  FinishNode(curr_frame, features);
+  return true;
+}
+
+// cc:444-470: node, odometry factor, sliding window.
+void Frontend::FinishNode(const Frame& curr_frame, const std::vector<VisionFeature>& features) {
+  const Vector3f loc = init_odom_rotation_.inverse() * (odom_translation_ - init_odom_translation_);
+  const Quaternionf angle = odom_rotation_ * init_odom_rotation_.inverse();
+  nodes_.push_back(SLAMNode(curr_frame_ID_, odom_timestamp_, RobotPose(loc, angle), features));
+  if (curr_frame_ID_ > 0) AddOdometryFactor();
+  prev_odom_rotation_ = odom_rotation_;
+  prev_odom_translation_ = odom_translation_;
+  curr_frame_ID_++;
+  if (frame_list_.size() >= config_.frame_life_ && !frame_list_.empty()) frame_list_.erase(frame_list_.begin());
+  frame_list_.push_back(curr_frame);
+}
+
 // cc:400-472
 bool Frontend::ObserveImage(const Image& left_image, const Image& right_image, double /*time*/) {
   if (!OdomCheck()) return false;
+  if (fused_ && config_.descriptor_extract_type_ == FrontendConfig::DescriptorExtractorType::ORB && !left_image.empty() &&
+      !right_image.empty() && left_image.cols == right_image.cols && left_image.rows == right_image.rows &&
+      left_image.step == right_image.step && config_.orb_nfeatures + 256 < 65536 && config_.frame_life_ >= 1 &&
+      config_.frame_life_ + 1 <= 64)
+    return ObserveImageFused(left_image, right_image);
   Frame curr_frame, right_temp_frame;
   if (!ExtractFeaturesPair(left_image, right_image, &curr_frame, &right_temp_frame)) return false;
   const std::vector<vsf_dmatch> stereo_matches = GetMatches(curr_frame, right_temp_frame, config_.nn_match_ratio_);
@@ -510,15 +624,7 @@ bool Frontend::ObserveImage(const Image& left_image, const Image& right_image, d
     features.push_back(VisionFeature(i, Vector2f(curr_frame.keypoints_[i].x, curr_frame.keypoints_[i].y), p3));
   }
   UndistortFeaturePoints(&features);
-  const Vector3f loc = init_odom_rotation_.inverse() * (odom_translation_ - init_odom_translation_);
-  const Quaternionf angle = odom_rotation_ * init_odom_rotation_.inverse();
-  nodes_.push_back(SLAMNode(curr_frame_ID_, odom_timestamp_, RobotPose(loc, angle), features));
-  if (curr_frame_ID_ > 0) AddOdometryFactor();
-  prev_odom_rotation_ = odom_rotation_;
-  prev_odom_translation_ = odom_translation_;
-  curr_frame_ID_++;
-  if (frame_list_.size() >= config_.frame_life_) frame_list_.erase(frame_list_.begin());
-  frame_list_.push_back(curr_frame);
+  FinishNode(curr_frame, features);
   return true;
 }
 

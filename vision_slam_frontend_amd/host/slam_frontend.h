@@ -105,6 +105,10 @@ class Frontend {
 
   // Additions (not in the reference): error reporting instead of abort, and read access for tests.
   vsf_status last_status() const { return last_status_; }
+  // true (default): ObserveImage is one GPU submission (vsf_observe_stereo); false: one C-ABI call per reference call
+  // (vsf_extract_pair, vsf_get_matches, ...) with the reference's host steps in between.  Same results; choose before
+  // the first ObserveImage.
+  void set_fused(bool on) { fused_ = on; }
   float stereo_ambig_constraint() const { return stereo_ambig_constraint_; }
   const std::vector<Frame>& frame_list() const { return frame_list_; }
   const std::vector<slam_types::SLAMNode>& nodes() const { return nodes_; }
@@ -127,6 +131,8 @@ class Frontend {
   void UndistortFeaturePoints(std::vector<slam_types::VisionFeature>* features);
   void Calculate3DPoints(Frame* left_frame, Frame* right_frame, std::vector<Vector3f>* points);
   bool EnsureContext(int width, int height);
+  bool ObserveImageFused(const Image& left_image, const Image& right_image);
+  void FinishNode(const Frame& curr_frame, const std::vector<slam_types::VisionFeature>& features);
 
   bool odom_initialized_;
   Vector3f init_odom_translation_;
@@ -144,6 +150,8 @@ class Frontend {
   std::vector<slam_types::OdometryFactor> odometry_factors_;
   // The reference keeps this in a file-static shared by all instances (cc:353, quirk Q3); here it is per object.
   float stereo_ambig_constraint_;
+  bool fused_;
+  std::vector<uint8_t> observe_buf_;
   vsf_ctx* ctx_;
   int device_;
   vsf_status last_status_;
