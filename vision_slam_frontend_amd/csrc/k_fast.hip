@@ -88,9 +88,9 @@ __device__ __forceinline__ v2s vmax3(v2s a, v2s b, v2s c) {
 
 // Scores of the two pixels at bytes 4+J0, 5+J0 of the centre row R3; R0..R6 are rows y-3..y+3.
 // Returns the two scores (0 = not a corner; a marker 1 when nms == 0) in the two 16-bit halves.
-template <int J0>
+template <int J0, bool NMS>
 __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3,
-                                          const Row3& R4, const Row3& R5, const Row3& R6, v2s tt, int nms) {
+                                          const Row3& R4, const Row3& R5, const Row3& R6, v2s tt) {
   const v2s v = pick2<4 + J0>(R3);
   v2s d[16];  // circle pixels p_k; min / max commute with the subtraction of v, which is applied once at the end
   // Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
@@ -144,7 +144,7 @@ __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const 
   const v2s one = {1, 1};
   const v2s sc = vmax(A - v, v - Bm);
   const v2s m = (tt - sc) >> 15;  // all ones where sc > t
-  return nms ? ((sc - one) & m) : (m & one);
+  return NMS ? ((sc - one) & m) : (m & one);
 }
 
 // One score row as the NMS needs it: the 4 score bytes, the centre pairs, and the horizontal maxima.
@@ -177,7 +177,8 @@ __device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
 //               columns = 28 lanes + 2 x 2 halo lanes) in two consecutive strips; each half keeps its own candidate
 //               segment, row-start table and counter, so downstream nothing changes.  (The pyramid's 50 levels leave a
 //               narrow remainder band almost everywhere: 510 -> 446 waves per 640x480 image.)
-template <bool HALF>
+// NMS = false (standalone FAST without suppression only) keeps every corner and a zero response.
+template <bool HALF, bool NMS>
 __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, int nwork) {
   const int lane = threadIdx.x & 63;
   // (readfirstlane: the work item and everything derived from it -- level, band, strip, row addresses -- is scalar)
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
     src = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
     pitch = L.pitch;
   }
-  const int t = a.threshold, nms = a.nms;
+  const int t = a.threshold;
+  constexpr bool nms = NMS;
   const v2s tt = {(short)t, (short)t};
   constexpr int HL = HALF ? 32 : 64;                        // lanes per cell
   const int half = HALF ? (lane >> 5) : 0, hl = lane & (HL - 1);
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
     // a 9-arc contains circle pixel 0 (row sy+3) or 8 (row sy-3), both in the centre pixel's column
     const uint32_t far = max(__builtin_amdgcn_sad_u8(R0.d, R3.d, 0u), __builtin_amdgcn_sad_u8(R6.d, R3.d, 0u));
     if (__any(row_ok && smask != 0 && far > (uint32_t)t)) {
-      const v2s r01 = score_pair<0>(R0, R1, R2, R3, R4, R5, R6, tt, nms);
-      const v2s r23 = score_pair<2>(R0, R1, R2, R3, R4, R5, R6, tt, nms);
+      const v2s r01 = score_pair<0, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);
+      const v2s r23 = score_pair<2, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);
       S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r23), __builtin_bit_cast(uint32_t, r01), 0x06040200u);
       S &= row_ok ? smask : 0u;
     }
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
       if (__any((S_mid.s & em) != 0)) {
         // keep iff score > every 8-neighbour (strict); without NMS every marked corner is kept
         const v2s zero = {0, 0};
-        const v2s nb01 = nms ? vmax(vmax(S_up.h3a, S_dn.h3a), S_mid.h2a) : zero;
-        const v2s nb23 = nms ? vmax(vmax(S_up.h3b, S_dn.h3b), S_mid.h2b) : zero;
+        const v2s nb01 = nms ? vmax3(S_up.h3a, S_dn.h3a, S_mid.h2a) : zero;  // (scores are 0..255 as well)
+        const v2s nb23 = nms ? vmax3(S_up.h3b, S_dn.h3b, S_mid.h2b) : zero;
         uint32_t k01 = __builtin_bit_cast(uint32_t, ((nb01 - S_mid.c01) >> 15) & em01);
         uint32_t k23 = __builtin_bit_cast(uint32_t, ((nb23 - S_mid.c23) >> 15) & em23);
         if (r >= nrows) k01 = k23 = 0;
@@ -420,11 +422,16 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.rowstart = d.rowstart;
   a.threshold = threshold;
   a.nms = nms;
-  if (g.nwork_full > 0)
-    hipLaunchKernelGGL(fast_march_kernel<false>, dim3((g.nwork_full + 3) / 4, im.n), dim3(256), 0, s, a, 0, g.nwork_full);
-  if (g.nwork_half > 0)
-    hipLaunchKernelGGL(fast_march_kernel<true>, dim3((g.nwork_half + 3) / 4, im.n), dim3(256), 0, s, a, g.nwork_full,
-                       g.nwork_half);
+  const dim3 gf((g.nwork_full + 3) / 4, im.n), gh((g.nwork_half + 3) / 4, im.n);
+  if (nms) {
+    if (g.nwork_full > 0) hipLaunchKernelGGL((fast_march_kernel<false, true>), gf, dim3(256), 0, s, a, 0, g.nwork_full);
+    if (g.nwork_half > 0)
+      hipLaunchKernelGGL((fast_march_kernel<true, true>), gh, dim3(256), 0, s, a, g.nwork_full, g.nwork_half);
+  } else {
+    if (g.nwork_full > 0) hipLaunchKernelGGL((fast_march_kernel<false, false>), gf, dim3(256), 0, s, a, 0, g.nwork_full);
+    if (g.nwork_half > 0)
+      hipLaunchKernelGGL((fast_march_kernel<true, false>), gh, dim3(256), 0, s, a, g.nwork_full, g.nwork_half);
+  }
 }
 
 void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int max_keypoints, vsf_keypoint* d_kp,
