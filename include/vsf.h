@@ -104,7 +104,8 @@ vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream);
 vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes);
 /* Cross-call pipelining for streams of batches (off by default).  With it on, the caller promises that the input
  * images of every *_batch_dev call are COMPLETE in device memory when the call is made (not merely ordered before it
- * on the stream).  The scale pyramid of a call -- which depends on nothing else -- is then built on internal streams
+ * on the stream); images produced by this library's own vsf_bayer_bg_to_gray_batch_dev on the same context are the
+ * exception -- the pipelined pyramid waits for that conversion by itself.  The scale pyramid of a call -- which depends on nothing else -- is then built on internal streams
  * into the second of two pyramid buffers while the previous call's later stages are still running; all other stages
  * and all outputs stay ordered on the context's stream as before. */
 vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);

@@ -147,15 +147,15 @@ def test_capacity_status_and_truncation(capi, oracle, stereo640):
 
 
 def test_randomised_sizes_and_parameters():
-    """A short run of tools/stress_parity.py (random sizes, ORB parameter sets, scenes incl. pure noise): keypoints,
-    descriptors and stereo matches bit for bit.  160 such cases were run by hand (seeds 11 and 2024): 0 mismatches."""
+    """tools/stress_parity.py in the suite: 100 random cases (sizes 80..900 x 70..700, six ORB parameter sets, thresholds,
+    scenes incl. pure noise), keypoints, descriptors and stereo matches bit for bit against the oracle."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    out = subprocess.run([sys.executable, str(root / "tools" / "stress_parity.py"), "10", "5"], capture_output=True, text=True)
+    out = subprocess.run([sys.executable, str(root / "tools" / "stress_parity.py"), "100", "5"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "mismatches: 0 of 10" in out.stdout
+    assert "mismatches: 0 of 100" in out.stdout
 
 
 @pytest.mark.parametrize("w,h,n", [(640, 480, 3), (641, 479, 2), (9, 5, 2), (4, 3, 1), (3, 3, 1), (2, 7, 1), (5, 2, 1),

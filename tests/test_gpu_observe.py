@@ -1,0 +1,72 @@
+"""vsf_observe_stereo -- one GPU submission per Frontend::ObserveImage (slam_frontend.cc:400-472) -- against the
+reference's sequence assembled from the CPU oracle's pieces, frame by frame over a window that fills, slides and
+meets a frame without stereo matches (quirk Q3).  Integer results (keypoints, descriptors, factor pairs, which match
+feeds which keypoint) bit for bit; point3d / pixel to the floating-point tolerance of row f2."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NF, LIFE = 700, 3
+F_RECT = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+POINT_RTOL, PIXEL_ATOL = 1e-5, 1e-4
+
+
+def test_observe_stereo_follows_the_reference_sequence(oracle):
+    from vision_slam_frontend_amd import capi, frontend, synth
+    sc = synth.Scene(320, 240, n_objects=400)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(7)]
+    frames[3] = (frames[3][0], np.full_like(frames[3][1], 128))  # no stereo match in frame 3
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    bp = float(np.float32(0.3))
+    ctx = capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF))
+    thr = np.float32(10000.0)
+    window = []  # filtered left descriptors of the kept frames, oldest first
+    sizes = []
+    for fid, (left, right) in enumerate(frames):
+        got = ctx.observe_stereo(left, right, calib, best_percent=bp, frame_life=LIFE)
+        # --- the reference's sequence on the oracle ---
+        ol, orr = oracle.Orb(nfeatures=NF), oracle.Orb(nfeatures=NF)
+        ol.run(left)
+        orr.run(right)
+        kl, dl = ol.result()
+        kr, dr = orr.result()
+        m = oracle.get_matches(dl, dr)
+        keep, res, thr_next, kept = oracle.remove_ambig_stereo(kl, kr, m, F_RECT, float(thr))
+        kl2, dl2 = kl[m["queryIdx"][keep]], dl[m["queryIdx"][keep]]
+        kr2, dr2 = kr[m["trainIdx"][keep]], dr[m["trainIdx"][keep]]
+        assert (got["n_left"], got["n_right"], got["n_stereo_matches"]) == (len(kl), len(kr), len(m))
+        assert got["threshold"].tobytes() == thr.tobytes() or (np.isnan(got["threshold"]) and np.isnan(thr))
+        assert got["threshold_next"].tobytes() == np.float32(thr_next).tobytes() or \
+            (np.isnan(got["threshold_next"]) and np.isnan(thr_next))
+        assert got["keypoints"].tobytes() == kl2.tobytes()
+        np.testing.assert_array_equal(got["descriptors"], dl2)
+        assert len(got["factors"]) == len(window)
+        for past, fac in zip(window, got["factors"]):  # cc:424-434, oldest kept frame first
+            mm = oracle.sort_and_trim(oracle.get_matches(past, dl2), bp)
+            np.testing.assert_array_equal(fac["feature_idx_initial"], mm["queryIdx"])
+            np.testing.assert_array_equal(fac["feature_idx_current"], mm["trainIdx"])
+        rl = oracle.sort_and_trim(oracle.get_matches(dr2, dl2), 1.0)  # cc:129-132
+        np.testing.assert_array_equal(got["stereo_pairs"]["feature_idx_initial"], rl["queryIdx"])
+        np.testing.assert_array_equal(got["stereo_pairs"]["feature_idx_current"], rl["trainIdx"])
+        want, npts = oracle.vision_features(kl2, dl2, kr2, dr2, calib.get("projection_left"), calib.get("projection_right"),
+                                            calib.get("camera_matrix_left"), calib.get("distortion_left"))
+        f = got["features"]
+        assert got["n_points"] == npts and len(f) == len(want)
+        np.testing.assert_array_equal(f["feature_idx"], want["feature_idx"])
+        assert np.abs(f["pixel"].astype(np.float64) - want["pixel"]).max(initial=0.0) <= PIXEL_ATOL
+        g, w = f["point3d"].astype(np.float64), want["point3d"].astype(np.float64)
+        fin = np.isfinite(w)
+        assert np.array_equal(np.isfinite(g), fin)
+        assert (np.abs(g[fin] - w[fin]) / np.maximum(np.abs(w[fin]), 1e-30)).max(initial=0.0) <= POINT_RTOL
+        thr = np.float32(thr_next)
+        if len(window) >= LIFE:
+            window.pop(0)
+        window.append(dl2)
+        sizes.append(len(kl2))
+    assert sizes[3] == 0 and sizes[4] == 0 and sizes[5] > 20  # no match; NaN threshold; filtering resumes
+    # a reset forgets the window and the threshold
+    ctx.observe_reset()
+    again = ctx.observe_stereo(*frames[0], calib, best_percent=bp, frame_life=LIFE)
+    assert again["threshold"] == np.float32(10000.0) and len(again["factors"]) == 0
+    ctx.close()

@@ -20,12 +20,17 @@ def test_orb_pattern_hash_and_first_rows(oracle):
     assert hashlib.sha256(p.tobytes()).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
     assert p[0].tolist() == [8, -3, 9, 5] and p[1].tolist() == [4, 2, 7, -12] and p[2].tolist() == [-11, 9, -8, 2]
     assert p.min() == -13 and p.max() == 12
-    # the product carries its own copy of the table: same bytes
+    # product and oracle are generated at build time from ONE tracked table (data/orb_pattern31.txt)
+    import subprocess
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
+    rows = [l.split() for l in (root / "data" / "orb_pattern31.txt").read_text().splitlines() if l and l[0] != "#"]
+    assert np.array_equal(np.array(rows, np.int64).astype(np.int8), p)
     a = (root / "oracle" / "orb_pattern31.inc").read_text()
     b = (root / "vision_slam_frontend_amd" / "csrc" / "orb_pattern31.inc").read_text()
-    assert a == b
+    assert a == b and "GENERATED" in a
+    tracked = subprocess.run(["git", "ls-files", "*orb_pattern31.inc"], cwd=root, capture_output=True, text=True)
+    assert tracked.returncode != 0 or tracked.stdout.strip() == ""  # the generated copies are not in the history
 
 
 def test_pyramid_geometry_appendix_c(oracle):

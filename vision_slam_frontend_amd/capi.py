@@ -34,7 +34,7 @@ EXPORTS = [
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
-    "vsf_pack_outputs_dev",
+    "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_reset",
 ]
 STAGE_COUNT = 8
 
@@ -121,6 +121,11 @@ def lib() -> C.CDLL:
         L.vsf_packed_outputs_capacity.argtypes = [vp, i32, i32]
         L.vsf_packed_outputs_capacity.restype = sz
         L.vsf_pack_outputs_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, sz]
+        L.vsf_observe_capacity.argtypes = [vp, i32]
+        L.vsf_observe_capacity.restype = sz
+        L.vsf_observe_stereo.argtypes = [vp, vp, vp, i32, i32, sz, C.POINTER(VsfCalibration), C.c_float, i32, vp, sz,
+                                         C.POINTER(sz)]
+        L.vsf_observe_reset.argtypes = [vp]
         L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
         L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
         L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
@@ -347,6 +352,24 @@ class Context:
                                                _p(d_npairs), n_pairs, _p(d_payload), payload_cap),
                     "vsf_pack_outputs_dev")
 
+    def observe_stereo(self, left: np.ndarray, right: np.ndarray, calib: VsfCalibration, best_percent: float = 0.3,
+                       frame_life: int = 10) -> dict:
+        """One Frontend::ObserveImage worth of GPU work in one submission (vsf_observe_stereo); returns the decoded
+        result: header fields, `features` (VISION_FEATURE_DTYPE), `factors` (FEATURE_MATCH_DTYPE arrays, oldest kept
+        frame first), `stereo_pairs` (the right->left matches of Calculate3DPoints), `keypoints`, `descriptors`."""
+        left, right = _u8(left), _u8(right)
+        assert left.shape == right.shape and left.strides == right.strides
+        cap = int(lib().vsf_observe_capacity(self._h, frame_life))
+        buf = np.zeros(max(cap, 64), np.uint8)
+        n = C.c_size_t()
+        self._check(lib().vsf_observe_stereo(self._h, _p(left), _p(right), left.shape[1], left.shape[0], left.strides[0],
+                                             C.byref(calib), float(np.float32(best_percent)), frame_life, _p(buf), cap,
+                                             C.byref(n)), "vsf_observe_stereo")
+        return decode_observation(buf[:n.value])
+
+    def observe_reset(self):
+        self._check(lib().vsf_observe_reset(self._h), "vsf_observe_reset")
+
     def bayer_bg_to_gray_batch_dev(self, d_src: int, n_images: int, width: int, height: int, src_image_stride: int,
                                    src_row_stride: int, d_dst: int, dst_image_stride: int, dst_row_stride: int):
         """DecodeImage's BayerBG2BGR + BGR2GRAY (slam_frontend_main.cc:101-106) on mosaics resident in HBM."""
@@ -434,3 +457,30 @@ def unpack_outputs(payload: np.ndarray):
         off += n
     assert off == total
     return feats, matches
+
+
+def decode_observation(buf: np.ndarray) -> dict:
+    """Decodes vsf_observe_stereo's result (layout: include/vsf.h)."""
+    b = np.ascontiguousarray(buf, np.uint8).reshape(-1)
+    hdr = b[:64].view(np.uint32)
+    if int(hdr[0]) != 0x4F465356:
+        raise ValueError("not an observation payload")
+    n_pairs, nfeat, total = int(hdr[1]), int(hdr[2]), int(hdr[3])
+    assert total == len(b), (total, len(b))
+    f32 = b[:64].view(np.float32)
+    npairs = b[64:64 + 4 * n_pairs].view(np.uint32).astype(np.int64)
+    off = 64 + 4 * ((n_pairs + 3) & ~3)
+    feats = b[off:off + 28 * nfeat].view(VISION_FEATURE_DTYPE).copy()
+    off += 28 * nfeat
+    lists = []
+    for p in range(n_pairs):
+        lists.append(b[off:off + 16 * int(npairs[p])].view(FEATURE_MATCH_DTYPE).copy())
+        off += 16 * int(npairs[p])
+    kp = b[off:off + 28 * nfeat].view(KEYPOINT_DTYPE).copy()
+    off += 28 * nfeat
+    desc = b[off:off + 32 * nfeat].reshape(nfeat, 32).copy()
+    off += 32 * nfeat
+    assert off == total
+    return {"n_left": int(hdr[4]), "n_right": int(hdr[5]), "n_stereo_matches": int(hdr[6]), "n_points": int(hdr[7]),
+            "mean": np.float32(f32[8]), "threshold": np.float32(f32[9]), "threshold_next": np.float32(f32[10]),
+            "features": feats, "factors": lists[:-1], "stereo_pairs": lists[-1], "keypoints": kp, "descriptors": desc}

@@ -2,11 +2,16 @@
 // core/stat.cpp batchDistance + normHamming) and the reference's ratio test, Frontend::GetMatches
 // (slam_frontend.cc:521-538).
 //
-// knn2: one lane per query row keeps its 256-bit descriptor in 8 VGPRs; the train set streams through LDS in
-// blocks of 256 rows (coalesced 16-byte loads, then wave-uniform ds_read_b128 broadcasts).  A distance is
-// 8 x (v_xor + v_bcnt accumulate); the running top-2 is kept on packed keys  (distance << 20 | train index),
-// so "smaller distance first, ties to the lower train index" -- exactly batchDistance's insertion rule -- is an
-// unsigned min / med3.  Integer VALU bound (not HBM, not MFMA): 2000 x 2000 rows move 128 KB.
+// knn2: Hamming distances on the int8 matrix cores.  Train bits are expanded to +-64 int8 and query bits to -+64, so a
+// train row x query column at Hamming distance d multiplies to 8192 d - 2^20; an accumulator initialised to 2^20 + (row
+// index inside its 8192-row range) therefore ends as the packed sort key  d << 13 | row  -- v_mfma_i32_32x32x32_i8
+// produces the key itself and the vector ALU only keeps the two smallest per query (v_min_u32 + v_med3_u32), which is
+// "smaller distance first, ties to the lower train index", exactly batchDistance's insertion rule.  A wave owns 64
+// queries (two column tiles), a workgroup's four waves share each expanded 32-row train tile through LDS (double
+// buffered, one barrier per tile); ranges beyond 8192 train rows are folded into  d << 20 | index  keys per range; with
+// few pairs the train set is split over workgroups and merged by 64-bit CAS.  Bound by the VALU fold beside the MFMA
+// pipe (bench.py reports pair-distances/s and the fraction of the dense int8 MFMA peak); 2000 x 2000 rows move 128 KB,
+// HBM is idle.  (A v_xor / v_bcnt kernel with per-lane queries took 2.7x as long and was retired in round 1.)
 // ratio_compact: per pair, keep  d1 * 2^shift < num * d2  (the double-precision compare of the reference,
 // exact in integers) and compact the survivors in ascending query index.
 #include <limits.h>

@@ -5,12 +5,17 @@
 // (features2d/orb.cpp), i.e. from slam_frontend.cc:274.  The coefficient tables (xofs/ialpha, yofs/ibeta) are
 // built once per context on the host exactly as cv::resize builds them, so the kernel is integer-only.
 //
-// Streaming march kernel (no LDS, no barriers): a wave owns 256 output columns (lane = 4 adjacent pixels) and walks
-// down a strip of output rows.  The lane's four x-taps are loop-invariant: they become four v_perm_b32 byte
-// selectors and four packed weight pairs, so one 8-byte load per source row + 4 x (v_perm + v_dot2_u32_u16) gives
-// the four horizontal sums; the vertical pass and a 32-bit store finish the row.  A wave handles 4 output rows and
-// issues all eight source-row loads before any arithmetic (rows shared between neighbouring output rows hit L1),
-// so the kernel is limited by memory-level parallelism across waves, not by a per-row dependency chain.
+// resize_strip_kernel<R> (no LDS, no barriers): a wave owns 256 output columns (lane = 4 adjacent pixels) x a strip of
+// R = 8 or 16 output rows.  The lane's four x-taps are loop-invariant: four v_perm_b32 byte selectors and four packed
+// weight pairs, evaluated IN the kernel with cv::resize's own double / float steps (no table load ahead of the row
+// loads); the y taps are evaluated once per wave (lane r <-> row r, v_readlane -> scalar addresses and weights).  At
+// scale 1.04 the R output rows touch at most R + 2 consecutive source rows (checked per level on the host,
+// VsfLevel::resize_rows), so every source row goes through the horizontal pass ONCE (one 8-byte load + 4 x (v_perm +
+// v_dot2_u32_u16)) and an output row picks its two with a wave-uniform branch; the vertical pass is v_mul_hi_u32_u24 on
+// pre-shifted weights.  One launch per level (the level chain is a true dependency), issued as two chains of half
+// batches on two streams.  pyramid_image_kernel: when the batch fills the chip, the 26 one-band levels (w <= 256) are
+// built by ONE launch, a 1024-thread workgroup per image with the levels ping-ponged through LDS.
+// resize_march_kernel is the general fallback for levels that fail the R + 2 check.
 #pragma clang fp contract(off)
 #include <algorithm>
 

@@ -296,10 +296,12 @@ struct vsf_ctx {
   bool pipeline = false;
   uint8_t* pyr_alt = nullptr;
   int pyr_flip = 0;
-  hipStream_t pipe_stream = nullptr;
-  VsfSideStream pipe_side{};
   hipEvent_t ev_pyr_done = nullptr, ev_pyr_free[2] = {nullptr, nullptr}, ev_fast_done = nullptr;
   bool pyr_free_valid[2] = {false, false}, fast_done_valid = false;
+  // A producer the library owns (the Bayer ingest) records this on the context's stream; a pipelined pyramid, which is
+  // NOT ordered after that stream's earlier work, waits for it.
+  hipEvent_t ev_ingest_done = nullptr;
+  bool ingest_done_valid = false;
   const uint8_t* last_pyr = nullptr;
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int last_hip = 0;
@@ -612,6 +614,8 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     // ... and not before the previous call's FAST kernel has finished: FAST fills every register of the chip, the
     // stages after it (selection, descriptors, matcher) are latency-bound and leave room for the resize chain
     if (ctx->fast_done_valid) (void)hipStreamWaitEvent(ps, ctx->ev_fast_done, 0);
+    // ... and not before images this library itself is still producing on the context's stream are complete
+    if (ctx->ingest_done_valid) (void)hipStreamWaitEvent(ps, ctx->ev_ingest_done, 0);
     {
       StageTimer t(ctx, ps, VSF_STAGE_PYRAMID, g.nlevels - 1);
       vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ps, nullptr);
@@ -845,17 +849,12 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
   if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
-  if (ctx->pipe_stream) {
-    hipStreamSynchronize(ctx->pipe_stream);
-    hipStreamSynchronize(ctx->pipe_side.stream[0]);
-    hipStreamDestroy(ctx->pipe_stream);
-    hipStreamDestroy(ctx->pipe_side.stream[0]);
-    hipEventDestroy(ctx->pipe_side.fork);
-    hipEventDestroy(ctx->pipe_side.join[0]);
+  if (ctx->ev_pyr_done) {
     hipEventDestroy(ctx->ev_pyr_done);
     hipEventDestroy(ctx->ev_fast_done);
     for (hipEvent_t e : ctx->ev_pyr_free) hipEventDestroy(e);
   }
+  if (ctx->ev_ingest_done) hipEventDestroy(ctx->ev_ingest_done);
   hipFree(ctx->pyr_alt);
   free_devset(&ctx->dorb);
   free_devset(&ctx->dfast);
@@ -928,14 +927,9 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->pipe_stream) VSF_HIP(hipStreamSynchronize(ctx->pipe_stream));
+  VSF_HIP(hipStreamSynchronize(ctx->aux_stream));  // (the pipelined pyramid chain runs there)
   if (on && !ctx->pyr_alt) {
     VSF_HIP(hipMalloc((void**)&ctx->pyr_alt, (size_t)ctx->p.max_images * ctx->orb.g.pyr_bytes));
-    VSF_HIP(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
-    VSF_HIP(hipStreamCreateWithFlags(&ctx->pipe_side.stream[0], hipStreamNonBlocking));
-    VSF_HIP(hipEventCreateWithFlags(&ctx->pipe_side.fork, hipEventDisableTiming));
-    VSF_HIP(hipEventCreateWithFlags(&ctx->pipe_side.join[0], hipEventDisableTiming));
-    ctx->pipe_side.n = 1;
     VSF_HIP(hipEventCreateWithFlags(&ctx->ev_pyr_done, hipEventDisableTiming));
     VSF_HIP(hipEventCreateWithFlags(&ctx->ev_fast_done, hipEventDisableTiming));
     for (hipEvent_t& e : ctx->ev_pyr_free) VSF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1220,6 +1214,10 @@ vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, in
   vsf_launch_bayer_bg_gray(d_src, n_images, width, height, src_image_stride, (int)src_row_stride, d_dst,
                            dst_image_stride, (int)dst_row_stride, ctx->stream);
   VSF_HIP(hipGetLastError());
+  // a pipelined extract that follows (vsf_set_pipeline) builds its pyramid off this stream: give it something to wait for
+  if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
+  VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));
+  ctx->ingest_done_valid = true;
   return VSF_OK;
 }
 
