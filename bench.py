@@ -70,6 +70,28 @@ def committed_counters(width: int, height: int, nfeatures: int, batch: int):
     return t.get("stages", {})
 
 
+def host_cores():
+    """(threads to use, how they were counted): the cores this process may actually run on -- its affinity mask, cut
+    down to the cgroup's CPU quota when there is one (a GPU box shows every core of the host but grants a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "all %d cores of the affinity mask" % n
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, how = q, "the cgroup CPU quota of %d cores (host shows %d)" % (q, len(os.sched_getaffinity(0)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), how
+
+
 def cpu_baseline(width, height, nfeatures, seed):
     """The CPU oracle (a scalar C++ restatement of the OpenCV routines, kind "port": real OpenCV cannot be built here)
     timed on ALL of this box's host cores, one stereo frame per thread at a time."""
@@ -79,12 +101,8 @@ def cpu_baseline(width, height, nfeatures, seed):
     from vision_slam_frontend_amd import synth
 
     ob.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, cores)
-    per_frame_s = 0.2 * (width * height) / (640 * 480)  # measured: ~0.2 s per VGA stereo frame and thread
-    rounds = max(1, int(round(15.0 / per_frame_s)))      # ~15 s of wall time ...
-    n = rounds * cores                                    # ... on every core
-    n_render = min(n, 4 * cores, 64)
+    cores, how = host_cores()
+    n_render = min(4 * cores, 64)
     frames = synth.bench_batch(n_render, width, height, seed=seed, n_scenes=min(4, n_render))
 
     def one(i):
@@ -96,14 +114,29 @@ def cpu_baseline(width, height, nfeatures, seed):
         return len(ob.get_matches(da, db))
 
     one(0)  # warm (page in, build tables)
-    t0 = time.perf_counter()
+    # A box may show more cores than it grants (a CPU share without a readable cgroup quota): one calibration round on
+    # the visible cores measures how many actually ran (process CPU time / wall time); the timed rounds use that many.
+    if cores > 1:
+        c0, w0 = sum(os.times()[:2]), time.perf_counter()
+        with ThreadPoolExecutor(min(cores, 64)) as ex:
+            list(ex.map(one, range(min(cores, 64))))
+        granted = (sum(os.times()[:2]) - c0) / max(time.perf_counter() - w0, 1e-9)
+        if granted < 0.75 * min(cores, 64):
+            cores = max(1, int(granted + 0.5))
+            how = "the %d cores this process was granted (measured: CPU time / wall time; the host shows more)" % cores
+    # rounds of one frame per thread until ~15 s of wall time have passed (at least two rounds): bounded whatever the box
+    n, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(one, range(n)))
-    dt = time.perf_counter() - t0
+        while True:
+            list(ex.map(one, range(n, n + cores)))
+            n += cores
+            dt = time.perf_counter() - t0
+            if dt >= 15.0 and n >= 2 * cores:
+                break
     return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
             "sample": "%d synthetic %dx%d stereo frames (%d kp) through the oracle port's extract(L)+extract(R)+GetMatches "
-                      "(scalar C++ restatement of OpenCV 3.2, not OpenCV itself), %d threads = all host cores, %.1f s wall"
-                      % (n, width, height, nfeatures, cores, dt)}
+                      "(scalar C++ restatement of OpenCV 3.2, not OpenCV itself), %d threads = %s, %.1f s wall"
+                      % (n, width, height, nfeatures, cores, how, dt)}
 
 
 def main() -> int:
