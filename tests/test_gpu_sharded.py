@@ -113,3 +113,48 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert sum(len(v) for v in want_m.values()) > 40
     # and the payloads were compact: sized by the counts, not by the capacity
     assert all(int(pl[:16].view(np.uint32)[3]) < sf1.cap // 4 for _, per in completed for pl in per)
+
+
+def _rccl_worker(rank: int, port: int, frames_path: str, out_path: str):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["VSF_FORCE_COLLECTIVES"] = "1"
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        frames = np.load(frames_path)
+        sf, _, ctx = _run(frames, WORLD * B, 0, 1)
+        assert sf.dist_on and not sf.host_detour and [c[0] for c in sf.completed] == list(range(STEPS))
+        np.savez(out_path, **{"s%d" % st: per[0].cpu().numpy() for st, per in sf.completed})
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_on_rccl_in_a_world_of_one(tmp_path):
+    """The same class on the REAL backend (nccl = RCCL) with device tensors: a one-GPU box cannot host two RCCL ranks, so
+    this runs every collective of the step (three all-gathers, the size exchange, the asynchronous sized gather with its
+    slot rotation) in a world of one and compares the gathered payloads with the collective-free run."""
+    import torch.multiprocessing as mp
+
+    from vision_slam_frontend_amd import distributed as vd
+    from vision_slam_frontend_amd import synth
+
+    n = WORLD * B * STEPS
+    frames = synth.stereo_stream(n, W_IMG, H_IMG, n_objects=400)
+    frames_path, out_path = str(tmp_path / "frames.npy"), str(tmp_path / "gathered.npz")
+    np.save(frames_path, frames)
+    sf1, local, ctx1 = _run(frames, WORLD * B, 0, 1)
+    ctx1.close()
+    mp.spawn(_rccl_worker, args=(_free_port(), frames_path, out_path), nprocs=1, join=True)
+    z = np.load(out_path)
+    for s, per in local:
+        want = per[0].numpy()
+        total = int(want[:16].view(np.uint32)[3])
+        got = z["s%d" % s]
+        assert len(got) >= total and got[:total].tobytes() == want[:total].tobytes(), "payload of step %d" % s
+    want_f, want_m = vd.assemble_outputs(local, 1, WORLD * B, WINDOW)
+    assert sum(len(v) for v in want_f.values()) > 200 and sum(len(v) for v in want_m.values()) > 40

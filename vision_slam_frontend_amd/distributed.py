@@ -15,6 +15,7 @@ CPU tensors in the CPU test-suite.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -190,7 +191,9 @@ class ShardedStereoFrontend:
         self.width, self.height = int(width), int(height)
         self.calib = calib
         self.best_percent = float(np.float32(best_percent))
-        self.dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # (VSF_FORCE_COLLECTIVES=1 runs every collective even in a world of one: the RCCL code path on a one-GPU box)
+        self.dist_on = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or bool(os.environ.get("VSF_FORCE_COLLECTIVES")))
         self.world = dist.get_world_size() if self.dist_on else 1
         self.rank = dist.get_rank() if self.dist_on else 0
         self.host_detour = self.dist_on and dist.get_backend() == "gloo"
