@@ -23,7 +23,14 @@
 namespace {
 
 constexpr int kTile = 32;          // train rows per MFMA tile
-constexpr int kTileStride = 272;   // bytes per expanded train row in LDS (256 + 16: conflict-free ds_read_b128)
+// Bytes per expanded train row in LDS: 256 + 16.  The ds_read_b128 operand reads are conflict-free with it (each of the
+// instruction's four 16-lane groups {0-3,12-15,20-27}, ... tiles all 64 banks).  The 1.6 extra LDS cycles per LDS
+// instruction that SQ_LDS_BANK_CONFLICT reports are the STAGING stores: ds_write_b128 is served in groups of 8 contiguous
+// lanes on 32 banks and a row's eight lanes write pieces 0, 2, .., 14, two by two on the same banks.  Letting lanes
+// s >= 4 write their odd piece first (rotate the dword by 16 bits, exchange the two addresses) removes every conflict
+// and was measured in round 2: 0.140 ms instead of 0.135 ms per 128 pairs of 2000 x 2000 -- the store's 13-cycle
+// register transfer hides a 2-way conflict, the extra v_alignbit does not hide in a kernel bound by its VALU fold.
+constexpr int kTileStride = 272;
 constexpr int kChunkRows = 8192;   // train rows per key range (13-bit relative index inside the accumulator)
 constexpr int kSplitAlign = 128;   // split chunks are multiples of this many train rows (four tiles)
 
