@@ -154,6 +154,9 @@ def main() -> int:
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap a step's pyramid with the previous step's latency-bound tail (vsf_set_pipeline); "
                          "the per-stage timers then overlap; off for the reported line")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run a step's tail (RemoveAmbigStereo ... payload, collectives) on the extraction's stream instead of "
+                         "beside the next step's extraction")
     ap.add_argument("--scene", choices=["bench", "sparse"], default="bench",
                     help="sparse: few objects on a smooth background (~2 %% corner pixels) instead of SURVEY 8(d)'s stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,7 +211,8 @@ def main() -> int:
     calib = frontend.default_calibration()
     # the synthetic pairs are rectified (pure horizontal disparity): l^T F r = y_r - y_l
     calib.set("fundamental", [0, 0, 0, 0, 0, -1, 0, 1, 0])
-    sf = vd.ShardedStereoFrontend(ctx, B, W, H, calib, window=args.window, device=dev, stream=stream)
+    sf = vd.ShardedStereoFrontend(ctx, B, W, H, calib, window=args.window, device=dev, stream=stream,
+                                  overlap=not args.no_overlap)
     sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
     ctx.set_lanes(args.lanes)
     ctx.set_pipeline(args.pipeline)  # (legal here: the synthetic stream is resident in HBM before every call)
@@ -217,8 +221,9 @@ def main() -> int:
     for _ in range(args.warmup):
         sf.step(d_img)
     sf.drain()
-    ctx.sync(allow_capacity=True)
-    ctx.profile_enable(True)
+    for c in sf.contexts():
+        c.sync(allow_capacity=True)
+        c.profile_enable(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -230,9 +235,12 @@ def main() -> int:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    stages = ctx.profile_read(reset=True)
-    ctx.profile_enable(False)
-    status = ctx.sync(allow_capacity=True)
+    stages, status = {}, capi.VSF_OK
+    for c in sf.contexts():  # the extraction's context and the tail's: together they cover the step
+        for k, (ms, n) in c.profile_read(reset=True).items():
+            stages[k] = (stages.get(k, (0.0, 0))[0] + ms, stages.get(k, (0.0, 0))[1] + n)
+        c.profile_enable(False)
+        status = max(status, c.sync(allow_capacity=True))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,6 +302,8 @@ def main() -> int:
                        "parallelism": "frames sharded over %d GPU(s)%s" %
                                       (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
                                               "(RCCL)" if world > 1 else ""),
+                       "tail_overlap": "step s's tail + collectives on a second stream beside step s+1's extraction"
+                                       if sf.overlap else "off (one stream)",
                        "mean_keypoints_per_image": float(counts.mean()), "mean_stereo_matches": float(nm.mean()),
                        "mean_features_per_frame": float(nfeat.mean()), "payload_bytes_per_step_per_gpu": payload_bytes,
                        "parity": "bit-exact vs the in-repo oracle (a restatement of OpenCV 3.2; parity with OpenCV itself unpinned)",
@@ -315,6 +325,7 @@ def main() -> int:
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    sf.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -41,10 +41,11 @@ def _run(frames, frames_per_rank, rank, world):
         d_img = torch.from_numpy(np.ascontiguousarray(frames[idx])).to(dev)
         sf.step(d_img)
         if world == 1:
-            sf.stream.synchronize()
+            sf.synchronize()
             local.append((s, [sf.local_payload(s).cpu().clone()]))
     sf.drain()
-    assert ctx.sync() == capi.VSF_OK
+    assert all(c.sync() == capi.VSF_OK for c in sf.contexts())
+    sf.close()
     return sf, local, ctx
 
 

@@ -176,6 +176,11 @@ class ShardedStereoFrontend:
      10. all-gather of the payload sizes (4 bytes per rank), then -- one step later, when the sizes have reached the
          host without stalling it -- an asynchronous gather of the payloads to rank 0, sized by the counts        RCCL
 
+    Steps 2-10 (the "tail": short latency-bound kernels and every collective) of step s run on a SECOND, high-priority
+    stream with a small context of their own while step s + 1's extraction fills the chip on the main stream: the raw
+    outputs of step 1 are double-buffered and two events per buffer order the streams (raw ready -> tail may read; tail
+    done -> the extraction after next may overwrite).  The tail's kernels leave the vector ALUs idle most of the time, so
+    this hides them -- and the collectives' rendezvous between ranks -- behind the VALU-bound extraction.
     With world == 1 the same kernels run and the collectives degenerate to local copies, so bench.py measures the same
     per-GPU work at every N.  Works on "nccl" (RCCL, device tensors) and, for one-GPU rehearsals and the CPU-side
     tests of the exchange logic, on "gloo" (tensors take a detour through the host).
@@ -184,8 +189,8 @@ class ShardedStereoFrontend:
     PAYLOAD_SLOTS = 3
 
     def __init__(self, ctx, frames_per_rank: int, width: int, height: int, calib, *, window: int = 1,
-                 best_percent: float = 0.3, device=None, stream=None):
-        from . import capi  # noqa: F401  (ctx is a capi.Context)
+                 best_percent: float = 0.3, device=None, stream=None, overlap: bool = True):
+        from . import capi  # (ctx is a capi.Context)
 
         self.ctx, self.B, self.W = ctx, int(frames_per_rank), int(window)
         self.width, self.height = int(width), int(height)
@@ -202,14 +207,26 @@ class ShardedStereoFrontend:
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.dev = dev
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.overlap = bool(overlap)
+        if self.overlap:
+            # the tail's own stream (high priority: its few small workgroups should not queue behind the thousands of
+            # the extraction kernels) and context (scratch buffers and stream are per context)
+            self.tail_stream = torch.cuda.Stream(device=dev, priority=-1)
+            tail_params = capi.VsfParams.from_buffer_copy(ctx.params)
+            tail_params.max_images = 2
+            self.tail_ctx = capi.Context(tail_params, device=ctx.device)
+            assert self.tail_ctx.params.max_keypoints == ctx.params.max_keypoints
+        else:
+            self.tail_stream, self.tail_ctx = self.stream, ctx
+        self.NRAW = 2 if self.overlap else 1
         B, W, world, K = self.B, self.W, self.world, ctx.params.max_keypoints
         self.K = K
         self.F = calib.get("fundamental")
         u8 = torch.uint8
         with torch.cuda.stream(self.stream):
             z = lambda *shape, dtype=u8: torch.zeros(shape, dtype=dtype, device=dev)  # noqa: E731
-            self.kp, self.desc, self.counts = z(2 * B, K, 28), z(2 * B, K, 32), z(2 * B, dtype=torch.int32)
-            self.matches, self.nmatches = z(B, K, 16), z(B, dtype=torch.int32)
+            self.raw = [dict(kp=z(2 * B, K, 28), desc=z(2 * B, K, 32), counts=z(2 * B, dtype=torch.int32),
+                             matches=z(B, K, 16), nmatches=z(B, dtype=torch.int32)) for _ in range(self.NRAW)]
             self.means = z(B, dtype=torch.float32)
             self.means_all = z(world * B, dtype=torch.float32)
             self.thr_all = z(world * B, dtype=torch.float32)
@@ -233,6 +250,8 @@ class ShardedStereoFrontend:
             self.pair_sets = {key: self._pair_sets(*key) for key in ((0, True), (1, True), (0, False), (1, False))}
         self.sizes_host = [torch.zeros(world, dtype=torch.int32).pin_memory() for _ in range(self.PAYLOAD_SLOTS)]
         self.size_events = [torch.cuda.Event() for _ in range(self.PAYLOAD_SLOTS)]
+        self.raw_ready = [torch.cuda.Event() for _ in range(self.NRAW)]  # extraction of the buffer's step has finished
+        self.raw_free = [torch.cuda.Event() for _ in range(self.NRAW)]   # the tail has read it: may be overwritten
         self.recv = None
         if self.rank == 0 and self.dist_on:
             # receive buffers sized by the largest possible payload; each gather uses a prefix sized by the counts
@@ -245,7 +264,33 @@ class ShardedStereoFrontend:
         self.completed = []  # on rank 0: (step, [uint8 tensor per rank]) in step order
         self.keep_outputs = True
         ctx.set_stream(self.stream.cuda_stream)
+        if self.overlap:
+            self.tail_ctx.set_stream(self.tail_stream.cuda_stream)
         self.stream.synchronize()
+
+    # the raw outputs of the most recent step (bench.py reports their counts)
+    @property
+    def counts(self):
+        return self.raw[(self.step_idx - 1) % self.NRAW]["counts"]
+
+    @property
+    def nmatches(self):
+        return self.raw[(self.step_idx - 1) % self.NRAW]["nmatches"]
+
+    def synchronize(self):
+        """Waits for everything issued so far on both streams (not for outstanding gathers: drain())."""
+        self.stream.synchronize()
+        self.tail_stream.synchronize()
+
+    def contexts(self):
+        """The vsf contexts whose per-stage timers together cover a step."""
+        return [self.ctx] + ([self.tail_ctx] if self.overlap else [])
+
+    def close(self):
+        if self.overlap and self.tail_ctx is not None:
+            self.tail_stream.synchronize()
+            self.tail_ctx.close()
+            self.tail_ctx = None
 
     # ---- static schedule of the temporal pairs ----
     def _pair_sets(self, parity: int, first_step: bool):
@@ -269,7 +314,7 @@ class ShardedStereoFrontend:
             out.view(-1).copy_(inp.reshape(-1))
             return
         if self.host_detour:
-            self.stream.synchronize()
+            self.tail_stream.synchronize()
             h_in = inp.contiguous().cpu().reshape(-1)
             parts = [torch.empty_like(h_in) for _ in range(self.world)]
             dist.all_gather(parts, h_in)
@@ -280,36 +325,46 @@ class ShardedStereoFrontend:
     # ---- one step ----
     def step(self, d_img: torch.Tensor):
         """d_img: (B, 2, H, W) uint8 resident in HBM: this rank's frames of step `step_idx`, in time order."""
-        ctx, B, W, K, world = self.ctx, self.B, self.W, self.K, self.world
+        ctx, tctx, B, W, K, world = self.ctx, self.tail_ctx, self.B, self.W, self.K, self.world
         s = self.step_idx
         parity, slot = s & 1, s % self.PAYLOAD_SLOTS
+        raw = self.raw[s % self.NRAW]
         p = lambda t: t.data_ptr()  # noqa: E731
         with torch.cuda.stream(self.stream):
+            if self.overlap and s >= self.NRAW:
+                self.stream.wait_event(self.raw_free[s % self.NRAW])  # the tail of step s - 2 has read this buffer
+            ctx.stereo_batch_dev(p(d_img), B, self.width * self.height, self.width, p(raw["kp"]), p(raw["desc"]),
+                                 p(raw["counts"]), p(raw["matches"]), p(raw["nmatches"]))
+            if self.overlap:
+                self.raw_ready[s % self.NRAW].record(self.stream)
+        with torch.cuda.stream(self.tail_stream):
+            if self.overlap:
+                self.tail_stream.wait_event(self.raw_ready[s % self.NRAW])
             if self.dist_on:  # payload slot `slot` (and the root's receive set) was last used by step s - PAYLOAD_SLOTS
                 self._retire_through(s - self.PAYLOAD_SLOTS)
-            ctx.stereo_batch_dev(p(d_img), B, self.width * self.height, self.width, p(self.kp), p(self.desc),
-                                 p(self.counts), p(self.matches), p(self.nmatches))
-            ctx.stereo_residuals_batch_dev(p(self.kp), p(self.matches), p(self.nmatches), B, self.F, p(self.means))
+            tctx.stereo_residuals_batch_dev(p(raw["kp"]), p(raw["matches"]), p(raw["nmatches"]), B, self.F, p(self.means))
             self._all_gather(self.means_all, self.means)
-            ctx.stereo_thresholds_dev(p(self.means_all), world * B, p(self.thr_state), p(self.thr_all))
-            ctx.stereo_filter_batch_dev(p(self.kp), p(self.desc), p(self.matches), p(self.nmatches), B,
-                                        p(self.thr_all) + 4 * self.rank * B, p(self.kpf), p(self.descf), p(self.countsf))
+            tctx.stereo_thresholds_dev(p(self.means_all), world * B, p(self.thr_state), p(self.thr_all))
+            tctx.stereo_filter_batch_dev(p(raw["kp"]), p(raw["desc"]), p(raw["matches"]), p(raw["nmatches"]), B,
+                                         p(self.thr_all) + 4 * self.rank * B, p(self.kpf), p(self.descf), p(self.countsf))
+            if self.overlap:
+                self.raw_free[s % self.NRAW].record(self.tail_stream)  # nothing below reads the raw outputs
             if W > 0:
                 r0 = self.tail0 + parity * world * W
                 self._all_gather(self.descf[r0:r0 + world * W], self.descf.index_select(0, self.tail_idx))
                 self._all_gather(self.countsf[r0:r0 + world * W], self.countsf.index_select(0, self.tail_idx))
                 q_set, t_set = self.pair_sets[(parity, s == 0)]
-                ctx.feature_matches_batch_dev(p(self.descf), p(self.countsf), K * 32, p(q_set), p(t_set), self.NP,
-                                              self.best_percent, p(self.pairs), p(self.npairs))
-            ctx.vision_features_batch_dev(self.calib, p(self.kpf), p(self.descf), p(self.countsf), B, p(self.feat),
-                                          p(self.nfeat), 0)
-            ctx.pack_outputs_dev(p(self.feat), p(self.nfeat), B, p(self.pairs), p(self.npairs), self.NP,
-                                 p(self.payload[slot]), self.cap)
+                tctx.feature_matches_batch_dev(p(self.descf), p(self.countsf), K * 32, p(q_set), p(t_set), self.NP,
+                                               self.best_percent, p(self.pairs), p(self.npairs))
+            tctx.vision_features_batch_dev(self.calib, p(self.kpf), p(self.descf), p(self.countsf), B, p(self.feat),
+                                           p(self.nfeat), 0)
+            tctx.pack_outputs_dev(p(self.feat), p(self.nfeat), B, p(self.pairs), p(self.npairs), self.NP,
+                                  p(self.payload[slot]), self.cap)
             if self.dist_on:
                 # sizes of every rank's payload -> host, without stalling it: read one step later
                 self._all_gather(self.sizes_dev[slot], self.payload[slot][12:16].view(torch.int32))
                 self.sizes_host[slot].copy_(self.sizes_dev[slot], non_blocking=True)
-                self.size_events[slot].record(self.stream)
+                self.size_events[slot].record(self.tail_stream)
                 while self.next_gather < s:
                     self._issue_gather(self.next_gather)
         self.step_idx += 1
@@ -340,10 +395,11 @@ class ShardedStereoFrontend:
     def drain(self):
         """Issues and completes every outstanding gather (call inside the timed region), then waits for the stream."""
         if self.dist_on:
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(self.tail_stream):
                 while self.next_gather < self.step_idx:
                     self._issue_gather(self.next_gather)
                 self._retire_through(self.step_idx)
+        self.tail_stream.synchronize()
         self.stream.synchronize()
 
     def local_payload(self, step: int) -> torch.Tensor:
