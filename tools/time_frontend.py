@@ -12,10 +12,18 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from vision_slam_frontend_amd import frontend, synth  # noqa: E402
 
 
-def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 24, width: int = 640, height: int = 480):
-    """Median ObserveImage time in ms once the window of 10 kept frames is full."""
-    sc = synth.Scene(width, height)
-    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(n_frames)]
+_FRAMES = {}
+
+
+def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 56, width: int = 640, height: int = 480):
+    """Median ObserveImage time in ms in the steady state: the window of 10 kept frames is full and every launch chain
+    the fused path replays as a hipGraph has been captured once (one per ring slot: the first 21 frames)."""
+    if (width, height) not in _FRAMES:
+        sc = synth.Scene(width, height)
+        base = [(sc.render(f, 0), sc.render(f, 1)) for f in range(14)]
+        _FRAMES[(width, height)] = base
+    base = _FRAMES[(width, height)]
+    frames = [base[f % len(base)] for f in range(n_frames)]
     F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
     fe = frontend.Frontend(width, height, nfeatures=nfeatures, fundamental=F)
     fe.set_fused(fused)
@@ -30,7 +38,7 @@ def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 24, wid
         assert added
     feats = [len(n["features"]) for n in fe.nodes()]
     fe.close()
-    return 1e3 * float(np.median(ts[11:])), ts, feats
+    return 1e3 * float(np.median(ts[32:])), ts, feats
 
 
 if __name__ == "__main__":
