@@ -393,8 +393,12 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   // A batch that fills the CUs with one workgroup per image (last round at least three quarters full) hands its
   // one-band levels to the image-major tail kernel; `side` doubles as the permission (the cross-call prefetch on the aux
   // stream keeps the plain chain).
+  // A batch of a frame or two (vsf_observe_stereo, the host-pointer calls) is bound by the LATENCY of the level chain
+  // (26 dependent launches at ~6.7 us against ~4 us per level inside the tail kernel), not by throughput: it takes the
+  // tail kernel as well, however empty the chip stays.
   int l_tail = g.nlevels;
-  if (side && im.n >= 64) {
+  const bool few = side && im.n <= 4;
+  if (side && (im.n >= 64 || few)) {
     static int ncu = 0;
     if (ncu == 0) {
       int dev = 0;
@@ -403,7 +407,7 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
       if (ncu <= 0) ncu = 256;
     }
     const int rounds = (im.n + ncu - 1) / ncu;
-    if (4 * im.n >= 3 * rounds * ncu) {
+    if (few || 4 * im.n >= 3 * rounds * ncu) {
       while (l_tail > 2 && h_levels[l_tail - 1].w <= 256 && h_levels[l_tail - 1].resize_rows >= 8 &&
              h_levels[l_tail - 1].pitch * h_levels[l_tail - 1].h + 16 <= kTailLdsBytes)
         --l_tail;
