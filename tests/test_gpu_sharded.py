@@ -28,13 +28,15 @@ def _calibration():
     return frontend.default_calibration().set("fundamental", F_RECT)
 
 
-def _run(frames, frames_per_rank, rank, world):
-    """All steps of one rank; returns the ShardedStereoFrontend (drained)."""
+def _run(frames, frames_per_rank, rank, world, overlap=True):
+    """All steps of one rank; returns the ShardedStereoFrontend (drained).  overlap: the tail of a step on a second
+    stream beside the next step's extraction (the default) or everything on one stream."""
     from vision_slam_frontend_amd import capi
     from vision_slam_frontend_amd import distributed as vd
     dev = torch.device("cuda", 0)
     ctx = capi.Context(capi.default_params(W_IMG, H_IMG, max_images=2 * frames_per_rank, nfeatures=NF))
-    sf = vd.ShardedStereoFrontend(ctx, frames_per_rank, W_IMG, H_IMG, _calibration(), window=WINDOW, device=dev)
+    sf = vd.ShardedStereoFrontend(ctx, frames_per_rank, W_IMG, H_IMG, _calibration(), window=WINDOW, device=dev,
+                                  overlap=overlap)
     local = []
     for s in range(STEPS):
         idx = list(vd.frame_block(s, frames_per_rank, world, rank))
@@ -127,7 +129,7 @@ def _rccl_worker(rank: int, port: int, frames_path: str, out_path: str):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         frames = np.load(frames_path)
-        sf, _, ctx = _run(frames, WORLD * B, 0, 1)
+        sf, _, ctx = _run(frames, WORLD * B, 0, 1, overlap=False)  # (the one-stream form of the step, for coverage)
         assert sf.dist_on and not sf.host_detour and [c[0] for c in sf.completed] == list(range(STEPS))
         np.savez(out_path, **{"s%d" % st: per[0].cpu().numpy() for st, per in sf.completed})
         ctx.close()
