@@ -15,7 +15,8 @@ for pass in fetch:FETCH_SIZE write:WRITE_SIZE "valu:SQ_INSTS_VALU SQ_ACTIVE_INST
   echo "pmc pass $name done"
 done
 python3 tools/make_traffic.py "$out/fetch" "$out/write" "$out/valu" 256
-cp profiles/traffic.json "$out/traffic.json"
+mkdir -p gpurun_out/prof_$tag && cp profiles/traffic.json gpurun_out/prof_$tag/traffic.json
+
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 python3 - "$out" <<'PY'
 import sys, glob
