@@ -31,7 +31,7 @@ class OrbParams(C.Structure):
 
 
 def build(force: bool = False) -> Path:
-    src = [_DIR / "vsf_oracle.cc", _DIR / "vsf_oracle.h", _DIR / "orb_pattern31.inc"]
+    src = [_DIR / "vsf_oracle.cc", _DIR / "vsf_oracle_jpeg.cc", _DIR / "vsf_oracle.h", _DIR.parent / "data" / "orb_pattern31.txt"]
     if force or not _LIB_PATH.exists() or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in src):
         subprocess.check_call(["make", "-s", "-C", str(_DIR), "-B" if force else "-s"])
     return _LIB_PATH
@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         L.vsfo_sort_and_trim.argtypes = [vp, i32, f32]
         L.vsfo_remove_ambig_stereo.argtypes = [vp, vp, vp, i32, vp, C.POINTER(f32), vp, vp]
         L.vsfo_bayer_bg_to_gray.argtypes = [vp, i32, i32, sz, vp, sz]
+        L.vsfo_jpeg_decode_gray.argtypes = [vp, sz, vp, sz, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.vsfo_triangulate_points.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.vsfo_undistort_points.argtypes = [vp, i32, vp, vp, vp]
         L.vsfo_vision_features.argtypes = [vp, vp, vp, vp, i32, C.c_double, vp, vp, vp, vp, i32, vp, C.POINTER(i32)]
@@ -303,3 +304,22 @@ def vision_features(left: np.ndarray, left_desc: np.ndarray, right: np.ndarray, 
     if r < 0:
         raise ValueError("vsfo_vision_features")
     return out[:n], npts.value
+
+
+def jpeg_decode_gray(data: bytes) -> np.ndarray:
+    """cv::imdecode(data, IMREAD_GRAYSCALE) for a baseline JPEG; raises ValueError (malformed) or NotImplementedError
+    (a JPEG process the oracle does not restate: progressive, arithmetic, multi-scan)."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    r = lib().vsfo_jpeg_decode_gray(_p(buf), len(buf), None, 0, 0, 0, C.byref(w), C.byref(h))
+    if r == -2:
+        raise NotImplementedError("JPEG process not restated")
+    if r != -3:
+        raise ValueError("malformed JPEG (%d)" % r)
+    out = np.zeros((h.value, w.value), np.uint8)
+    r = lib().vsfo_jpeg_decode_gray(_p(buf), len(buf), _p(out), out.strides[0], w.value, h.value, C.byref(w), C.byref(h))
+    if r == -2:
+        raise NotImplementedError("JPEG process not restated")
+    if r != 0:
+        raise ValueError("malformed JPEG (%d)" % r)
+    return out

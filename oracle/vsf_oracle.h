@@ -153,6 +153,13 @@ int vsfo_vision_features(const vsfo_keypoint* left, const uint8_t* left_desc, co
  * loops leave them. */
 int vsfo_bayer_bg_to_gray(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
 
+/* DecodeImage's cv::imdecode(data, IMREAD_GRAYSCALE) for baseline JPEG (slam_frontend_main.cc:99-100): T.81 Huffman
+ * decoding + libjpeg's ISLOW inverse DCT of the luminance component (vsf_oracle_jpeg.cc; PINNED by libjpeg-turbo-decoded
+ * fixtures, tests/golden/jpeg).  out: cap_w x cap_h bytes at `ostride`.  Returns 0; -1 malformed; -2 a JPEG process not
+ * restated (progressive, arithmetic, 12 bit, multi-scan); -3 does not fit (w_out / h_out still report the size). */
+int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w, int cap_h,
+                          int* w_out, int* h_out);
+
 #ifdef __cplusplus
 }
 #endif

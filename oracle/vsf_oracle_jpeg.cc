@@ -1,0 +1,328 @@
+// vsf_oracle_jpeg.cc -- CPU ORACLE (test infrastructure, NOT product code) for SURVEY.md section 8(f) row f4, the part
+// in front of the Bayer conversion: DecodeImage's  cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE)  for the JPEG payloads
+// of sensor_msgs::CompressedImage (slam_frontend_main.cc:98-100).
+//
+// OpenCV 3.2's JPEG reader (imgcodecs/src/grfmt_jpeg.cpp) hands the stream to libjpeg with
+// cinfo.out_color_space = JCS_GRAYSCALE for a gray read and leaves dct_method at its default JDCT_ISLOW, so the result
+// is: ITU-T T.81 baseline entropy decoding (Annex F: Huffman categories, EXTEND, DC prediction, restart intervals), and
+// for the luminance component only libjpeg's jidctint.c (jpeg_idct_islow: 13-bit constants, PASS1_BITS = 2, exact 32-bit
+// integer arithmetic) followed by the range limit; chroma components are parsed and dropped.  Both are restated here
+// from the standard and from the published libjpeg algorithm.
+//
+// PINNED (unlike the rest of the oracle): tests/golden/jpeg/ holds JPEG files and their JCS_GRAYSCALE decode by
+// libjpeg-turbo (through Pillow, which happens to be in the image; tools/make_jpeg_golden.py); this file reproduces
+// every one of them bit for bit (tests/test_jpeg_oracle.py).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "vsf_oracle.h"
+
+namespace {
+
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {  // T.81 Annex C / F.2.2.3: code lengths -> MINCODE / MAXCODE / VALPTR
+  bool present = false;
+  uint8_t bits[17] = {0};
+  uint8_t vals[256] = {0};
+  int32_t mincode[17], maxcode[18], valptr[17];
+  void derive() {
+    int32_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; l++) {
+      valptr[l] = k;
+      mincode[l] = code;
+      code += bits[l];
+      k += bits[l];
+      maxcode[l] = bits[l] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7FFFFFFF;
+  }
+};
+
+struct Comp {
+  int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+};
+
+struct BitReader {  // entropy-coded segment: MSB first, FF00 -> FF, stops feeding at any other marker
+  const uint8_t* p;
+  const uint8_t* end;
+  uint32_t acc = 0;
+  int n = 0;
+  bool hit_marker = false;
+  int get_bit() {
+    if (n == 0) {
+      uint8_t b = 0;
+      if (!hit_marker && p < end) {
+        b = *p++;
+        if (b == 0xFF) {
+          if (p < end && *p == 0x00) {
+            p++;
+          } else {  // a marker: leave it in place, feed zero bits (libjpeg does the same with a warning)
+            p--;
+            hit_marker = true;
+            b = 0;
+          }
+        }
+      }
+      acc = b;
+      n = 8;
+    }
+    n--;
+    return (acc >> n) & 1;
+  }
+  int receive(int s) {
+    int v = 0;
+    for (int i = 0; i < s; i++) v = (v << 1) | get_bit();
+    return v;
+  }
+  int decode(const Huff& h) {  // F.2.2.3 DECODE
+    int32_t code = get_bit();
+    int l = 1;
+    while (l <= 16 && code > h.maxcode[l]) {
+      code = (code << 1) | get_bit();
+      l++;
+    }
+    if (l > 16) return 0;  // corrupt stream
+    return h.vals[h.valptr[l] + code - h.mincode[l]];
+  }
+  // RSTn between restart intervals: drop the remaining bits, step over the marker
+  bool restart() {
+    n = 0;
+    hit_marker = false;
+    while (p + 1 < end) {
+      if (p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) {
+        p += 2;
+        return true;
+      }
+      if (p[0] == 0xFF && p[1] != 0x00 && p[1] != 0xFF) return false;  // another marker: stream is broken
+      p++;
+    }
+    return false;
+  }
+};
+
+inline int extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }  // F.2.2.1
+
+// libjpeg jidctint.c jpeg_idct_islow on one dequantised 8 x 8 block (natural order), result incl. the range limit.
+#define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+inline uint8_t range_limit(int32_t x) {
+  // sample_range_limit + CENTERJSAMPLE indexed with (x & RANGE_MASK), RANGE_MASK = 1023 (jdmaster.c prepare_range_limit_table)
+  const int t = x & 1023;
+  if (t < 128) return (uint8_t)(t + 128);
+  if (t < 512) return 255;
+  if (t < 896) return 0;
+  return (uint8_t)(t - 896);
+}
+void idct_islow(const int32_t* in, uint8_t* out, size_t ostride) {
+  const int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
+                F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  const int CONST_BITS = 13, PASS1_BITS = 2;
+  int32_t ws[64];
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i = 0; i < 8; i++) {
+      int32_t d[8];
+      for (int k = 0; k < 8; k++) d[k] = pass == 0 ? in[8 * k + i] : ws[8 * i + k];
+      int32_t z2 = d[2], z3 = d[6];
+      int32_t z1 = (z2 + z3) * F0541;
+      int32_t tmp2 = z1 + z3 * (-F1847);
+      int32_t tmp3 = z1 + z2 * F0765;
+      z2 = d[0];
+      z3 = d[4];
+      int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << CONST_BITS);
+      int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << CONST_BITS);
+      const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+      tmp0 = d[7];
+      tmp1 = d[5];
+      tmp2 = d[3];
+      tmp3 = d[1];
+      z1 = tmp0 + tmp3;
+      z2 = tmp1 + tmp2;
+      z3 = tmp0 + tmp2;
+      int32_t z4 = tmp1 + tmp3;
+      const int32_t z5 = (z3 + z4) * F1175;
+      tmp0 *= F0298;
+      tmp1 *= F2053;
+      tmp2 *= F3072;
+      tmp3 *= F1501;
+      z1 *= -F0899;
+      z2 *= -F2562;
+      z3 *= -F1961;
+      z4 *= -F0390;
+      z3 += z5;
+      z4 += z5;
+      tmp0 += z1 + z3;
+      tmp1 += z2 + z4;
+      tmp2 += z2 + z3;
+      tmp3 += z1 + z4;
+      const int32_t r[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0,
+                            tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+      if (pass == 0) {
+        for (int k = 0; k < 8; k++) ws[8 * k + i] = DESCALE(r[k], CONST_BITS - PASS1_BITS);
+      } else {
+        for (int k = 0; k < 8; k++) out[i * ostride + k] = range_limit(DESCALE(r[k], CONST_BITS + PASS1_BITS + 3));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w,
+                                     int cap_h, int* w_out, int* h_out) {
+  // returns 0 ok; -1 malformed; -2 a JPEG process this decoder does not restate (progressive, arithmetic, 12 bit,
+  // non-interleaved multi-scan); -3 the image does not fit cap_w x cap_h
+  if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
+  uint16_t qt[4][64];
+  bool qt_present[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  std::vector<Comp> comps;
+  int W = 0, H = 0, restart_interval = 0;
+  size_t pos = 2;
+  bool have_sof = false;
+  while (pos + 4 <= nbytes) {
+    if (data[pos] != 0xFF) return -1;
+    while (pos < nbytes && data[pos] == 0xFF) pos++;  // fill bytes
+    if (pos >= nbytes) return -1;
+    const int m = data[pos++];
+    if (m == 0xD9) return -1;  // EOI before any scan
+    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (pos + 2 > nbytes) return -1;
+    const size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
+    if (len < 2 || pos + len > nbytes) return -1;
+    const uint8_t* s = data + pos + 2;
+    const size_t n = len - 2;
+    if (m == 0xDB) {  // DQT
+      size_t i = 0;
+      while (i < n) {
+        const int pq = s[i] >> 4, tq = s[i] & 15;
+        i++;
+        if (tq > 3 || pq > 1 || i + 64 * (pq + 1) > n) return -1;
+        for (int k = 0; k < 64; k++) {
+          qt[tq][kZigzag[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];
+          i += pq + 1;
+        }
+        qt_present[tq] = true;
+      }
+    } else if (m == 0xC4) {  // DHT
+      size_t i = 0;
+      while (i < n) {
+        if (i + 17 > n) return -1;
+        const int tc = s[i] >> 4, th = s[i] & 15;
+        if (tc > 1 || th > 3) return -1;
+        Huff& h = tc ? ac[th] : dc[th];
+        int total = 0;
+        for (int l = 1; l <= 16; l++) total += (h.bits[l] = s[i + l]);
+        i += 17;
+        if (total > 256 || i + total > n) return -1;
+        std::memset(h.vals, 0, sizeof(h.vals));
+        std::memcpy(h.vals, s + i, total);
+        i += total;
+        h.present = true;
+        h.derive();
+      }
+    } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: sequential DCT, Huffman
+      if (n < 6 || s[0] != 8) return -2;
+      H = (s[1] << 8) | s[2];
+      W = (s[3] << 8) | s[4];
+      const int nf = s[5];
+      if (W < 1 || H < 1 || (nf != 1 && nf != 3) || n < (size_t)(6 + 3 * nf)) return nf == 4 ? -2 : -1;
+      comps.resize(nf);
+      for (int c = 0; c < nf; c++) {
+        comps[c].id = s[6 + 3 * c];
+        comps[c].h = s[7 + 3 * c] >> 4;
+        comps[c].v = s[7 + 3 * c] & 15;
+        comps[c].tq = s[8 + 3 * c];
+        if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) return -1;
+      }
+      have_sof = true;
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      return -2;  // progressive, lossless, arithmetic, hierarchical
+    } else if (m == 0xDD) {  // DRI
+      if (n < 2) return -1;
+      restart_interval = (s[0] << 8) | s[1];
+    } else if (m == 0xDA) {  // SOS: the one scan
+      if (!have_sof || n < 1) return -1;
+      const int ns = s[0];
+      if (ns != (int)comps.size()) return -2;  // non-interleaved multi-scan files are not restated
+      if (n < (size_t)(4 + 2 * ns)) return -1;
+      for (int c = 0; c < ns; c++) {
+        if (s[1 + 2 * c] != comps[c].id) return -2;
+        comps[c].td = s[2 + 2 * c] >> 4;
+        comps[c].ta = s[2 + 2 * c] & 15;
+        if (comps[c].td > 3 || comps[c].ta > 3 || !dc[comps[c].td].present || !ac[comps[c].ta].present ||
+            !qt_present[comps[c].tq])
+          return -1;
+      }
+      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return -2;
+      pos += len;
+      break;
+    }
+    pos += len;
+  }
+  if (!have_sof || comps.empty() || pos >= nbytes) return -1;
+  if (w_out) *w_out = W;
+  if (h_out) *h_out = H;
+  if (W > cap_w || H > cap_h || !out) return -3;
+  int hmax = 1, vmax = 1;
+  for (const Comp& c : comps) {
+    hmax = c.h > hmax ? c.h : hmax;
+    vmax = c.v > vmax ? c.v : vmax;
+  }
+  // libjpeg would upsample a luminance component that is not sampled at full rate; such files do not occur (and a
+  // single-component scan is always one block per MCU, whatever its sampling factors say: T.81 A.2.2)
+  if (comps.size() > 1 && (comps[0].h != hmax || comps[0].v != vmax)) return -2;
+  const bool single = comps.size() == 1;
+  const int mcu_w = single ? 8 : 8 * hmax, mcu_h = single ? 8 : 8 * vmax;
+  const int mcus_x = (W + mcu_w - 1) / mcu_w, mcus_y = (H + mcu_h - 1) / mcu_h;
+  const int yh = single ? 1 : comps[0].h, yv = single ? 1 : comps[0].v;
+  const int pw = mcus_x * mcu_w, ph = mcus_y * mcu_h;  // padded luminance plane
+  std::vector<uint8_t> plane((size_t)pw * ph);
+  BitReader br{data + pos, data + nbytes};
+  int pred[4] = {0, 0, 0, 0};
+  int until_restart = restart_interval;
+  for (int my = 0; my < mcus_y; my++)
+    for (int mx = 0; mx < mcus_x; mx++) {
+      if (restart_interval && until_restart == 0) {
+        if (!br.restart()) return -1;
+        pred[0] = pred[1] = pred[2] = pred[3] = 0;
+        until_restart = restart_interval;
+      }
+      for (size_t ci = 0; ci < comps.size(); ci++) {
+        const Comp& c = comps[ci];
+        const int bh = single ? 1 : c.h, bv = single ? 1 : c.v;
+        for (int by = 0; by < bv; by++)
+          for (int bx = 0; bx < bh; bx++) {
+            int32_t coef[64];
+            std::memset(coef, 0, sizeof(coef));
+            // F.2.2.1 DC, F.2.2.2 AC
+            const int t = br.decode(dc[c.td]);
+            pred[ci] += extend(br.receive(t), t);
+            coef[0] = pred[ci] * (int32_t)qt[c.tq][0];
+            for (int k = 1; k < 64;) {
+              const int rs = br.decode(ac[c.ta]);
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz == 0) {
+                if (r != 15) break;  // EOB
+                k += 16;
+                continue;
+              }
+              k += r;
+              if (k > 63) break;  // corrupt
+              const int nat = kZigzag[k];
+              coef[nat] = extend(br.receive(sz), sz) * (int32_t)qt[c.tq][nat];
+              k++;
+            }
+            if (ci == 0)  // only the luminance is reconstructed (component_needed, jdmaster.c / jdapimin.c)
+              idct_islow(coef, &plane[(size_t)(my * yv * 8 + by * 8) * pw + (size_t)(mx * yh * 8 + bx * 8)], (size_t)pw);
+          }
+      }
+      if (restart_interval) until_restart--;
+    }
+  for (int y = 0; y < H; y++) std::memcpy(out + (size_t)y * ostride, &plane[(size_t)y * pw], (size_t)W);
+  return 0;
+}
