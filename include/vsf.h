@@ -280,6 +280,21 @@ vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
                               size_t cap, size_t* out_bytes);
 vsf_status vsf_observe_reset(vsf_ctx* ctx);
 
+/* SURVEY section 8(f) row f4, the decode itself: DecodeImage's cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE)
+ * (slam_frontend_main.cc:99-100) for n baseline-JPEG files in HOST memory (the CompressedImage payloads), all of
+ * width x height: ITU-T T.81 Huffman decoding + libjpeg's ISLOW inverse DCT of the luminance component, which is what
+ * OpenCV's reader computes for a gray read (JCS_GRAYSCALE; chroma is parsed and dropped).  Gray and YCbCr files with any
+ * sampling factors up to 4, restart intervals, custom tables; progressive / arithmetic / 12-bit / multi-scan files return
+ * VSF_ERR_UNSUPPORTED, files of another size or malformed headers VSF_ERR_INVALID_ARG (nothing is launched then).
+ * The images land at d_dst + i * dst_image_stride (DEVICE memory, rows dst_row_stride apart; base and strides multiples
+ * of 4) -- the input of vsf_bayer_bg_to_gray_batch_dev or of the extraction.  The files are copied before the call
+ * returns; the decode is asynchronous on the context's stream (one wave per image: run it on a context / stream of its
+ * own beside other work).  A stream that breaks off inside its entropy-coded data decodes as libjpeg does (zero bits) and
+ * makes the next vsf_sync return VSF_ERR_INVALID_ARG.  PNG (the other format imdecode reads) is not built. */
+vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, const size_t* nbytes, int n_images,
+                                      int width, int height, uint8_t* d_dst, size_t dst_image_stride,
+                                      size_t dst_row_stride);
+
 /* SURVEY section 8(f) row f4, the part behind cv::imdecode: DecodeImage's cvtColor(COLOR_BayerBG2BGR) +
  * cvtColor(COLOR_BGR2GRAY) (slam_frontend_main.cc:101-106) for n 8-bit mosaics of width x height resident in HBM, in
  * one pass.  d_src / d_dst: image i at base + i * image_stride, rows row_stride bytes apart; bases and strides multiples

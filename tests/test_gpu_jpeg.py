@@ -1,0 +1,119 @@
+"""SURVEY 8(f) row f4, the decode: vsf_jpeg_decode_gray_batch == cv::imdecode(data, IMREAD_GRAYSCALE) for baseline JPEG
+(slam_frontend_main.cc:99-100), bit for bit against (1) what libjpeg-turbo decoded (tests/golden/jpeg: real
+third-party vectors) and (2) the CPU oracle on freshly encoded images, incl. the whole ingest chain
+JPEG -> Bayer mosaic -> gray image -> keypoints."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+GOLD = Path(__file__).resolve().parent / "golden" / "jpeg"
+EXPECTED = np.load(GOLD / "expected_gray.npz")
+NAMES = sorted(k for k in EXPECTED.files if not k.startswith("progressive"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vision_slam_frontend_amd import capi
+    c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500))
+    yield c
+    c.close()
+
+
+def _decode(ctx, files, w, h, pitch=None):
+    from vision_slam_frontend_amd import capi
+    dev = torch.device("cuda", 0)
+    pitch = pitch or (w + 3) // 4 * 4
+    d = torch.full((len(files), h, pitch), 0xEE, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.jpeg_decode_gray_batch(files, w, h, d.data_ptr(), h * pitch, pitch)
+    assert ctx.sync() == capi.VSF_OK
+    return d.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_equals_libjpeg_turbo(ctx, name):
+    want = EXPECTED[name]
+    h, w = want.shape
+    got = _decode(ctx, [(GOLD / (name + ".jpg")).read_bytes()], w, h, pitch=(w + 3) // 4 * 4 + 8)
+    np.testing.assert_array_equal(got[0, :, :w], want)
+    assert (got[0, :, (w + 3) // 4 * 4:] == 0xEE).all()  # nothing written beyond the row (padding past w up to 4 may be)
+
+
+def test_batch_of_mixed_tables_equals_the_oracle(ctx, oracle):
+    """One call, many files with DIFFERENT quantisation / Huffman tables, sampling factors and restart intervals."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    from vision_slam_frontend_amd import synth
+    rng = np.random.default_rng(5)
+    files = []
+    for i in range(12):
+        img = synth.stereo_pair(200, 136, 100 + i, n_objects=150)[i & 1]
+        b = io.BytesIO()
+        if i % 3 == 2:
+            rgb = np.stack([img, np.roll(img, 3, 0), np.roll(img, 5, 1)], 2)
+            PIL.fromarray(rgb, "RGB").save(b, "JPEG", quality=int(rng.integers(40, 96)), subsampling=int(i % 3 == 2) * (i % 2 + 1))
+        else:
+            PIL.fromarray(img, "L").save(b, "JPEG", quality=int(rng.integers(30, 100)), optimize=bool(i & 2),
+                                         restart_marker_blocks=int(rng.integers(0, 9)))
+        files.append(b.getvalue())
+    got = _decode(ctx, files, 200, 136)
+    for i, f in enumerate(files):
+        np.testing.assert_array_equal(got[i, :, :200], oracle.jpeg_decode_gray(f), err_msg="file %d" % i)
+
+
+def test_refusals_and_truncation(ctx, oracle):
+    from vision_slam_frontend_amd import capi
+    dev = torch.device("cuda", 0)
+    d = torch.zeros((1, 48, 64), dtype=torch.uint8, device=dev)
+    good = (GOLD / "gray_64x48_noise_q80.jpg").read_bytes()
+    prog = (GOLD / "progressive_64x48.jpg").read_bytes()
+    call = lambda f, w=64, h=48: ctx.jpeg_decode_gray_batch([f], w, h, d.data_ptr(), 48 * 64, 64, allow_status=range(1, 6))
+    assert call(prog) == capi.VSF_ERR_UNSUPPORTED
+    assert call(good, 48, 64) == capi.VSF_ERR_INVALID_ARG      # not the announced size
+    assert call(good[:100]) == capi.VSF_ERR_INVALID_ARG        # cut inside the headers
+    assert call(b"\x89PNG\r\n" + good) == capi.VSF_ERR_INVALID_ARG
+    # cut inside the entropy-coded data: decodes like libjpeg (zero bits), never reads past the buffer, flags the sync
+    half = good[:len(good) // 2]
+    assert call(half) == capi.VSF_OK
+    st = ctx.sync(allow_capacity=True)
+    np.testing.assert_array_equal(d.cpu().numpy()[0], oracle.jpeg_decode_gray(half))
+    assert st == capi.VSF_OK  # (a stream that merely ends early is not "broken": only a missing restart marker is)
+    assert call(good) == capi.VSF_OK and ctx.sync() == capi.VSF_OK
+
+
+def test_ingest_chain_jpeg_bayer_extract(ctx, oracle):
+    """DecodeImage as a whole (slam_frontend_main.cc:98-109) followed by ExtractFeatures: a Bayer mosaic stored as a gray
+    JPEG -> imdecode -> BayerBG2BGR -> BGR2GRAY -> ORB, against the same chain on the oracle."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    from vision_slam_frontend_amd import capi, synth
+    dev = torch.device("cuda", 0)
+    mosaic = synth.stereo_pair(640, 480, 5)[0]
+    b = io.BytesIO()
+    PIL.fromarray(mosaic, "L").save(b, "JPEG", quality=90)
+    f = b.getvalue()
+    d_mosaic = torch.zeros((1, 480, 640), dtype=torch.uint8, device=dev)
+    d_gray = torch.zeros((1, 480, 640), dtype=torch.uint8, device=dev)
+    K = ctx.params.max_keypoints
+    d_kp = torch.zeros((1, K, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((1, K, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.jpeg_decode_gray_batch([f], 640, 480, d_mosaic.data_ptr(), 640 * 480, 640)
+    ctx.bayer_bg_to_gray_batch_dev(d_mosaic.data_ptr(), 1, 640, 480, 640 * 480, 640, d_gray.data_ptr(), 640 * 480, 640)
+    ctx.extract_batch_dev(d_gray.data_ptr(), 1, 640 * 480, 640, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr())
+    assert ctx.sync() == capi.VSF_OK
+    gray = oracle.bayer_bg_to_gray(oracle.jpeg_decode_gray(f))
+    np.testing.assert_array_equal(d_gray.cpu().numpy()[0], gray)
+    o = oracle.Orb(nfeatures=500)
+    o.run(gray)
+    rk, rd = o.result()
+    n = int(d_n.cpu()[0])
+    assert n == len(rk) > 300
+    assert d_kp.cpu().numpy()[0, :n].tobytes() == rk.tobytes()
+    np.testing.assert_array_equal(d_desc.cpu().numpy()[0, :n], rd)

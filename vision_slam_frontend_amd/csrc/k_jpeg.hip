@@ -1,0 +1,511 @@
+// k_jpeg.hip -- SURVEY.md section 8(f) row f4, the decode in front of the Bayer conversion: DecodeImage's
+//   cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE)                                   (slam_frontend_main.cc:99-100)
+// for the baseline-JPEG payloads of sensor_msgs::CompressedImage, a batch of images per call, result in HBM.
+//
+// What OpenCV 3.2 does there (imgcodecs/src/grfmt_jpeg.cpp -> libjpeg, out_color_space = JCS_GRAYSCALE, default
+// JDCT_ISLOW): ITU-T T.81 baseline entropy decoding and, for the luminance component only, libjpeg's jidctint.c inverse
+// DCT (13-bit constants, PASS1_BITS = 2, exact 32-bit integers) + range limit; chroma is parsed and dropped.
+//
+// The entropy-coded segment of a baseline JPEG is one serial bit stream (the reference's camera driver writes no restart
+// markers): there is nothing to spread over lanes.  So ONE WAVE DECODES ONE IMAGE -- lane 0 walks the Huffman codes
+// (9-bit lookahead tables in LDS, T.81 F.2.2.3 for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops
+// chroma blocks and parks up to 16 luminance blocks of coefficients in LDS; then all 64 lanes dequantise and run the two
+// IDCT passes (lane = block x column, then block x row) and store the pixels -- and a batch runs as many waves as it
+// has images, two per CU at 512 images: a latency-bound kernel that occupies < 1 % of the chip's issue slots and is meant to
+// run on its own stream BESIDE the extraction of the previous batch.  Markers and tables are parsed on the host (the
+// compressed bytes come from host memory anyway), which also builds the lookahead tables once per distinct table set.
+//
+// Checked bit for bit against JPEG files decoded by libjpeg-turbo (tests/golden/jpeg, tests/test_gpu_jpeg.py).
+// Progressive / arithmetic / 12-bit / multi-scan files are refused (VSF_ERR_UNSUPPORTED).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vsf_internal.h"
+
+namespace {
+
+constexpr int kLookBits = 9;
+constexpr int kMaxSlots = 6;     // distinct Huffman tables one image may use (3 components x DC / AC)
+constexpr int kGroupBlocks = 16; // luminance blocks parked in LDS between two IDCT phases
+
+struct DevHuff {                 // one Huffman table as the kernel reads it (1424 bytes)
+  uint16_t look[1 << kLookBits]; // 9-bit prefix -> (code length << 8 | symbol), 0 = longer than 9 bits
+  int32_t maxcode[18];           // T.81 F.2.2.3 (maxcode[17] = INT_MAX)
+  int32_t valoff[17];            // VALPTR - MINCODE
+  uint8_t vals[256];
+  uint32_t pad;
+};
+static_assert(sizeof(DevHuff) == 1024 + 72 + 68 + 256 + 4, "DevHuff layout");
+
+struct DevTables {               // one distinct table set
+  DevHuff huff[kMaxSlots];
+  uint16_t qt_luma[64];          // natural order
+};
+
+struct DevImage {
+  uint32_t stream_off;           // entropy-coded segment inside the packed stream buffer (4-byte aligned)
+  uint32_t stream_len;
+  uint32_t tables;               // index into the table sets
+  int32_t ncomp, restart_interval, mcus_x, mcus_y;
+  int32_t h[3], v[3];            // blocks per MCU of each component (1 x 1 for a single-component scan)
+  int32_t dc_slot[3], ac_slot[3];
+};
+
+const uint8_t kZigzagHost[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+__constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---- lane 0's view of the entropy-coded segment ----
+struct BitReader {
+  const uint8_t* base;
+  uint32_t pos, len;
+  uint64_t acc;   // the next `n` bits of the stream sit in the low n bits, oldest on top
+  int n;
+  bool marker;    // a marker has been met: zero bits are fed from here on (until restart())
+  __device__ __forceinline__ void fill() {  // >= 32 bits available afterwards
+    while (n <= 56) {
+      uint32_t b = 0;
+      if (!marker) {
+        if (pos < len) {
+          b = base[pos];
+          if (b == 0xFFu) {
+            const uint32_t nx = pos + 1 < len ? base[pos + 1] : 0xD9u;
+            if (nx == 0) {
+              pos += 2;
+            } else {
+              marker = true;
+              b = 0;
+            }
+          } else {
+            pos++;
+          }
+        } else {
+          marker = true;
+        }
+      }
+      acc = (acc << 8) | b;
+      n += 8;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (n - k)) & ((1u << k) - 1u); }
+  __device__ __forceinline__ void drop(int k) { n -= k; }
+  __device__ __forceinline__ int receive_extend(int s) {  // T.81 F.2.2.1 RECEIVE + EXTEND
+    if (s == 0) return 0;
+    const int v = (int)peek(s);
+    drop(s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+  }
+  __device__ __forceinline__ int decode(const DevHuff& h) {
+    const uint32_t e = h.look[peek(kLookBits)];
+    if (e) {
+      drop((int)(e >> 8));
+      return (int)(e & 255u);
+    }
+    int l = kLookBits + 1;
+    int32_t code = (int32_t)peek(l);
+    while (l <= 16 && code > h.maxcode[l]) {
+      l++;
+      code = (int32_t)peek(l);
+    }
+    if (l > 16) {  // corrupt stream
+      drop(16);
+      return 0;
+    }
+    drop(l);
+    return h.vals[(h.valoff[l] + code) & 255];
+  }
+  __device__ bool restart() {  // drop the remaining bits, step over RSTn
+    // bytes already pulled into the accumulator beyond the marker position cannot exist: fill() stops at a marker
+    acc = 0;
+    n = 0;
+    marker = false;
+    while (pos + 1 < len) {
+      const uint32_t a = base[pos], b = base[pos + 1];
+      if (a == 0xFFu && b >= 0xD0u && b <= 0xD7u) {
+        pos += 2;
+        return true;
+      }
+      if (a == 0xFFu && b != 0u && b != 0xFFu) return false;
+      pos++;
+    }
+    return false;
+  }
+};
+
+__device__ __forceinline__ uint8_t range_limit(int32_t x) {  // sample_range_limit + CENTERJSAMPLE, index x & 1023
+  const int t = x & 1023;
+  return (uint8_t)(t < 128 ? t + 128 : (t < 512 ? 255 : (t < 896 ? 0 : t - 896)));
+}
+
+// jidctint.c: one 8-point pass on d[0..7]; r[k] are the values before DESCALE
+__device__ __forceinline__ void idct8(const int32_t d[8], int32_t r[8]) {
+  const int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
+                F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  int32_t z2 = d[2], z3 = d[6];
+  int32_t z1 = (z2 + z3) * F0541;
+  int32_t tmp2 = z1 + z3 * (-F1847);
+  int32_t tmp3 = z1 + z2 * F0765;
+  z2 = d[0];
+  z3 = d[4];
+  int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << 13);
+  int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << 13);
+  const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = d[7];
+  tmp1 = d[5];
+  tmp2 = d[3];
+  tmp3 = d[1];
+  z1 = tmp0 + tmp3;
+  z2 = tmp1 + tmp2;
+  z3 = tmp0 + tmp2;
+  int32_t z4 = tmp1 + tmp3;
+  const int32_t z5 = (z3 + z4) * F1175;
+  tmp0 *= F0298;
+  tmp1 *= F2053;
+  tmp2 *= F3072;
+  tmp3 *= F1501;
+  z1 *= -F0899;
+  z2 *= -F2562;
+  z3 *= -F1961;
+  z4 *= -F0390;
+  z3 += z5;
+  z4 += z5;
+  tmp0 += z1 + z3;
+  tmp1 += z2 + z4;
+  tmp2 += z2 + z3;
+  tmp3 += z1 + z4;
+  r[0] = tmp10 + tmp3;
+  r[1] = tmp11 + tmp2;
+  r[2] = tmp12 + tmp1;
+  r[3] = tmp13 + tmp0;
+  r[4] = tmp13 - tmp0;
+  r[5] = tmp12 - tmp1;
+  r[6] = tmp11 - tmp2;
+  r[7] = tmp10 - tmp3;
+}
+
+__global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restrict__ images,
+                                                        const DevTables* __restrict__ tables,
+                                                        const uint8_t* __restrict__ stream, int width, int height,
+                                                        uint8_t* __restrict__ dst, size_t dst_image_stride,
+                                                        int dst_pitch, int32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) DevTables s_tab;
+  __shared__ __attribute__((aligned(16))) int16_t s_coef[kGroupBlocks][64];
+  __shared__ __attribute__((aligned(16))) int32_t s_ws[kGroupBlocks][64];
+  __shared__ int32_t s_dest[kGroupBlocks];  // y0 << 16 | x0
+  __shared__ int32_t s_count, s_done;
+  const int lane = threadIdx.x;
+  const DevImage im = images[blockIdx.x];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + im.tables);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&s_tab);
+    for (int i = lane; i < (int)(sizeof(DevTables) / 4); i += 64) d[i] = src[i];
+  }
+  uint8_t* out = dst + (size_t)blockIdx.x * dst_image_stride;
+  // decoder state: meaningful in lane 0 only
+  BitReader br{stream + im.stream_off, 0u, im.stream_len, 0ull, 0, false};
+  int pred[3] = {0, 0, 0};
+  int mcu = 0, until_restart = im.restart_interval;
+  const int nmcu = im.mcus_x * im.mcus_y;
+  const int luma_per_mcu = im.h[0] * im.v[0];
+  bool broken = false;
+  __syncthreads();
+  for (;;) {
+    {  // clear the coefficient buffer
+      uint32_t* c = reinterpret_cast<uint32_t*>(&s_coef[0][0]);
+      for (int i = lane; i < kGroupBlocks * 32; i += 64) c[i] = 0u;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      int count = 0;
+      while (mcu < nmcu && count + luma_per_mcu <= kGroupBlocks && !broken) {
+        if (im.restart_interval && until_restart == 0) {
+          if (!br.restart()) {
+            broken = true;
+            break;
+          }
+          pred[0] = pred[1] = pred[2] = 0;
+          until_restart = im.restart_interval;
+        }
+        const int my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
+        for (int ci = 0; ci < im.ncomp; ci++) {
+          const DevHuff& hd = s_tab.huff[im.dc_slot[ci]];
+          const DevHuff& ha = s_tab.huff[im.ac_slot[ci]];
+          for (int by = 0; by < im.v[ci]; by++)
+            for (int bx = 0; bx < im.h[ci]; bx++) {
+              int16_t* coef = ci == 0 ? s_coef[count] : nullptr;
+              br.fill();
+              const int t = br.decode(hd);
+              br.fill();
+              pred[ci] += br.receive_extend(t);
+              if (coef) coef[0] = (int16_t)pred[ci];
+              for (int k = 1; k < 64;) {
+                br.fill();
+                const int rs = br.decode(ha);
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                  if (r != 15) break;  // EOB
+                  k += 16;
+                  continue;
+                }
+                k += r;
+                if (k > 63) break;  // corrupt
+                const int val = br.receive_extend(sz);  // (fill() left >= 32 - 16 bits after the code)
+                if (coef) coef[c_zigzag[k]] = (int16_t)val;
+                k++;
+              }
+              if (ci == 0) {
+                s_dest[count] = ((my * im.v[0] * 8 + by * 8) << 16) | (mx * im.h[0] * 8 + bx * 8);
+                count++;
+              }
+            }
+        }
+        if (im.restart_interval) until_restart--;
+        mcu++;
+      }
+      s_count = count;
+      s_done = (mcu >= nmcu || broken) ? 1 : 0;
+    }
+    __syncthreads();
+    const int count = s_count;
+    // ---- dequantise + IDCT of the parked blocks: 8 blocks x 8 columns, then 8 blocks x 8 rows, per round ----
+    for (int b0 = 0; b0 < count; b0 += 8) {
+      const int b = b0 + (lane >> 3), i = lane & 7;
+      if (b < count) {
+        int32_t d[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (int32_t)s_coef[b][8 * k + i] * (int32_t)s_tab.qt_luma[8 * k + i];
+        idct8(d, r);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_ws[b][8 * k + i] = (r[k] + (1 << 10)) >> 11;  // DESCALE(., CONST_BITS - PASS1_BITS)
+      }
+      __syncthreads();
+      if (b < count) {
+        int32_t d[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = s_ws[b][8 * i + k];
+        idct8(d, r);
+        const int x0 = s_dest[b] & 0xFFFF, y = (s_dest[b] >> 16) + i;
+        if (y < height && x0 < width) {
+          uint8_t px[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) px[k] = range_limit((r[k] + (1 << 17)) >> 18);  // DESCALE(., 13 + 2 + 3)
+          uint8_t* row = out + (size_t)y * dst_pitch + x0;
+          if (x0 + 8 <= width) {
+            uint32_t lo, hi;
+            memcpy(&lo, px, 4);
+            memcpy(&hi, px + 4, 4);
+            reinterpret_cast<uint32_t*>(row)[0] = lo;  // (x0 % 8 == 0, base and pitch are multiples of 4)
+            reinterpret_cast<uint32_t*>(row)[1] = hi;
+          } else {
+            for (int k = 0; k < 8 && x0 + k < width; k++) row[k] = px[k];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (s_done) break;
+    __syncthreads();
+  }
+  if (lane == 0 && broken) atomicOr(status, 2);
+}
+
+// ---- host: markers and tables (ITU-T T.81 Annex B) ----
+struct HostHuff {
+  bool present = false;
+  uint8_t bits[17] = {0};
+  uint8_t vals[256] = {0};
+};
+
+void build_dev_huff(const HostHuff& h, DevHuff* d) {
+  std::memset(d, 0, sizeof(*d));
+  int32_t code = 0;
+  int k = 0;
+  for (int l = 1; l <= 16; l++) {
+    const int32_t mincode = code;
+    d->valoff[l] = k - mincode;
+    for (int i = 0; i < h.bits[l]; i++, k++, code++) {
+      if (l <= kLookBits) {  // every 9-bit prefix that starts with this code
+        const int shift = kLookBits - l;
+        for (int f = 0; f < (1 << shift); f++)
+          d->look[((uint32_t)code << shift) | (uint32_t)f] = (uint16_t)((l << 8) | h.vals[k]);
+      }
+    }
+    d->maxcode[l] = h.bits[l] ? code - 1 : -1;
+    code <<= 1;
+  }
+  d->maxcode[17] = 0x7FFFFFFF;
+  d->valoff[0] = 0;
+  std::memcpy(d->vals, h.vals, 256);
+}
+
+}  // namespace
+
+// Parses one JPEG file; fills the image descriptor (without stream_off / tables) and the table set it needs.
+// Returns VSF_OK, VSF_ERR_INVALID_ARG (malformed, or not width x height) or VSF_ERR_UNSUPPORTED.
+static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int height, DevImage* im, DevTables* tab,
+                             size_t* scan_begin) {
+  if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return VSF_ERR_INVALID_ARG;
+  uint16_t qt[4][64];
+  bool qt_present[4] = {false, false, false, false};
+  HostHuff dc[4], ac[4];
+  int ncomp = 0, cid[3], ch[3], cv[3], ctq[3], W = 0, H = 0, restart_interval = 0;
+  bool have_sof = false;
+  size_t pos = 2;
+  std::memset(im, 0, sizeof(*im));
+  while (pos + 4 <= nbytes) {
+    if (data[pos] != 0xFF) return VSF_ERR_INVALID_ARG;
+    while (pos < nbytes && data[pos] == 0xFF) pos++;
+    if (pos >= nbytes) return VSF_ERR_INVALID_ARG;
+    const int m = data[pos++];
+    if (m == 0xD9) return VSF_ERR_INVALID_ARG;
+    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (pos + 2 > nbytes) return VSF_ERR_INVALID_ARG;
+    const size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
+    if (len < 2 || pos + len > nbytes) return VSF_ERR_INVALID_ARG;
+    const uint8_t* s = data + pos + 2;
+    const size_t n = len - 2;
+    if (m == 0xDB) {
+      for (size_t i = 0; i < n;) {
+        const int pq = s[i] >> 4, tq = s[i] & 15;
+        i++;
+        if (tq > 3 || pq > 1 || i + 64 * (size_t)(pq + 1) > n) return VSF_ERR_INVALID_ARG;
+        for (int k = 0; k < 64; k++, i += pq + 1)
+          qt[tq][kZigzagHost[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];
+        qt_present[tq] = true;
+      }
+    } else if (m == 0xC4) {
+      for (size_t i = 0; i < n;) {
+        if (i + 17 > n) return VSF_ERR_INVALID_ARG;
+        const int tc = s[i] >> 4, th = s[i] & 15;
+        if (tc > 1 || th > 3) return VSF_ERR_INVALID_ARG;
+        HostHuff& h = tc ? ac[th] : dc[th];
+        int total = 0;
+        for (int l = 1; l <= 16; l++) total += (h.bits[l] = s[i + l]);
+        i += 17;
+        if (total > 256 || i + total > n) return VSF_ERR_INVALID_ARG;
+        std::memset(h.vals, 0, sizeof(h.vals));
+        std::memcpy(h.vals, s + i, (size_t)total);
+        i += total;
+        h.present = true;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (n < 6 || s[0] != 8) return VSF_ERR_UNSUPPORTED;
+      H = (s[1] << 8) | s[2];
+      W = (s[3] << 8) | s[4];
+      ncomp = s[5];
+      if (ncomp == 4) return VSF_ERR_UNSUPPORTED;
+      if ((ncomp != 1 && ncomp != 3) || n < (size_t)(6 + 3 * ncomp)) return VSF_ERR_INVALID_ARG;
+      for (int c = 0; c < ncomp; c++) {
+        cid[c] = s[6 + 3 * c];
+        ch[c] = s[7 + 3 * c] >> 4;
+        cv[c] = s[7 + 3 * c] & 15;
+        ctq[c] = s[8 + 3 * c];
+        if (ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4 || ctq[c] > 3) return VSF_ERR_INVALID_ARG;
+      }
+      have_sof = true;
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      return VSF_ERR_UNSUPPORTED;  // progressive, lossless, arithmetic, hierarchical
+    } else if (m == 0xDD) {
+      if (n < 2) return VSF_ERR_INVALID_ARG;
+      restart_interval = (s[0] << 8) | s[1];
+    } else if (m == 0xDA) {
+      if (!have_sof || n < 1) return VSF_ERR_INVALID_ARG;
+      const int ns = s[0];
+      if (ns != ncomp) return VSF_ERR_UNSUPPORTED;  // one interleaved scan only
+      if (n < (size_t)(4 + 2 * ns)) return VSF_ERR_INVALID_ARG;
+      std::vector<std::pair<int, int>> slots;  // (class, id) in use
+      auto slot_of = [&](int cls, int id) {
+        for (size_t i = 0; i < slots.size(); i++)
+          if (slots[i].first == cls && slots[i].second == id) return (int)i;
+        slots.emplace_back(cls, id);
+        return (int)slots.size() - 1;
+      };
+      for (int c = 0; c < ns; c++) {
+        if (s[1 + 2 * c] != cid[c]) return VSF_ERR_UNSUPPORTED;
+        const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
+        if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !qt_present[ctq[c]]) return VSF_ERR_INVALID_ARG;
+        im->dc_slot[c] = slot_of(0, td);
+        im->ac_slot[c] = slot_of(1, ta);
+      }
+      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return VSF_ERR_UNSUPPORTED;
+      int hmax = 1, vmax = 1;
+      for (int c = 0; c < ncomp; c++) {
+        hmax = std::max(hmax, ch[c]);
+        vmax = std::max(vmax, cv[c]);
+      }
+      if (ncomp > 1 && (ch[0] != hmax || cv[0] != vmax)) return VSF_ERR_UNSUPPORTED;  // luminance would need upsampling
+      if (W != width || H != height) return VSF_ERR_INVALID_ARG;
+      const bool single = ncomp == 1;  // T.81 A.2.2: a one-component scan has one block per MCU
+      const int mw = single ? 8 : 8 * hmax, mh = single ? 8 : 8 * vmax;
+      if (!single && hmax * vmax > kGroupBlocks) return VSF_ERR_UNSUPPORTED;
+      im->ncomp = ncomp;
+      im->restart_interval = restart_interval;
+      im->mcus_x = (W + mw - 1) / mw;
+      im->mcus_y = (H + mh - 1) / mh;
+      for (int c = 0; c < ncomp; c++) {
+        im->h[c] = single ? 1 : ch[c];
+        im->v[c] = single ? 1 : cv[c];
+      }
+      std::memset(tab, 0, sizeof(*tab));
+      for (size_t i = 0; i < slots.size(); i++)
+        build_dev_huff(slots[i].first ? ac[slots[i].second] : dc[slots[i].second], &tab->huff[i]);
+      std::memcpy(tab->qt_luma, qt[ctq[0]], sizeof(tab->qt_luma));
+      *scan_begin = pos + len;
+      return *scan_begin < nbytes ? VSF_OK : VSF_ERR_INVALID_ARG;
+    }
+    pos += len;
+  }
+  return VSF_ERR_INVALID_ARG;
+}
+
+// Host half of vsf_jpeg_decode_gray_batch: parses every file, packs the entropy-coded segments, image descriptors and
+// distinct table sets into `blob` (one upload) and reports where each part starts.
+vsf_status vsf_jpeg_prepare(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height,
+                            std::vector<uint8_t>* blob, size_t* off_images, size_t* off_tables, size_t* off_stream,
+                            int* n_tables) {
+  std::vector<DevImage> images((size_t)n);
+  std::vector<DevTables> tables;
+  std::map<std::string, uint32_t> seen;
+  std::vector<size_t> begin((size_t)n);
+  size_t stream_bytes = 0;
+  for (int i = 0; i < n; i++) {
+    DevTables t;
+    const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &begin[i]);
+    if (st != VSF_OK) return st;
+    const std::string key(reinterpret_cast<const char*>(&t), sizeof(t));
+    auto it = seen.find(key);
+    if (it == seen.end()) {
+      it = seen.emplace(key, (uint32_t)tables.size()).first;
+      tables.push_back(t);
+    }
+    images[i].tables = it->second;
+    images[i].stream_off = (uint32_t)stream_bytes;
+    images[i].stream_len = (uint32_t)(nbytes[i] - begin[i]);
+    stream_bytes += (images[i].stream_len + 3u + 8u) & ~(size_t)3;
+    if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
+  }
+  *off_images = 0;
+  *off_tables = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
+  *off_stream = (*off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
+  blob->assign(*off_stream + stream_bytes + 16, 0);
+  std::memcpy(blob->data() + *off_images, images.data(), images.size() * sizeof(DevImage));
+  std::memcpy(blob->data() + *off_tables, tables.data(), tables.size() * sizeof(DevTables));
+  for (int i = 0; i < n; i++)
+    std::memcpy(blob->data() + *off_stream + images[i].stream_off, jpeg[i] + begin[i], images[i].stream_len);
+  *n_tables = (int)tables.size();
+  return VSF_OK;
+}
+
+void vsf_launch_jpeg_gray(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, int n, int width,
+                          int height, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch, int32_t* d_status,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(jpeg_gray_kernel, dim3(n), dim3(64), 0, s, reinterpret_cast<const DevImage*>(d_blob + off_images),
+                     reinterpret_cast<const DevTables*>(d_blob + off_tables), d_blob + off_stream, width, height, d_dst,
+                     dst_image_stride, dst_pitch, d_status);
+}

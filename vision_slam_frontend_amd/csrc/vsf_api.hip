@@ -358,6 +358,11 @@ struct vsf_ctx {
     ObserveMeta* h_meta = nullptr;
     std::vector<int> order;         // ring slots of the kept frames, oldest first
   } ob;
+  // vsf_jpeg_decode_gray_batch: pinned staging + device copy of the packed headers / tables / entropy-coded segments
+  uint8_t* jp_host = nullptr;
+  uint8_t* jp_dev = nullptr;
+  size_t jp_cap = 0;
+  hipEvent_t jp_copied = nullptr;  // the last upload out of jp_host has finished
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -524,6 +529,7 @@ vsf_status check_status_word(vsf_ctx* ctx) {
   VSF_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   VSF_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
+  if (*ctx->h_status & 2) return VSF_ERR_INVALID_ARG;  // a JPEG stream broke off inside its entropy-coded data
   return (*ctx->h_status & 1) ? VSF_ERR_CAPACITY : VSF_OK;
 }
 
@@ -872,6 +878,9 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
   free_observe(ctx);
+  if (ctx->jp_host) hipHostFree(ctx->jp_host);
+  hipFree(ctx->jp_dev);
+  if (ctx->jp_copied) hipEventDestroy(ctx->jp_copied);
   hipFree(ctx->v_pairs);
   hipFree(ctx->v_npairs);
   hipFree(ctx->v_sets);
@@ -1217,6 +1226,50 @@ vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, in
   // a pipelined extract that follows (vsf_set_pipeline) builds its pyramid off this stream: give it something to wait for
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));
+  ctx->ingest_done_valid = true;
+  return VSF_OK;
+}
+
+vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, const size_t* nbytes, int n_images,
+                                      int width, int height, uint8_t* d_dst, size_t dst_image_stride,
+                                      size_t dst_row_stride) {
+  if (!ctx || !jpeg || !nbytes || n_images < 1 || n_images > 65535 || width < 1 || height < 1 || width > 65535 ||
+      height > 65535 || !d_dst)
+    return VSF_ERR_INVALID_ARG;
+  if (((uintptr_t)d_dst & 3) || (dst_image_stride & 3) || (dst_row_stride & 3) || dst_row_stride < (size_t)width ||
+      dst_row_stride > 0x7FFFFFFF || dst_image_stride < dst_row_stride * (size_t)height)
+    return VSF_ERR_INVALID_ARG;
+  for (int i = 0; i < n_images; i++)
+    if (!jpeg[i] || nbytes[i] < 4 || nbytes[i] > 0x40000000u) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  std::vector<uint8_t> blob;
+  size_t off_images = 0, off_tables = 0, off_stream = 0;
+  int n_tables = 0;
+  vsf_status st = vsf_jpeg_prepare(jpeg, nbytes, n_images, width, height, &blob, &off_images, &off_tables, &off_stream,
+                                   &n_tables);
+  if (st != VSF_OK) return st;
+  if (!ctx->jp_copied) VSF_HIP(hipEventCreateWithFlags(&ctx->jp_copied, hipEventDisableTiming));
+  if (blob.size() > ctx->jp_cap) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->jp_host) hipHostFree(ctx->jp_host);
+    hipFree(ctx->jp_dev);
+    ctx->jp_host = ctx->jp_dev = nullptr;
+    ctx->jp_cap = 0;
+    const size_t cap = blob.size() + blob.size() / 4 + 4096;
+    VSF_HIP(hipHostMalloc((void**)&ctx->jp_host, cap, hipHostMallocDefault));
+    VSF_HIP(hipMalloc((void**)&ctx->jp_dev, cap));
+    ctx->jp_cap = cap;
+  } else {
+    VSF_HIP(hipEventSynchronize(ctx->jp_copied));  // the previous call's upload has left the staging buffer
+  }
+  std::memcpy(ctx->jp_host, blob.data(), blob.size());
+  VSF_HIP(hipMemcpyAsync(ctx->jp_dev, ctx->jp_host, blob.size(), hipMemcpyHostToDevice, ctx->stream));
+  VSF_HIP(hipEventRecord(ctx->jp_copied, ctx->stream));
+  vsf_launch_jpeg_gray(ctx->jp_dev, off_images, off_tables, off_stream, n_images, width, height, d_dst, dst_image_stride,
+                       (int)dst_row_stride, ctx->d_status, ctx->stream);
+  VSF_HIP(hipGetLastError());
+  if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
+  VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)
   ctx->ingest_done_valid = true;
   return VSF_OK;
 }

@@ -178,4 +178,15 @@ struct VsfObserveArgs {
 };
 void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s);
 
+// k_jpeg.hip (cv::imdecode(IMREAD_GRAYSCALE) for baseline JPEG)
+#ifdef __cplusplus
+#include <vector>
+vsf_status vsf_jpeg_prepare(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height,
+                            std::vector<uint8_t>* blob, size_t* off_images, size_t* off_tables, size_t* off_stream,
+                            int* n_tables);
+#endif
+void vsf_launch_jpeg_gray(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, int n, int width,
+                          int height, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch, int32_t* d_status,
+                          hipStream_t s);
+
 #endif  // VSF_INTERNAL_H_
