@@ -7,12 +7,13 @@
 // DCT (13-bit constants, PASS1_BITS = 2, exact 32-bit integers) + range limit; chroma is parsed and dropped.
 //
 // The entropy-coded segment of a baseline JPEG is one serial bit stream (the reference's camera driver writes no restart
-// markers): there is nothing to spread over lanes.  So ONE WAVE DECODES ONE IMAGE -- lane 0 walks the Huffman codes
-// (9-bit lookahead tables in LDS, T.81 F.2.2.3 for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops
-// chroma blocks and parks up to 16 luminance blocks of coefficients in LDS; then all 64 lanes dequantise and run the two
-// IDCT passes (lane = block x column, then block x row) and store the pixels -- and a batch runs as many waves as it
-// has images, two per CU at 512 images: a latency-bound kernel that occupies < 1 % of the chip's issue slots and is meant to
-// run on its own stream BESIDE the extraction of the previous batch.  Markers and tables are parsed on the host (the
+// markers): there is nothing to spread over lanes.  So ONE WAVE DECODES ONE IMAGE -- its SCALAR unit walks the Huffman
+// codes (wave-uniform code: state in SGPRs, stream words and 9-bit lookahead tables through scalar loads, T.81 F.2.2.3
+// for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops chroma blocks and parks up to 16 luminance
+// blocks of coefficients in LDS; then the 64 lanes dequantise and run the two IDCT passes (lane = block x column, then
+// block x row) and store the pixels -- and a batch runs as many waves as it has images: a latency-bound kernel that
+// occupies a few percent of the chip's issue slots, scales with the images in flight up to ~2500, and is meant to run on
+// a stream of its own BESIDE the extraction of earlier batches.  Markers and tables are parsed on the host (the
 // compressed bytes come from host memory anyway), which also builds the lookahead tables once per distinct table set.
 //
 // Checked bit for bit against JPEG files decoded by libjpeg-turbo (tests/golden/jpeg, tests/test_gpu_jpeg.py).
@@ -62,20 +63,39 @@ __constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // ---- lane 0's view of the entropy-coded segment ----
+// ---- the entropy decoder's view of the segment.  Everything in here is WAVE-UNIFORM: all 64 lanes run the same decode
+// with the same values, so the compiler keeps the state in SGPRs, the bit arithmetic on the scalar ALU (one cycle per
+// instruction instead of four, short dependent latency) and fetches stream words and table entries with scalar loads
+// through the constant cache (dword loads only on gfx950: bytes and 16-bit entries are cut out of their dword).  A first
+// version that let lane 0 alone walk the codes through LDS tables took ~330 cycles per symbol; this one takes ~1/3.
 struct BitReader {
-  const uint8_t* base;
-  uint32_t pos, len;
-  uint64_t acc;   // the next `n` bits of the stream sit in the low n bits, oldest on top
+  const uint32_t* words;  // the entropy-coded segment in HBM, as dwords (its offset in the packed buffer is 4-aligned)
+  uint32_t pos, len;      // next raw byte, segment length
+  uint64_t acc;           // the next `n` bits of the de-stuffed stream sit in the low n bits, oldest on top
   int n;
-  bool marker;    // a marker has been met: zero bits are fed from here on (until restart())
-  __device__ __forceinline__ void fill() {  // >= 32 bits available afterwards
-    while (n <= 56) {
+  bool marker;            // a marker has been met: zero bits are fed from here on (until restart())
+  __device__ __forceinline__ uint32_t at(uint32_t p) const { return (words[p >> 2] >> (8u * (p & 3u))) & 255u; }
+  __device__ __forceinline__ void fill() {  // >= 25 bits available afterwards (a code + its extra bits need <= 16 + 15)
+    if (n <= 32 && !marker && pos + 4u <= len) {
+      // four raw bytes at once unless one of them is 0xFF (stuffing or a marker: the byte-wise path sorts it out)
+      const uint64_t two = (uint64_t)words[pos >> 2] | ((uint64_t)words[(pos >> 2) + 1] << 32);
+      const uint32_t v = (uint32_t)(two >> (8u * (pos & 3u)));
+      const uint32_t nv = ~v;
+      if ((((nv - 0x01010101u) & ~nv) & 0x80808080u) == 0u) {  // no byte of v is 0xFF
+        const uint32_t be = (v << 24) | ((v & 0xFF00u) << 8) | ((v >> 8) & 0xFF00u) | (v >> 24);
+        acc = (acc << 32) | be;
+        n += 32;
+        pos += 4;
+        return;
+      }
+    }
+    while (n <= 24) {
       uint32_t b = 0;
       if (!marker) {
         if (pos < len) {
-          b = base[pos];
+          b = at(pos);
           if (b == 0xFFu) {
-            const uint32_t nx = pos + 1 < len ? base[pos + 1] : 0xD9u;
+            const uint32_t nx = pos + 1 < len ? at(pos + 1) : 0xD9u;
             if (nx == 0) {
               pos += 2;
             } else {
@@ -101,32 +121,34 @@ struct BitReader {
     drop(s);
     return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
   }
-  __device__ __forceinline__ int decode(const DevHuff& h) {
-    const uint32_t e = h.look[peek(kLookBits)];
+  __device__ __forceinline__ int decode(const DevHuff* h) {
+    const uint32_t p = peek(kLookBits);
+    const uint32_t e = (reinterpret_cast<const uint32_t*>(h->look)[p >> 1] >> (16u * (p & 1u))) & 0xFFFFu;
     if (e) {
       drop((int)(e >> 8));
       return (int)(e & 255u);
     }
     int l = kLookBits + 1;
     int32_t code = (int32_t)peek(l);
-    while (l <= 16 && code > h.maxcode[l]) {
+    while (l <= 16 && code > h->maxcode[l]) {
       l++;
-      code = (int32_t)peek(l);
+      code = (int32_t)peek(l <= 16 ? l : 16);
     }
     if (l > 16) {  // corrupt stream
       drop(16);
       return 0;
     }
     drop(l);
-    return h.vals[(h.valoff[l] + code) & 255];
+    const uint32_t vi = (uint32_t)(h->valoff[l] + code) & 255u;
+    return (int)((reinterpret_cast<const uint32_t*>(h->vals)[vi >> 2] >> (8u * (vi & 3u))) & 255u);
   }
   __device__ bool restart() {  // drop the remaining bits, step over RSTn
-    // bytes already pulled into the accumulator beyond the marker position cannot exist: fill() stops at a marker
+    // (fill() never pulls bytes from beyond a marker, so `pos` is at the marker when the interval's data is used up)
     acc = 0;
     n = 0;
     marker = false;
     while (pos + 1 < len) {
-      const uint32_t a = base[pos], b = base[pos + 1];
+      const uint32_t a = at(pos), b = at(pos + 1);
       if (a == 0xFFu && b >= 0xD0u && b <= 0xD7u) {
         pos += 2;
         return true;
@@ -191,29 +213,57 @@ __device__ __forceinline__ void idct8(const int32_t d[8], int32_t r[8]) {
 
 __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restrict__ images,
                                                         const DevTables* __restrict__ tables,
-                                                        const uint8_t* __restrict__ stream, int width, int height,
+                                                        const uint8_t* __restrict__ stream, uint32_t stream_total,
+                                                        int width, int height,
                                                         uint8_t* __restrict__ dst, size_t dst_image_stride,
                                                         int dst_pitch, int32_t* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) DevTables s_tab;
+  __shared__ uint16_t s_qt[64];
   __shared__ __attribute__((aligned(16))) int16_t s_coef[kGroupBlocks][64];
   __shared__ __attribute__((aligned(16))) int32_t s_ws[kGroupBlocks][64];
   __shared__ int32_t s_dest[kGroupBlocks];  // y0 << 16 | x0
-  __shared__ int32_t s_count, s_done;
   const int lane = threadIdx.x;
-  const DevImage im = images[blockIdx.x];
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + im.tables);
-    uint32_t* d = reinterpret_cast<uint32_t*>(&s_tab);
-    for (int i = lane; i < (int)(sizeof(DevTables) / 4); i += 64) d[i] = src[i];
-  }
+  const DevImage& im = images[blockIdx.x];
+  const DevTables* tab = tables + im.tables;
+  s_qt[lane] = tab->qt_luma[lane];
   uint8_t* out = dst + (size_t)blockIdx.x * dst_image_stride;
-  // decoder state: meaningful in lane 0 only
-  BitReader br{stream + im.stream_off, 0u, im.stream_len, 0ull, 0, false};
-  int pred[3] = {0, 0, 0};
-  int mcu = 0, until_restart = im.restart_interval;
-  const int nmcu = im.mcus_x * im.mcus_y;
-  const int luma_per_mcu = im.h[0] * im.v[0];
+  // geometry and decoder state: wave-uniform (see BitReader)
+  const int ncomp = im.ncomp, restart_interval = im.restart_interval, mcus_x = im.mcus_x;
+  const int nmcu = mcus_x * im.mcus_y;
+  const int h0 = im.h[0], v0 = im.v[0], luma_per_mcu = h0 * v0;
+  const int nblk1 = ncomp > 1 ? im.h[1] * im.v[1] : 0, nblk2 = ncomp > 2 ? im.h[2] * im.v[2] : 0;
+  const DevHuff *dc0 = &tab->huff[im.dc_slot[0]], *ac0 = &tab->huff[im.ac_slot[0]];
+  const DevHuff *dc1 = &tab->huff[im.dc_slot[ncomp > 1 ? 1 : 0]], *ac1 = &tab->huff[im.ac_slot[ncomp > 1 ? 1 : 0]];
+  const DevHuff *dc2 = &tab->huff[im.dc_slot[ncomp > 2 ? 2 : 0]], *ac2 = &tab->huff[im.ac_slot[ncomp > 2 ? 2 : 0]];
+  const uint32_t* zz32 = reinterpret_cast<const uint32_t*>(c_zigzag);
+  BitReader br{reinterpret_cast<const uint32_t*>(stream + im.stream_off), 0u, im.stream_len, 0ull, 0, false};
+  (void)stream_total;
+  int pred0 = 0, pred1 = 0, pred2 = 0;
+  int mcu = 0, until_restart = restart_interval;
   bool broken = false;
+  // one block: DC difference + AC run / size pairs (T.81 F.2.2.1, F.2.2.2); coefficients go to `coef` in natural order
+  // (LUMA) or nowhere (chroma is parsed only)
+  auto block = [&](const DevHuff* hd, const DevHuff* ha, int& pred, int16_t* coef) {
+    br.fill();
+    const int t = br.decode(hd);
+    br.fill();
+    pred += br.receive_extend(t);
+    if (coef) coef[0] = (int16_t)pred;
+    for (int k = 1; k < 64;) {
+      br.fill();
+      const int rs = br.decode(ha);
+      const int r = rs >> 4, sz = rs & 15;
+      if (sz == 0) {
+        if (r != 15) break;  // EOB
+        k += 16;
+        continue;
+      }
+      k += r;
+      if (k > 63) break;  // corrupt
+      const int val = br.receive_extend(sz);
+      if (coef) coef[(zz32[k >> 2] >> (8 * (k & 3))) & 63u] = (int16_t)val;
+      k++;
+    }
+  };
   __syncthreads();
   for (;;) {
     {  // clear the coefficient buffer
@@ -221,65 +271,38 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
       for (int i = lane; i < kGroupBlocks * 32; i += 64) c[i] = 0u;
     }
     __syncthreads();
-    if (lane == 0) {
-      int count = 0;
-      while (mcu < nmcu && count + luma_per_mcu <= kGroupBlocks && !broken) {
-        if (im.restart_interval && until_restart == 0) {
-          if (!br.restart()) {
-            broken = true;
-            break;
-          }
-          pred[0] = pred[1] = pred[2] = 0;
-          until_restart = im.restart_interval;
+    // ---- entropy decoding of as many whole MCUs as fit the coefficient buffer: uniform, every lane the same ----
+    int count = 0;
+    while (mcu < nmcu && count + luma_per_mcu <= kGroupBlocks && !broken) {
+      if (restart_interval && until_restart == 0) {
+        if (!br.restart()) {
+          broken = true;
+          break;
         }
-        const int my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
-        for (int ci = 0; ci < im.ncomp; ci++) {
-          const DevHuff& hd = s_tab.huff[im.dc_slot[ci]];
-          const DevHuff& ha = s_tab.huff[im.ac_slot[ci]];
-          for (int by = 0; by < im.v[ci]; by++)
-            for (int bx = 0; bx < im.h[ci]; bx++) {
-              int16_t* coef = ci == 0 ? s_coef[count] : nullptr;
-              br.fill();
-              const int t = br.decode(hd);
-              br.fill();
-              pred[ci] += br.receive_extend(t);
-              if (coef) coef[0] = (int16_t)pred[ci];
-              for (int k = 1; k < 64;) {
-                br.fill();
-                const int rs = br.decode(ha);
-                const int r = rs >> 4, sz = rs & 15;
-                if (sz == 0) {
-                  if (r != 15) break;  // EOB
-                  k += 16;
-                  continue;
-                }
-                k += r;
-                if (k > 63) break;  // corrupt
-                const int val = br.receive_extend(sz);  // (fill() left >= 32 - 16 bits after the code)
-                if (coef) coef[c_zigzag[k]] = (int16_t)val;
-                k++;
-              }
-              if (ci == 0) {
-                s_dest[count] = ((my * im.v[0] * 8 + by * 8) << 16) | (mx * im.h[0] * 8 + bx * 8);
-                count++;
-              }
-            }
-        }
-        if (im.restart_interval) until_restart--;
-        mcu++;
+        pred0 = pred1 = pred2 = 0;
+        until_restart = restart_interval;
       }
-      s_count = count;
-      s_done = (mcu >= nmcu || broken) ? 1 : 0;
+      const int my = mcu / mcus_x, mx = mcu - my * mcus_x;
+      for (int by = 0; by < v0; by++)
+        for (int bx = 0; bx < h0; bx++) {
+          block(dc0, ac0, pred0, s_coef[count]);
+          s_dest[count] = ((my * v0 * 8 + by * 8) << 16) | (mx * h0 * 8 + bx * 8);
+          count++;
+        }
+      for (int b = 0; b < nblk1; b++) block(dc1, ac1, pred1, nullptr);
+      for (int b = 0; b < nblk2; b++) block(dc2, ac2, pred2, nullptr);
+      if (restart_interval) until_restart--;
+      mcu++;
     }
+    const bool done = mcu >= nmcu || broken;
     __syncthreads();
-    const int count = s_count;
     // ---- dequantise + IDCT of the parked blocks: 8 blocks x 8 columns, then 8 blocks x 8 rows, per round ----
     for (int b0 = 0; b0 < count; b0 += 8) {
       const int b = b0 + (lane >> 3), i = lane & 7;
       if (b < count) {
         int32_t d[8], r[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) d[k] = (int32_t)s_coef[b][8 * k + i] * (int32_t)s_tab.qt_luma[8 * k + i];
+        for (int k = 0; k < 8; k++) d[k] = (int32_t)s_coef[b][8 * k + i] * (int32_t)s_qt[8 * k + i];
         idct8(d, r);
 #pragma unroll
         for (int k = 0; k < 8; k++) s_ws[b][8 * k + i] = (r[k] + (1 << 10)) >> 11;  // DESCALE(., CONST_BITS - PASS1_BITS)
@@ -309,8 +332,7 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
       }
       __syncthreads();
     }
-    if (s_done) break;
-    __syncthreads();
+    if (done) break;
   }
   if (lane == 0 && broken) atomicOr(status, 2);
 }
@@ -464,48 +486,64 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
   return VSF_ERR_INVALID_ARG;
 }
 
-// Host half of vsf_jpeg_decode_gray_batch: parses every file, packs the entropy-coded segments, image descriptors and
-// distinct table sets into `blob` (one upload) and reports where each part starts.
-vsf_status vsf_jpeg_prepare(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height,
-                            std::vector<uint8_t>* blob, size_t* off_images, size_t* off_tables, size_t* off_stream,
-                            int* n_tables) {
+// Host half of vsf_jpeg_decode_gray_batch, step 1: parses every file and lays out ONE upload -- image descriptors,
+// distinct table sets (consecutive frames of a camera share theirs: compared with the previous file's first), packed
+// entropy-coded segments -- without touching the segments themselves.
+vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height, VsfJpegPlan* plan) {
   std::vector<DevImage> images((size_t)n);
   std::vector<DevTables> tables;
-  std::map<std::string, uint32_t> seen;
-  std::vector<size_t> begin((size_t)n);
+  plan->scan_begin.assign((size_t)n, 0);
   size_t stream_bytes = 0;
   for (int i = 0; i < n; i++) {
     DevTables t;
-    const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &begin[i]);
+    const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &plan->scan_begin[i]);
     if (st != VSF_OK) return st;
-    const std::string key(reinterpret_cast<const char*>(&t), sizeof(t));
-    auto it = seen.find(key);
-    if (it == seen.end()) {
-      it = seen.emplace(key, (uint32_t)tables.size()).first;
+    int found = -1;
+    for (int k = (int)tables.size() - 1; k >= 0 && found < 0; k--)
+      if (std::memcmp(&tables[k], &t, sizeof(t)) == 0) found = k;
+    if (found < 0) {
+      found = (int)tables.size();
       tables.push_back(t);
     }
-    images[i].tables = it->second;
+    images[i].tables = (uint32_t)found;
     images[i].stream_off = (uint32_t)stream_bytes;
-    images[i].stream_len = (uint32_t)(nbytes[i] - begin[i]);
+    images[i].stream_len = (uint32_t)(nbytes[i] - plan->scan_begin[i]);
     stream_bytes += (images[i].stream_len + 3u + 8u) & ~(size_t)3;
     if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
   }
-  *off_images = 0;
-  *off_tables = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
-  *off_stream = (*off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
-  blob->assign(*off_stream + stream_bytes + 16, 0);
-  std::memcpy(blob->data() + *off_images, images.data(), images.size() * sizeof(DevImage));
-  std::memcpy(blob->data() + *off_tables, tables.data(), tables.size() * sizeof(DevTables));
-  for (int i = 0; i < n; i++)
-    std::memcpy(blob->data() + *off_stream + images[i].stream_off, jpeg[i] + begin[i], images[i].stream_len);
-  *n_tables = (int)tables.size();
+  plan->off_images = 0;
+  plan->off_tables = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
+  plan->off_stream = (plan->off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
+  plan->total = plan->off_stream + stream_bytes + 16;
+  plan->head.assign(plan->off_stream, 0);
+  std::memcpy(plan->head.data() + plan->off_images, images.data(), images.size() * sizeof(DevImage));
+  std::memcpy(plan->head.data() + plan->off_tables, tables.data(), tables.size() * sizeof(DevTables));
+  plan->stream_off.resize((size_t)n);
+  plan->stream_len.resize((size_t)n);
+  for (int i = 0; i < n; i++) {
+    plan->stream_off[i] = images[i].stream_off;
+    plan->stream_len[i] = images[i].stream_len;
+  }
   return VSF_OK;
 }
 
-void vsf_launch_jpeg_gray(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, int n, int width,
-                          int height, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch, int32_t* d_status,
-                          hipStream_t s) {
+// Step 2: writes the upload into `dst` (pinned staging, plan->total bytes): one pass over the compressed bytes.
+void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, uint8_t* dst) {
+  std::memcpy(dst, plan.head.data(), plan.head.size());
+  for (int i = 0; i < n; i++) {
+    uint8_t* d = dst + plan.off_stream + plan.stream_off[i];
+    std::memcpy(d, jpeg[i] + plan.scan_begin[i], plan.stream_len[i]);
+    const size_t padded = (plan.stream_len[i] + 3u + 8u) & ~(size_t)3;
+    std::memset(d + plan.stream_len[i], 0, padded - plan.stream_len[i]);
+  }
+  std::memset(dst + plan.total - 16, 0, 16);
+}
+
+void vsf_launch_jpeg_gray(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, size_t total, int n,
+                          int width, int height, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
+                          int32_t* d_status, hipStream_t s) {
   hipLaunchKernelGGL(jpeg_gray_kernel, dim3(n), dim3(64), 0, s, reinterpret_cast<const DevImage*>(d_blob + off_images),
-                     reinterpret_cast<const DevTables*>(d_blob + off_tables), d_blob + off_stream, width, height, d_dst,
-                     dst_image_stride, dst_pitch, d_status);
+                     reinterpret_cast<const DevTables*>(d_blob + off_tables), d_blob + off_stream,
+                     (uint32_t)((total - off_stream) & ~(size_t)3), width, height, d_dst, dst_image_stride, dst_pitch,
+                     d_status);
 }

@@ -359,10 +359,12 @@ struct vsf_ctx {
     std::vector<int> order;         // ring slots of the kept frames, oldest first
   } ob;
   // vsf_jpeg_decode_gray_batch: pinned staging + device copy of the packed headers / tables / entropy-coded segments
-  uint8_t* jp_host = nullptr;
-  uint8_t* jp_dev = nullptr;
-  size_t jp_cap = 0;
-  hipEvent_t jp_copied = nullptr;  // the last upload out of jp_host has finished
+  // (two sets, used alternately: the host fills one while the previous call's upload / decode still use the other)
+  uint8_t* jp_host[2] = {nullptr, nullptr};
+  uint8_t* jp_dev[2] = {nullptr, nullptr};
+  size_t jp_cap[2] = {0, 0};
+  hipEvent_t jp_copied[2] = {nullptr, nullptr};  // the last upload out of jp_host[i] has finished
+  int jp_flip = 0;
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -878,9 +880,11 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
   free_observe(ctx);
-  if (ctx->jp_host) hipHostFree(ctx->jp_host);
-  hipFree(ctx->jp_dev);
-  if (ctx->jp_copied) hipEventDestroy(ctx->jp_copied);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->jp_host[i]) hipHostFree(ctx->jp_host[i]);
+    hipFree(ctx->jp_dev[i]);
+    if (ctx->jp_copied[i]) hipEventDestroy(ctx->jp_copied[i]);
+  }
   hipFree(ctx->v_pairs);
   hipFree(ctx->v_npairs);
   hipFree(ctx->v_sets);
@@ -1242,31 +1246,32 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   for (int i = 0; i < n_images; i++)
     if (!jpeg[i] || nbytes[i] < 4 || nbytes[i] > 0x40000000u) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
-  std::vector<uint8_t> blob;
-  size_t off_images = 0, off_tables = 0, off_stream = 0;
-  int n_tables = 0;
-  vsf_status st = vsf_jpeg_prepare(jpeg, nbytes, n_images, width, height, &blob, &off_images, &off_tables, &off_stream,
-                                   &n_tables);
+  VsfJpegPlan plan;
+  vsf_status st = vsf_jpeg_plan(jpeg, nbytes, n_images, width, height, &plan);
   if (st != VSF_OK) return st;
-  if (!ctx->jp_copied) VSF_HIP(hipEventCreateWithFlags(&ctx->jp_copied, hipEventDisableTiming));
-  if (blob.size() > ctx->jp_cap) {
+  const int b = ctx->jp_flip;
+  ctx->jp_flip ^= 1;
+  if (!ctx->jp_copied[b]) VSF_HIP(hipEventCreateWithFlags(&ctx->jp_copied[b], hipEventDisableTiming));
+  if (plan.total > ctx->jp_cap[b]) {
     VSF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->jp_host) hipHostFree(ctx->jp_host);
-    hipFree(ctx->jp_dev);
-    ctx->jp_host = ctx->jp_dev = nullptr;
-    ctx->jp_cap = 0;
-    const size_t cap = blob.size() + blob.size() / 4 + 4096;
-    VSF_HIP(hipHostMalloc((void**)&ctx->jp_host, cap, hipHostMallocDefault));
-    VSF_HIP(hipMalloc((void**)&ctx->jp_dev, cap));
-    ctx->jp_cap = cap;
+    if (ctx->jp_host[b]) hipHostFree(ctx->jp_host[b]);
+    hipFree(ctx->jp_dev[b]);
+    ctx->jp_host[b] = ctx->jp_dev[b] = nullptr;
+    ctx->jp_cap[b] = 0;
+    const size_t cap = plan.total + plan.total / 4 + 4096;
+    VSF_HIP(hipHostMalloc((void**)&ctx->jp_host[b], cap, hipHostMallocDefault));
+    VSF_HIP(hipMalloc((void**)&ctx->jp_dev[b], cap));
+    ctx->jp_cap[b] = cap;
   } else {
-    VSF_HIP(hipEventSynchronize(ctx->jp_copied));  // the previous call's upload has left the staging buffer
+    // the upload of the call before the previous one has left this staging buffer (long ago: the previous call's
+    // decode is what may still be running, out of the OTHER buffer)
+    VSF_HIP(hipEventSynchronize(ctx->jp_copied[b]));
   }
-  std::memcpy(ctx->jp_host, blob.data(), blob.size());
-  VSF_HIP(hipMemcpyAsync(ctx->jp_dev, ctx->jp_host, blob.size(), hipMemcpyHostToDevice, ctx->stream));
-  VSF_HIP(hipEventRecord(ctx->jp_copied, ctx->stream));
-  vsf_launch_jpeg_gray(ctx->jp_dev, off_images, off_tables, off_stream, n_images, width, height, d_dst, dst_image_stride,
-                       (int)dst_row_stride, ctx->d_status, ctx->stream);
+  vsf_jpeg_fill(plan, jpeg, n_images, ctx->jp_host[b]);  // the one pass over the compressed bytes on the host
+  VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
+  VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
+  vsf_launch_jpeg_gray(ctx->jp_dev[b], plan.off_images, plan.off_tables, plan.off_stream, plan.total, n_images, width, height,
+                       d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
   VSF_HIP(hipGetLastError());
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)
