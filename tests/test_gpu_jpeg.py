@@ -117,3 +117,34 @@ def test_ingest_chain_jpeg_bayer_extract(ctx, oracle):
     assert n == len(rk) > 300
     assert d_kp.cpu().numpy()[0, :n].tobytes() == rk.tobytes()
     np.testing.assert_array_equal(d_desc.cpu().numpy()[0, :n], rd)
+
+
+def test_parallel_and_serial_decoders_agree(oracle, monkeypatch):
+    """Files without restart intervals take the self-synchronising parallel decoder, the others (and VSF_JPEG_SERIAL=1)
+    the one-wave-per-image decoder: both against the oracle on a batch of different images, gray and colour."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    from vision_slam_frontend_amd import capi, synth
+    rng = np.random.default_rng(11)
+    files = []
+    for i in range(24):
+        img = synth.stereo_pair(328, 200, 300 + i, n_objects=int(rng.integers(20, 400)))[i & 1]
+        if i % 5 == 0:
+            img = rng.integers(0, 256, img.shape, dtype=np.uint8)  # pure noise: long codes, many 0xFF bytes
+        if i % 7 == 3:
+            img = np.full_like(img, int(rng.integers(0, 256)))     # flat: a stream of EOBs, segments far longer than blocks
+        b = io.BytesIO()
+        if i % 4 == 1:
+            rgb = np.stack([img, np.roll(img, 7, 0), np.roll(img, 11, 1)], 2)
+            PIL.fromarray(rgb, "RGB").save(b, "JPEG", quality=int(rng.integers(25, 98)), subsampling=int(rng.integers(0, 3)))
+        else:
+            PIL.fromarray(img, "L").save(b, "JPEG", quality=int(rng.integers(5, 101)), optimize=bool(i & 2))
+        files.append(b.getvalue())
+    want = [oracle.jpeg_decode_gray(f) for f in files]
+    for serial in ("0", "1"):
+        monkeypatch.setenv("VSF_JPEG_SERIAL", serial)
+        c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500))
+        got = _decode(c, files, 328, 200)
+        c.close()
+        for i in range(len(files)):
+            np.testing.assert_array_equal(got[i, :, :328], want[i], err_msg="file %d, VSF_JPEG_SERIAL=%s" % (i, serial))

@@ -6,8 +6,10 @@
 // JDCT_ISLOW): ITU-T T.81 baseline entropy decoding and, for the luminance component only, libjpeg's jidctint.c inverse
 // DCT (13-bit constants, PASS1_BITS = 2, exact 32-bit integers) + range limit; chroma is parsed and dropped.
 //
-// The entropy-coded segment of a baseline JPEG is one serial bit stream (the reference's camera driver writes no restart
-// markers): there is nothing to spread over lanes.  So ONE WAVE DECODES ONE IMAGE -- its SCALAR unit walks the Huffman
+// Two decoders.  Files without restart intervals (what a camera driver writes) take the PARALLEL one further down:
+// 256 threads per image decode 256 segments of the stream speculatively and iterate until their states agree
+// (jpeg_par_decode_kernel).  Files with restart intervals -- and everything under VSF_JPEG_SERIAL=1 -- take the one
+// described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
 // codes (wave-uniform code: state in SGPRs, stream words and 9-bit lookahead tables through scalar loads, T.81 F.2.2.3
 // for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops chroma blocks and parks up to 16 luminance
 // blocks of coefficients in LDS; then the 64 lanes dequantise and run the two IDCT passes (lane = block x column, then
@@ -337,6 +339,343 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
   if (lane == 0 && broken) atomicOr(status, 2);
 }
 
+// =====================================================================================================================
+// Parallel entropy decoding (files without restart intervals -- what a camera driver writes).
+//
+// A Huffman-coded stream has no markers to split it at, but it is SELF-SYNCHRONISING: a decoder started at a wrong bit
+// soon falls into step with the true one (Klein & Wiseman; for JPEG on GPUs: Weissenberger & Schmidt 2018/2021).  So a
+// 256-thread workgroup per image
+//   1. removes the byte stuffing in parallel (FF00 -> FF, stop at the first marker) into a "clean" stream of big-endian
+//      dwords, in which a position is ONE integer (a bit index);
+//   2. cuts the clean stream into 256 segments.  Thread t decodes segment t from an ASSUMED state (bit t * B, first block of
+//      an MCU, DC next) up to the first symbol boundary past its end and records that end state (bit, block in MCU, zigzag
+//      index).  Thread 0's assumption is true.  Then, round after round, every thread restarts from its predecessor's end
+//      state whenever that state changed, until no end state changes: then start[t] == end[t-1] for all t, and by
+//      induction from thread 0 every start is the TRUE decoder's state.  A thread whose decode has merged with the true one
+//      never moves again, so the work is one segment per thread and round, and gray streams settle in two or three rounds;
+//   3. prefix-sums the blocks each segment completes, and decodes once more, now writing luminance coefficients (DC still
+//      as differences) into the coefficient buffer.
+// A second kernel turns the DC differences into values (a scan per image) and a third does dequantisation + IDCT for all
+// blocks of all images at once.  Latency per image: a few segment decodes instead of the whole stream.
+// =====================================================================================================================
+constexpr int kParThreads = 256;
+
+struct ParState {
+  uint32_t q;  // bit position in the clean stream
+  uint32_t ck; // block index inside the MCU << 8 | zigzag index (0: the next symbol is a DC size)
+};
+
+struct ParCtx {  // per-thread decoder over the clean stream (big-endian dwords)
+  const uint32_t* clean;
+  uint32_t ndwords;  // dwords that hold stream bits (zero bits are fed beyond, as libjpeg does past the end of the data)
+  uint32_t base;     // dword index of w0
+  uint32_t w0, w1;
+  __device__ __forceinline__ uint64_t window(uint32_t q) {  // the 33+ bits from q on, left-aligned
+    const uint32_t b = q >> 5;
+    if (b != base) {
+      base = b;
+      w0 = b < ndwords ? clean[b] : 0u;
+      w1 = b + 1 < ndwords ? clean[b + 1] : 0u;
+    }
+    return (((uint64_t)w0 << 32) | w1) << (q & 31u);
+  }
+};
+
+// One symbol (a DC size + its bits, or an AC run/size + its bits) of the block described by (c, k); returns true when it
+// ends the block.  val / zpos: the coefficient it produced (zpos < 0: none).
+__device__ __forceinline__ bool par_symbol(ParCtx& cx, uint32_t& q, int& k, const DevHuff& hd, const DevHuff& ha, int& val,
+                                           int& zpos) {
+  const uint64_t x = cx.window(q);
+  const DevHuff& h = k == 0 ? hd : ha;
+  const uint32_t p9 = (uint32_t)(x >> (64 - kLookBits));
+  uint32_t e = h.look[p9];
+  int len, sym;
+  if (e) {
+    len = (int)(e >> 8);
+    sym = (int)(e & 255u);
+  } else {
+    int l = kLookBits + 1;
+    int32_t code = (int32_t)(x >> (64 - l));
+    while (l <= 16 && code > h.maxcode[l]) {
+      l++;
+      code = (int32_t)(x >> (64 - (l <= 16 ? l : 16)));
+    }
+    if (l > 16) {
+      len = 16;
+      sym = 0;
+    } else {
+      len = l;
+      sym = h.vals[(h.valoff[l] + code) & 255];
+    }
+  }
+  zpos = -1;
+  val = 0;
+  if (k == 0) {  // DC: `sym` further bits
+    const int s = sym & 15;
+    if (s) {
+      const int v = (int)((x << len) >> (64 - s));
+      val = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    }
+    q += (uint32_t)(len + s);
+    zpos = 0;
+    k = 1;
+    return false;
+  }
+  const int r = sym >> 4, s = sym & 15;
+  if (s == 0) {
+    q += (uint32_t)len;
+    if (r != 15) return true;  // EOB
+    k += 16;
+    return k > 63;
+  }
+  k += r;
+  if (k > 63) {  // (cannot happen on the true chain)
+    q += (uint32_t)(len + s);
+    return true;
+  }
+  const int v = (int)((x << len) >> (64 - s));
+  val = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+  q += (uint32_t)(len + s);
+  zpos = k;
+  k++;
+  return k > 63;
+}
+
+__global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevImage* __restrict__ images,
+                                                                       const DevTables* __restrict__ tables,
+                                                                       const uint8_t* __restrict__ stream,
+                                                                       uint32_t* __restrict__ clean_all,
+                                                                       int16_t* __restrict__ coef_all, size_t coef_stride,
+                                                                       int32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) DevTables s_tab;
+  __shared__ uint32_t s_q[kParThreads + 1], s_ck[kParThreads + 1];  // end states; [t] = start of segment t (entry 0: truth)
+  __shared__ uint32_t s_cnt[kParThreads];
+  __shared__ uint32_t s_scan[kParThreads / 64];
+  __shared__ uint32_t s_marker, s_total, s_changed;
+  __shared__ uint8_t s_zz[64];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const DevImage& im = images[blockIdx.x];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + im.tables);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&s_tab);
+    for (int i = t; i < (int)(sizeof(DevTables) / 4); i += kParThreads) d[i] = src[i];
+  }
+  if (t < 64) s_zz[t] = c_zigzag[t];
+  if (t == 0) s_marker = im.stream_len;
+  const uint8_t* raw = stream + im.stream_off;
+  uint8_t* clean8 = reinterpret_cast<uint8_t*>(clean_all) + im.stream_off;
+  const uint32_t* clean = clean_all + (im.stream_off >> 2);
+  const uint32_t len = im.stream_len;
+  __syncthreads();
+  // ---- 1. remove the byte stuffing ----
+  const uint32_t chunk = ((len + kParThreads - 1) / kParThreads + 3u) & ~3u;
+  const uint32_t c_begin = min((uint32_t)t * chunk, len), c_end = min(c_begin + chunk, len);
+  {
+    uint32_t first = len;
+    for (uint32_t i = c_begin; i < c_end; i++)
+      if (raw[i] == 0xFFu && (i + 1 >= len || raw[i + 1] != 0u)) {
+        first = i;
+        break;
+      }
+    if (first < len) atomicMin(&s_marker, first);
+  }
+  __syncthreads();
+  const uint32_t mpos = s_marker;  // the entropy-coded data ends here (EOI, normally)
+  uint32_t keep = 0;
+  for (uint32_t i = c_begin; i < min(c_end, mpos); i++) keep += !(raw[i] == 0u && i > 0 && raw[i - 1] == 0xFFu);
+  uint32_t inc = keep;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) s_scan[wid] = inc;
+  __syncthreads();
+  uint32_t off = inc - keep;
+  for (int w = 0; w < wid; w++) off += s_scan[w];
+  if (t == kParThreads - 1) s_total = off + keep;
+  for (uint32_t i = c_begin; i < min(c_end, mpos); i++) {
+    const uint32_t b = raw[i];
+    if (b == 0u && i > 0 && raw[i - 1] == 0xFFu) continue;
+    clean8[off ^ 3u] = (uint8_t)b;  // big-endian dwords: stream bit q is bit 31 - (q & 31) of dword q >> 5
+    off++;
+  }
+  __syncthreads();
+  const uint32_t L = s_total;  // clean bytes
+  {  // zero the rest of the last dword (zero bits are what libjpeg feeds past the end of the data)
+    const uint32_t z1 = (L + 3u) & ~3u;
+    for (uint32_t i = L + t; i < z1; i += kParThreads) clean8[i ^ 3u] = 0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- 2. segment end states until they stop changing ----
+  const int ncomp = im.ncomp;
+  const int lum = im.h[0] * im.v[0];
+  const int n1 = ncomp > 1 ? im.h[1] * im.v[1] : 0, n2 = ncomp > 2 ? im.h[2] * im.v[2] : 0;
+  const int m = lum + n1 + n2;  // blocks per MCU
+  const DevHuff &hd0 = s_tab.huff[im.dc_slot[0]], &ha0 = s_tab.huff[im.ac_slot[0]];
+  const DevHuff &hd1 = s_tab.huff[im.dc_slot[ncomp > 1 ? 1 : 0]], &ha1 = s_tab.huff[im.ac_slot[ncomp > 1 ? 1 : 0]];
+  const DevHuff &hd2 = s_tab.huff[im.dc_slot[ncomp > 2 ? 2 : 0]], &ha2 = s_tab.huff[im.ac_slot[ncomp > 2 ? 2 : 0]];
+  const uint32_t nbits = L * 8u;
+  const uint32_t seg = max(64u, ((nbits + kParThreads - 1) / kParThreads + 31u) & ~31u);
+  const uint32_t limit = min((uint32_t)(t + 1) * seg, nbits);
+  ParCtx cx{clean, (L + 3u) >> 2, 0xFFFFFFFFu, 0u, 0u};
+  // decodes from (q, c, k) to the first symbol boundary at or past `limit`; WRITE: coefficients of luminance blocks
+  // go to coef[(g / m) * lum + c][...] with g = blocks completed before this one in the whole image
+  // (`finish`: the last segment of the writing pass keeps going on zero bits until the image has all its blocks -- what
+  // libjpeg does with a stream that breaks off -- and never loops for ever: every symbol consumes at least one bit of at
+  // most 2^32)
+  auto run = [&](uint32_t& q, int& c, int& k, bool write, uint32_t g, int16_t* coef, uint32_t total_blocks,
+                 bool finish = false) -> uint32_t {
+    uint32_t done = 0;
+    while (q < limit || (finish && g + done < total_blocks && q < 0xFFFF0000u)) {
+      const bool is0 = c < lum, is1 = !is0 && c < lum + n1;
+      const DevHuff& hd = is0 ? hd0 : (is1 ? hd1 : hd2);
+      const DevHuff& ha = is0 ? ha0 : (is1 ? ha1 : ha2);
+      int val, zpos;
+      const bool end = par_symbol(cx, q, k, hd, ha, val, zpos);
+      if (write && is0 && zpos >= 0 && g + done < total_blocks) {
+        const uint32_t lb = ((g + done) / (uint32_t)m) * (uint32_t)lum + (uint32_t)c;
+        coef[(size_t)lb * 64 + s_zz[zpos]] = (int16_t)val;
+      }
+      if (end) {
+        k = 0;
+        c = c + 1 == m ? 0 : c + 1;
+        done++;
+      }
+    }
+    return done;
+  };
+  uint32_t sq = (uint32_t)t * seg, sck = 0;  // assumed start: first block of an MCU, DC next (true for t == 0)
+  if (t == 0) {
+    s_q[0] = 0;
+    s_ck[0] = 0;
+    s_changed = 0;
+  }
+  {
+    uint32_t q = min(sq, nbits);
+    int c = 0, k = 0;
+    s_cnt[t] = run(q, c, k, false, 0, nullptr, 0);
+    s_q[t + 1] = q;
+    s_ck[t + 1] = ((uint32_t)c << 8) | (uint32_t)k;
+  }
+  __syncthreads();
+  for (int round = 0; round < kParThreads; round++) {
+    const uint32_t nq = s_q[t], nck = s_ck[t];  // the predecessor's end state (the truth for t == 0)
+    bool redo = t > 0 && (nq != sq || nck != sck);
+    uint32_t q = nq, cnt = 0;
+    int c = (int)(nck >> 8), k = (int)(nck & 255u);
+    if (redo) cnt = run(q, c, k, false, 0, nullptr, 0);
+    __syncthreads();  // (everybody has read its predecessor's state)
+    if (redo) {
+      sq = nq;
+      sck = nck;
+      const uint32_t eck = ((uint32_t)c << 8) | (uint32_t)k;
+      if (s_q[t + 1] != q || s_ck[t + 1] != eck) atomicOr(&s_changed, 1u);
+      s_q[t + 1] = q;
+      s_ck[t + 1] = eck;
+      s_cnt[t] = cnt;
+    }
+    __syncthreads();
+    const uint32_t any = s_changed;
+    __syncthreads();
+    if (t == 0) s_changed = 0;
+    if (!any) break;  // uniform: nothing moved, so nothing will
+  }
+  __syncthreads();
+  // (thread 0 never re-ran: its start was true; sq / sck of the others now equal their predecessors' end states)
+  // ---- 3. block offsets, then the writing pass ----
+  uint32_t mine = s_cnt[t], incb = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incb, o, 64);
+    if (lane >= o) incb += v;
+  }
+  if (lane == 63) s_scan[wid] = incb;
+  __syncthreads();
+  uint32_t g = incb - mine;
+  for (int w = 0; w < wid; w++) g += s_scan[w];
+  {
+    const uint32_t total_blocks = (uint32_t)(im.mcus_x * im.mcus_y * m);
+    uint32_t q = t == 0 ? 0u : s_q[t];
+    const uint32_t ck = t == 0 ? 0u : s_ck[t];
+    int c = (int)(ck >> 8), k = (int)(ck & 255u);
+    int16_t* coef = coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t));
+    (void)run(q, c, k, true, g, coef, total_blocks, t == kParThreads - 1);
+  }
+}
+
+// DC differences -> DC values of the luminance blocks (decode order), one wave per image
+__global__ __launch_bounds__(64) void jpeg_dc_scan_kernel(const DevImage* __restrict__ images, int16_t* __restrict__ coef_all,
+                                                          size_t coef_stride) {
+  const DevImage& im = images[blockIdx.x];
+  const int nlb = im.mcus_x * im.mcus_y * im.h[0] * im.v[0];
+  int16_t* coef = coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t));
+  const int lane = threadIdx.x, per = (nlb + 63) / 64;
+  const int b0 = min(lane * per, nlb), b1 = min(b0 + per, nlb);
+  int sum = 0;
+  for (int b = b0; b < b1; b++) sum += coef[(size_t)b * 64];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  int run = inc - sum;
+  for (int b = b0; b < b1; b++) {
+    run += coef[(size_t)b * 64];
+    coef[(size_t)b * 64] = (int16_t)run;
+  }
+}
+
+// dequantisation + IDCT + range limit of 8 luminance blocks per wave, from the coefficient buffer
+__global__ __launch_bounds__(64) void jpeg_idct_kernel(const DevImage* __restrict__ images,
+                                                        const DevTables* __restrict__ tables,
+                                                        const int16_t* __restrict__ coef_all, size_t coef_stride, int width,
+                                                        int height, uint8_t* __restrict__ dst, size_t dst_image_stride,
+                                                        int dst_pitch) {
+  __shared__ int32_t s_ws[8][64];
+  const DevImage& im = images[blockIdx.y];
+  const int lum_w = im.h[0], lum = im.h[0] * im.v[0];
+  const int nlb = im.mcus_x * im.mcus_y * lum;
+  const int lane = threadIdx.x, b = blockIdx.x * 8 + (lane >> 3), i = lane & 7;
+  const int16_t* coef = coef_all + (size_t)blockIdx.y * (coef_stride / sizeof(int16_t)) + (size_t)b * 64;
+  const uint16_t* qt = tables[im.tables].qt_luma;
+  if (b < nlb) {
+    int32_t d[8], r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = (int32_t)coef[8 * k + i] * (int32_t)qt[8 * k + i];
+    idct8(d, r);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_ws[lane >> 3][8 * k + i] = (r[k] + (1 << 10)) >> 11;
+  }
+  __syncthreads();
+  if (b < nlb) {
+    int32_t d[8], r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = s_ws[lane >> 3][8 * i + k];
+    idct8(d, r);
+    const int mcu = b / lum, c = b - mcu * lum;
+    const int my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
+    const int x0 = (mx * lum_w + c % lum_w) * 8, y = (my * im.v[0] + c / lum_w) * 8 + i;
+    if (y < height && x0 < width) {
+      uint8_t px[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) px[k] = range_limit((r[k] + (1 << 17)) >> 18);
+      uint8_t* row = dst + (size_t)blockIdx.y * dst_image_stride + (size_t)y * dst_pitch + x0;
+      if (x0 + 8 <= width) {
+        uint32_t lo, hi;
+        memcpy(&lo, px, 4);
+        memcpy(&hi, px + 4, 4);
+        reinterpret_cast<uint32_t*>(row)[0] = lo;
+        reinterpret_cast<uint32_t*>(row)[1] = hi;
+      } else {
+        for (int k = 0; k < 8 && x0 + k < width; k++) row[k] = px[k];
+      }
+    }
+  }
+}
+
 // ---- host: markers and tables (ITU-T T.81 Annex B) ----
 struct HostHuff {
   bool present = false;
@@ -493,6 +832,8 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   std::vector<DevImage> images((size_t)n);
   std::vector<DevTables> tables;
   plan->scan_begin.assign((size_t)n, 0);
+  plan->parallel_ok = true;
+  plan->max_luma_blocks = 0;
   size_t stream_bytes = 0;
   for (int i = 0; i < n; i++) {
     DevTables t;
@@ -508,7 +849,9 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
     images[i].tables = (uint32_t)found;
     images[i].stream_off = (uint32_t)stream_bytes;
     images[i].stream_len = (uint32_t)(nbytes[i] - plan->scan_begin[i]);
-    stream_bytes += (images[i].stream_len + 3u + 8u) & ~(size_t)3;
+    stream_bytes += (images[i].stream_len + 3u + 32u) & ~(size_t)3;
+    if (images[i].restart_interval != 0) plan->parallel_ok = false;
+    plan->max_luma_blocks = std::max(plan->max_luma_blocks, images[i].mcus_x * images[i].mcus_y * images[i].h[0] * images[i].v[0]);
     if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
   }
   plan->off_images = 0;
@@ -533,10 +876,26 @@ void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, u
   for (int i = 0; i < n; i++) {
     uint8_t* d = dst + plan.off_stream + plan.stream_off[i];
     std::memcpy(d, jpeg[i] + plan.scan_begin[i], plan.stream_len[i]);
-    const size_t padded = (plan.stream_len[i] + 3u + 8u) & ~(size_t)3;
+    const size_t padded = (plan.stream_len[i] + 3u + 32u) & ~(size_t)3;
     std::memset(d + plan.stream_len[i], 0, padded - plan.stream_len[i]);
   }
   std::memset(dst + plan.total - 16, 0, 16);
+}
+
+// Parallel path (every file of the batch without restart intervals): d_clean has the size of the upload, d_coef holds
+// n * coef_stride bytes (coef_stride = 128 * luminance blocks of the padded image) and is zeroed here.
+void vsf_launch_jpeg_gray_parallel(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, int n,
+                                   int max_luma_blocks, int width, int height, uint8_t* d_clean, int16_t* d_coef,
+                                   size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
+                                   int32_t* d_status, hipStream_t s) {
+  const DevImage* images = reinterpret_cast<const DevImage*>(d_blob + off_images);
+  const DevTables* tables = reinterpret_cast<const DevTables*>(d_blob + off_tables);
+  (void)hipMemsetAsync(d_coef, 0, (size_t)n * coef_stride, s);
+  hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n), dim3(kParThreads), 0, s, images, tables, d_blob + off_stream,
+                     reinterpret_cast<uint32_t*>(d_clean), d_coef, coef_stride, d_status);
+  hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n), dim3(64), 0, s, images, d_coef, coef_stride);
+  hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n), dim3(64), 0, s, images, tables, d_coef, coef_stride,
+                     width, height, d_dst, dst_image_stride, dst_pitch);
 }
 
 void vsf_launch_jpeg_gray(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, size_t total, int n,

@@ -365,6 +365,11 @@ struct vsf_ctx {
   size_t jp_cap[2] = {0, 0};
   hipEvent_t jp_copied[2] = {nullptr, nullptr};  // the last upload out of jp_host[i] has finished
   int jp_flip = 0;
+  uint8_t* jp_clean = nullptr;   // parallel decode: the de-stuffed streams (layout of the upload's stream part)
+  size_t jp_clean_cap = 0;
+  int16_t* jp_coef = nullptr;    // ... and the luminance coefficients of the batch
+  size_t jp_coef_cap = 0;
+  int jp_serial = -1;            // VSF_JPEG_SERIAL=1 forces the one-wave-per-image decoder (tests, comparison)
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -880,6 +885,8 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
   free_observe(ctx);
+  hipFree(ctx->jp_clean);
+  hipFree(ctx->jp_coef);
   for (int i = 0; i < 2; i++) {
     if (ctx->jp_host[i]) hipHostFree(ctx->jp_host[i]);
     hipFree(ctx->jp_dev[i]);
@@ -1270,8 +1277,38 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   vsf_jpeg_fill(plan, jpeg, n_images, ctx->jp_host[b]);  // the one pass over the compressed bytes on the host
   VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
   VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
-  vsf_launch_jpeg_gray(ctx->jp_dev[b], plan.off_images, plan.off_tables, plan.off_stream, plan.total, n_images, width, height,
-                       d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
+  if (ctx->jp_serial < 0) {
+    const char* env = std::getenv("VSF_JPEG_SERIAL");
+    ctx->jp_serial = (env && env[0] == '1') ? 1 : 0;
+  }
+  if (plan.parallel_ok && !ctx->jp_serial) {
+    // files without restart intervals (what a camera driver writes): self-synchronising parallel decode (k_jpeg.hip)
+    const size_t coef_stride = (size_t)plan.max_luma_blocks * 64 * sizeof(int16_t);
+    const size_t clean_need = plan.total - plan.off_stream + 64, coef_need = (size_t)n_images * coef_stride;
+    if (clean_need > ctx->jp_clean_cap || coef_need > ctx->jp_coef_cap) {
+      VSF_HIP(hipStreamSynchronize(ctx->stream));
+      if (clean_need > ctx->jp_clean_cap) {
+        hipFree(ctx->jp_clean);
+        ctx->jp_clean = nullptr;
+        ctx->jp_clean_cap = 0;
+        VSF_HIP(hipMalloc((void**)&ctx->jp_clean, clean_need + clean_need / 4));
+        ctx->jp_clean_cap = clean_need + clean_need / 4;
+      }
+      if (coef_need > ctx->jp_coef_cap) {
+        hipFree(ctx->jp_coef);
+        ctx->jp_coef = nullptr;
+        ctx->jp_coef_cap = 0;
+        VSF_HIP(hipMalloc((void**)&ctx->jp_coef, coef_need + coef_need / 4));
+        ctx->jp_coef_cap = coef_need + coef_need / 4;
+      }
+    }
+    vsf_launch_jpeg_gray_parallel(ctx->jp_dev[b], plan.off_images, plan.off_tables, plan.off_stream, n_images,
+                                  plan.max_luma_blocks, width, height, ctx->jp_clean, ctx->jp_coef, coef_stride, d_dst,
+                                  dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
+  } else {
+    vsf_launch_jpeg_gray(ctx->jp_dev[b], plan.off_images, plan.off_tables, plan.off_stream, plan.total, n_images, width,
+                         height, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
+  }
   VSF_HIP(hipGetLastError());
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)
