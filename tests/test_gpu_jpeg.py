@@ -148,3 +148,30 @@ def test_parallel_and_serial_decoders_agree(oracle, monkeypatch):
         c.close()
         for i in range(len(files)):
             np.testing.assert_array_equal(got[i, :, :328], want[i], err_msg="file %d, VSF_JPEG_SERIAL=%s" % (i, serial))
+
+
+def test_random_sizes_and_qualities(ctx, oracle):
+    """60 random files (1..300 px a side, gray / 4:4:4 / 4:2:2 / 4:2:0, qualities 1..100, plain and optimised tables, with
+    and without restart intervals), one call per file (every size needs its own call), against the pinned oracle."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(2026)
+    for case in range(60):
+        w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        kind = int(rng.integers(0, 4))
+        base = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        if rng.random() < 0.5:  # smooth content: short codes, long zero runs
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = ((np.sin(xx / 9.0) + np.cos(yy / 13.0)) * 60 + 128 + rng.integers(-4, 5, (h, w))).clip(0, 255).astype(np.uint8)
+        kw = dict(quality=int(rng.integers(1, 101)), optimize=bool(rng.integers(0, 2)))
+        if rng.random() < 0.3:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 20))
+        b = io.BytesIO()
+        if kind == 0:
+            PIL.fromarray(base, "L").save(b, "JPEG", **kw)
+        else:
+            rgb = np.stack([base, np.roll(base, 1, 0), 255 - base], 2)
+            PIL.fromarray(rgb, "RGB").save(b, "JPEG", subsampling=kind - 1, **kw)
+        f = b.getvalue()
+        got = _decode(ctx, [f], w, h)
+        np.testing.assert_array_equal(got[0, :, :w], oracle.jpeg_decode_gray(f), err_msg="case %d: %dx%d kind %d %r" % (case, w, h, kind, kw))

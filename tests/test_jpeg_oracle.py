@@ -52,3 +52,32 @@ def test_pillow_agrees_when_present(oracle):
         PIL.fromarray(img, "L").save(b, "JPEG", **kw)
         want = np.asarray(PIL.open(io.BytesIO(b.getvalue())))
         np.testing.assert_array_equal(oracle.jpeg_decode_gray(b.getvalue()), want)
+
+
+def test_random_files_against_pillow_when_present(oracle):
+    """The same 60 random files tests/test_gpu_jpeg.py feeds the GPU (sizes 1..300, gray / 4:4:4 / 4:2:2 / 4:2:0,
+    qualities 1..100, optimised tables, restart intervals): oracle == libjpeg-turbo (JCS_GRAYSCALE) on every one."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(2026)
+    for case in range(60):
+        w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        kind = int(rng.integers(0, 4))
+        base = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        if rng.random() < 0.5:
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = ((np.sin(xx / 9.0) + np.cos(yy / 13.0)) * 60 + 128 + rng.integers(-4, 5, (h, w))).clip(0, 255).astype(np.uint8)
+        kw = dict(quality=int(rng.integers(1, 101)), optimize=bool(rng.integers(0, 2)))
+        if rng.random() < 0.3:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 20))
+        b = io.BytesIO()
+        if kind == 0:
+            PIL.fromarray(base, "L").save(b, "JPEG", **kw)
+        else:
+            rgb = np.stack([base, np.roll(base, 1, 0), 255 - base], 2)
+            PIL.fromarray(rgb, "RGB").save(b, "JPEG", subsampling=kind - 1, **kw)
+        f = b.getvalue()
+        im = PIL.open(io.BytesIO(f))
+        im.draft("L", im.size)
+        want = np.asarray(im.convert("L") if im.mode != "L" else im)
+        np.testing.assert_array_equal(oracle.jpeg_decode_gray(f), want, err_msg="case %d: %dx%d kind %d %r" % (case, w, h, kind, kw))
