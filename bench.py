@@ -139,6 +139,69 @@ def cpu_baseline(width, height, nfeatures, seed):
                       % (n, width, height, nfeatures, cores, how, dt)}
 
 
+class JpegIngest:
+    """DecodeImage (slam_frontend_main.cc:98-109) on the device for `bench.py --ingest jpeg`: the frames of a step arrive
+    as baseline-JPEG files in HOST memory (the CompressedImage payloads; encoded here once with Pillow, quality 80, and
+    treated as bayer_rggb8 mosaics like the reference's camera topics) and are uploaded, decoded
+    (vsf_jpeg_decode_gray_batch) and demosaiced (vsf_bayer_bg_to_gray_batch_dev) on a context and stream of their own,
+    one step AHEAD of the extraction: two image buffers alternate, two events per buffer order the streams."""
+
+    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream):
+        import ctypes as C
+        import io
+
+        import numpy as np
+        import torch
+        from PIL import Image
+
+        from vision_slam_frontend_amd import capi
+        self.capi, self.C, self.torch = capi, C, torch
+        self.W, self.H, self.consumer = width, height, consumer_stream
+        self.files = []
+        for f in frames.reshape(-1, height, width):
+            bio = io.BytesIO()
+            Image.fromarray(f, "L").save(bio, "JPEG", quality=80)
+            self.files.append(np.frombuffer(bio.getvalue(), np.uint8))
+        self.n_files = len(self.files)
+        self.avg_kb = sum(len(f) for f in self.files) / self.n_files / 1024
+        self.ptrs = (C.c_void_p * self.n_files)(*[f.ctypes.data for f in self.files])
+        self.sizes = (C.c_size_t * self.n_files)(*[len(f) for f in self.files])
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ctx = capi.Context(capi.default_params(width, height, max_images=2, nfeatures=nfeatures), device=device_index)
+        self.ctx.set_stream(self.stream.cuda_stream)
+        self.d_mosaic = torch.empty((self.n_files, height, width), dtype=torch.uint8, device=dev)
+        self.d_in = [torch.empty((self.n_files // 2, 2, height, width), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+        self.issued = 0
+        self.current = 0
+        self._issue(0)
+
+    def _issue(self, slot):
+        C, W, H = self.C, self.W, self.H
+        if self.issued >= 2:
+            self.stream.wait_event(self.consumed[slot])
+        st = self.capi.lib().vsf_jpeg_decode_gray_batch(self.ctx._h, C.cast(self.ptrs, C.c_void_p),
+                                                        C.cast(self.sizes, C.c_void_p), self.n_files, W, H,
+                                                        C.c_void_p(self.d_mosaic.data_ptr()), W * H, W)
+        if st != self.capi.VSF_OK:
+            raise self.capi.VsfError(st, "vsf_jpeg_decode_gray_batch")
+        self.ctx.bayer_bg_to_gray_batch_dev(self.d_mosaic.data_ptr(), self.n_files, W, H, W * H, W,
+                                            self.d_in[slot].data_ptr(), W * H, W)
+        self.ready[slot].record(self.stream)
+        self.issued += 1
+
+    def next_batch(self):
+        slot = (self.issued - 1) & 1
+        self.consumer.wait_event(self.ready[slot])
+        self._issue(slot ^ 1)
+        self.current = slot
+        return self.d_in[slot]
+
+    def release(self):
+        self.consumed[self.current].record(self.consumer)
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,62 +286,19 @@ def main() -> int:
     ctx.set_pipeline(args.pipeline)  # (legal here: the synthetic stream is resident in HBM before every call)
     torch.cuda.synchronize()
 
-    step_input = lambda: d_img  # noqa: E731
+    ingest = None
     if args.ingest == "jpeg":
-        # DecodeImage (slam_frontend_main.cc:98-109) on the device, on a context and stream of its own, one step AHEAD of
-        # the extraction: files (host) -> pinned staging -> HBM -> Huffman decode + IDCT -> Bayer demosaic + gray.  The
-        # frames are treated as bayer_rggb8 mosaics, as the reference's camera topics are.
-        import ctypes as C
-        import io
+        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream)
 
-        from PIL import Image
-        files = []
-        for f in frames.reshape(-1, H, W):
-            bio = io.BytesIO()
-            Image.fromarray(f, "L").save(bio, "JPEG", quality=80)
-            files.append(np.frombuffer(bio.getvalue(), np.uint8))
-        n_files = len(files)
-        ptrs = (C.c_void_p * n_files)(*[f.ctypes.data for f in files])
-        sizes = (C.c_size_t * n_files)(*[len(f) for f in files])
-        ingest_stream = torch.cuda.Stream(device=dev)
-        ictx = capi.Context(capi.default_params(W, H, max_images=2, nfeatures=NF), device=local_rank)
-        ictx.set_stream(ingest_stream.cuda_stream)
-        d_mosaic = torch.empty((2 * B, H, W), dtype=torch.uint8, device=dev)
-        d_in = [torch.empty((B, 2, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
-        ready = [torch.cuda.Event() for _ in range(2)]
-        consumed = [torch.cuda.Event() for _ in range(2)]
-        state = {"k": 0}
-
-        def ingest(slot):
-            if state["k"] >= 2:
-                ingest_stream.wait_event(consumed[slot])  # the step that read this buffer has finished with it
-            st = capi.lib().vsf_jpeg_decode_gray_batch(ictx._h, C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), n_files,
-                                                       W, H, C.c_void_p(d_mosaic.data_ptr()), W * H, W)
-            assert st == capi.VSF_OK, st
-            ictx.bayer_bg_to_gray_batch_dev(d_mosaic.data_ptr(), n_files, W, H, W * H, W, d_in[slot].data_ptr(), W * H, W)
-            ready[slot].record(ingest_stream)
-            state["k"] += 1
-
-        ingest(0)
-
-        def step_input():
-            slot = (state["k"] - 1) & 1
-            stream.wait_event(ready[slot])
-            ingest(slot ^ 1)  # the NEXT step's files, beside this step's extraction
-            state["cur"] = slot
-            return d_in[slot]
-
-        _plain_step = sf.step
-
-        def _step_and_release(img):
-            _plain_step(img)
-            consumed[state["cur"]].record(stream)
-
-        sf.step = _step_and_release
-        avg_kb = sum(len(f) for f in files) / n_files / 1024
+    def run_step():
+        if ingest is None:
+            sf.step(d_img)
+        else:
+            sf.step(ingest.next_batch())   # waits (on the GPU) for this step's decode, starts the next step's
+            ingest.release()               # the buffer may be overwritten once this step's extraction has read it
 
     for _ in range(args.warmup):
-        sf.step(step_input())
+        run_step()
     sf.drain()
     for c in sf.contexts():
         c.sync(allow_capacity=True)
@@ -288,7 +308,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sf.step(step_input())
+        run_step()
     sf.drain()  # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -366,7 +386,8 @@ def main() -> int:
                        "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "scene": args.scene,
                        "ingest": "frames resident in HBM" if args.ingest == "hbm" else
                                  "per step: %d baseline-JPEG files of %.0f KB (quality 80) from host memory -> upload -> "
-                                 "vsf_jpeg_decode_gray_batch -> Bayer->gray, one step ahead on its own stream" % (n_files, avg_kb),
+                                 "vsf_jpeg_decode_gray_batch -> Bayer->gray, one step ahead on its own stream"
+                                 % (ingest.n_files, ingest.avg_kb),
                        "parallelism": "frames sharded over %d GPU(s)%s" %
                                       (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
                                               "(RCCL)" if world > 1 else ""),
