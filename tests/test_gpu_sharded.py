@@ -51,7 +51,7 @@ def _run(frames, frames_per_rank, rank, world, overlap=True):
     return sf, local, ctx
 
 
-def _worker(rank: int, world: int, port: int, frames_path: str, out_path: str):
+def _worker(rank: int, world: int, port: int, frames_path: str, out_path: str, frames_per_rank: int = B):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -61,7 +61,7 @@ def _worker(rank: int, world: int, port: int, frames_path: str, out_path: str):
     try:
         torch.cuda.set_device(0)
         frames = np.load(frames_path)
-        sf, _, ctx = _run(frames, B, rank, world)
+        sf, _, ctx = _run(frames, frames_per_rank, rank, world)
         if rank == 0:
             assert [c[0] for c in sf.completed] == list(range(STEPS))
             np.savez(out_path, **{"s%d_r%d" % (st, r): pl.cpu().numpy() for st, per in sf.completed
@@ -161,3 +161,36 @@ def test_collectives_on_rccl_in_a_world_of_one(tmp_path):
         assert len(got) >= total and got[:total].tobytes() == want[:total].tobytes(), "payload of step %d" % s
     want_f, want_m = vd.assemble_outputs(local, 1, WORLD * B, WINDOW)
     assert sum(len(v) for v in want_f.values()) > 200 and sum(len(v) for v in want_m.values()) > 40
+
+
+def test_three_ranks_equal_one_process(tmp_path):
+    """World of three, two frames per rank, window 2 (= the whole block of a rank): the middle rank has its predecessors on
+    rank 0 and its successors on rank 2, every temporal pair of a rank's first frame lives on another rank, rank 0 fetches
+    its predecessors from rank 2's tail of the PREVIOUS step, and the NaN threshold (quirk Q3) crosses from rank 1's
+    first to its second frame while the finite one after it crosses into rank 2."""
+    import torch.multiprocessing as mp
+
+    from vision_slam_frontend_amd import distributed as vd
+    from vision_slam_frontend_amd import synth
+
+    world, per = 3, 2
+    n = world * per * STEPS
+    frames = synth.stereo_stream(n, W_IMG, H_IMG, n_objects=400)
+    frames[per, 1] = 128  # rank 1's first frame of step 0 has no stereo match: its second frame meets the NaN threshold
+    frames_path, out_path = str(tmp_path / "frames.npy"), str(tmp_path / "gathered.npz")
+    np.save(frames_path, frames)
+    sf1, local, ctx1 = _run(frames, world * per, 0, 1)
+    want_f, want_m = vd.assemble_outputs(local, 1, world * per, WINDOW)
+    ctx1.close()
+    mp.spawn(_worker, args=(world, _free_port(), frames_path, out_path, per), nprocs=world, join=True)
+    z = np.load(out_path)
+    completed = [(s, [z["s%d_r%d" % (s, r)] for r in range(world)]) for s in range(STEPS)]
+    got_f, got_m = vd.assemble_outputs(completed, world, per, WINDOW)
+    assert sorted(got_f) == sorted(want_f) == list(range(n)) and sorted(got_m) == sorted(want_m)
+    for g in range(n):
+        assert got_f[g].tobytes() == want_f[g].tobytes(), "VisionFeature records of global frame %d" % g
+    for key in want_m:
+        assert got_m[key].tobytes() == want_m[key].tobytes(), "FeatureMatch records of factor %s" % (key,)
+    sizes = [len(want_f[g]) for g in range(n)]
+    assert sizes[per] == 0 and sizes[per + 1] == 0 and sizes[per + 2] > 10
+    assert (per * 3 - 2, per * 3) in want_m and (per * 3 - 1, per * 3) in want_m  # rank 0, step 1 <- rank 2, step 0
