@@ -72,6 +72,21 @@ __device__ __forceinline__ v2s pick2(const Row3& r) {
   }
 }
 
+// Bytes B and B+2 of the same run: the pixel pairs the score works on are (x, x+2) and (x+1, x+3), so that the second
+// pair's circle pixel at column offset dx IS the first pair's at dx + 1 -- four of the 34 picks of a lane-row coincide
+// (the three-pixel rows y +- 3 of the circle) and are computed once.
+template <int B>
+__device__ __forceinline__ v2s pick2s(const Row3& r) {
+  static_assert(B >= 0 && B + 2 <= 11, "byte range");
+  if constexpr (B + 2 <= 7) {
+    constexpr uint32_t sel = (uint32_t)B | 0x0C000C00u | ((uint32_t)(B + 2) << 16);
+    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.d, r.p, sel));
+  } else {
+    constexpr uint32_t sel = (uint32_t)(B - 4) | 0x0C000C00u | ((uint32_t)(B - 2) << 16);
+    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.n, r.d, sel));
+  }
+}
+
 __device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 // Three-input packed minimum / maximum of values 0..255 held in 16-bit halves (see score_pair).
@@ -86,31 +101,32 @@ __device__ __forceinline__ v2s vmax3(v2s a, v2s b, v2s c) {
   return r;
 }
 
-// Scores of the two pixels at bytes 4+J0, 5+J0 of the centre row R3; R0..R6 are rows y-3..y+3.
+// Scores of the two pixels at bytes 4+J0, 6+J0 of the centre row R3 (J0 = 0: the lane's pixels 0 and 2, J0 = 1: pixels 1
+// and 3); R0..R6 are rows y-3..y+3.
 // Returns the two scores (0 = not a corner; a marker 1 when nms == 0) in the two 16-bit halves.
 template <int J0, bool NMS>
 __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3,
                                           const Row3& R4, const Row3& R5, const Row3& R6, v2s tt) {
-  const v2s v = pick2<4 + J0>(R3);
+  const v2s v = pick2s<4 + J0>(R3);
   v2s d[16];  // circle pixels p_k; min / max commute with the subtraction of v, which is applied once at the end
   // Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
   // (-3,0)(-3,1)(-2,2)(-1,3); window row = R[3 + dy].
-  d[0] = pick2<4 + J0 + 0>(R6);
-  d[1] = pick2<4 + J0 + 1>(R6);
-  d[2] = pick2<4 + J0 + 2>(R5);
-  d[3] = pick2<4 + J0 + 3>(R4);
-  d[4] = pick2<4 + J0 + 3>(R3);
-  d[5] = pick2<4 + J0 + 3>(R2);
-  d[6] = pick2<4 + J0 + 2>(R1);
-  d[7] = pick2<4 + J0 + 1>(R0);
-  d[8] = pick2<4 + J0 + 0>(R0);
-  d[9] = pick2<4 + J0 - 1>(R0);
-  d[10] = pick2<4 + J0 - 2>(R1);
-  d[11] = pick2<4 + J0 - 3>(R2);
-  d[12] = pick2<4 + J0 - 3>(R3);
-  d[13] = pick2<4 + J0 - 3>(R4);
-  d[14] = pick2<4 + J0 - 2>(R5);
-  d[15] = pick2<4 + J0 - 1>(R6);
+  d[0] = pick2s<4 + J0 + 0>(R6);
+  d[1] = pick2s<4 + J0 + 1>(R6);
+  d[2] = pick2s<4 + J0 + 2>(R5);
+  d[3] = pick2s<4 + J0 + 3>(R4);
+  d[4] = pick2s<4 + J0 + 3>(R3);
+  d[5] = pick2s<4 + J0 + 3>(R2);
+  d[6] = pick2s<4 + J0 + 2>(R1);
+  d[7] = pick2s<4 + J0 + 1>(R0);
+  d[8] = pick2s<4 + J0 + 0>(R0);
+  d[9] = pick2s<4 + J0 - 1>(R0);
+  d[10] = pick2s<4 + J0 - 2>(R1);
+  d[11] = pick2s<4 + J0 - 3>(R2);
+  d[12] = pick2s<4 + J0 - 3>(R3);
+  d[13] = pick2s<4 + J0 - 3>(R4);
+  d[14] = pick2s<4 + J0 - 2>(R5);
+  d[15] = pick2s<4 + J0 - 1>(R6);
   // Arc k = d[k .. k+8] (indices mod 16).  Arcs 2j and 2j+1 share the eight pixels C = d[2j+1 .. 2j+8]:
   //   max(min(d[2j], C), min(C, d[2j+9])) = min(C, max(d[2j], d[2j+9]))                       (distributive lattice)
   // and C is four pixel pairs E_i = min(d[2i+1], d[2i+2]), i = j .. j+3, i.e. two quads F_i = min(E_i, E_{i+1}):
@@ -261,9 +277,9 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
     // a 9-arc contains circle pixel 0 (row sy+3) or 8 (row sy-3), both in the centre pixel's column
     const uint32_t far = max(__builtin_amdgcn_sad_u8(R0.d, R3.d, 0u), __builtin_amdgcn_sad_u8(R6.d, R3.d, 0u));
     if (__any(row_ok && smask != 0 && far > (uint32_t)t)) {
-      const v2s r01 = score_pair<0, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);
-      const v2s r23 = score_pair<2, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);
-      S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r23), __builtin_bit_cast(uint32_t, r01), 0x06040200u);
+      const v2s r02 = score_pair<0, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);  // pixels 0 and 2
+      const v2s r13 = score_pair<1, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);  // pixels 1 and 3
+      S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r13), __builtin_bit_cast(uint32_t, r02), 0x06020400u);
       S &= row_ok ? smask : 0u;
     }
     S_dn = make_score_row(S);
