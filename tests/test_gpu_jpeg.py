@@ -45,7 +45,8 @@ def test_equals_libjpeg_turbo(ctx, name):
 
 
 def test_batch_of_mixed_tables_equals_the_oracle(ctx, oracle):
-    """One call, many files with DIFFERENT quantisation / Huffman tables, sampling factors and restart intervals."""
+    """One call, many files with DIFFERENT quantisation / Huffman tables, sampling factors and restart intervals: the
+    files without restart intervals go through the parallel decoder, the others through the serial one, in one batch."""
     PIL = pytest.importorskip("PIL.Image")
     import io
     from vision_slam_frontend_amd import synth

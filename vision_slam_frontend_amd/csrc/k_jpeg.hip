@@ -213,7 +213,9 @@ __device__ __forceinline__ void idct8(const int32_t d[8], int32_t r[8]) {
   r[7] = tmp10 - tmp3;
 }
 
+// `index`: the images (positions in `images` and in the destination) this launch decodes, one per workgroup
 __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restrict__ images,
+                                                        const uint32_t* __restrict__ index,
                                                         const DevTables* __restrict__ tables,
                                                         const uint8_t* __restrict__ stream, uint32_t stream_total,
                                                         int width, int height,
@@ -224,10 +226,11 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
   __shared__ __attribute__((aligned(16))) int32_t s_ws[kGroupBlocks][64];
   __shared__ int32_t s_dest[kGroupBlocks];  // y0 << 16 | x0
   const int lane = threadIdx.x;
-  const DevImage& im = images[blockIdx.x];
+  const uint32_t image = index[blockIdx.x];
+  const DevImage& im = images[image];
   const DevTables* tab = tables + im.tables;
   s_qt[lane] = tab->qt_luma[lane];
-  uint8_t* out = dst + (size_t)blockIdx.x * dst_image_stride;
+  uint8_t* out = dst + (size_t)image * dst_image_stride;
   // geometry and decoder state: wave-uniform (see BitReader)
   const int ncomp = im.ncomp, restart_interval = im.restart_interval, mcus_x = im.mcus_x;
   const int nmcu = mcus_x * im.mcus_y;
@@ -442,6 +445,7 @@ __device__ __forceinline__ bool par_symbol(ParCtx& cx, uint32_t& q, int& k, cons
 }
 
 __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevImage* __restrict__ images,
+                                                                       const uint32_t* __restrict__ index,
                                                                        const DevTables* __restrict__ tables,
                                                                        const uint8_t* __restrict__ stream,
                                                                        uint32_t* __restrict__ clean_all,
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   __shared__ uint32_t s_marker, s_total, s_changed;
   __shared__ uint8_t s_zz[64];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const DevImage& im = images[blockIdx.x];
+  const DevImage& im = images[index[blockIdx.x]];  // (the coefficient buffer is indexed by the launch's own numbering)
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + im.tables);
     uint32_t* d = reinterpret_cast<uint32_t*>(&s_tab);
@@ -606,9 +610,10 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
 }
 
 // DC differences -> DC values of the luminance blocks (decode order), one wave per image
-__global__ __launch_bounds__(64) void jpeg_dc_scan_kernel(const DevImage* __restrict__ images, int16_t* __restrict__ coef_all,
+__global__ __launch_bounds__(64) void jpeg_dc_scan_kernel(const DevImage* __restrict__ images,
+                                                          const uint32_t* __restrict__ index, int16_t* __restrict__ coef_all,
                                                           size_t coef_stride) {
-  const DevImage& im = images[blockIdx.x];
+  const DevImage& im = images[index[blockIdx.x]];
   const int nlb = im.mcus_x * im.mcus_y * im.h[0] * im.v[0];
   int16_t* coef = coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t));
   const int lane = threadIdx.x, per = (nlb + 63) / 64;
@@ -630,12 +635,14 @@ __global__ __launch_bounds__(64) void jpeg_dc_scan_kernel(const DevImage* __rest
 
 // dequantisation + IDCT + range limit of 8 luminance blocks per wave, from the coefficient buffer
 __global__ __launch_bounds__(64) void jpeg_idct_kernel(const DevImage* __restrict__ images,
+                                                        const uint32_t* __restrict__ index,
                                                         const DevTables* __restrict__ tables,
                                                         const int16_t* __restrict__ coef_all, size_t coef_stride, int width,
                                                         int height, uint8_t* __restrict__ dst, size_t dst_image_stride,
                                                         int dst_pitch) {
   __shared__ int32_t s_ws[8][64];
-  const DevImage& im = images[blockIdx.y];
+  const uint32_t image = index[blockIdx.y];
+  const DevImage& im = images[image];
   const int lum_w = im.h[0], lum = im.h[0] * im.v[0];
   const int nlb = im.mcus_x * im.mcus_y * lum;
   const int lane = threadIdx.x, b = blockIdx.x * 8 + (lane >> 3), i = lane & 7;
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(const DevImage* __restric
       uint8_t px[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) px[k] = range_limit((r[k] + (1 << 17)) >> 18);
-      uint8_t* row = dst + (size_t)blockIdx.y * dst_image_stride + (size_t)y * dst_pitch + x0;
+      uint8_t* row = dst + (size_t)image * dst_image_stride + (size_t)y * dst_pitch + x0;
       if (x0 + 8 <= width) {
         uint32_t lo, hi;
         memcpy(&lo, px, 4);
@@ -828,11 +835,11 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
 // Host half of vsf_jpeg_decode_gray_batch, step 1: parses every file and lays out ONE upload -- image descriptors,
 // distinct table sets (consecutive frames of a camera share theirs: compared with the previous file's first), packed
 // entropy-coded segments -- without touching the segments themselves.
-vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height, VsfJpegPlan* plan) {
+vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height, bool force_serial,
+                         VsfJpegPlan* plan) {
   std::vector<DevImage> images((size_t)n);
   std::vector<DevTables> tables;
   plan->scan_begin.assign((size_t)n, 0);
-  plan->parallel_ok = true;
   plan->max_luma_blocks = 0;
   size_t stream_bytes = 0;
   for (int i = 0; i < n; i++) {
@@ -850,16 +857,24 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
     images[i].stream_off = (uint32_t)stream_bytes;
     images[i].stream_len = (uint32_t)(nbytes[i] - plan->scan_begin[i]);
     stream_bytes += (images[i].stream_len + 3u + 32u) & ~(size_t)3;
-    if (images[i].restart_interval != 0) plan->parallel_ok = false;
     plan->max_luma_blocks = std::max(plan->max_luma_blocks, images[i].mcus_x * images[i].mcus_y * images[i].h[0] * images[i].v[0]);
     if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
   }
+  // which decoder takes which file: those without restart intervals first
+  std::vector<uint32_t> index;
+  for (int pass = 0; pass < 2; pass++)
+    for (int i = 0; i < n; i++)
+      if ((images[i].restart_interval == 0 && !force_serial) == (pass == 0)) index.push_back((uint32_t)i);
+  plan->n_par = 0;
+  for (int i = 0; i < n; i++) plan->n_par += images[i].restart_interval == 0 && !force_serial;
   plan->off_images = 0;
-  plan->off_tables = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
+  plan->off_index = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
+  plan->off_tables = (plan->off_index + index.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
   plan->off_stream = (plan->off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
   plan->total = plan->off_stream + stream_bytes + 16;
   plan->head.assign(plan->off_stream, 0);
   std::memcpy(plan->head.data() + plan->off_images, images.data(), images.size() * sizeof(DevImage));
+  std::memcpy(plan->head.data() + plan->off_index, index.data(), index.size() * sizeof(uint32_t));
   std::memcpy(plan->head.data() + plan->off_tables, tables.data(), tables.size() * sizeof(DevTables));
   plan->stream_off.resize((size_t)n);
   plan->stream_len.resize((size_t)n);
@@ -882,27 +897,27 @@ void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, u
   std::memset(dst + plan.total - 16, 0, 16);
 }
 
-// Parallel path (every file of the batch without restart intervals): d_clean has the size of the upload, d_coef holds
-// n * coef_stride bytes (coef_stride = 128 * luminance blocks of the padded image) and is zeroed here.
-void vsf_launch_jpeg_gray_parallel(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, int n,
-                                   int max_luma_blocks, int width, int height, uint8_t* d_clean, int16_t* d_coef,
-                                   size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
-                                   int32_t* d_status, hipStream_t s) {
+// Both decoders over one upload: the files without restart intervals (n_par of them, listed first in the index array
+// at off_index) take the self-synchronising parallel decode, the others the one-wave-per-image decode.  d_clean has the
+// size of the upload's stream part, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
+// largest padded image) and is zeroed here.
+void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_stream,
+                            size_t total, int n_par, int n_ser, int max_luma_blocks, int width, int height, uint8_t* d_clean,
+                            int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
+                            int32_t* d_status, hipStream_t s) {
   const DevImage* images = reinterpret_cast<const DevImage*>(d_blob + off_images);
   const DevTables* tables = reinterpret_cast<const DevTables*>(d_blob + off_tables);
-  (void)hipMemsetAsync(d_coef, 0, (size_t)n * coef_stride, s);
-  hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n), dim3(kParThreads), 0, s, images, tables, d_blob + off_stream,
-                     reinterpret_cast<uint32_t*>(d_clean), d_coef, coef_stride, d_status);
-  hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n), dim3(64), 0, s, images, d_coef, coef_stride);
-  hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n), dim3(64), 0, s, images, tables, d_coef, coef_stride,
-                     width, height, d_dst, dst_image_stride, dst_pitch);
-}
-
-void vsf_launch_jpeg_gray(const uint8_t* d_blob, size_t off_images, size_t off_tables, size_t off_stream, size_t total, int n,
-                          int width, int height, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
-                          int32_t* d_status, hipStream_t s) {
-  hipLaunchKernelGGL(jpeg_gray_kernel, dim3(n), dim3(64), 0, s, reinterpret_cast<const DevImage*>(d_blob + off_images),
-                     reinterpret_cast<const DevTables*>(d_blob + off_tables), d_blob + off_stream,
-                     (uint32_t)((total - off_stream) & ~(size_t)3), width, height, d_dst, dst_image_stride, dst_pitch,
-                     d_status);
+  const uint32_t* index = reinterpret_cast<const uint32_t*>(d_blob + off_index);
+  if (n_par > 0) {
+    (void)hipMemsetAsync(d_coef, 0, (size_t)n_par * coef_stride, s);
+    hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n_par), dim3(kParThreads), 0, s, images, index, tables, d_blob + off_stream,
+                       reinterpret_cast<uint32_t*>(d_clean), d_coef, coef_stride, d_status);
+    hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n_par), dim3(64), 0, s, images, index, d_coef, coef_stride);
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n_par), dim3(64), 0, s, images, index, tables, d_coef,
+                       coef_stride, width, height, d_dst, dst_image_stride, dst_pitch);
+  }
+  if (n_ser > 0)
+    hipLaunchKernelGGL(jpeg_gray_kernel, dim3(n_ser), dim3(64), 0, s, images, index + n_par, tables, d_blob + off_stream,
+                       (uint32_t)((total - off_stream) & ~(size_t)3), width, height, d_dst, dst_image_stride, dst_pitch,
+                       d_status);
 }

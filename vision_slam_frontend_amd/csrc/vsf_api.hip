@@ -1253,8 +1253,12 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   for (int i = 0; i < n_images; i++)
     if (!jpeg[i] || nbytes[i] < 4 || nbytes[i] > 0x40000000u) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
+  if (ctx->jp_serial < 0) {
+    const char* env = std::getenv("VSF_JPEG_SERIAL");
+    ctx->jp_serial = (env && env[0] == '1') ? 1 : 0;
+  }
   VsfJpegPlan plan;
-  vsf_status st = vsf_jpeg_plan(jpeg, nbytes, n_images, width, height, &plan);
+  vsf_status st = vsf_jpeg_plan(jpeg, nbytes, n_images, width, height, ctx->jp_serial != 0, &plan);
   if (st != VSF_OK) return st;
   const int b = ctx->jp_flip;
   ctx->jp_flip ^= 1;
@@ -1274,17 +1278,11 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
     // decode is what may still be running, out of the OTHER buffer)
     VSF_HIP(hipEventSynchronize(ctx->jp_copied[b]));
   }
-  vsf_jpeg_fill(plan, jpeg, n_images, ctx->jp_host[b]);  // the one pass over the compressed bytes on the host
-  VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
-  VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
-  if (ctx->jp_serial < 0) {
-    const char* env = std::getenv("VSF_JPEG_SERIAL");
-    ctx->jp_serial = (env && env[0] == '1') ? 1 : 0;
-  }
-  if (plan.parallel_ok && !ctx->jp_serial) {
-    // files without restart intervals (what a camera driver writes): self-synchronising parallel decode (k_jpeg.hip)
-    const size_t coef_stride = (size_t)plan.max_luma_blocks * 64 * sizeof(int16_t);
-    const size_t clean_need = plan.total - plan.off_stream + 64, coef_need = (size_t)n_images * coef_stride;
+  // files without restart intervals (what a camera driver writes): self-synchronising parallel decode; it needs the
+  // de-stuffed streams and the luminance coefficients in HBM
+  const size_t coef_stride = (size_t)plan.max_luma_blocks * 64 * sizeof(int16_t);
+  if (plan.n_par > 0) {
+    const size_t clean_need = plan.total - plan.off_stream + 64, coef_need = (size_t)plan.n_par * coef_stride;
     if (clean_need > ctx->jp_clean_cap || coef_need > ctx->jp_coef_cap) {
       VSF_HIP(hipStreamSynchronize(ctx->stream));
       if (clean_need > ctx->jp_clean_cap) {
@@ -1302,13 +1300,13 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
         ctx->jp_coef_cap = coef_need + coef_need / 4;
       }
     }
-    vsf_launch_jpeg_gray_parallel(ctx->jp_dev[b], plan.off_images, plan.off_tables, plan.off_stream, n_images,
-                                  plan.max_luma_blocks, width, height, ctx->jp_clean, ctx->jp_coef, coef_stride, d_dst,
-                                  dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
-  } else {
-    vsf_launch_jpeg_gray(ctx->jp_dev[b], plan.off_images, plan.off_tables, plan.off_stream, plan.total, n_images, width,
-                         height, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
   }
+  vsf_jpeg_fill(plan, jpeg, n_images, ctx->jp_host[b]);  // the one pass over the compressed bytes on the host
+  VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
+  VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
+  vsf_launch_jpeg_decode(ctx->jp_dev[b], plan.off_images, plan.off_index, plan.off_tables, plan.off_stream, plan.total,
+                         plan.n_par, n_images - plan.n_par, plan.max_luma_blocks, width, height, ctx->jp_clean, ctx->jp_coef,
+                         coef_stride, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
   VSF_HIP(hipGetLastError());
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)
