@@ -176,3 +176,16 @@ def test_random_sizes_and_qualities(ctx, oracle):
         f = b.getvalue()
         got = _decode(ctx, [f], w, h)
         np.testing.assert_array_equal(got[0, :, :w], oracle.jpeg_decode_gray(f), err_msg="case %d: %dx%d kind %d %r" % (case, w, h, kind, kw))
+
+
+def test_crafted_huffman_tables(ctx, oracle):
+    """AC tables with scores of long codes (tests/jpeg_craft.py): 80 distinct 9-bit prefixes of 10-bit codes are more than
+    the parallel decoder's second-level tables hold, so that file must fall to the one-wave decoder; the 13- and 16-bit
+    tables stay on the parallel path and live in its second-level lookups.  All must equal the pinned oracle."""
+    from test_jpeg_oracle import crafted_files
+    for name, data in crafted_files():
+        want = oracle.jpeg_decode_gray(data)
+        h, w = want.shape
+        got = _decode(ctx, [data, data], w, h)
+        np.testing.assert_array_equal(got[0, :, :w], want, err_msg=name)
+        np.testing.assert_array_equal(got[1, :, :w], want, err_msg=name)

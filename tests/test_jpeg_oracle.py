@@ -81,3 +81,25 @@ def test_random_files_against_pillow_when_present(oracle):
         im.draft("L", im.size)
         want = np.asarray(im.convert("L") if im.mode != "L" else im)
         np.testing.assert_array_equal(oracle.jpeg_decode_gray(f), want, err_msg="case %d: %dx%d kind %d %r" % (case, w, h, kind, kw))
+
+
+def crafted_files():
+    """Files libjpeg's encoder would never write (tests/jpeg_craft.py): AC tables with 160 codes of 10 bits (80 distinct
+    9-bit prefixes) or of 16 bits, coefficients chosen at random."""
+    import jpeg_craft as jc
+    rng = np.random.default_rng(99)
+    out = []
+    for name, long_len, by, bx in (("ac_10bit_codes", 10, 6, 9), ("ac_16bit_codes", 16, 5, 7), ("ac_13bit_codes", 13, 30, 40)):
+        coef = jc.random_coefficients(rng, by, bx)
+        qt = rng.integers(1, 12, 64)
+        out.append((name, jc.write_gray_jpeg(coef, qt, (jc.STD_DC_BITS, jc.STD_DC_VALS), jc.flat_ac_table(long_len=long_len))))
+    return out
+
+
+def test_crafted_huffman_tables_against_pillow(oracle):
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    for name, data in crafted_files():
+        want = np.asarray(PIL.open(io.BytesIO(data)))
+        assert want.ndim == 2 and want.std() > 5, name
+        np.testing.assert_array_equal(oracle.jpeg_decode_gray(data), want, err_msg=name)

@@ -6,10 +6,10 @@
 // JDCT_ISLOW): ITU-T T.81 baseline entropy decoding and, for the luminance component only, libjpeg's jidctint.c inverse
 // DCT (13-bit constants, PASS1_BITS = 2, exact 32-bit integers) + range limit; chroma is parsed and dropped.
 //
-// Two decoders.  Files without restart intervals (what a camera driver writes) take the PARALLEL one further down:
-// 256 threads per image decode 256 segments of the stream speculatively and iterate until their states agree
-// (jpeg_par_decode_kernel).  Files with restart intervals -- and everything under VSF_JPEG_SERIAL=1 -- take the one
-// described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
+// Two decoders, chosen per file.  Files without restart intervals (what a camera driver writes) take the PARALLEL one
+// further down: 256 threads per image decode 256 segments of the stream speculatively and iterate until their states
+// agree (jpeg_par_decode_kernel).  Files with restart intervals, files whose Huffman tables need more second-level
+// lookup tables than DevHuff holds -- and everything under VSF_JPEG_SERIAL=1 -- take the one described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
 // codes (wave-uniform code: state in SGPRs, stream words and 9-bit lookahead tables through scalar loads, T.81 F.2.2.3
 // for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops chroma blocks and parks up to 16 luminance
 // blocks of coefficients in LDS; then the 64 lanes dequantise and run the two IDCT passes (lane = block x column, then
@@ -33,15 +33,20 @@ namespace {
 constexpr int kLookBits = 9;
 constexpr int kMaxSlots = 6;     // distinct Huffman tables one image may use (3 components x DC / AC)
 constexpr int kGroupBlocks = 16; // luminance blocks parked in LDS between two IDCT phases
+constexpr int kSubBits = 16 - kLookBits;  // bits of a code beyond the first lookup
+constexpr int kMaxSub = 12;      // second-level tables per Huffman table (the Annex K tables need 5 or 6)
+constexpr uint32_t kLongCode = 0x8000u;
+constexpr uint16_t kNoCode = 16 << 8;  // a prefix no code starts with: 16 bits, symbol 0 (corrupt streams only)
 
-struct DevHuff {                 // one Huffman table as the kernel reads it (1424 bytes)
-  uint16_t look[1 << kLookBits]; // 9-bit prefix -> (code length << 8 | symbol), 0 = longer than 9 bits
+struct DevHuff {                 // one Huffman table as the kernels read it
+  uint16_t look[1 << kLookBits]; // 9-bit prefix -> (code length << 8 | symbol), or kLongCode | second-level table
   int32_t maxcode[18];           // T.81 F.2.2.3 (maxcode[17] = INT_MAX)
   int32_t valoff[17];            // VALPTR - MINCODE
   uint8_t vals[256];
-  uint32_t pad;
+  uint32_t nsub;                 // second-level tables in use; > kMaxSub: they do not fit (one-wave decoder only)
+  uint16_t sub[kMaxSub][1 << kSubBits];  // the next 7 bits -> (code length << 8 | symbol)
 };
-static_assert(sizeof(DevHuff) == 1024 + 72 + 68 + 256 + 4, "DevHuff layout");
+static_assert(sizeof(DevHuff) == 1024 + 72 + 68 + 256 + 4 + kMaxSub * 256, "DevHuff layout");
 
 struct DevTables {               // one distinct table set
   DevHuff huff[kMaxSlots];
@@ -55,6 +60,7 @@ struct DevImage {
   int32_t ncomp, restart_interval, mcus_x, mcus_y;
   int32_t h[3], v[3];            // blocks per MCU of each component (1 x 1 for a single-component scan)
   int32_t dc_slot[3], ac_slot[3];
+  int32_t par_ok;                // every Huffman table in use fits its second-level tables (the parallel decoder's need)
 };
 
 const uint8_t kZigzagHost[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -126,7 +132,7 @@ struct BitReader {
   __device__ __forceinline__ int decode(const DevHuff* h) {
     const uint32_t p = peek(kLookBits);
     const uint32_t e = (reinterpret_cast<const uint32_t*>(h->look)[p >> 1] >> (16u * (p & 1u))) & 0xFFFFu;
-    if (e) {
+    if (!(e & kLongCode)) {
       drop((int)(e >> 8));
       return (int)(e & 255u);
     }
@@ -348,100 +354,162 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 // A Huffman-coded stream has no markers to split it at, but it is SELF-SYNCHRONISING: a decoder started at a wrong bit
 // soon falls into step with the true one (Klein & Wiseman; for JPEG on GPUs: Weissenberger & Schmidt 2018/2021).  So a
 // 256-thread workgroup per image
-//   1. removes the byte stuffing in parallel (FF00 -> FF, stop at the first marker) into a "clean" stream of big-endian
-//      dwords, in which a position is ONE integer (a bit index);
-//   2. cuts the clean stream into 256 segments.  Thread t decodes segment t from an ASSUMED state (bit t * B, first block of
-//      an MCU, DC next) up to the first symbol boundary past its end and records that end state (bit, block in MCU, zigzag
-//      index).  Thread 0's assumption is true.  Then, round after round, every thread restarts from its predecessor's end
-//      state whenever that state changed, until no end state changes: then start[t] == end[t-1] for all t, and by
-//      induction from thread 0 every start is the TRUE decoder's state.  A thread whose decode has merged with the true one
-//      never moves again, so the work is one segment per thread and round, and gray streams settle in two or three rounds;
-//   3. prefix-sums the blocks each segment completes, and decodes once more, now writing luminance coefficients (DC still
-//      as differences) into the coefficient buffer.
+//   1. removes the byte stuffing in parallel (FF00 -> FF, stop at the first marker) -- 16 coalesced bytes per thread and
+//      round, the 0xFF / 0x00 tests on whole dwords -- into a "clean" stream in which a position is ONE integer (a bit
+//      index), cuts it into 256 segments and stores it once more SEGMENT-MAJOR (dword j of segment s at [j][s], as
+//      big-endian dwords), so that the threads of a wave, each walking its own segment, fetch neighbouring addresses;
+//   2. thread t decodes segment t from an ASSUMED state (bit t * B, first block of an MCU, DC next) up to the first
+//      symbol boundary past its end and records that end state (bit, block in MCU, zigzag index).  Thread 0's assumption
+//      is true.  Then, round after round, every thread restarts from its predecessor's end state whenever that state
+//      changed, until no end state changes: then start[t] == end[t-1] for all t, and by induction from thread 0 every
+//      start is the TRUE decoder's state.  A thread whose decode has merged with the true one never moves again, so the
+//      work is one segment per thread and round, and gray streams settle in two or three rounds;
+//   3. prefix-sums the blocks each segment completes, and decodes once more, now gathering each luminance block's
+//      coefficients (DC still as differences) in LDS; finished blocks leave for the coefficient buffer as whole 128-byte
+//      lines, copied by the wave together (a block belongs to the thread it starts with).
 // A second kernel turns the DC differences into values (a scan per image) and a third does dequantisation + IDCT for all
 // blocks of all images at once.  Latency per image: a few segment decodes instead of the whole stream.
+// Round-2 history of this kernel for 512 files of 114 KB (profiles/r02/README.md): 4.03 ms with byte-wise stuffing
+// removal, table references the compiler parked in scratch memory, and one 2-byte store per coefficient; 1.2 ms as
+// described here (stuffing removal 1.27 -> 0.07 ms, each decode pass 0.55 -> 0.27 ms, the writing pass 1.33 -> 0.53 ms).
 // =====================================================================================================================
 constexpr int kParThreads = 256;
+constexpr int kTileBytes = kParThreads * 16;  // bytes of the raw stream one round of the stuffing removal covers
 
-struct ParState {
-  uint32_t q;  // bit position in the clean stream
-  uint32_t ck; // block index inside the MCU << 8 | zigzag index (0: the next symbol is a DC size)
+constexpr int kTransSlack = 4096;  // bytes the segment-major copy of one clean stream may exceed the stream by
+
+// The decode loop reads its tables out of LDS through explicitly LDS-typed pointers and offsets: references to one of
+// several tables picked per lane made the compiler keep a pointer array in scratch memory and fetch the entries with
+// generic loads -- two trips to HBM-backed memory per symbol, 1.8 k cycles per loop round.
+using lds_u16 = const __attribute__((address_space(3))) uint16_t*;
+using lds_u8 = const __attribute__((address_space(3))) uint8_t*;
+constexpr uint32_t kHuff16 = sizeof(DevHuff) / 2;            // one table, in 16-bit entries
+constexpr uint32_t kSub16 = offsetof(DevHuff, sub) / 2;      // its second-level tables
+
+struct ParGeom {  // wave-uniform: blocks per MCU and the table slots of the components (8 bits each, component 0 lowest;
+  int lum, n1, m;  // packed so that the pick is arithmetic: a choice between six variables became a load from scratch)
+  uint32_t dc_slots, ac_slots;
+  const uint32_t* trans;  // the clean stream, SEGMENT-MAJOR: dword j of segment s (big-endian: stream bit q is bit
+  uint32_t segdw, magic;  // 31 - (q & 31) of dword q >> 5) sits at trans[j * kParThreads + s], so the threads of a wave,
+                          // each inside its own segment and all about equally far into it, fetch neighbouring addresses;
+                          // magic = floor(2^32 / segdw) + 1
+  __device__ __forceinline__ uint32_t fetch(uint32_t b) const {
+    const uint32_t s = __umulhi(b, magic);  // b / segdw (exact while b * segdw < 2^32)
+    return s < (uint32_t)kParThreads ? trans[(b - s * segdw) * (uint32_t)kParThreads + s] : 0u;  // zero bits past the end
+  }
 };
 
-struct ParCtx {  // per-thread decoder over the clean stream (big-endian dwords)
-  const uint32_t* clean;
-  uint32_t ndwords;  // dwords that hold stream bits (zero bits are fed beyond, as libjpeg does past the end of the data)
-  uint32_t base;     // dword index of w0
-  uint32_t w0, w1;
-  __device__ __forceinline__ uint64_t window(uint32_t q) {  // the 33+ bits from q on, left-aligned
-    const uint32_t b = q >> 5;
-    if (b != base) {
-      base = b;
-      w0 = b < ndwords ? clean[b] : 0u;
-      w1 = b + 1 < ndwords ? clean[b + 1] : 0u;
-    }
-    return (((uint64_t)w0 << 32) | w1) << (q & 31u);
+// One symbol (a DC size + its bits, or an AC run/size + its bits) of the block at (c, k) -- block inside the MCU, zigzag
+// index (0: a DC size comes next) -- read at bit position q through the window (base, w0, w1).  Straight-line code but
+// for the second table lookup: the lanes of a wave sit at different places of different blocks, so every branch in here
+// would be taken by somebody in every round.  Returns true when the symbol ends its block; kk / val: the coefficient it
+// carries (kk < 0: none).
+__device__ __forceinline__ bool par_symbol(const ParGeom& G, lds_u16 tab, uint32_t& q, int c, int& k, uint32_t& base,
+                                           uint32_t& w0, uint32_t& w1, int& kk, int& val) {
+  // the 32 bits from q on (a code + its extra bits need <= 27, so q moves on by at most one dword per symbol)
+  const uint32_t b = q >> 5, sh = q & 31u;
+  if (b != base) {
+    base = b;
+    w0 = w1;
+    w1 = G.fetch(b + 1u);
   }
-};
-
-// One symbol (a DC size + its bits, or an AC run/size + its bits) of the block described by (c, k); returns true when it
-// ends the block.  val / zpos: the coefficient it produced (zpos < 0: none).
-__device__ __forceinline__ bool par_symbol(ParCtx& cx, uint32_t& q, int& k, const DevHuff& hd, const DevHuff& ha, int& val,
-                                           int& zpos) {
-  const uint64_t x = cx.window(q);
-  const DevHuff& h = k == 0 ? hd : ha;
-  const uint32_t p9 = (uint32_t)(x >> (64 - kLookBits));
-  uint32_t e = h.look[p9];
-  int len, sym;
-  if (e) {
-    len = (int)(e >> 8);
-    sym = (int)(e & 255u);
-  } else {
-    int l = kLookBits + 1;
-    int32_t code = (int32_t)(x >> (64 - l));
-    while (l <= 16 && code > h.maxcode[l]) {
-      l++;
-      code = (int32_t)(x >> (64 - (l <= 16 ? l : 16)));
-    }
-    if (l > 16) {
-      len = 16;
-      sym = 0;
-    } else {
-      len = l;
-      sym = h.vals[(h.valoff[l] + code) & 255];
-    }
+  const uint32_t x = sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+  const bool is0 = c < G.lum, is1 = c < G.lum + G.n1;
+  const bool isdc = k == 0;
+  const uint32_t slot = (((isdc ? G.dc_slots : G.ac_slots) >> (is0 ? 0 : (is1 ? 8 : 16))) & 255u) * kHuff16;
+  uint32_t e = tab[slot + (x >> (32 - kLookBits))];
+  if (e & kLongCode) {
+    const uint32_t ti = e & 255u;
+    e = ti < (uint32_t)kMaxSub ? tab[slot + kSub16 + (ti << kSubBits) + ((x >> (32 - 16)) & ((1u << kSubBits) - 1u))]
+                               : (uint32_t)kNoCode;
   }
-  zpos = -1;
-  val = 0;
-  if (k == 0) {  // DC: `sym` further bits
-    const int s = sym & 15;
-    if (s) {
-      const int v = (int)((x << len) >> (64 - s));
-      val = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
-    }
-    q += (uint32_t)(len + s);
-    zpos = 0;
-    k = 1;
-    return false;
-  }
-  const int r = sym >> 4, s = sym & 15;
-  if (s == 0) {
-    q += (uint32_t)len;
-    if (r != 15) return true;  // EOB
-    k += 16;
-    return k > 63;
-  }
-  k += r;
-  if (k > 63) {  // (cannot happen on the true chain)
-    q += (uint32_t)(len + s);
-    return true;
-  }
-  const int v = (int)((x << len) >> (64 - s));
-  val = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+  const int len = (int)(e >> 8), sym = (int)(e & 255u);
+  const int s = sym & 15, r = isdc ? 0 : sym >> 4;
+  // RECEIVE + EXTEND (T.81 F.2.2.1): s bits after the code; v < 2^(s-1) stands for v - 2^s + 1
+  const int v = (int)__builtin_amdgcn_ubfe(x, (uint32_t)(32 - len - s), (uint32_t)s);
+  const int ones = (1 << s) - 1;
+  val = 2 * v > ones ? v : v - ones;
   q += (uint32_t)(len + s);
-  zpos = k;
-  k++;
-  return k > 63;
+  const bool stop = !isdc && s == 0;  // EOB (r != 15) or ZRL (r == 15): no coefficient
+  const bool zrl = stop && r == 15;
+  const int at = k + r;
+  kk = (stop || at > 63) ? -1 : at;  // (at > 63 cannot happen on the true chain)
+  k = zrl ? k + 16 : at + 1;
+  return (stop && !zrl) || k > 63;
+}
+
+// Decodes from (q, c, k) to the first symbol boundary at or past `limit`; returns the blocks completed.
+__device__ __forceinline__ uint32_t par_count(const ParGeom& G, lds_u16 tab, uint32_t limit, uint32_t& q_io, int& c_io,
+                                              int& k_io) {
+  uint32_t q = q_io, done = 0;
+  int c = c_io, k = k_io;
+  uint32_t base = q >> 5, w0 = G.fetch(base), w1 = G.fetch(base + 1u);
+  while (q < limit) {
+    int kk, val;
+    if (par_symbol(G, tab, q, c, k, base, w0, w1, kk, val)) {
+      k = 0;
+      done++;
+      c = c + 1 == G.m ? 0 : c + 1;
+    }
+  }
+  q_io = q;
+  c_io = c;
+  k_io = k;
+  return done;
+}
+
+// The writing pass over a segment whose true start state is (q, c, k), g = blocks completed before it in the whole image.
+// A block belongs to the thread it STARTS with: the rest of a block under way at the segment's start is decoded and
+// skipped, the last block is decoded to its end beyond `limit`.  Luminance coefficients (DC still as differences) are
+// gathered in the thread's 64-entry block in LDS (`blk`: kBlkStride dwords apart, zero at entry); whenever lanes finish
+// luminance blocks the whole wave copies them out, one 128-byte line per block, to coef[(g / m) * lum + c] and clears
+// them.  The loop is therefore wave-uniform (lanes that are done idle along).
+// `finish`: the last segment keeps going on zero bits until the image has all its blocks -- what libjpeg does with a
+// stream that breaks off -- and never loops for ever: every symbol consumes at least one bit of at most 2^32.
+constexpr int kBlkStride = 33;  // dwords between the LDS blocks of neighbouring threads (32 + 1: the banks spread)
+__device__ __forceinline__ void par_write(const ParGeom& G, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave, int lane,
+                                          uint32_t limit, uint32_t q, int c, int k, uint32_t g, uint32_t* __restrict__ coef32,
+                                          uint32_t total_blocks, bool finish) {
+  uint32_t done = 0;
+  uint32_t base = q >> 5, w0 = G.fetch(base), w1 = G.fetch(base + 1u);
+  uint32_t mb = ((g - (uint32_t)c) / (uint32_t)G.m) * (uint32_t)G.lum;  // luminance blocks of the MCUs before
+  bool skip = k != 0;                                                    // inside a block somebody else started
+  int16_t* mine = reinterpret_cast<int16_t*>(blk_wave + lane * kBlkStride);
+  for (;;) {
+    const bool more = g + done < total_blocks;
+    const bool active = q < limit || (k != 0 && more) || (finish && more && q < 0xFFFF0000u);
+    if (__ballot(active) == 0ull) break;
+    bool flush = false;
+    uint32_t dst = 0;
+    if (active) {
+      int kk, val;
+      const bool lum = c < G.lum;
+      const bool end = par_symbol(G, tab, q, c, k, base, w0, w1, kk, val);
+      if (lum && !skip && more && kk >= 0) mine[zz[kk]] = (int16_t)val;
+      if (end) {
+        flush = lum && !skip && more;
+        dst = mb + (uint32_t)c;
+        skip = false;
+        k = 0;
+        done++;
+        if (++c == G.m) {
+          c = 0;
+          mb += (uint32_t)G.lum;
+        }
+      }
+    }
+    uint64_t todo = __ballot(flush);
+    while (todo) {  // wave-uniform: one finished block per round, 32 lanes x 4 bytes
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dst, src);
+      if (lane < 32) {
+        uint32_t* p = blk_wave + src * kBlkStride + lane;
+        coef32[(size_t)d * 32 + lane] = *p;
+        *p = 0u;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevImage* __restrict__ images,
@@ -449,15 +517,19 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
                                                                        const DevTables* __restrict__ tables,
                                                                        const uint8_t* __restrict__ stream,
                                                                        uint32_t* __restrict__ clean_all,
+                                                                       uint32_t* __restrict__ trans_all,
                                                                        int16_t* __restrict__ coef_all, size_t coef_stride,
                                                                        int32_t* __restrict__ status) {
+  constexpr int kWaves = kParThreads / 64;
   __shared__ __attribute__((aligned(16))) DevTables s_tab;
   __shared__ uint32_t s_q[kParThreads + 1], s_ck[kParThreads + 1];  // end states; [t] = start of segment t (entry 0: truth)
   __shared__ uint32_t s_cnt[kParThreads];
-  __shared__ uint32_t s_scan[kParThreads / 64];
-  __shared__ uint32_t s_marker, s_total, s_changed;
+  __shared__ uint32_t s_scan[2][kWaves];
+  __shared__ uint32_t s_end, s_changed;
   __shared__ uint8_t s_zz[64];
+  __shared__ uint32_t s_blk[kParThreads * kBlkStride];  // one coefficient block per thread (the writing pass)
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  for (int i = t; i < kParThreads * kBlkStride; i += kParThreads) s_blk[i] = 0u;
   const DevImage& im = images[index[blockIdx.x]];  // (the coefficient buffer is indexed by the launch's own numbering)
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + im.tables);
@@ -465,91 +537,116 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
     for (int i = t; i < (int)(sizeof(DevTables) / 4); i += kParThreads) d[i] = src[i];
   }
   if (t < 64) s_zz[t] = c_zigzag[t];
-  if (t == 0) s_marker = im.stream_len;
+  if (t == 0) s_end = 0xFFFFFFFFu;
   const uint8_t* raw = stream + im.stream_off;
+  const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);  // (stream_off is a multiple of 4)
   uint8_t* clean8 = reinterpret_cast<uint8_t*>(clean_all) + im.stream_off;
   const uint32_t* clean = clean_all + (im.stream_off >> 2);
   const uint32_t len = im.stream_len;
   __syncthreads();
-  // ---- 1. remove the byte stuffing ----
-  const uint32_t chunk = ((len + kParThreads - 1) / kParThreads + 3u) & ~3u;
-  const uint32_t c_begin = min((uint32_t)t * chunk, len), c_end = min(c_begin + chunk, len);
-  {
-    uint32_t first = len;
-    for (uint32_t i = c_begin; i < c_end; i++)
-      if (raw[i] == 0xFFu && (i + 1 >= len || raw[i + 1] != 0u)) {
-        first = i;
-        break;
-      }
-    if (first < len) atomicMin(&s_marker, first);
-  }
-  __syncthreads();
-  const uint32_t mpos = s_marker;  // the entropy-coded data ends here (EOI, normally)
-  uint32_t keep = 0;
-  for (uint32_t i = c_begin; i < min(c_end, mpos); i++) keep += !(raw[i] == 0u && i > 0 && raw[i - 1] == 0xFFu);
-  uint32_t inc = keep;
+  // ---- 1. remove the byte stuffing: raw -> clean, a tile of 16 bytes per thread at a time (coalesced) ----
+  // Per dword: flags (bit 7 of each byte) for "is 0xFF" and "is 0x00"; a zero after an 0xFF is dropped, an 0xFF before a
+  // non-zero byte is a marker and ends the entropy-coded data (EOI, normally).  The clean offset of the first marker --
+  // or of the end of the segment -- is the length of the clean stream.
+  uint32_t kept_before = 0;  // clean bytes of earlier tiles (uniform)
+  for (uint32_t tile = 0, round = 0; tile < len; tile += kTileBytes, round++) {
+    const uint32_t i = tile + (uint32_t)t * 16u;
+    uint32_t d[4] = {0u, 0u, 0u, 0u}, ff[4], zz[4];
+    uint32_t prev_ff = 0u, next_zero = 0x80u;
+    const int valid = i < len ? (int)min(16u, len - i) : 0;
+    if (valid) {  // (the host pads every segment with 32 zero bytes: these loads stay inside)
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
+      for (int j = 0; j < 4; j++) d[j] = raw32[(i >> 2) + j];
+      prev_ff = i && raw[i - 1] == 0xFFu ? 0x80000000u : 0u;
+      next_zero = raw[i + 16] == 0u ? 0x80u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t n = ~d[j];
+      ff[j] = ~((((n & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | n) | 0x7F7F7F7Fu);
+      zz[j] = ~((((d[j] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d[j]) | 0x7F7F7F7Fu);
+    }
+    uint32_t drop[4], mark[4];
+    int kc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t live = valid >= 4 * j + 4 ? 0x80808080u : (valid > 4 * j ? (0x80808080u >> (8 * (4 * j + 4 - valid))) : 0u);
+      drop[j] = zz[j] & __builtin_amdgcn_alignbit(ff[j], j ? ff[j - 1] : prev_ff, 24) & live;
+      mark[j] = ff[j] & ~__builtin_amdgcn_alignbit(j < 3 ? zz[j + 1] : next_zero, zz[j], 8) & live;
+      kc += __popc(live & ~drop[j]);
+    }
+    uint32_t inc = (uint32_t)kc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_scan[round & 1u][wid] = inc;
+    __syncthreads();
+    uint32_t off = kept_before + inc - (uint32_t)kc, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      const uint32_t v = s_scan[round & 1u][w];
+      if (w < wid) off += v;
+      tile_total += v;
+    }
+    kept_before += tile_total;
+    if (valid) {
+      if ((mark[0] | mark[1] | mark[2] | mark[3]) != 0u) {  // the clean offset of the first marker in here
+        uint32_t o = off;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (!found && mark[j]) {
+            const uint32_t below = (1u << (__ffs(mark[j]) - 8)) - 1u;  // the bytes before the marker in this dword
+            o += __popc(~drop[j] & 0x80808080u & below);
+            found = true;
+          }
+          if (!found) o += __popc(~drop[j] & 0x80808080u);
+        }
+        atomicMin(&s_end, o);
+      }
+      if (valid == 16 && (drop[0] | drop[1] | drop[2] | drop[3]) == 0u) {
+        __builtin_memcpy(clean8 + off, d, 16);
+      } else {
+        uint32_t o = off;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          if (j < valid && !((drop[j >> 2] >> (8 * (j & 3) + 7)) & 1u)) clean8[o++] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
+      }
+    }
   }
-  if (lane == 63) s_scan[wid] = inc;
   __syncthreads();
-  uint32_t off = inc - keep;
-  for (int w = 0; w < wid; w++) off += s_scan[w];
-  if (t == kParThreads - 1) s_total = off + keep;
-  for (uint32_t i = c_begin; i < min(c_end, mpos); i++) {
-    const uint32_t b = raw[i];
-    if (b == 0u && i > 0 && raw[i - 1] == 0xFFu) continue;
-    clean8[off ^ 3u] = (uint8_t)b;  // big-endian dwords: stream bit q is bit 31 - (q & 31) of dword q >> 5
-    off++;
-  }
-  __syncthreads();
-  const uint32_t L = s_total;  // clean bytes
-  {  // zero the rest of the last dword (zero bits are what libjpeg feeds past the end of the data)
-    const uint32_t z1 = (L + 3u) & ~3u;
-    for (uint32_t i = L + t; i < z1; i += kParThreads) clean8[i ^ 3u] = 0;
-  }
+  const uint32_t L = min(s_end, kept_before);  // clean bytes
+  if (t < 8) clean8[L + t] = 0;  // (zero bits are what libjpeg feeds past the end of the data; the buffer is padded)
   __threadfence_block();
   __syncthreads();
   // ---- 2. segment end states until they stop changing ----
   const int ncomp = im.ncomp;
-  const int lum = im.h[0] * im.v[0];
-  const int n1 = ncomp > 1 ? im.h[1] * im.v[1] : 0, n2 = ncomp > 2 ? im.h[2] * im.v[2] : 0;
-  const int m = lum + n1 + n2;  // blocks per MCU
-  const DevHuff &hd0 = s_tab.huff[im.dc_slot[0]], &ha0 = s_tab.huff[im.ac_slot[0]];
-  const DevHuff &hd1 = s_tab.huff[im.dc_slot[ncomp > 1 ? 1 : 0]], &ha1 = s_tab.huff[im.ac_slot[ncomp > 1 ? 1 : 0]];
-  const DevHuff &hd2 = s_tab.huff[im.dc_slot[ncomp > 2 ? 2 : 0]], &ha2 = s_tab.huff[im.ac_slot[ncomp > 2 ? 2 : 0]];
   const uint32_t nbits = L * 8u;
   const uint32_t seg = max(64u, ((nbits + kParThreads - 1) / kParThreads + 31u) & ~31u);
   const uint32_t limit = min((uint32_t)(t + 1) * seg, nbits);
-  ParCtx cx{clean, (L + 3u) >> 2, 0xFFFFFFFFu, 0u, 0u};
-  // decodes from (q, c, k) to the first symbol boundary at or past `limit`; WRITE: coefficients of luminance blocks
-  // go to coef[(g / m) * lum + c][...] with g = blocks completed before this one in the whole image
-  // (`finish`: the last segment of the writing pass keeps going on zero bits until the image has all its blocks -- what
-  // libjpeg does with a stream that breaks off -- and never loops for ever: every symbol consumes at least one bit of at
-  // most 2^32)
-  auto run = [&](uint32_t& q, int& c, int& k, bool write, uint32_t g, int16_t* coef, uint32_t total_blocks,
-                 bool finish = false) -> uint32_t {
-    uint32_t done = 0;
-    while (q < limit || (finish && g + done < total_blocks && q < 0xFFFF0000u)) {
-      const bool is0 = c < lum, is1 = !is0 && c < lum + n1;
-      const DevHuff& hd = is0 ? hd0 : (is1 ? hd1 : hd2);
-      const DevHuff& ha = is0 ? ha0 : (is1 ? ha1 : ha2);
-      int val, zpos;
-      const bool end = par_symbol(cx, q, k, hd, ha, val, zpos);
-      if (write && is0 && zpos >= 0 && g + done < total_blocks) {
-        const uint32_t lb = ((g + done) / (uint32_t)m) * (uint32_t)lum + (uint32_t)c;
-        coef[(size_t)lb * 64 + s_zz[zpos]] = (int16_t)val;
-      }
-      if (end) {
-        k = 0;
-        c = c + 1 == m ? 0 : c + 1;
-        done++;
-      }
-    }
-    return done;
-  };
+  const uint32_t segdw = seg >> 5, ndw = (L + 3u) >> 2;
+  uint32_t* trans = trans_all + ((im.stream_off + (uint32_t)blockIdx.x * (uint32_t)kTransSlack) >> 2);
+  for (uint32_t j = 0; j < segdw; j++) {  // the segment-major copy (zero bits past the end, as libjpeg feeds them)
+    const uint32_t b = (uint32_t)t * segdw + j;
+    trans[j * (uint32_t)kParThreads + (uint32_t)t] = b < ndw ? __builtin_bswap32(clean[b]) : 0u;
+  }
+  __threadfence_block();
+  __syncthreads();
+  ParGeom G;
+  G.lum = im.h[0] * im.v[0];
+  G.n1 = ncomp > 1 ? im.h[1] * im.v[1] : 0;
+  G.m = G.lum + G.n1 + (ncomp > 2 ? im.h[2] * im.v[2] : 0);  // blocks per MCU
+  G.dc_slots = (uint32_t)im.dc_slot[0] | ((uint32_t)im.dc_slot[ncomp > 1 ? 1 : 0] << 8) |
+               ((uint32_t)im.dc_slot[ncomp > 2 ? 2 : 0] << 16);
+  G.ac_slots = (uint32_t)im.ac_slot[0] | ((uint32_t)im.ac_slot[ncomp > 1 ? 1 : 0] << 8) |
+               ((uint32_t)im.ac_slot[ncomp > 2 ? 2 : 0] << 16);
+  G.trans = trans;
+  G.segdw = segdw;
+  G.magic = 0xFFFFFFFFu / segdw + 1u;
+  const lds_u16 tab = (lds_u16)(&s_tab.huff[0].look[0]);
+  const lds_u8 zz = (lds_u8)(&s_zz[0]);
   uint32_t sq = (uint32_t)t * seg, sck = 0;  // assumed start: first block of an MCU, DC next (true for t == 0)
   if (t == 0) {
     s_q[0] = 0;
@@ -559,7 +656,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   {
     uint32_t q = min(sq, nbits);
     int c = 0, k = 0;
-    s_cnt[t] = run(q, c, k, false, 0, nullptr, 0);
+    s_cnt[t] = par_count(G, tab, limit, q, c, k);
     s_q[t + 1] = q;
     s_ck[t + 1] = ((uint32_t)c << 8) | (uint32_t)k;
   }
@@ -569,7 +666,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
     bool redo = t > 0 && (nq != sq || nck != sck);
     uint32_t q = nq, cnt = 0;
     int c = (int)(nck >> 8), k = (int)(nck & 255u);
-    if (redo) cnt = run(q, c, k, false, 0, nullptr, 0);
+    if (redo) cnt = par_count(G, tab, limit, q, c, k);
     __syncthreads();  // (everybody has read its predecessor's state)
     if (redo) {
       sq = nq;
@@ -595,17 +692,17 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
     const uint32_t v = __shfl_up(incb, o, 64);
     if (lane >= o) incb += v;
   }
-  if (lane == 63) s_scan[wid] = incb;
+  if (lane == 63) s_scan[0][wid] = incb;
   __syncthreads();
   uint32_t g = incb - mine;
-  for (int w = 0; w < wid; w++) g += s_scan[w];
+  for (int w = 0; w < wid; w++) g += s_scan[0][w];
   {
-    const uint32_t total_blocks = (uint32_t)(im.mcus_x * im.mcus_y * m);
+    const uint32_t total_blocks = (uint32_t)(im.mcus_x * im.mcus_y * G.m);
     uint32_t q = t == 0 ? 0u : s_q[t];
     const uint32_t ck = t == 0 ? 0u : s_ck[t];
     int c = (int)(ck >> 8), k = (int)(ck & 255u);
-    int16_t* coef = coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t));
-    (void)run(q, c, k, true, g, coef, total_blocks, t == kParThreads - 1);
+    uint32_t* coef32 = reinterpret_cast<uint32_t*>(coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t)));
+    par_write(G, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, coef32, total_blocks, t == kParThreads - 1);
   }
 }
 
@@ -692,6 +789,9 @@ struct HostHuff {
 
 void build_dev_huff(const HostHuff& h, DevHuff* d) {
   std::memset(d, 0, sizeof(*d));
+  for (auto& e : d->look) e = kNoCode;
+  for (auto& t : d->sub)
+    for (auto& e : t) e = kNoCode;
   int32_t code = 0;
   int k = 0;
   for (int l = 1; l <= 16; l++) {
@@ -702,6 +802,15 @@ void build_dev_huff(const HostHuff& h, DevHuff* d) {
         const int shift = kLookBits - l;
         for (int f = 0; f < (1 << shift); f++)
           d->look[((uint32_t)code << shift) | (uint32_t)f] = (uint16_t)((l << 8) | h.vals[k]);
+      } else {  // second level: the table of this code's 9-bit prefix, every 7-bit continuation that starts with its rest
+        const uint32_t p9 = (uint32_t)code >> (l - kLookBits);
+        if (!(d->look[p9] & kLongCode)) d->look[p9] = (uint16_t)(kLongCode | std::min<uint32_t>(d->nsub++, 255u));
+        const uint32_t ti = d->look[p9] & 255u;
+        if (ti < (uint32_t)kMaxSub) {
+          const int shift = 16 - l;
+          const uint32_t rest = (uint32_t)code & ((1u << (l - kLookBits)) - 1u);
+          for (int f = 0; f < (1 << shift); f++) d->sub[ti][(rest << shift) | (uint32_t)f] = (uint16_t)((l << 8) | h.vals[k]);
+        }
       }
     }
     d->maxcode[l] = h.bits[l] ? code - 1 : -1;
@@ -821,8 +930,11 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         im->v[c] = single ? 1 : cv[c];
       }
       std::memset(tab, 0, sizeof(*tab));
-      for (size_t i = 0; i < slots.size(); i++)
+      im->par_ok = 1;
+      for (size_t i = 0; i < slots.size(); i++) {
         build_dev_huff(slots[i].first ? ac[slots[i].second] : dc[slots[i].second], &tab->huff[i]);
+        if (tab->huff[i].nsub > (uint32_t)kMaxSub) im->par_ok = 0;
+      }
       std::memcpy(tab->qt_luma, qt[ctq[0]], sizeof(tab->qt_luma));
       *scan_begin = pos + len;
       return *scan_begin < nbytes ? VSF_OK : VSF_ERR_INVALID_ARG;
@@ -862,11 +974,12 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   }
   // which decoder takes which file: those without restart intervals first
   std::vector<uint32_t> index;
+  auto parallel = [&](int i) { return images[i].restart_interval == 0 && images[i].par_ok && !force_serial; };
   for (int pass = 0; pass < 2; pass++)
     for (int i = 0; i < n; i++)
-      if ((images[i].restart_interval == 0 && !force_serial) == (pass == 0)) index.push_back((uint32_t)i);
+      if (parallel(i) == (pass == 0)) index.push_back((uint32_t)i);
   plan->n_par = 0;
-  for (int i = 0; i < n; i++) plan->n_par += images[i].restart_interval == 0 && !force_serial;
+  for (int i = 0; i < n; i++) plan->n_par += parallel(i);
   plan->off_images = 0;
   plan->off_index = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
   plan->off_tables = (plan->off_index + index.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
@@ -897,10 +1010,17 @@ void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, u
   std::memset(dst + plan.total - 16, 0, 16);
 }
 
+// Bytes of the parallel decoder's stream scratch: the clean streams in the layout of the upload's stream part, then
+// their segment-major copies.
+size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par) {
+  const size_t linear = (stream_bytes + 64 + 255) & ~(size_t)255;
+  return n_par > 0 ? 2 * linear + (size_t)n_par * kTransSlack : linear;
+}
+
 // Both decoders over one upload: the files without restart intervals (n_par of them, listed first in the index array
-// at off_index) take the self-synchronising parallel decode, the others the one-wave-per-image decode.  d_clean has the
-// size of the upload's stream part, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
-// largest padded image) and is zeroed here.
+// at off_index) take the self-synchronising parallel decode, the others the one-wave-per-image decode.  d_clean has
+// vsf_jpeg_clean_bytes(total - off_stream, n_par) bytes, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
+// largest padded image): every luminance block is written whole.
 void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_stream,
                             size_t total, int n_par, int n_ser, int max_luma_blocks, int width, int height, uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
@@ -909,9 +1029,10 @@ void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off
   const DevTables* tables = reinterpret_cast<const DevTables*>(d_blob + off_tables);
   const uint32_t* index = reinterpret_cast<const uint32_t*>(d_blob + off_index);
   if (n_par > 0) {
-    (void)hipMemsetAsync(d_coef, 0, (size_t)n_par * coef_stride, s);
     hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n_par), dim3(kParThreads), 0, s, images, index, tables, d_blob + off_stream,
-                       reinterpret_cast<uint32_t*>(d_clean), d_coef, coef_stride, d_status);
+                       reinterpret_cast<uint32_t*>(d_clean),
+                       reinterpret_cast<uint32_t*>(d_clean + vsf_jpeg_clean_bytes(total - off_stream, 0)), d_coef, coef_stride,
+                       d_status);
     hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n_par), dim3(64), 0, s, images, index, d_coef, coef_stride);
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n_par), dim3(64), 0, s, images, index, tables, d_coef,
                        coef_stride, width, height, d_dst, dst_image_stride, dst_pitch);

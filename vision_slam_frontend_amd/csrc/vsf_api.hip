@@ -1282,7 +1282,7 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   // de-stuffed streams and the luminance coefficients in HBM
   const size_t coef_stride = (size_t)plan.max_luma_blocks * 64 * sizeof(int16_t);
   if (plan.n_par > 0) {
-    const size_t clean_need = plan.total - plan.off_stream + 64, coef_need = (size_t)plan.n_par * coef_stride;
+    const size_t clean_need = vsf_jpeg_clean_bytes(plan.total - plan.off_stream, plan.n_par), coef_need = (size_t)plan.n_par * coef_stride;
     if (clean_need > ctx->jp_clean_cap || coef_need > ctx->jp_coef_cap) {
       VSF_HIP(hipStreamSynchronize(ctx->stream));
       if (clean_need > ctx->jp_clean_cap) {
