@@ -9,8 +9,8 @@ def sub(old, new):
 sub('  // ---- 1. remove the byte stuffing: raw -> clean', '  long long T0 = wall_clock64(), T1, T2, T3, T4; int ROUNDS = 0;\n  // ---- 1. remove the byte stuffing: raw -> clean')
 sub('  // ---- 2. segment end states until they stop changing ----', '  T1 = wall_clock64();\n  // ---- 2. segment end states until they stop changing ----')
 sub('  for (int round = 0; round < kParThreads; round++) {\n    const uint32_t nq', '  T2 = wall_clock64();\n  for (int round = 0; round < kParThreads; round++) { ROUNDS++;\n    const uint32_t nq')
-sub('  // ---- 3. block offsets, then the writing pass ----', '  T3 = wall_clock64();\n  // ---- 3. block offsets, then the writing pass ----')
-sub('    par_write(G, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, coef32, total_blocks, t == kParThreads - 1);\n  }\n}', '''    par_write(G, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, coef32, total_blocks, t == kParThreads - 1);
+sub('  // ---- 3. block and DC offsets, then the writing pass ----', '  T3 = wall_clock64();\n  // ---- 3. block and DC offsets, then the writing pass ----')
+sub('    par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, pred, coef32, total_blocks,\n              t == kParThreads - 1);\n  }\n}', '''    par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, pred, coef32, total_blocks,\n              t == kParThreads - 1);
   }
   __syncthreads();
   T4 = wall_clock64();

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vsf_internal.h"
@@ -364,11 +365,12 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 //      changed, until no end state changes: then start[t] == end[t-1] for all t, and by induction from thread 0 every
 //      start is the TRUE decoder's state.  A thread whose decode has merged with the true one never moves again, so the
 //      work is one segment per thread and round, and gray streams settle in two or three rounds;
-//   3. prefix-sums the blocks each segment completes, and decodes once more, now gathering each luminance block's
-//      coefficients (DC still as differences) in LDS; finished blocks leave for the coefficient buffer as whole 128-byte
+//      A re-run that arrives at a state its thread's earlier run went through (remembered at a few block ends) stops
+//      there: the rest is known;
+//   3. prefix-sums the blocks each segment completes and the luminance DC differences it read, and decodes once more,
+//      now gathering each luminance block's coefficients (the DC as a value) in LDS; finished blocks leave for the coefficient buffer as whole 128-byte
 //      lines, copied by the wave together (a block belongs to the thread it starts with).
-// A second kernel turns the DC differences into values (a scan per image) and a third does dequantisation + IDCT for all
-// blocks of all images at once.  Latency per image: a few segment decodes instead of the whole stream.
+// A second kernel does dequantisation + IDCT for all blocks of all images at once.  Latency per image: a few segment decodes instead of the whole stream.
 // Round-2 history of this kernel for 512 files of 114 KB (profiles/r02/README.md): 4.03 ms with byte-wise stuffing
 // removal, table references the compiler parked in scratch memory, and one 2-byte store per coefficient; 1.2 ms as
 // described here (stuffing removal 1.27 -> 0.07 ms, each decode pass 0.55 -> 0.27 ms, the writing pass 1.33 -> 0.53 ms).
@@ -376,7 +378,8 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 constexpr int kParThreads = 256;
 constexpr int kTileBytes = kParThreads * 16;  // bytes of the raw stream one round of the stuffing removal covers
 
-constexpr int kTransSlack = 4096;  // bytes the segment-major copy of one clean stream may exceed the stream by
+constexpr int kOverlap = 8;   // rows every segment's column carries past its end: the first rows of the next segment
+constexpr int kTransSlack = kParThreads * (kOverlap + 2) * 4 + 2048;  // bytes the segment-major copy may exceed the stream by
 
 // The decode loop reads its tables out of LDS through explicitly LDS-typed pointers and offsets: references to one of
 // several tables picked per lane made the compiler keep a pointer array in scratch memory and fetch the entries with
@@ -390,30 +393,45 @@ struct ParGeom {  // wave-uniform: blocks per MCU and the table slots of the com
   int lum, n1, m;  // packed so that the pick is arithmetic: a choice between six variables became a load from scratch)
   uint32_t dc_slots, ac_slots;
   const uint32_t* trans;  // the clean stream, SEGMENT-MAJOR: dword j of segment s (big-endian: stream bit q is bit
-  uint32_t segdw, magic;  // 31 - (q & 31) of dword q >> 5) sits at trans[j * kParThreads + s], so the threads of a wave,
-                          // each inside its own segment and all about equally far into it, fetch neighbouring addresses;
-                          // magic = floor(2^32 / segdw) + 1
-  __device__ __forceinline__ uint32_t fetch(uint32_t b) const {
+  uint32_t segdw, magic;  // 31 - (q & 31) of dword q >> 5) sits at trans[j * kParThreads + s]; rows segdw .. segdw +
+                          // kOverlap - 1 of a column repeat the next segment's first rows; magic = floor(2^32 / segdw) + 1
+  __device__ __forceinline__ uint32_t fetch(uint32_t b) const {  // dword b of the stream, wherever the caller stands
     const uint32_t s = __umulhi(b, magic);  // b / segdw (exact while b * segdw < 2^32)
     return s < (uint32_t)kParThreads ? trans[(b - s * segdw) * (uint32_t)kParThreads + s] : 0u;  // zero bits past the end
   }
 };
 
-// One symbol (a DC size + its bits, or an AC run/size + its bits) of the block at (c, k) -- block inside the MCU, zigzag
-// index (0: a DC size comes next) -- read at bit position q through the window (base, w0, w1).  Straight-line code but
-// for the second table lookup: the lanes of a wave sit at different places of different blocks, so every branch in here
-// would be taken by somebody in every round.  Returns true when the symbol ends its block; kk / val: the coefficient it
-// carries (kk < 0: none).
-__device__ __forceinline__ bool par_symbol(const ParGeom& G, lds_u16 tab, uint32_t& q, int c, int& k, uint32_t& base,
-                                           uint32_t& w0, uint32_t& w1, int& kk, int& val) {
-  // the 32 bits from q on (a code + its extra bits need <= 27, so q moves on by at most one dword per symbol)
-  const uint32_t b = q >> 5, sh = q & 31u;
-  if (b != base) {
-    base = b;
-    w0 = w1;
-    w1 = G.fetch(b + 1u);
+// A lane's place in its segment's column: row jb and the two dwords (w0, w1) the current symbol is cut from.  Stepping to
+// the next row is an add (the column's kOverlap extra rows cover every overshoot of the counting passes); only the end
+// of a long block in the writing pass leaves the column and asks ParGeom::fetch.
+struct ParWin {
+  const uint32_t* col;  // trans + the lane's column
+  uint32_t rows;        // rows a column holds (segdw + kOverlap)
+  uint32_t gbase;       // dword index of the lane's row 0 in the whole stream
+  uint32_t jb, w0, w1;
+  __device__ __forceinline__ uint32_t row(const ParGeom& G, uint32_t r) const {
+    return r < rows ? col[(size_t)r * kParThreads] : G.fetch(gbase + r);
   }
-  const uint32_t x = sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+  __device__ __forceinline__ void open(const ParGeom& G, uint32_t q) {
+    jb = (q >> 5) - gbase;  // (0 for a start state; "negative" for the last thread of a stream that ends before its segment)
+    w0 = row(G, jb);
+    w1 = row(G, jb + 1u);
+  }
+};
+
+// One symbol (a DC size + its bits, or an AC run/size + its bits) of the block at (c, k) -- block inside the MCU, zigzag
+// index (0: a DC size comes next) -- read at bit position q.  Straight-line code but for the second table lookup: the
+// lanes of a wave sit at different places of different blocks, so every branch in here would be taken by somebody in
+// every round.  Returns true when the symbol ends its block; kk / val: the coefficient it carries (kk < 0: none).
+__device__ __forceinline__ bool par_symbol(const ParGeom& G, ParWin& W, lds_u16 tab, uint32_t& q, int c, int& k, int& kk,
+                                           int& val) {
+  // the 32 bits from q on (a code + its extra bits need <= 27, so q moves on by at most one dword per symbol)
+  if ((q >> 5) - W.gbase != W.jb) {
+    W.jb++;
+    W.w0 = W.w1;
+    W.w1 = W.row(G, W.jb + 1u);
+  }
+  const uint32_t x = (uint32_t)(((((uint64_t)W.w0) << 32) | W.w1) >> (32u - (q & 31u)));
   const bool is0 = c < G.lum, is1 = c < G.lum + G.n1;
   const bool isdc = k == 0;
   const uint32_t slot = (((isdc ? G.dc_slots : G.ac_slots) >> (is0 ? 0 : (is1 ? 8 : 16))) & 255u) * kHuff16;
@@ -438,54 +456,114 @@ __device__ __forceinline__ bool par_symbol(const ParGeom& G, lds_u16 tab, uint32
   return (stop && !zrl) || k > 63;
 }
 
-// Decodes from (q, c, k) to the first symbol boundary at or past `limit`; returns the blocks completed.
-__device__ __forceinline__ uint32_t par_count(const ParGeom& G, lds_u16 tab, uint32_t limit, uint32_t& q_io, int& c_io,
-                                              int& k_io) {
+// What a counting pass remembers of its way: the decoder's state at the ends of its 2nd, 4th, 8th and 16th block, and how
+// many blocks / how much luminance DC were still to come from there.  A later pass over the same segment from another
+// start state that arrives at one of these states has MERGED with the remembered pass -- the rest of its way is known.
+constexpr int kMarks = 4;
+static_assert(kMarks == 4, "par_count tests the four marks by name");
+struct ParMarks {
+  uint32_t q[kMarks];    // bit position (0xFFFFFFFF: none)
+  uint32_t cr[kMarks];   // block inside the MCU | blocks from here to the end of the segment << 8
+  int dc[kMarks];        // luminance DC differences from here to the end of the segment, summed
+};
+
+// Decodes from (q, c, k) to the first symbol boundary at or past `limit`, or until it meets one of `marks`' states (then
+// `merged`: the end state is the remembered pass's, which the caller still holds).  blocks / dcsum: blocks completed and sum of the luminance DC differences read in [start, limit).  A pass
+// that runs to the end leaves its own marks.
+__device__ __forceinline__ void par_count(const ParGeom& G, ParWin& W, lds_u16 tab, uint32_t limit, uint32_t& q_io, int& c_io,
+                                          int& k_io, ParMarks& marks, uint32_t& blocks, int& dcsum, bool& merged) {
   uint32_t q = q_io, done = 0;
-  int c = c_io, k = k_io;
-  uint32_t base = q >> 5, w0 = G.fetch(base), w1 = G.fetch(base + 1u);
-  while (q < limit) {
-    int kk, val;
-    if (par_symbol(G, tab, q, c, k, base, w0, w1, kk, val)) {
-      k = 0;
-      done++;
-      c = c + 1 == G.m ? 0 : c + 1;
+  int c = c_io, k = k_io, dc = 0;
+  merged = false;
+  W.open(G, q);
+  uint32_t tq[kMarks], tcn[kMarks];
+  int td[kMarks];
+#pragma unroll
+  for (int i = 0; i < kMarks; i++) {
+    tq[i] = 0xFFFFFFFFu;
+    tcn[i] = 0u;
+    td[i] = 0;
+  }
+  while (q < limit && !merged) {
+    {
+      int kk, val;
+      const bool lum = c < G.lum;
+      const bool end = par_symbol(G, W, tab, q, c, k, kk, val);
+      if (kk == 0 && lum) dc += val;
+      if (end) {
+        k = 0;
+        done++;
+        c = c + 1 == G.m ? 0 : c + 1;
+        if (q == marks.q[0] || q == marks.q[1] || q == marks.q[2] || q == marks.q[3]) {  // (rare: kept out of the way)
+#pragma unroll
+          for (int i = 0; i < kMarks; i++)
+            if (q == marks.q[i] && (uint32_t)c == (marks.cr[i] & 255u)) {
+              merged = true;
+              done += marks.cr[i] >> 8;
+              dc += marks.dc[i];
+            }
+        } else if (done <= (2u << (kMarks - 1)) && (done & (done - 1u)) == 0u) {
+#pragma unroll
+          for (int i = 0; i < kMarks; i++)
+            if (done == (2u << i)) {
+              tq[i] = q;
+              tcn[i] = (uint32_t)c | (done << 8);
+              td[i] = dc;
+            }
+        }
+      }
     }
   }
-  q_io = q;
-  c_io = c;
-  k_io = k;
-  return done;
+  if (!merged) {
+#pragma unroll
+    for (int i = 0; i < kMarks; i++) {
+      marks.q[i] = tq[i];
+      marks.cr[i] = (tcn[i] & 255u) | ((done - (tcn[i] >> 8)) << 8);
+      marks.dc[i] = dc - td[i];
+    }
+    q_io = q;
+    c_io = c;
+    k_io = k;
+  }
+  blocks = done;
+  dcsum = dc;
 }
 
 // The writing pass over a segment whose true start state is (q, c, k), g = blocks completed before it in the whole image.
 // A block belongs to the thread it STARTS with: the rest of a block under way at the segment's start is decoded and
-// skipped, the last block is decoded to its end beyond `limit`.  Luminance coefficients (DC still as differences) are
-// gathered in the thread's 64-entry block in LDS (`blk`: kBlkStride dwords apart, zero at entry); whenever lanes finish
+// skipped, the last block is decoded to its end beyond `limit`.  Luminance coefficients (the DC as a value: `pred` is the
+// sum of the DC differences before the segment) are gathered in the thread's 64-entry block in LDS (`blk`: kBlkStride dwords apart, zero at entry); whenever lanes finish
 // luminance blocks the whole wave copies them out, one 128-byte line per block, to coef[(g / m) * lum + c] and clears
-// them.  The loop is therefore wave-uniform (lanes that are done idle along).
+// them.  ALL lanes of a wave call this (the loop is wave-uniform; lanes that are done idle along).
 // `finish`: the last segment keeps going on zero bits until the image has all its blocks -- what libjpeg does with a
 // stream that breaks off -- and never loops for ever: every symbol consumes at least one bit of at most 2^32.
 constexpr int kBlkStride = 33;  // dwords between the LDS blocks of neighbouring threads (32 + 1: the banks spread)
-__device__ __forceinline__ void par_write(const ParGeom& G, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave, int lane,
-                                          uint32_t limit, uint32_t q, int c, int k, uint32_t g, uint32_t* __restrict__ coef32,
-                                          uint32_t total_blocks, bool finish) {
+__device__ __forceinline__ void par_write(const ParGeom& G, ParWin& W, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave, int lane,
+                                          uint32_t limit, uint32_t q, int c, int k, uint32_t g, int pred,
+                                          uint32_t* __restrict__ coef32, uint32_t total_blocks, bool finish) {
   uint32_t done = 0;
-  uint32_t base = q >> 5, w0 = G.fetch(base), w1 = G.fetch(base + 1u);
   uint32_t mb = ((g - (uint32_t)c) / (uint32_t)G.m) * (uint32_t)G.lum;  // luminance blocks of the MCUs before
   bool skip = k != 0;                                                    // inside a block somebody else started
   int16_t* mine = reinterpret_cast<int16_t*>(blk_wave + lane * kBlkStride);
-  for (;;) {
+  auto has_work = [&]() {
     const bool more = g + done < total_blocks;
-    const bool active = q < limit || (k != 0 && more) || (finish && more && q < 0xFFFF0000u);
-    if (__ballot(active) == 0ull) break;
+    return q < limit || (k != 0 && more) || (finish && more && q < 0xFFFF0000u);
+  };
+  bool busy = has_work();
+  if (__ballot(busy) == 0ull) return;
+  W.open(G, q);
+  while (__ballot(busy) != 0ull) {
     bool flush = false;
     uint32_t dst = 0;
-    if (active) {
+    if (busy) {
       int kk, val;
+      const bool more = g + done < total_blocks;
       const bool lum = c < G.lum;
-      const bool end = par_symbol(G, tab, q, c, k, base, w0, w1, kk, val);
-      if (lum && !skip && more && kk >= 0) mine[zz[kk]] = (int16_t)val;
+      const bool end = par_symbol(G, W, tab, q, c, k, kk, val);
+      if (lum && !skip && more && kk >= 0) {
+        if (kk == 0) val = pred += val;  // (a block's DC symbol is its first: never inside a skipped rest)
+        mine[zz[kk]] = (int16_t)val;
+      }
       if (end) {
         flush = lum && !skip && more;
         dst = mb + (uint32_t)c;
@@ -497,6 +575,7 @@ __device__ __forceinline__ void par_write(const ParGeom& G, lds_u16 tab, lds_u8 
           mb += (uint32_t)G.lum;
         }
       }
+      busy = has_work();
     }
     uint64_t todo = __ballot(flush);
     while (todo) {  // wave-uniform: one finished block per round, 32 lanes x 4 bytes
@@ -519,11 +598,13 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
                                                                        uint32_t* __restrict__ clean_all,
                                                                        uint32_t* __restrict__ trans_all,
                                                                        int16_t* __restrict__ coef_all, size_t coef_stride,
-                                                                       int32_t* __restrict__ status) {
+                                                                       int max_slots, int32_t* __restrict__ status) {
   constexpr int kWaves = kParThreads / 64;
-  __shared__ __attribute__((aligned(16))) DevTables s_tab;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];  // max_slots Huffman tables (DevTables::huff): what
+                                                                     // the batch's files use -- two for gray streams
   __shared__ uint32_t s_q[kParThreads + 1], s_ck[kParThreads + 1];  // end states; [t] = start of segment t (entry 0: truth)
   __shared__ uint32_t s_cnt[kParThreads];
+  __shared__ int s_dc[kParThreads];
   __shared__ uint32_t s_scan[2][kWaves];
   __shared__ uint32_t s_end, s_changed;
   __shared__ uint8_t s_zz[64];
@@ -533,8 +614,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   const DevImage& im = images[index[blockIdx.x]];  // (the coefficient buffer is indexed by the launch's own numbering)
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + im.tables);
-    uint32_t* d = reinterpret_cast<uint32_t*>(&s_tab);
-    for (int i = t; i < (int)(sizeof(DevTables) / 4); i += kParThreads) d[i] = src[i];
+    for (int i = t; i < max_slots * (int)(sizeof(DevHuff) / 4); i += kParThreads) s_tab[i] = src[i];
   }
   if (t < 64) s_zz[t] = c_zigzag[t];
   if (t == 0) s_end = 0xFFFFFFFFu;
@@ -628,7 +708,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   const uint32_t limit = min((uint32_t)(t + 1) * seg, nbits);
   const uint32_t segdw = seg >> 5, ndw = (L + 3u) >> 2;
   uint32_t* trans = trans_all + ((im.stream_off + (uint32_t)blockIdx.x * (uint32_t)kTransSlack) >> 2);
-  for (uint32_t j = 0; j < segdw; j++) {  // the segment-major copy (zero bits past the end, as libjpeg feeds them)
+  for (uint32_t j = 0; j < segdw + kOverlap; j++) {  // the segment-major copy (zero bits past the end, as libjpeg feeds them)
     const uint32_t b = (uint32_t)t * segdw + j;
     trans[j * (uint32_t)kParThreads + (uint32_t)t] = b < ndw ? __builtin_bswap32(clean[b]) : 0u;
   }
@@ -645,37 +725,55 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   G.trans = trans;
   G.segdw = segdw;
   G.magic = 0xFFFFFFFFu / segdw + 1u;
-  const lds_u16 tab = (lds_u16)(&s_tab.huff[0].look[0]);
+  ParWin W;
+  W.col = trans + t;
+  W.rows = segdw + kOverlap;
+  W.gbase = (uint32_t)t * segdw;
+  W.jb = W.w0 = W.w1 = 0u;
+  const lds_u16 tab = (lds_u16)(&s_tab[0]);
   const lds_u8 zz = (lds_u8)(&s_zz[0]);
   uint32_t sq = (uint32_t)t * seg, sck = 0;  // assumed start: first block of an MCU, DC next (true for t == 0)
+  ParMarks marks;
+#pragma unroll
+  for (int i = 0; i < kMarks; i++) {
+    marks.q[i] = 0xFFFFFFFFu;
+    marks.cr[i] = 0u;
+    marks.dc[i] = 0;
+  }
   if (t == 0) {
     s_q[0] = 0;
     s_ck[0] = 0;
     s_changed = 0;
   }
   {
-    uint32_t q = min(sq, nbits);
-    int c = 0, k = 0;
-    s_cnt[t] = par_count(G, tab, limit, q, c, k);
+    uint32_t q = min(sq, nbits), cnt;
+    int c = 0, k = 0, dc;
+    bool merged;
+    par_count(G, W, tab, limit, q, c, k, marks, cnt, dc, merged);
+    s_cnt[t] = cnt;
+    s_dc[t] = dc;
     s_q[t + 1] = q;
     s_ck[t + 1] = ((uint32_t)c << 8) | (uint32_t)k;
   }
   __syncthreads();
   for (int round = 0; round < kParThreads; round++) {
     const uint32_t nq = s_q[t], nck = s_ck[t];  // the predecessor's end state (the truth for t == 0)
-    bool redo = t > 0 && (nq != sq || nck != sck);
+    bool redo = t > 0 && (nq != sq || nck != sck), merged = false;
     uint32_t q = nq, cnt = 0;
-    int c = (int)(nck >> 8), k = (int)(nck & 255u);
-    if (redo) cnt = par_count(G, tab, limit, q, c, k);
+    int c = (int)(nck >> 8), k = (int)(nck & 255u), dc = 0;
+    if (redo) par_count(G, W, tab, limit, q, c, k, marks, cnt, dc, merged);
     __syncthreads();  // (everybody has read its predecessor's state)
     if (redo) {
       sq = nq;
       sck = nck;
-      const uint32_t eck = ((uint32_t)c << 8) | (uint32_t)k;
-      if (s_q[t + 1] != q || s_ck[t + 1] != eck) atomicOr(&s_changed, 1u);
-      s_q[t + 1] = q;
-      s_ck[t + 1] = eck;
       s_cnt[t] = cnt;
+      s_dc[t] = dc;
+      if (!merged) {  // (merged: the rest of the way, end state included, is the one already on record)
+        const uint32_t eck = ((uint32_t)c << 8) | (uint32_t)k;
+        if (s_q[t + 1] != q || s_ck[t + 1] != eck) atomicOr(&s_changed, 1u);
+        s_q[t + 1] = q;
+        s_ck[t + 1] = eck;
+      }
     }
     __syncthreads();
     const uint32_t any = s_changed;
@@ -685,48 +783,39 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   }
   __syncthreads();
   // (thread 0 never re-ran: its start was true; sq / sck of the others now equal their predecessors' end states)
-  // ---- 3. block offsets, then the writing pass ----
-  uint32_t mine = s_cnt[t], incb = mine;
+  // ---- 3. block and DC offsets, then the writing pass ----
+  const uint32_t mine = s_cnt[t];
+  const int mine_dc = s_dc[t];
+  uint32_t incb = mine;
+  int incd = mine_dc;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t v = __shfl_up(incb, o, 64);
-    if (lane >= o) incb += v;
+    const int d = __shfl_up(incd, o, 64);
+    if (lane >= o) {
+      incb += v;
+      incd += d;
+    }
   }
-  if (lane == 63) s_scan[0][wid] = incb;
+  if (lane == 63) {
+    s_scan[0][wid] = incb;
+    s_scan[1][wid] = (uint32_t)incd;
+  }
   __syncthreads();
   uint32_t g = incb - mine;
-  for (int w = 0; w < wid; w++) g += s_scan[0][w];
+  int pred = incd - mine_dc;
+  for (int w = 0; w < wid; w++) {
+    g += s_scan[0][w];
+    pred += (int)s_scan[1][w];
+  }
   {
     const uint32_t total_blocks = (uint32_t)(im.mcus_x * im.mcus_y * G.m);
     uint32_t q = t == 0 ? 0u : s_q[t];
     const uint32_t ck = t == 0 ? 0u : s_ck[t];
     int c = (int)(ck >> 8), k = (int)(ck & 255u);
     uint32_t* coef32 = reinterpret_cast<uint32_t*>(coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t)));
-    par_write(G, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, coef32, total_blocks, t == kParThreads - 1);
-  }
-}
-
-// DC differences -> DC values of the luminance blocks (decode order), one wave per image
-__global__ __launch_bounds__(64) void jpeg_dc_scan_kernel(const DevImage* __restrict__ images,
-                                                          const uint32_t* __restrict__ index, int16_t* __restrict__ coef_all,
-                                                          size_t coef_stride) {
-  const DevImage& im = images[index[blockIdx.x]];
-  const int nlb = im.mcus_x * im.mcus_y * im.h[0] * im.v[0];
-  int16_t* coef = coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t));
-  const int lane = threadIdx.x, per = (nlb + 63) / 64;
-  const int b0 = min(lane * per, nlb), b1 = min(b0 + per, nlb);
-  int sum = 0;
-  for (int b = b0; b < b1; b++) sum += coef[(size_t)b * 64];
-  int inc = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
-  }
-  int run = inc - sum;
-  for (int b = b0; b < b1; b++) {
-    run += coef[(size_t)b * 64];
-    coef[(size_t)b * 64] = (int16_t)run;
+    par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, pred, coef32, total_blocks,
+              t == kParThreads - 1);
   }
 }
 
@@ -787,6 +876,17 @@ struct HostHuff {
   uint8_t vals[256] = {0};
 };
 
+struct HostTableSet {  // what one file's scan uses, as read from its DQT / DHT segments (compared before anything is built:
+  int nslots = 0;      // consecutive frames of a camera carry the same tables)
+  uint8_t bits[kMaxSlots][17];
+  uint8_t vals[kMaxSlots][256];
+  uint16_t qt_luma[64];
+  bool same(const HostTableSet& o) const {
+    return nslots == o.nslots && std::memcmp(bits, o.bits, sizeof(bits[0]) * nslots) == 0 &&
+           std::memcmp(vals, o.vals, sizeof(vals[0]) * nslots) == 0 && std::memcmp(qt_luma, o.qt_luma, sizeof(qt_luma)) == 0;
+  }
+};
+
 void build_dev_huff(const HostHuff& h, DevHuff* d) {
   std::memset(d, 0, sizeof(*d));
   for (auto& e : d->look) e = kNoCode;
@@ -825,7 +925,7 @@ void build_dev_huff(const HostHuff& h, DevHuff* d) {
 
 // Parses one JPEG file; fills the image descriptor (without stream_off / tables) and the table set it needs.
 // Returns VSF_OK, VSF_ERR_INVALID_ARG (malformed, or not width x height) or VSF_ERR_UNSUPPORTED.
-static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int height, DevImage* im, DevTables* tab,
+static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int height, DevImage* im, HostTableSet* tab,
                              size_t* scan_begin) {
   if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return VSF_ERR_INVALID_ARG;
   uint16_t qt[4][64];
@@ -929,11 +1029,11 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         im->h[c] = single ? 1 : ch[c];
         im->v[c] = single ? 1 : cv[c];
       }
-      std::memset(tab, 0, sizeof(*tab));
-      im->par_ok = 1;
+      tab->nslots = (int)slots.size();
       for (size_t i = 0; i < slots.size(); i++) {
-        build_dev_huff(slots[i].first ? ac[slots[i].second] : dc[slots[i].second], &tab->huff[i]);
-        if (tab->huff[i].nsub > (uint32_t)kMaxSub) im->par_ok = 0;
+        const HostHuff& h = slots[i].first ? ac[slots[i].second] : dc[slots[i].second];
+        std::memcpy(tab->bits[i], h.bits, 17);
+        std::memcpy(tab->vals[i], h.vals, 256);
       }
       std::memcpy(tab->qt_luma, qt[ctq[0]], sizeof(tab->qt_luma));
       *scan_begin = pos + len;
@@ -951,21 +1051,39 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
                          VsfJpegPlan* plan) {
   std::vector<DevImage> images((size_t)n);
   std::vector<DevTables> tables;
+  std::vector<HostTableSet> sets;
+  std::vector<int> set_par_ok;
   plan->scan_begin.assign((size_t)n, 0);
   plan->max_luma_blocks = 0;
+  plan->max_slots = 1;
   size_t stream_bytes = 0;
   for (int i = 0; i < n; i++) {
-    DevTables t;
+    HostTableSet t;
     const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &plan->scan_begin[i]);
     if (st != VSF_OK) return st;
     int found = -1;
-    for (int k = (int)tables.size() - 1; k >= 0 && found < 0; k--)
-      if (std::memcmp(&tables[k], &t, sizeof(t)) == 0) found = k;
-    if (found < 0) {
-      found = (int)tables.size();
-      tables.push_back(t);
+    for (int k = (int)sets.size() - 1; k >= 0 && found < 0; k--)
+      if (sets[k].same(t)) found = k;
+    if (found < 0) {  // a new table set: the kernels' lookup tables are built once per set
+      found = (int)sets.size();
+      sets.push_back(t);
+      plan->max_slots = std::max(plan->max_slots, t.nslots);
+      tables.emplace_back();
+      DevTables& d = tables.back();
+      std::memset(&d, 0, sizeof(d));
+      int ok = 1;
+      for (int k = 0; k < t.nslots; k++) {
+        HostHuff h;
+        std::memcpy(h.bits, t.bits[k], 17);
+        std::memcpy(h.vals, t.vals[k], 256);
+        build_dev_huff(h, &d.huff[k]);
+        if (d.huff[k].nsub > (uint32_t)kMaxSub) ok = 0;
+      }
+      std::memcpy(d.qt_luma, t.qt_luma, sizeof(d.qt_luma));
+      set_par_ok.push_back(ok);
     }
     images[i].tables = (uint32_t)found;
+    images[i].par_ok = set_par_ok[(size_t)found];
     images[i].stream_off = (uint32_t)stream_bytes;
     images[i].stream_len = (uint32_t)(nbytes[i] - plan->scan_begin[i]);
     stream_bytes += (images[i].stream_len + 3u + 32u) & ~(size_t)3;
@@ -998,14 +1116,28 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   return VSF_OK;
 }
 
-// Step 2: writes the upload into `dst` (pinned staging, plan->total bytes): one pass over the compressed bytes.
+// Step 2: writes the upload into `dst` (pinned staging, plan->total bytes): one pass over the compressed bytes, shared
+// by a few threads when there is enough of it (one core copies ~19 GB/s into pinned memory).
 void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, uint8_t* dst) {
   std::memcpy(dst, plan.head.data(), plan.head.size());
-  for (int i = 0; i < n; i++) {
-    uint8_t* d = dst + plan.off_stream + plan.stream_off[i];
-    std::memcpy(d, jpeg[i] + plan.scan_begin[i], plan.stream_len[i]);
-    const size_t padded = (plan.stream_len[i] + 3u + 32u) & ~(size_t)3;
-    std::memset(d + plan.stream_len[i], 0, padded - plan.stream_len[i]);
+  auto copy_range = [&](int i0, int i1) {
+    for (int i = i0; i < i1; i++) {
+      uint8_t* d = dst + plan.off_stream + plan.stream_off[i];
+      std::memcpy(d, jpeg[i] + plan.scan_begin[i], plan.stream_len[i]);
+      const size_t padded = (plan.stream_len[i] + 3u + 32u) & ~(size_t)3;
+      std::memset(d + plan.stream_len[i], 0, padded - plan.stream_len[i]);
+    }
+  };
+  const size_t stream_bytes = plan.total - plan.off_stream;
+  const int workers = (int)std::min<size_t>({(size_t)4, stream_bytes >> 22, (size_t)n,
+                                             (size_t)std::max(1u, std::thread::hardware_concurrency())});
+  if (workers <= 1) {
+    copy_range(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; w++) pool.emplace_back(copy_range, (int)((int64_t)n * w / workers), (int)((int64_t)n * (w + 1) / workers));
+    copy_range(0, n / workers);
+    for (auto& th : pool) th.join();
   }
   std::memset(dst + plan.total - 16, 0, 16);
 }
@@ -1022,18 +1154,21 @@ size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par) {
 // vsf_jpeg_clean_bytes(total - off_stream, n_par) bytes, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
 // largest padded image): every luminance block is written whole.
 void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_stream,
-                            size_t total, int n_par, int n_ser, int max_luma_blocks, int width, int height, uint8_t* d_clean,
+                            size_t total, int n_par, int n_ser, int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
                             int32_t* d_status, hipStream_t s) {
   const DevImage* images = reinterpret_cast<const DevImage*>(d_blob + off_images);
   const DevTables* tables = reinterpret_cast<const DevTables*>(d_blob + off_tables);
   const uint32_t* index = reinterpret_cast<const uint32_t*>(d_blob + off_index);
   if (n_par > 0) {
-    hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n_par), dim3(kParThreads), 0, s, images, index, tables, d_blob + off_stream,
+    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(jpeg_par_decode_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)(kMaxSlots * sizeof(DevHuff)));
+    (void)lds_ok;
+    hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n_par), dim3(kParThreads), (size_t)max_slots * sizeof(DevHuff), s, images, index, tables, d_blob + off_stream,
                        reinterpret_cast<uint32_t*>(d_clean),
                        reinterpret_cast<uint32_t*>(d_clean + vsf_jpeg_clean_bytes(total - off_stream, 0)), d_coef, coef_stride,
-                       d_status);
-    hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n_par), dim3(64), 0, s, images, index, d_coef, coef_stride);
+                       max_slots, d_status);
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n_par), dim3(64), 0, s, images, index, tables, d_coef,
                        coef_stride, width, height, d_dst, dst_image_stride, dst_pitch);
   }

@@ -1305,7 +1305,7 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
   VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
   vsf_launch_jpeg_decode(ctx->jp_dev[b], plan.off_images, plan.off_index, plan.off_tables, plan.off_stream, plan.total,
-                         plan.n_par, n_images - plan.n_par, plan.max_luma_blocks, width, height, ctx->jp_clean, ctx->jp_coef,
+                         plan.n_par, n_images - plan.n_par, plan.max_luma_blocks, plan.max_slots, width, height, ctx->jp_clean, ctx->jp_coef,
                          coef_stride, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
   VSF_HIP(hipGetLastError());
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));

@@ -188,6 +188,7 @@ struct VsfJpegPlan {  // layout of one upload: [image descriptors | decode order
   std::vector<uint32_t> stream_off, stream_len;
   int n_par = 0;             // files without restart intervals: they take the self-synchronising parallel decode
   int max_luma_blocks = 0;   // luminance blocks of the (padded) image, largest over the batch
+  int max_slots = 1;         // Huffman tables one file's scan uses, largest over the batch
 };
 vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height, bool force_serial,
                          VsfJpegPlan* plan);
@@ -195,7 +196,7 @@ void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, u
 #endif
 size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par);
 void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_stream,
-                            size_t total, int n_par, int n_ser, int max_luma_blocks, int width, int height, uint8_t* d_clean,
+                            size_t total, int n_par, int n_ser, int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
                             int32_t* d_status, hipStream_t s);
 
