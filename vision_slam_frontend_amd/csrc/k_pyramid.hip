@@ -18,6 +18,9 @@
 // resize_march_kernel is the general fallback for levels that fail the R + 2 check.
 #pragma clang fp contract(off)
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
 
 #include "vsf_internal.h"
 
@@ -190,12 +193,29 @@ __device__ __forceinline__ StripX strip_setup(const ResizeArgs& a, int band) {
   return c;
 }
 
-template <int R, bool ALIGNED = false>
-__device__ __forceinline__ void strip_issue_from(const ResizeArgs& a, const StripX& c, const uint8_t* S, int strip,
+// LDS images of a level are reached through LDS-typed pointers where the compiler cannot see that for itself (an
+// address computed from a kernel argument): a generic pointer costs a flat instruction per access.
+using lds_u8p = __attribute__((address_space(3))) uint8_t*;
+using lds_cu8p = const __attribute__((address_space(3))) uint8_t*;
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+__device__ __forceinline__ uint32_t ld32(lds_cu8p p) { return *(const __attribute__((address_space(3))) uint32_t*)p; }
+__device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { *reinterpret_cast<uint32_t*>(p) = v; }
+__device__ __forceinline__ void st32(lds_u8p p, uint32_t v) { *(__attribute__((address_space(3))) uint32_t*)p = v; }
+
+// cv::resize's yofs for output row y (the upper tap's source row, clamped like the table the host builds)
+__device__ __forceinline__ int ytap_row(const ResizeArgs& a, int y) {
+  const int dy = min(y, a.dh - 1);
+  const float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+  return min(max((int)floorf(fy), 0), a.sh - 1);
+}
+
+// ys: first output row of the strip (any row: the R + 2 window holds for every start, VsfLevel::resize_any8, not only for
+// multiples of R)
+template <int R, bool ALIGNED = false, class SP = const uint8_t*>
+__device__ __forceinline__ void strip_issue_from(const ResizeArgs& a, const StripX& c, SP S, int ys,
                                                  StripRows<R>& o) {  // S = the source level of this image (HBM or LDS)
   const int lane = threadIdx.x & 63;
   // y taps: lane r evaluates output row ys + r (only row index i0 and the two weights are needed)
-  const int ys = strip * R;
   {
     const int dy = min(ys + (lane & (R - 1)), a.dh - 1);
     float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
@@ -207,33 +227,32 @@ __device__ __forceinline__ void strip_issue_from(const ResizeArgs& a, const Stri
   const uint32_t first = __builtin_amdgcn_readlane(o.ty_i0, 0);
 #pragma unroll
   for (int k = 0; k < R + 2; k++) {
-    const uint8_t* row = S + (size_t)(min(first + (uint32_t)k, (uint32_t)(a.sh - 1)) * (uint32_t)a.src_pitch);  // scalar
+    const SP row = S + (min(first + (uint32_t)k, (uint32_t)(a.sh - 1)) * (uint32_t)a.src_pitch);  // scalar
     if constexpr (ALIGNED) {
       // LDS source: an unaligned 8-byte read is split by the hardware and stalls the LDS queue; three aligned dwords and
       // two v_alignbyte give the same window (levels are padded to their 64-byte pitch, so the third dword exists)
       const uint32_t b0 = c.base & ~3u;
       // (the third dword is clamped into the row: when it would start past the pitch none of its bytes is needed)
-      const uint32_t d0 = *reinterpret_cast<const uint32_t*>(row + b0), d1 = *reinterpret_cast<const uint32_t*>(row + b0 + 4u),
-                     d2 = *reinterpret_cast<const uint32_t*>(row + min(b0 + 8u, (uint32_t)a.src_pitch - 4u));
+      const uint32_t d0 = ld32(row + b0), d1 = ld32(row + b0 + 4u), d2 = ld32(row + min(b0 + 8u, (uint32_t)a.src_pitch - 4u));
       o.v[k].lo = __builtin_amdgcn_alignbyte(d1, d0, c.base & 3u);
       o.v[k].hi = __builtin_amdgcn_alignbyte(d2, d1, c.base & 3u);
     } else {
-      o.v[k] = *reinterpret_cast<const U8B*>(row + c.base);
+      o.v[k] = *reinterpret_cast<const U8B*>((const uint8_t*)row + c.base);
     }
   }
 }
 
 template <int R>
 __device__ __forceinline__ void strip_issue(const ResizeArgs& a, const StripX& c, int image, int strip, StripRows<R>& o) {
-  strip_issue_from<R>(a, c, a.src + (size_t)image * a.src_img_stride, strip, o);
+  strip_issue_from<R>(a, c, a.src + (size_t)image * a.src_img_stride, strip * R, o);
 }
 
-// lcopy != nullptr: the output rows are also written to an LDS image of the level (same pitch as in HBM)
-template <int R>
-__device__ __forceinline__ void strip_finish(const ResizeArgs& a, const StripX& c, int image, int strip,
-                                             const StripRows<R>& in, uint8_t* lcopy = nullptr) {
+// Output rows [ys, min(ys + R, yend)).  lcopy != nullptr: the rows are also written to an LDS image of the level (same
+// pitch as in HBM; lcopy points at where the level's row 0 would be)
+template <int R, class LP = uint8_t*>
+__device__ __forceinline__ void strip_finish(const ResizeArgs& a, const StripX& c, int image, int ys, int yend,
+                                             const StripRows<R>& in, LP lcopy = nullptr, bool to_lds = false) {
   uint8_t* D = a.dst + (size_t)image * a.dst_img_stride;
-  const int ys = strip * R;
   const uint32_t first = __builtin_amdgcn_readlane(in.ty_i0, 0);
   struct H4 {
     uint32_t a, b, c, d;
@@ -255,7 +274,7 @@ __device__ __forceinline__ void strip_finish(const ResizeArgs& a, const StripX& 
   };
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    if (ys + r >= a.dh) break;  // wave-uniform
+    if (ys + r >= yend) break;  // wave-uniform
     const uint32_t wts = __builtin_amdgcn_readlane(in.ty_wts, r);
     const uint32_t b0 = (wts & 0xFFFFu) << 12, b1 = (wts >> 16) << 12;  // scalar, <= 2^23
     const bool skip = __builtin_amdgcn_readlane(in.ty_i0, r) != first + (uint32_t)r;  // then it is first + r + 1
@@ -269,16 +288,16 @@ __device__ __forceinline__ void strip_finish(const ResizeArgs& a, const StripX& 
       return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
     };
     uint8_t* drow = D + (size_t)((uint32_t)(ys + r) * (uint32_t)a.dst_pitch);  // scalar
-    uint8_t* lrow = lcopy + (uint32_t)(ys + r) * (uint32_t)a.dst_pitch;
+    const LP lrow = lcopy + (uint32_t)(ys + r) * (uint32_t)a.dst_pitch;
     if (skip) {
       const uint32_t out = vrow(H[r + 1], H[r + 2]);
       if (c.active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)c.x4) = out;
-      if (lcopy && c.active) *reinterpret_cast<uint32_t*>(lrow + (uint32_t)c.x4) = out;
+      if (to_lds && c.active) st32(lrow + (uint32_t)c.x4, out);
       asm volatile("" ::: "memory");  // keeps the two arms distinct (no select of the eight operands)
     } else {
       const uint32_t out = vrow(H[r], H[r + 1]);
       if (c.active) *reinterpret_cast<uint32_t*>(drow + (uint32_t)c.x4) = out;
-      if (lcopy && c.active) *reinterpret_cast<uint32_t*>(lrow + (uint32_t)c.x4) = out;
+      if (to_lds && c.active) st32(lrow + (uint32_t)c.x4, out);
     }
   }
 }
@@ -288,7 +307,7 @@ __device__ __forceinline__ void resize_strip_unit(const ResizeArgs& a, int image
   const StripX c = strip_setup(a, band);
   StripRows<R> rows;
   strip_issue<R>(a, c, image, strip, rows);
-  strip_finish<R>(a, c, image, strip, rows);
+  strip_finish<R>(a, c, image, strip * R, a.dh, rows);
 }
 
 template <int R>
@@ -372,14 +391,176 @@ __global__ __launch_bounds__(1024) void pyramid_image_kernel(PyramidArgs p) {
     for (int strip = wave; strip < a.nstrips; strip += 16) {
       StripRows<8> rows;
       if (from_lds)  // (workgroup-uniform; two inlined copies so that the LDS one reads with ds_read_b64)
-        strip_issue_from<8, true>(a, c, lsrc, strip, rows);
+        strip_issue_from<8, true>(a, c, lsrc, strip * 8, rows);
       else
-        strip_issue_from<8>(a, c, gsrc, strip, rows);
-      strip_finish<8>(a, c, image, strip, rows, lcopy);
+        strip_issue_from<8>(a, c, gsrc, strip * 8, rows);
+      strip_finish<8>(a, c, image, strip * 8, a.dh, rows, lcopy, lcopy != nullptr);
     }
     if (wave == 0 && l + 1 < p.nlevels) publish(l + 1);
     __syncthreads();  // (waits for this wave's LDS writes; the HBM copy is not read in this kernel)
   }
+}
+
+// The whole level chain for a frame or two (vsf_observe_stereo, the host-pointer calls): there the 48 dependent launches
+// are nothing but latency (~6.7 us each against ~1.5 us of work).  A launch of this kernel walks a CHAIN of levels
+// [la, lb); the last level's rows are cut into `nslabs` slabs, one 1024-thread workgroup each, and a workgroup computes,
+// level by level, exactly the rows its slab of the last level descends from -- a few rows more than its share on the
+// earlier levels, which its neighbours compute as well (the same values, written twice) -- so that no workgroup ever
+// waits for another.  Levels pass from one to the next through two LDS buffers (and go to HBM for the other stages); the
+// chain's first level is read from HBM.  Row ranges follow cv::resize's own yofs; 8-row strips start at any row.
+constexpr int kSlabMaxLevels = 32;
+constexpr int kSlabBands = 3;                                    // levels up to 768 columns
+constexpr size_t kSlabTapBytes = sizeof(uint32_t) * 2 * kSlabBands * 9 * 64;
+constexpr size_t kSlabFixedBytes = kSlabTapBytes + 2 * kSlabMaxLevels * sizeof(int) + (kSlabMaxLevels + 1) * sizeof(VsfLevel);
+
+struct SlabArgs {
+  PyramidArgs p;    // (l_begin / nlevels unused)
+  int la, lb;       // levels [la, lb), la >= 1, lb - la <= kSlabMaxLevels
+  int nslabs;
+  uint32_t cap;     // bytes of one LDS level buffer
+  int32_t* status;  // bit 0 is raised when a slab does not fit `cap` (a host-side sizing error)
+};
+
+// (L, P: levels l and l - 1 -- the kernel keeps the chain's entries in LDS: a scalar load per level and wave from the
+// table in HBM sat at the head of every level's dependency chain)
+__device__ __forceinline__ ResizeArgs slab_level_args(const PyramidArgs& p, int l, const VsfLevel& L, const VsfLevel& P) {
+  ResizeArgs a;
+  if (l >= 2) {
+    a.src = p.pyr + P.offset;
+    a.src_img_stride = (size_t)p.pyr_bytes;
+    a.src_pitch = P.pitch;
+  } else {
+    a.src = p.img0;
+    a.src_img_stride = p.img0_stride;
+    a.src_pitch = p.img0_pitch;
+  }
+  a.sw = P.w;
+  a.sh = P.h;
+  a.dst = p.pyr + L.offset;
+  a.dst_img_stride = (size_t)p.pyr_bytes;
+  a.dst_pitch = L.pitch;
+  a.dw = L.w;
+  a.dh = L.h;
+  a.scale_x = __builtin_bit_cast(double, ((unsigned long long)L.rscale_x[1] << 32) | L.rscale_x[0]);
+  a.scale_y = __builtin_bit_cast(double, ((unsigned long long)L.rscale_y[1] << 32) | L.rscale_y[0]);
+  a.nstrips = (L.h + 7) / 8;
+  return a;
+}
+
+__global__ __launch_bounds__(1024) void pyramid_slab_kernel(SlabArgs q) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const lds_u8p buf0 = (lds_u8p)smem, buf1 = buf0 + q.cap;
+  uint32_t(*xs)[kSlabBands][9][64] = reinterpret_cast<uint32_t(*)[kSlabBands][9][64]>(smem + 2 * (size_t)q.cap);
+  int* s_lo = reinterpret_cast<int*>(smem + 2 * (size_t)q.cap + kSlabTapBytes);
+  int* s_hi = s_lo + kSlabMaxLevels;
+  VsfLevel* s_lev = reinterpret_cast<VsfLevel*>(s_hi + kSlabMaxLevels);  // levels la - 1 .. lb - 1
+  const int image = blockIdx.y, slab = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nl = q.lb - q.la;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(q.p.levels + (q.la - 1));
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_lev);
+    for (int i = threadIdx.x; i < (nl + 1) * (int)(sizeof(VsfLevel) / 4); i += 1024) dst[i] = src[i];
+  }
+  __syncthreads();
+  auto level_args = [&](int l) { return slab_level_args(q.p, l, s_lev[l - q.la + 1], s_lev[l - q.la]); };
+  if (threadIdx.x == 0) {  // the slab's rows [lo, hi) of every level of the chain, from the last level backwards
+    const int hz = s_lev[nl].h;
+    int lo = (int)((long)hz * slab / q.nslabs), hi = (int)((long)hz * (slab + 1) / q.nslabs);
+    bool fits = true;
+    s_lo[nl - 1] = lo;
+    s_hi[nl - 1] = hi;
+    for (int l = q.lb - 1; l > q.la; l--) {
+      const ResizeArgs a = level_args(l);
+      if (hi > lo) {
+        const int f = ytap_row(a, lo), g = ytap_row(a, hi - 1);
+        lo = f;
+        hi = min(g + 1, a.sh - 1) + 1;
+        fits = fits && (size_t)(hi - lo) * (size_t)a.src_pitch <= (size_t)q.cap;
+      }
+      s_lo[l - 1 - q.la] = lo;
+      s_hi[l - 1 - q.la] = hi;
+    }
+    if (!fits) {
+      atomicOr(q.status, 1);
+      s_hi[nl - 1] = s_lo[nl - 1];  // (nothing is computed)
+    }
+  }
+  // the LAST waves evaluate the next level's x taps (one band each, -> xs[l & 1]) while the first ones work on the
+  // current level's strips: a level's taps cost about as much as a strip
+  auto publish = [&](int l) {
+    const ResizeArgs a = level_args(l);
+    const int band = 15 - wave;
+    if (band < ((a.dw + 255) >> 8)) {
+      const StripX c = strip_setup(a, band);
+      uint32_t(*o)[64] = xs[l & 1][band];
+      o[0][lane] = c.s0, o[1][lane] = c.s1, o[2][lane] = c.s2, o[3][lane] = c.s3;
+      o[4][lane] = c.q0, o[5][lane] = c.q1, o[6][lane] = c.q2, o[7][lane] = c.q3;
+      o[8][lane] = c.base;
+    }
+  };
+  if (wave >= 16 - kSlabBands) publish(q.la);
+  __syncthreads();
+  if (s_hi[nl - 1] <= s_lo[nl - 1]) return;  // (workgroup-uniform) more slabs than rows, or the sizing error
+  for (int l = q.la; l < q.lb; l++) {
+    const ResizeArgs a = level_args(l);
+    const int j = l - q.la;
+    if (wave >= 16 - kSlabBands && l + 1 < q.lb) publish(l + 1);
+    const int ylo = s_lo[j], yhi = s_hi[j];
+    const int nb = (a.dw + 255) >> 8;
+    const bool from_lds = j > 0;
+    // (LDS images are addressed as if they began at the level's row 0)
+    const bool to_lds = l + 1 < q.lb;
+    const lds_u8p lcopy = ((j & 1) ? buf1 : buf0) - (uint32_t)ylo * (uint32_t)a.dst_pitch;
+    const lds_cu8p lsrc = ((j & 1) ? buf0 : buf1) - (uint32_t)(from_lds ? s_lo[j - 1] : 0) * (uint32_t)a.src_pitch;
+    const uint8_t* gsrc = a.src + (size_t)image * a.src_img_stride;
+    // A strip is one wave's serial instruction stream (~2.5 us for 8 rows): when 8-row strips would leave half the
+    // waves idle the level is cut into 4-row strips instead
+    auto run = [&](auto rows_tag) {
+      constexpr int R = decltype(rows_tag)::value;
+      const int nunits = ((yhi - ylo + R - 1) / R) * nb;
+      for (int u = wave; u < nunits; u += 16) {
+        const int st = u / nb, band = u - st * nb;
+        StripX c;
+        {
+          const uint32_t(*o)[64] = xs[l & 1][band];
+          c.s0 = o[0][lane], c.s1 = o[1][lane], c.s2 = o[2][lane], c.s3 = o[3][lane];
+          c.q0 = o[4][lane], c.q1 = o[5][lane], c.q2 = o[6][lane], c.q3 = o[7][lane];
+          c.base = o[8][lane];
+          c.x4 = band * 256 + lane * 4;
+          c.active = c.x4 < a.dw;
+        }
+        const int ys = ylo + st * R;
+        StripRows<R> rows;
+        if (from_lds)  // (workgroup-uniform; two inlined copies so that the LDS one reads with ds_read_b32)
+          strip_issue_from<R, true, lds_cu8p>(a, c, lsrc, ys, rows);
+        else
+          strip_issue_from<R>(a, c, gsrc, ys, rows);
+        strip_finish<R, lds_u8p>(a, c, image, ys, yhi, rows, lcopy, to_lds);
+      }
+    };
+    if (((yhi - ylo + 1) >> 1) * nb <= 16 - kSlabBands)  // (the last waves are busy with the next level's taps)
+      run(std::integral_constant<int, 2>{});
+    else if (((yhi - ylo + 3) >> 2) * nb <= 16 - kSlabBands)
+      run(std::integral_constant<int, 4>{});
+    else
+      run(std::integral_constant<int, 8>{});
+    __syncthreads();  // (waits for this wave's LDS writes; the HBM copy is not read in this kernel)
+  }
+}
+
+// Sizes a chain [la, lb) for `nslabs` slabs: bytes of the largest LDS level image a workgroup keeps (levels la .. lb - 2),
+// from the bound rows(l - 1) <= floor(rows(l) * scale_y) + 4 (two taps per row and the float rounding of yofs).
+size_t slab_chain_bytes(const VsfLevel* lv, int la, int lb, int nslabs) {
+  long rows = (lv[lb - 1].h + nslabs - 1) / nslabs + 1;
+  size_t need = 0;
+  for (int l = lb - 1; l > la; l--) {
+    const double sy = 1. / ((double)lv[l].h / lv[l - 1].h);
+    rows = std::min<long>((long)std::floor((double)rows * sy) + 4, lv[l - 1].h);
+    need = std::max(need, (size_t)rows * (size_t)lv[l - 1].pitch);
+  }
+  return need;
 }
 
 }  // namespace
@@ -398,6 +579,54 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   // tail kernel as well, however empty the chip stays.
   int l_tail = g.nlevels;
   const bool few = side && im.n <= 4;
+  if (few && g.nlevels > 1) {
+    bool ok = true;
+    for (int l = 1; l < g.nlevels; l++) ok = ok && h_levels[l].resize_any8 && h_levels[l].w <= 256 * kSlabBands;
+    static const int chain_env = [] {
+      const char* e = std::getenv("VSF_PYRAMID_CHAIN");
+      return e ? std::atoi(e) : 8;
+    }();
+    if (ok && chain_env > 0) {
+      static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_slab_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)lds_ok;
+      const size_t fixed = kSlabFixedBytes;
+      const size_t budget = 144 * 1024;
+      for (int la = 1; la < g.nlevels;) {
+        int lb = std::min({la + chain_env, la + kSlabMaxLevels, g.nlevels});
+        static const int rows_env = [] {
+          const char* e = std::getenv("VSF_PYRAMID_ROWS");
+          return e ? std::max(1, std::atoi(e)) : 6;
+        }();
+        int nslabs = std::max(1, std::min(64, h_levels[lb - 1].h / rows_env));
+        size_t need = slab_chain_bytes(h_levels, la, lb, nslabs);
+        while (2 * need + fixed > budget && (nslabs < 64 || lb > la + 1)) {  // thinner slabs, then a shorter chain
+          if (nslabs < 64)
+            nslabs = std::min(64, nslabs * 2);
+          else
+            --lb;
+          need = slab_chain_bytes(h_levels, la, lb, nslabs);
+        }
+        SlabArgs q;
+        q.p.levels = d.levels;
+        q.p.img0 = im.base;
+        q.p.img0_stride = im.image_stride;
+        q.p.img0_pitch = (int)im.row_stride;
+        q.p.pyr = d.pyr;
+        q.p.pyr_bytes = g.pyr_bytes;
+        q.p.l_begin = la;
+        q.p.nlevels = lb;
+        q.la = la;
+        q.lb = lb;
+        q.nslabs = nslabs;
+        q.cap = (uint32_t)((need + 255) & ~(size_t)255);
+        q.status = d.status;
+        hipLaunchKernelGGL(pyramid_slab_kernel, dim3(nslabs, im.n), dim3(1024), 2 * (size_t)q.cap + fixed, s, q);
+        la = lb;
+      }
+      return;
+    }
+  }
   if (side && (im.n >= 64 || few)) {
     static int ncu = 0;
     if (ncu == 0) {

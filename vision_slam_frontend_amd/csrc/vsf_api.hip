@@ -219,6 +219,16 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
           break;
         }
       }
+      // the same property for 8-row strips that start at any row (pyramid_slab_kernel cuts levels where its slabs fall)
+      L.resize_any8 = 1;
+      for (int ys = 0; ys < L.h && L.resize_any8; ys++) {
+        const int f = G.yt[L.ytab + ys].i0;
+        for (int r = 0; r < 8 && ys + r < L.h && L.resize_any8; r++) {
+          const VsfTap& t = G.yt[L.ytab + ys + r];
+          const int dlt = (int)t.i0 - f - r;
+          if (!((dlt == 0 || dlt == 1) && (int)t.i1 == std::min((int)t.i0 + 1, P.h - 1))) L.resize_any8 = 0;
+        }
+      }
     }
     for (int l = 0; l < nlevels; l++) {
       const VsfLevel& L = G.levels[l];

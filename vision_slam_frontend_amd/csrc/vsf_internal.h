@@ -43,6 +43,7 @@ struct VsfLevel {
   int32_t blur_vec_end;    // columns [0, blur_vec_end) round half-even (SSE2 path), the rest half-up
   uint32_t xtab, ytab;     // entry offsets of this level's resize tables in the host-side Geometry (level >= 1)
   int32_t resize_rows;     // largest strip height (16, 8, 4) the shared-row resize kernel may use for this level, or 0
+  int32_t resize_any8;     // 1: an 8-row strip starting at ANY row stays inside 10 consecutive source rows
   uint32_t rscale_x[2], rscale_y[2];  // bit patterns of cv::resize's double scale_x / scale_y from level - 1 (host-computed)
 };
 
