@@ -212,3 +212,38 @@ def test_parallel_retain_best_packed_scores(ctx640, oracle):
             rk, rid = oracle.retain_best(score.astype(np.float32), k)
             gk, gid = ctx640.debug_retain_best(packed.view(np.float32), k, mode=1)
             np.testing.assert_array_equal(gid, rid, err_msg="n=%d k=%d" % (n, k))
+
+
+@pytest.mark.parametrize("size", [(97, 61), (333, 217), (752, 480), (768, 432), (800, 600), (64, 64)])
+def test_pyramid_of_small_batches_any_size(capi, oracle, size):
+    """A batch of one to four images builds its pyramid with pyramid_slab_kernel (chains of levels per launch, the last
+    level cut into slabs that recompute their border rows; widths above 768 keep the per-level launches): every level of
+    every image, for the reference's 50-level / 1.04 pyramid and for a classic 8-level / 1.2 one, against the oracle."""
+    import torch
+    from vision_slam_frontend_amd import synth
+    w, h = size
+    dev = torch.device("cuda", 0)
+    for kw in (dict(), dict(scale_factor=1.2, nlevels=8)):
+        p = capi.default_params(w, h, max_images=4, nfeatures=300)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        with capi.Context(p) as ctx:
+            K = ctx.params.max_keypoints
+            for n in (1, 2, 3, 4):
+                imgs = np.stack([synth.stereo_pair(w, h, 300 + 7 * n + i, n_objects=40)[i & 1] for i in range(n)])
+                pitch = (w + 15) // 16 * 16  # (device-pointer calls take rows at a multiple of four bytes)
+                padded = np.zeros((n, h, pitch), np.uint8)
+                padded[:, :, :w] = imgs
+                d = torch.from_numpy(padded).to(dev)
+                kp = torch.zeros((n, K, 28), dtype=torch.uint8, device=dev)
+                de = torch.zeros((n, K, 32), dtype=torch.uint8, device=dev)
+                cn = torch.zeros(n, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                ctx.extract_batch_dev(d.data_ptr(), n, pitch * h, pitch, kp.data_ptr(), de.data_ptr(), cn.data_ptr())
+                ctx.sync(allow_capacity=True)
+                for i in range(n):
+                    o = oracle.Orb(nfeatures=300, **kw)
+                    o.run(imgs[i])
+                    for l in range(ctx.nlevels):
+                        np.testing.assert_array_equal(ctx.debug_level_image(i, l, False), o.level_image(l, False),
+                                                      err_msg="%dx%d n=%d image %d level %d %s" % (w, h, n, i, l, kw))

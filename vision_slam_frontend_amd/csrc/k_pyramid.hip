@@ -15,6 +15,8 @@
 // pre-shifted weights.  One launch per level (the level chain is a true dependency), issued as two chains of half
 // batches on two streams.  pyramid_image_kernel: when the batch fills the chip, the 26 one-band levels (w <= 256) are
 // built by ONE launch, a 1024-thread workgroup per image with the levels ping-ponged through LDS.
+// pyramid_slab_kernel: a batch of one to four images (a frame) walks chains of levels per launch, the last level of a
+// chain cut into slabs whose workgroups never wait for each other (border rows are computed twice).
 // resize_march_kernel is the general fallback for levels that fail the R + 2 check.
 #pragma clang fp contract(off)
 #include <algorithm>
@@ -574,9 +576,9 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   // A batch that fills the CUs with one workgroup per image (last round at least three quarters full) hands its
   // one-band levels to the image-major tail kernel; `side` doubles as the permission (the cross-call prefetch on the aux
   // stream keeps the plain chain).
-  // A batch of a frame or two (vsf_observe_stereo, the host-pointer calls) is bound by the LATENCY of the level chain
-  // (26 dependent launches at ~6.7 us against ~4 us per level inside the tail kernel), not by throughput: it takes the
-  // tail kernel as well, however empty the chip stays.
+  // A batch of a frame or two (vsf_observe_stereo, the host-pointer calls) is bound by the LATENCY of the level chain,
+  // not by throughput: it takes pyramid_slab_kernel for every level (VSF_PYRAMID_CHAIN=0 keeps the launches + tail kernel;
+  // VSF_PYRAMID_CHAIN / VSF_PYRAMID_ROWS: levels per launch and rows per slab, for experiments).
   int l_tail = g.nlevels;
   const bool few = side && im.n <= 4;
   if (few && g.nlevels > 1) {
