@@ -216,7 +216,7 @@ def test_parallel_retain_best_packed_scores(ctx640, oracle):
 
 @pytest.mark.parametrize("size", [(97, 61), (333, 217), (752, 480), (768, 432), (800, 600), (64, 64)])
 def test_pyramid_of_small_batches_any_size(capi, oracle, size):
-    """A batch of one to four images builds its pyramid with pyramid_slab_kernel (chains of levels per launch, the last
+    """A batch of up to 16 images builds its pyramid with pyramid_slab_kernel (chains of levels per launch, the last
     level cut into slabs that recompute their border rows; widths above 768 keep the per-level launches): every level of
     every image, for the reference's 50-level / 1.04 pyramid and for a classic 8-level / 1.2 one, against the oracle."""
     import torch
@@ -224,12 +224,12 @@ def test_pyramid_of_small_batches_any_size(capi, oracle, size):
     w, h = size
     dev = torch.device("cuda", 0)
     for kw in (dict(), dict(scale_factor=1.2, nlevels=8)):
-        p = capi.default_params(w, h, max_images=4, nfeatures=300)
+        p = capi.default_params(w, h, max_images=9, nfeatures=300)
         for k, v in kw.items():
             setattr(p, k, v)
         with capi.Context(p) as ctx:
             K = ctx.params.max_keypoints
-            for n in (1, 2, 3, 4):
+            for n in (1, 2, 3, 4, 9):
                 imgs = np.stack([synth.stereo_pair(w, h, 300 + 7 * n + i, n_objects=40)[i & 1] for i in range(n)])
                 pitch = (w + 15) // 16 * 16  # (device-pointer calls take rows at a multiple of four bytes)
                 padded = np.zeros((n, h, pitch), np.uint8)

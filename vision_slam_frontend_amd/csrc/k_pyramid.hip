@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void pyramid_image_kernel(PyramidArgs p) {
   }
 }
 
-// The whole level chain for a frame or two (vsf_observe_stereo, the host-pointer calls): there the 48 dependent launches
+// The whole level chain for up to 16 images (vsf_observe_stereo, the host-pointer calls, small batches): there the 48 dependent launches
 // are nothing but latency (~6.7 us each against ~1.5 us of work).  A launch of this kernel walks a CHAIN of levels
 // [la, lb); the last level's rows are cut into `nslabs` slabs, one 1024-thread workgroup each, and a workgroup computes,
 // level by level, exactly the rows its slab of the last level descends from -- a few rows more than its share on the
@@ -580,7 +580,11 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   // not by throughput: it takes pyramid_slab_kernel for every level (VSF_PYRAMID_CHAIN=0 keeps the launches + tail kernel;
   // VSF_PYRAMID_CHAIN / VSF_PYRAMID_ROWS: levels per launch and rows per slab, for experiments).
   int l_tail = g.nlevels;
-  const bool few = side && im.n <= 4;
+  static const int few_max = [] {
+    const char* e = std::getenv("VSF_PYRAMID_FEW");
+    return e ? std::atoi(e) : 16;  // images: 2 -> 105 us (335 as launches), 8 -> 137 (335), 16 -> 212 (348), 32 -> 386 (341)
+  }();
+  const bool few = side && im.n <= few_max;
   if (few && g.nlevels > 1) {
     bool ok = true;
     for (int l = 1; l < g.nlevels; l++) ok = ok && h_levels[l].resize_any8 && h_levels[l].w <= 256 * kSlabBands;
