@@ -20,11 +20,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 W, H = 640, 480
 dev = torch.device("cuda", 0)
 base = synth.bench_batch(16, W, H, n_scenes=4).reshape(-1, H, W)
-for q in (80, 90):
+for q, extra in ((80, {}), (90, {}), (80, {"restart_marker_rows": 1})):
     files = []
     for i in range(N):
         b = io.BytesIO()
-        Image.fromarray(base[i % len(base)], "L").save(b, "JPEG", quality=q)
+        Image.fromarray(base[i % len(base)], "L").save(b, "JPEG", quality=q, **extra)
         files.append(b.getvalue())
     kb = sum(len(f) for f in files) / N / 1024
     ctx = capi.Context(capi.default_params(W, H, max_images=2, nfeatures=2000))
@@ -52,7 +52,7 @@ for q in (80, 90):
         host += time.perf_counter() - h0
     ctx.sync()
     dt = (time.perf_counter() - t0) / reps
-    print("quality %d (%.0f KB per image): %d images in %.2f ms = %.0f images/s = %.0f stereo frames/s "
+    print(("restart interval = one MCU row, " if extra else "") + "quality %d (%.0f KB per image): %d images in %.2f ms = %.0f images/s = %.0f stereo frames/s "
           "(host parse + staging %.2f ms of it, not overlapped here)" % (q, kb, N, dt * 1e3, N / dt, N / dt / 2, host / reps * 1e3))
     # beside the extraction of another batch (different context and stream)
     ectx = capi.Context(capi.default_params(W, H, max_images=N, nfeatures=2000))

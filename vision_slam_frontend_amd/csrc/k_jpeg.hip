@@ -6,10 +6,11 @@
 // JDCT_ISLOW): ITU-T T.81 baseline entropy decoding and, for the luminance component only, libjpeg's jidctint.c inverse
 // DCT (13-bit constants, PASS1_BITS = 2, exact 32-bit integers) + range limit; chroma is parsed and dropped.
 //
-// Two decoders, chosen per file.  Files without restart intervals (what a camera driver writes) take the PARALLEL one
-// further down: 256 threads per image decode 256 segments of the stream speculatively and iterate until their states
-// agree (jpeg_par_decode_kernel).  Files with restart intervals, files whose Huffman tables need more second-level
-// lookup tables than DevHuff holds -- and everything under VSF_JPEG_SERIAL=1 -- take the one described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
+// Two decoders, chosen per file.  The PARALLEL one further down (jpeg_par_decode_kernel) takes nearly everything: 256
+// threads per image decode 256 segments of the stream speculatively and iterate until their states agree, or -- files
+// with restart intervals -- decode the intervals, whose start states are known, side by side.  Files whose Huffman
+// tables need more second-level lookup tables than DevHuff holds, files with more restart intervals than the scratch
+// has room to list -- and everything under VSF_JPEG_SERIAL=1 -- take the one described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
 // codes (wave-uniform code: state in SGPRs, stream words and 9-bit lookahead tables through scalar loads, T.81 F.2.2.3
 // for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops chroma blocks and parks up to 16 luminance
 // blocks of coefficients in LDS; then the 64 lanes dequantise and run the two IDCT passes (lane = block x column, then
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 }
 
 // =====================================================================================================================
-// Parallel entropy decoding (files without restart intervals -- what a camera driver writes).
+// Parallel entropy decoding.  Files without restart intervals (what a camera driver writes) first; files WITH them need
+// no guessing and use steps 1 and 3 only (the end of this comment).
 //
 // A Huffman-coded stream has no markers to split it at, but it is SELF-SYNCHRONISING: a decoder started at a wrong bit
 // soon falls into step with the true one (Klein & Wiseman; for JPEG on GPUs: Weissenberger & Schmidt 2018/2021).  So a
@@ -370,7 +372,10 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 //   3. prefix-sums the blocks each segment completes and the luminance DC differences it read, and decodes once more,
 //      now gathering each luminance block's coefficients (the DC as a value) in LDS; finished blocks leave for the coefficient buffer as whole 128-byte
 //      lines, copied by the wave together (a block belongs to the thread it starts with).
-// A second kernel does dequantisation + IDCT for all blocks of all images at once.  Latency per image: a few segment decodes instead of the whole stream.
+// A second kernel does dequantisation + IDCT for all blocks of all images at once.
+// Files with restart intervals: step 1 also drops the RSTn markers and lists the clean offset behind each (where the
+// next interval begins: byte-aligned, first block of an MCU, DC prediction zero); thread t then runs step 3 over
+// intervals t, t + 256, ... of the clean stream as it lies.  11 k -> 138 k images/s against the one-wave decoder.  Latency per image: a few segment decodes instead of the whole stream.
 // Round-2 history of this kernel for 512 files of 114 KB (profiles/r02/README.md): 4.03 ms with byte-wise stuffing
 // removal, table references the compiler parked in scratch memory, and one 2-byte store per coefficient; 1.2 ms as
 // described here (stuffing removal 1.27 -> 0.07 ms, each decode pass 0.55 -> 0.27 ms, the writing pass 1.33 -> 0.53 ms).
@@ -409,7 +414,9 @@ struct ParWin {
   uint32_t rows;        // rows a column holds (segdw + kOverlap)
   uint32_t gbase;       // dword index of the lane's row 0 in the whole stream
   uint32_t jb, w0, w1;
+  const uint32_t* lin;  // non-null (files with restart intervals: no segments): the clean stream itself, `rows` dwords
   __device__ __forceinline__ uint32_t row(const ParGeom& G, uint32_t r) const {
+    if (lin) return r < rows ? __builtin_bswap32(lin[r]) : 0u;  // (workgroup-uniform)
     return r < rows ? col[(size_t)r * kParThreads] : G.fetch(gbase + r);
   }
   __device__ __forceinline__ void open(const ParGeom& G, uint32_t q) {
@@ -538,9 +545,9 @@ __device__ __forceinline__ void par_count(const ParGeom& G, ParWin& W, lds_u16 t
 // `finish`: the last segment keeps going on zero bits until the image has all its blocks -- what libjpeg does with a
 // stream that breaks off -- and never loops for ever: every symbol consumes at least one bit of at most 2^32.
 constexpr int kBlkStride = 33;  // dwords between the LDS blocks of neighbouring threads (32 + 1: the banks spread)
-__device__ __forceinline__ void par_write(const ParGeom& G, ParWin& W, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave, int lane,
-                                          uint32_t limit, uint32_t q, int c, int k, uint32_t g, int pred,
-                                          uint32_t* __restrict__ coef32, uint32_t total_blocks, bool finish) {
+__device__ __forceinline__ uint32_t par_write(const ParGeom& G, ParWin& W, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave,
+                                              int lane, uint32_t limit, uint32_t q, int c, int k, uint32_t g, int pred,
+                                              uint32_t* __restrict__ coef32, uint32_t total_blocks, bool finish) {
   uint32_t done = 0;
   uint32_t mb = ((g - (uint32_t)c) / (uint32_t)G.m) * (uint32_t)G.lum;  // luminance blocks of the MCUs before
   bool skip = k != 0;                                                    // inside a block somebody else started
@@ -550,7 +557,7 @@ __device__ __forceinline__ void par_write(const ParGeom& G, ParWin& W, lds_u16 t
     return q < limit || (k != 0 && more) || (finish && more && q < 0xFFFF0000u);
   };
   bool busy = has_work();
-  if (__ballot(busy) == 0ull) return;
+  if (__ballot(busy) == 0ull) return q;
   W.open(G, q);
   while (__ballot(busy) != 0ull) {
     bool flush = false;
@@ -589,6 +596,7 @@ __device__ __forceinline__ void par_write(const ParGeom& G, ParWin& W, lds_u16 t
       }
     }
   }
+  return q;  // (where the lane stopped)
 }
 
 __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevImage* __restrict__ images,
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   __shared__ uint32_t s_q[kParThreads + 1], s_ck[kParThreads + 1];  // end states; [t] = start of segment t (entry 0: truth)
   __shared__ uint32_t s_cnt[kParThreads];
   __shared__ int s_dc[kParThreads];
-  __shared__ uint32_t s_scan[2][kWaves];
+  __shared__ uint32_t s_scan[2][kWaves], s_rscan[2][kWaves];
   __shared__ uint32_t s_end, s_changed;
   __shared__ uint8_t s_zz[64];
   __shared__ uint32_t s_blk[kParThreads * kBlkStride];  // one coefficient block per thread (the writing pass)
@@ -628,17 +636,26 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   // Per dword: flags (bit 7 of each byte) for "is 0xFF" and "is 0x00"; a zero after an 0xFF is dropped, an 0xFF before a
   // non-zero byte is a marker and ends the entropy-coded data (EOI, normally).  The clean offset of the first marker --
   // or of the end of the segment -- is the length of the clean stream.
-  uint32_t kept_before = 0;  // clean bytes of earlier tiles (uniform)
+  // Files with restart intervals (ri > 0): an RSTn marker (0xFF, 0xD0..0xD7) is dropped as well and the clean offset
+  // behind it -- where the next interval begins, byte-aligned -- goes into the interval table (ivl, in the space the
+  // segment-major copy would take).
+  const int ri = im.restart_interval;
+  uint32_t* trans = trans_all + ((im.stream_off + (uint32_t)blockIdx.x * (uint32_t)kTransSlack) >> 2);
+  uint32_t* ivl = trans;
+  const uint32_t ivl_cap = (len + (uint32_t)kTransSlack) >> 2;  // entries of the table (the host sends only files that fit)
+  uint32_t kept_before = 0, rst_before = 0;  // clean bytes / RSTn markers of earlier tiles (uniform)
   for (uint32_t tile = 0, round = 0; tile < len; tile += kTileBytes, round++) {
     const uint32_t i = tile + (uint32_t)t * 16u;
-    uint32_t d[4] = {0u, 0u, 0u, 0u}, ff[4], zz[4];
-    uint32_t prev_ff = 0u, next_zero = 0x80u;
+    uint32_t d[4] = {0u, 0u, 0u, 0u}, ff[4], zz[4], rs[4] = {0u, 0u, 0u, 0u};
+    uint32_t prev_ff = 0u, next_zero = 0x80u, next_rst = 0u;
     const int valid = i < len ? (int)min(16u, len - i) : 0;
     if (valid) {  // (the host pads every segment with 32 zero bytes: these loads stay inside)
 #pragma unroll
       for (int j = 0; j < 4; j++) d[j] = raw32[(i >> 2) + j];
       prev_ff = i && raw[i - 1] == 0xFFu ? 0x80000000u : 0u;
-      next_zero = raw[i + 16] == 0u ? 0x80u : 0u;
+      const uint32_t nx = raw[i + 16];
+      next_zero = nx == 0u ? 0x80u : 0u;
+      next_rst = ri && (nx & 0xF8u) == 0xD0u && i + 16u < len ? 0x80u : 0u;
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -646,31 +663,67 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
       ff[j] = ~((((n & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | n) | 0x7F7F7F7Fu);
       zz[j] = ~((((d[j] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d[j]) | 0x7F7F7F7Fu);
     }
-    uint32_t drop[4], mark[4];
-    int kc = 0;
+    if (ri) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t y = (d[j] ^ 0xD0D0D0D0u) & 0xF8F8F8F8u;  // zero bytes: 0xD0..0xD7
+        rs[j] = ~((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) | 0x7F7F7F7Fu);
+      }
+    }
+    uint32_t drop[4], mark[4], rstb[4];
+    int kc = 0, rc = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const uint32_t live = valid >= 4 * j + 4 ? 0x80808080u : (valid > 4 * j ? (0x80808080u >> (8 * (4 * j + 4 - valid))) : 0u);
-      drop[j] = zz[j] & __builtin_amdgcn_alignbit(ff[j], j ? ff[j - 1] : prev_ff, 24) & live;
-      mark[j] = ff[j] & ~__builtin_amdgcn_alignbit(j < 3 ? zz[j + 1] : next_zero, zz[j], 8) & live;
+      const uint32_t after_ff = __builtin_amdgcn_alignbit(ff[j], j ? ff[j - 1] : prev_ff, 24);  // the byte before is 0xFF
+      const uint32_t rst_first = ff[j] & __builtin_amdgcn_alignbit(j < 3 ? rs[j + 1] : next_rst, rs[j], 8);  // 0xFF of an RSTn
+      rstb[j] = rs[j] & after_ff & live;                                                                    // its second byte
+      drop[j] = ((zz[j] & after_ff) | rst_first | rstb[j]) & live;
+      mark[j] = ff[j] & ~__builtin_amdgcn_alignbit(j < 3 ? zz[j + 1] : next_zero, zz[j], 8) & ~rst_first & live;
       kc += __popc(live & ~drop[j]);
+      rc += __popc(rstb[j]);
     }
-    uint32_t inc = (uint32_t)kc;
+    uint32_t inc = (uint32_t)kc, incr = (uint32_t)rc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
+      const uint32_t vr = __shfl_up(incr, o, 64);
+      if (lane >= o) {
+        inc += v;
+        incr += vr;
+      }
     }
-    if (lane == 63) s_scan[round & 1u][wid] = inc;
+    if (lane == 63) {
+      s_scan[round & 1u][wid] = inc;
+      s_rscan[round & 1u][wid] = incr;
+    }
     __syncthreads();
     uint32_t off = kept_before + inc - (uint32_t)kc, tile_total = 0;
+    uint32_t ridx = rst_before + incr - (uint32_t)rc, tile_rst = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; w++) {
-      const uint32_t v = s_scan[round & 1u][w];
-      if (w < wid) off += v;
+      const uint32_t v = s_scan[round & 1u][w], vr = s_rscan[round & 1u][w];
+      if (w < wid) {
+        off += v;
+        ridx += vr;
+      }
       tile_total += v;
+      tile_rst += vr;
     }
     kept_before += tile_total;
+    rst_before += tile_rst;
+    if (rc) {  // (rare) interval ridx + 1 begins at the clean offset behind this marker
+      uint32_t o = off;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t bit = 1u << (8 * (j & 3) + 7);
+        if (rstb[j >> 2] & bit) {
+          ++ridx;
+          if (ridx < ivl_cap) ivl[ridx] = o;
+        }
+        if (j < valid && !(drop[j >> 2] & bit)) o++;
+      }
+    }
     if (valid) {
       if ((mark[0] | mark[1] | mark[2] | mark[3]) != 0u) {  // the clean offset of the first marker in here
         uint32_t o = off;
@@ -701,19 +754,9 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
   if (t < 8) clean8[L + t] = 0;  // (zero bits are what libjpeg feeds past the end of the data; the buffer is padded)
   __threadfence_block();
   __syncthreads();
-  // ---- 2. segment end states until they stop changing ----
   const int ncomp = im.ncomp;
   const uint32_t nbits = L * 8u;
-  const uint32_t seg = max(64u, ((nbits + kParThreads - 1) / kParThreads + 31u) & ~31u);
-  const uint32_t limit = min((uint32_t)(t + 1) * seg, nbits);
-  const uint32_t segdw = seg >> 5, ndw = (L + 3u) >> 2;
-  uint32_t* trans = trans_all + ((im.stream_off + (uint32_t)blockIdx.x * (uint32_t)kTransSlack) >> 2);
-  for (uint32_t j = 0; j < segdw + kOverlap; j++) {  // the segment-major copy (zero bits past the end, as libjpeg feeds them)
-    const uint32_t b = (uint32_t)t * segdw + j;
-    trans[j * (uint32_t)kParThreads + (uint32_t)t] = b < ndw ? __builtin_bswap32(clean[b]) : 0u;
-  }
-  __threadfence_block();
-  __syncthreads();
+  const uint32_t ndw = (L + 3u) >> 2;
   ParGeom G;
   G.lum = im.h[0] * im.v[0];
   G.n1 = ncomp > 1 ? im.h[1] * im.v[1] : 0;
@@ -722,16 +765,61 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
                ((uint32_t)im.dc_slot[ncomp > 2 ? 2 : 0] << 16);
   G.ac_slots = (uint32_t)im.ac_slot[0] | ((uint32_t)im.ac_slot[ncomp > 1 ? 1 : 0] << 8) |
                ((uint32_t)im.ac_slot[ncomp > 2 ? 2 : 0] << 16);
+  const lds_u16 tab = (lds_u16)(&s_tab[0]);
+  const lds_u8 zz = (lds_u8)(&s_zz[0]);
+  uint32_t* coef32 = reinterpret_cast<uint32_t*>(coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t)));
+  if (ri) {
+    // ---- files with restart intervals: every interval starts in a known state (byte-aligned, first block of an MCU,
+    // DC prediction zero), so there is nothing to guess: thread t decodes intervals t, t + 256, ... straight into the
+    // coefficient buffer (the writing pass of the other files, over the clean stream as it lies) ----
+    const uint32_t nmcu = (uint32_t)(im.mcus_x * im.mcus_y);
+    const uint32_t want = (nmcu + (uint32_t)ri - 1u) / (uint32_t)ri, have = min(rst_before + 1u, ivl_cap);
+    const uint32_t n_use = min(want, have);
+    bool broken = have < want;  // a restart marker is missing (what the one-wave decoder reports, too)
+    if (t == 0) ivl[0] = 0u;
+    __threadfence_block();
+    __syncthreads();
+    G.trans = nullptr;
+    G.segdw = 1u;
+    G.magic = 0u;
+    ParWin W;
+    W.col = nullptr;
+    W.lin = clean;
+    W.rows = ndw;
+    W.gbase = 0u;
+    W.jb = W.w0 = W.w1 = 0u;
+    for (uint32_t j0 = 0; j0 < n_use; j0 += kParThreads) {
+      const uint32_t j = j0 + (uint32_t)t;
+      const bool live = j < n_use;
+      const uint32_t begin = live ? ivl[j] * 8u : 0u, end = live && j + 1u < have ? ivl[j + 1u] * 8u : nbits;
+      const uint32_t g = j * (uint32_t)ri * (uint32_t)G.m;
+      const uint32_t blocks = live ? min((uint32_t)ri, nmcu - j * (uint32_t)ri) * (uint32_t)G.m : 0u;
+      const uint32_t q = par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, 0u, begin, 0, 0, g, 0, coef32, g + blocks,
+                                   true);
+      broken = broken || (live && q > end);  // the interval's data ran out before its blocks did
+    }
+    if (broken) atomicOr(status, 2);
+    return;
+  }
+  // ---- 2. segment end states until they stop changing ----
+  const uint32_t seg = max(64u, ((nbits + kParThreads - 1) / kParThreads + 31u) & ~31u);
+  const uint32_t limit = min((uint32_t)(t + 1) * seg, nbits);
+  const uint32_t segdw = seg >> 5;
+  for (uint32_t j = 0; j < segdw + kOverlap; j++) {  // the segment-major copy (zero bits past the end, as libjpeg feeds them)
+    const uint32_t b = (uint32_t)t * segdw + j;
+    trans[j * (uint32_t)kParThreads + (uint32_t)t] = b < ndw ? __builtin_bswap32(clean[b]) : 0u;
+  }
+  __threadfence_block();
+  __syncthreads();
   G.trans = trans;
   G.segdw = segdw;
   G.magic = 0xFFFFFFFFu / segdw + 1u;
   ParWin W;
   W.col = trans + t;
+  W.lin = nullptr;
   W.rows = segdw + kOverlap;
   W.gbase = (uint32_t)t * segdw;
   W.jb = W.w0 = W.w1 = 0u;
-  const lds_u16 tab = (lds_u16)(&s_tab[0]);
-  const lds_u8 zz = (lds_u8)(&s_zz[0]);
   uint32_t sq = (uint32_t)t * seg, sck = 0;  // assumed start: first block of an MCU, DC next (true for t == 0)
   ParMarks marks;
 #pragma unroll
@@ -813,8 +901,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
     uint32_t q = t == 0 ? 0u : s_q[t];
     const uint32_t ck = t == 0 ? 0u : s_ck[t];
     int c = (int)(ck >> 8), k = (int)(ck & 255u);
-    uint32_t* coef32 = reinterpret_cast<uint32_t*>(coef_all + (size_t)blockIdx.x * (coef_stride / sizeof(int16_t)));
-    par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, pred, coef32, total_blocks,
+    (void)par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, pred, coef32, total_blocks,
               t == kParThreads - 1);
   }
 }
@@ -1092,7 +1179,14 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   }
   // which decoder takes which file: those without restart intervals first
   std::vector<uint32_t> index;
-  auto parallel = [&](int i) { return images[i].restart_interval == 0 && images[i].par_ok && !force_serial; };
+  auto parallel = [&](int i) {
+    const DevImage& im = images[i];
+    if (!im.par_ok || force_serial) return false;
+    if (im.restart_interval == 0) return true;
+    // restart intervals: the table of their start offsets must fit the scratch behind the clean stream
+    const size_t intervals = ((size_t)im.mcus_x * im.mcus_y + im.restart_interval - 1) / im.restart_interval;
+    return 4 * (intervals + 2) <= (size_t)im.stream_len + kTransSlack;
+  };
   for (int pass = 0; pass < 2; pass++)
     for (int i = 0; i < n; i++)
       if (parallel(i) == (pass == 0)) index.push_back((uint32_t)i);
