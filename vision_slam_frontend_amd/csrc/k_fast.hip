@@ -194,16 +194,14 @@ __device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
 //               segment, row-start table and counter, so downstream nothing changes.  (The pyramid's 50 levels leave a
 //               narrow remainder band almost everywhere: 510 -> 446 waves per 640x480 image.)
 // NMS = false (standalone FAST without suppression only) keeps every corner and a zero response.
+// (`work`: index into a.units, wave-uniform -- the work item and everything derived from it: level, band, strip, row
+// addresses, is scalar)
 template <bool HALF, bool NMS>
-__global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, int nwork) {
+__device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int image) {
   const int lane = threadIdx.x & 63;
-  // (readfirstlane: the work item and everything derived from it -- level, band, strip, row addresses -- is scalar)
-  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (item >= nwork) return;  // wave-uniform
-  const uint32_t ud = a.units[work0 + item];
+  const uint32_t ud = a.units[work];
   const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip0 = (int)(ud & 0x7FFF);
   const VsfLevel L = a.levels[level];
-  const int image = blockIdx.y;
   const uint8_t* src;
   int pitch;
   if (level == 0) {
@@ -388,6 +386,25 @@ __global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, 
   }
 }
 
+template <bool HALF, bool NMS>
+__global__ __launch_bounds__(256) void fast_march_kernel(FastArgs a, int work0, int nwork) {
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (item >= nwork) return;  // wave-uniform
+  fast_march_body<HALF, NMS>(a, work0 + item, blockIdx.y);
+}
+
+// Full cells and the half-wave cells of the narrow last bands in ONE launch, for batches that leave the chip nearly
+// empty: there a launch lasts as long as one cell's march, and two launches in a row last twice that.
+template <bool NMS>
+__global__ __launch_bounds__(256) void fast_march_both_kernel(FastArgs a, int nfull, int nhalf) {
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (item >= nfull + nhalf) return;  // wave-uniform
+  if (item < nfull)
+    fast_march_body<false, NMS>(a, item, blockIdx.y);
+  else
+    fast_march_body<true, NMS>(a, item, blockIdx.y);
+}
+
 // Standalone FAST detect: unit segments -> contiguous cv::KeyPoint list in raster order.
 __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restrict__ levels,
                                                         const uint32_t* __restrict__ cand, uint32_t cand_entries,
@@ -439,6 +456,14 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.threshold = threshold;
   a.nms = nms;
   const dim3 gf((g.nwork_full + 3) / 4, im.n), gh((g.nwork_half + 3) / 4, im.n);
+  if (im.n <= 16 && g.nwork_full > 0 && g.nwork_half > 0) {
+    const dim3 gb((g.nwork_full + g.nwork_half + 3) / 4, im.n);
+    if (nms)
+      hipLaunchKernelGGL((fast_march_both_kernel<true>), gb, dim3(256), 0, s, a, g.nwork_full, g.nwork_half);
+    else
+      hipLaunchKernelGGL((fast_march_both_kernel<false>), gb, dim3(256), 0, s, a, g.nwork_full, g.nwork_half);
+    return;
+  }
   if (nms) {
     if (g.nwork_full > 0) hipLaunchKernelGGL((fast_march_kernel<false, true>), gf, dim3(256), 0, s, a, 0, g.nwork_full);
     if (g.nwork_half > 0)
