@@ -21,6 +21,8 @@
 // wave (ballot masks in SGPRs, no workgroup barriers), the rare depth-limit / heap-select case by one lane.
 // The arrays live in LDS when they fit and in an HBM scratch area otherwise.
 #include "vsf_gather.h"
+#include <cstdlib>
+
 #include "vsf_internal.h"
 #include "vsf_select.h"
 
@@ -946,7 +948,16 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   // 5120 entries, three per CU 0.58 ms; 4096, four per CU 0.53 ms; 3072, five per CU 0.50 ms; 2560, six per CU 0.50 ms.
   a.nimages = im.n;
   const int n8 = (im.n + 7) / 8 * 8;
-  if (ntiny0 > 0) {
+  // A frame or two leaves the chip nearly empty and the stage lasts as long as its slowest workgroup -- level 0 of a
+  // 640x480 image: 8 500 candidates, 92 us of selection passes with 256 threads on an HBM-resident array, 39 us with 1 024
+  // threads on an LDS array that holds the whole level (105 KB, one workgroup per CU: at most 256 of them).
+  static const bool wide_off = std::getenv("VSF_SELECT_WIDE") && std::atoi(std::getenv("VSF_SELECT_WIDE")) == 0;
+  if (ntiny0 > 0 && !wide_off && (long)ntiny0 * im.n <= 256) {
+    if ((long)g.nlevels * im.n <= 256) ntiny0 = g.nlevels;  // ... and the small top levels ride along (one launch)
+    a.level0 = 0;
+    a.nlv = ntiny0;
+    hipLaunchKernelGGL((orb_select_kernel<1024, 12288, 512, 192>), dim3(a.nlv * n8), dim3(1024), 0, s, a);
+  } else if (ntiny0 > 0) {
     a.level0 = 0;
     a.nlv = ntiny0;
     hipLaunchKernelGGL((orb_select_kernel<256, 3072, 512, 64>), dim3(a.nlv * n8), dim3(256), 0, s, a);
