@@ -24,6 +24,8 @@
 // Output per unit: a candidate segment in unit-local raster order + the start offset of every row, which
 // vsf_gather.h merges into the level's global raster order.
 #include "vsf_gather.h"
+#include <cstdlib>
+
 #include "vsf_internal.h"
 
 namespace {
@@ -456,7 +458,8 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.threshold = threshold;
   a.nms = nms;
   const dim3 gf((g.nwork_full + 3) / 4, im.n), gh((g.nwork_half + 3) / 4, im.n);
-  if (im.n <= 16 && g.nwork_full > 0 && g.nwork_half > 0) {
+  static const int both_max = std::getenv("VSF_FAST_BOTH") ? std::atoi(std::getenv("VSF_FAST_BOTH")) : 16;
+  if (im.n <= both_max && g.nwork_full > 0 && g.nwork_half > 0) {
     const dim3 gb((g.nwork_full + g.nwork_half + 3) / 4, im.n);
     if (nms)
       hipLaunchKernelGGL((fast_march_both_kernel<true>), gb, dim3(256), 0, s, a, g.nwork_full, g.nwork_half);
