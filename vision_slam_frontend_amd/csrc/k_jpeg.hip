@@ -1255,10 +1255,16 @@ void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off
   const DevTables* tables = reinterpret_cast<const DevTables*>(d_blob + off_tables);
   const uint32_t* index = reinterpret_cast<const uint32_t*>(d_blob + off_index);
   if (n_par > 0) {
-    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(jpeg_par_decode_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         (int)(kMaxSlots * sizeof(DevHuff)));
-    (void)lds_ok;
+    {  // static + dynamic LDS exceed 64 KB for colour files: the limit is raised once per device
+      static bool raised[64] = {false};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jpeg_par_decode_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxSlots * sizeof(DevHuff)));
+        raised[dev] = true;
+      }
+    }
     hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n_par), dim3(kParThreads), (size_t)max_slots * sizeof(DevHuff), s, images, index, tables, d_blob + off_stream,
                        reinterpret_cast<uint32_t*>(d_clean),
                        reinterpret_cast<uint32_t*>(d_clean + vsf_jpeg_clean_bytes(total - off_stream, 0)), d_coef, coef_stride,

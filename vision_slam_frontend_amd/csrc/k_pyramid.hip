@@ -593,9 +593,16 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
       return e ? std::atoi(e) : 8;
     }();
     if (ok && chain_env > 0) {
-      static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_slab_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)lds_ok;
+      {  // the kernel's dynamic LDS exceeds the default limit: raised once per device (a process may drive several)
+        static bool raised[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_slab_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+          raised[dev] = true;
+        }
+      }
       const size_t fixed = kSlabFixedBytes;
       const size_t budget = 144 * 1024;
       for (int la = 1; la < g.nlevels;) {
