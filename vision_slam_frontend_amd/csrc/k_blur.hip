@@ -24,7 +24,7 @@ constexpr int kStripRows = VSF_BLUR_STRIP_ROWS; // output rows per wave
 
 struct BlurArgs {
   const VsfLevel* levels;
-  const uint32_t* units;  // level << 24 | band << 16 | strip
+  const uint32_t* units;  // level << 24 | band << 16 | two strips per wave << 15 | strip
   int nunits;
   const uint8_t* img0;
   size_t img0_stride;
@@ -76,15 +76,18 @@ __device__ __forceinline__ uint32_t round_fix16(uint32_t n, uint32_t tie_up) {
   return min(n + 0x7FFFu + b, 0x00FFFFFFu);
 }
 
-__global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
+// HALF = false: the wave is one unit, a band of 248 columns x a strip of 64 rows.
+// HALF = true : the level's LAST band is narrow (<= 120 columns = 30 lanes + 2 halo lanes) and the two 32-lane halves of
+//               the wave take it in two consecutive strips (the second half idles when the level ends first): the
+//               pyramid's widths leave such a remainder on most levels, 66 % -> 75 % of the lanes carry pixels.  The
+//               wave shifts of the row pass cross the halves only into halo lanes, whose sums nobody uses.
+template <bool HALF>
+__device__ __forceinline__ void blur_march_body(const BlurArgs& a, uint32_t ud, int image) {
   const int lane = threadIdx.x & 63;
-  // (readfirstlane: the unit and everything derived from it -- level, strip, row addresses -- stays on the scalar unit)
-  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (unit >= a.nunits) return;  // wave-uniform
-  const uint32_t ud = a.units[unit];
-  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip = (int)(ud & 0xFFFF);
+  const int hl = HALF ? (lane & 31) : lane;  // lane inside its cell
+  const bool upper = HALF && lane >= 32;    // the second strip's half
+  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip = (int)(ud & 0x7FFF);
   const VsfLevel L = a.levels[level];
-  const int image = blockIdx.y;
   const uint8_t* src;
   int pitch;
   if (level == 0) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
                  p_k1k0 = k1 | (k0 << 16), p_k0k1 = k0 | (k1 << 16), p_k2k3 = k2 | (k3 << 16),
                  p_k2k1 = k2 | (k1 << 16);
   const int w = L.w, h = L.h;
-  const int c0 = band * kBandCols - 4 + 4 * lane;  // first column of this lane's dword
+  const int c0 = band * kBandCols - 4 + 4 * hl;  // first column of this lane's dword
   // BORDER_REFLECT_101 columns without a divergent slow path: every column a lane can need lies in an aligned
   // 8-byte window [a0, a0 + 8) of the row (a0 = c0 inside the image, 0 left of it, (w - 4) & ~3 at the right edge;
   // level widths are >= 8), so a lane loads that window's two dwords and picks its 4 bytes with one v_perm_b32.
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, pitch * L.h, 0x00020000);
   const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, L.pitch * ((L.h + 7) & ~7), 0x00020000);
   const bool all_interior = __all(interior);
-  const bool writer = lane >= 1 && lane <= 62 && c0 < w;
-  const int ys = strip * kStripRows, ye = min(ys + kStripRows, h);
+  const bool writer = hl >= 1 && hl <= (HALF ? 30 : 62) && c0 < w;
+  const int ys = strip * kStripRows, ye = min(ys + kStripRows, h);  // (the first strip: never the shorter one)
   const uint32_t t0 = c0 + 0 < L.blur_vec_end ? 0u : 1u, t1 = c0 + 1 < L.blur_vec_end ? 0u : 1u,
                  t2 = c0 + 2 < L.blur_vec_end ? 0u : 1u, t3 = c0 + 3 < L.blur_vec_end ? 0u : 1u;
 
@@ -142,8 +145,15 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
     // buffer load: lane offset in a VGPR, row offset in an SGPR -- no vector address arithmetic per row
     const uint32_t row_off = (uint32_t)reflect101(y, h) * (uint32_t)pitch;  // scalar
     Raw r;
-    r.d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a0, row_off, 0);
-    r.d1 = all_interior ? 0u : __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a1, row_off, 0);  // wave-uniform
+    if constexpr (HALF) {  // two rows, one per half: the row offset joins the lane offset
+      const uint32_t row_up = (uint32_t)reflect101(y + kStripRows, h) * (uint32_t)pitch;  // scalar
+      const uint32_t ro = upper ? row_up : row_off;
+      r.d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a0 + ro, 0, 0);
+      r.d1 = all_interior ? 0u : __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a1 + ro, 0, 0);  // wave-uniform
+    } else {
+      r.d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a0, row_off, 0);
+      r.d1 = all_interior ? 0u : __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, a1, row_off, 0);  // wave-uniform
+    }
     return r;
   };
   auto unpack = [&](const Raw& r) -> Px4 {
@@ -162,14 +172,20 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
     const uint32_t n1 = dot2(rlo, p_k0_0, dot2(chi, p_k2k1, dot2(clo, p_k2k3, dot2(lhi, p_k0k1, 0u))));
     const uint32_t n2 = dot2(rlo, p_k1k0, dot2(chi, p_k3k2, dot2(clo, p_k1k2, dot2(lhi, p_0k0, 0u))));
     const uint32_t n3 = dot2(rhi, p_k0_0, dot2(rlo, p_k2k1, dot2(chi, p_k2k3, dot2(clo, p_k0k1, 0u))));
-    if (writer) {
+    if (writer && (!HALF || !upper || y + kStripRows < h)) {
       const uint32_t v0 = round_fix16(n0, t0), v1 = round_fix16(n1, t1), v2 = round_fix16(n2, t2),
                      v3 = round_fix16(n3, t3);
       // byte 2 of each value -> bytes 0..3
       const uint32_t lo2 = __builtin_amdgcn_perm(v1, v0, 0x0C0C0602u), hi2 = __builtin_amdgcn_perm(v3, v2, 0x06020C0Cu);
       // tiled store (VSF_BLUR_TILE_OFFSET): the row part is scalar, the lane part loop-invariant (c0 % 4 == 0)
       const uint32_t drow = (uint32_t)(y >> 2) * (uint32_t)(L.pitch * 4) + (uint32_t)((y & 3) << 5);
-      __builtin_amdgcn_raw_buffer_store_b32(lo2 | hi2, dst_rsrc, tile_col, drow, 0);
+      if constexpr (HALF) {
+        const int yu = y + kStripRows;
+        const uint32_t drow_up = (uint32_t)(yu >> 2) * (uint32_t)(L.pitch * 4) + (uint32_t)((yu & 3) << 5);
+        __builtin_amdgcn_raw_buffer_store_b32(lo2 | hi2, dst_rsrc, tile_col + (upper ? drow_up : drow), 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(lo2 | hi2, dst_rsrc, tile_col, drow, 0);
+      }
     }
   };
 
@@ -199,6 +215,17 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
     VSF_BLUR_STEP(6, W6, W0, W1, W2, W3, W4, W5)
   }
 #undef VSF_BLUR_STEP
+}
+
+__global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
+  // (readfirstlane: the unit and everything derived from it -- level, strip, row addresses -- stays on the scalar unit)
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (unit >= a.nunits) return;  // wave-uniform
+  const uint32_t ud = a.units[unit];
+  if (ud & 0x8000u)  // (wave-uniform) two strips of a narrow last band
+    blur_march_body<true>(a, ud, blockIdx.y);
+  else
+    blur_march_body<false>(a, ud, blockIdx.y);
 }
 
 }  // namespace

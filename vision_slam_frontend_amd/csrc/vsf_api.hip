@@ -232,10 +232,20 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
     }
     for (int l = 0; l < nlevels; l++) {
       const VsfLevel& L = G.levels[l];
-      // blur work units: (level, 248-column band, 64-row strip), one wave each
-      for (int st = 0; st * VSF_BLUR_STRIP_ROWS < L.h; st++)
-        for (int b = 0; b * VSF_BLUR_BAND_COLS < L.w; b++)
-          G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)st);
+      // blur work units: (level, 248-column band, 64-row strip), one wave each -- except that a narrow last band
+      // (<= 120 columns) is walked two strips per wave (k_blur.hip: bit 15)
+      const int nb = (L.w + VSF_BLUR_BAND_COLS - 1) / VSF_BLUR_BAND_COLS;
+      const int ns = (L.h + VSF_BLUR_STRIP_ROWS - 1) / VSF_BLUR_STRIP_ROWS;
+      static const bool half_off = std::getenv("VSF_BLUR_HALF") && std::atoi(std::getenv("VSF_BLUR_HALF")) == 0;
+      const bool half_last = !half_off && ns >= 2 && L.w - VSF_BLUR_BAND_COLS * (nb - 1) <= 120;
+      for (int st = 0; st < ns; st++)
+        for (int b = 0; b < nb; b++) {
+          if (half_last && b == nb - 1) {
+            if ((st & 1) == 0) G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | 0x8000u | (uint32_t)st);
+          } else {
+            G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)st);
+          }
+        }
     }
   }
   if (G.xt.empty()) G.xt.push_back(VsfTap{0, 0, 0, 0});
