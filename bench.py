@@ -166,7 +166,22 @@ class JpegIngest:
         self.avg_kb = sum(len(f) for f in self.files) / self.n_files / 1024
         self.ptrs = (C.c_void_p * self.n_files)(*[f.ctypes.data for f in self.files])
         self.sizes = (C.c_size_t * self.n_files)(*[len(f) for f in self.files])
-        self.stream = torch.cuda.Stream(device=dev)
+        # The decode should only fill what the extraction leaves free: the LOWEST stream priority.  torch offers two
+        # levels (and the step's tail already has the high one); HIP has a third, so the stream is made with HIP itself.
+        self.stream = None
+        if os.environ.get("VSF_BENCH_INGEST_PRIO", "low") == "low":
+            try:
+                hip = C.CDLL("libamdhip64.so")
+                least, greatest, h = C.c_int(0), C.c_int(0), C.c_void_p()
+                if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0 and \
+                        hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), least) == 0 and h.value:
+                    self.stream = torch.cuda.ExternalStream(h.value, device=dev)
+                    self.stream_priority = least.value
+            except OSError:
+                pass
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+            self.stream_priority = 0
         self.ctx = capi.Context(capi.default_params(width, height, max_images=2, nfeatures=nfeatures), device=device_index)
         self.ctx.set_stream(self.stream.cuda_stream)
         self.d_mosaic = torch.empty((self.n_files, height, width), dtype=torch.uint8, device=dev)
@@ -386,8 +401,9 @@ def main() -> int:
                        "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "scene": args.scene,
                        "ingest": "frames resident in HBM" if args.ingest == "hbm" else
                                  "per step: %d baseline-JPEG files of %.0f KB (quality 80) from host memory -> upload -> "
-                                 "vsf_jpeg_decode_gray_batch -> Bayer->gray, one step ahead on its own stream"
-                                 % (ingest.n_files, ingest.avg_kb),
+                                 "vsf_jpeg_decode_gray_batch -> Bayer->gray, one step ahead on its own stream "
+                                 "(HIP stream priority %d: it fills what the extraction leaves free)"
+                                 % (ingest.n_files, ingest.avg_kb, ingest.stream_priority),
                        "parallelism": "frames sharded over %d GPU(s)%s" %
                                       (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
                                               "(RCCL)" if world > 1 else ""),
