@@ -228,6 +228,185 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
     blur_march_body<false>(a, ud, blockIdx.y);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same blur on the MATRIX cores.  The march kernel above issues vector-ALU instructions at 79 % of the
+// chip's rate (86 wave-instructions per 256 pixels); both passes are banded-Toeplitz products, so they can leave the
+// vector ALU altogether:
+//   pass 1 (rows of the separable filter = horizontal):  R[y][x] = sum_c  (Img[y][c] - 128) * T[c][x]  + 128 * sum k
+//            v_mfma_i32_32x32x32_i8: A = 32 image rows x 32 columns straight from memory (one 16-byte load per lane,
+//            v_xor 0x80 makes the bytes signed), B = the 32 x 32 band of T (a constant operand: BORDER_REFLECT_101 of
+//            the columns is folded into the weights of the level's first / last tiles on the host), C = the bias, so
+//            R = sum k_j p_j exactly, 0 .. 65535.  An output tile of 32 columns takes the two operands that cover
+//            columns [32 c - 16, 32 c + 48).
+//   pass 2 (columns = vertical):  the accumulator layout of pass 1 (column on the lane, 16 rows in the registers) IS
+//            the A-operand layout of the next MFMA (cdna guide, "an accumulator tile as the next MFMA's operand"), so R
+//            never moves between lanes: its low and high bytes are zero-extended to 16 bit with one v_perm_b32 per pair
+//            of values -- a byte b in a 16-bit half is the f16 DENORMAL b * 2^-24, which v_mfma_f32_32x32x16_f16 takes
+//            without flushing (tools/exp/mfma_probe.hip: 204 800 sums, all exact) -- and multiplied by the taps k_i
+//            (low bytes) resp. 256 k_i (high bytes), both exact f16 numbers; the f32 accumulator starts at -0.5 and ends
+//            as N * 2^-24 - 0.5 with N = sum k_i R_i < 2^24.01: every partial sum is an integer multiple of 2^-24 below
+//            2^24 of them in magnitude, i.e. exact.
+//   rounding: t = acc * 256 + 128 = N / 65536 exactly (below 256; above it saturates), v_cvt_pk_u8_f32 rounds to nearest
+//            even, saturates and inserts the byte (probe: 2 083 values incl. every tie) = cvtps2dq + packus of OpenCV's
+//            SSE2 column pass; the <= 3 scalar-tail columns of a level (half-up) take floor(t + 0.5) first.
+//   layout:  pass 2 leaves an output row on a lane (4 x 4 columns per half wave); two v_permlane32_swap give each lane 16
+//            contiguous bytes and the tile is written with ONE 16-byte store per lane: eight whole 128-byte lines of the
+//            tiled blurred level.
+// A wave owns a band of two column tiles (64 columns) and walks down a strip in steps of 26 output rows: a step loads 32
+// rows (row reflection by address: lane = row), so a step is stateless -- no ring of row sums in registers, and any list
+// of (band, step) units works (round 3's sparse mode blurs only the tiles descriptors read).  Per step and tile: 2 int8 +
+// 4 f16 MFMAs and ~65 vector instructions per lane for 832 pixels (the march kernel: ~280 per 832).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+constexpr int kMmaRows = VSF_BLUR_MMA_ROWS;  // output rows per step (32 loaded rows - 6)
+
+struct BlurMmaArgs {
+  const VsfLevel* levels;
+  const uint32_t* units;  // level << 24 | band << 16 | first step << 8 | steps
+  int nunits;
+  const uint8_t* img0;
+  size_t img0_stride;
+  int img0_pitch;
+  const uint8_t* pyr;
+  uint8_t* blur;
+  uint32_t pyr_bytes;
+  const uint4* tcol;  // [level's blur_tcol + 4 band + {L0, R0, L1, R1}][64 lanes]: B operands of pass 1
+  const uint4* tv;    // [{lo k-step 0, lo k-step 1, hi k-step 0, hi k-step 1}][64 lanes]: B operands of pass 2
+  int bias;           // 128 * sum of the taps
+};
+
+__device__ __forceinline__ v4i as_v4i(uint4 v) { return __builtin_bit_cast(v4i, v); }
+
+// TAIL: the band holds columns of the level's scalar tail (x >= blur_vec_end, rounded half-up); wave-uniform, a template
+// parameter so that the other bands' code carries none of it.
+template <bool TAIL>
+__device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLevel& L, int level, int band, int step0,
+                                              int nsteps, int image) {
+  const uint8_t* src;
+  int pitch;
+  if (level == 0) {
+    src = a.img0 + (size_t)image * a.img0_stride;
+    pitch = a.img0_pitch;
+  } else {
+    src = a.pyr + (size_t)image * a.pyr_bytes + L.offset;
+    pitch = L.pitch;
+  }
+  uint8_t* dst = a.blur + (size_t)image * a.pyr_bytes + L.offset;
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int h = L.h;
+  const __amdgpu_buffer_rsrc_t src_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, pitch * h, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, L.pitch * ((h + 7) & ~7), 0x00020000);
+  // constant operands
+  const uint4* tc = a.tcol + ((size_t)L.blur_tcol + (size_t)band * 4) * 64 + lane;
+  const v4i TL0 = as_v4i(tc[0]), TR0 = as_v4i(tc[64]), TL1 = as_v4i(tc[128]), TR1 = as_v4i(tc[192]);
+  const v8h VL0 = __builtin_bit_cast(v8h, a.tv[lane]), VL1 = __builtin_bit_cast(v8h, a.tv[64 + lane]),
+            VH0 = __builtin_bit_cast(v8h, a.tv[128 + lane]), VH1 = __builtin_bit_cast(v8h, a.tv[192 + lane]);
+  v16i bias;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    bias[i] = a.bias;
+    asm volatile("" : "+v"(bias[i]));  // stays in its registers (the compiler would otherwise re-create it per MFMA)
+  }
+  // column part of the lane's load address: the band's first operand starts 16 columns left of its first tile (left of
+  // the image the offset wraps, far beyond the buffer's end: the load returns 0, and the weights there are 0 anyway)
+  const int col_off = band * 64 - 16 + 16 * hh;
+  const int vec_end = L.blur_vec_end;
+  const uint32_t pitch4 = (uint32_t)(L.pitch * 4);
+
+  struct Q3 {
+    v4i q0, q1, q2;
+  };
+  auto request = [&](int step) -> Q3 {
+    const int y = reflect101(step * kMmaRows - 3 + r, h);
+    const uint32_t off = (uint32_t)(y * pitch + col_off);
+    Q3 q;
+    q.q0 = as_v4i(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0)));
+    q.q1 = as_v4i(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off + 32, 0, 0)));
+    q.q2 = as_v4i(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off + 64, 0, 0)));
+    return q;
+  };
+  auto sgn = [](v4i q) -> v4i { return q ^ (int)0x80808080; };
+  // pass 2 + rounding + store of one tile: racc = row sums (lane = column, registers = rows)
+  auto finish = [&](const v16i& racc, uint32_t row_off, bool writer, int tile) {
+    v4i lo0, lo1, hi0, hi1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      lo0[i] = (int)__builtin_amdgcn_perm((uint32_t)racc[2 * i + 1], (uint32_t)racc[2 * i], 0x0C040C00u);
+      hi0[i] = (int)__builtin_amdgcn_perm((uint32_t)racc[2 * i + 1], (uint32_t)racc[2 * i], 0x0C050C01u);
+      lo1[i] = (int)__builtin_amdgcn_perm((uint32_t)racc[8 + 2 * i + 1], (uint32_t)racc[8 + 2 * i], 0x0C040C00u);
+      hi1[i] = (int)__builtin_amdgcn_perm((uint32_t)racc[8 + 2 * i + 1], (uint32_t)racc[8 + 2 * i], 0x0C050C01u);
+    }
+    v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = -0.5f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo0), VL0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo1), VL1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi0), VH0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi1), VH1, acc, 0, 0, 0);
+    // lane = output row, register i = column (i & 3) + 8 (i >> 2) + 4 hh of the tile
+    uint32_t d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t w;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float t = __builtin_fmaf(acc[4 * j + i], 256.f, 128.f);
+        if (TAIL) {
+          const int col = band * 64 + tile * 32 + 8 * j + 4 * hh + i;
+          t = col >= vec_end ? __builtin_floorf(t + 0.5f) : t;
+        }
+        if (i == 0)
+          asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(w) : "v"(t));
+        else
+          asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(w) : "v"(t), "n"(i));
+      }
+      d[j] = w;
+    }
+    auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    if (writer) {
+      typedef unsigned int u4 __attribute__((__vector_size__(16)));
+      const u4 v = {s02[0], s02[1], s13[0], s13[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(v, dst_rsrc, row_off + (uint32_t)((band * 2 + tile) << 7), 0, 0);
+    }
+  };
+
+  Q3 cur = request(step0);
+  for (int s = 0; s < nsteps; s++) {
+    const int step = step0 + s;
+    Q3 nxt = cur;
+    if (s + 1 < nsteps) nxt = request(step + 1);  // wave-uniform
+    const v4i q0 = sgn(cur.q0), q1 = sgn(cur.q1), q2 = sgn(cur.q2);
+    v16i r0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q0, TL0, bias, 0, 0, 0);
+    r0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, TR0, r0, 0, 0, 0);
+    v16i r1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, TL1, bias, 0, 0, 0);
+    r1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q2, TR1, r1, 0, 0, 0);
+    const int yo = step * kMmaRows + r;
+    const bool writer = r < kMmaRows && yo < h;
+    const uint32_t row_off = (uint32_t)(yo >> 2) * pitch4 + (uint32_t)((yo & 3) << 5) + (uint32_t)(16 * hh);
+    finish(r0, row_off, writer, 0);
+    finish(r1, row_off, writer, 1);
+    cur = nxt;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void blur_mma_kernel(BlurMmaArgs a) {
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (unit >= a.nunits) return;  // wave-uniform
+  const uint32_t ud = a.units[unit];
+  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), step0 = (int)((ud >> 8) & 0xFF), nsteps = (int)(ud & 0xFF);
+  const VsfLevel L = a.levels[level];
+  if (band * 64 + 64 > L.blur_vec_end)  // (wave-uniform) the band reaches into the scalar-tail columns
+    blur_mma_body<true>(a, L, level, band, step0, nsteps, blockIdx.y);
+  else
+    blur_mma_body<false>(a, L, level, band, step0, nsteps, blockIdx.y);
+}
+
 }  // namespace
 
 void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_units, int nunits,
@@ -247,4 +426,22 @@ void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, con
   a.k2 = k[2];
   a.k3 = k[3];
   hipLaunchKernelGGL(blur_march_kernel, dim3((nunits + 3) / 4, im.n), dim3(256), 0, s, a);
+}
+
+void vsf_launch_blur_mma(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_units, int nunits,
+                         const uint4* d_tcol, const uint4* d_tv, int bias, hipStream_t s) {
+  BlurMmaArgs a;
+  a.levels = d.levels;
+  a.units = d_units;
+  a.nunits = nunits;
+  a.img0 = im.base;
+  a.img0_stride = im.image_stride;
+  a.img0_pitch = (int)im.row_stride;
+  a.pyr = d.pyr;
+  a.blur = d.blur;
+  a.pyr_bytes = g.pyr_bytes;
+  a.tcol = d_tcol;
+  a.tv = d_tv;
+  a.bias = bias;
+  hipLaunchKernelGGL(blur_mma_kernel, dim3((nunits + 3) / 4, im.n), dim3(256), 0, s, a);
 }

@@ -36,6 +36,10 @@ struct Geometry {
   std::vector<uint32_t> units;
   std::vector<VsfTap> xt, yt;
   std::vector<uint32_t> blur_tiles;
+  // matrix-core blur (k_blur.hip blur_mma_kernel): work units and constant MFMA operands
+  std::vector<uint32_t> blur_mma_units;
+  std::vector<uint4> blur_tcol, blur_tv;
+  int blur_bias = 0;
 };
 
 // cv::resize(INTER_LINEAR, 8u) coefficient tables for one level (source sw x sh -> dw x dh).
@@ -82,6 +86,84 @@ std::vector<int> orb_umax(int patch_size) {
     ++v0;
   }
   return umax;
+}
+
+void gaussian_taps(int k[4]);
+
+inline int reflect101_host(int p, int len) {
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * len - 2 - p;
+  return p < 0 ? 0 : (p >= len ? len - 1 : p);
+}
+
+uint16_t f16_bits_of_small_int(int v) {  // exact binary16 encoding of an integer 0 <= v < 2048 * 32
+  if (v == 0) return 0;
+  int e = 0;
+  while ((v >> (e + 1)) != 0) e++;           // v = 1.m * 2^e
+  const int mant = e <= 10 ? (v << (10 - e)) & 0x3FF : (v >> (e - 10)) & 0x3FF;  // (exact: callers pass <= 11 significant bits)
+  return (uint16_t)(((e + 15) << 10) | mant);
+}
+
+// Constant operands of the matrix-core blur (k_blur.hip).
+//  pass 1, per level and 64-column band: four 32 x 32 int8 bands of the row filter, {L0, R0, L1, R1}: tile t = 2 band + j
+//  takes operand Lj with the image columns [32 t - 16, 32 t + 16) and Rj with [32 t + 16, 32 t + 48); lane (n, h) holds, in
+//  byte s, the weight of image column (operand's first column) + 16 h + s for output column 32 t + n -- BORDER_REFLECT_101
+//  folded in: a reflected column's tap is added to the weight of the column it reflects onto.
+//  pass 2, once: four 16 x 32 f16 operands {lo k-step 0, lo k-step 1, hi k-step 0, hi k-step 1}: lane (n, h) element j is
+//  the tap of loaded row 16 s + 8 (j >> 2) + 4 h + (j & 3) for output row n + 3 of the 32 loaded rows (n < 26), times 256
+//  for the high byte of the row sums.
+void build_blur_mma_tables(Geometry* G) {
+  int k4[4];
+  gaussian_taps(k4);
+  const int k[7] = {k4[0], k4[1], k4[2], k4[3], k4[2], k4[1], k4[0]};
+  G->blur_bias = 128 * (k[0] + k[1] + k[2] + k[3] + k[4] + k[5] + k[6]);
+  G->blur_tcol.clear();
+  G->blur_mma_units.clear();
+  for (size_t l = 0; l < G->levels.size(); l++) {
+    VsfLevel& L = G->levels[l];
+    L.blur_tcol = (uint32_t)(G->blur_tcol.size() / 64);
+    const int nbands = (L.w + 63) / 64;
+    for (int b = 0; b < nbands; b++)
+      for (int op = 0; op < 4; op++) {
+        const int tile = 2 * b + (op >> 1);
+        const int first = 32 * tile - 16 + 32 * (op & 1);
+        for (int lane = 0; lane < 64; lane++) {
+          const int n = lane & 31, h = lane >> 5, x = 32 * tile + n;
+          int8_t wgt[16] = {0};
+          if (x < L.w)
+            for (int j = 0; j < 7; j++) {
+              const int c = reflect101_host(x + j - 3, L.w) - (first + 16 * h);
+              if (c >= 0 && c < 16) wgt[c] = (int8_t)(wgt[c] + k[j]);
+            }
+          uint4 v;
+          memcpy(&v, wgt, 16);
+          G->blur_tcol.push_back(v);
+        }
+      }
+    // units: (band, strip of <= VSF_BLUR_MMA_STEPS steps), the bands of a strip next to each other (a workgroup's four
+    // waves then share the operand between two bands through the L1)
+    const int nsteps = (L.h + VSF_BLUR_MMA_ROWS - 1) / VSF_BLUR_MMA_ROWS;
+    const int nstrips = (nsteps + VSF_BLUR_MMA_STEPS - 1) / VSF_BLUR_MMA_STEPS;
+    for (int st = 0; st < nstrips; st++) {
+      const int s0 = (int)((long long)nsteps * st / nstrips), s1 = (int)((long long)nsteps * (st + 1) / nstrips);
+      for (int b = 0; b < nbands; b++)
+        G->blur_mma_units.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | ((uint32_t)s0 << 8) | (uint32_t)(s1 - s0));
+    }
+  }
+  G->blur_tv.clear();
+  for (int op = 0; op < 4; op++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int n = lane & 31, h = lane >> 5, s = op & 1;
+      uint16_t e[8];
+      for (int j = 0; j < 8; j++) {
+        const int row = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3), d = row - n;
+        const int tap = (n < VSF_BLUR_MMA_ROWS && d >= 0 && d < 7) ? k[d] : 0;
+        e[j] = f16_bits_of_small_int(op >= 2 ? tap * 256 : tap);
+      }
+      uint4 v;
+      memcpy(&v, e, 16);
+      G->blur_tv.push_back(v);
+    }
 }
 
 // orb == true: the 50-level ORB pyramid with edge-threshold border; false: one full-resolution level with the
@@ -251,6 +333,17 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
   if (G.xt.empty()) G.xt.push_back(VsfTap{0, 0, 0, 0});
   if (G.yt.empty()) G.yt.push_back(VsfTap{0, 0, 0, 0});
   if (G.blur_tiles.empty()) G.blur_tiles.push_back(0);
+  if (orb) {
+    // matrix-core blur: taps must be int8, the row sums 16 bit, bands / steps fit the unit word
+    int k4[4];
+    gaussian_taps(k4);
+    const int ksum = 2 * (k4[0] + k4[1] + k4[2]) + k4[3];
+    if (ksum > 257 || k4[3] > 127 || G.levels[0].w > 64 * 255 || G.levels[0].h > VSF_BLUR_MMA_ROWS * 255) return false;
+    build_blur_mma_tables(&G);
+  }
+  if (G.blur_mma_units.empty()) G.blur_mma_units.push_back(0);
+  if (G.blur_tcol.empty()) G.blur_tcol.push_back(make_uint4(0, 0, 0, 0));
+  if (G.blur_tv.empty()) G.blur_tv.push_back(make_uint4(0, 0, 0, 0));
   return true;
 }
 
@@ -296,6 +389,9 @@ struct DevSet {  // device copies of one Geometry + its work buffers
   VsfLevel* levels = nullptr;
   uint32_t* units = nullptr;
   uint32_t* blur_tiles = nullptr;
+  uint32_t* blur_mma_units = nullptr;
+  uint4* blur_tcol = nullptr;
+  uint4* blur_tv = nullptr;
   uint2* ic_table = nullptr;
   bool ready = false;
 };
@@ -436,6 +532,9 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   VSF_HIP(upload(&ds->levels, G.levels));
   VSF_HIP(upload(&ds->units, G.units));
   VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
+  VSF_HIP(upload(&ds->blur_mma_units, G.blur_mma_units));
+  VSF_HIP(upload(&ds->blur_tcol, G.blur_tcol));
+  VSF_HIP(upload(&ds->blur_tv, G.blur_tv));
   VSF_HIP(upload(&ds->ic_table, build_ic_table()));
   VsfDev& d = ds->d;
   d.ic_table = ds->ic_table;
@@ -463,6 +562,9 @@ void free_devset(DevSet* ds) {
   hipFree(ds->levels);
   hipFree(ds->units);
   hipFree(ds->blur_tiles);
+  hipFree(ds->blur_mma_units);
+  hipFree(ds->blur_tcol);
+  hipFree(ds->blur_tv);
   hipFree(ds->ic_table);
   hipFree(ds->d.pyr);
   hipFree(ds->d.blur);
@@ -675,7 +777,13 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_BLUR, 1);
-    vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, st);
+    // VSF_BLUR=march: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
+    static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
+    if (march)
+      vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, st);
+    else
+      vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units, (int)ctx->orb.blur_mma_units.size(), ctx->dorb.blur_tcol,
+                          ctx->dorb.blur_tv, ctx->orb.blur_bias, st);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);

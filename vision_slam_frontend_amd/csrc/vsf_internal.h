@@ -15,6 +15,8 @@
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
 #define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
+#define VSF_BLUR_MMA_ROWS 26     // output rows per step of the matrix-core blur (32 loaded rows - 2 x 3 halo rows)
+#define VSF_BLUR_MMA_STEPS 8     // steps per unit (a wave walks this many steps down its 64-column band)
 // The blurred levels are stored in tiles of 4 rows x 32 bytes (= one 128-byte cache line), tiles in row-major order:
 // the descriptor kernel gathers 39 x 39 windows from them and a window then touches ~24 lines instead of 39..78,
 // while the blur kernel still writes whole 32-byte sectors (8 lanes x 4 bytes).
@@ -45,6 +47,7 @@ struct VsfLevel {
   int32_t resize_rows;     // largest strip height (16, 8, 4) the shared-row resize kernel may use for this level, or 0
   int32_t resize_any8;     // 1: an 8-row strip starting at ANY row stays inside 10 consecutive source rows
   uint32_t rscale_x[2], rscale_y[2];  // bit patterns of cv::resize's double scale_x / scale_y from level - 1 (host-computed)
+  uint32_t blur_tcol;      // matrix-core blur: index of this level's first pass-1 operand (4 per 64-column band) in the table
 };
 
 // Resize coefficients of one output column / row (cv::resize INTER_LINEAR 8u: xofs/ialpha resp. yofs/ibeta with the
@@ -120,6 +123,9 @@ void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n
                                  int* d_out_n, hipStream_t s);
 void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_tiles, int ntiles,
                      const int k[4], hipStream_t s);
+// Matrix-core blur (k_blur.hip, round 3): units = level << 24 | band << 16 | first step << 8 | steps.
+void vsf_launch_blur_mma(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_units, int nunits,
+                         const uint4* d_tcol, const uint4* d_tv, int bias, hipStream_t s);
 void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int max_keypoints,
                          vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts, hipStream_t s);
 void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int max_keypoints, vsf_keypoint* d_kp,
