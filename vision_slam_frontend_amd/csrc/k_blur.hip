@@ -234,11 +234,10 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
 // chip's rate (86 wave-instructions per 256 pixels); both passes are banded-Toeplitz products, so they can leave the
 // vector ALU altogether:
 //   pass 1 (rows of the separable filter = horizontal):  R[y][x] = sum_c  (Img[y][c] - 128) * T[c][x]  + 128 * sum k
-//            v_mfma_i32_32x32x32_i8: A = 32 image rows x 32 columns straight from memory (one 16-byte load per lane,
-//            v_xor 0x80 makes the bytes signed), B = the 32 x 32 band of T (a constant operand: BORDER_REFLECT_101 of
-//            the columns is folded into the weights of the level's first / last tiles on the host), C = the bias, so
-//            R = sum k_j p_j exactly, 0 .. 65535.  An output tile of 32 columns takes the two operands that cover
-//            columns [32 c - 16, 32 c + 48).
+//            v_mfma_i32_32x32x32_i8: A = 32 image rows x 32 columns (16 bytes per lane, v_xor 0x80 makes them signed),
+//            B = the 32 x 32 band of T (a constant operand: BORDER_REFLECT_101 of the columns is folded into the weights of
+//            the level's first / last tiles on the host), C = the bias, so R = sum k_j p_j exactly, 0 .. 65535.  An output
+//            tile of 32 columns takes the two operands that cover columns [32 c - 16, 32 c + 48).
 //   pass 2 (columns = vertical):  the accumulator layout of pass 1 (column on the lane, 16 rows in the registers) IS
 //            the A-operand layout of the next MFMA (cdna guide, "an accumulator tile as the next MFMA's operand"), so R
 //            never moves between lanes: its low and high bytes are zero-extended to 16 bit with one v_perm_b32 per pair
@@ -253,21 +252,28 @@ __global__ __launch_bounds__(256) void blur_march_kernel(BlurArgs a) {
 //   layout:  pass 2 leaves an output row on a lane (4 x 4 columns per half wave); two v_permlane32_swap give each lane 16
 //            contiguous bytes and the tile is written with ONE 16-byte store per lane: eight whole 128-byte lines of the
 //            tiled blurred level.
-// A wave owns a band of two column tiles (64 columns) and walks down a strip in steps of 26 output rows: a step loads 32
-// rows (row reflection by address: lane = row), so a step is stateless -- no ring of row sums in registers, and any list
-// of (band, step) units works (round 3's sparse mode blurs only the tiles descriptors read).  Per step and tile: 2 int8 +
-// 4 f16 MFMAs and ~65 vector instructions per lane for 832 pixels (the march kernel: ~280 per 832).
+// A wave computes 26 output rows x 64 columns (two tiles) per step from 32 rows x 96 columns of the source (row reflection
+// by address), statelessly: no ring of row sums in registers.  The source reaches the A operands through LDS: loading them
+// straight from memory (lane = row: 32 rows x 32 bytes per instruction) kept the texture addresser busy with 32 cache lines
+// per instruction and fetched every line 2.7 times (measured: 0.85 ms per step for loads + arithmetic against 0.47 for the
+// arithmetic alone).  A workgroup of four waves = 2 bands x 2 steps shares a block of 58 rows x 256 bytes, fetched in
+// whole 128-byte rows by buffer_load_dwordx4 ... lds (8 rows per instruction, no registers, no vector-ALU work), double
+// buffered, one workgroup barrier per block; the image is XOR-swizzled through the SOURCE address (slot (rho, s) of a piece
+// holds chunk s ^ rho of row rho) and the pieces of odd piece rows start 128 bytes later, which makes every ds_read_b128
+// of an operand conflict-free (checked for all lane groups).
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
 constexpr int kMmaRows = VSF_BLUR_MMA_ROWS;  // output rows per step (32 loaded rows - 6)
+constexpr int kPieceRowStride = 2 * 1024 + 128;  // LDS bytes per piece row (two 1-KB pieces; odd rows shifted by half a bank row)
+constexpr int kBlockBytes = 8 * kPieceRowStride;  // one staged block: 64 rows x 256 bytes
 
 struct BlurMmaArgs {
   const VsfLevel* levels;
-  const uint32_t* units;  // level << 24 | band << 16 | first step << 8 | steps
-  int nunits;
+  const uint32_t* units;  // level << 24 | band pair << 16 | first double step << 8 | double steps
+  int nunits, nimages;
   const uint8_t* img0;
   size_t img0_stride;
   int img0_pitch;
@@ -281,11 +287,13 @@ struct BlurMmaArgs {
 
 __device__ __forceinline__ v4i as_v4i(uint4 v) { return __builtin_bit_cast(v4i, v); }
 
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
 // TAIL: the band holds columns of the level's scalar tail (x >= blur_vec_end, rounded half-up); wave-uniform, a template
 // parameter so that the other bands' code carries none of it.
 template <bool TAIL>
-__device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLevel& L, int level, int band, int step0,
-                                              int nsteps, int image) {
+__device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLevel& L, lds_u8* lds, int level, int bp,
+                                              int ds0, int nds, int image) {
   const uint8_t* src;
   int pitch;
   if (level == 0) {
@@ -297,11 +305,15 @@ __device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLev
   }
   uint8_t* dst = a.blur + (size_t)image * a.pyr_bytes + L.offset;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wx = wave & 1, wy = wave >> 1;
+  const int band = 2 * bp + wx;
   const int h = L.h;
+  const int nsteps = (h + kMmaRows - 1) / kMmaRows;
+  const bool has_band = band * 64 < L.w;  // (an odd number of bands: the pair's second wave only helps loading)
   const __amdgpu_buffer_rsrc_t src_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, pitch * h, 0x00020000);
   const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, L.pitch * ((h + 7) & ~7), 0x00020000);
-  // constant operands
+  // constant operands (the table is padded to an even number of bands)
   const uint4* tc = a.tcol + ((size_t)L.blur_tcol + (size_t)band * 4) * 64 + lane;
   const v4i TL0 = as_v4i(tc[0]), TR0 = as_v4i(tc[64]), TL1 = as_v4i(tc[128]), TR1 = as_v4i(tc[192]);
   const v8h VL0 = __builtin_bit_cast(v8h, a.tv[lane]), VL1 = __builtin_bit_cast(v8h, a.tv[64 + lane]),
@@ -312,27 +324,39 @@ __device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLev
     bias[i] = a.bias;
     asm volatile("" : "+v"(bias[i]));  // stays in its registers (the compiler would otherwise re-create it per MFMA)
   }
-  // column part of the lane's load address: the band's first operand starts 16 columns left of its first tile (left of
-  // the image the offset wraps, far beyond the buffer's end: the load returns 0, and the weights there are 0 anyway)
-  const int col_off = band * 64 - 16 + 16 * hh;
   const int vec_end = L.blur_vec_end;
   const uint32_t pitch4 = (uint32_t)(L.pitch * 4);
 
-  struct Q3 {
-    v4i q0, q1, q2;
+  // ---- staging: this wave loads piece rows 2 wave, 2 wave + 1 (block rows 16 wave .. 16 wave + 15), both piece columns.
+  // Lane = slot (rho = lane >> 3, s = lane & 7) of a piece; it fetches chunk s ^ rho of the piece's row rho.
+  const int rho = lane >> 3;
+  const int src_col = bp * 128 - 64 + 16 * ((lane & 7) ^ rho);  // (left of the image the offset wraps: the load returns 0)
+  auto stage = [&](int dstep, int buf) {
+    const int y0 = dstep * (2 * kMmaRows) - 3 + 16 * wave + rho;
+    const uint32_t o0 = (uint32_t)(reflect101(y0, h) * pitch + src_col);
+    const uint32_t o1 = (uint32_t)(reflect101(y0 + 8, h) * pitch + src_col);
+    lds_u8* base = lds + buf * kBlockBytes + (2 * wave) * kPieceRowStride;
+    // (the second piece column's +128 is added to the lane offset: an instruction offset would move the LDS address too,
+    // and a scalar offset is not part of the range check -- row 0's wrapped negative lane offsets must stay out of range
+    // for the first piece column only)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, base, 16, o0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, base + 1024, 16, o0 + 128u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, base + kPieceRowStride, 16, o1, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, base + kPieceRowStride + 1024, 16, o1 + 128u, 0, 0, 0);
   };
-  auto request = [&](int step) -> Q3 {
-    const int y = reflect101(step * kMmaRows - 3 + r, h);
-    const uint32_t off = (uint32_t)(y * pitch + col_off);
-    Q3 q;
-    q.q0 = as_v4i(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0)));
-    q.q1 = as_v4i(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off + 32, 0, 0)));
-    q.q2 = as_v4i(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off + 64, 0, 0)));
-    return q;
-  };
+  // ---- operand reads: block row j = 26 wy + r, chunk 4 wx + 3 + 2 q + hh of the 16 (columns 64 band - 16 + 32 q + 16 hh)
+  uint32_t qaddr[3];
+  {
+    const int j = kMmaRows * wy + r, pr = j >> 3, rj = j & 7;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int chunk = 4 * wx + 3 + 2 * q + hh, pc = chunk >> 3, cc = chunk & 7;
+      qaddr[q] = (uint32_t)(pr * kPieceRowStride + pc * 1024 + (rj * 8 + (cc ^ rj)) * 16);
+    }
+  }
   auto sgn = [](v4i q) -> v4i { return q ^ (int)0x80808080; };
   // pass 2 + rounding + store of one tile: racc = row sums (lane = column, registers = rows)
-  auto finish = [&](const v16i& racc, uint32_t row_off, bool writer, int tile) {
+  auto finish = [&](const v16i& racc, uint32_t row_off, int tile) {
     v4i lo0, lo1, hi0, hi1;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -343,7 +367,7 @@ __device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLev
     }
     v16f acc;
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = -0.5f;
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo0), VL0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo1), VL1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi0), VH0, acc, 0, 0, 0);
@@ -352,59 +376,94 @@ __device__ __forceinline__ void blur_mma_body(const BlurMmaArgs& a, const VsfLev
     uint32_t d[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      uint32_t w;
+      uint32_t w = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        float t = __builtin_fmaf(acc[4 * j + i], 256.f, 128.f);
+        float t = acc[4 * j + i] * 256.f;
         if (TAIL) {
           const int col = band * 64 + tile * 32 + 8 * j + 4 * hh + i;
           t = col >= vec_end ? __builtin_floorf(t + 0.5f) : t;
         }
-        if (i == 0)
-          asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(w) : "v"(t));
-        else
-          asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(w) : "v"(t), "n"(i));
+        // (the builtin, not inline asm: v_permlane32_swap must not read a register a vector instruction wrote in the two
+        // slots before it, and the compiler's hazard recognizer does not look into asm statements -- an asm here left the
+        // swap one slot behind the last v_cvt_pk and lanes 12..15 of a tile's first dwords came out stale now and then)
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t, (uint32_t)i, i == 0 ? 0u : w);
       }
       d[j] = w;
     }
     auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
     auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-    if (writer) {
-      typedef unsigned int u4 __attribute__((__vector_size__(16)));
-      const u4 v = {s02[0], s02[1], s13[0], s13[1]};
-      __builtin_amdgcn_raw_buffer_store_b128(v, dst_rsrc, row_off + (uint32_t)((band * 2 + tile) << 7), 0, 0);
-    }
+    // (no branch around the store: a lane without an output row carries an offset beyond the buffer, and the range
+    // check drops its write)
+    typedef unsigned int u4 __attribute__((__vector_size__(16)));
+    const u4 v = {s02[0], s02[1], s13[0], s13[1]};
+    // The tile's offset rides in the lane offset (band) and the instruction offset (tile), NOT in the scalar offset: the
+    // compiler assumes that a 16-byte store with a scalar offset register may be followed at once by a vector write to
+    // its data registers; on gfx950 that overwrote the first data dword of lanes 12..15 / 44..47 now and then (the next
+    // tile's first v_perm_b32 landed in it).  Without a scalar offset register it keeps the wait state.
+    __builtin_amdgcn_raw_buffer_store_b128(v, dst_rsrc, row_off + (tile << 7), 0, 0);
   };
-
-  Q3 cur = request(step0);
-  for (int s = 0; s < nsteps; s++) {
-    const int step = step0 + s;
-    Q3 nxt = cur;
-    if (s + 1 < nsteps) nxt = request(step + 1);  // wave-uniform
-    const v4i q0 = sgn(cur.q0), q1 = sgn(cur.q1), q2 = sgn(cur.q2);
+  auto compute = [&](int buf, int step) {
+    v4i q[3];
+    const uint32_t bo = (uint32_t)(uintptr_t)lds + (uint32_t)(buf * kBlockBytes);
+    // (inline asm: the compiler would put s_waitcnt vmcnt(0) in front of an LDS read it can see while an LDS-DMA is in
+    // flight, i.e. wait for the NEXT block's loads.  Reads and their wait are ONE statement: the compiler takes an asm's
+    // outputs as available when the statement ends.)
+    asm volatile(
+        "ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2])
+        : "v"(bo + qaddr[0]), "v"(bo + qaddr[1]), "v"(bo + qaddr[2])
+        : "memory");
+    const v4i q0 = sgn(q[0]), q1 = sgn(q[1]), q2 = sgn(q[2]);
     v16i r0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q0, TL0, bias, 0, 0, 0);
     r0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, TR0, r0, 0, 0, 0);
     v16i r1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, TL1, bias, 0, 0, 0);
     r1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(q2, TR1, r1, 0, 0, 0);
     const int yo = step * kMmaRows + r;
     const bool writer = r < kMmaRows && yo < h;
-    const uint32_t row_off = (uint32_t)(yo >> 2) * pitch4 + (uint32_t)((yo & 3) << 5) + (uint32_t)(16 * hh);
-    finish(r0, row_off, writer, 0);
-    finish(r1, row_off, writer, 1);
-    cur = nxt;
+    const uint32_t row_off =
+        writer ? (uint32_t)(yo >> 2) * pitch4 + (uint32_t)((yo & 3) << 5) + (uint32_t)(16 * hh) + (uint32_t)(band << 8)
+               : 0x80000000u;
+    finish(r0, row_off, 0);
+    finish(r1, row_off, 1);
+  };
+
+  // Blocks are double buffered: block d + 1 is requested right after the barrier that says every wave has block d (and
+  // has therefore finished reading block d - 1, whose buffer the request overwrites).  vmcnt counts in issue order: the
+  // two stores of a step are younger than the four loads issued before it, so "at most 2 outstanding" = loads landed.
+  stage(ds0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int d = 0; d < nds; d++) {
+    __builtin_amdgcn_s_barrier();
+    if (d + 1 < nds) stage(ds0 + d + 1, (d + 1) & 1);  // wave-uniform
+    const int step = 2 * (ds0 + d) + wy;
+    if (has_band && step < nsteps) compute(d & 1, step);  // wave-uniform
+    if (d + 1 < nds) {
+      if (has_band && step < nsteps)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
 }
 
 __global__ __launch_bounds__(256, 2) void blur_mma_kernel(BlurMmaArgs a) {
-  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (unit >= a.nunits) return;  // wave-uniform
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[2 * kBlockBytes];
+  // Workgroups are dealt to the 8 XCDs round-robin by their linear id; all workgroups of an image get ids of one residue
+  // class, so the halo rows and columns neighbouring blocks fetch twice come out of ONE XCD's L2 the second time (with the
+  // blocks spread over the XCDs, 70 % of the L2 requests missed and the kernel fetched 3.6 GB per 2-GB pyramid pass).
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int image = xcd + 8 * (seq / a.nunits), unit = seq - (seq / a.nunits) * a.nunits;
+  if (image >= a.nimages) return;
   const uint32_t ud = a.units[unit];
-  const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), step0 = (int)((ud >> 8) & 0xFF), nsteps = (int)(ud & 0xFF);
+  const int level = (int)(ud >> 24), bp = (int)((ud >> 16) & 0xFF), ds0 = (int)((ud >> 8) & 0xFF), nds = (int)(ud & 0xFF);
   const VsfLevel L = a.levels[level];
-  if (band * 64 + 64 > L.blur_vec_end)  // (wave-uniform) the band reaches into the scalar-tail columns
-    blur_mma_body<true>(a, L, level, band, step0, nsteps, blockIdx.y);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lds_u8* lds = (lds_u8*)lds_raw;
+  if ((2 * bp + (wave & 1)) * 64 + 64 > L.blur_vec_end)  // (wave-uniform) the band reaches into the scalar-tail columns
+    blur_mma_body<true>(a, L, lds, level, bp, ds0, nds, image);
   else
-    blur_mma_body<false>(a, L, level, band, step0, nsteps, blockIdx.y);
+    blur_mma_body<false>(a, L, lds, level, bp, ds0, nds, image);
 }
 
 }  // namespace
@@ -443,5 +502,6 @@ void vsf_launch_blur_mma(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
   a.tcol = d_tcol;
   a.tv = d_tv;
   a.bias = bias;
-  hipLaunchKernelGGL(blur_mma_kernel, dim3((nunits + 3) / 4, im.n), dim3(256), 0, s, a);
+  a.nimages = im.n;
+  hipLaunchKernelGGL(blur_mma_kernel, dim3(nunits * ((im.n + 7) / 8 * 8)), dim3(256), 0, s, a);
 }

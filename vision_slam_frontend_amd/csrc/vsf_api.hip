@@ -37,7 +37,7 @@ struct Geometry {
   std::vector<VsfTap> xt, yt;
   std::vector<uint32_t> blur_tiles;
   // matrix-core blur (k_blur.hip blur_mma_kernel): work units and constant MFMA operands
-  std::vector<uint32_t> blur_mma_units;
+  std::vector<uint32_t> blur_mma_units, blur_mma_units_small;  // long strips (batches) / short strips (a frame or two)
   std::vector<uint4> blur_tcol, blur_tv;
   int blur_bias = 0;
 };
@@ -119,11 +119,12 @@ void build_blur_mma_tables(Geometry* G) {
   G->blur_bias = 128 * (k[0] + k[1] + k[2] + k[3] + k[4] + k[5] + k[6]);
   G->blur_tcol.clear();
   G->blur_mma_units.clear();
+  G->blur_mma_units_small.clear();
   for (size_t l = 0; l < G->levels.size(); l++) {
     VsfLevel& L = G->levels[l];
     L.blur_tcol = (uint32_t)(G->blur_tcol.size() / 64);
-    const int nbands = (L.w + 63) / 64;
-    for (int b = 0; b < nbands; b++)
+    const int nbands = (L.w + 63) / 64, npairs = (nbands + 1) / 2;
+    for (int b = 0; b < 2 * npairs; b++)  // (padded to whole band pairs: a padding band's weights are zero)
       for (int op = 0; op < 4; op++) {
         const int tile = 2 * b + (op >> 1);
         const int first = 32 * tile - 16 + 32 * (op & 1);
@@ -140,14 +141,20 @@ void build_blur_mma_tables(Geometry* G) {
           G->blur_tcol.push_back(v);
         }
       }
-    // units: (band, strip of <= VSF_BLUR_MMA_STEPS steps), the bands of a strip next to each other (a workgroup's four
-    // waves then share the operand between two bands through the L1)
-    const int nsteps = (L.h + VSF_BLUR_MMA_ROWS - 1) / VSF_BLUR_MMA_ROWS;
-    const int nstrips = (nsteps + VSF_BLUR_MMA_STEPS - 1) / VSF_BLUR_MMA_STEPS;
-    for (int st = 0; st < nstrips; st++) {
-      const int s0 = (int)((long long)nsteps * st / nstrips), s1 = (int)((long long)nsteps * (st + 1) / nstrips);
-      for (int b = 0; b < nbands; b++)
-        G->blur_mma_units.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | ((uint32_t)s0 << 8) | (uint32_t)(s1 - s0));
+    // units = one workgroup each: (band pair, strip of double steps); a workgroup's four waves are 2 bands x 2 steps.
+    // Two lists: long strips for batches that fill the chip anyway (a workgroup's first block is pure latency: 16 double
+    // steps per unit 0.93 ms per 512 images, 4: 1.01, 2: 1.29), short ones for a frame or two (parallelism).
+    const int nsteps = (L.h + VSF_BLUR_MMA_ROWS - 1) / VSF_BLUR_MMA_ROWS, ndsteps = (nsteps + 1) / 2;
+    for (int pass = 0; pass < 2; pass++) {
+      static const int env_steps = std::getenv("VSF_BLUR_MMA_STEPS") ? std::max(1, std::atoi(std::getenv("VSF_BLUR_MMA_STEPS"))) : 0;
+      const int per_unit = pass == 0 ? (env_steps ? env_steps : VSF_BLUR_MMA_STEPS) : VSF_BLUR_MMA_STEPS_SMALL;
+      std::vector<uint32_t>& units = pass == 0 ? G->blur_mma_units : G->blur_mma_units_small;
+      const int nstrips = (ndsteps + per_unit - 1) / per_unit;
+      for (int st = 0; st < nstrips; st++) {
+        const int s0 = (int)((long long)ndsteps * st / nstrips), s1 = (int)((long long)ndsteps * (st + 1) / nstrips);
+        for (int b = 0; b < npairs; b++)
+          units.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | ((uint32_t)s0 << 8) | (uint32_t)(s1 - s0));
+      }
     }
   }
   G->blur_tv.clear();
@@ -342,6 +349,7 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
     build_blur_mma_tables(&G);
   }
   if (G.blur_mma_units.empty()) G.blur_mma_units.push_back(0);
+  if (G.blur_mma_units_small.empty()) G.blur_mma_units_small.push_back(0);
   if (G.blur_tcol.empty()) G.blur_tcol.push_back(make_uint4(0, 0, 0, 0));
   if (G.blur_tv.empty()) G.blur_tv.push_back(make_uint4(0, 0, 0, 0));
   return true;
@@ -390,6 +398,7 @@ struct DevSet {  // device copies of one Geometry + its work buffers
   uint32_t* units = nullptr;
   uint32_t* blur_tiles = nullptr;
   uint32_t* blur_mma_units = nullptr;
+  uint32_t* blur_mma_units_small = nullptr;
   uint4* blur_tcol = nullptr;
   uint4* blur_tv = nullptr;
   uint2* ic_table = nullptr;
@@ -533,6 +542,7 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   VSF_HIP(upload(&ds->units, G.units));
   VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
   VSF_HIP(upload(&ds->blur_mma_units, G.blur_mma_units));
+  VSF_HIP(upload(&ds->blur_mma_units_small, G.blur_mma_units_small));
   VSF_HIP(upload(&ds->blur_tcol, G.blur_tcol));
   VSF_HIP(upload(&ds->blur_tv, G.blur_tv));
   VSF_HIP(upload(&ds->ic_table, build_ic_table()));
@@ -563,6 +573,7 @@ void free_devset(DevSet* ds) {
   hipFree(ds->units);
   hipFree(ds->blur_tiles);
   hipFree(ds->blur_mma_units);
+  hipFree(ds->blur_mma_units_small);
   hipFree(ds->blur_tcol);
   hipFree(ds->blur_tv);
   hipFree(ds->ic_table);
@@ -781,9 +792,12 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
     if (march)
       vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, st);
-    else
+    else if (im.n >= 32)
       vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units, (int)ctx->orb.blur_mma_units.size(), ctx->dorb.blur_tcol,
                           ctx->dorb.blur_tv, ctx->orb.blur_bias, st);
+    else
+      vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units_small, (int)ctx->orb.blur_mma_units_small.size(),
+                          ctx->dorb.blur_tcol, ctx->dorb.blur_tv, ctx->orb.blur_bias, st);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);

@@ -16,7 +16,8 @@
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
 #define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
 #define VSF_BLUR_MMA_ROWS 26     // output rows per step of the matrix-core blur (32 loaded rows - 2 x 3 halo rows)
-#define VSF_BLUR_MMA_STEPS 8     // steps per unit (a wave walks this many steps down its 64-column band)
+#define VSF_BLUR_MMA_STEPS 16    // double steps (52 rows) per unit: a workgroup walks this many blocks down its band pair
+#define VSF_BLUR_MMA_STEPS_SMALL 2  // ... for batches below 32 images
 // The blurred levels are stored in tiles of 4 rows x 32 bytes (= one 128-byte cache line), tiles in row-major order:
 // the descriptor kernel gathers 39 x 39 windows from them and a window then touches ~24 lines instead of 39..78,
 // while the blur kernel still writes whole 32-byte sectors (8 lanes x 4 bytes).
@@ -123,7 +124,7 @@ void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n
                                  int* d_out_n, hipStream_t s);
 void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_tiles, int ntiles,
                      const int k[4], hipStream_t s);
-// Matrix-core blur (k_blur.hip, round 3): units = level << 24 | band << 16 | first step << 8 | steps.
+// Matrix-core blur (k_blur.hip, round 3): units = level << 24 | band pair << 16 | first double step << 8 | double steps.
 void vsf_launch_blur_mma(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_units, int nunits,
                          const uint4* d_tcol, const uint4* d_tv, int bias, hipStream_t s);
 void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int max_keypoints,
