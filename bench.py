@@ -242,6 +242,9 @@ def main() -> int:
                          "step starts from 2*B baseline-JPEG files in HOST memory (the CompressedImage payloads of "
                          "slam_frontend_main.cc:98-109): upload, vsf_jpeg_decode_gray_batch, Bayer->gray, then the step; an "
                          "extra data point, reported under another metric name (needs Pillow to make the files)")
+    ap.add_argument("--blur-inline", action="store_true",
+                    help="keep the Gaussian blur on the extraction's stream (vsf_set_blur_overlap(0)); default: it runs on its "
+                         "own stream beside FAST and the keypoint selection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -291,6 +294,11 @@ def main() -> int:
     else:
         frames = synth.bench_batch(B, W, H, seed=synth.BASE_SEED + 100003 * rank)
     d_img = torch.from_numpy(frames).to(dev)  # [B, 2, H, W] uint8, resident in HBM before timing
+    # Three distinct batches take turns (the second and third are the first one rolled by a few pixels: different images
+    # with the same statistics): 3 x 157 MB of input do not stay in the 256-MB Infinity Cache from step to step, so the
+    # level-0 reads of every step come out of HBM as they would on a live stream.
+    d_imgs = [d_img, torch.roll(d_img, shifts=(3, 11), dims=(2, 3)), torch.roll(d_img, shifts=(8, 29), dims=(2, 3))]
+    step_no = [0]
     calib = frontend.default_calibration()
     # the synthetic pairs are rectified (pure horizontal disparity): l^T F r = y_r - y_l
     calib.set("fundamental", [0, 0, 0, 0, 0, -1, 0, 1, 0])
@@ -298,6 +306,7 @@ def main() -> int:
                                   overlap=not args.no_overlap)
     sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
     ctx.set_lanes(args.lanes)
+    ctx.set_blur_overlap(not args.blur_inline)
     ctx.set_pipeline(args.pipeline)  # (legal here: the synthetic stream is resident in HBM before every call)
     torch.cuda.synchronize()
 
@@ -307,7 +316,8 @@ def main() -> int:
 
     def run_step():
         if ingest is None:
-            sf.step(d_img)
+            sf.step(d_imgs[step_no[0] % len(d_imgs)])
+            step_no[0] += 1
         else:
             sf.step(ingest.next_batch())   # waits (on the GPU) for this step's decode, starts the next step's
             ingest.release()               # the buffer may be overwritten once this step's extraction has read it
@@ -339,6 +349,25 @@ def main() -> int:
         status = max(status, c.sync(allow_capacity=True))
     stages = per_ctx[0]
     tail_stages = {k: v for k, v in per_ctx[1].items() if v[1] > 0} if len(per_ctx) > 1 else None
+    # With the blur on its own stream its stage timer is the wall span of a kernel that shares the chip with FAST and the
+    # selection, not its duration.  A few untimed steps with the blur back in line give every stage's own duration; the
+    # roofline figures of the streaming stages use those, the headline value and ms_per_step do not.
+    blur_beside = not args.blur_inline and 2 * B >= 32
+    inline_stages = None
+    if blur_beside:
+        ctx.set_blur_overlap(False)
+        inline_steps = 3
+        run_step()
+        sf.drain()
+        ctx.sync(allow_capacity=True)
+        ctx.profile_enable(True)
+        for _ in range(inline_steps):
+            run_step()
+        sf.drain()
+        torch.cuda.synchronize()
+        inline_stages = {k: v[0] / inline_steps for k, v in ctx.profile_read(reset=True).items()}
+        ctx.profile_enable(False)
+        ctx.set_blur_overlap(True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -353,7 +382,8 @@ def main() -> int:
         value = total_frames / elapsed
         alg = stage_algorithmic_bytes(ctx, 2 * B, B, NF)
         pmc = committed_counters(W, H, NF, B)
-        dom = max(stages, key=lambda k: stages[k][0])
+        concurrent = ["gauss_blur7"] if blur_beside else []
+        dom = max((k for k in stages if k not in concurrent), key=lambda k: stages[k][0])
         dom_ms, dom_launches = stages[dom]
         per_launch_bytes = alg[dom] * args.steps / max(dom_launches, 1)
         per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
@@ -385,7 +415,7 @@ def main() -> int:
                        "ms_per_step": knn_ms / args.steps,
                        "note": "the stereo L->R launch of each step (B pairs of ~N x N)" if tail_stages is not None else
                                "all knn2 launches of a step (stereo + R'->L' + temporal) over the stereo pair count"}
-        device_ms = sum(v[0] for v in stages.values())
+        device_ms = sum(v[0] for k, v in stages.items() if k not in concurrent)
         out = {
             "metric": ("stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
                        else "stereo frames/s (%dx%d, %d kp/frame)" % (W, H, NF)) +
@@ -407,6 +437,11 @@ def main() -> int:
                        "parallelism": "frames sharded over %d GPU(s)%s" %
                                       (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
                                               "(RCCL)" if world > 1 else ""),
+                       "blur_overlap": "gauss_blur7 on its own stream beside fast_score_nms / select_harris_angle (its "
+                                       "stages_ms_per_step entry is a wall span; stages_ms_per_step_blur_inline: 3 untimed "
+                                       "steps with it back in line)" if blur_beside else "off",
+                       "input_rotation": "3 distinct %d-frame batches in turn (471 MB > Infinity Cache)" % B
+                                         if args.ingest == "hbm" else "per-step decode",
                        "tail_overlap": "step s's tail + collectives on a second stream beside step s+1's extraction"
                                        if sf.overlap else "off (one stream)",
                        "mean_keypoints_per_image": float(counts.mean()), "mean_stereo_matches": float(nm.mean()),
@@ -422,9 +457,11 @@ def main() -> int:
             "roofline_valu": valu,
             "matcher": matcher,
             # every streaming stage against the same roofline (algorithmic bytes / measured stage time)
-            "streaming_stages_gbs": {k: alg[k] * args.steps / (stages[k][0] * 1e-3) / 1e9
+            "streaming_stages_gbs": {k: alg[k] / ((inline_stages[k] if inline_stages else stages[k][0] / args.steps) * 1e-3) / 1e9
                                      for k in ("pyramid_resize", "fast_score_nms", "gauss_blur7") if stages[k][0] > 0},
             "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
+            "concurrent_stages": concurrent,
+            "stages_ms_per_step_blur_inline": inline_stages,
             "device_ms_per_step": device_ms / args.steps,
             "tail_stream_ms_per_step": None if tail_stages is None else
             {k: v[0] / args.steps for k, v in tail_stages.items()},

@@ -109,6 +109,12 @@ vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes);
  * into the second of two pyramid buffers while the previous call's later stages are still running; all other stages
  * and all outputs stay ordered on the context's stream as before. */
 vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
+/* Batched entry points (>= 32 images per call) run the Gaussian blur of a call -- matrix cores and memory -- on an
+ * internal stream forked behind the pyramid and joined in front of the descriptors, i.e. beside FAST and the keypoint
+ * selection, which live on the vector ALU and on latency (default: on; the caller still sees ONE stream-ordered
+ * operation, results do not depend on it).  With it on, the per-stage timer of the blur (vsf_profile_read) is the wall
+ * span of a kernel that shares the chip, not its own duration.  0 puts the blur back in line. */
+vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
 

@@ -415,6 +415,9 @@ struct vsf_ctx {
   // (frames are independent), so latency-bound stages of one half overlap VALU-bound stages of the other.
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // the blur (matrix cores + memory) beside FAST (vector ALU) in batched calls: its own stream, forked after the pyramid
+  hipStream_t blur_stream = nullptr;
+  hipEvent_t ev_blur_fork = nullptr, ev_blur_done = nullptr;
   VsfSideStream side{};  // aux_stream, for the pyramid's second launch chain
   // Cross-call pipelining (vsf_set_pipeline): the pyramid of call k + 1 is built on side streams, into the other of
   // two pyramid buffers, while call k's later stages still run.
@@ -429,6 +432,7 @@ struct vsf_ctx {
   bool ingest_done_valid = false;
   const uint8_t* last_pyr = nullptr;
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
+  int blur_overlap = 1;  // the blur on blur_stream beside FAST / selection (vsf_set_blur_overlap)
   int last_hip = 0;
   Geometry orb, fast;
   DevSet dorb, dfast;
@@ -774,6 +778,34 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, ctx->lanes == 1 ? &ctx->side : nullptr);
   }
   ctx->last_pyr = d.pyr - (size_t)i0 * g.pyr_bytes;
+  // The blur needs the pyramid only.  It lives on the matrix cores and on memory bandwidth, FAST on the vector ALU (93 % of
+  // its issue rate) and the selection on latency: forked behind the pyramid onto its own stream, the blur's workgroups
+  // fill in as FAST drains and run beside the selection (7.61 -> 7.25 ms per 256-frame step).  Measured and left out:
+  // forking behind FAST instead (7.52: the overlap with FAST's tail is lost); making room beside FAST with an LDS
+  // reservation that caps FAST at four workgroups per CU (7.46: FAST 3.3 -> 4.2 ms, it is the blur's vector instructions
+  // that FAST has no slots for); a high- or low-priority blur stream (7.39 / 7.65).
+  static const int overlap_env = std::getenv("VSF_BLUR_OVERLAP") ? std::atoi(std::getenv("VSF_BLUR_OVERLAP")) : 1;
+  static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
+  const bool blur_beside = overlap_env && ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
+  auto launch_blur = [&](hipStream_t bs) {
+    StageTimer t(ctx, bs, VSF_STAGE_BLUR, 1);
+    // VSF_BLUR=march: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
+    if (march)
+      vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, bs);
+    else if (im.n >= 32)
+      vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units, (int)ctx->orb.blur_mma_units.size(), ctx->dorb.blur_tcol,
+                          ctx->dorb.blur_tv, ctx->orb.blur_bias, bs);
+    else
+      vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units_small, (int)ctx->orb.blur_mma_units_small.size(),
+                          ctx->dorb.blur_tcol, ctx->dorb.blur_tv, ctx->orb.blur_bias, bs);
+  };
+  auto fork_blur = [&]() {
+    (void)hipEventRecord(ctx->ev_blur_fork, st);
+    (void)hipStreamWaitEvent(ctx->blur_stream, ctx->ev_blur_fork, 0);
+    launch_blur(ctx->blur_stream);
+    (void)hipEventRecord(ctx->ev_blur_done, ctx->blur_stream);
+  };
+  if (blur_beside) fork_blur();
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
     vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st);
@@ -786,19 +818,10 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     StageTimer t(ctx, st, VSF_STAGE_SELECT, 1);
     vsf_launch_select(d, g, ctx->orb.levels.data(), im, st);
   }
-  {
-    StageTimer t(ctx, st, VSF_STAGE_BLUR, 1);
-    // VSF_BLUR=march: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
-    static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
-    if (march)
-      vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, st);
-    else if (im.n >= 32)
-      vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units, (int)ctx->orb.blur_mma_units.size(), ctx->dorb.blur_tcol,
-                          ctx->dorb.blur_tv, ctx->orb.blur_bias, st);
-    else
-      vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units_small, (int)ctx->orb.blur_mma_units_small.size(),
-                          ctx->dorb.blur_tcol, ctx->dorb.blur_tv, ctx->orb.blur_bias, st);
-  }
+  if (blur_beside)
+    (void)hipStreamWaitEvent(st, ctx->ev_blur_done, 0);
+  else
+    launch_blur(st);
   {
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);
     vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp + i0 * K, d_desc + i0 * K * VSF_DESC_BYTES, d_counts + i0,
@@ -972,6 +995,10 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming) != hipSuccess)
     return fail(VSF_ERR_HIP);
+  if (hipStreamCreateWithFlags(&ctx->blur_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_blur_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_blur_done, hipEventDisableTiming) != hipSuccess)
+    return fail(VSF_ERR_HIP);
   ctx->side.stream[0] = ctx->aux_stream;
   for (int i = 0; i < VSF_SIDE_STREAMS; i++) {
     if (i > 0 && hipStreamCreateWithFlags(&ctx->side.stream[i], hipStreamNonBlocking) != hipSuccess)
@@ -1004,6 +1031,7 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
   if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
+  if (ctx->blur_stream) hipStreamSynchronize(ctx->blur_stream);
   if (ctx->ev_pyr_done) {
     hipEventDestroy(ctx->ev_pyr_done);
     hipEventDestroy(ctx->ev_fast_done);
@@ -1058,6 +1086,9 @@ void vsf_destroy(vsf_ctx* ctx) {
     }
   }
   if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
+  if (ctx->blur_stream) hipStreamDestroy(ctx->blur_stream);
+  if (ctx->ev_blur_fork) hipEventDestroy(ctx->ev_blur_fork);
+  if (ctx->ev_blur_done) hipEventDestroy(ctx->ev_blur_done);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -1082,6 +1113,13 @@ vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes) {
   if (!ctx || lanes < 1 || lanes > 2) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->lanes = lanes;
+  return VSF_OK;
+}
+
+vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->blur_overlap = on ? 1 : 0;
   return VSF_OK;
 }
 
