@@ -82,6 +82,10 @@ typedef struct {
   int32_t width, height;   /* image size in pixels */
   int32_t max_images;      /* images per batch (2 per stereo frame) */
   int32_t max_keypoints;   /* per-image capacity of keypoint/descriptor outputs; 0 = nfeatures + 256 */
+  /* --- RemoveAmbigStereo (slam_frontend.cc:381-383): order in which the three-term dot products of
+   * left_ph.transpose() * F * right_ph are summed.  0 (default): a0*b0 + (a1*b1 + a2*b2), what Eigen 3.3's unrolled
+   * reduction of a fixed-size-3 lazy product does; 1: (a0*b0 + a1*b1) + a2*b2. --- */
+  int32_t residual_order;
 } vsf_params;
 
 typedef struct vsf_ctx vsf_ctx;

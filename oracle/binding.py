@@ -239,6 +239,11 @@ def sort_and_trim(m: np.ndarray, best_percent: float) -> np.ndarray:
     return m[:n]
 
 
+def set_residual_order(order: int) -> None:
+    """0: Eigen 3.3's a0*b0 + (a1*b1 + a2*b2) (default); 1: left to right."""
+    lib().vsfo_set_residual_order(int(order))
+
+
 def remove_ambig_stereo(left: np.ndarray, right: np.ndarray, matches: np.ndarray, F: np.ndarray, threshold: float):
     left = np.ascontiguousarray(left, KEYPOINT_DTYPE)
     right = np.ascontiguousarray(right, KEYPOINT_DTYPE)

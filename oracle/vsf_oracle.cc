@@ -790,9 +790,25 @@ int vsfo_sort_and_trim(vsfo_dmatch* m, int n, float best_percent) {
   return std::min(std::max(num_good, 0), n);
 }
 
+// Order in which a three-term dot product of  left_ph.transpose() * F * right_ph  (slam_frontend.cc:381-383) is summed.
+// 0 (default): a0 b0 + (a1 b1 + a2 b2) -- Eigen 3.3's lazy coefficient product of fixed size 3 is
+//    lhs.row(i).transpose().cwiseProduct(rhs.col(j)).sum(), and its unrolled reduction (Redux.h,
+//    redux_novec_unroller<Func, Derived, 0, 3>: HalfLength = 1) adds element 0 to the sum of elements 1 and 2;
+// 1: (a0 b0 + a1 b1) + a2 b2, plain left to right (what rounds 1 and 2 of this repo computed).
+// With the rectified F of the synthetic stream (one non-zero per row) the two agree bit for bit; with a dense F they differ
+// by an ulp now and then, which moves which pairs pass `<=`, the mean and every index downstream.
+static int g_residual_order = 0;
+void vsfo_set_residual_order(int order) { g_residual_order = order ? 1 : 0; }
+int vsfo_get_residual_order(void) { return g_residual_order; }
+static inline float Dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  const float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+  return g_residual_order ? (p0 + p1) + p2 : p0 + (p1 + p2);
+}
+
 int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* right, const vsfo_dmatch* matches,
                              int n, const float F[9], float* threshold_io, uint8_t* keep, float* residual) {
-  // slam_frontend.cc:369-394. (l^T F r).norm() of a 1x1 == |l^T F r|; products accumulated left to right.
+  // slam_frontend.cc:369-394.  (l^T F r).norm() of a 1x1 is sqrt(x * x) == |x| (exactly, barring under- / overflow of
+  // x * x: |x| below 1e-19 or above 1.8e19, never a pixel residual).
   float avg = 0.0f;
   int kept = 0;
   const float thr = *threshold_io;
@@ -800,8 +816,8 @@ int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* rig
     const float l[3] = {left[matches[m].queryIdx].x, left[matches[m].queryIdx].y, 1.0f};
     const float r[3] = {right[matches[m].trainIdx].x, right[matches[m].trainIdx].y, 1.0f};
     float t[3];
-    for (int j = 0; j < 3; j++) t[j] = (l[0] * F[0 * 3 + j] + l[1] * F[1 * 3 + j]) + l[2] * F[2 * 3 + j];
-    const float c = std::fabs((t[0] * r[0] + t[1] * r[1]) + t[2] * r[2]);
+    for (int j = 0; j < 3; j++) t[j] = Dot3(l[0], F[0 * 3 + j], l[1], F[1 * 3 + j], l[2], F[2 * 3 + j]);
+    const float c = std::fabs(Dot3(t[0], r[0], t[1], r[1], t[2], r[2]));
     avg += c;
     if (residual) residual[m] = c;
     const bool k = c <= thr;

@@ -121,6 +121,10 @@ int vsfo_get_matches_mt(const uint8_t* q, int nq, const uint8_t* t, int nt, doub
 int vsfo_sort_and_trim(vsfo_dmatch* m, int n, float best_percent);
 /* Frontend::RemoveAmbigStereo (slam_frontend.cc:353-398). F is row-major 3x3. keep[i] in {0,1};
  * *threshold_io is the file-static stereo_ambig_constraint (in: current, out: updated). Returns kept. */
+/* Summation order of the three-term dot products in RemoveAmbigStereo: 0 = Eigen 3.3 (a0 b0 + (a1 b1 + a2 b2), default),
+ * 1 = left to right.  Process-wide switch of the checker. */
+void vsfo_set_residual_order(int order);
+int vsfo_get_residual_order(void);
 int vsfo_remove_ambig_stereo(const vsfo_keypoint* left, const vsfo_keypoint* right,
                              const vsfo_dmatch* matches, int n, const float F[9], float* threshold_io,
                              uint8_t* keep, float* residual);

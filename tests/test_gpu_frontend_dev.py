@@ -148,3 +148,48 @@ def test_feature_matches_sorted_and_trimmed(batch, oracle, capi, best_percent):
         np.testing.assert_array_equal(pairs[i, :len(mm), 1], mm["trainIdx"], err_msg="pair %d current idx" % i)
         total += len(mm)
     assert npr[2] == 0 and total > 10
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_residuals_dense_fundamental_both_orders(capi, batch, oracle, order):
+    """slam_frontend.cc:381-383 with a dense F: the device residuals, means and kept sets equal the oracle's in Eigen 3.3's
+    summation order (vsf_params::residual_order 0, the default) and in plain left-to-right order (1); the two orders
+    disagree on this input, so each run pins one of them."""
+    _, t, B, K = batch
+    F = np.array([[2.31e-08, -1.17e-05, 3.45e-03], [1.22e-05, 9.8e-08, -0.11], [-4.1e-03, 0.108, 1.0]], np.float32)
+    p = capi.default_params(640, 480, max_images=2 * B, nfeatures=NF)
+    p.residual_order = order
+    dev = torch.device("cuda", 0)
+    means = torch.zeros(B, dtype=torch.float32, device=dev)
+    thr = torch.zeros(B + 1, dtype=torch.float32, device=dev)
+    kp2, desc2, counts2 = torch.zeros_like(t["kp2"]), torch.zeros_like(t["desc2"]), torch.zeros_like(t["counts2"])
+    torch.cuda.synchronize()
+    with capi.Context(p) as ctx:
+        ctx.remove_ambig_stereo_batch_dev(t["kp"].data_ptr(), t["desc"].data_ptr(), t["m"].data_ptr(), t["nm"].data_ptr(), B,
+                                          F, 10000.0, 0, means.data_ptr(), thr.data_ptr(), kp2.data_ptr(),
+                                          desc2.data_ptr(), counts2.data_ptr())
+        assert ctx.sync() == capi.VSF_OK
+    kp = _np(t["kp"]).reshape(2 * B, K * 28).view(oracle.KEYPOINT_DTYPE)
+    counts, nm = _np(t["counts"]), _np(t["nm"])
+    m = _np(t["m"]).reshape(B, K * 16).view(oracle.DMATCH_DTYPE)
+    g_thr, g_counts2 = _np(thr), _np(counts2)
+    g_kp2 = _np(kp2).reshape(2 * B, K * 28).view(oracle.KEYPOINT_DTYPE)
+    cur = np.float32(10000.0)
+    differs = False
+    try:
+        for f in range(B):
+            kl, kr = kp[2 * f, :counts[2 * f]], kp[2 * f + 1, :counts[2 * f + 1]]
+            mm = m[f, :nm[f]]
+            oracle.set_residual_order(order)
+            keep, res, nxt, kept = oracle.remove_ambig_stereo(kl, kr, mm, F, float(cur))
+            oracle.set_residual_order(1 - order)
+            _, res_other, _, _ = oracle.remove_ambig_stereo(kl, kr, mm, F, float(cur))
+            differs |= bool((res != res_other).any())
+            assert g_thr[f].tobytes() == cur.tobytes() or (np.isnan(g_thr[f]) and np.isnan(cur))
+            assert g_counts2[2 * f] == kept
+            assert g_kp2[2 * f, :kept].tobytes() == kl[mm["queryIdx"][keep]].tobytes()
+            cur = np.float32(nxt)
+    finally:
+        oracle.set_residual_order(0)
+    assert g_thr[B].tobytes() == cur.tobytes()
+    assert differs

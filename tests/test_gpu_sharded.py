@@ -194,3 +194,64 @@ def test_three_ranks_equal_one_process(tmp_path):
     sizes = [len(want_f[g]) for g in range(n)]
     assert sizes[per] == 0 and sizes[per + 1] == 0 and sizes[per + 2] > 10
     assert (per * 3 - 2, per * 3) in want_m and (per * 3 - 1, per * 3) in want_m  # rank 0, step 1 <- rank 2, step 0
+
+
+def test_sharded_outputs_follow_the_reference_sequence(oracle):
+    """Not a self-comparison: the payloads ShardedStereoFrontend gathers (world of one, two steps of three frames, window
+    2) against the reference's sequence assembled from the CPU oracle's pieces -- extract L / R, GetMatches,
+    RemoveAmbigStereo with the threshold carried from frame to frame (slam_frontend.cc:353-398), GetFeatureMatches
+    against the two previous frames (cc:282-309, 424-434), Calculate3DPoints / UndistortFeaturePoints (cc:117-173,
+    323-351).  Indices bit for bit, point3d / pixel to the tolerance of row f2."""
+    from vision_slam_frontend_amd import distributed as vd
+    from vision_slam_frontend_amd import synth
+
+    steps, per_step = 2, 3
+    n = steps * per_step
+    frames = synth.stereo_stream(n, W_IMG, H_IMG, n_objects=400)
+    frames[1, 1] = 128  # frame 1 has no stereo match: frame 2 meets the NaN threshold (quirk Q3), frame 3 is normal again
+    global STEPS
+    saved, STEPS = STEPS, steps
+    try:
+        sf, local, ctx = _run(frames, per_step, 0, 1)
+    finally:
+        STEPS = saved
+    got_f, got_m = vd.assemble_outputs(local, 1, per_step, WINDOW)
+    calib = _calibration()
+    ctx.close()
+    bp = float(np.float32(0.3))
+    thr = np.float32(10000.0)
+    filtered = []  # filtered left descriptors per frame
+    sizes = []
+    for g in range(n):
+        left, right = frames[g, 0], frames[g, 1]
+        ol, orr = oracle.Orb(nfeatures=NF), oracle.Orb(nfeatures=NF)
+        ol.run(left)
+        orr.run(right)
+        kl, dl = ol.result()
+        kr, dr = orr.result()
+        m = oracle.get_matches(dl, dr)
+        keep, _, thr_next, kept = oracle.remove_ambig_stereo(kl, kr, m, F_RECT, float(thr))
+        kl2, dl2 = kl[m["queryIdx"][keep]], dl[m["queryIdx"][keep]]
+        kr2, dr2 = kr[m["trainIdx"][keep]], dr[m["trainIdx"][keep]]
+        want, npts = oracle.vision_features(kl2, dl2, kr2, dr2, calib.get("projection_left"), calib.get("projection_right"),
+                                            calib.get("camera_matrix_left"), calib.get("distortion_left"))
+        f = got_f[g]
+        assert len(f) == len(want) == kept, "frame %d" % g
+        np.testing.assert_array_equal(f["feature_idx"], want["feature_idx"])
+        assert np.abs(f["pixel"].astype(np.float64) - want["pixel"]).max(initial=0.0) <= 1e-4
+        a, b = f["point3d"].astype(np.float64), want["point3d"].astype(np.float64)
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin)
+        assert (np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-30)).max(initial=0.0) <= 1e-5
+        for w in range(WINDOW, 0, -1):
+            if g - w < 0:
+                continue
+            mm = oracle.sort_and_trim(oracle.get_matches(filtered[g - w], dl2), bp)
+            fac = got_m[(g - w, g)]
+            np.testing.assert_array_equal(fac["feature_idx_initial"], mm["queryIdx"], err_msg="factor (%d, %d)" % (g - w, g))
+            np.testing.assert_array_equal(fac["feature_idx_current"], mm["trainIdx"])
+        filtered.append(dl2)
+        sizes.append(kept)
+        thr = np.float32(thr_next)
+    assert sizes[1] == 0 and sizes[2] == 0 and sizes[3] > 20 and sizes[0] > 20
+    assert sum(len(v) for v in got_m.values()) > 5

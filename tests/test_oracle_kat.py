@@ -268,6 +268,53 @@ def test_remove_ambig_stereo(oracle):
     assert kept_c == 4 and keep_c.all()
 
 
+def _residuals_from_definition(left, right, F, eigen33):
+    """|l^T F r| in float32, each three-term dot product summed as stated: Eigen 3.3 adds element 0 to (element 1 + element
+    2) -- redux_novec_unroller<Func, Derived, 0, 3> splits 1 + 2 --, the alternative is left to right."""
+    f32 = np.float32
+
+    def dot3(a, b):
+        p = [f32(f32(a[i]) * f32(b[i])) for i in range(3)]
+        return f32(p[0] + f32(p[1] + p[2])) if eigen33 else f32(f32(p[0] + p[1]) + p[2])
+
+    out = []
+    for lk, rk in zip(left, right):
+        l, r = [lk["x"], lk["y"], f32(1)], [rk["x"], rk["y"], f32(1)]
+        t = [dot3(l, F[:, j]) for j in range(3)]
+        out.append(abs(dot3(t, r)))
+    return np.array(out, np.float32)
+
+
+def test_remove_ambig_stereo_summation_order(oracle):
+    """slam_frontend.cc:381-383 with a DENSE fundamental matrix: the two summation orders differ in the last bit for a
+    good share of the matches (with the rectified F of the synthetic stream they cannot), the oracle's default is Eigen
+    3.3's order and the switch gives the other one."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    n = 400
+    K = oracle.KEYPOINT_DTYPE
+    left, right = np.zeros(n, K), np.zeros(n, K)
+    left["x"], left["y"] = rng.uniform(0, 640, n).astype(np.float32), rng.uniform(0, 480, n).astype(np.float32)
+    right["x"], right["y"] = rng.uniform(0, 640, n).astype(np.float32), rng.uniform(0, 480, n).astype(np.float32)
+    # a dense F with entries of the very different magnitudes a calibrated pair gives (the reference computes its F from the
+    # camera matrices, slam_frontend.cc:635-644: nine non-zero entries)
+    F = np.array([[2.31e-08, -1.17e-05, 3.45e-03], [1.22e-05, 9.8e-08, -0.11], [-4.1e-03, 0.108, 1.0]], np.float32)
+    m = np.zeros(n, oracle.DMATCH_DTYPE)
+    m["queryIdx"] = m["trainIdx"] = np.arange(n)
+    want_e = _residuals_from_definition(left, right, F, True)
+    want_s = _residuals_from_definition(left, right, F, False)
+    assert (want_e != want_s).sum() > n // 20  # the orders are distinguishable on this input
+    try:
+        _, res_e, thr_e, _ = oracle.remove_ambig_stereo(left, right, m, F, 10000.0)
+        oracle.set_residual_order(1)
+        _, res_s, thr_s, _ = oracle.remove_ambig_stereo(left, right, m, F, 10000.0)
+    finally:
+        oracle.set_residual_order(0)
+    assert res_e.tobytes() == want_e.tobytes()
+    assert res_s.tobytes() == want_s.tobytes()
+    # x86's default float arithmetic keeps sqrt(x * x) == |x| for every residual here (the reference's .norm())
+    assert np.array_equal(np.sqrt(res_e * res_e), res_e)
+
+
 def test_retain_best_keeps_boundary_ties(oracle):
     keys = np.array([5, 9, 7, 7, 7, 1, 7, 3], np.float32)
     r, ids = oracle.retain_best(keys, 3)

@@ -46,7 +46,7 @@ class VsfParams(C.Structure):
                 ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32),
                 ("blur_sse2", C.c_int32), ("fast_detector_threshold", C.c_int32), ("fast_detector_nms", C.c_int32),
                 ("ratio_num", C.c_uint32), ("ratio_shift", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
-                ("max_images", C.c_int32), ("max_keypoints", C.c_int32)]
+                ("max_images", C.c_int32), ("max_keypoints", C.c_int32), ("residual_order", C.c_int32)]
 
 
 class VsfCalibration(C.Structure):

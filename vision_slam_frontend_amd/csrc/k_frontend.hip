@@ -22,10 +22,19 @@
 namespace {
 
 // ---- RemoveAmbigStereo, step 1: residuals + ordered mean per frame ----
+// A three-term dot product as the reference's Eigen expression sums it (vsf_params::residual_order): Eigen 3.3's unrolled
+// reduction of a fixed-size-3 lazy product adds element 0 to the sum of elements 1 and 2 (Redux.h, redux_novec_unroller
+// with HalfLength = 1); order 1 is plain left to right.
+__device__ __forceinline__ float dot3(int order, float a0, float b0, float a1, float b1, float a2, float b2) {
+  const float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+  return order ? (p0 + p1) + p2 : p0 + (p1 + p2);
+}
+
 __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint* __restrict__ kp,
                                                               const vsf_dmatch* __restrict__ matches,
                                                               const int32_t* __restrict__ nmatches, int max_rows,
                                                               const float* __restrict__ F,  // 9 floats, row major
+                                                              int order,  // vsf_params::residual_order
                                                               float* __restrict__ residual,  // [frames][max_rows]
                                                               float* __restrict__ mean) {    // [frames], NaN if empty
   const int f = blockIdx.x;
@@ -43,8 +52,8 @@ __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint
     const float rx = right[dm.trainIdx].x, ry = right[dm.trainIdx].y;
     float t[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) t[j] = (lx * Fm[0 * 3 + j] + ly * Fm[1 * 3 + j]) + 1.0f * Fm[2 * 3 + j];
-    res[i] = fabsf((t[0] * rx + t[1] * ry) + t[2] * 1.0f);
+    for (int j = 0; j < 3; j++) t[j] = dot3(order, lx, Fm[0 * 3 + j], ly, Fm[1 * 3 + j], 1.0f, Fm[2 * 3 + j]);
+    res[i] = fabsf(dot3(order, t[0], rx, t[1], ry, t[2], 1.0f));
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -245,10 +254,10 @@ __global__ __launch_bounds__(256) void observe_pack_kernel(VsfObserveArgs a) {
 }  // namespace
 
 void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
-                                 int n_frames, int max_rows, const float* d_F, float* d_residual, float* d_mean,
+                                 int n_frames, int max_rows, const float* d_F, int order, float* d_residual, float* d_mean,
                                  hipStream_t s) {
   hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_matches, d_nmatches, max_rows,
-                     d_F, d_residual, d_mean);
+                     d_F, order, d_residual, d_mean);
 }
 
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
@@ -260,10 +269,10 @@ void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_de
 }
 
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
-                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F,
+                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, int order,
                               const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
                               vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s) {
-  vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, max_rows, d_F, d_residual, d_mean, s);
+  vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, max_rows, d_F, order, d_residual, d_mean, s);
   if (!d_thr_override)
     hipLaunchKernelGGL(stereo_threshold_chain_kernel, dim3(1), dim3(64), 0, s, d_mean, n_frames, thr_in, d_thr);
   vsf_launch_stereo_filter_only(d_kp, d_desc, d_matches, d_nmatches, n_frames, max_rows, d_residual,

@@ -924,6 +924,7 @@ vsf_status vsf_params_default(vsf_params* p, int width, int height, int max_imag
   p->patch_size = 31;
   p->fast_threshold = 20;
   p->blur_sse2 = 1;
+  p->residual_order = 0;  // Eigen 3.3's a0*b0 + (a1*b1 + a2*b2)
   p->fast_detector_threshold = 10;
   p->fast_detector_nms = 1;
   p->width = width;
@@ -1273,7 +1274,7 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
     if (st != VSF_OK) return st;
   }
   VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, ctx->f_F, d_thr_override, thr_in,
+  vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, ctx->f_F, ctx->p.residual_order, d_thr_override, thr_in,
                            ctx->f_residual, d_means, d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
   VSF_HIP(hipGetLastError());
   return VSF_OK;
@@ -1288,7 +1289,7 @@ vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp
   VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   {
     StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
-    vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_F, ctx->f_residual,
+    vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_F, ctx->p.residual_order, ctx->f_residual,
                                 d_means, ctx->stream);
   }
   VSF_HIP(hipGetLastError());
@@ -1618,7 +1619,7 @@ vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   int32_t* cur_counts = o.ring_counts + S;
   {
     StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
-    vsf_launch_stereo_residuals(ctx->st_kp, o.matches, nmatches, 1, Kc, M.F, ctx->f_residual, means, s);
+    vsf_launch_stereo_residuals(ctx->st_kp, o.matches, nmatches, 1, Kc, M.F, ctx->p.residual_order, ctx->f_residual, means, s);
     vsf_launch_stereo_thresholds(means, 1, thr_state, thr, s);
     vsf_launch_stereo_filter_only(ctx->st_kp, ctx->st_desc, o.matches, nmatches, 1, Kc, ctx->f_residual, thr, o.kpf,
                                   cur_desc, cur_counts, s);

@@ -141,11 +141,11 @@ void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, c
 
 // k_frontend.hip
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
-                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F,
+                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, int order,
                               const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
                               vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s);
 void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
-                                 int n_frames, int max_rows, const float* d_F, float* d_residual, float* d_mean,
+                                 int n_frames, int max_rows, const float* d_F, int order, float* d_residual, float* d_mean,
                                  hipStream_t s);
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
                                    const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_residual,

@@ -128,6 +128,7 @@ FrontendConfig::FrontendConfig() {
   min_odom_translation = 0.2f;
   min_vision_matches = 10;
   orb_nfeatures = 10000;  // cc:205
+  residual_order = 0;     // Eigen 3.3's reduction order of a fixed-size-3 lazy product (cc:381-383)
   image_width = 0;        // 0: taken from the first observed image
   image_height = 0;
 
@@ -238,6 +239,7 @@ bool Frontend::EnsureContext(int width, int height) {
   vsf_params p;
   vsf_params_default(&p, width, height, 2);
   p.nfeatures = config_.orb_nfeatures;
+  p.residual_order = config_.residual_order;
   last_status_ = vsf_params_set_ratio(&p, config_.nn_match_ratio_);
   if (last_status_ != VSF_OK) return false;
   last_status_ = vsf_create(&p, device_, &ctx_);
@@ -424,8 +426,18 @@ void Frontend::AddOdometryFactor() {
   odometry_factors_.push_back(OdometryFactor(curr_frame_ID_ - 1, curr_frame_ID_, translation, rotation));
 }
 
-// cc:353-398.  |l^T F r| per stereo match (float, products accumulated left to right); survivors re-index both
-// frames; the next frame's threshold is this frame's mean residual + 2.
+// cc:353-398.  |l^T F r| per stereo match; survivors re-index both frames; the next frame's threshold is this frame's
+// mean residual + 2.  The reference's `(left_ph.transpose() * F * right_ph).norm()` is two rounds of three-term dot
+// products; Eigen 3.3 evaluates a fixed-size-3 lazy product coefficient as cwiseProduct().sum() with the unrolled
+// reduction redux_novec_unroller<.., 0, 3>, which splits 1 + 2: a0 b0 + (a1 b1 + a2 b2) (config_.residual_order 0);
+// .norm() of the 1 x 1 result is sqrt(x * x) == |x| barring under- / overflow of the square.
+namespace {
+inline float Dot3(int order, float a0, float b0, float a1, float b1, float a2, float b2) {
+  const float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+  return order ? (p0 + p1) + p2 : p0 + (p1 + p2);
+}
+}  // namespace
+
 void Frontend::RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vsf_dmatch>& stereo_matches) {
   std::vector<vsf_keypoint> left_keypoints, right_keypoints;
   std::vector<uint8_t> left_descs, right_descs;
@@ -437,8 +449,9 @@ void Frontend::RemoveAmbigStereo(Frame* left, Frame* right, const std::vector<vs
     const vsf_keypoint& rk = right->keypoints_[match.trainIdx];
     const float l[3] = {lk.x, lk.y, 1.0f}, r[3] = {rk.x, rk.y, 1.0f};
     float t[3];
-    for (int j = 0; j < 3; j++) t[j] = (l[0] * F(0, j) + l[1] * F(1, j)) + l[2] * F(2, j);
-    const float constraint = std::fabs((t[0] * r[0] + t[1] * r[1]) + t[2] * r[2]);
+    const int order = config_.residual_order;
+    for (int j = 0; j < 3; j++) t[j] = Dot3(order, l[0], F(0, j), l[1], F(1, j), l[2], F(2, j));
+    const float constraint = std::fabs(Dot3(order, t[0], r[0], t[1], r[1], t[2], r[2]));
     avg_constraint += constraint;
     if (constraint <= stereo_ambig_constraint_) {
       left_keypoints.push_back(lk);

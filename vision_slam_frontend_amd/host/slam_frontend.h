@@ -64,6 +64,9 @@ struct FrontendConfig {
   // ORB parameters the reference hard-codes in cv::ORB::create (cc:205-213); exposed so BASELINE configs can set
   // nfeatures = 2000 / 8000.
   int orb_nfeatures;
+  // How RemoveAmbigStereo's three-term dot products are summed (vsf_params::residual_order): 0 = as Eigen 3.3 does,
+  // a0 b0 + (a1 b1 + a2 b2) (default); 1 = left to right.
+  int residual_order;
   // Image geometry the GPU context is created for (the reference takes it from the first cv::Mat).
   int image_width, image_height;
 };
