@@ -264,10 +264,11 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" %
-                  (args.gpus, args.gpus), file=sys.stderr)
-            return 2
+        # a run that was asked for N GPUs and got another world size must not pass for an N-GPU measurement
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run --nnodes=1 "
+              "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`" % (args.gpus, world, args.gpus, args.gpus),
+              file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
@@ -282,6 +283,13 @@ def main() -> int:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+
+    # the ranks that really take part, seen through the backend that carries the step's collectives (part of the setup)
+    handshake = vd.collective_handshake(dev)
+    if sorted(handshake["ranks_seen"]) != list(range(world)):
+        print("bench.py: the all-gather of rank ids returned %s in a world of %d" % (handshake["ranks_seen"], world),
+              file=sys.stderr)
+        return 3
 
     # One explicit (non-default) stream carries everything: the HIP kernels (vsf_set_stream), torch's copies, the
     # per-stage hipEvents and, for N > 1, the RCCL collectives' dependencies.
@@ -368,10 +376,18 @@ def main() -> int:
         inline_stages = {k: v[0] / inline_steps for k, v in ctx.profile_read(reset=True).items()}
         ctx.profile_enable(False)
         ctx.set_blur_overlap(True)
+    rank_ms = [1e3 * elapsed / args.steps]
+    blocked_ms, overflow_ranks = 1e3 * sf.blocked_s, [0] if status == capi.VSF_ERR_CAPACITY else []
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        cdev = "cpu" if rehearsal else dev
+        mine = torch.tensor([elapsed, sf.blocked_s, float(status == capi.VSF_ERR_CAPACITY)], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu()
+        rank_ms = [1e3 * float(v) / args.steps for v in every[:, 0]]
+        elapsed = float(every[:, 0].max())  # the step time of the job is its slowest rank's
+        blocked_ms = 1e3 * float(every[:, 1].max())
+        overflow_ranks = [r for r in range(world) if every[r, 2] > 0]
 
     counts = sf.counts.cpu().numpy()
     nm = sf.nmatches.cpu().numpy()
@@ -440,20 +456,25 @@ def main() -> int:
                        "blur_overlap": "gauss_blur7 on its own stream beside fast_score_nms / select_harris_angle (its "
                                        "stages_ms_per_step entry is a wall span; stages_ms_per_step_blur_inline: 3 untimed "
                                        "steps with it back in line)" if blur_beside else "off",
-                       "input_rotation": "3 distinct %d-frame batches in turn (471 MB > Infinity Cache)" % B
+                       "input_rotation": "3 distinct %d-frame batches in turn (%.0f MB of input; the Infinity Cache holds 256 MB)"
+                                         % (B, 3 * B * 2 * W * H / 1e6)
                                          if args.ingest == "hbm" else "per-step decode",
                        "tail_overlap": "step s's tail + collectives on a second stream beside step s+1's extraction"
                                        if sf.overlap else "off (one stream)",
                        "mean_keypoints_per_image": float(counts.mean()), "mean_stereo_matches": float(nm.mean()),
                        "mean_features_per_frame": float(nfeat.mean()), "payload_bytes_per_step_per_gpu": payload_bytes,
                        "parity": "bit-exact vs the in-repo oracle (a restatement of OpenCV 3.2; parity with OpenCV itself unpinned)",
-                       "capacity_overflow": bool(status == capi.VSF_ERR_CAPACITY)},
+                       "capacity_overflow": bool(overflow_ranks)},
             # "bound" names the roofline this object is measured against (the contract knows "hbm" and "mfma");
             # "limited_by" says what the counters show the kernel is actually limited by (see "roofline_valu")
             "roofline": {"bound": "hbm", "limited_by": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbm_frac, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "launches": dom_launches},
+            # self-verification of a multi-GPU run: what the process group says it is, the ranks an all-gather of rank ids
+            # saw on that backend, every rank's own step time, the longest any rank's host waited inside a gather
+            "rccl": dict(handshake, per_rank_ms_per_step={"min": min(rank_ms), "max": max(rank_ms)},
+                         max_rank_blocked_in_gather_ms=blocked_ms, capacity_overflow_ranks=overflow_ranks),
             "roofline_valu": valu,
             "matcher": matcher,
             # every streaming stage against the same roofline (algorithmic bytes / measured stage time)
@@ -475,6 +496,11 @@ def main() -> int:
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if overflow_ranks:
+        if rank == 0:
+            print("bench.py: keypoint / match capacity overflowed on rank(s) %s: outputs were truncated, the line above is "
+                  "not a valid measurement" % overflow_ranks, file=sys.stderr)
+        return 4
     return 0
 
 

@@ -32,6 +32,8 @@ def _worker(rank: int, world: int, port: int, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         all_ok = True
+        hs = vd.collective_handshake()  # bench.py's self-verification: every rank sees every rank through the backend
+        all_ok &= hs["world"] == world and hs["ranks_seen"] == list(range(world)) and hs["backend"] == "gloo"
         for step in range(2):
             frames = vd.frame_block(step, B, world, rank)
             outs = [_fake_outputs(f) for f in frames]
@@ -92,6 +94,10 @@ def test_two_rank_gloo_gather_and_threshold_exchange():
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
     assert dict(results) == {0: True, 1: True}
+
+
+def test_handshake_without_a_process_group():
+    assert vd.collective_handshake() == {"backend": "none", "world": 1, "nccl_version": None, "ranks_seen": [0]}
 
 
 def test_frame_blocks_partition_the_stream():

@@ -128,9 +128,13 @@ def _rccl_worker(rank: int, port: int, frames_path: str, out_path: str):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        from vision_slam_frontend_amd import distributed as vd
+        hs = vd.collective_handshake(torch.device("cuda", 0))  # what bench.py prints as "rccl" for the first 8-GPU run
+        assert hs["backend"].startswith("nccl") and hs["world"] == 1 and hs["ranks_seen"] == [0] and hs["nccl_version"]
         frames = np.load(frames_path)
         sf, _, ctx = _run(frames, WORLD * B, 0, 1, overlap=False)  # (the one-stream form of the step, for coverage)
         assert sf.dist_on and not sf.host_detour and [c[0] for c in sf.completed] == list(range(STEPS))
+        assert sf.blocked_s >= 0.0
         np.savez(out_path, **{"s%d" % st: per[0].cpu().numpy() for st, per in sf.completed})
         ctx.close()
     finally:

@@ -16,6 +16,7 @@ CPU tensors in the CPU test-suite.
 from __future__ import annotations
 
 import os
+import time
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -158,6 +159,28 @@ def temporal_pair_sets(frames_per_rank: int, window: int, world: int, rank: int,
     return q, t
 
 
+def collective_handshake(device=None) -> dict:
+    """What a multi-GPU run needs in order to verify itself: the backend, the world size the process group reports, the
+    collective library's version and -- by an all-gather of the rank ids on the backend that will carry the step's
+    collectives (device tensors on RCCL) -- the ranks that actually took part.  Call once, after init_process_group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": "none", "world": 1, "nccl_version": None, "ranks_seen": [0]}
+    backend, world, rank = dist.get_backend(), dist.get_world_size(), dist.get_rank()
+    on_device = backend == "nccl"
+    dev = device if (on_device and device is not None) else (torch.device("cuda", torch.cuda.current_device()) if on_device else "cpu")
+    mine = torch.tensor([rank], dtype=torch.int32, device=dev)
+    seen = torch.full((world,), -1, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(seen, mine) if on_device else dist.all_gather(list(seen.split(1)), mine)
+    version = None
+    if on_device:
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 -- a version string is a nicety, never a reason to fail the run
+            version = "unknown"
+    return {"backend": backend + (" (RCCL)" if on_device and getattr(torch.version, "hip", None) else ""), "world": world,
+            "nccl_version": version, "ranks_seen": [int(v) for v in seen.cpu().tolist()]}
+
+
 class ShardedStereoFrontend:
     """One rank's share of a time-ordered stereo stream, one step = `frames_per_rank` frames on this GPU.
 
@@ -263,6 +286,7 @@ class ShardedStereoFrontend:
         self.inflight = []   # (step, work, send tensor, receive views) of the gathers not yet waited for
         self.completed = []  # on rank 0: (step, [uint8 tensor per rank]) in step order
         self.keep_outputs = True
+        self.blocked_s = 0.0  # host wall time spent waiting inside _issue_gather / _retire_through (bench.py reports it)
         ctx.set_stream(self.stream.cuda_stream)
         if self.overlap:
             self.tail_ctx.set_stream(self.tail_stream.cuda_stream)
@@ -371,7 +395,9 @@ class ShardedStereoFrontend:
 
     def _issue_gather(self, step: int):
         slot = step % self.PAYLOAD_SLOTS
+        t0 = time.perf_counter()
         self.size_events[slot].synchronize()  # (long done: the GPU is at least one step ahead of this point)
+        self.blocked_s += time.perf_counter() - t0
         nbytes = int(self.sizes_host[slot].max())
         nbytes = min((nbytes + 15) & ~15, self.cap)
         send = self.payload[slot][:nbytes]
@@ -388,7 +414,9 @@ class ShardedStereoFrontend:
         """Waits (stream-ordered on RCCL, on the host with gloo) for the gathers of all steps <= `step`."""
         while self.inflight and self.inflight[0][0] <= step:
             st, work, _send, recv = self.inflight.pop(0)
+            t0 = time.perf_counter()
             work.wait()
+            self.blocked_s += time.perf_counter() - t0
             if self.rank == 0 and self.keep_outputs:
                 self.completed.append((st, [r.clone() for r in recv]))
 
