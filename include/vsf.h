@@ -288,6 +288,18 @@ size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life);
 vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
                               size_t cap, size_t* out_bytes);
+/* The same, split in two so that the caller need not wait for the GPU between frames: vsf_observe_submit copies the two
+ * images into pinned staging, queues the whole chain and returns a ticket; vsf_observe_collect waits for that frame and
+ * hands over its result (same layout and status as vsf_observe_stereo, which is submit + collect).  Frontend::ObserveImage
+ * returns what OdomCheck decided (slam_frontend.cc:404-409), so nothing in the reference's control flow needs a frame's
+ * result before the next frame arrives.  A context with max_images >= 4 keeps TWO frames in flight: the extraction of
+ * frame k + 1 (its own stream and buffers) runs beside the tail of frame k, while the tails -- which carry the
+ * RemoveAmbigStereo threshold and the temporal window from frame to frame -- stay in frame order on the context's stream.
+ * Tickets are collected in the order they were issued; a submit whose slot still holds an uncollected frame returns
+ * VSF_ERR_INVALID_ARG.  Results are those of the synchronous call, bit for bit. */
+vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                              const vsf_calibration* calib, float best_percent, int frame_life, int64_t* ticket);
+vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_t cap, size_t* out_bytes);
 vsf_status vsf_observe_reset(vsf_ctx* ctx);
 
 /* SURVEY section 8(f) row f4, the decode itself: DecodeImage's cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE)

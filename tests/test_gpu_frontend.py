@@ -167,19 +167,38 @@ def test_fused_observe_equals_call_by_call():
     frames[2] = (frames[2][0], np.full_like(frames[2][1], 128))  # no stereo match in frame 2
     q = np.array([1, 0, 0, 0], np.float32)
     runs = []
-    for fused in (True, False):
+    for fused, pipelined in ((True, False), (False, False), (True, True)):
         fe = frontend.Frontend(320, 240, nfeatures=600, fundamental=F_RECT, frame_life=3)
         fe.set_fused(fused)
+        fe.set_pipelined(pipelined)
         fe.observe_odometry([0, 0, 0], q, 0.0)
         thr = []
         for f, (l, r) in enumerate(frames):
             fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
             assert fe.observe_image(l, r) is True
-            thr.append(fe.stereo_ambig_constraint)
+            if not pipelined:  # (reading the threshold would drain the pipeline: two frames stay in flight instead)
+                thr.append(fe.stereo_ambig_constraint)
+            elif f % 3 == 2:   # the odometry gate holds a frame back while others are still on the GPU
+                fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.5 + f)
+                assert fe.observe_image(l, r) is False
         runs.append(dict(thr=np.float32(thr), factors=fe.vision_factors(), nodes=fe.nodes(),
-                         frames=[fe.frame(i) for i in range(3)], wire=fe.serialize_problem()))
+                         frames=[fe.frame(i) for i in range(3)], wire=fe.serialize_problem(),
+                         odo=fe.odometry_factors()))
         fe.close()
-    a, b = runs
+    a, b, c = runs
+    # pipelined mode (two frames in flight, results booked late with the odometry of their own call): the same problem
+    assert c["wire"] == a["wire"] and len(c["nodes"]) == len(a["nodes"]) == 7
+    for na, nc in zip(a["nodes"], c["nodes"]):
+        assert na["node_idx"] == nc["node_idx"] and na["timestamp"] == nc["timestamp"]
+        np.testing.assert_array_equal(na["pose"], nc["pose"])
+        assert na["features"].tobytes() == nc["features"].tobytes()
+    for (a0, a1, ap), (c0, c1, cp) in zip(a["factors"], c["factors"]):
+        assert (a0, a1) == (c0, c1)
+        np.testing.assert_array_equal(ap, cp)
+    assert len(a["odo"]) == len(c["odo"]) == 6
+    for oa, oc in zip(a["odo"], c["odo"]):
+        assert oa[:2] == oc[:2]
+        np.testing.assert_array_equal(oa[2], oc[2])
     assert a["thr"].tobytes() == b["thr"].tobytes() and np.isnan(a["thr"][2]) and np.isfinite(a["thr"][3])
     assert len(a["factors"]) == len(b["factors"]) == 0 + 1 + 2 + 3 + 3 + 3 + 3
     for (a0, a1, ap), (b0, b1, bp) in zip(a["factors"], b["factors"]):

@@ -70,3 +70,53 @@ def test_observe_stereo_follows_the_reference_sequence(oracle):
     again = ctx.observe_stereo(*frames[0], calib, best_percent=bp, frame_life=LIFE)
     assert again["threshold"] == np.float32(10000.0) and len(again["factors"]) == 0
     ctx.close()
+
+
+def _same_observation(a: dict, b: dict):
+    for k in a:
+        va, vb = a[k], b[k]
+        if isinstance(va, np.ndarray):
+            assert va.tobytes() == vb.tobytes(), k
+        elif isinstance(va, list):
+            assert len(va) == len(vb) and all(x.tobytes() == y.tobytes() for x, y in zip(va, vb)), k
+        elif isinstance(va, (float, np.floating)):
+            assert np.float32(va).tobytes() == np.float32(vb).tobytes(), k
+        else:
+            assert va == vb, k
+
+
+def test_two_frames_in_flight_equal_the_synchronous_calls():
+    """vsf_observe_submit / vsf_observe_collect with TWO frames in flight (context with max_images = 4: the extraction of
+    frame k + 1 on its own stream beside the tail of frame k) return, frame for frame and byte for byte, what the
+    synchronous vsf_observe_stereo returns -- across the window filling and sliding, the frame without stereo matches and
+    the NaN threshold after it, whose state travels from tail to tail on the device."""
+    from vision_slam_frontend_amd import capi, frontend, synth
+    sc = synth.Scene(320, 240, n_objects=400)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(9)]
+    frames[3] = (frames[3][0], np.full_like(frames[3][1], 128))
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    bp = float(np.float32(0.3))
+    with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
+        want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
+    with capi.Context(capi.default_params(320, 240, max_images=4, nfeatures=NF)) as ctx:
+        got, tickets = [], []
+        for l, r in frames:
+            if len(tickets) == 2:
+                got.append(ctx.observe_collect(tickets.pop(0), frame_life=LIFE))
+            tickets.append(ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE))
+        # a third frame cannot enter while both slots hold uncollected frames; the newer frame cannot leave first
+        with pytest.raises(capi.VsfError):
+            ctx.observe_submit(*frames[0], calib, best_percent=bp, frame_life=LIFE)
+        with pytest.raises(capi.VsfError):
+            ctx.observe_collect(tickets[1], frame_life=LIFE)
+        while tickets:
+            got.append(ctx.observe_collect(tickets.pop(0), frame_life=LIFE))
+        with pytest.raises(capi.VsfError):
+            ctx.observe_collect(0, frame_life=LIFE)  # collected long ago
+        # the synchronous call still works on the same context and continues the same sequence
+        extra = ctx.observe_stereo(*frames[0], calib, best_percent=bp, frame_life=LIFE)
+        assert len(extra["factors"]) == LIFE
+    assert len(got) == len(want) == len(frames)
+    for g, w in zip(got, want):
+        _same_observation(w, g)
+    assert sum(len(f["features"]) for f in want) > 100

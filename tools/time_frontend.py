@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Latency of the one-frame-at-a-time path (C++ slam::Frontend): ObserveImage per stereo frame at 640x480, window 10,
-as one GPU submission (vsf_observe_stereo) and call by call (one C-ABI call per reference call).
-    python tools/time_frontend.py [nfeatures ...]     (default 2000 10000)"""
+"""The one-frame-at-a-time path (C++ slam::Frontend): ObserveImage per stereo frame at 640x480, window 10 -- as one GPU
+submission per call (vsf_observe_stereo: synchronous latency), call by call (one C-ABI call per reference call), and
+pipelined (vsf_observe_submit / vsf_observe_collect, two frames in flight: frames per second of the drop-in API).
+    python tools/time_frontend.py [--json] [nfeatures ...]     (default 2000 10000)"""
+import json
 import sys
 import time
 from pathlib import Path
@@ -15,9 +17,11 @@ from vision_slam_frontend_amd import frontend, synth  # noqa: E402
 _FRAMES = {}
 
 
-def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 56, width: int = 640, height: int = 480):
-    """Median ObserveImage time in ms in the steady state: the window of 10 kept frames is full and every launch chain
-    the fused path replays as a hipGraph has been captured once (one per ring slot: the first 21 frames)."""
+def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 56, width: int = 640, height: int = 480,
+                     pipelined: bool = False):
+    """Median ObserveImage time in ms in the steady state (the window of 10 kept frames is full; the first 32 calls are
+    left out).  pipelined: the call returns once the frame is queued, so the per-call time is host work only; the
+    frames-per-second figure is the wall time of the steady-state calls INCLUDING the final flush."""
     if (width, height) not in _FRAMES:
         sc = synth.Scene(width, height)
         base = [(sc.render(f, 0), sc.render(f, 1)) for f in range(14)]
@@ -27,23 +31,46 @@ def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 56, wid
     F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
     fe = frontend.Frontend(width, height, nfeatures=nfeatures, fundamental=F)
     fe.set_fused(fused)
+    fe.set_pipelined(pipelined)
     q = np.array([1, 0, 0, 0], np.float32)
     fe.observe_odometry([0, 0, 0], q, 0.0)
     ts = []
+    t_steady = None
     for f, (l, r) in enumerate(frames):
+        if f == 32:
+            fe.flush()
+            t_steady = time.perf_counter()
         fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
         t0 = time.perf_counter()
         added = fe.observe_image(l, r)
         ts.append(time.perf_counter() - t0)
         assert added
+    fe.flush()
+    fps = (n_frames - 32) / (time.perf_counter() - t_steady)
     feats = [len(n["features"]) for n in fe.nodes()]
     fe.close()
-    return 1e3 * float(np.median(ts[32:])), ts, feats
+    return 1e3 * float(np.median(ts[32:])), ts, feats, fps
 
 
 if __name__ == "__main__":
-    for nf in [int(a) for a in sys.argv[1:]] or [2000, 10000]:
-        for fused in (True, False):
-            ms, ts, feats = observe_image_ms(nf, fused)
-            print("nfeatures %5d %-12s ObserveImage median %.3f ms (window full); first %.1f ms; features/frame ~%d" %
-                  (nf, "fused" if fused else "call-by-call", ms, 1e3 * ts[0], int(np.median(feats))))
+    if "--dump" in sys.argv[1:]:  # frames for tools/time_frontend (the C++ driver): --dump FILE [n_frames]
+        i = sys.argv.index("--dump")
+        n = int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 16
+        sc = synth.Scene(640, 480)
+        np.stack([np.stack([sc.render(f, 0), sc.render(f, 1)]) for f in range(n)]).astype(np.uint8).tofile(sys.argv[i + 1])
+        print("wrote %d stereo frames 640x480 to %s" % (n, sys.argv[i + 1]))
+        sys.exit(0)
+    args = [a for a in sys.argv[1:] if a != "--json"]
+    record = {}
+    for nf in [int(a) for a in args] or [2000, 10000]:
+        for name, fused, pipelined, n in (("fused", True, False, 56), ("call-by-call", False, False, 56),
+                                          ("pipelined", True, True, 232)):
+            ms, ts, feats, fps = observe_image_ms(nf, fused, n_frames=n, pipelined=pipelined)
+            print("nfeatures %5d %-12s ObserveImage median %.3f ms per call (window full), %6.0f frames/s over %d steady "
+                  "frames; first call %.1f ms; features/frame ~%d" %
+                  (nf, name, ms, fps, n - 32, 1e3 * ts[0], int(np.median(feats))))
+            record["%s_%d" % (name.replace("-", "_"), nf)] = {"observe_image_ms": ms, "frames_per_s": fps,
+                                                             "features_per_frame": int(np.median(feats))}
+    if "--json" in sys.argv[1:]:
+        print(json.dumps({"what": "slam::Frontend::ObserveImage, 640x480, frame_life 10 (tools/time_frontend.py)",
+                          "results": record}))

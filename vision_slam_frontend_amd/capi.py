@@ -34,7 +34,7 @@ EXPORTS = [
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
-    "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_reset",
+    "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
     "vsf_jpeg_decode_gray_batch",
 ]
 STAGE_COUNT = 8
@@ -125,6 +125,9 @@ def lib() -> C.CDLL:
         L.vsf_pack_outputs_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, sz]
         L.vsf_observe_capacity.argtypes = [vp, i32]
         L.vsf_observe_capacity.restype = sz
+        L.vsf_observe_submit.argtypes = [vp, vp, vp, i32, i32, sz, C.POINTER(VsfCalibration), C.c_float, i32,
+                                         C.POINTER(C.c_int64)]
+        L.vsf_observe_collect.argtypes = [vp, C.c_int64, vp, sz, C.POINTER(sz)]
         L.vsf_observe_stereo.argtypes = [vp, vp, vp, i32, i32, sz, C.POINTER(VsfCalibration), C.c_float, i32, vp, sz,
                                          C.POINTER(sz)]
         L.vsf_observe_reset.argtypes = [vp]
@@ -371,6 +374,25 @@ class Context:
         self._check(lib().vsf_observe_stereo(self._h, _p(left), _p(right), left.shape[1], left.shape[0], left.strides[0],
                                              C.byref(calib), float(np.float32(best_percent)), frame_life, _p(buf), cap,
                                              C.byref(n)), "vsf_observe_stereo")
+        return decode_observation(buf[:n.value])
+
+    def observe_submit(self, left: np.ndarray, right: np.ndarray, calib: VsfCalibration, best_percent: float = 0.3,
+                       frame_life: int = 10) -> int:
+        """Queues one ObserveImage (vsf_observe_submit) and returns its ticket without waiting for the GPU."""
+        left, right = _u8(left), _u8(right)
+        assert left.shape == right.shape and left.strides == right.strides
+        t = C.c_int64(-1)
+        self._check(lib().vsf_observe_submit(self._h, _p(left), _p(right), left.shape[1], left.shape[0], left.strides[0],
+                                             C.byref(calib), float(np.float32(best_percent)), frame_life, C.byref(t)),
+                    "vsf_observe_submit")
+        return int(t.value)
+
+    def observe_collect(self, ticket: int, frame_life: int = 10) -> dict:
+        """Waits for the frame of `ticket` (vsf_observe_collect) and returns its decoded result."""
+        cap = int(lib().vsf_observe_capacity(self._h, frame_life))
+        buf = np.zeros(max(cap, 64), np.uint8)
+        n = C.c_size_t()
+        self._check(lib().vsf_observe_collect(self._h, C.c_int64(ticket), _p(buf), cap, C.byref(n)), "vsf_observe_collect")
         return decode_observation(buf[:n.value])
 
     def observe_reset(self):

@@ -475,16 +475,28 @@ struct vsf_ctx {
     uint8_t* ring = nullptr;        // [frame_life + 2][K][32]: kept frames, then the current left / right frame
     int32_t* ring_counts = nullptr; // [frame_life + 2]
     vsf_keypoint* kpf = nullptr;    // [2][K]
-    vsf_dmatch* matches = nullptr;  // [K] raw stereo matches
-    int32_t* ints = nullptr;        // nmatches, nfeat, npoints
+    vsf_dmatch* matches = nullptr;  // [slots][K] raw stereo matches
+    int32_t* ints = nullptr;        // [slots] nmatches, then nfeat, npoints
     float* floats = nullptr;        // mean, thr, thr_state
     vsf_vision_feature* features = nullptr;
     uint64_t* pairs = nullptr;      // [frame_life + 1][K][2]
     int32_t* npairs = nullptr;
-    uint8_t* h_img = nullptr;       // pinned: both images at the staging pitch
-    uint8_t* h_out = nullptr;       // pinned, written by observe_pack_kernel
+    // Two frames may be in flight (vsf_observe_submit / vsf_observe_collect, contexts with max_images >= 4): everything
+    // one frame's EXTRACTION writes exists once per slot -- pinned staging, per-call parameters, result buffer, status
+    // word, the slot's two images of every extraction buffer, raw stereo matches -- and runs on the slot's own stream;
+    // the TAIL (RemoveAmbigStereo ... result) of all frames runs in frame order on the context's stream, so its buffers
+    // exist once.
+    int slots = 1;
+    uint8_t* h_img[2] = {nullptr, nullptr};       // pinned: both images at the staging pitch
+    uint8_t* h_out[2] = {nullptr, nullptr};       // pinned, written by observe_pack_kernel
     size_t out_cap = 0;
-    ObserveMeta* h_meta = nullptr;
+    ObserveMeta* h_meta[2] = {nullptr, nullptr};
+    int32_t* h_status[2] = {nullptr, nullptr};    // pinned copy of the status word after the frame's last kernel
+    hipStream_t ex_stream[2] = {nullptr, nullptr};  // extraction of slot i (slot 0 of a one-slot context: ctx->stream)
+    hipEvent_t ev_extracted[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool done_valid[2] = {false, false};
+    int64_t ticket_of[2] = {-1, -1};  // submitted and not yet collected
+    int64_t next_ticket = 0;
     std::vector<int> order;         // ring slots of the kept frames, oldest first
   } ob;
   // vsf_jpeg_decode_gray_batch: pinned staging + device copy of the packed headers / tables / entropy-coded segments
@@ -645,9 +657,16 @@ void free_observe(vsf_ctx* ctx) {
   hipFree(o.features);
   hipFree(o.pairs);
   hipFree(o.npairs);
-  if (o.h_img) hipHostFree(o.h_img);
-  if (o.h_out) hipHostFree(o.h_out);
-  if (o.h_meta) hipHostFree(o.h_meta);
+  for (int i = 0; i < 2; i++) {
+    if (o.h_img[i]) hipHostFree(o.h_img[i]);
+    if (o.h_out[i]) hipHostFree(o.h_out[i]);
+    if (o.h_meta[i]) hipHostFree(o.h_meta[i]);
+    if (o.h_status[i]) hipHostFree(o.h_status[i]);
+    if (o.ex_stream[i] && o.ex_stream[i] != ctx->stream && (i == 0 || o.ex_stream[i] != o.ex_stream[0]))
+      hipStreamDestroy(o.ex_stream[i]);
+    if (o.ev_extracted[i]) hipEventDestroy(o.ev_extracted[i]);
+    if (o.ev_done[i]) hipEventDestroy(o.ev_done[i]);
+  }
   o = vsf_ctx::Observe();
 }
 
@@ -695,6 +714,14 @@ void prof_fold(vsf_ctx* ctx) {  // stream must be idle
   ctx->ev_used = 0;
 }
 
+void sync_all_streams(vsf_ctx* ctx) {  // every stream the context launches on
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+  if (ctx->blur_stream) (void)hipStreamSynchronize(ctx->blur_stream);
+  for (int i = 0; i < 2; i++)
+    if (ctx->ob.ex_stream[i] && ctx->ob.ex_stream[i] != ctx->stream) (void)hipStreamSynchronize(ctx->ob.ex_stream[i]);
+}
+
 struct StageTimer {  // records an event pair around one stage when profiling is on
   vsf_ctx* ctx;
   size_t slot = 0;
@@ -703,8 +730,7 @@ struct StageTimer {  // records an event pair around one stage when profiling is
   StageTimer(vsf_ctx* c, hipStream_t stream, int stage, int launches) : ctx(c), on(c->prof_on), st(stream) {
     if (!on) return;
     if (ctx->ev_used >= 2048) {
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipStreamSynchronize(ctx->aux_stream);
+      sync_all_streams(ctx);
       prof_fold(ctx);
     }
     slot = ctx->ev_used++;
@@ -1207,7 +1233,7 @@ vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_
 
 vsf_status vsf_profile_enable(vsf_ctx* ctx, int on) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
-  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  sync_all_streams(ctx);
   prof_fold(ctx);
   ctx->prof_on = on != 0;
   return VSF_OK;
@@ -1215,7 +1241,7 @@ vsf_status vsf_profile_enable(vsf_ctx* ctx, int on) {
 
 vsf_status vsf_profile_read(vsf_ctx* ctx, double* ms_total, int64_t* launches, int reset) {
   if (!ctx || !ms_total || !launches) return VSF_ERR_INVALID_ARG;
-  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  sync_all_streams(ctx);
   prof_fold(ctx);
   for (int i = 0; i < VSF_STAGE_COUNT; i++) {
     ms_total[i] = ctx->prof_ms[i];
@@ -1530,16 +1556,19 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   vsf_ctx::Observe& o = ctx->ob;
   if (o.ring && o.frame_life == frame_life) return VSF_OK;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 2; i++)
+    if (o.ex_stream[i]) VSF_HIP(hipStreamSynchronize(o.ex_stream[i]));
   float thr_state = 10000.0f;  // cc:353
   const bool had = o.floats != nullptr;
   if (had) VSF_HIP(hipMemcpy(&thr_state, o.floats + 2, sizeof(float), hipMemcpyDeviceToHost));
   free_observe(ctx);
   const size_t K = (size_t)ctx->p.max_keypoints, S = (size_t)frame_life + 2;
+  o.slots = ctx->p.max_images >= 4 ? 2 : 1;
   VSF_HIP(hipMalloc((void**)&o.ring, S * K * VSF_DESC_BYTES));
   VSF_HIP(hipMalloc((void**)&o.ring_counts, S * sizeof(int32_t)));
   VSF_HIP(hipMemset(o.ring_counts, 0, S * sizeof(int32_t)));
   VSF_HIP(hipMalloc((void**)&o.kpf, 2 * K * sizeof(vsf_keypoint)));
-  VSF_HIP(hipMalloc((void**)&o.matches, K * sizeof(vsf_dmatch)));
+  VSF_HIP(hipMalloc((void**)&o.matches, 2 * K * sizeof(vsf_dmatch)));
   VSF_HIP(hipMalloc((void**)&o.ints, 4 * sizeof(int32_t)));
   VSF_HIP(hipMemset(o.ints, 0, 4 * sizeof(int32_t)));
   VSF_HIP(hipMalloc((void**)&o.floats, 4 * sizeof(float)));
@@ -1548,13 +1577,34 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   VSF_HIP(hipMalloc((void**)&o.features, K * sizeof(vsf_vision_feature)));
   VSF_HIP(hipMalloc((void**)&o.pairs, (size_t)(frame_life + 1) * K * 2 * sizeof(uint64_t)));
   VSF_HIP(hipMalloc((void**)&o.npairs, (size_t)(frame_life + 1) * sizeof(int32_t)));
-  VSF_HIP(hipHostMalloc((void**)&o.h_img, 2 * ctx->st_img_stride, hipHostMallocMapped));
   o.out_cap = vsf_observe_capacity(ctx, frame_life);
-  VSF_HIP(hipHostMalloc((void**)&o.h_out, o.out_cap, hipHostMallocMapped));
-  VSF_HIP(hipHostMalloc((void**)&o.h_meta, sizeof(vsf_ctx::ObserveMeta), hipHostMallocMapped));
-  std::memset(o.h_meta, 0, sizeof(vsf_ctx::ObserveMeta));
+  for (int i = 0; i < o.slots; i++) {
+    VSF_HIP(hipHostMalloc((void**)&o.h_img[i], 2 * ctx->st_img_stride, hipHostMallocMapped));
+    VSF_HIP(hipHostMalloc((void**)&o.h_out[i], o.out_cap, hipHostMallocMapped));
+    VSF_HIP(hipHostMalloc((void**)&o.h_meta[i], sizeof(vsf_ctx::ObserveMeta), hipHostMallocMapped));
+    std::memset(o.h_meta[i], 0, sizeof(vsf_ctx::ObserveMeta));
+    VSF_HIP(hipHostMalloc((void**)&o.h_status[i], sizeof(int32_t), hipHostMallocMapped));
+    *o.h_status[i] = 0;
+    // ONE extraction stream for both slots, at the highest stream priority.  HIP multiplexes streams onto a few hardware
+    // queues (round-robin at creation) and kernels of streams that share a queue run one after the other: with a stream
+    // per slot, one of the two landed on the tail stream's queue and its frames overlapped nothing (kernel trace:
+    // 0.33 ms per frame, no better than one stream).  Streams of different priorities never share a queue, and what has
+    // to overlap is the extraction of frame k + 1 with the tail of frame k, not two extractions.
+    if (o.slots == 1) {
+      o.ex_stream[i] = ctx->stream;
+    } else if (i == 0) {
+      int prio_lo = 0, prio_hi = 0;
+      VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[0], hipStreamNonBlocking, prio_hi));
+    } else {
+      o.ex_stream[1] = o.ex_stream[0];
+    }
+    VSF_HIP(hipEventCreateWithFlags(&o.ev_extracted[i], hipEventDisableTiming));
+    VSF_HIP(hipEventCreateWithFlags(&o.ev_done[i], hipEventDisableTiming));
+  }
   o.frame_life = frame_life;
-  vsf_status st = ensure_match_buffers(ctx, frame_life + 1, (int)K);
+  // matcher scratch: pairs [0, frame_life] belong to the tail, pair frame_life + 1 + slot to the slot's stereo match
+  vsf_status st = ensure_match_buffers(ctx, frame_life + 1 + 2, (int)K);
   if (st == VSF_OK) st = ensure_temporal_buffers(ctx, frame_life + 1);
   if (st == VSF_OK) st = ensure_residual_buffers(ctx, 1);
   return st;
@@ -1563,39 +1613,54 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
 vsf_status vsf_observe_reset(vsf_ctx* ctx) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
+  for (int i = 0; i < 2; i++)
+    if (ctx->ob.ex_stream[i]) VSF_HIP(hipStreamSynchronize(ctx->ob.ex_stream[i]));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   free_observe(ctx);
   return VSF_OK;
 }
 
-vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
-                              const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
-                              size_t cap, size_t* out_bytes) {
-  if (!ctx || !left || !right || !calib || !out || !out_bytes || !(best_percent >= 0.f) || frame_life < 0 ||
+vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                              const vsf_calibration* calib, float best_percent, int frame_life, int64_t* ticket) {
+  if (!ctx || !left || !right || !calib || !ticket || !(best_percent >= 0.f) || frame_life < 0 ||
       frame_life + 1 > VSF_OBSERVE_MAX_PAIRS)
     return VSF_ERR_INVALID_ARG;
-  *out_bytes = 0;
+  *ticket = -1;
   if (w != ctx->p.width || h != ctx->p.height || stride < (size_t)w || ctx->p.max_images < 2) return VSF_ERR_INVALID_ARG;
   if (ctx->p.max_keypoints >= 65536) return VSF_ERR_UNSUPPORTED;
   if (calib->triangulate_rows != 0 && calib->triangulate_rows != 4 && calib->triangulate_rows != 6)
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
+  if (ctx->ob.ring && ctx->ob.frame_life != frame_life)  // (re-sizing the window drops nothing that is still in flight)
+    for (int i = 0; i < 2; i++)
+      if (ctx->ob.ticket_of[i] >= 0) return VSF_ERR_INVALID_ARG;
   vsf_status st = ensure_observe(ctx, frame_life);
   if (st != VSF_OK) return st;
   vsf_ctx::Observe& o = ctx->ob;
-  hipStream_t s = ctx->stream;
+  const int slot = (int)(o.next_ticket % o.slots);
+  if (o.ticket_of[slot] >= 0) return VSF_ERR_INVALID_ARG;  // collect that frame first: its buffers are about to be reused
+  hipStream_t ex = o.ex_stream[slot], s = ctx->stream;
   const size_t K = (size_t)ctx->p.max_keypoints;
   const int Kc = (int)K;
-  // ---- upload: rows into the pinned staging at the device pitch, ONE copy command for both images ----
+  // ---- upload: rows into the slot's pinned staging at the device pitch, ONE copy command for both images ----
   const uint8_t* src[2] = {left, right};
-  for (int i = 0; i < 2; i++)
-    for (int y = 0; y < h; y++)
-      std::memcpy(o.h_img + (size_t)i * ctx->st_img_stride + (size_t)y * ctx->st_img_pitch, src[i] + (size_t)y * stride,
-                  (size_t)w);
-  VSF_HIP(hipMemcpyAsync(ctx->st_img, o.h_img, 2 * ctx->st_img_stride, hipMemcpyHostToDevice, s));
+  uint8_t* h_img = o.h_img[slot];
+  for (int i = 0; i < 2; i++) {
+    uint8_t* dst = h_img + (size_t)i * ctx->st_img_stride;
+    if (stride == ctx->st_img_pitch) {  // the caller's rows already sit at the staging pitch: one copy per image
+      std::memcpy(dst, src[i], (size_t)(h - 1) * stride + (size_t)w);
+    } else {
+      for (int y = 0; y < h; y++) std::memcpy(dst + (size_t)y * ctx->st_img_pitch, src[i] + (size_t)y * stride, (size_t)w);
+    }
+  }
+  // the slot's previous frame has been collected, i.e. its tail has finished reading what the extraction now overwrites;
+  // with the extraction on a stream of its own that order has to be spelt out once more for the device
+  if (ex != s && o.done_valid[slot]) VSF_HIP(hipStreamWaitEvent(ex, o.ev_done[slot], 0));
+  uint8_t* d_img = ctx->st_img + (size_t)(2 * slot) * ctx->st_img_stride;
+  VSF_HIP(hipMemcpyAsync(d_img, h_img, 2 * ctx->st_img_stride, hipMemcpyHostToDevice, ex));
   // ---- per-call parameters: written into pinned memory the kernels read directly ----
   const int n_past = (int)o.order.size(), n_pairs = n_past + 1, S = frame_life;
-  vsf_ctx::ObserveMeta& M = *o.h_meta;
+  vsf_ctx::ObserveMeta& M = *o.h_meta[slot];
   std::memcpy(M.F, calib->fundamental, sizeof(M.F));
   for (int p = 0; p < n_past; p++) {
     M.q_set[p] = o.order[p];  // oldest kept frame first: the order frame_list_ is walked in (cc:424)
@@ -1605,24 +1670,35 @@ vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   M.q_set[n_past] = S + 1;  // Calculate3DPoints: GetFeatureMatches(right, left) with best_percent_ 1.0 (cc:129-132)
   M.t_set[n_past] = S;
   M.best_percent[n_past] = 1.0f;
-  // ---- ExtractFeatures x 2 + GetMatches (cc:411-416) ----
-  const VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
-  extract_on(ctx, s, im, 0, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts);
-  ctx->last_images = im;
+  // ---- ExtractFeatures x 2 + GetMatches (cc:411-416), on the slot's stream and in the slot's buffers ----
+  const VsfImages im{ctx->st_img, ctx->st_img_stride, ctx->st_img_pitch, 2 * (slot + 1)};
+  vsf_keypoint* kp_raw = ctx->st_kp + (size_t)(2 * slot) * K;
+  uint8_t* desc_raw = ctx->st_desc + (size_t)(2 * slot) * K * VSF_DESC_BYTES;
+  int32_t* counts_raw = ctx->st_counts + 2 * slot;
+  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts);
+  ctx->last_images = VsfImages{d_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
   ctx->last_valid = true;
-  int32_t* nmatches = o.ints;
-  match_on(ctx, s, ctx->st_desc, ctx->st_counts, K * VSF_DESC_BYTES, nullptr, nullptr, 0, 1, ctx->m_idx2, ctx->m_dist2,
-           o.matches, nmatches);
+  int32_t* nmatches = o.ints + slot;
+  vsf_dmatch* raw_matches = o.matches + (size_t)slot * K;
+  {
+    const size_t scratch = (size_t)(frame_life + 1 + slot) * K * 2;
+    match_on(ctx, ex, desc_raw, counts_raw, K * VSF_DESC_BYTES, nullptr, nullptr, 0, 1, ctx->m_idx2 + scratch,
+             ctx->m_dist2 + scratch, raw_matches, nmatches);
+  }
+  if (ex != s) {
+    VSF_HIP(hipEventRecord(o.ev_extracted[slot], ex));
+    VSF_HIP(hipStreamWaitEvent(s, o.ev_extracted[slot], 0));
+  }
   // ---- RemoveAmbigStereo (cc:417): the current frame lands in ring sets S (left) and S + 1 (right) ----
   float *means = o.floats, *thr = o.floats + 1, *thr_state = o.floats + 2;
   uint8_t* cur_desc = o.ring + (size_t)S * K * VSF_DESC_BYTES;
   int32_t* cur_counts = o.ring_counts + S;
   {
     StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
-    vsf_launch_stereo_residuals(ctx->st_kp, o.matches, nmatches, 1, Kc, M.F, ctx->p.residual_order, ctx->f_residual, means, s);
+    vsf_launch_stereo_residuals(kp_raw, raw_matches, nmatches, 1, Kc, M.F, ctx->p.residual_order, ctx->f_residual, means, s);
     vsf_launch_stereo_thresholds(means, 1, thr_state, thr, s);
-    vsf_launch_stereo_filter_only(ctx->st_kp, ctx->st_desc, o.matches, nmatches, 1, Kc, ctx->f_residual, thr, o.kpf,
-                                  cur_desc, cur_counts, s);
+    vsf_launch_stereo_filter_only(kp_raw, desc_raw, raw_matches, nmatches, 1, Kc, ctx->f_residual, thr, o.kpf, cur_desc,
+                                  cur_counts, s);
   }
   // ---- GetFeatureMatches against every kept frame + the right->left matches of Calculate3DPoints: one matcher
   // launch, one sort launch (per-pair best_percent) ----
@@ -1640,27 +1716,27 @@ vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, Kc, best_percent, M.best_percent, ctx->t_sortkeys,
                          o.pairs, o.npairs, s);
     // ---- Calculate3DPoints + VisionFeature + UndistortFeaturePoints (cc:437-443) ----
-    int32_t *nfeat = o.ints + 1, *npoints = o.ints + 2;
+    int32_t *nfeat = o.ints + 2, *npoints = o.ints + 3;
     vsf_launch_vision_features(o.kpf, cur_counts, o.pairs + (size_t)n_past * K * 2, o.npairs + n_past, 1, Kc, *calib,
                                o.features, nfeat, npoints, s);
     // ---- the compact result into pinned memory; the filtered left frame into its ring slot (cc:467-470) ----
-    int slot;
+    int ring_slot;
     if (frame_life == 0) {
-      slot = S + 1;  // nothing is kept: park it on the right frame's set
+      ring_slot = S + 1;  // nothing is kept: park it on the right frame's set
     } else if (n_past >= frame_life) {
-      slot = o.order.front();
+      ring_slot = o.order.front();
     } else {
-      slot = n_past;
+      ring_slot = n_past;
       for (int c = 0; c < frame_life; c++)
         if (std::find(o.order.begin(), o.order.end(), c) == o.order.end()) {
-          slot = c;
+          ring_slot = c;
           break;
         }
     }
     VsfObserveArgs a;
     a.n_pairs = n_pairs;
     a.max_rows = Kc;
-    a.counts_raw = ctx->st_counts;
+    a.counts_raw = counts_raw;
     a.nmatches = nmatches;
     a.counts_f = cur_counts;
     a.npoints = npoints;
@@ -1672,26 +1748,59 @@ vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     a.desc_f = cur_desc;
     a.pairs = o.pairs;
     a.npairs = o.npairs;
-    a.ring_desc = o.ring + (size_t)slot * K * VSF_DESC_BYTES;
-    a.ring_count = o.ring_counts + slot;
-    a.out = o.h_out;
+    a.ring_desc = o.ring + (size_t)ring_slot * K * VSF_DESC_BYTES;
+    a.ring_count = o.ring_counts + ring_slot;
+    a.out = o.h_out[slot];
     a.out_cap = (uint32_t)std::min<size_t>(o.out_cap, 0xFFFFFFF0u);
     vsf_launch_observe_pack(a, s);
     if (frame_life > 0) {
       if (n_past >= frame_life) o.order.erase(o.order.begin());
-      o.order.push_back(slot);
+      o.order.push_back(ring_slot);
     }
   }
+  // the status word of everything up to here, then "this frame is done"
+  VSF_HIP(hipMemcpyAsync(o.h_status[slot], ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  VSF_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), s));
+  VSF_HIP(hipEventRecord(o.ev_done[slot], s));
+  o.done_valid[slot] = true;
   VSF_HIP(hipGetLastError());
-  st = check_status_word(ctx);  // synchronises
-  if (st == VSF_ERR_HIP) return st;
-  const uint32_t* hdr = reinterpret_cast<const uint32_t*>(o.h_out);
+  o.ticket_of[slot] = o.next_ticket;
+  *ticket = o.next_ticket++;
+  return VSF_OK;
+}
+
+vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_t cap, size_t* out_bytes) {
+  if (!ctx || !out || !out_bytes || ticket < 0) return VSF_ERR_INVALID_ARG;
+  *out_bytes = 0;
+  vsf_ctx::Observe& o = ctx->ob;
+  const int slot = (int)(ticket % std::max(o.slots, 1));
+  if (!o.ring || o.ticket_of[slot] != ticket) return VSF_ERR_INVALID_ARG;
+  // frames leave in the order they entered (the host's bookkeeping is sequential): an older frame must be collected first
+  for (int i = 0; i < o.slots; i++)
+    if (o.ticket_of[i] >= 0 && o.ticket_of[i] < ticket) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VSF_HIP(hipEventSynchronize(o.ev_done[slot]));
+  o.ticket_of[slot] = -1;
+  vsf_status st = VSF_OK;
+  if (*o.h_status[slot] & 1) st = VSF_ERR_CAPACITY;
+  const uint32_t* hdr = reinterpret_cast<const uint32_t*>(o.h_out[slot]);
   if (hdr[0] != 0x4F465356u) return VSF_ERR_HIP;
   const size_t total = hdr[3];
   *out_bytes = total;
   if (hdr[11] != 0 || total > cap) return VSF_ERR_CAPACITY;
-  std::memcpy(out, o.h_out, total);
+  std::memcpy(out, o.h_out[slot], total);
   return st;
+}
+
+vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                              const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
+                              size_t cap, size_t* out_bytes) {
+  if (!out || !out_bytes) return VSF_ERR_INVALID_ARG;
+  *out_bytes = 0;
+  int64_t ticket = -1;
+  const vsf_status st = vsf_observe_submit(ctx, left, right, w, h, stride, calib, best_percent, frame_life, &ticket);
+  if (st != VSF_OK) return st;
+  return vsf_observe_collect(ctx, ticket, out, cap, out_bytes);
 }
 
 // ---------------- host-pointer entry points ----------------

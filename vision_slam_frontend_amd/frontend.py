@@ -44,6 +44,9 @@ def lib() -> C.CDLL:
         L.vsfh_default_calibration.restype = None
         L.vsfh_set_fused.argtypes = [vp, i32]
         L.vsfh_set_fused.restype = None
+        L.vsfh_set_pipelined.argtypes = [vp, i32]
+        L.vsfh_set_pipelined.restype = None
+        L.vsfh_flush.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -73,6 +76,16 @@ class Frontend:
         """True (default): ObserveImage is one GPU submission (vsf_observe_stereo); False: one C-ABI call per
         reference call with the reference's host steps in between.  Choose before the first observe_image."""
         lib().vsfh_set_fused(self._h, int(on))
+
+    def set_pipelined(self, on: bool):
+        """observe_image queues its frame on the GPU and returns (its return value is the odometry gate's decision); results
+        are collected and booked, in frame order, two frames later or when the problem is read.  Fused mode; choose before the
+        first observe_image."""
+        lib().vsfh_set_pipelined(self._h, int(on))
+
+    def flush(self) -> bool:
+        """Collects and books every frame still in flight."""
+        return bool(lib().vsfh_flush(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

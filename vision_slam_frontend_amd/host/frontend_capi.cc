@@ -27,6 +27,8 @@ void* vsfh_frontend_create(int nfeatures, int width, int height, int device, con
 void vsfh_default_calibration(vsf_calibration* out) { *out = slam::MakeCalibration(FrontendConfig()); }
 
 void vsfh_set_fused(void* f, int on) { static_cast<Frontend*>(f)->set_fused(on != 0); }
+void vsfh_set_pipelined(void* f, int on) { static_cast<Frontend*>(f)->set_pipelined(on != 0); }
+int vsfh_flush(void* f) { return static_cast<Frontend*>(f)->Flush() ? 1 : 0; }
 
 void vsfh_frontend_destroy(void* f) { delete static_cast<Frontend*>(f); }
 

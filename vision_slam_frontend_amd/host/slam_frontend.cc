@@ -217,6 +217,7 @@ Frontend::Frontend(const std::string& /*config_path*/, const FrontendConfig& con
       curr_frame_ID_(0),
       stereo_ambig_constraint_(10000),  // cc:353
       fused_(true),
+      pipelined_(false),
       ctx_(nullptr),
       device_(device),
       last_status_(VSF_OK) {
@@ -232,12 +233,12 @@ bool Frontend::EnsureContext(int width, int height) {
   if (ctx_) {
     vsf_params p;
     vsf_get_params(ctx_, &p);
-    if (p.width == width && p.height == height) return true;
+    if (p.width == width && p.height == height && p.max_images >= (pipelined_ ? 4 : 2)) return true;
     vsf_destroy(ctx_);
     ctx_ = nullptr;
   }
   vsf_params p;
-  vsf_params_default(&p, width, height, 2);
+  vsf_params_default(&p, width, height, pipelined_ ? 4 : 2);  // two frames in flight need two slots of buffers
   p.nfeatures = config_.orb_nfeatures;
   p.residual_order = config_.residual_order;
   last_status_ = vsf_params_set_ratio(&p, config_.nn_match_ratio_);
@@ -532,12 +533,41 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
     return false;
   }
   const vsf_calibration calib = MakeCalibration(config_);
+  // the slot this frame goes into must be free: with two frames in flight, the older one is collected and booked first
+  while (pending_.size() >= (pipelined_ ? 2u : 1u))
+    if (!RetireOldest()) return false;
+  PendingFrame pf;
+  last_status_ = vsf_observe_submit(ctx_, left_image.data, right_image.data, left_image.cols, left_image.rows,
+                                    left_image.step, &calib, config_.best_percent_, (int)config_.frame_life_, &pf.ticket);
+  if (last_status_ != VSF_OK) return false;
+  pf.odom_translation = odom_translation_;
+  pf.odom_rotation = odom_rotation_;
+  pf.prev_odom_translation = prev_odom_translation_;
+  pf.prev_odom_rotation = prev_odom_rotation_;
+  pf.odom_timestamp = odom_timestamp_;
+  pending_.push_back(pf);
+  // cc:457-458: the pose of this frame is what the NEXT call's OdomCheck compares with
+  prev_odom_rotation_ = odom_rotation_;
+  prev_odom_translation_ = odom_translation_;
+  if (!pipelined_) return RetireOldest();
+  return true;
+}
+
+bool Frontend::Flush() {
+  while (!pending_.empty())
+    if (!RetireOldest()) return false;
+  return true;
+}
+
+// The second half of ObserveImageFused for the oldest frame in flight: wait for its result, decode it, and do the
+// reference's bookkeeping (cc:424-470) with the odometry that frame's call saw.
+bool Frontend::RetireOldest() {
+  const PendingFrame pf = pending_.front();
+  pending_.erase(pending_.begin());
   const size_t cap = vsf_observe_capacity(ctx_, (int)config_.frame_life_);
   if (observe_buf_.size() < cap) observe_buf_.resize(cap);
   size_t bytes = 0;
-  last_status_ = vsf_observe_stereo(ctx_, left_image.data, right_image.data, left_image.cols, left_image.rows,
-                                    left_image.step, &calib, config_.best_percent_, (int)config_.frame_life_,
-                                    observe_buf_.data(), observe_buf_.size(), &bytes);
+  last_status_ = vsf_observe_collect(ctx_, pf.ticket, observe_buf_.data(), observe_buf_.size(), &bytes);
   if (last_status_ != VSF_OK) return false;
   const uint8_t* b = observe_buf_.data();
   uint32_t hdr[16];
@@ -597,7 +627,18 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
     features.push_back(VisionFeature((uint64_t)f.feature_idx_lo | ((uint64_t)f.feature_idx_hi << 32),
                                      Vector2f(f.pixel[0], f.pixel[1]), Vector3f(f.point3d[0], f.point3d[1], f.point3d[2])));
   }
-  FinishNode(curr_frame, features);
+  // cc:444-470 with the odometry of this frame's call
+  const Vector3f loc = init_odom_rotation_.inverse() * (pf.odom_translation - init_odom_translation_);
+  const Quaternionf angle = pf.odom_rotation * init_odom_rotation_.inverse();
+  nodes_.push_back(SLAMNode(curr_frame_ID_, pf.odom_timestamp, RobotPose(loc, angle), features));
+  if (curr_frame_ID_ > 0) {  // AddOdometryFactor, cc:311-321
+    const Vector3f translation = pf.prev_odom_rotation.inverse() * (pf.odom_translation - pf.prev_odom_translation);
+    const Quaternionf rotation(pf.odom_rotation * pf.prev_odom_rotation.inverse());
+    odometry_factors_.push_back(OdometryFactor(curr_frame_ID_ - 1, curr_frame_ID_, translation, rotation));
+  }
+  curr_frame_ID_++;
+  if (frame_list_.size() >= config_.frame_life_ && !frame_list_.empty()) frame_list_.erase(frame_list_.begin());
+  frame_list_.push_back(curr_frame);
   return true;
 }
 
@@ -642,9 +683,13 @@ bool Frontend::ObserveImage(const Image& left_image, const Image& right_image, d
 }
 
 void Frontend::GetSLAMProblem(SLAMProblem* problem) const {
+  Sync();  // (pipelined mode: frames still on the GPU are booked first)
   *problem = SLAMProblem(nodes_, vision_factors_, odometry_factors_);
 }
 
-int Frontend::GetNumPoses() { return (int)nodes_.size(); }
+int Frontend::GetNumPoses() {
+  Flush();
+  return (int)nodes_.size();
+}
 
 }  // namespace slam

@@ -112,11 +112,19 @@ class Frontend {
   // (vsf_extract_pair, vsf_get_matches, ...) with the reference's host steps in between.  Same results; choose before
   // the first ObserveImage.
   void set_fused(bool on) { fused_ = on; }
-  float stereo_ambig_constraint() const { return stereo_ambig_constraint_; }
-  const std::vector<Frame>& frame_list() const { return frame_list_; }
-  const std::vector<slam_types::SLAMNode>& nodes() const { return nodes_; }
-  const std::vector<slam_types::VisionFactor>& vision_factors() const { return vision_factors_; }
-  const std::vector<slam_types::OdometryFactor>& odometry_factors() const { return odometry_factors_; }
+  // ObserveImage's return value is OdomCheck's decision (cc:404-409): nothing in the reference's control flow needs a
+  // frame's features before the next frame arrives.  With pipelining on (fused mode; choose before the first
+  // ObserveImage) a call queues its frame on the GPU (vsf_observe_submit) and returns; the frame's result is collected
+  // and booked -- in frame order, with the odometry of ITS call -- when its slot is needed again (two frames later) or
+  // when anything reads the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and
+  // bytes as the synchronous mode; a GPU failure then surfaces in last_status() one or two calls late.
+  void set_pipelined(bool on) { pipelined_ = on; }
+  bool Flush();  // collects and books every frame still in flight; false (and last_status()) if one of them failed
+  float stereo_ambig_constraint() const { Sync(); return stereo_ambig_constraint_; }
+  const std::vector<Frame>& frame_list() const { Sync(); return frame_list_; }
+  const std::vector<slam_types::SLAMNode>& nodes() const { Sync(); return nodes_; }
+  const std::vector<slam_types::VisionFactor>& vision_factors() const { Sync(); return vision_factors_; }
+  const std::vector<slam_types::OdometryFactor>& odometry_factors() const { Sync(); return odometry_factors_; }
 
  private:
   bool OdomCheck();
@@ -136,6 +144,16 @@ class Frontend {
   bool EnsureContext(int width, int height);
   bool ObserveImageFused(const Image& left_image, const Image& right_image);
   void FinishNode(const Frame& curr_frame, const std::vector<slam_types::VisionFeature>& features);
+  // A frame the GPU is still working on, with the odometry its ObserveImage call saw (cc:444-458 reads it at the END of
+  // the call; between submit and collect the driver may already have delivered the next pose).
+  struct PendingFrame {
+    int64_t ticket;
+    Vector3f odom_translation, prev_odom_translation;
+    Quaternionf odom_rotation, prev_odom_rotation;
+    double odom_timestamp;
+  };
+  bool RetireOldest();
+  void Sync() const { const_cast<Frontend*>(this)->Flush(); }
 
   bool odom_initialized_;
   Vector3f init_odom_translation_;
@@ -154,6 +172,8 @@ class Frontend {
   // The reference keeps this in a file-static shared by all instances (cc:353, quirk Q3); here it is per object.
   float stereo_ambig_constraint_;
   bool fused_;
+  bool pipelined_;
+  std::vector<PendingFrame> pending_;  // oldest first; at most two
   std::vector<uint8_t> observe_buf_;
   vsf_ctx* ctx_;
   int device_;
