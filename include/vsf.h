@@ -345,6 +345,12 @@ vsf_status vsf_debug_level_keypoints(vsf_ctx* ctx, int image, int level, vsf_key
  * (packed FAST candidates).  use_lds: run on an LDS copy when n <= 4096.  *n_out = surviving count. */
 vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids, int n, int n_points, int use_lds,
                                  int mode, int* n_out);
+/* Test hook of the order-exact sort of Frontend::GetFeatureMatches (slam_frontend.cc:289-291): n_lists lists of n host
+ * matches each (list i at matches + i * n; the context's max_keypoints bounds n) go through the device's std::sort
+ * restatement + the cut to int(n * best_percent); pairs_out[i * n * 2 ...] receives (queryIdx, trainIdx) of the survivors
+ * in sorted order and counts_out[i] their number.  serial != 0 forces the one-lane kernel. */
+vsf_status vsf_debug_sort_trim(vsf_ctx* ctx, const vsf_dmatch* matches, int n_lists, int n, float best_percent,
+                               int serial, uint64_t* pairs_out, int32_t* counts_out);
 
 /* Per-stage device timing (hipEvents recorded on the context's stream around every stage of the batched entry
  * points).  vsf_profile_read synchronises the stream, adds the elapsed milliseconds and launch counts of every

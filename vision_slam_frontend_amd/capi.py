@@ -32,7 +32,7 @@ EXPORTS = [
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_pair", "vsf_get_matches_multi", "vsf_extract_batch_dev", "vsf_match_batch_dev",
     "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_set_blur_overlap", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_bayer_bg_to_gray_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
-    "vsf_stage_name", "vsf_debug_retain_best", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
+    "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
     "vsf_jpeg_decode_gray_batch",
@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
         L.vsf_packed_outputs_capacity.argtypes = [vp, i32, i32]
         L.vsf_packed_outputs_capacity.restype = sz
         L.vsf_pack_outputs_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, sz]
+        L.vsf_debug_sort_trim.argtypes = [vp, vp, i32, i32, C.c_float, i32, vp, vp]
         L.vsf_observe_capacity.argtypes = [vp, i32]
         L.vsf_observe_capacity.restype = sz
         L.vsf_observe_submit.argtypes = [vp, vp, vp, i32, i32, sz, C.POINTER(VsfCalibration), C.c_float, i32,
@@ -428,6 +429,19 @@ class Context:
         self._check(lib().vsf_debug_retain_best(self._h, _p(kb), _p(ids), len(kb), n_points, int(use_lds), mode,
                                                 C.byref(n)), "vsf_debug_retain_best")
         return kb[:n.value], ids[:n.value]
+
+    def debug_sort_trim(self, matches: np.ndarray, best_percent: float = 1.0, serial: bool = False):
+        """matches: (n_lists, n) DMATCH_DTYPE.  Returns a list of (queryIdx, trainIdx) int arrays, one per list: the first
+        int(n * best_percent) matches in the order the device's restatement of std::sort leaves them."""
+        m = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        if m.ndim == 1:
+            m = m[None]
+        nl, n = m.shape
+        pairs = np.zeros((nl, max(n, 1), 2), np.uint64)
+        counts = np.zeros(nl, np.int32)
+        self._check(lib().vsf_debug_sort_trim(self._h, _p(m), nl, n, float(np.float32(best_percent)), int(serial),
+                                              _p(pairs), _p(counts)), "vsf_debug_sort_trim")
+        return [pairs[i, :counts[i]].astype(np.int64) for i in range(nl)]
 
     # ---- per-stage device timing ----
     def profile_enable(self, on: bool = True):

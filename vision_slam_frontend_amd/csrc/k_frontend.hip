@@ -14,8 +14,12 @@
 // The residual kernel is embarrassingly parallel except for the ordered sum (one lane, 4 values per LDS read); the
 // sort runs the sequential restatement on one lane per (query set, train set) pair with the keys in LDS -- pairs are
 // independent, a batch sorts them all concurrently.
+#include <cstdlib>
+#include <cstring>
+
 #include "vsf_internal.h"
 #include "vsf_select.h"
+#include "vsf_hoare.h"
 
 #pragma clang fp contract(off)
 
@@ -179,6 +183,228 @@ __global__ __launch_bounds__(64) void sort_trim_kernel(const vsf_dmatch* __restr
   if (lane == 0) npairs[p] = good;
 }
 
+// ---- the same, data-parallel: libstdc++'s introsort restated on a whole workgroup ----
+// std::sort = __introsort_loop (median-of-3 pivot, __unguarded_partition, recursion on the right part, loop on the left,
+// ranges of <= 16 elements left alone, heap sort once 2 lg n levels are used up) + __final_insertion_sort.  The partitions
+// of a level work on disjoint ranges and a partition's swaps depend on nothing but its own range, so the order in which
+// ranges are processed does not matter; and the final insertion sort never moves an element out of the <= 16-element block
+// the partitions left it in (everything in an earlier block is <= everything in a later one, and equal elements do not
+// pass each other), so it is an independent stable insertion sort per block.  Hence:
+//   A  ranges of more than 256 elements: one Hoare pass each by the whole workgroup (vsf_hoare.h hoare_pass: ballots,
+//      block scan, rank -> position tables, pairwise swaps), an explicit stack of ranges in LDS;
+//   B  ranges of <= 256 elements: the waves take them from a queue and each wave finishes its range alone (wave_hoare_pass,
+//      no workgroup barriers), noting the blocks it leaves;
+//   C  one LANE per block: insertion sort.
+// Same comparisons on the same elements as the sequential code => the same permutation (tests: random, tie-heavy, sorted,
+// reversed, organ-pipe and median-of-3-killer inputs against std::sort through vsf_debug_sort_trim).
+// The one-lane kernel above took 90 us for the eleven pairs of a 2000-feature frame and 1 ms for the 8000-row right->left
+// match of a 1080p frame.
+constexpr int kSortQueue = 1024;     // small ranges waiting for a wave
+constexpr int kSortStack = 192;      // phase A's stack of large ranges
+constexpr int kSortWaveStack = 40;   // a wave's stack inside its range (depth <= 2 lg 256 + slack)
+constexpr int kSortWaveBlocks = 160; // blocks a wave may leave per range (a range of <= 256 elements has <= 128 of >= 2)
+
+struct SortRange {
+  int first, last, depth;
+};
+
+struct SortShared {  // fixed-size part of the kernel's LDS (after the variable arrays)
+  vsf_par::PassCtl ctl;
+  SortRange stack[kSortStack];
+  SortRange queue[kSortQueue];
+  int sp, qn, qhead, overflow;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void sort_trim_par_kernel(const vsf_dmatch* __restrict__ matches,
+                                                           const int32_t* __restrict__ nmatches, int max_rows, int cap,
+                                                           float best_percent,
+                                                           const float* __restrict__ best_percent_of,
+                                                           uint64_t* __restrict__ pairs, int32_t* __restrict__ npairs) {
+  using namespace vsf_par;
+  extern __shared__ __attribute__((aligned(16))) uint8_t sort_lds[];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NT / 64;
+  const int n = min(min(nmatches[p], max_rows), cap);
+  // carve the LDS
+  const int maxw = (cap + 63) / 64;
+  uint8_t* q = sort_lds;
+  SortKey* A = reinterpret_cast<SortKey*>(q);
+  q += (size_t)cap * sizeof(SortKey);
+  PassMem<uint16_t> pm;
+  pm.maskL = reinterpret_cast<unsigned long long*>(q);
+  q += (size_t)maxw * 8;
+  pm.maskR = reinterpret_cast<unsigned long long*>(q);
+  q += (size_t)maxw * 8;
+  pm.preL = reinterpret_cast<int*>(q);
+  q += (size_t)maxw * 4;
+  pm.preR = reinterpret_cast<int*>(q);
+  q += (size_t)maxw * 4;
+  pm.Lp = reinterpret_cast<uint16_t*>(q);
+  q += (size_t)cap * 2;
+  pm.Rp = reinterpret_cast<uint16_t*>(q);
+  q += (size_t)cap * 2;
+  q = reinterpret_cast<uint8_t*>(((uintptr_t)q + 15) & ~(uintptr_t)15);
+  SortShared& S = *reinterpret_cast<SortShared*>(q);
+  q += sizeof(SortShared);
+  uint16_t* wtab = reinterpret_cast<uint16_t*>(q + (size_t)wave * kWaveTable);
+  q += (size_t)NW * kWaveTable;
+  SortRange* wstack = reinterpret_cast<SortRange*>(q) + (size_t)wave * kSortWaveStack;
+  q += (size_t)NW * kSortWaveStack * sizeof(SortRange);
+  uint16_t* wblocks = reinterpret_cast<uint16_t*>(q) + (size_t)wave * kSortWaveBlocks * 2;
+  pm.maxw = maxw;
+  pm.c = &S.ctl;
+  pm.wbuf = nullptr;
+  const vsf_dmatch* m = matches + (size_t)p * max_rows;
+  for (int i = tid; i < n; i += NT) {
+    const vsf_dmatch dm = m[i];
+    A[i] = SortKey{(uint32_t)(int)dm.distance, (uint32_t)dm.queryIdx | ((uint32_t)dm.trainIdx << 16)};
+  }
+  if (tid == 0) {
+    S.sp = 0;
+    S.qn = 0;
+    S.qhead = 0;
+    S.overflow = 0;
+    if (n > 1) {
+      S.stack[0] = SortRange{0, n, vsf_sel::lg_(n) * 2};
+      S.sp = 1;
+    }
+  }
+  __syncthreads();
+  const SortLess less;
+  // ---- A: large ranges, one workgroup pass each ----
+  while (true) {
+    const int sp = S.sp;
+    if (sp == 0) break;  // (uniform: S.sp only changes between barriers)
+    const SortRange r = S.stack[sp - 1];
+    __syncthreads();
+    if (r.last - r.first <= kWaveCutoff) {
+      if (tid == 0) {
+        S.sp = sp - 1;
+        if (r.last - r.first > 1) {
+          if (S.qn < kSortQueue)
+            S.queue[S.qn++] = r;
+          else
+            S.overflow = 1, vsf_sel::sort_from_(A, r.first, r.last, r.depth, less);  // (never seen: kept for safety)
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (r.depth == 0) {  // std::__partial_sort(first, last, last): heap sort, sequential (adversarial inputs only)
+      if (tid == 0) {
+        vsf_sel::heap_select_(A, r.first, r.last, r.last, less);
+        vsf_sel::sort_heap_(A, r.first, r.last, less);
+        S.sp = sp - 1;
+      }
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) {
+      const int mid = r.first + (r.last - r.first) / 2;
+      vsf_sel::move_median_to_first_(A, r.first, r.first + 1, mid, r.last - 1, less);
+    }
+    __syncthreads();
+    const SortKey pivot = A[r.first];
+    hoare_pass<NT>(
+        A, r.first + 1, r.last, [&](const SortKey& x) { return !less(x, pivot); },
+        [&](const SortKey& x) { return !less(pivot, x); }, pm);
+    if (tid == 0) {
+      const int cut = S.ctl.st[4];
+      S.stack[sp - 1] = SortRange{r.first, cut, r.depth - 1};
+      if (sp < kSortStack) {
+        S.stack[sp] = SortRange{cut, r.last, r.depth - 1};
+        S.sp = sp + 1;
+      } else {  // (the stack cannot grow past ~2 lg n entries; kept for safety)
+        S.overflow = 1;
+        vsf_sel::sort_from_(A, cut, r.last, r.depth - 1, less);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- B: small ranges, one wave each ----
+  while (true) {
+    int qi = 0;
+    if (lane == 0) qi = atomicAdd(&S.qhead, 1);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+    if (qi >= S.qn) break;
+    int wsp = 1, nblocks = 0;
+    wstack[0] = S.queue[qi];
+    wave_fence();
+    while (wsp > 0) {
+      SortRange r = wstack[wsp - 1];
+      --wsp;
+      bool sorted = false;
+      while (r.last - r.first > 16) {
+        if (r.depth == 0) {
+          if (lane == 0) {
+            vsf_sel::heap_select_(A, r.first, r.last, r.last, less);
+            vsf_sel::sort_heap_(A, r.first, r.last, less);
+          }
+          wave_fence();
+          sorted = true;
+          break;
+        }
+        --r.depth;
+        // std::__move_median_to_first(first, first + 1, mid, last - 1): uniform reads, one lane stores the swap
+        const int pa = r.first + 1, pb = r.first + (r.last - r.first) / 2, pc = r.last - 1;
+        const SortKey vf = A[r.first], va = A[pa], vb = A[pb], vc = A[pc];
+        int pmid;
+        if (less(va, vb))
+          pmid = less(vb, vc) ? pb : less(va, vc) ? pc : pa;
+        else
+          pmid = less(va, vc) ? pa : less(vb, vc) ? pc : pb;
+        const SortKey pivot = pmid == pa ? va : pmid == pb ? vb : vc;
+        wave_fence();
+        if (lane == 0) {
+          A[r.first] = pivot;
+          A[pmid] = vf;
+        }
+        wave_fence();
+        int total_r, cut;
+        wave_hoare_pass(
+            A, r.first + 1, r.last, [&](const SortKey& x) { return !less(x, pivot); },
+            [&](const SortKey& x) { return !less(pivot, x); }, total_r, cut, wtab);
+        if (wsp < kSortWaveStack) {
+          if (lane == 0) wstack[wsp] = SortRange{cut, r.last, r.depth};
+          ++wsp;
+        } else {  // (cannot happen: depth <= 2 lg n bounds the stack)
+          if (lane == 0) vsf_sel::sort_from_(A, cut, r.last, r.depth, less);
+        }
+        wave_fence();
+        r.last = cut;
+      }
+      if (!sorted && r.last - r.first > 1) {
+        if (nblocks < kSortWaveBlocks) {
+          if (lane == 0) {
+            wblocks[2 * nblocks] = (uint16_t)r.first;
+            wblocks[2 * nblocks + 1] = (uint16_t)r.last;
+          }
+          ++nblocks;
+        } else {
+          if (lane == 0) vsf_sel::insertion_sort_(A, r.first, r.last, less);
+        }
+      }
+    }
+    wave_fence();
+    // ---- C: the final insertion sort, block by block, one lane each ----
+    for (int b = lane; b < nblocks; b += 64) vsf_sel::insertion_sort_(A, (int)wblocks[2 * b], (int)wblocks[2 * b + 1], less);
+    wave_fence();
+  }
+  __syncthreads();
+  // const int num_good_matches = matches.size() * config_.best_percent_;   (size_t -> float, float product, -> int)
+  if (best_percent_of) best_percent = best_percent_of[p];
+  int good = (int)((float)(size_t)n * best_percent);
+  good = min(max(good, 0), n);
+  uint64_t* out = pairs + (size_t)p * max_rows * 2;
+  for (int i = tid; i < good; i += NT) {
+    const SortKey k = A[i];
+    out[2 * i] = (uint64_t)(k.qt & 0xFFFFu);      // FeatureMatch::feature_idx_initial  = queryIdx (cc:295)
+    out[2 * i + 1] = (uint64_t)(k.qt >> 16);      // FeatureMatch::feature_idx_current  = trainIdx (cc:296)
+  }
+  if (tid == 0) npairs[p] = good;
+}
+
 // ---- vsf_observe_stereo: everything one ObserveImage returns, compact, written straight into pinned host memory ----
 // header (16 words) | npairs[n_pairs] padded to 4 words | VisionFeature x nfeat | FeatureMatch x sum(npairs) |
 // cv::KeyPoint x nfeat (the filtered left frame) | descriptors x nfeat; also stores the filtered left frame into its
@@ -281,7 +507,27 @@ void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, c
 
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
                           float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
-                          int32_t* d_npairs, hipStream_t s) {
+                          int32_t* d_npairs, hipStream_t s, bool force_serial) {
+  // VSF_SORT=serial: the one-lane kernel (A/B measurements, and pairs beyond the parallel kernel's LDS layout)
+  static const bool serial = std::getenv("VSF_SORT") && !strcmp(std::getenv("VSF_SORT"), "serial");
+  constexpr int NT = 256;
+  const int cap = max_rows;
+  const size_t maxw = (size_t)(cap + 63) / 64;
+  const size_t lds = (size_t)cap * sizeof(SortKey) + maxw * 2 * sizeof(unsigned long long) + maxw * 2 * sizeof(int) +
+                     (size_t)cap * 2 * sizeof(uint16_t) + 16 + sizeof(SortShared) +
+                     (size_t)(NT / 64) * (vsf_par::kWaveTable + kSortWaveStack * sizeof(SortRange) +
+                                         kSortWaveBlocks * 2 * sizeof(uint16_t));
+  if (!serial && !force_serial && cap < 65536 && lds <= 160 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_trim_par_kernel<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((sort_trim_par_kernel<NT>), dim3(n_pairs), dim3(NT), lds, s, d_matches, d_nmatches, max_rows, cap,
+                       best_percent, d_best_percent_of, d_pairs, d_npairs);
+    return;
+  }
   hipLaunchKernelGGL(sort_trim_kernel, dim3(n_pairs), dim3(64), VSF_SORT_LDS_ROWS * sizeof(SortKey), s, d_matches,
                      d_nmatches, max_rows, best_percent, d_best_percent_of, reinterpret_cast<SortKey*>(d_scratch), d_pairs,
                      d_npairs);

@@ -2087,6 +2087,45 @@ vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids
   return VSF_OK;
 }
 
+vsf_status vsf_debug_sort_trim(vsf_ctx* ctx, const vsf_dmatch* matches, int n_lists, int n, float best_percent,
+                               int serial, uint64_t* pairs_out, int32_t* counts_out) {
+  if (!ctx || !matches || !pairs_out || !counts_out || n_lists < 1 || n < 0 || n > ctx->p.max_keypoints)
+    return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  vsf_dmatch* dm = nullptr;
+  int32_t *dn = nullptr, *dc = nullptr;
+  uint64_t* dp = nullptr;
+  void* dscratch = nullptr;
+  hipError_t e = hipMalloc((void**)&dm, (size_t)n_lists * K * sizeof(vsf_dmatch));
+  if (e == hipSuccess) e = hipMalloc((void**)&dn, (size_t)n_lists * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dc, (size_t)n_lists * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dp, (size_t)n_lists * K * 2 * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc(&dscratch, (size_t)n_lists * K * 8);
+  std::vector<int32_t> hn((size_t)n_lists, n);
+  if (e == hipSuccess) e = hipMemcpy(dn, hn.data(), hn.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  for (int i = 0; i < n_lists && e == hipSuccess && n > 0; i++)
+    e = hipMemcpy(dm + (size_t)i * K, matches + (size_t)i * n, (size_t)n * sizeof(vsf_dmatch), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    vsf_launch_sort_trim(dm, dn, n_lists, (int)K, best_percent, nullptr, dscratch, dp, dc, ctx->stream, serial != 0);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(counts_out, dc, (size_t)n_lists * sizeof(int32_t), hipMemcpyDeviceToHost);
+  for (int i = 0; i < n_lists && e == hipSuccess && n > 0; i++)
+    e = hipMemcpy(pairs_out + (size_t)i * n * 2, dp + (size_t)i * K * 2, (size_t)n * 2 * sizeof(uint64_t),
+                  hipMemcpyDeviceToHost);
+  hipFree(dm);
+  hipFree(dn);
+  hipFree(dc);
+  hipFree(dp);
+  hipFree(dscratch);
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    return VSF_ERR_HIP;
+  }
+  return VSF_OK;
+}
+
 vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t ostride) {
   if (!ctx || !out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
       level >= ctx->orb.g.nlevels)

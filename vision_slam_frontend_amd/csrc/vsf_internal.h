@@ -162,7 +162,7 @@ void vsf_launch_pack_outputs(const vsf_vision_feature* d_features, const int32_t
                              hipStream_t s);
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
                           float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
-                          int32_t* d_npairs, hipStream_t s);
+                          int32_t* d_npairs, hipStream_t s, bool force_serial = false);
 // vsf_observe_stereo's output kernel (k_frontend.hip)
 #define VSF_OBSERVE_MAX_PAIRS 64
 struct VsfObserveArgs {

@@ -288,6 +288,40 @@ VSF_HD void sort_(T* a, int n, Comp comp) {
   }
 }
 
+// ---- the part of std::sort that concerns a[first, last) once __introsort_loop has reached it with `depth` levels left:
+// the remaining partitions of the range and the (block-local) final insertion sort.  Sequential fallback of the parallel
+// restatement in k_frontend.hip.
+template <class T, class Comp>
+VSF_HD void sort_from_(T* a, int first0, int last0, int depth0, Comp comp) {
+  int stack_first[64], stack_last[64], stack_depth[64];
+  int sp = 0;
+  stack_first[sp] = first0;
+  stack_last[sp] = last0;
+  stack_depth[sp] = depth0;
+  ++sp;
+  while (sp > 0) {
+    --sp;
+    int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+    bool sorted = false;
+    while (last - first > 16) {
+      if (depth == 0) {
+        heap_select_(a, first, last, last, comp);
+        sort_heap_(a, first, last, comp);
+        sorted = true;
+        break;
+      }
+      --depth;
+      const int cut = unguarded_partition_pivot_(a, first, last, comp);
+      stack_first[sp] = cut;
+      stack_last[sp] = last;
+      stack_depth[sp] = depth;
+      ++sp;
+      last = cut;
+    }
+    if (!sorted) insertion_sort_(a, first, last, comp);  // the final insertion sort never leaves this block
+  }
+}
+
 // ---- cv::KeyPointsFilter::retainBest(kps, n_points) on an array; returns the new size ----
 // greater(a, b): a.response > b.response;  ge(x, y): x.response >= y.response
 template <class T, class Greater, class GreaterEq>
