@@ -14,7 +14,8 @@ from pathlib import Path
 import numpy as np
 
 _DIR = Path(__file__).resolve().parent
-_LIB_PATH = _DIR / "libvsf_oracle.so"
+# VSF_ORACLE_LIB: load another build of the same sources instead (tests/test_sanitizers.py: the -fsanitize build)
+_LIB_PATH = Path(os.environ["VSF_ORACLE_LIB"]) if os.environ.get("VSF_ORACLE_LIB") else _DIR / "libvsf_oracle.so"
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                            ("octave", "<i4"), ("class_id", "<i4")])
@@ -31,6 +32,8 @@ class OrbParams(C.Structure):
 
 
 def build(force: bool = False) -> Path:
+    if os.environ.get("VSF_ORACLE_LIB"):
+        return _LIB_PATH
     src = [_DIR / "vsf_oracle.cc", _DIR / "vsf_oracle_jpeg.cc", _DIR / "vsf_oracle.h", _DIR.parent / "data" / "orb_pattern31.txt"]
     if force or not _LIB_PATH.exists() or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in src):
         subprocess.check_call(["make", "-s", "-C", str(_DIR), "-B" if force else "-s"])

@@ -189,3 +189,53 @@ def test_crafted_huffman_tables(ctx, oracle):
         got = _decode(ctx, [data, data], w, h)
         np.testing.assert_array_equal(got[0, :, :w], want, err_msg=name)
         np.testing.assert_array_equal(got[1, :, :w], want, err_msg=name)
+
+
+def test_corrupted_batches_return_and_never_fault():
+    """Robustness of the device half: 400 batches of 8 damaged files (tests/jpeg_mutate.py: bit flips, truncation, stray
+    markers, header damage, garbage behind the headers; gray, optimised tables, restart intervals, 4:2:0) through
+    vsf_jpeg_decode_gray_batch.  Every call returns -- VSF_OK (libjpeg too decodes damaged entropy data to SOMETHING),
+    invalid argument or unsupported -- the device never faults, and a good batch decodes bit-exactly afterwards."""
+    import io
+
+    import torch
+    from PIL import Image
+    from jpeg_mutate import mutate
+    from vision_slam_frontend_amd import capi, synth
+
+    W, H = 160, 120
+    img = synth.stereo_pair(W, H, 5, n_objects=60)[0]
+    base = []
+    for kw in (dict(quality=85), dict(quality=40, optimize=True), dict(quality=90, restart_marker_blocks=5)):
+        b = io.BytesIO()
+        Image.fromarray(img, "L").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
+    rgb = np.stack([img, img[::-1], img[:, ::-1]], 2)
+    b = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(b, "JPEG", quality=75, subsampling=2)
+    base.append(b.getvalue())
+    rng = np.random.Generator(np.random.PCG64(20261004))
+    dev = torch.device("cuda", 0)
+    d = torch.zeros((8, H, W), dtype=torch.uint8, device=dev)
+    outcomes = {}
+    with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
+        for it in range(400):
+            files = [mutate(base[int(rng.integers(len(base)))], rng) for _ in range(8)]
+            try:
+                ctx.jpeg_decode_gray_batch(files, W, H, d.data_ptr(), W * H, W)
+                ctx.sync(allow_capacity=True)
+                outcomes["ok"] = outcomes.get("ok", 0) + 1
+            except capi.VsfError as e:
+                assert e.status in (capi.VSF_ERR_INVALID_ARG, capi.VSF_ERR_UNSUPPORTED), e
+                outcomes[e.status] = outcomes.get(e.status, 0) + 1
+                try:
+                    ctx.sync(allow_capacity=True)
+                except capi.VsfError as e2:
+                    assert e2.status in (capi.VSF_ERR_INVALID_ARG, capi.VSF_ERR_UNSUPPORTED), e2
+        # the context still works: the undamaged files decode to what libjpeg-turbo gives
+        ctx.jpeg_decode_gray_batch(base[:3], W, H, d.data_ptr(), W * H, W)
+        assert ctx.sync() == capi.VSF_OK
+        got = d[:3].cpu().numpy()
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], np.asarray(Image.open(io.BytesIO(base[i]))))
+    assert outcomes.get("ok", 0) > 5 and sum(v for k, v in outcomes.items() if k != "ok") > 20

@@ -1,0 +1,93 @@
+"""SURVEY section 5 (sanitizers) for the one place where the product parses UNTRUSTED bytes on the host: the JPEG marker /
+table parser and upload planner (csrc/vsf_jpeg_host.cc; reference counterpart: cv::imdecode at slam_frontend_main.cc:98-100).
+`make -C vision_slam_frontend_amd/csrc asan` builds that translation unit alone with -fsanitize=address,undefined (plain
+g++, no GPU code); a child process preloads the sanitizer runtime, runs the 16 fixture files and 2000 seeded mutations of
+them (bit flips, truncation, stray markers, header damage, garbage) through vsf_jpeg_plan + vsf_jpeg_fill, and must exit
+cleanly: any out-of-bounds access, overflow or misaligned access aborts it with a report.  No GPU involved."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "vision_slam_frontend_amd" / "csrc"
+LIB = ROOT / "vision_slam_frontend_amd" / "libvsf_jpeg_host_asan.so"
+GOLD = Path(__file__).resolve().parent / "golden" / "jpeg"
+
+DRIVER = r'''
+import ctypes as C, sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, sys.argv[3])
+from jpeg_mutate import mutate
+lib = C.CDLL(sys.argv[1])
+lib.vsf_jpeg_host_check.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+gold = Path(sys.argv[2])
+expected = np.load(gold / "expected_gray.npz")
+files = {p.stem: p.read_bytes() for p in sorted(gold.glob("*.jpg"))}
+
+def check(batch, w, h, serial=0):
+    n = len(batch)
+    ptrs = (C.c_char_p * n)(*batch)
+    sizes = (C.c_size_t * n)(*[len(b) for b in batch])
+    total, csum = C.c_uint64(), C.c_uint32()
+    return lib.vsf_jpeg_host_check(ptrs, sizes, n, w, h, serial, C.byref(total), C.byref(csum)), total.value
+
+ok = bad = 0
+for name, data in files.items():
+    if name.startswith("progressive"):
+        st, _ = check([data], 64, 48)
+        assert st == 4, ("progressive must be refused as unsupported", st)
+        continue
+    h, w = expected[name].shape
+    for serial in (0, 1):
+        st, total = check([data], w, h, serial)
+        assert st == 0 and total > len(data) // 2, (name, st, total)
+    st, _ = check([data], w + 1, h)
+    assert st == 1, ("wrong size must be refused", name, st)
+rng = np.random.Generator(np.random.PCG64(20261004))
+names = [n for n in files if not n.startswith("progressive")]
+for it in range(2000):
+    name = names[int(rng.integers(len(names)))]
+    h, w = expected[name].shape
+    batch = [mutate(files[name], rng) for _ in range(int(rng.integers(1, 4)))]
+    if it % 7 == 0:
+        batch.append(files[name])  # a good file next to damaged ones
+    st, _ = check(batch, w, h, int(rng.integers(2)))
+    assert st in (0, 1, 4), st   # VSF_OK, VSF_ERR_INVALID_ARG, VSF_ERR_UNSUPPORTED -- never anything else, never a crash
+    ok += st == 0
+    bad += st != 0
+for junk in (b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"\xff\xd8\xff\xda\x00", bytes(100), b"\xff\xd8" + b"\xff\xc0" * 50):
+    st, _ = check([junk], 8, 8)
+    assert st in (1, 4), (junk[:8], st)
+print("done ok=%d refused=%d" % (ok, bad))
+'''
+
+
+def test_jpeg_host_parser_under_asan_and_ubsan(tmp_path):
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan_rt = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (asan_rt and Path(asan_rt).exists() and ubsan_rt and Path(ubsan_rt).exists()):
+        pytest.skip("no sanitizer runtime in this toolchain")
+    r = subprocess.run(["make", "-s", "-C", str(CSRC), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0 and LIB.exists(), r.stderr[-2000:]
+    script = tmp_path / "drive.py"
+    script.write_text(DRIVER)
+    env = dict(os.environ, LD_PRELOAD="%s %s" % (asan_rt, ubsan_rt),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([sys.executable, str(script), str(LIB), str(GOLD), str(Path(__file__).resolve().parent)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-4000:])
+    assert p.stdout.strip().startswith("done") and "ok=" in p.stdout
+    ok = int(p.stdout.split("ok=")[1].split()[0])
+    refused = int(p.stdout.split("refused=")[1].split()[0])
+    assert ok > 300 and refused > 100  # the mutations reached both the accepting and the refusing paths
+    # the instrumentation is live: a deliberate one-byte heap overflow (VSF_ASAN_SELFTEST) aborts the same child
+    q = subprocess.run([sys.executable, str(script), str(LIB), str(GOLD), str(Path(__file__).resolve().parent)],
+                       capture_output=True, text=True, env=dict(env, VSF_ASAN_SELFTEST="1"), timeout=600)
+    assert q.returncode != 0 and "heap-buffer-overflow" in q.stderr, (q.returncode, q.stderr[-1500:])

@@ -29,45 +29,12 @@
 #include <vector>
 
 #include "vsf_internal.h"
+#include "vsf_jpeg_host.h"
+
+using namespace vsf_jpeg;
 
 namespace {
 
-constexpr int kLookBits = 9;
-constexpr int kMaxSlots = 6;     // distinct Huffman tables one image may use (3 components x DC / AC)
-constexpr int kGroupBlocks = 16; // luminance blocks parked in LDS between two IDCT phases
-constexpr int kSubBits = 16 - kLookBits;  // bits of a code beyond the first lookup
-constexpr int kMaxSub = 12;      // second-level tables per Huffman table (the Annex K tables need 5 or 6)
-constexpr uint32_t kLongCode = 0x8000u;
-constexpr uint16_t kNoCode = 16 << 8;  // a prefix no code starts with: 16 bits, symbol 0 (corrupt streams only)
-
-struct DevHuff {                 // one Huffman table as the kernels read it
-  uint16_t look[1 << kLookBits]; // 9-bit prefix -> (code length << 8 | symbol), or kLongCode | second-level table
-  int32_t maxcode[18];           // T.81 F.2.2.3 (maxcode[17] = INT_MAX)
-  int32_t valoff[17];            // VALPTR - MINCODE
-  uint8_t vals[256];
-  uint32_t nsub;                 // second-level tables in use; > kMaxSub: they do not fit (one-wave decoder only)
-  uint16_t sub[kMaxSub][1 << kSubBits];  // the next 7 bits -> (code length << 8 | symbol)
-};
-static_assert(sizeof(DevHuff) == 1024 + 72 + 68 + 256 + 4 + kMaxSub * 256, "DevHuff layout");
-
-struct DevTables {               // one distinct table set
-  DevHuff huff[kMaxSlots];
-  uint16_t qt_luma[64];          // natural order
-};
-
-struct DevImage {
-  uint32_t stream_off;           // entropy-coded segment inside the packed stream buffer (4-byte aligned)
-  uint32_t stream_len;
-  uint32_t tables;               // index into the table sets
-  int32_t ncomp, restart_interval, mcus_x, mcus_y;
-  int32_t h[3], v[3];            // blocks per MCU of each component (1 x 1 for a single-component scan)
-  int32_t dc_slot[3], ac_slot[3];
-  int32_t par_ok;                // every Huffman table in use fits its second-level tables (the parallel decoder's need)
-};
-
-const uint8_t kZigzagHost[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 __constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
@@ -380,11 +347,8 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 // removal, table references the compiler parked in scratch memory, and one 2-byte store per coefficient; 1.2 ms as
 // described here (stuffing removal 1.27 -> 0.07 ms, each decode pass 0.55 -> 0.27 ms, the writing pass 1.33 -> 0.53 ms).
 // =====================================================================================================================
-constexpr int kParThreads = 256;
 constexpr int kTileBytes = kParThreads * 16;  // bytes of the raw stream one round of the stuffing removal covers
-
-constexpr int kOverlap = 8;   // rows every segment's column carries past its end: the first rows of the next segment
-constexpr int kTransSlack = kParThreads * (kOverlap + 2) * 4 + 2048;  // bytes the segment-major copy may exceed the stream by
+// (kParThreads, kOverlap, kTransSlack: vsf_jpeg_host.h -- the host's plan sizes its scratch with them)
 
 // The decode loop reads its tables out of LDS through explicitly LDS-typed pointers and offsets: references to one of
 // several tables picked per lane made the compiler keep a pointer array in scratch memory and fetch the entries with
@@ -956,285 +920,7 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(const DevImage* __restric
   }
 }
 
-// ---- host: markers and tables (ITU-T T.81 Annex B) ----
-struct HostHuff {
-  bool present = false;
-  uint8_t bits[17] = {0};
-  uint8_t vals[256] = {0};
-};
-
-struct HostTableSet {  // what one file's scan uses, as read from its DQT / DHT segments (compared before anything is built:
-  int nslots = 0;      // consecutive frames of a camera carry the same tables)
-  uint8_t bits[kMaxSlots][17];
-  uint8_t vals[kMaxSlots][256];
-  uint16_t qt_luma[64];
-  bool same(const HostTableSet& o) const {
-    return nslots == o.nslots && std::memcmp(bits, o.bits, sizeof(bits[0]) * nslots) == 0 &&
-           std::memcmp(vals, o.vals, sizeof(vals[0]) * nslots) == 0 && std::memcmp(qt_luma, o.qt_luma, sizeof(qt_luma)) == 0;
-  }
-};
-
-void build_dev_huff(const HostHuff& h, DevHuff* d) {
-  std::memset(d, 0, sizeof(*d));
-  for (auto& e : d->look) e = kNoCode;
-  for (auto& t : d->sub)
-    for (auto& e : t) e = kNoCode;
-  int32_t code = 0;
-  int k = 0;
-  for (int l = 1; l <= 16; l++) {
-    const int32_t mincode = code;
-    d->valoff[l] = k - mincode;
-    for (int i = 0; i < h.bits[l]; i++, k++, code++) {
-      if (l <= kLookBits) {  // every 9-bit prefix that starts with this code
-        const int shift = kLookBits - l;
-        for (int f = 0; f < (1 << shift); f++)
-          d->look[((uint32_t)code << shift) | (uint32_t)f] = (uint16_t)((l << 8) | h.vals[k]);
-      } else {  // second level: the table of this code's 9-bit prefix, every 7-bit continuation that starts with its rest
-        const uint32_t p9 = (uint32_t)code >> (l - kLookBits);
-        if (!(d->look[p9] & kLongCode)) d->look[p9] = (uint16_t)(kLongCode | std::min<uint32_t>(d->nsub++, 255u));
-        const uint32_t ti = d->look[p9] & 255u;
-        if (ti < (uint32_t)kMaxSub) {
-          const int shift = 16 - l;
-          const uint32_t rest = (uint32_t)code & ((1u << (l - kLookBits)) - 1u);
-          for (int f = 0; f < (1 << shift); f++) d->sub[ti][(rest << shift) | (uint32_t)f] = (uint16_t)((l << 8) | h.vals[k]);
-        }
-      }
-    }
-    d->maxcode[l] = h.bits[l] ? code - 1 : -1;
-    code <<= 1;
-  }
-  d->maxcode[17] = 0x7FFFFFFF;
-  d->valoff[0] = 0;
-  std::memcpy(d->vals, h.vals, 256);
-}
-
 }  // namespace
-
-// Parses one JPEG file; fills the image descriptor (without stream_off / tables) and the table set it needs.
-// Returns VSF_OK, VSF_ERR_INVALID_ARG (malformed, or not width x height) or VSF_ERR_UNSUPPORTED.
-static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int height, DevImage* im, HostTableSet* tab,
-                             size_t* scan_begin) {
-  if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return VSF_ERR_INVALID_ARG;
-  uint16_t qt[4][64];
-  bool qt_present[4] = {false, false, false, false};
-  HostHuff dc[4], ac[4];
-  int ncomp = 0, cid[3], ch[3], cv[3], ctq[3], W = 0, H = 0, restart_interval = 0;
-  bool have_sof = false;
-  size_t pos = 2;
-  std::memset(im, 0, sizeof(*im));
-  while (pos + 4 <= nbytes) {
-    if (data[pos] != 0xFF) return VSF_ERR_INVALID_ARG;
-    while (pos < nbytes && data[pos] == 0xFF) pos++;
-    if (pos >= nbytes) return VSF_ERR_INVALID_ARG;
-    const int m = data[pos++];
-    if (m == 0xD9) return VSF_ERR_INVALID_ARG;
-    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-    if (pos + 2 > nbytes) return VSF_ERR_INVALID_ARG;
-    const size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
-    if (len < 2 || pos + len > nbytes) return VSF_ERR_INVALID_ARG;
-    const uint8_t* s = data + pos + 2;
-    const size_t n = len - 2;
-    if (m == 0xDB) {
-      for (size_t i = 0; i < n;) {
-        const int pq = s[i] >> 4, tq = s[i] & 15;
-        i++;
-        if (tq > 3 || pq > 1 || i + 64 * (size_t)(pq + 1) > n) return VSF_ERR_INVALID_ARG;
-        for (int k = 0; k < 64; k++, i += pq + 1)
-          qt[tq][kZigzagHost[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];
-        qt_present[tq] = true;
-      }
-    } else if (m == 0xC4) {
-      for (size_t i = 0; i < n;) {
-        if (i + 17 > n) return VSF_ERR_INVALID_ARG;
-        const int tc = s[i] >> 4, th = s[i] & 15;
-        if (tc > 1 || th > 3) return VSF_ERR_INVALID_ARG;
-        HostHuff& h = tc ? ac[th] : dc[th];
-        int total = 0;
-        for (int l = 1; l <= 16; l++) total += (h.bits[l] = s[i + l]);
-        i += 17;
-        if (total > 256 || i + total > n) return VSF_ERR_INVALID_ARG;
-        std::memset(h.vals, 0, sizeof(h.vals));
-        std::memcpy(h.vals, s + i, (size_t)total);
-        i += total;
-        h.present = true;
-      }
-    } else if (m == 0xC0 || m == 0xC1) {
-      if (n < 6 || s[0] != 8) return VSF_ERR_UNSUPPORTED;
-      H = (s[1] << 8) | s[2];
-      W = (s[3] << 8) | s[4];
-      ncomp = s[5];
-      if (ncomp == 4) return VSF_ERR_UNSUPPORTED;
-      if ((ncomp != 1 && ncomp != 3) || n < (size_t)(6 + 3 * ncomp)) return VSF_ERR_INVALID_ARG;
-      for (int c = 0; c < ncomp; c++) {
-        cid[c] = s[6 + 3 * c];
-        ch[c] = s[7 + 3 * c] >> 4;
-        cv[c] = s[7 + 3 * c] & 15;
-        ctq[c] = s[8 + 3 * c];
-        if (ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4 || ctq[c] > 3) return VSF_ERR_INVALID_ARG;
-      }
-      have_sof = true;
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      return VSF_ERR_UNSUPPORTED;  // progressive, lossless, arithmetic, hierarchical
-    } else if (m == 0xDD) {
-      if (n < 2) return VSF_ERR_INVALID_ARG;
-      restart_interval = (s[0] << 8) | s[1];
-    } else if (m == 0xDA) {
-      if (!have_sof || n < 1) return VSF_ERR_INVALID_ARG;
-      const int ns = s[0];
-      if (ns != ncomp) return VSF_ERR_UNSUPPORTED;  // one interleaved scan only
-      if (n < (size_t)(4 + 2 * ns)) return VSF_ERR_INVALID_ARG;
-      std::vector<std::pair<int, int>> slots;  // (class, id) in use
-      auto slot_of = [&](int cls, int id) {
-        for (size_t i = 0; i < slots.size(); i++)
-          if (slots[i].first == cls && slots[i].second == id) return (int)i;
-        slots.emplace_back(cls, id);
-        return (int)slots.size() - 1;
-      };
-      for (int c = 0; c < ns; c++) {
-        if (s[1 + 2 * c] != cid[c]) return VSF_ERR_UNSUPPORTED;
-        const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
-        if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !qt_present[ctq[c]]) return VSF_ERR_INVALID_ARG;
-        im->dc_slot[c] = slot_of(0, td);
-        im->ac_slot[c] = slot_of(1, ta);
-      }
-      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return VSF_ERR_UNSUPPORTED;
-      int hmax = 1, vmax = 1;
-      for (int c = 0; c < ncomp; c++) {
-        hmax = std::max(hmax, ch[c]);
-        vmax = std::max(vmax, cv[c]);
-      }
-      if (ncomp > 1 && (ch[0] != hmax || cv[0] != vmax)) return VSF_ERR_UNSUPPORTED;  // luminance would need upsampling
-      if (W != width || H != height) return VSF_ERR_INVALID_ARG;
-      const bool single = ncomp == 1;  // T.81 A.2.2: a one-component scan has one block per MCU
-      const int mw = single ? 8 : 8 * hmax, mh = single ? 8 : 8 * vmax;
-      if (!single && hmax * vmax > kGroupBlocks) return VSF_ERR_UNSUPPORTED;
-      im->ncomp = ncomp;
-      im->restart_interval = restart_interval;
-      im->mcus_x = (W + mw - 1) / mw;
-      im->mcus_y = (H + mh - 1) / mh;
-      for (int c = 0; c < ncomp; c++) {
-        im->h[c] = single ? 1 : ch[c];
-        im->v[c] = single ? 1 : cv[c];
-      }
-      tab->nslots = (int)slots.size();
-      for (size_t i = 0; i < slots.size(); i++) {
-        const HostHuff& h = slots[i].first ? ac[slots[i].second] : dc[slots[i].second];
-        std::memcpy(tab->bits[i], h.bits, 17);
-        std::memcpy(tab->vals[i], h.vals, 256);
-      }
-      std::memcpy(tab->qt_luma, qt[ctq[0]], sizeof(tab->qt_luma));
-      *scan_begin = pos + len;
-      return *scan_begin < nbytes ? VSF_OK : VSF_ERR_INVALID_ARG;
-    }
-    pos += len;
-  }
-  return VSF_ERR_INVALID_ARG;
-}
-
-// Host half of vsf_jpeg_decode_gray_batch, step 1: parses every file and lays out ONE upload -- image descriptors,
-// distinct table sets (consecutive frames of a camera share theirs: compared with the previous file's first), packed
-// entropy-coded segments -- without touching the segments themselves.
-vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n, int width, int height, bool force_serial,
-                         VsfJpegPlan* plan) {
-  std::vector<DevImage> images((size_t)n);
-  std::vector<DevTables> tables;
-  std::vector<HostTableSet> sets;
-  std::vector<int> set_par_ok;
-  plan->scan_begin.assign((size_t)n, 0);
-  plan->max_luma_blocks = 0;
-  plan->max_slots = 1;
-  size_t stream_bytes = 0;
-  for (int i = 0; i < n; i++) {
-    HostTableSet t;
-    const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &plan->scan_begin[i]);
-    if (st != VSF_OK) return st;
-    int found = -1;
-    for (int k = (int)sets.size() - 1; k >= 0 && found < 0; k--)
-      if (sets[k].same(t)) found = k;
-    if (found < 0) {  // a new table set: the kernels' lookup tables are built once per set
-      found = (int)sets.size();
-      sets.push_back(t);
-      plan->max_slots = std::max(plan->max_slots, t.nslots);
-      tables.emplace_back();
-      DevTables& d = tables.back();
-      std::memset(&d, 0, sizeof(d));
-      int ok = 1;
-      for (int k = 0; k < t.nslots; k++) {
-        HostHuff h;
-        std::memcpy(h.bits, t.bits[k], 17);
-        std::memcpy(h.vals, t.vals[k], 256);
-        build_dev_huff(h, &d.huff[k]);
-        if (d.huff[k].nsub > (uint32_t)kMaxSub) ok = 0;
-      }
-      std::memcpy(d.qt_luma, t.qt_luma, sizeof(d.qt_luma));
-      set_par_ok.push_back(ok);
-    }
-    images[i].tables = (uint32_t)found;
-    images[i].par_ok = set_par_ok[(size_t)found];
-    images[i].stream_off = (uint32_t)stream_bytes;
-    images[i].stream_len = (uint32_t)(nbytes[i] - plan->scan_begin[i]);
-    stream_bytes += (images[i].stream_len + 3u + 32u) & ~(size_t)3;
-    plan->max_luma_blocks = std::max(plan->max_luma_blocks, images[i].mcus_x * images[i].mcus_y * images[i].h[0] * images[i].v[0]);
-    if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
-  }
-  // which decoder takes which file: those without restart intervals first
-  std::vector<uint32_t> index;
-  auto parallel = [&](int i) {
-    const DevImage& im = images[i];
-    if (!im.par_ok || force_serial) return false;
-    if (im.restart_interval == 0) return true;
-    // restart intervals: the table of their start offsets must fit the scratch behind the clean stream
-    const size_t intervals = ((size_t)im.mcus_x * im.mcus_y + im.restart_interval - 1) / im.restart_interval;
-    return 4 * (intervals + 2) <= (size_t)im.stream_len + kTransSlack;
-  };
-  for (int pass = 0; pass < 2; pass++)
-    for (int i = 0; i < n; i++)
-      if (parallel(i) == (pass == 0)) index.push_back((uint32_t)i);
-  plan->n_par = 0;
-  for (int i = 0; i < n; i++) plan->n_par += parallel(i);
-  plan->off_images = 0;
-  plan->off_index = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
-  plan->off_tables = (plan->off_index + index.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
-  plan->off_stream = (plan->off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
-  plan->total = plan->off_stream + stream_bytes + 16;
-  plan->head.assign(plan->off_stream, 0);
-  std::memcpy(plan->head.data() + plan->off_images, images.data(), images.size() * sizeof(DevImage));
-  std::memcpy(plan->head.data() + plan->off_index, index.data(), index.size() * sizeof(uint32_t));
-  std::memcpy(plan->head.data() + plan->off_tables, tables.data(), tables.size() * sizeof(DevTables));
-  plan->stream_off.resize((size_t)n);
-  plan->stream_len.resize((size_t)n);
-  for (int i = 0; i < n; i++) {
-    plan->stream_off[i] = images[i].stream_off;
-    plan->stream_len[i] = images[i].stream_len;
-  }
-  return VSF_OK;
-}
-
-// Step 2: writes the upload into `dst` (pinned staging, plan->total bytes): one pass over the compressed bytes, shared
-// by a few threads when there is enough of it (one core copies ~19 GB/s into pinned memory).
-void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, uint8_t* dst) {
-  std::memcpy(dst, plan.head.data(), plan.head.size());
-  auto copy_range = [&](int i0, int i1) {
-    for (int i = i0; i < i1; i++) {
-      uint8_t* d = dst + plan.off_stream + plan.stream_off[i];
-      std::memcpy(d, jpeg[i] + plan.scan_begin[i], plan.stream_len[i]);
-      const size_t padded = (plan.stream_len[i] + 3u + 32u) & ~(size_t)3;
-      std::memset(d + plan.stream_len[i], 0, padded - plan.stream_len[i]);
-    }
-  };
-  const size_t stream_bytes = plan.total - plan.off_stream;
-  const int workers = (int)std::min<size_t>({(size_t)4, stream_bytes >> 22, (size_t)n,
-                                             (size_t)std::max(1u, std::thread::hardware_concurrency())});
-  if (workers <= 1) {
-    copy_range(0, n);
-  } else {
-    std::vector<std::thread> pool;
-    for (int w = 1; w < workers; w++) pool.emplace_back(copy_range, (int)((int64_t)n * w / workers), (int)((int64_t)n * (w + 1) / workers));
-    copy_range(0, n / workers);
-    for (auto& th : pool) th.join();
-  }
-  std::memset(dst + plan.total - 16, 0, 16);
-}
 
 // Bytes of the parallel decoder's stream scratch: the clean streams in the layout of the upload's stream part, then
 // their segment-major copies.

@@ -1,0 +1,49 @@
+// vsf_jpeg_host.h -- what the host half (vsf_jpeg_host.cc: markers, tables, the upload plan; plain C++, parses UNTRUSTED
+// bytes, built with AddressSanitizer by `make asan`) and the device half (k_jpeg.hip) of the JPEG decoder share: the
+// layouts of one upload.
+#ifndef VSF_JPEG_HOST_H_
+#define VSF_JPEG_HOST_H_
+
+#include <stdint.h>
+
+namespace vsf_jpeg {
+
+constexpr int kLookBits = 9;
+constexpr int kMaxSlots = 6;     // distinct Huffman tables one image may use (3 components x DC / AC)
+constexpr int kGroupBlocks = 16; // luminance blocks parked in LDS between two IDCT phases
+constexpr int kSubBits = 16 - kLookBits;  // bits of a code beyond the first lookup
+constexpr int kMaxSub = 12;      // second-level tables per Huffman table (the Annex K tables need 5 or 6)
+constexpr uint32_t kLongCode = 0x8000u;
+constexpr uint16_t kNoCode = 16 << 8;  // a prefix no code starts with: 16 bits, symbol 0 (corrupt streams only)
+
+struct DevHuff {                 // one Huffman table as the kernels read it
+  uint16_t look[1 << kLookBits]; // 9-bit prefix -> (code length << 8 | symbol), or kLongCode | second-level table
+  int32_t maxcode[18];           // T.81 F.2.2.3 (maxcode[17] = INT_MAX)
+  int32_t valoff[17];            // VALPTR - MINCODE
+  uint8_t vals[256];
+  uint32_t nsub;                 // second-level tables in use; > kMaxSub: they do not fit (one-wave decoder only)
+  uint16_t sub[kMaxSub][1 << kSubBits];  // the next 7 bits -> (code length << 8 | symbol)
+};
+static_assert(sizeof(DevHuff) == 1024 + 72 + 68 + 256 + 4 + kMaxSub * 256, "DevHuff layout");
+
+struct DevTables {               // one distinct table set
+  DevHuff huff[kMaxSlots];
+  uint16_t qt_luma[64];          // natural order
+};
+
+struct DevImage {
+  uint32_t stream_off;           // entropy-coded segment inside the packed stream buffer (4-byte aligned)
+  uint32_t stream_len;
+  uint32_t tables;               // index into the table sets
+  int32_t ncomp, restart_interval, mcus_x, mcus_y;
+  int32_t h[3], v[3];            // blocks per MCU of each component (1 x 1 for a single-component scan)
+  int32_t dc_slot[3], ac_slot[3];
+  int32_t par_ok;                // every Huffman table in use fits its second-level tables (the parallel decoder's need)
+};
+
+constexpr int kParThreads = 256;  // threads (= segments) of the parallel decoder per image
+constexpr int kOverlap = 8;       // rows every segment's column carries past its end: the first rows of the next segment
+constexpr int kTransSlack = kParThreads * (kOverlap + 2) * 4 + 2048;  // bytes the segment-major copy may exceed the stream by
+
+}  // namespace vsf_jpeg
+#endif  // VSF_JPEG_HOST_H_
