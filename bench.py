@@ -60,14 +60,15 @@ def committed_counters(width: int, height: int, nfeatures: int, batch: int):
     """Per-stage counters of the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE, WRITE_SIZE and
     SQ_INSTS_VALU collected in their own runs), if they were taken on this configuration; {} otherwise.  PMC counters
     cannot be collected inside the timed run."""
-    try:
-        t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-    except (OSError, ValueError):
-        return {}
-    c = t.get("config", {})
-    if (c.get("width"), c.get("height"), c.get("nfeatures"), c.get("batch")) != (width, height, nfeatures, batch):
-        return {}
-    return t.get("stages", {})
+    for name in ("traffic.json", "traffic_1080p.json"):  # one file per profiled configuration
+        try:
+            t = json.loads((ROOT / "profiles" / name).read_text())
+        except (OSError, ValueError):
+            continue
+        c = t.get("config", {})
+        if (c.get("width"), c.get("height"), c.get("nfeatures"), c.get("batch")) == (width, height, nfeatures, batch):
+            return t.get("stages", {})
+    return {}
 
 
 def host_cores():
@@ -415,7 +416,7 @@ def main() -> int:
             a = float(insts) * args.steps / (dom_ms * 1e-3) / 1e9
             valu = {"bound": "valu", "kernel": dom, "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                     "frac": a / VALU_PEAK_GINST, "valu_wave_insts_per_launch": float(insts) * args.steps / max(dom_launches, 1),
-                    "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass) / stage time of this run"}
+                    "source": "profiles/traffic*.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass) / stage time of this run"}
         hbm_frac = achieved / HBM_PEAK_GBS
         bound = "valu" if valu and valu["frac"] > hbm_frac else "hbm"
         # matcher (K9): pair distances per second of the stereo knn2 launches and the int8 matrix-core rate they imply

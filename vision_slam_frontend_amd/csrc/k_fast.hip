@@ -14,9 +14,14 @@
 //      A = max over the 16 arcs of min(d over the 9-arc),  B = -min over arcs of max(d over the arc)
 //    (computed on the p_k, v subtracted once at the end),
 //    the pixel is a FAST-9 corner iff max(A, B) > t and cornerScore is max(A, B) - 1.  Two pixels are processed per
-//    VALU lane-op with packed 16-bit min/max (v_pk_min_i16 / v_pk_max_i16); circle bytes are pulled out of the
-//    window with v_perm_b32.  The 16 arc minima come from prefix/suffix minima of the two circle halves (an arc
-//    of 9 = a suffix of one half + a prefix of the other): 59 instead of 80 packed ops per polarity;
+//    VALU lane-op on packed 16-bit halves; circle bytes are pulled out of the window with v_perm_b32.  Arcs 2j and 2j + 1
+//    share eight pixels, so max(arc 2j, arc 2j + 1) = min(octet, max(d[2j], d[2j + 9])) (min / max distribute): an octet
+//    is two quads of two pixel pairs -> 8 + 8 + 8 two-input ops, 8 THREE-input ops and a 4-op reduction = 36 packed ops
+//    per polarity (59 with prefix / suffix minima of the circle halves, 80 naively).  The three-input ops are gfx950's
+//    v_pk_minimum3_f16 / v_pk_maximum3_f16 applied to the pixel values as they sit in the halves: 0..255 are f16
+//    denormals, ordered like the integers and not flushed in the default mode (tools/exp/m3.hip: all 2^24 triples, full
+//    issue rate).  With 1.86 G wave-instructions per 512-image launch the kernel issues at 93 % of the vector ALU's rate:
+//    the floor of a dense score;
 //  * the only branch is wave-wide: a row is skipped when v_sad_u8 of every lane's 4 pixels against the rows 3 above
 //    and 3 below stays <= t (circle pixels 0 and 8: every 9-arc contains one of them);
 //  * scores stay in registers; the strict 8-neighbour NMS is packed too (row-wise 3-maxima shared between the rows
