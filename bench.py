@@ -247,6 +247,8 @@ def main() -> int:
                     help="keep the Gaussian blur on the extraction's stream (vsf_set_blur_overlap(0)); default: it runs on its "
                          "own stream beside FAST and the keypoint selection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-observe", action="store_true",
+                    help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     W = args.width or cfg["width"]
@@ -488,6 +490,21 @@ def main() -> int:
             "tail_stream_ms_per_step": None if tail_stages is None else
             {k: v[0] / args.steps for k, v in tail_stages.items()},
         }
+        # The drop-in API one frame at a time (slam::Frontend::ObserveImage, cc:400-472, through the C++ host class): NOT the
+        # benchmarked value, reported beside it.  Synchronous latency per call and frames/s with two frames in flight
+        # (Frontend::set_pipelined), at 2000 features and at the reference's own 10000; driven from Python here (ctypes,
+        # ~10 % slower than tools/time_frontend.cc, whose record is profiles/r03/observe_image.json).
+        out["observe_image"] = None
+        if world == 1 and not args.no_observe and (W, H) == (640, 480):
+            sys.path.insert(0, str(ROOT / "tools"))
+            import time_frontend as tf
+            obs = {}
+            for nf in (2000, 10000):
+                ms, _, _, _ = tf.observe_image_ms(nf, True, n_frames=96)
+                _, _, _, fps = tf.observe_image_ms(nf, True, n_frames=232, pipelined=True)
+                obs["nfeatures_%d" % nf] = {"observe_image_ms": ms, "observe_image_pipelined_fps": fps}
+            obs["note"] = "640x480, frame_life 10, window full; per stereo frame through slam::Frontend (host/slam_frontend.cc)"
+            out["observe_image"] = obs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, synth.BASE_SEED)
         else:

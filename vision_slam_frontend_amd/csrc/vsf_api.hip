@@ -494,6 +494,7 @@ struct vsf_ctx {
     int32_t* h_status[2] = {nullptr, nullptr};    // pinned copy of the status word after the frame's last kernel
     hipStream_t ex_stream[2] = {nullptr, nullptr};  // extraction of slot i (slot 0 of a one-slot context: ctx->stream)
     hipEvent_t ev_extracted[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    VsfSideStream side[2] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
     bool done_valid[2] = {false, false};
     int64_t ticket_of[2] = {-1, -1};  // submitted and not yet collected
     int64_t next_ticket = 0;
@@ -662,8 +663,7 @@ void free_observe(vsf_ctx* ctx) {
     if (o.h_out[i]) hipHostFree(o.h_out[i]);
     if (o.h_meta[i]) hipHostFree(o.h_meta[i]);
     if (o.h_status[i]) hipHostFree(o.h_status[i]);
-    if (o.ex_stream[i] && o.ex_stream[i] != ctx->stream && (i == 0 || o.ex_stream[i] != o.ex_stream[0]))
-      hipStreamDestroy(o.ex_stream[i]);
+    if (o.ex_stream[i] && o.ex_stream[i] != ctx->stream) hipStreamDestroy(o.ex_stream[i]);
     if (o.ev_extracted[i]) hipEventDestroy(o.ev_extracted[i]);
     if (o.ev_done[i]) hipEventDestroy(o.ev_done[i]);
   }
@@ -768,7 +768,7 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
 
 // detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.
 void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp,
-                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete = false) {
+                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete = false, const VsfSideStream* own_side = nullptr) {
   const VsfGeom& g = ctx->orb.g;
   VsfDev d = shifted(ctx->dorb.d, g, i0);
   VsfImages im = im_all;
@@ -801,7 +801,9 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   } else {
     StageTimer t(ctx, st, VSF_STAGE_PYRAMID, g.nlevels - 1);
     // one lane: the aux stream is idle, the pyramid chain of the second half of the batch runs on it
-    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, ctx->lanes == 1 ? &ctx->side : nullptr);
+    // (own_side: a caller that runs several extractions at once on different streams brings a side-stream set of its own --
+    // the context's fork / join events must not be recorded from two streams at a time)
+    vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, own_side ? own_side : (ctx->lanes == 1 ? &ctx->side : nullptr));
   }
   ctx->last_pyr = d.pyr - (size_t)i0 * g.pyr_bytes;
   // The blur needs the pyramid only.  It lives on the matrix cores and on memory bandwidth, FAST on the vector ALU (93 % of
@@ -1585,11 +1587,13 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
     std::memset(o.h_meta[i], 0, sizeof(vsf_ctx::ObserveMeta));
     VSF_HIP(hipHostMalloc((void**)&o.h_status[i], sizeof(int32_t), hipHostMallocMapped));
     *o.h_status[i] = 0;
-    // ONE extraction stream for both slots, at the highest stream priority.  HIP multiplexes streams onto a few hardware
-    // queues (round-robin at creation) and kernels of streams that share a queue run one after the other: with a stream
-    // per slot, one of the two landed on the tail stream's queue and its frames overlapped nothing (kernel trace:
-    // 0.33 ms per frame, no better than one stream).  Streams of different priorities never share a queue, and what has
-    // to overlap is the extraction of frame k + 1 with the tail of frame k, not two extractions.
+    // An extraction stream per slot, at the HIGHEST and the LOWEST stream priority (the tail's stream has the middle
+    // one).  HIP multiplexes streams onto a few hardware queues (round-robin at creation) and kernels of streams that share
+    // a queue run one after the other: with two streams of the default priority, one of them landed on the tail stream's
+    // queue and its frames overlapped nothing (kernel trace: 0.33 ms per frame, no better than one stream).  Streams of
+    // different priorities never share a queue: the chains of frame k (extraction), frame k + 1 (extraction) and frame
+    // k - 1 (tail) -- ~25 small kernels each, bound by launch-to-launch latency -- then run side by side (3 050 -> 4 300
+    // frames/s; one shared high-priority extraction stream: 3 290).
     if (o.slots == 1) {
       o.ex_stream[i] = ctx->stream;
     } else if (i == 0) {
@@ -1597,7 +1601,9 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
       VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
       VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[0], hipStreamNonBlocking, prio_hi));
     } else {
-      o.ex_stream[1] = o.ex_stream[0];
+      int prio_lo = 0, prio_hi = 0;
+      VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[1], hipStreamNonBlocking, prio_lo));
     }
     VSF_HIP(hipEventCreateWithFlags(&o.ev_extracted[i], hipEventDisableTiming));
     VSF_HIP(hipEventCreateWithFlags(&o.ev_done[i], hipEventDisableTiming));
@@ -1675,7 +1681,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   vsf_keypoint* kp_raw = ctx->st_kp + (size_t)(2 * slot) * K;
   uint8_t* desc_raw = ctx->st_desc + (size_t)(2 * slot) * K * VSF_DESC_BYTES;
   int32_t* counts_raw = ctx->st_counts + 2 * slot;
-  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts);
+  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts, false, ex != s ? &o.side[slot] : nullptr);
   ctx->last_images = VsfImages{d_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
   ctx->last_valid = true;
   int32_t* nmatches = o.ints + slot;
