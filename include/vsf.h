@@ -292,9 +292,10 @@ vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
  * images into pinned staging, queues the whole chain and returns a ticket; vsf_observe_collect waits for that frame and
  * hands over its result (same layout and status as vsf_observe_stereo, which is submit + collect).  Frontend::ObserveImage
  * returns what OdomCheck decided (slam_frontend.cc:404-409), so nothing in the reference's control flow needs a frame's
- * result before the next frame arrives.  A context with max_images >= 4 keeps TWO frames in flight: the extraction of
- * frame k + 1 (its own stream and buffers) runs beside the tail of frame k, while the tails -- which carry the
- * RemoveAmbigStereo threshold and the temporal window from frame to frame -- stay in frame order on the context's stream.
+ * result before the next frame arrives.  A context with max_images >= 4 keeps TWO frames in flight, one with
+ * max_images >= 6 THREE: every frame runs on its slot's stream and buffers from upload to result, and its tail -- which
+ * carries the RemoveAmbigStereo threshold and the temporal window from frame to frame -- first waits for the previous
+ * frame's tail, so the tails stay in frame order.
  * Tickets are collected in the order they were issued; a submit whose slot still holds an uncollected frame returns
  * VSF_ERR_INVALID_ARG.  Results are those of the synchronous call, bit for bit. */
 vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,

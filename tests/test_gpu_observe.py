@@ -85,9 +85,10 @@ def _same_observation(a: dict, b: dict):
             assert va == vb, k
 
 
-def test_two_frames_in_flight_equal_the_synchronous_calls():
-    """vsf_observe_submit / vsf_observe_collect with TWO frames in flight (context with max_images = 4: the extraction of
-    frame k + 1 on its own stream beside the tail of frame k) return, frame for frame and byte for byte, what the
+@pytest.mark.parametrize("slots", [2, 3])
+def test_frames_in_flight_equal_the_synchronous_calls(slots):
+    """vsf_observe_submit / vsf_observe_collect with two / three frames in flight (contexts with max_images = 4 / 6: every
+    frame on its slot's stream, the tails chained by events) return, frame for frame and byte for byte, what the
     synchronous vsf_observe_stereo returns -- across the window filling and sliding, the frame without stereo matches and
     the NaN threshold after it, whose state travels from tail to tail on the device."""
     from vision_slam_frontend_amd import capi, frontend, synth
@@ -98,13 +99,13 @@ def test_two_frames_in_flight_equal_the_synchronous_calls():
     bp = float(np.float32(0.3))
     with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
         want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
-    with capi.Context(capi.default_params(320, 240, max_images=4, nfeatures=NF)) as ctx:
+    with capi.Context(capi.default_params(320, 240, max_images=2 * slots, nfeatures=NF)) as ctx:
         got, tickets = [], []
         for l, r in frames:
-            if len(tickets) == 2:
+            if len(tickets) == slots:
                 got.append(ctx.observe_collect(tickets.pop(0), frame_life=LIFE))
             tickets.append(ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE))
-        # a third frame cannot enter while both slots hold uncollected frames; the newer frame cannot leave first
+        # another frame cannot enter while every slot holds an uncollected frame; a newer frame cannot leave first
         with pytest.raises(capi.VsfError):
             ctx.observe_submit(*frames[0], calib, best_percent=bp, frame_life=LIFE)
         with pytest.raises(capi.VsfError):

@@ -481,22 +481,23 @@ struct vsf_ctx {
     vsf_vision_feature* features = nullptr;
     uint64_t* pairs = nullptr;      // [frame_life + 1][K][2]
     int32_t* npairs = nullptr;
-    // Two frames may be in flight (vsf_observe_submit / vsf_observe_collect, contexts with max_images >= 4): everything
-    // one frame's EXTRACTION writes exists once per slot -- pinned staging, per-call parameters, result buffer, status
-    // word, the slot's two images of every extraction buffer, raw stereo matches -- and runs on the slot's own stream;
-    // the TAIL (RemoveAmbigStereo ... result) of all frames runs in frame order on the context's stream, so its buffers
-    // exist once.
+    // Up to three frames may be in flight (vsf_observe_submit / vsf_observe_collect; two slots with max_images >= 4,
+    // three with >= 6): everything one frame's EXTRACTION writes exists once per slot -- pinned staging, per-call
+    // parameters, result buffer, status word, the slot's two images of every extraction buffer, raw stereo matches.  A
+    // frame runs on its slot's stream from upload to result; its TAIL (RemoveAmbigStereo ... result) first waits for the
+    // previous frame's tail (an event), so the tails -- which carry the threshold and the temporal window from frame to
+    // frame -- run in frame order and their buffers exist once.
     int slots = 1;
-    uint8_t* h_img[2] = {nullptr, nullptr};       // pinned: both images at the staging pitch
-    uint8_t* h_out[2] = {nullptr, nullptr};       // pinned, written by observe_pack_kernel
+    uint8_t* h_img[3] = {nullptr, nullptr, nullptr};       // pinned: both images at the staging pitch
+    uint8_t* h_out[3] = {nullptr, nullptr, nullptr};       // pinned, written by observe_pack_kernel
     size_t out_cap = 0;
-    ObserveMeta* h_meta[2] = {nullptr, nullptr};
-    int32_t* h_status[2] = {nullptr, nullptr};    // pinned copy of the status word after the frame's last kernel
-    hipStream_t ex_stream[2] = {nullptr, nullptr};  // extraction of slot i (slot 0 of a one-slot context: ctx->stream)
-    hipEvent_t ev_extracted[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    VsfSideStream side[2] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
-    bool done_valid[2] = {false, false};
-    int64_t ticket_of[2] = {-1, -1};  // submitted and not yet collected
+    ObserveMeta* h_meta[3] = {nullptr, nullptr, nullptr};
+    int32_t* h_status[3] = {nullptr, nullptr, nullptr};    // pinned copy of the status word after the frame's last kernel
+    hipStream_t ex_stream[3] = {nullptr, nullptr, nullptr};  // the stream of slot i (a one-slot context: ctx->stream)
+    hipEvent_t ev_done[3] = {nullptr, nullptr, nullptr};
+    VsfSideStream side[3] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
+    bool done_valid[3] = {false, false, false};
+    int64_t ticket_of[3] = {-1, -1, -1};  // submitted and not yet collected
     int64_t next_ticket = 0;
     std::vector<int> order;         // ring slots of the kept frames, oldest first
   } ob;
@@ -658,13 +659,12 @@ void free_observe(vsf_ctx* ctx) {
   hipFree(o.features);
   hipFree(o.pairs);
   hipFree(o.npairs);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     if (o.h_img[i]) hipHostFree(o.h_img[i]);
     if (o.h_out[i]) hipHostFree(o.h_out[i]);
     if (o.h_meta[i]) hipHostFree(o.h_meta[i]);
     if (o.h_status[i]) hipHostFree(o.h_status[i]);
     if (o.ex_stream[i] && o.ex_stream[i] != ctx->stream) hipStreamDestroy(o.ex_stream[i]);
-    if (o.ev_extracted[i]) hipEventDestroy(o.ev_extracted[i]);
     if (o.ev_done[i]) hipEventDestroy(o.ev_done[i]);
   }
   o = vsf_ctx::Observe();
@@ -718,7 +718,7 @@ void sync_all_streams(vsf_ctx* ctx) {  // every stream the context launches on
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
   if (ctx->blur_stream) (void)hipStreamSynchronize(ctx->blur_stream);
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (ctx->ob.ex_stream[i] && ctx->ob.ex_stream[i] != ctx->stream) (void)hipStreamSynchronize(ctx->ob.ex_stream[i]);
 }
 
@@ -1558,21 +1558,21 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   vsf_ctx::Observe& o = ctx->ob;
   if (o.ring && o.frame_life == frame_life) return VSF_OK;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (o.ex_stream[i]) VSF_HIP(hipStreamSynchronize(o.ex_stream[i]));
   float thr_state = 10000.0f;  // cc:353
   const bool had = o.floats != nullptr;
   if (had) VSF_HIP(hipMemcpy(&thr_state, o.floats + 2, sizeof(float), hipMemcpyDeviceToHost));
   free_observe(ctx);
   const size_t K = (size_t)ctx->p.max_keypoints, S = (size_t)frame_life + 2;
-  o.slots = ctx->p.max_images >= 4 ? 2 : 1;
+  o.slots = ctx->p.max_images >= 6 ? 3 : (ctx->p.max_images >= 4 ? 2 : 1);
   VSF_HIP(hipMalloc((void**)&o.ring, S * K * VSF_DESC_BYTES));
   VSF_HIP(hipMalloc((void**)&o.ring_counts, S * sizeof(int32_t)));
   VSF_HIP(hipMemset(o.ring_counts, 0, S * sizeof(int32_t)));
   VSF_HIP(hipMalloc((void**)&o.kpf, 2 * K * sizeof(vsf_keypoint)));
-  VSF_HIP(hipMalloc((void**)&o.matches, 2 * K * sizeof(vsf_dmatch)));
-  VSF_HIP(hipMalloc((void**)&o.ints, 4 * sizeof(int32_t)));
-  VSF_HIP(hipMemset(o.ints, 0, 4 * sizeof(int32_t)));
+  VSF_HIP(hipMalloc((void**)&o.matches, 3 * K * sizeof(vsf_dmatch)));
+  VSF_HIP(hipMalloc((void**)&o.ints, 8 * sizeof(int32_t)));  // [0..2] raw stereo matches per slot, [4] features, [5] points
+  VSF_HIP(hipMemset(o.ints, 0, 8 * sizeof(int32_t)));
   VSF_HIP(hipMalloc((void**)&o.floats, 4 * sizeof(float)));
   const float f4[4] = {0.f, 0.f, thr_state, 0.f};
   VSF_HIP(hipMemcpy(o.floats, f4, sizeof(f4), hipMemcpyHostToDevice));
@@ -1587,30 +1587,24 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
     std::memset(o.h_meta[i], 0, sizeof(vsf_ctx::ObserveMeta));
     VSF_HIP(hipHostMalloc((void**)&o.h_status[i], sizeof(int32_t), hipHostMallocMapped));
     *o.h_status[i] = 0;
-    // An extraction stream per slot, at the HIGHEST and the LOWEST stream priority (the tail's stream has the middle
-    // one).  HIP multiplexes streams onto a few hardware queues (round-robin at creation) and kernels of streams that share
-    // a queue run one after the other: with two streams of the default priority, one of them landed on the tail stream's
-    // queue and its frames overlapped nothing (kernel trace: 0.33 ms per frame, no better than one stream).  Streams of
-    // different priorities never share a queue: the chains of frame k (extraction), frame k + 1 (extraction) and frame
-    // k - 1 (tail) -- ~25 small kernels each, bound by launch-to-launch latency -- then run side by side (3 050 -> 4 300
-    // frames/s; one shared high-priority extraction stream: 3 290).
+    // A stream per slot, each at a DIFFERENT stream priority (highest, default, lowest).  HIP multiplexes streams onto a few
+    // hardware queues (round-robin at creation) and kernels of streams that share a queue run one after the other: with
+    // streams of the default priority, one slot's stream landed on another's queue and its frames overlapped nothing
+    // (kernel trace: 0.33 ms per frame, no better than one stream).  Streams of different priorities never share a queue,
+    // so the chains of up to three frames -- ~25 small kernels each, bound by launch-to-launch latency -- run side by side.
     if (o.slots == 1) {
       o.ex_stream[i] = ctx->stream;
-    } else if (i == 0) {
-      int prio_lo = 0, prio_hi = 0;
-      VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[0], hipStreamNonBlocking, prio_hi));
     } else {
       int prio_lo = 0, prio_hi = 0;
       VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[1], hipStreamNonBlocking, prio_lo));
+      const int prio = i == 0 ? prio_hi : (i == 1 ? prio_lo : (prio_lo + prio_hi) / 2);
+      VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[i], hipStreamNonBlocking, prio));
     }
-    VSF_HIP(hipEventCreateWithFlags(&o.ev_extracted[i], hipEventDisableTiming));
     VSF_HIP(hipEventCreateWithFlags(&o.ev_done[i], hipEventDisableTiming));
   }
   o.frame_life = frame_life;
   // matcher scratch: pairs [0, frame_life] belong to the tail, pair frame_life + 1 + slot to the slot's stereo match
-  vsf_status st = ensure_match_buffers(ctx, frame_life + 1 + 2, (int)K);
+  vsf_status st = ensure_match_buffers(ctx, frame_life + 1 + 3, (int)K);
   if (st == VSF_OK) st = ensure_temporal_buffers(ctx, frame_life + 1);
   if (st == VSF_OK) st = ensure_residual_buffers(ctx, 1);
   return st;
@@ -1619,7 +1613,7 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
 vsf_status vsf_observe_reset(vsf_ctx* ctx) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (ctx->ob.ex_stream[i]) VSF_HIP(hipStreamSynchronize(ctx->ob.ex_stream[i]));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   free_observe(ctx);
@@ -1638,14 +1632,14 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   if (ctx->ob.ring && ctx->ob.frame_life != frame_life)  // (re-sizing the window drops nothing that is still in flight)
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
       if (ctx->ob.ticket_of[i] >= 0) return VSF_ERR_INVALID_ARG;
   vsf_status st = ensure_observe(ctx, frame_life);
   if (st != VSF_OK) return st;
   vsf_ctx::Observe& o = ctx->ob;
   const int slot = (int)(o.next_ticket % o.slots);
   if (o.ticket_of[slot] >= 0) return VSF_ERR_INVALID_ARG;  // collect that frame first: its buffers are about to be reused
-  hipStream_t ex = o.ex_stream[slot], s = ctx->stream;
+  hipStream_t ex = o.ex_stream[slot], s = ex;  // the frame's one stream
   const size_t K = (size_t)ctx->p.max_keypoints;
   const int Kc = (int)K;
   // ---- upload: rows into the slot's pinned staging at the device pitch, ONE copy command for both images ----
@@ -1659,9 +1653,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
       for (int y = 0; y < h; y++) std::memcpy(dst + (size_t)y * ctx->st_img_pitch, src[i] + (size_t)y * stride, (size_t)w);
     }
   }
-  // the slot's previous frame has been collected, i.e. its tail has finished reading what the extraction now overwrites;
-  // with the extraction on a stream of its own that order has to be spelt out once more for the device
-  if (ex != s && o.done_valid[slot]) VSF_HIP(hipStreamWaitEvent(ex, o.ev_done[slot], 0));
+  // (the slot's previous frame ran on this same stream: its tail has finished reading what the extraction now overwrites)
   uint8_t* d_img = ctx->st_img + (size_t)(2 * slot) * ctx->st_img_stride;
   VSF_HIP(hipMemcpyAsync(d_img, h_img, 2 * ctx->st_img_stride, hipMemcpyHostToDevice, ex));
   // ---- per-call parameters: written into pinned memory the kernels read directly ----
@@ -1681,7 +1673,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   vsf_keypoint* kp_raw = ctx->st_kp + (size_t)(2 * slot) * K;
   uint8_t* desc_raw = ctx->st_desc + (size_t)(2 * slot) * K * VSF_DESC_BYTES;
   int32_t* counts_raw = ctx->st_counts + 2 * slot;
-  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts, false, ex != s ? &o.side[slot] : nullptr);
+  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts, false, o.slots > 1 ? &o.side[slot] : nullptr);
   ctx->last_images = VsfImages{d_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
   ctx->last_valid = true;
   int32_t* nmatches = o.ints + slot;
@@ -1691,9 +1683,10 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     match_on(ctx, ex, desc_raw, counts_raw, K * VSF_DESC_BYTES, nullptr, nullptr, 0, 1, ctx->m_idx2 + scratch,
              ctx->m_dist2 + scratch, raw_matches, nmatches);
   }
-  if (ex != s) {
-    VSF_HIP(hipEventRecord(o.ev_extracted[slot], ex));
-    VSF_HIP(hipStreamWaitEvent(s, o.ev_extracted[slot], 0));
+  // the tails run in frame order: this frame's waits for the previous frame's (on another slot's stream)
+  if (o.slots > 1 && o.next_ticket > 0) {
+    const int prev = (int)((o.next_ticket - 1) % o.slots);
+    if (o.done_valid[prev]) VSF_HIP(hipStreamWaitEvent(s, o.ev_done[prev], 0));
   }
   // ---- RemoveAmbigStereo (cc:417): the current frame lands in ring sets S (left) and S + 1 (right) ----
   float *means = o.floats, *thr = o.floats + 1, *thr_state = o.floats + 2;
@@ -1722,7 +1715,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, Kc, best_percent, M.best_percent, ctx->t_sortkeys,
                          o.pairs, o.npairs, s);
     // ---- Calculate3DPoints + VisionFeature + UndistortFeaturePoints (cc:437-443) ----
-    int32_t *nfeat = o.ints + 2, *npoints = o.ints + 3;
+    int32_t *nfeat = o.ints + 4, *npoints = o.ints + 5;
     vsf_launch_vision_features(o.kpf, cur_counts, o.pairs + (size_t)n_past * K * 2, o.npairs + n_past, 1, Kc, *calib,
                                o.features, nfeat, npoints, s);
     // ---- the compact result into pinned memory; the filtered left frame into its ring slot (cc:467-470) ----

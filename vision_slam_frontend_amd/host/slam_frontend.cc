@@ -233,12 +233,12 @@ bool Frontend::EnsureContext(int width, int height) {
   if (ctx_) {
     vsf_params p;
     vsf_get_params(ctx_, &p);
-    if (p.width == width && p.height == height && p.max_images >= (pipelined_ ? 4 : 2)) return true;
+    if (p.width == width && p.height == height && p.max_images >= (pipelined_ ? 6 : 2)) return true;
     vsf_destroy(ctx_);
     ctx_ = nullptr;
   }
   vsf_params p;
-  vsf_params_default(&p, width, height, pipelined_ ? 4 : 2);  // two frames in flight need two slots of buffers
+  vsf_params_default(&p, width, height, pipelined_ ? 6 : 2);  // three frames in flight need three slots of buffers
   p.nfeatures = config_.orb_nfeatures;
   p.residual_order = config_.residual_order;
   last_status_ = vsf_params_set_ratio(&p, config_.nn_match_ratio_);
@@ -533,8 +533,8 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
     return false;
   }
   const vsf_calibration calib = MakeCalibration(config_);
-  // the slot this frame goes into must be free: with two frames in flight, the older one is collected and booked first
-  while (pending_.size() >= (pipelined_ ? 2u : 1u))
+  // the slot this frame goes into must be free: with three frames in flight, the oldest is collected and booked first
+  while (pending_.size() >= (pipelined_ ? 3u : 1u))
     if (!RetireOldest()) return false;
   PendingFrame pf;
   last_status_ = vsf_observe_submit(ctx_, left_image.data, right_image.data, left_image.cols, left_image.rows,

@@ -115,7 +115,7 @@ class Frontend {
   // ObserveImage's return value is OdomCheck's decision (cc:404-409): nothing in the reference's control flow needs a
   // frame's features before the next frame arrives.  With pipelining on (fused mode; choose before the first
   // ObserveImage) a call queues its frame on the GPU (vsf_observe_submit) and returns; the frame's result is collected
-  // and booked -- in frame order, with the odometry of ITS call -- when its slot is needed again (two frames later) or
+  // and booked -- in frame order, with the odometry of ITS call -- when its slot is needed again (three frames later) or
   // when anything reads the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and
   // bytes as the synchronous mode; a GPU failure then surfaces in last_status() one or two calls late.
   void set_pipelined(bool on) { pipelined_ = on; }
@@ -173,7 +173,7 @@ class Frontend {
   float stereo_ambig_constraint_;
   bool fused_;
   bool pipelined_;
-  std::vector<PendingFrame> pending_;  // oldest first; at most two
+  std::vector<PendingFrame> pending_;  // oldest first; at most three
   std::vector<uint8_t> observe_buf_;
   vsf_ctx* ctx_;
   int device_;
