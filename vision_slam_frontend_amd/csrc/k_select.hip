@@ -459,8 +459,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 5 : 1) void orb_select_kernel(Selec
   const int tid = threadIdx.x;
   // image -> XCD affinity (workgroups go to the 8 XCDs round-robin by linear id): an image's candidates, pixels and
   // scratch stay in one L2 (speed only)
+  // Dispatch order = level-major: level 0 of every image first, then level 1, ... -- the heaviest workgroups (the widest
+  // levels: most candidates) start first and the light ones fill the tail of the launch (longest job first), instead of
+  // the last images' widest levels starting when the chip has already drained.
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int image = xcd + 8 * (seq / a.nlv), level = a.level0 + seq - (seq / a.nlv) * a.nlv;
+  const int groups = (a.nimages + 7) >> 3;
+  const int image = xcd + 8 * (seq - (seq / groups) * groups), level = a.level0 + seq / groups;
   if (image >= a.nimages) return;
   const VsfLevel L = a.levels[level];
   const uint8_t* img;

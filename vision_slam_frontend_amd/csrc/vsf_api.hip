@@ -811,7 +811,10 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   // fill in as FAST drains and run beside the selection (7.61 -> 7.25 ms per 256-frame step).  Measured and left out:
   // forking behind FAST instead (7.52: the overlap with FAST's tail is lost); making room beside FAST with an LDS
   // reservation that caps FAST at four workgroups per CU (7.46: FAST 3.3 -> 4.2 ms, it is the blur's vector instructions
-  // that FAST has no slots for); a high- or low-priority blur stream (7.39 / 7.65).
+  // that FAST has no slots for); a high- or low-priority blur stream (7.39 / 7.65); slices of the blur forked from INSIDE
+  // the pyramid's launch chain as soon as their levels exist (marks after level 6 / 14, 8, 3 / 8 / 16, ...: the chain's
+  // dependent launches stretch from 1.28 to 1.8-2.2 ms beside the blur's memory traffic, 7.37-7.46 ms per step against
+  // 7.31); the first 3 / 6 / 10 / 16 levels blurred in line in front of FAST and only the rest beside it (7.25-7.36: noise).
   static const int overlap_env = std::getenv("VSF_BLUR_OVERLAP") ? std::atoi(std::getenv("VSF_BLUR_OVERLAP")) : 1;
   static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
   const bool blur_beside = overlap_env && ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
