@@ -230,9 +230,10 @@ def main() -> int:
     ap.add_argument("--nfeatures", type=int, default=None)
     ap.add_argument("--window", type=int, default=1, help="temporal GetFeatureMatches per frame (previous frames)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches per step (vsf_set_lanes)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="overlap a step's pyramid with the previous step's latency-bound tail (vsf_set_pipeline); "
-                         "the per-stage timers then overlap; off for the reported line")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap a step's pyramid with the previous step's latency-bound stages (vsf_set_pipeline); "
+                         "default: on when the frames are resident in HBM (the call's promise: inputs complete in device memory)")
+    ap.add_argument("--pipeline", action="store_true", help="(accepted for compatibility: now the default)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run a step's tail (RemoveAmbigStereo ... payload, collectives) on the extraction's stream instead of "
                          "beside the next step's extraction")
@@ -318,7 +319,10 @@ def main() -> int:
     sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
     ctx.set_lanes(args.lanes)
     ctx.set_blur_overlap(not args.blur_inline)
-    ctx.set_pipeline(args.pipeline)  # (legal here: the synthetic stream is resident in HBM before every call)
+    # cross-call pipelining: legal when every step's input is complete in HBM before the call (the rotating synthetic
+    # batches are; frames arriving from the JPEG ingest stream are only ORDERED before the call, so it stays off there)
+    pipeline = not args.no_pipeline and args.ingest == "hbm"
+    ctx.set_pipeline(pipeline)
     torch.cuda.synchronize()
 
     ingest = None
@@ -365,8 +369,9 @@ def main() -> int:
     # roofline figures of the streaming stages use those, the headline value and ms_per_step do not.
     blur_beside = not args.blur_inline and 2 * B >= 32
     inline_stages = None
-    if blur_beside:
+    if blur_beside or pipeline:
         ctx.set_blur_overlap(False)
+        ctx.set_pipeline(False)
         inline_steps = 3
         run_step()
         sf.drain()
@@ -378,7 +383,8 @@ def main() -> int:
         torch.cuda.synchronize()
         inline_stages = {k: v[0] / inline_steps for k, v in ctx.profile_read(reset=True).items()}
         ctx.profile_enable(False)
-        ctx.set_blur_overlap(True)
+        ctx.set_blur_overlap(not args.blur_inline)
+        ctx.set_pipeline(pipeline)
     rank_ms = [1e3 * elapsed / args.steps]
     blocked_ms, overflow_ranks = 1e3 * sf.blocked_s, [0] if status == capi.VSF_ERR_CAPACITY else []
     if world > 1:
@@ -401,9 +407,9 @@ def main() -> int:
         value = total_frames / elapsed
         alg = stage_algorithmic_bytes(ctx, 2 * B, B, NF)
         pmc = committed_counters(W, H, NF, B)
-        concurrent = ["gauss_blur7"] if blur_beside else []
+        concurrent = (["gauss_blur7"] if blur_beside else []) + (["pyramid_resize"] if pipeline else [])
         dom = max((k for k in stages if k not in concurrent), key=lambda k: stages[k][0])
-        dom_ms, dom_launches = stages[dom]
+        dom_ms, dom_launches = stages[dom]  # (the dominant stage runs alone in the timed steps: its own duration)
         per_launch_bytes = alg[dom] * args.steps / max(dom_launches, 1)
         per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9
@@ -457,11 +463,13 @@ def main() -> int:
                                       (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
                                               "(RCCL)" if world > 1 else ""),
                        "blur_overlap": "gauss_blur7 on its own stream beside fast_score_nms / select_harris_angle (its "
-                                       "stages_ms_per_step entry is a wall span; stages_ms_per_step_blur_inline: 3 untimed "
-                                       "steps with it back in line)" if blur_beside else "off",
+                                       "stages_ms_per_step entry is a wall span; stages_ms_per_step_in_line: 3 untimed "
+                                       "steps with every stage back in line)" if blur_beside else "off",
                        "input_rotation": "3 distinct %d-frame batches in turn (%.0f MB of input; the Infinity Cache holds 256 MB)"
                                          % (B, 3 * B * 2 * W * H / 1e6)
                                          if args.ingest == "hbm" else "per-step decode",
+                       "pipeline": "step s + 1's pyramid beside step s's selection / descriptors / matcher (vsf_set_pipeline)"
+                                   if pipeline else "off",
                        "tail_overlap": "step s's tail + collectives on a second stream beside step s+1's extraction"
                                        if sf.overlap else "off (one stream)",
                        "mean_keypoints_per_image": float(counts.mean()), "mean_stereo_matches": float(nm.mean()),
@@ -485,7 +493,7 @@ def main() -> int:
                                      for k in ("pyramid_resize", "fast_score_nms", "gauss_blur7") if stages[k][0] > 0},
             "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
             "concurrent_stages": concurrent,
-            "stages_ms_per_step_blur_inline": inline_stages,
+            "stages_ms_per_step_in_line": inline_stages,
             "device_ms_per_step": device_ms / args.steps,
             "tail_stream_ms_per_step": None if tail_stages is None else
             {k: v[0] / args.steps for k, v in tail_stages.items()},

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json (or traffic_<name>.json) from three rocprofv3 --pmc passes (counters only, one counter set per
 pass: FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES -- tools/prof_round.sh) of
-`bench.py --steps 3 --warmup 1 --blur-inline` (in line: a kernel's counters do not depend on what runs beside it, and the
+`bench.py --steps 3 --warmup 1 --blur-inline --no-pipeline` (in line: a kernel's counters do not depend on what runs beside it, and the
 run then has exactly 4 steps):
     python tools/make_traffic.py <fetch_dir> <write_dir> <valu_dir> <batch> [width height nfeatures [name]]"""
 import collections
@@ -38,7 +38,7 @@ batch = int(sys.argv[4])
 w, h, nf = (int(v) for v in sys.argv[5:8]) if len(sys.argv) >= 8 else (640, 480, 2000)
 name = sys.argv[8] if len(sys.argv) >= 9 else ""
 out = {
-    "note": "rocprofv3 --pmc passes (separate runs, counters only) of `python bench.py --steps 3 --warmup 1 --blur-inline`, summed over the "
+    "note": "rocprofv3 --pmc passes (separate runs, counters only) of `python bench.py --steps 3 --warmup 1 --blur-inline --no-pipeline`, summed over the "
             "stage's kernels, per step (= per launch for single-launch stages).  gfx950 FETCH_SIZE reports half the bytes of a "
             "coalesced stream (MI355X_MICROARCH.md, HBM); calibrated on the blur kernel, whose 4-byte-per-lane reads of ~1.12x "
             "its algorithmic bytes read 0.54x: hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB units).  valu_wave_insts = "
