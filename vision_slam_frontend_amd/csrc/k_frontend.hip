@@ -518,11 +518,15 @@ void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches
                      (size_t)(NT / 64) * (vsf_par::kWaveTable + kSortWaveStack * sizeof(SortRange) +
                                          kSortWaveBlocks * 2 * sizeof(uint16_t));
   if (!serial && !force_serial && cap < 65536 && lds <= 160 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_trim_par_kernel<NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
+    {  // the kernel's dynamic LDS exceeds the default limit: raised once per device (a process may drive several)
+      static bool raised[64] = {false};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_trim_par_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised[dev] = true;
+      }
     }
     hipLaunchKernelGGL((sort_trim_par_kernel<NT>), dim3(n_pairs), dim3(NT), lds, s, d_matches, d_nmatches, max_rows, cap,
                        best_percent, d_best_percent_of, d_pairs, d_npairs);
