@@ -119,6 +119,12 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
  * operation, results do not depend on it).  With it on, the per-stage timer of the blur (vsf_profile_read) is the wall
  * span of a kernel that shares the chip, not its own duration.  0 puts the blur back in line. */
 vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on);
+/* With the blur beside it, FAST can run as one RESIDENT workgroup per CU (`waves` = 2..4 waves per SIMD, fed with cells
+ * through a counter) instead of a grid that fills every register of the chip for as long as cells are left, so that the
+ * blur's workgroups find room beside it.  -1 (default): the library times the selection and the blur of the second
+ * eligible call of each batch size in line and keeps the resident form (3 waves) when the blur outlasts the selection it
+ * would otherwise hide behind; 0: never; 2..4: always.  Speed only: results do not depend on it. */
+vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
 

@@ -32,7 +32,7 @@ def _oracle_frame(oracle, left, right, nf):
     return ka, da, kb, db, oracle.get_matches(da, db)
 
 
-def _run_stereo_batch(capi, frames, nf, lanes=1, pipeline=False, repeats=1):
+def _run_stereo_batch(capi, frames, nf, lanes=1, pipeline=False, repeats=1, resident=None):
     """frames: (B, 2, h, w) uint8 -> per-image keypoints / descriptors and per-frame matches (numpy)."""
     B, _, H, W = frames.shape
     dev = torch.device("cuda", 0)
@@ -46,6 +46,8 @@ def _run_stereo_batch(capi, frames, nf, lanes=1, pipeline=False, repeats=1):
         torch.cuda.synchronize()  # torch's fills are done before the context's stream touches the buffers
         ctx.set_lanes(lanes)
         ctx.set_pipeline(pipeline)
+        if resident is not None:
+            ctx.set_fast_resident(resident)
         torch.cuda.synchronize()
         for _ in range(repeats):
             ctx.stereo_batch_dev(d_img.data_ptr(), B, W * H, W, d_kp.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(),
@@ -103,6 +105,25 @@ def test_half_batches_equal_full_batch(capi):
     piped = _run_stereo_batch(capi, frames, 2000, pipeline=True, repeats=3)
     for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), full, piped):
         np.testing.assert_array_equal(a, b, err_msg="pipeline " + name)
+
+
+def test_resident_fast_equals_grid_fast(capi, oracle):
+    """vsf_set_fast_resident: FAST as one resident workgroup per CU that draws cells from a counter (the form a batched
+    call uses when its blur would outlast the selection) against FAST as one workgroup per four cells -- same candidates,
+    so the same keypoints, descriptors and matches; and the default (the library measures and chooses between the two on
+    its second call) as well."""
+    from vision_slam_frontend_amd import synth
+    frames = synth.bench_batch(16, 640, 480, seed=synth.BASE_SEED + 33, n_scenes=4)  # 32 images: the blur runs beside FAST
+    grid = _run_stereo_batch(capi, frames, 2000, resident=0)
+    for waves in (3, 2, 4):
+        res = _run_stereo_batch(capi, frames, 2000, resident=waves, repeats=2)  # (twice: the cell counters are re-armed)
+        for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), grid, res):
+            np.testing.assert_array_equal(a, b, err_msg="%d waves per SIMD: %s" % (waves, name))
+    auto = _run_stereo_batch(capi, frames, 2000, repeats=4)  # call 2 is the timed one, calls 3 and 4 use its outcome
+    for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), grid, auto):
+        np.testing.assert_array_equal(a, b, err_msg="measured choice: " + name)
+    for f in (0, 15):
+        _check_frame(oracle, frames, f, 2000, *grid)
 
 
 @pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 96), (320, 240, 500, 100), (1920, 1080, 8000, 96)])

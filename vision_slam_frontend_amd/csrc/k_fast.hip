@@ -61,6 +61,18 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {  // lane i <- lane i
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
 }
 
+// *p, read by every lane and declared the same in all of them (v_readfirstlane per dword)
+template <class T>
+__device__ __forceinline__ T uniform_copy(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dwords");
+  T out;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(p);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; i++) dst[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
+  return out;
+}
+
 // One image row as seen by a lane: its own 4 pixels (d) and the neighbouring lanes' (p = left, n = right).
 struct Row3 {
   uint32_t p, d, n;
@@ -206,9 +218,12 @@ __device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
 template <bool HALF, bool NMS>
 __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int image) {
   const int lane = threadIdx.x & 63;
-  const uint32_t ud = a.units[work];
+  // (explicitly wave-uniform: in the resident kernels' cell loop these loads follow the previous cell's stores, so the
+  // compiler will not prove them invariant and use scalar loads; vector loads would make every row address, the buffer
+  // descriptor included, a per-lane value)
+  const uint32_t ud = uniform_copy(a.units + work);
   const int level = (int)(ud >> 24), band = (int)((ud >> 16) & 0xFF), strip0 = (int)(ud & 0x7FFF);
-  const VsfLevel L = a.levels[level];
+  const VsfLevel L = uniform_copy(a.levels + level);
   const uint8_t* src;
   int pitch;
   if (level == 0) {
@@ -412,6 +427,37 @@ __global__ __launch_bounds__(256) void fast_march_both_kernel(FastArgs a, int nf
     fast_march_body<true, NMS>(a, item, blockIdx.y);
 }
 
+// The same cells walked by ONE resident workgroup per CU (4 x `waves per SIMD` waves; a second one does not fit beside it, so
+// every CU gets its share -- four-wave workgroups were packed five to a CU on some CUs and none on others).  For the batched
+// calls that run the blur beside FAST: a grid of one workgroup per four cells occupies every register of the chip for as
+// long as cells are left and whatever else is queued waits behind it; a fixed set of resident waves leaves the rest of each
+// SIMD's registers to the kernel beside it.  Alone, FAST reaches 93 % of the vector ALU's issue rate with five waves per
+// SIMD, the same with four, 92 % of that with three and 76 % with two (occupancy sweep).
+template <bool HALF, bool NMS>
+__global__ __launch_bounds__(1024) void fast_march_resident_kernel(FastArgs a, int work0, int nwork, int nimages,
+                                                                  uint32_t* next_cell) {
+  // cells are handed out through a counter (zeroed by the launcher): a wave slowed down by its neighbours takes fewer
+  const int total = nwork * nimages;
+  while (true) {  // (wave-uniform; the counter passes `total` for every wave)
+    // one atomic per wave, issued with the execution mask narrowed to lane 0 inside one asm statement: straight-line code
+    // for the compiler (an `if (lane == 0)` in front of a uniform loop exit left it structurising a divergent loop)
+    uint32_t r;
+    asm volatile(
+        "s_mov_b64 s[34:35], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %0, %1, %2, %3 sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, s[34:35]"
+        : "=&v"(r)
+        : "v"(0u), "v"(1u), "s"(next_cell)
+        : "memory", "s34", "s35");
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    if (u >= (uint32_t)total) break;
+    const int image = (int)u / nwork, cell = (int)u - image * nwork;
+    fast_march_body<HALF, NMS>(a, work0 + cell, image);
+  }
+}
+
 // Standalone FAST detect: unit segments -> contiguous cv::KeyPoint list in raster order.
 __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restrict__ levels,
                                                         const uint32_t* __restrict__ cand, uint32_t cand_entries,
@@ -447,7 +493,8 @@ __global__ __launch_bounds__(256) void fast_emit_kernel(const VsfLevel* __restri
 
 }  // namespace
 
-void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s) {
+void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s,
+                     int resident_waves_per_simd, int n_cus, uint32_t* d_cell_counters) {
   FastArgs a;
   a.levels = d.levels;
   a.units = d.units;
@@ -462,6 +509,17 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.rowstart = d.rowstart;
   a.threshold = threshold;
   a.nms = nms;
+  if (resident_waves_per_simd > 0 && resident_waves_per_simd <= 4 && nms && d_cell_counters) {
+    (void)hipMemsetAsync(d_cell_counters, 0, 2 * sizeof(uint32_t), s);
+    const dim3 block(256 * resident_waves_per_simd);
+    if (g.nwork_full > 0)
+      hipLaunchKernelGGL((fast_march_resident_kernel<false, true>), dim3(n_cus), block, 0, s, a, 0, g.nwork_full, im.n,
+                         d_cell_counters);
+    if (g.nwork_half > 0)
+      hipLaunchKernelGGL((fast_march_resident_kernel<true, true>), dim3(n_cus), block, 0, s, a, g.nwork_full,
+                         g.nwork_half, im.n, d_cell_counters + 1);
+    return;
+  }
   const dim3 gf((g.nwork_full + 3) / 4, im.n), gh((g.nwork_half + 3) / 4, im.n);
   static const int both_max = std::getenv("VSF_FAST_BOTH") ? std::atoi(std::getenv("VSF_FAST_BOTH")) : 16;
   if (im.n <= both_max && g.nwork_full > 0 && g.nwork_half > 0) {

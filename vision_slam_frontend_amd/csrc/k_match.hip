@@ -15,6 +15,8 @@
 // ratio_compact: per pair, keep  d1 * 2^shift < num * d2  (the double-precision compare of the reference,
 // exact in integers) and compact the survivors in ascending query index.
 #include <limits.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -76,8 +78,8 @@ __device__ inline void merge_top2(uint32_t& m1, uint32_t& m2, uint32_t b1, uint3
 //                knn2_finalize_kernel then unpacks.
 // Keys leave the kernel as  distance << 20 | train index  ("smaller distance first, ties to the lower train index",
 // batchDistance's insertion rule).
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ desc,
+template <bool SPLIT, int NJ>
+__global__ __launch_bounds__(256, NJ == 1 ? 4 : 2) void knn2_kernel(const uint8_t* __restrict__ desc,
                                                    const int32_t* __restrict__ counts, size_t set_stride,
                                                    const int32_t* __restrict__ q_set,
                                                    const int32_t* __restrict__ t_set, int max_rows,
@@ -86,16 +88,17 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
   const int pair = blockIdx.y;
   const int qs = q_set ? q_set[pair] : 2 * pair, ts = t_set ? t_set[pair] : 2 * pair + 1;
   const int nq = min(counts[qs], max_rows), nt = min(counts[ts], max_rows);
-  if ((int)blockIdx.x * 256 >= nq) return;  // whole block idle (uniform)
+  constexpr int kWgQueries = 128 * NJ;
+  if ((int)blockIdx.x * kWgQueries >= nq) return;  // whole block idle (uniform)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   const uint8_t* Q = desc + (size_t)qs * set_stride;
   const uint32_t* T = reinterpret_cast<const uint32_t*>(desc + (size_t)ts * set_stride);
   // query operands: column c of the wave's two tiles, bits [16 h, 16 h + 16) of each descriptor dword
-  const int qbase = blockIdx.x * 256 + wave * 64;
-  v4i qf[2][8];
+  const int qbase = blockIdx.x * kWgQueries + wave * (32 * NJ);
+  v4i qf[NJ][8];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < NJ; j++) {
     const int q = min(qbase + 32 * j + c, nq - 1);
     const uint4 lo = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[0];
     const uint4 hi = reinterpret_cast<const uint4*>(Q + (size_t)q * 32)[1];
@@ -109,7 +112,9 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
     t_begin = min((int)blockIdx.z * chunk, nt);
     t_end = min(t_begin + chunk, nt);
   }
-  uint32_t g1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, g2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // distance << 20 | train index
+  uint32_t g1[NJ], g2[NJ];  // distance << 20 | train index
+#pragma unroll
+  for (int j = 0; j < NJ; j++) g1[j] = g2[j] = 0xFFFFFFFFu;
   // staging: thread tid expands dword (tid & 7) of train row (tid >> 3) of the tile: 32 bytes at row * 272 + 32 s.
   // Rows past the chunk's end are clamped to its last row (never folded: the last tile's fold checks the row index).
   const int st_row = tid >> 3, st_s = tid & 7;
@@ -122,19 +127,30 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
   for (int c0 = t_begin; c0 < t_end; c0 += kChunkRows) {
     const int c_end = min(c0 + kChunkRows, t_end);
     const int ntiles = (c_end - c0 + kTile - 1) / kTile;
-    uint32_t m1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, m2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // distance << 13 | row - c0
-    v16i base;  // 2^20 + (train row of accumulator register i) - c0, advanced by 32 per tile
+    uint32_t m1[NJ], m2[NJ];  // distance << 13 | row - c0
 #pragma unroll
-    for (int i = 0; i < 16; i++) base[i] = (1 << 20) + (i & 3) + 8 * (i >> 2) + 4 * h;
+    for (int j = 0; j < NJ; j++) m1[j] = m2[j] = 0xFFFFFFFFu;
+    // accumulator register i of tile t starts at  2^20 + (its train row - c0)  =  (2^20 + 32 t + (i & 3) + 8 (i >> 2)) + 4 h:
+    // a scalar sum plus one lane-dependent term -- one v_add per register and no register set held across the tiles
+    const int vh = 4 * h;
+    auto acc_init = [&](int t) -> v16i {
+      v16i a;
+#pragma unroll
+      for (int i = 0; i < 16; i++) a[i] = vh + ((1 << 20) + t * kTile + (i & 3) + 8 * (i >> 2));
+      return a;
+    };
     auto fold = [&](const v16i& a0, const v16i& a1, int t0, bool check) {
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const bool valid = !check || t0 + (i & 3) + 8 * (i >> 2) + 4 * h < c_end;
-        const uint32_t k0 = valid ? (uint32_t)a0[i] : 0xFFFFFFFFu, k1 = valid ? (uint32_t)a1[i] : 0xFFFFFFFFu;
+        const uint32_t k0 = valid ? (uint32_t)a0[i] : 0xFFFFFFFFu;
         m2[0] = umed3(m1[0], m2[0], k0);
         m1[0] = min(m1[0], k0);
-        m2[1] = umed3(m1[1], m2[1], k1);
-        m1[1] = min(m1[1], k1);
+        if constexpr (NJ == 2) {
+          const uint32_t k1 = valid ? (uint32_t)a1[i] : 0xFFFFFFFFu;
+          m2[NJ - 1] = umed3(m1[NJ - 1], m2[NJ - 1], k1);
+          m1[NJ - 1] = min(m1[NJ - 1], k1);
+        }
       }
     };
     // One pipeline step = tile t: its sixteen MFMAs (into `n0`, `n1`) are issued one at a time with eight vector-ALU
@@ -150,24 +166,22 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
       v4i tf[8];
 #pragma unroll
       for (int s = 0; s < 8; s++) tf[s] = *reinterpret_cast<const v4i*>(rowp + 32 * s);
-      n0 = base;
-      n1 = base;
+      n0 = acc_init(t);
+      if constexpr (NJ == 2) n1 = acc_init(t);
 #pragma unroll
       for (int s = 0; s < 8; s++) {
         n0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf[s], qf[0][s], n0, 0, 0, 0);
-        n1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf[s], qf[1][s], n1, 0, 0, 0);
+        if constexpr (NJ == 2) n1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf[s], qf[NJ - 1][s], n1, 0, 0, 0);
       }
       if (fold_prev) fold(p0, p1, 0, false);  // (every tile but a chunk's last is full)
-#pragma unroll
-      for (int i = 0; i < 16; i++) base[i] += kTile;
       stage(buf ^ 1, bits_next[0]);
 #pragma unroll
       for (int k = 0; k + 1 < kAhead; k++) bits_next[k] = bits_next[k + 1];
       bits_next[kAhead - 1] = bits_after;
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // eight VALU
+      for (int g = 0; g < 8 * NJ; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NJ == 2 ? 8 : 10, 0);  // its share of the vector-ALU work
       }
       __syncthreads();
     };
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
 #pragma unroll
     for (int k = 0; k < kAhead; k++) bits_next[k] = load_bits(c0 + (1 + k) * kTile, c_end);
     __syncthreads();
-    v16i accA0, accA1, accB0 = base, accB1 = base;  // (B is not folded before it is written)
+    v16i accA0, accA1, accB0 = acc_init(0), accB1 = accB0;  // (B is not folded before it is written)
     step(0, accB0, accB1, accA0, accA1, false);
     int t = 1;
     for (; t + 1 < ntiles; t += 2) {
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
     }
     // chunk keys -> global keys, merged into the running best two
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < NJ; j++) {
       const uint32_t a1 = m1[j] == 0xFFFFFFFFu ? m1[j] : ((m1[j] >> 13) << 20) | ((m1[j] & 8191u) + (uint32_t)c0);
       const uint32_t a2 = m2[j] == 0xFFFFFFFFu ? m2[j] : ((m2[j] >> 13) << 20) | ((m2[j] & 8191u) + (uint32_t)c0);
       merge_top2(g1[j], g2[j], a1, a2);
@@ -199,13 +213,13 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ d
   }
   // the two lane halves hold the rows 4 h + ... of every tile: merge them
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < NJ; j++) {
     const uint32_t o1 = __shfl_xor(g1[j], 32), o2 = __shfl_xor(g2[j], 32);
     merge_top2(g1[j], g2[j], o1, o2);
   }
   if (h != 0) return;
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < NJ; j++) {
     const int q = qbase + 32 * j + c;
     if (q >= nq) continue;
     const uint32_t b1 = g1[j], b2 = g2[j];
@@ -301,26 +315,40 @@ __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __res
 
 }  // namespace
 
-void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
-                     const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                     hipStream_t s) {
-  const int qtiles = (max_rows + 255) / 256;
-  // Two workgroups fit a CU (register-limited), 512 run at once.  A batch of 128 stereo pairs brings ~1000 query tiles,
-  // two full rounds, and runs unsplit; with fewer (one pair of one frame at a time) the train sets are split until about
-  // that many workgroups exist (each at least eight 32-row tiles) and merged through the packed key pairs.
+template <int NJ>
+static void launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
+                        const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
+                        hipStream_t s) {
+  const int wgq = 128 * NJ;
+  const int qtiles = (max_rows + wgq - 1) / wgq;
+  // A batch of 128 stereo pairs brings ~1000 workgroups of 256 queries, two full rounds of the chip, and runs unsplit; with
+  // fewer (one pair of one frame at a time) the train sets are split until about that many workgroups exist (each at least
+  // eight 32-row tiles) and merged through the packed key pairs.
   int nsplit = 1;
-  if ((long)qtiles * n_pairs < 768) nsplit = (int)std::min<long>(32, 1024 / ((long)qtiles * n_pairs));
+  if ((long)qtiles * n_pairs * NJ < 2 * 768) nsplit = (int)std::min<long>(32, 2 * 1024 / ((long)qtiles * n_pairs * NJ));
   nsplit = std::max(1, std::min(nsplit, max_rows / (2 * kSplitAlign)));
   if (nsplit <= 1) {
-    hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride, d_q_set,
-                       d_t_set, max_rows, d_idx2, d_dist2);
+    hipLaunchKernelGGL((knn2_kernel<false, NJ>), dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride,
+                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
     return;
   }
   (void)hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s);
-  hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
+  hipLaunchKernelGGL((knn2_kernel<true, NJ>), dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
                      d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
-  hipLaunchKernelGGL(knn2_finalize_kernel, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set, max_rows, d_idx2,
-                     d_dist2);
+  hipLaunchKernelGGL(knn2_finalize_kernel, dim3((max_rows + 255) / 256, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set,
+                     max_rows, d_idx2, d_dist2);
+}
+
+void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
+                     const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
+                     hipStream_t s) {
+  // VSF_KNN=wide: 64 queries per wave (two column tiles: 256 registers per lane, two waves per SIMD); default: 32 queries
+  // per wave in half the registers, which a workgroup finds free beside another kernel's waves
+  static const bool wide = std::getenv("VSF_KNN") && !strcmp(std::getenv("VSF_KNN"), "wide");
+  if (wide)
+    launch_knn2<2>(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, max_rows, d_idx2, d_dist2, s);
+  else
+    launch_knn2<1>(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, max_rows, d_idx2, d_dist2, s);
 }
 
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,

@@ -410,6 +410,7 @@ struct DevSet {  // device copies of one Geometry + its work buffers
 struct vsf_ctx {
   vsf_params p{};
   int device = 0;
+  int n_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   // Second lane of the batched entry points: half of a batch runs on `stream`, the other half on `aux_stream`
   // (frames are independent), so latency-bound stages of one half overlap VALU-bound stages of the other.
@@ -433,11 +434,18 @@ struct vsf_ctx {
   const uint8_t* last_pyr = nullptr;
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int blur_overlap = 1;  // the blur on blur_stream beside FAST / selection (vsf_set_blur_overlap)
+  int fast_resident = -1;  // vsf_set_fast_resident
   int last_hip = 0;
   Geometry orb, fast;
   DevSet dorb, dfast;
   int gauss[4] = {0, 0, 0, 0};
   int32_t* d_status = nullptr;
+  uint32_t* fast_cells = nullptr;  // [2] cell counters of the resident FAST kernels (k_fast.hip)
+  struct FastTune {  // resident FAST or one workgroup per four cells: measured once per batch size (extract_on)
+    int n = 0, choice = -1, calls = 0;
+    bool pending = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  } fast_tune;
   int32_t* h_status = nullptr;  // pinned
   // staging for the host-pointer entry points
   uint8_t* st_img = nullptr;
@@ -810,14 +818,49 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   // its issue rate) and the selection on latency: forked behind the pyramid onto its own stream, the blur's workgroups
   // fill in as FAST drains and run beside the selection (7.61 -> 7.25 ms per 256-frame step).  Measured and left out:
   // forking behind FAST instead (7.52: the overlap with FAST's tail is lost); making room beside FAST with an LDS
-  // reservation that caps FAST at four workgroups per CU (7.46: FAST 3.3 -> 4.2 ms, it is the blur's vector instructions
-  // that FAST has no slots for); a high- or low-priority blur stream (7.39 / 7.65); slices of the blur forked from INSIDE
+  // reservation that caps FAST at four workgroups per CU (7.46: the reservation is LDS the blur needs; the resident
+  // kernel below caps FAST without it); a high- or low-priority blur stream (7.39 / 7.65); slices of the blur forked from INSIDE
   // the pyramid's launch chain as soon as their levels exist (marks after level 6 / 14, 8, 3 / 8 / 16, ...: the chain's
   // dependent launches stretch from 1.28 to 1.8-2.2 ms beside the blur's memory traffic, 7.37-7.46 ms per step against
   // 7.31); the first 3 / 6 / 10 / 16 levels blurred in line in front of FAST and only the rest beside it (7.25-7.36: noise).
   static const int overlap_env = std::getenv("VSF_BLUR_OVERLAP") ? std::atoi(std::getenv("VSF_BLUR_OVERLAP")) : 1;
   static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
-  const bool blur_beside = overlap_env && ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
+  const bool beside_ok = overlap_env && ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
+  // With the blur beside it FAST can run as ONE resident workgroup per CU (k_fast.hip): three waves per SIMD keep 92 % of
+  // its own rate and leave the other 224 of a SIMD's 512 registers -- which a grid of one workgroup per four cells fills
+  // for as long as cells are left -- to the blur, which then finishes INSIDE the FAST pass instead of after it.  That pays
+  // when the blur outlasts the selection it otherwise hides behind (640x480 / 2000 features: 7.21-7.37 -> 7.03 ms per
+  // 256-frame step; four waves per SIMD 7.09-7.12, two 8.0) and costs when it does not (1920x1080 / 8000: 6.54 -> 6.80 ms
+  // per 32-frame step), so the second eligible call of a batch size runs blur and selection in line between timed events
+  // and the calls after it use what was measured.  vsf_set_fast_resident (or VSF_FAST_RESIDENT=0 / 2..4) overrides it.
+  static const int resident_env = std::getenv("VSF_FAST_RESIDENT") ? std::atoi(std::getenv("VSF_FAST_RESIDENT")) : -1;
+  int resident = 0;
+  bool measure = false;
+  if (beside_ok && ctx->lanes == 1 && st == ctx->stream && i0 == 0 && !own_side) {
+    vsf_ctx::FastTune& T = ctx->fast_tune;
+    if (ctx->fast_resident >= 0 || resident_env >= 0) {
+      resident = ctx->fast_resident >= 0 ? ctx->fast_resident : resident_env;
+    } else {
+      if (T.n != im.n) {
+        T.n = im.n;
+        T.choice = -1;
+        T.pending = false;
+        T.calls = 0;
+      }
+      if (T.choice < 0 && !T.pending && T.calls++ > 0) {  // (not the first call: its kernels start cold)
+        measure = true;
+        for (hipEvent_t& e : T.ev)
+          if (!e && hipEventCreate(&e) != hipSuccess) measure = false;
+      } else if (T.choice < 0 && T.pending && hipEventQuery(T.ev[2]) == hipSuccess) {
+        float t_select = 0.f, t_blur = 0.f;
+        if (hipEventElapsedTime(&t_select, T.ev[0], T.ev[1]) == hipSuccess &&
+            hipEventElapsedTime(&t_blur, T.ev[1], T.ev[2]) == hipSuccess)
+          T.choice = t_blur > t_select ? 3 : 0;
+      }
+      resident = T.choice > 0 ? T.choice : 0;
+    }
+  }
+  const bool blur_beside = beside_ok && !measure;
   auto launch_blur = [&](hipStream_t bs) {
     StageTimer t(ctx, bs, VSF_STAGE_BLUR, 1);
     // VSF_BLUR=march: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
@@ -839,20 +882,26 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   if (blur_beside) fork_blur();
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
-    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st);
+    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
   }
   if (pipe) {
     (void)hipEventRecord(ctx->ev_fast_done, st);
     ctx->fast_done_valid = true;
   }
+  if (measure) (void)hipEventRecord(ctx->fast_tune.ev[0], st);
   {
     StageTimer t(ctx, st, VSF_STAGE_SELECT, 1);
     vsf_launch_select(d, g, ctx->orb.levels.data(), im, st);
   }
+  if (measure) (void)hipEventRecord(ctx->fast_tune.ev[1], st);
   if (blur_beside)
     (void)hipStreamWaitEvent(st, ctx->ev_blur_done, 0);
   else
     launch_blur(st);
+  if (measure) {
+    (void)hipEventRecord(ctx->fast_tune.ev[2], st);
+    ctx->fast_tune.pending = true;
+  }
   {
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);
     vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp + i0 * K, d_desc + i0 * K * VSF_DESC_BYTES, d_counts + i0,
@@ -1018,6 +1067,10 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
     return s;
   };
   if (hipSetDevice(device) != hipSuccess) return fail(VSF_ERR_NO_DEVICE);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
+  }
   if (!build_geometry(ctx->p, true, true, &ctx->orb)) return fail(VSF_ERR_INVALID_ARG);
   gaussian_taps(ctx->gauss);
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(VSF_ERR_HIP);
@@ -1040,6 +1093,7 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
   }
   if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMalloc((void**)&ctx->fast_cells, 2 * sizeof(uint32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipHostMalloc((void**)&ctx->h_status, sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
     return fail(VSF_ERR_HIP);
   vsf_status st = alloc_devset(ctx, ctx->orb, &ctx->dorb, true, ctx->p.max_images);
@@ -1074,6 +1128,9 @@ void vsf_destroy(vsf_ctx* ctx) {
   free_devset(&ctx->dorb);
   free_devset(&ctx->dfast);
   hipFree(ctx->d_status);
+  hipFree(ctx->fast_cells);
+  for (hipEvent_t e : ctx->fast_tune.ev)
+    if (e) hipEventDestroy(e);
   if (ctx->h_status) hipHostFree(ctx->h_status);
   hipFree(ctx->st_img);
   hipFree(ctx->st_kp);
@@ -1152,6 +1209,13 @@ vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->blur_overlap = on ? 1 : 0;
+  return VSF_OK;
+}
+
+vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves) {
+  if (!ctx || waves < -1 || waves == 1 || waves > 4) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->fast_resident = waves;
   return VSF_OK;
 }
 

@@ -117,7 +117,8 @@ void vsf_launch_bayer_bg_gray(const uint8_t* d_src, int n, int w, int h, size_t 
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                         hipStream_t s, const VsfSideStream* side);
 // threshold: FAST threshold; nms == 0 keeps every corner (standalone FAST only).
-void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s);
+void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s,
+                     int resident_waves_per_simd = 0, int n_cus = 0, uint32_t* d_cell_counters = nullptr);
 void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                        hipStream_t s);
 void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n_points, int use_lds, int mode,
