@@ -40,13 +40,18 @@ __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint
                                                               const float* __restrict__ F,  // 9 floats, row major
                                                               int order,  // vsf_params::residual_order
                                                               float* __restrict__ residual,  // [frames][max_rows]
-                                                              float* __restrict__ mean) {    // [frames], NaN if empty
+                                                              float* __restrict__ mean,      // [frames], NaN if empty
+                                                              int lds_rows) {
+  // lds_rows >= max_rows: the residuals are kept in LDS for the one thread that adds them up in match order (the
+  // reference's float accumulation); read back from memory, every term of that chain was a trip to the L2
+  extern __shared__ __attribute__((aligned(16))) float s_res[];
   const int f = blockIdx.x;
   const int n = min(nmatches[f], max_rows);
   const vsf_keypoint* left = kp + (size_t)(2 * f) * max_rows;
   const vsf_keypoint* right = kp + (size_t)(2 * f + 1) * max_rows;
   const vsf_dmatch* m = matches + (size_t)f * max_rows;
   float* res = residual + (size_t)f * max_rows;
+  const bool in_lds = lds_rows >= max_rows;
   float Fm[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) Fm[i] = F[i];
@@ -57,12 +62,27 @@ __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint
     float t[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) t[j] = dot3(order, lx, Fm[0 * 3 + j], ly, Fm[1 * 3 + j], 1.0f, Fm[2 * 3 + j]);
-    res[i] = fabsf(dot3(order, t[0], rx, t[1], ry, t[2], 1.0f));
+    const float r = fabsf(dot3(order, t[0], rx, t[1], ry, t[2], 1.0f));
+    res[i] = r;
+    if (in_lds) s_res[i] = r;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     float avg = 0.0f;  // avg_constraint += constraint, in match order
-    for (int i = 0; i < n; i++) avg += res[i];
+    if (in_lds) {
+      int i = 0;
+#pragma unroll 4
+      for (; i + 4 <= n; i += 4) {  // (the loads run ahead of the chain of additions)
+        const float4 v = *reinterpret_cast<const float4*>(s_res + i);
+        avg += v.x;
+        avg += v.y;
+        avg += v.z;
+        avg += v.w;
+      }
+      for (; i < n; i++) avg += s_res[i];
+    } else {
+      for (int i = 0; i < n; i++) avg += res[i];
+    }
     // 0.0f / 0 on the reference's x86 is the default ("real indefinite") NaN, sign bit set; the bits travel into the
     // threshold and the gathered records, so they are reproduced rather than left to this GPU's own default NaN
     mean[f] = n > 0 ? avg / (float)n : __uint_as_float(0xFFC00000u);
@@ -482,8 +502,9 @@ __global__ __launch_bounds__(256) void observe_pack_kernel(VsfObserveArgs a) {
 void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
                                  int n_frames, int max_rows, const float* d_F, int order, float* d_residual, float* d_mean,
                                  hipStream_t s) {
-  hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_matches, d_nmatches, max_rows,
-                     d_F, order, d_residual, d_mean);
+  const int lds_rows = max_rows <= 16000 ? (max_rows + 3) & ~3 : 0;  // (64 KB of LDS without asking for more)
+  hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), (size_t)lds_rows * sizeof(float), s, d_kp,
+                     d_matches, d_nmatches, max_rows, d_F, order, d_residual, d_mean, lds_rows);
 }
 
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
