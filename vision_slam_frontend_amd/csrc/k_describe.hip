@@ -99,6 +99,8 @@ __device__ __forceinline__ void sincos_2pi(double x, double* s_out, double* c_ou
   *c_out = ((k + 1) & 2) ? -cv : cv;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 constexpr int kKpPerWave = 4;  // consecutive output keypoints per wave (per 256-frame step: 2 -> 0.89 ms, 4 -> 0.83, 8 -> 0.85,
                                 // 16 -> 0.89, 32 -> 0.97: the kernel lives on waves in flight, not on amortised prologues)
 
@@ -226,12 +228,12 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
 
   // ---- K8: rotated BRIEF on the blurred level ----
   // this lane's four pattern pairs
-  float pat[4][4];
+  f2 patx[4], paty[4];  // (x0, x1), (y0, y1) of pair lane + 64 j
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int pair = lane + 64 * j;
-#pragma unroll
-    for (int c = 0; c < 4; c++) pat[j][c] = (float)c_pattern31[4 * pair + c];
+    patx[j] = f2{(float)c_pattern31[4 * pair + 0], (float)c_pattern31[4 * pair + 2]};
+    paty[j] = f2{(float)c_pattern31[4 * pair + 1], (float)c_pattern31[4 * pair + 3]};
   }
   // A keypoint's 512 pattern points fall in the 39 x 39 window around it (|rotated pattern| <= 18.4).  Gathering them
   // straight from memory costs the L1 one tag lookup per distinct cache line per load instruction (~40 lines x 8
@@ -245,13 +247,12 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
   const int pseg0 = pc0 & 3, pseg1 = pc1 & 3, pseg2 = pc2 & 3;
   const int pdst0 = prow0 * kWinPitch + 16 * pseg0, pdst1 = prow1 * kWinPitch + 16 * pseg1,
             pdst2 = prow2 * kWinPitch + 16 * pseg2;
+  // the window centres, one keypoint per lane (KeyPoint::pt scaled up and back down, as computeDescriptors sees it)
+  const int cx_k = __float2int_rn((float)(int)(xy_k & 0xFFFu) * scale_k * inv_k);
+  const int cy_k = __float2int_rn((float)(int)(xy_k >> 12) * scale_k * inv_k);
   auto centre = [&](int kk, int* cx, int* cy) {
-    const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_k, kk);
-    const float lscale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scale_k), kk));
-    const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_k), kk));
-    const float fx = (float)(int)(xy & 0xFFFu) * lscale, fy = (float)(int)(xy >> 12) * lscale;
-    *cx = __float2int_rn(fx * inv);
-    *cy = __float2int_rn(fy * inv);
+    *cx = __builtin_amdgcn_readlane(cx_k, kk);
+    *cy = __builtin_amdgcn_readlane(cy_k, kk);
   };
   uint4 q0, q1, q2;
   auto fetch = [&](int kk) {
@@ -285,16 +286,28 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
     const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sb_k), kk));
     int cx, cy;
     centre(kk, &cx, &cy);
-    // tile origin = (centre - 19 rows, (centre - 19 columns) rounded down to 16): lane offsets are non-negative
-    const uint8_t* corner = win + 19 * kWinPitch + 19 + ((cx - 19) & 15);
+    // tile origin = (centre - 19 rows, (centre - 19 columns) rounded down to 16): lane offsets are non-negative.
+    // The two points of a pair are rotated together on packed floats (v_pk_mul_f32 / v_pk_add_f32: every product and
+    // sum rounded by itself, as in the scalar code); cvRound = round to nearest even comes out of one more addition:
+    // |coordinate| < 2^22, so  c + 1.5 * 2^23  is rounded to an integer by the addition itself and its bit pattern is
+    // 0x4B400000 + cvRound(c).  Row * 64 + column of the two patterns, less 65 * 0x4B400000, is the window offset.
+    // (formed as a 32-bit LDS address that wraps around, not as an index into the window array: out of range as an index)
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+    const uint32_t corner = (uint32_t)(size_t)(lds_u8*)win + (uint32_t)(19 * kWinPitch + 19 + ((cx - 19) & 15)) -
+                            65u * 0x4B400000u;
+    const f2 ca2 = {ca, ca}, sb2 = {sb, sb};
+    const f2 magic = {12582912.0f, 12582912.0f};
     uint64_t w[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const float x0f = pat[j][0], y0f = pat[j][1], x1f = pat[j][2], y1f = pat[j][3];
-      const int ix0 = __float2int_rn(x0f * ca - y0f * sb), iy0 = __float2int_rn(x0f * sb + y0f * ca);
-      const int ix1 = __float2int_rn(x1f * ca - y1f * sb), iy1 = __float2int_rn(x1f * sb + y1f * ca);
-      const int t0 = corner[iy0 * kWinPitch + ix0];
-      const int t1 = corner[iy1 * kWinPitch + ix1];
+      const f2 xa = patx[j] * ca2, yb = paty[j] * sb2, xb = patx[j] * sb2, ya = paty[j] * ca2;
+      const f2 fx = (xa - yb) + magic, fy = (xb + ya) + magic;
+      // (__float_as_uint of a copy: __builtin_bit_cast applied to a vector ELEMENT comes out undefined with this compiler)
+      const float fx0 = fx.x, fx1 = fx.y, fy0 = fy.x, fy1 = fy.y;
+      const uint32_t o0 = (__float_as_uint(fy0) << 6) + __float_as_uint(fx0) + corner;
+      const uint32_t o1 = (__float_as_uint(fy1) << 6) + __float_as_uint(fx1) + corner;
+      const int t0 = *(lds_u8*)(size_t)o0;
+      const int t1 = *(lds_u8*)(size_t)o1;
       w[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {
