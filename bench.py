@@ -408,8 +408,16 @@ def main() -> int:
         alg = stage_algorithmic_bytes(ctx, 2 * B, B, NF)
         pmc = committed_counters(W, H, NF, B)
         concurrent = (["gauss_blur7"] if blur_beside else []) + (["pyramid_resize"] if pipeline else [])
-        dom = max((k for k in stages if k not in concurrent), key=lambda k: stages[k][0])
-        dom_ms, dom_launches = stages[dom]  # (the dominant stage runs alone in the timed steps: its own duration)
+        # the dominant stage by its OWN duration (the in-line pass when stages share the chip in the timed steps)
+        if inline_stages:
+            dom = max(inline_stages, key=lambda k: inline_stages[k])
+        else:
+            dom = max((k for k in stages if k not in concurrent), key=lambda k: stages[k][0])
+        dom_ms, dom_launches = stages[dom]
+        fast_waves = ctx.get_fast_resident()
+        # FAST as resident workgroups shares every SIMD with the blur: its stage time in the timed steps is then a span
+        # under contention as well; its own duration comes from the in-line pass
+        shares = ["gauss_blur7"] if (dom == "fast_score_nms" and blur_beside and fast_waves > 0) else []
         per_launch_bytes = alg[dom] * args.steps / max(dom_launches, 1)
         per_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9
@@ -425,6 +433,8 @@ def main() -> int:
             valu = {"bound": "valu", "kernel": dom, "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                     "frac": a / VALU_PEAK_GINST, "valu_wave_insts_per_launch": float(insts) * args.steps / max(dom_launches, 1),
                     "source": "profiles/traffic*.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass) / stage time of this run"}
+            if inline_stages:  # the kernel by itself (see roofline.in_line)
+                valu["frac_in_line"] = float(insts) / (inline_stages[dom] * 1e-3) / 1e9 / VALU_PEAK_GINST
         hbm_frac = achieved / HBM_PEAK_GBS
         bound = "valu" if valu and valu["frac"] > hbm_frac else "hbm"
         # matcher (K9): pair distances per second of the stereo knn2 launches and the int8 matrix-core rate they imply
@@ -468,6 +478,9 @@ def main() -> int:
                        "input_rotation": "3 distinct %d-frame batches in turn (%.0f MB of input; the Infinity Cache holds 256 MB)"
                                          % (B, 3 * B * 2 * W * H / 1e6)
                                          if args.ingest == "hbm" else "per-step decode",
+                       "fast_resident": ("measured choice: %s" % ("one resident workgroup per CU, %d waves per SIMD (the blur "
+                                         "finishes inside the FAST pass)" % fast_waves if fast_waves > 0 else
+                                         "one workgroup per four cells" if fast_waves == 0 else "open")) if blur_beside else "off",
                        "pipeline": "step s + 1's pyramid beside step s's selection / descriptors / matcher (vsf_set_pipeline)"
                                    if pipeline else "off",
                        "tail_overlap": "step s's tail + collectives on a second stream beside step s+1's extraction"
@@ -481,7 +494,12 @@ def main() -> int:
             "roofline": {"bound": "hbm", "limited_by": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbm_frac, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
-                         "launches": dom_launches},
+                         "launches": dom_launches, "shares_the_chip_with": shares,
+                         "in_line": None if not inline_stages else {
+                             "avg_launch_ms": inline_stages[dom] * args.steps / max(dom_launches, 1),
+                             "achieved": alg[dom] / (inline_stages[dom] * 1e-3) / 1e9,
+                             "frac": alg[dom] / (inline_stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "the kernel by itself: 3 untimed steps with every stage back in line on one stream"}},
             # self-verification of a multi-GPU run: what the process group says it is, the ranks an all-gather of rank ids
             # saw on that backend, every rank's own step time, the longest any rank's host waited inside a gather
             "rccl": dict(handshake, per_rank_ms_per_step={"min": min(rank_ms), "max": max(rank_ms)},

@@ -125,6 +125,9 @@ vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on);
  * eligible call of each batch size in line and keeps the resident form (3 waves) when the blur outlasts the selection it
  * would otherwise hide behind; 0: never; 2..4: always.  Speed only: results do not depend on it. */
 vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves);
+/* What the batched calls currently do: *waves = 0 (grid form), 2..4 (resident, waves per SIMD), or -1 while the measured
+ * choice for the last batch size is still open. */
+vsf_status vsf_get_fast_resident(const vsf_ctx* ctx, int* waves);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
 

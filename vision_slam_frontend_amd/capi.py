@@ -30,7 +30,7 @@ EXPORTS = [
     "vsf_params_default", "vsf_params_set_ratio", "vsf_create", "vsf_destroy", "vsf_status_string",
     "vsf_last_hip_error", "vsf_get_params", "vsf_set_stream", "vsf_sync", "vsf_level_info", "vsf_extract",
     "vsf_fast_detect", "vsf_knn2_hamming", "vsf_get_matches", "vsf_extract_pair", "vsf_get_matches_multi", "vsf_extract_batch_dev", "vsf_match_batch_dev",
-    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_set_blur_overlap", "vsf_set_fast_resident", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_bayer_bg_to_gray_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
+    "vsf_stereo_batch_dev", "vsf_set_lanes", "vsf_set_pipeline", "vsf_set_blur_overlap", "vsf_set_fast_resident", "vsf_get_fast_resident", "vsf_remove_ambig_stereo_batch_dev", "vsf_feature_matches_batch_dev", "vsf_bayer_bg_to_gray_batch_dev", "vsf_debug_level_image", "vsf_debug_fast_candidates", "vsf_debug_level_keypoints",
     "vsf_algorithmic_bytes_per_image", "vsf_pyramid_pixels", "vsf_profile_enable", "vsf_profile_read",
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
         L.vsf_set_pipeline.argtypes = [vp, i32]
         L.vsf_set_blur_overlap.argtypes = [vp, i32]
         L.vsf_set_fast_resident.argtypes = [vp, i32]
+        L.vsf_get_fast_resident.argtypes = [vp, C.POINTER(C.c_int)]
         L.vsf_remove_ambig_stereo_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.c_float, vp, vp, vp, vp, vp, vp]
         L.vsf_feature_matches_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, C.c_float, vp, vp]
         L.vsf_bayer_bg_to_gray_batch_dev.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, sz, sz]
@@ -233,6 +234,11 @@ class Context:
     def set_fast_resident(self, waves: int):
         """-1: measured choice (default); 0: FAST as one workgroup per four cells; 2..4: resident, that many waves per SIMD."""
         self._check(lib().vsf_set_fast_resident(self._h, int(waves)), "vsf_set_fast_resident")
+
+    def get_fast_resident(self) -> int:
+        w = C.c_int(-1)
+        self._check(lib().vsf_get_fast_resident(self._h, C.byref(w)), "vsf_get_fast_resident")
+        return w.value
 
     def set_pipeline(self, on: bool):
         self._check(lib().vsf_set_pipeline(self._h, int(on)), "vsf_set_pipeline")

@@ -1219,6 +1219,12 @@ vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves) {
   return VSF_OK;
 }
 
+vsf_status vsf_get_fast_resident(const vsf_ctx* ctx, int* waves) {
+  if (!ctx || !waves) return VSF_ERR_INVALID_ARG;
+  *waves = ctx->fast_resident >= 0 ? ctx->fast_resident : ctx->fast_tune.choice;
+  return VSF_OK;
+}
+
 vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
