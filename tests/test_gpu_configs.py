@@ -107,23 +107,24 @@ def test_half_batches_equal_full_batch(capi):
         np.testing.assert_array_equal(a, b, err_msg="pipeline " + name)
 
 
-def test_resident_fast_equals_grid_fast(capi, oracle):
+@pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 16), (320, 240, 500, 20), (1920, 1080, 8000, 16), (752, 480, 1500, 16)])
+def test_resident_fast_equals_grid_fast(capi, oracle, w, h, nf, B):
     """vsf_set_fast_resident: FAST as one resident workgroup per CU that draws cells from a counter (the form a batched
     call uses when its blur would outlast the selection) against FAST as one workgroup per four cells -- same candidates,
     so the same keypoints, descriptors and matches; and the default (the library measures and chooses between the two on
     its second call) as well."""
     from vision_slam_frontend_amd import synth
-    frames = synth.bench_batch(16, 640, 480, seed=synth.BASE_SEED + 33, n_scenes=4)  # 32 images: the blur runs beside FAST
-    grid = _run_stereo_batch(capi, frames, 2000, resident=0)
-    for waves in (3, 2, 4):
-        res = _run_stereo_batch(capi, frames, 2000, resident=waves, repeats=2)  # (twice: the cell counters are re-armed)
+    frames = synth.bench_batch(B, w, h, seed=synth.BASE_SEED + 33, n_scenes=4)  # >= 32 images: the blur runs beside FAST
+    grid = _run_stereo_batch(capi, frames, nf, resident=0)
+    for waves in ((3, 2, 4) if w == 640 else (3,)):
+        res = _run_stereo_batch(capi, frames, nf, resident=waves, repeats=2)  # (twice: the cell counters are re-armed)
         for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), grid, res):
             np.testing.assert_array_equal(a, b, err_msg="%d waves per SIMD: %s" % (waves, name))
-    auto = _run_stereo_batch(capi, frames, 2000, repeats=4)  # call 2 is the timed one, calls 3 and 4 use its outcome
+    auto = _run_stereo_batch(capi, frames, nf, repeats=4)  # call 2 is the timed one, calls 3 and 4 use its outcome
     for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), grid, auto):
         np.testing.assert_array_equal(a, b, err_msg="measured choice: " + name)
-    for f in (0, 15):
-        _check_frame(oracle, frames, f, 2000, *grid)
+    for f in ((0, B - 1) if w <= 752 else (B - 1,)):
+        _check_frame(oracle, frames, f, nf, *grid)
 
 
 @pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 96), (320, 240, 500, 100), (1920, 1080, 8000, 96)])
