@@ -829,10 +829,14 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   // With the blur beside it FAST can run as ONE resident workgroup per CU (k_fast.hip): three waves per SIMD keep 92 % of
   // its own rate and leave the other 224 of a SIMD's 512 registers -- which a grid of one workgroup per four cells fills
   // for as long as cells are left -- to the blur, which then finishes INSIDE the FAST pass instead of after it.  That pays
-  // when the blur outlasts the selection it otherwise hides behind (640x480 / 2000 features: 7.21-7.37 -> 7.03 ms per
-  // 256-frame step; four waves per SIMD 7.09-7.12, two 8.0) and costs when it does not (1920x1080 / 8000: 6.54 -> 6.80 ms
-  // per 32-frame step), so the second eligible call of a batch size runs blur and selection in line between timed events
-  // and the calls after it use what was measured.  vsf_set_fast_resident (or VSF_FAST_RESIDENT=0 / 2..4) overrides it.
+  // when the blur outlasts the selection it otherwise hides behind AND the batch is large (640x480 / 2000 features, frames
+  // per second grid -> resident: 512 frames 35.4 -> 37.5 k, 256 frames 7.21-7.37 -> 7.03 ms per step, 128 frames equal,
+  // 64 frames 31.3 -> 29.8 k, 32 frames 25.7 -> 24.3 k; four waves per SIMD at 256 frames 7.09-7.12 ms, two 8.0) and costs
+  // when it does not (1920x1080 / 8000: 6.54 -> 6.80 ms per 32-frame step, the selection being the longer one there).  So
+  // the second eligible call of a batch size runs selection and blur in line between timed events (and waits for itself:
+  // nothing of the next call may run beside them), and the calls after it take the resident form when the batch has at
+  // least 384 images and the blur took more than 1.1 x the selection.  vsf_set_fast_resident (or VSF_FAST_RESIDENT=0 /
+  // 2..4) overrides it.
   static const int resident_env = std::getenv("VSF_FAST_RESIDENT") ? std::atoi(std::getenv("VSF_FAST_RESIDENT")) : -1;
   int resident = 0;
   bool measure = false;
@@ -855,7 +859,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
         float t_select = 0.f, t_blur = 0.f;
         if (hipEventElapsedTime(&t_select, T.ev[0], T.ev[1]) == hipSuccess &&
             hipEventElapsedTime(&t_blur, T.ev[1], T.ev[2]) == hipSuccess)
-          T.choice = t_blur > t_select ? 3 : 0;
+          T.choice = (im.n >= 384 && t_blur > 1.1f * t_select) ? 3 : 0;
       }
       resident = T.choice > 0 ? T.choice : 0;
     }
@@ -901,6 +905,8 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   if (measure) {
     (void)hipEventRecord(ctx->fast_tune.ev[2], st);
     ctx->fast_tune.pending = true;
+    // the one call that blocks: nothing of the NEXT call (its pipelined pyramid) may run beside the two timed kernels
+    (void)hipStreamSynchronize(st);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);
