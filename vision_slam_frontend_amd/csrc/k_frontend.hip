@@ -34,18 +34,18 @@ __device__ __forceinline__ float dot3(int order, float a0, float b0, float a1, f
   return order ? (p0 + p1) + p2 : p0 + (p1 + p2);
 }
 
-// Frame f's residuals and their mean (thread 0 returns it and has stored it; all threads call this, one barrier inside).
-__device__ __forceinline__ float stereo_residual_body(int f, const vsf_keypoint* __restrict__ kp,
-                                                      const vsf_dmatch* __restrict__ matches,
-                                                      const int32_t* __restrict__ nmatches, int max_rows,
-                                                      const float* __restrict__ F,  // 9 floats, row major
-                                                      int order,  // vsf_params::residual_order
-                                                      float* __restrict__ residual,  // [frames][max_rows]
-                                                      float* __restrict__ mean,      // [frames], NaN if empty
-                                                      int lds_rows) {
+__global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint* __restrict__ kp,
+                                                              const vsf_dmatch* __restrict__ matches,
+                                                              const int32_t* __restrict__ nmatches, int max_rows,
+                                                              const float* __restrict__ F,  // 9 floats, row major
+                                                              int order,  // vsf_params::residual_order
+                                                              float* __restrict__ residual,  // [frames][max_rows]
+                                                              float* __restrict__ mean,      // [frames], NaN if empty
+                                                              int lds_rows) {
   // lds_rows >= max_rows: the residuals are kept in LDS for the one thread that adds them up in match order (the
   // reference's float accumulation); read back from memory, every term of that chain was a trip to the L2
   extern __shared__ __attribute__((aligned(16))) float s_res[];
+  const int f = blockIdx.x;
   const int n = min(nmatches[f], max_rows);
   const vsf_keypoint* left = kp + (size_t)(2 * f) * max_rows;
   const vsf_keypoint* right = kp + (size_t)(2 * f + 1) * max_rows;
@@ -67,7 +67,6 @@ __device__ __forceinline__ float stereo_residual_body(int f, const vsf_keypoint*
     if (in_lds) s_res[i] = r;
   }
   __syncthreads();
-  float result = 0.f;
   if (threadIdx.x == 0) {
     float avg = 0.0f;  // avg_constraint += constraint, in match order
     if (in_lds) {
@@ -86,19 +85,8 @@ __device__ __forceinline__ float stereo_residual_body(int f, const vsf_keypoint*
     }
     // 0.0f / 0 on the reference's x86 is the default ("real indefinite") NaN, sign bit set; the bits travel into the
     // threshold and the gathered records, so they are reproduced rather than left to this GPU's own default NaN
-    result = n > 0 ? avg / (float)n : __uint_as_float(0xFFC00000u);
-    mean[f] = result;
+    mean[f] = n > 0 ? avg / (float)n : __uint_as_float(0xFFC00000u);
   }
-  return result;
-}
-
-__global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint* __restrict__ kp,
-                                                              const vsf_dmatch* __restrict__ matches,
-                                                              const int32_t* __restrict__ nmatches, int max_rows,
-                                                              const float* __restrict__ F, int order,
-                                                              float* __restrict__ residual, float* __restrict__ mean,
-                                                              int lds_rows) {
-  (void)stereo_residual_body(blockIdx.x, kp, matches, nmatches, max_rows, F, order, residual, mean, lds_rows);
 }
 
 // ---- step 2: thr[0] = thr_in, thr[k] = mean[k-1] + 2 (NaN when frame k-1 had no match: frame k then keeps nothing, and
@@ -115,17 +103,20 @@ __global__ void stereo_threshold_chain_kernel(const float* __restrict__ mean, in
 }
 
 // ---- step 3: keep residual <= thr, rebuild both frames in match order ----
-__device__ __forceinline__ void stereo_filter_body(int f, float th, const vsf_keypoint* __restrict__ kp,
-                                                   const uint8_t* __restrict__ desc,
-                                                   const vsf_dmatch* __restrict__ matches,
-                                                   const int32_t* __restrict__ nmatches, int max_rows,
-                                                   const float* __restrict__ residual,
-                                                   vsf_keypoint* __restrict__ kp_out,   // [2*frames][max_rows]
-                                                   uint8_t* __restrict__ desc_out,      // [2*frames][max_rows][32]
-                                                   int32_t* __restrict__ counts_out) {  // [2*frames]
+__global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* __restrict__ kp,
+                                                            const uint8_t* __restrict__ desc,
+                                                            const vsf_dmatch* __restrict__ matches,
+                                                            const int32_t* __restrict__ nmatches, int max_rows,
+                                                            const float* __restrict__ residual,
+                                                            const float* __restrict__ thr,
+                                                            vsf_keypoint* __restrict__ kp_out,   // [2*frames][max_rows]
+                                                            uint8_t* __restrict__ desc_out,      // [2*frames][max_rows][32]
+                                                            int32_t* __restrict__ counts_out) {  // [2*frames]
   __shared__ int wsum[4];
   __shared__ int s_base;
+  const int f = blockIdx.x;
   const int n = min(nmatches[f], max_rows);
+  const float th = thr[f];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const size_t L = (size_t)(2 * f) * max_rows, R = (size_t)(2 * f + 1) * max_rows;
   if (threadIdx.x == 0) s_base = 0;
@@ -165,41 +156,6 @@ __device__ __forceinline__ void stereo_filter_body(int f, float th, const vsf_ke
     counts_out[2 * f] = s_base;
     counts_out[2 * f + 1] = s_base;
   }
-}
-
-__global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* __restrict__ kp,
-                                                            const uint8_t* __restrict__ desc,
-                                                            const vsf_dmatch* __restrict__ matches,
-                                                            const int32_t* __restrict__ nmatches, int max_rows,
-                                                            const float* __restrict__ residual,
-                                                            const float* __restrict__ thr,
-                                                            vsf_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
-                                                            int32_t* __restrict__ counts_out) {
-  stereo_filter_body(blockIdx.x, thr[blockIdx.x], kp, desc, matches, nmatches, max_rows, residual, kp_out, desc_out,
-                     counts_out);
-}
-
-// RemoveAmbigStereo of ONE frame in one launch (vsf_observe_*): residuals and their mean, the threshold handed on from
-// the previous frame (state) and the one left for the next, the filter -- three launches of 5 us otherwise.
-__global__ __launch_bounds__(256) void stereo_one_frame_kernel(const vsf_keypoint* __restrict__ kp,
-                                                               const uint8_t* __restrict__ desc,
-                                                               const vsf_dmatch* __restrict__ matches,
-                                                               const int32_t* __restrict__ nmatches, int max_rows,
-                                                               const float* __restrict__ F, int order,
-                                                               float* __restrict__ residual, float* __restrict__ mean,
-                                                               float* __restrict__ state, float* __restrict__ thr,
-                                                               vsf_keypoint* __restrict__ kp_out,
-                                                               uint8_t* __restrict__ desc_out,
-                                                               int32_t* __restrict__ counts_out, int lds_rows) {
-  __shared__ float s_th;
-  const float m = stereo_residual_body(0, kp, matches, nmatches, max_rows, F, order, residual, mean, lds_rows);
-  if (threadIdx.x == 0) {  // stereo_thresholds_kernel with n = 1
-    s_th = *state;
-    thr[0] = s_th;
-    *state = m + 2.0f;
-  }
-  __syncthreads();
-  stereo_filter_body(0, s_th, kp, desc, matches, nmatches, max_rows, residual, kp_out, desc_out, counts_out);
 }
 
 // ---- GetFeatureMatches: std::sort by distance + cut to int(n * best_percent) ----
@@ -549,16 +505,6 @@ void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_m
   const int lds_rows = max_rows <= 16000 ? (max_rows + 3) & ~3 : 0;  // (64 KB of LDS without asking for more)
   hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), (size_t)lds_rows * sizeof(float), s, d_kp,
                      d_matches, d_nmatches, max_rows, d_F, order, d_residual, d_mean, lds_rows);
-}
-
-void vsf_launch_stereo_one_frame(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
-                                 const int32_t* d_nmatches, int max_rows, const float* d_F, int order, float* d_residual,
-                                 float* d_mean, float* d_thr_state, float* d_thr, vsf_keypoint* d_kp_out,
-                                 uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s) {
-  const int lds_rows = max_rows <= 16000 ? (max_rows + 3) & ~3 : 0;
-  hipLaunchKernelGGL(stereo_one_frame_kernel, dim3(1), dim3(256), (size_t)lds_rows * sizeof(float), s, d_kp, d_desc,
-                     d_matches, d_nmatches, max_rows, d_F, order, d_residual, d_mean, d_thr_state, d_thr, d_kp_out,
-                     d_desc_out, d_counts_out, lds_rows);
 }
 
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,

@@ -81,9 +81,7 @@ __device__ inline void merge_top2(uint32_t& m1, uint32_t& m2, uint32_t b1, uint3
 // SPLIT = true : gridDim.z workgroups share a query tile, each walks one chunk of the train set and merges its top-2 into
 //                the query's packed 64-bit key pair (best << 32 | second) kept in the dist2 slot, with a CAS loop (the
 //                merge  m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2))  is associative and commutative);
-//                knn2_finalize_kernel then unpacks.  With `partial` set, each chunk writes its two keys to its own slot
-//                instead and ratio_compact_kernel merges them: the form one frame at a time uses (vsf_observe_*), where a
-//                memset and a finalize launch in front of the ratio test are 10 us of a 380-us frame.
+//                knn2_finalize_kernel then unpacks.
 // Keys leave the kernel as  distance << 20 | train index.
 constexpr int kWgQueries = 128;   // 4 waves x 32 queries
 constexpr int kKeyNone = 0x7FFFFFFF;
@@ -95,8 +93,7 @@ __global__ __launch_bounds__(256, 4) void knn2_kernel(const uint8_t* __restrict_
                                                       const int32_t* __restrict__ counts, size_t set_stride,
                                                       const int32_t* __restrict__ q_set,
                                                       const int32_t* __restrict__ t_set, int max_rows,
-                                                      int32_t* __restrict__ idx2, int32_t* __restrict__ dist2,
-                                                      uint2* __restrict__ partial) {
+                                                      int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][kTile * kTileStride];
   const int pair = blockIdx.y;
   const int qs = q_set ? q_set[pair] : 2 * pair, ts = t_set ? t_set[pair] : 2 * pair + 1;
@@ -220,10 +217,6 @@ __global__ __launch_bounds__(256, 4) void knn2_kernel(const uint8_t* __restrict_
   if (q >= nq) return;
   const uint32_t b1 = g1, b2 = g2;
   if (SPLIT) {
-    if (partial) {  // every chunk leaves its best two in a slot of its own: no initialisation, no atomics (ratio_compact merges)
-      partial[((size_t)pair * gridDim.z + blockIdx.z) * max_rows + q] = make_uint2(b1, b2);
-      return;
-    }
     if (t_begin >= t_end) return;
     unsigned long long* slot = reinterpret_cast<unsigned long long*>(dist2) + (size_t)pair * max_rows + q;
     unsigned long long seen = *slot;
@@ -266,11 +259,10 @@ __global__ __launch_bounds__(256) void knn2_finalize_kernel(const int32_t* __res
 __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __restrict__ counts,
                                                             const int32_t* __restrict__ q_set,
                                                             const int32_t* __restrict__ t_set, int max_rows,
-                                                            int32_t* __restrict__ idx2, int32_t* __restrict__ dist2,
-                                                            uint32_t ratio_num, uint32_t ratio_shift,
-                                                            vsf_dmatch* __restrict__ matches,
-                                                            int32_t* __restrict__ nmatches,
-                                                            const uint2* __restrict__ partial, int nsplit) {
+                                                            const int32_t* __restrict__ idx2,
+                                                            const int32_t* __restrict__ dist2, uint32_t ratio_num,
+                                                            uint32_t ratio_shift, vsf_dmatch* __restrict__ matches,
+                                                            int32_t* __restrict__ nmatches) {
   __shared__ int wsum[4];
   __shared__ int s_base;
   const int pair = blockIdx.x;
@@ -279,21 +271,6 @@ __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __res
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
-  if (partial) {  // the chunks' key pairs of a split knn2 launch -> idx2 / dist2, as knn2_finalize_kernel would leave them
-    for (int q = threadIdx.x; q < nq; q += 256) {
-      uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
-      for (int z = 0; z < nsplit; z++) {
-        const uint2 k = partial[((size_t)pair * nsplit + z) * max_rows + q];
-        merge_top2(b1, b2, k.x, k.y);
-      }
-      const size_t o = ((size_t)pair * max_rows + q) * 2;
-      idx2[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFFu);
-      idx2[o + 1] = b2 == 0xFFFFFFFFu ? -1 : (int32_t)(b2 & 0xFFFFFu);
-      dist2[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 20);
-      dist2[o + 1] = b2 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b2 >> 20);
-    }
-    __syncthreads();  // (a thread reads back what it wrote itself; the barrier is for the shared counters below)
-  }
   if (nt >= 2) {  // quirk Q6: with fewer than 2 train rows the reference reads matches[i][1] out of bounds
     for (int q0 = 0; q0 < nq; q0 += 256) {
       const int q = q0 + threadIdx.x;
@@ -330,32 +307,6 @@ __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __res
 
 }  // namespace
 
-static int knn2_splits(int n_pairs, int max_rows) {
-  const int qtiles = (max_rows + kWgQueries - 1) / kWgQueries;
-  int nsplit = 1;
-  if ((long)qtiles * n_pairs < 2 * 768) nsplit = (int)std::min<long>(32, 2 * 1024 / ((long)qtiles * n_pairs));
-  return std::max(1, std::min(nsplit, max_rows / (2 * kSplitAlign)));
-}
-
-size_t vsf_knn2_partial_entries(int n_pairs, int max_rows) {
-  const int ns = knn2_splits(n_pairs, max_rows);
-  return ns > 1 ? (size_t)n_pairs * ns * max_rows : 0;
-}
-
-int vsf_launch_knn2_partial(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
-                            const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                            void* d_partial, hipStream_t s) {
-  const int qtiles = (max_rows + kWgQueries - 1) / kWgQueries;
-  const int nsplit = knn2_splits(n_pairs, max_rows);
-  if (nsplit <= 1 || !d_partial) {
-    vsf_launch_knn2(d_desc, d_counts, set_stride, d_q_set, d_t_set, n_pairs, max_rows, d_idx2, d_dist2, s);
-    return 0;
-  }
-  hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                     d_q_set, d_t_set, max_rows, d_idx2, d_dist2, reinterpret_cast<uint2*>(d_partial));
-  return nsplit;
-}
-
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
                      hipStream_t s) {
@@ -363,25 +314,26 @@ void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_
   // A batch of 128 stereo pairs brings ~2000 workgroups, two full rounds of the chip at four workgroups per CU, and runs
   // unsplit; with fewer (one pair of one frame at a time) the train sets are split until about that many workgroups exist
   // (each at least eight 32-row tiles) and merged through the packed key pairs.
-  const int nsplit = knn2_splits(n_pairs, max_rows);
+  int nsplit = 1;
+  if ((long)qtiles * n_pairs < 2 * 768) nsplit = (int)std::min<long>(32, 2 * 1024 / ((long)qtiles * n_pairs));
+  nsplit = std::max(1, std::min(nsplit, max_rows / (2 * kSplitAlign)));
   if (nsplit <= 1) {
     hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2, (uint2*)nullptr);
+                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
     return;
   }
   (void)hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s);
   hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                     d_q_set, d_t_set, max_rows, d_idx2, d_dist2, (uint2*)nullptr);
+                     d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
   hipLaunchKernelGGL(knn2_finalize_kernel, dim3((max_rows + 255) / 256, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set,
                      max_rows, d_idx2, d_dist2);
 }
 
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
-                              int max_rows, int32_t* d_idx2, int32_t* d_dist2, uint32_t ratio_num,
+                              int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
-                              hipStream_t s, const void* d_partial, int nsplit) {
+                              hipStream_t s) {
   (void)d_status;
   hipLaunchKernelGGL(ratio_compact_kernel, dim3(n_pairs), dim3(256), 0, s, d_counts, d_q_set, d_t_set, max_rows,
-                     d_idx2, d_dist2, ratio_num, ratio_shift, d_matches, d_nmatches,
-                     nsplit > 1 ? reinterpret_cast<const uint2*>(d_partial) : nullptr, nsplit);
+                     d_idx2, d_dist2, ratio_num, ratio_shift, d_matches, d_nmatches);
 }

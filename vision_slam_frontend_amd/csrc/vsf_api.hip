@@ -502,8 +502,6 @@ struct vsf_ctx {
     ObserveMeta* h_meta[3] = {nullptr, nullptr, nullptr};
     int32_t* h_status[3] = {nullptr, nullptr, nullptr};    // pinned copy of the status word after the frame's last kernel
     hipStream_t ex_stream[3] = {nullptr, nullptr, nullptr};  // the stream of slot i (a one-slot context: ctx->stream)
-    uint8_t* partial = nullptr;      // split-matcher key pairs: a region per slot (stereo match) + one for the tails
-    size_t partial_region = 0;       // bytes per region
     hipEvent_t ev_done[3] = {nullptr, nullptr, nullptr};
     VsfSideStream side[3] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
     bool done_valid[3] = {false, false, false};
@@ -669,7 +667,6 @@ void free_observe(vsf_ctx* ctx) {
   hipFree(o.features);
   hipFree(o.pairs);
   hipFree(o.npairs);
-  hipFree(o.partial);
   for (int i = 0; i < 3; i++) {
     if (o.h_img[i]) hipHostFree(o.h_img[i]);
     if (o.h_out[i]) hipHostFree(o.h_out[i]);
@@ -1689,12 +1686,6 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   vsf_status st = ensure_match_buffers(ctx, frame_life + 1 + 3, (int)K);
   if (st == VSF_OK) st = ensure_temporal_buffers(ctx, frame_life + 1);
   if (st == VSF_OK) st = ensure_residual_buffers(ctx, 1);
-  if (st == VSF_OK) {  // the split matcher's key pairs: the largest launch of 1 .. frame_life + 1 pairs, four regions
-    size_t most = 0;
-    for (int p = 1; p <= frame_life + 1; p++) most = std::max(most, vsf_knn2_partial_entries(p, (int)K));
-    o.partial_region = (most * 8 + 255) & ~(size_t)255;
-    if (o.partial_region > 0) VSF_HIP(hipMalloc((void**)&o.partial, 4 * o.partial_region));
-  }
   return st;
 }
 
@@ -1767,21 +1758,9 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   int32_t* nmatches = o.ints + slot;
   vsf_dmatch* raw_matches = o.matches + (size_t)slot * K;
   {
-    // (the matcher splits a single pair's train set over workgroups; each leaves its key pair in the slot's region of
-    // o.partial and the ratio test merges them: no memset in front, no finalize launch behind)
     const size_t scratch = (size_t)(frame_life + 1 + slot) * K * 2;
-    void* part = o.partial ? o.partial + (size_t)slot * o.partial_region : nullptr;
-    int ns;
-    {
-      StageTimer t(ctx, ex, VSF_STAGE_KNN2, 1);
-      ns = vsf_launch_knn2_partial(desc_raw, counts_raw, K * VSF_DESC_BYTES, nullptr, nullptr, 1, Kc, ctx->m_idx2 + scratch,
-                                   ctx->m_dist2 + scratch, part, ex);
-    }
-    {
-      StageTimer t(ctx, ex, VSF_STAGE_RATIO, 1);
-      vsf_launch_ratio_compact(counts_raw, nullptr, nullptr, 1, Kc, ctx->m_idx2 + scratch, ctx->m_dist2 + scratch,
-                               ctx->p.ratio_num, ctx->p.ratio_shift, raw_matches, nmatches, ctx->d_status, ex, part, ns);
-    }
+    match_on(ctx, ex, desc_raw, counts_raw, K * VSF_DESC_BYTES, nullptr, nullptr, 0, 1, ctx->m_idx2 + scratch,
+             ctx->m_dist2 + scratch, raw_matches, nmatches);
   }
   // the tails run in frame order: this frame's waits for the previous frame's (on another slot's stream)
   if (o.slots > 1 && o.next_ticket > 0) {
@@ -1793,26 +1772,22 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   uint8_t* cur_desc = o.ring + (size_t)S * K * VSF_DESC_BYTES;
   int32_t* cur_counts = o.ring_counts + S;
   {
-    StageTimer t(ctx, s, VSF_STAGE_TAIL, 1);
-    // (residuals, threshold hand-over and filter of the one frame in one launch; with the matcher's split form below --
-    // no memset, no finalize launch -- six launches fewer per frame: nothing for the synchronous call, whose time is not
-    // the GPU's chain alone, 6 200 -> 6 350 frames/s with three frames in flight)
-    vsf_launch_stereo_one_frame(kp_raw, desc_raw, raw_matches, nmatches, Kc, M.F, ctx->p.residual_order, ctx->f_residual,
-                                means, thr_state, thr, o.kpf, cur_desc, cur_counts, s);
+    StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
+    vsf_launch_stereo_residuals(kp_raw, raw_matches, nmatches, 1, Kc, M.F, ctx->p.residual_order, ctx->f_residual, means, s);
+    vsf_launch_stereo_thresholds(means, 1, thr_state, thr, s);
+    vsf_launch_stereo_filter_only(kp_raw, desc_raw, raw_matches, nmatches, 1, Kc, ctx->f_residual, thr, o.kpf, cur_desc,
+                                  cur_counts, s);
   }
   // ---- GetFeatureMatches against every kept frame + the right->left matches of Calculate3DPoints: one matcher
   // launch, one sort launch (per-pair best_percent) ----
-  void* tail_part = o.partial ? o.partial + 3 * o.partial_region : nullptr;  // (the tails run one after the other)
-  int tail_ns;
   {
     StageTimer t(ctx, s, VSF_STAGE_KNN2, 1);
-    tail_ns = vsf_launch_knn2_partial(o.ring, o.ring_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2,
-                                      ctx->m_dist2, tail_part, s);
+    vsf_launch_knn2(o.ring, o.ring_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, s);
   }
   {
     StageTimer t(ctx, s, VSF_STAGE_RATIO, 1);
     vsf_launch_ratio_compact(o.ring_counts, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
-                             ctx->p.ratio_shift, ctx->t_matches, ctx->t_nmatches, ctx->d_status, s, tail_part, tail_ns);
+                             ctx->p.ratio_shift, ctx->t_matches, ctx->t_nmatches, ctx->d_status, s);
   }
   {
     StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);

@@ -135,23 +135,12 @@ void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int m
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
                      hipStream_t s);
-// (the split form that leaves every chunk's key pair in `d_partial` [pair][split][max_rows] x 8 bytes, at least
-// vsf_knn2_partial_entries() of them, for vsf_launch_ratio_compact to merge; returns the number of splits, 0 when the
-// launch was not split and idx2 / dist2 are final)
-size_t vsf_knn2_partial_entries(int n_pairs, int max_rows);
-int vsf_launch_knn2_partial(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
-                            const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                            void* d_partial, hipStream_t s);
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
-                              int max_rows, int32_t* d_idx2, int32_t* d_dist2, uint32_t ratio_num,
+                              int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
-                              hipStream_t s, const void* d_partial = nullptr, int nsplit = 0);
+                              hipStream_t s);
 
 // k_frontend.hip
-void vsf_launch_stereo_one_frame(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
-                                 const int32_t* d_nmatches, int max_rows, const float* d_F, int order, float* d_residual,
-                                 float* d_mean, float* d_thr_state, float* d_thr, vsf_keypoint* d_kp_out,
-                                 uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s);
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
                               const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, int order,
                               const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
