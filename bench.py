@@ -450,6 +450,18 @@ def main() -> int:
                        "ms_per_step": knn_ms / args.steps,
                        "note": "the stereo L->R launch of each step (B pairs of ~N x N)" if tail_stages is not None else
                                "all knn2 launches of a step (stereo + R'->L' + temporal) over the stereo pair count"}
+        step_s = elapsed / args.steps
+        step_rooflines = {"hbm_algorithmic": {"achieved": sum(alg.values()) / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": sum(alg.values()) / step_s / 1e9 / HBM_PEAK_GBS}}
+        if pmc:
+            tr = sum(float(v.get("hbm_bytes_per_step", 0)) for v in pmc.values())
+            vi = sum(float(v.get("valu_wave_insts_per_step", 0)) for v in pmc.values())
+            step_rooflines["hbm_counted"] = {"achieved": tr / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": tr / step_s / 1e9 / HBM_PEAK_GBS}
+            step_rooflines["valu"] = {"achieved": vi / step_s / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
+                                      "frac": vi / step_s / 1e9 / VALU_PEAK_GINST,
+                                      "note": "what the step is closest to: FAST by itself issues at 92 % of this peak, "
+                                              "the other stages wait on latency with the vector ALU half idle (DESIGN 6)"}
         device_ms = sum(v[0] for k, v in stages.items() if k not in concurrent)
         out = {
             "metric": ("stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
@@ -505,6 +517,9 @@ def main() -> int:
             "rccl": dict(handshake, per_rank_ms_per_step={"min": min(rank_ms), "max": max(rank_ms)},
                          max_rank_blocked_in_gather_ms=blocked_ms, capacity_overflow_ranks=overflow_ranks),
             "roofline_valu": valu,
+            # the whole step against the two rooflines: every stage's algorithmic bytes (and counted HBM bytes, and wave64
+            # VALU instructions from the committed counter passes) over the step time of this run
+            "step_rooflines": step_rooflines,
             "matcher": matcher,
             # every streaming stage against the same roofline (algorithmic bytes / measured stage time)
             "streaming_stages_gbs": {k: alg[k] / ((inline_stages[k] if inline_stages else stages[k][0] / args.steps) * 1e-3) / 1e9
