@@ -127,6 +127,44 @@ def test_resident_fast_equals_grid_fast(capi, oracle, w, h, nf, B):
         _check_frame(oracle, frames, f, nf, *grid)
 
 
+def test_fast_resident_switch(capi):
+    """vsf_set_fast_resident / vsf_get_fast_resident: argument checking, and the measured choice of a batch that is large
+    enough to qualify (>= 384 images): open until the second call has been timed, then 0 or 3 -- with the same outputs as
+    the grid form either way."""
+    from vision_slam_frontend_amd import synth
+    B, w, h, nf = 192, 320, 240, 500
+    frames = synth.bench_batch(B, w, h, seed=synth.BASE_SEED + 41, n_scenes=4)
+    dev = torch.device("cuda", 0)
+    p = capi.default_params(w, h, max_images=2 * B, nfeatures=nf)
+    outs = []
+    with capi.Context(p) as ctx:
+        for bad in (1, 5, -2):
+            with pytest.raises(capi.VsfError):
+                ctx.set_fast_resident(bad)
+        assert ctx.get_fast_resident() == -1
+        K = ctx.params.max_keypoints
+        d_img = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+        bufs = _dev_outputs(2 * B, K, dev) + (torch.zeros((B, K, 16), dtype=torch.uint8, device=dev),
+                                              torch.zeros(B, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize()
+        for call in range(4):
+            ctx.stereo_batch_dev(d_img.data_ptr(), B, w * h, w, *[t.data_ptr() for t in bufs])
+            assert ctx.sync() == capi.VSF_OK
+            if call == 0:
+                assert ctx.get_fast_resident() == -1  # (the first call is never the timed one)
+            outs.append([t.cpu().numpy().copy() for t in bufs])
+        assert ctx.get_fast_resident() in (0, 3)
+        ctx.set_fast_resident(0)
+        assert ctx.get_fast_resident() == 0
+        ctx.stereo_batch_dev(d_img.data_ptr(), B, w * h, w, *[t.data_ptr() for t in bufs])
+        assert ctx.sync() == capi.VSF_OK
+        ref = [t.cpu().numpy().copy() for t in bufs]
+    for call, o in enumerate(outs):
+        for name, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), ref, o):
+            np.testing.assert_array_equal(a, b, err_msg="call %d: %s" % (call, name))
+    assert int(ref[2].min()) > 100
+
+
 @pytest.mark.parametrize("w,h,nf,B", [(640, 480, 2000, 96), (320, 240, 500, 100), (1920, 1080, 8000, 96)])
 def test_large_batch_equals_small_batches(capi, oracle, w, h, nf, B):
     """A batch that fills the CUs (>= 192 images on an MI355X) builds the one-band levels of its pyramids with the
