@@ -121,10 +121,9 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
 vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on);
 /* With the blur beside it, FAST can run as one RESIDENT workgroup per CU (`waves` = 2..4 waves per SIMD, fed with cells
  * through a counter) instead of a grid that fills every register of the chip for as long as cells are left, so that the
- * blur's workgroups find room beside it.  -1 (default): the library times the selection and the blur of the second
- * eligible call of each batch size in line (that one call waits for its own completion) and takes the resident form
- * (3 waves) when the batch has at least 384 images and the blur outlasts the selection it would otherwise hide behind;
- * 0: never; 2..4: always.  Speed only: results do not depend on it. */
+ * blur's workgroups find room beside it.  -1 (default): of each batch size's eligible calls the library times the second in
+ * the grid form and the third in the resident form (3 waves; these two calls wait for their own completion) and keeps
+ * the faster; 0: never; 2..4: always.  Speed only: results do not depend on it. */
 vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves);
 /* What the batched calls currently do: *waves = 0 (grid form), 2..4 (resident, waves per SIMD), or -1 while the measured
  * choice for the last batch size is still open. */

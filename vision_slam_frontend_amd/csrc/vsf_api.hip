@@ -443,8 +443,7 @@ struct vsf_ctx {
   uint32_t* fast_cells = nullptr;  // [2] cell counters of the resident FAST kernels (k_fast.hip)
   struct FastTune {  // resident FAST or one workgroup per four cells: measured once per batch size (extract_on)
     int n = 0, choice = -1, calls = 0;
-    bool pending = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // grid form: [0] .. [1], resident form: [2] .. [3]
   } fast_tune;
   int32_t* h_status = nullptr;  // pinned
   // staging for the host-pointer entry points
@@ -828,18 +827,18 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   const bool beside_ok = overlap_env && ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
   // With the blur beside it FAST can run as ONE resident workgroup per CU (k_fast.hip): three waves per SIMD keep 92 % of
   // its own rate and leave the other 224 of a SIMD's 512 registers -- which a grid of one workgroup per four cells fills
-  // for as long as cells are left -- to the blur, which then finishes INSIDE the FAST pass instead of after it.  That pays
-  // when the blur outlasts the selection it otherwise hides behind AND the batch is large (640x480 / 2000 features, frames
-  // per second grid -> resident: 512 frames 35.4 -> 37.5 k, 256 frames 7.21-7.37 -> 7.03 ms per step, 128 frames equal,
-  // 64 frames 31.3 -> 29.8 k, 32 frames 25.7 -> 24.3 k; four waves per SIMD at 256 frames 7.09-7.12 ms, two 8.0) and costs
-  // when it does not (1920x1080 / 8000: 6.54 -> 6.80 ms per 32-frame step, the selection being the longer one there).  So
-  // the second eligible call of a batch size runs selection and blur in line between timed events (and waits for itself:
-  // nothing of the next call may run beside them), and the calls after it take the resident form when the batch has at
-  // least 384 images and the blur took more than 1.1 x the selection.  vsf_set_fast_resident (or VSF_FAST_RESIDENT=0 /
-  // 2..4) overrides it.
+  // for as long as cells are left -- to the blur, which then finishes INSIDE the FAST pass instead of after it.  Whether
+  // that pays depends on the batch and on how well the blur hides behind the selection anyway (frames per second, grid ->
+  // resident; 640x480 / 2000 features: 512 frames per step 35.4 -> 37.5 k, 256 frames 35.0 -> 36.4 k, 128 frames equal,
+  // 64 frames 31.3 -> 29.8 k, 32 frames 25.7 -> 24.3 k; 1920x1080 / 8000: 32 frames 4 900 -> 4 700, 96 frames
+  // 5 000 -> 5 140, 192 frames 5 030 -> 5 320; four waves per SIMD at 256 VGA frames 7.09-7.12 ms against 7.03, two 8.0).
+  // So the library measures: of a batch size's eligible calls the second runs the grid form and the third the resident
+  // form between two timed events (FAST ... descriptors), each waiting for itself so that nothing of the next call runs
+  // beside it, and the calls after them take the faster one.  vsf_set_fast_resident (or VSF_FAST_RESIDENT=0 / 2..4)
+  // overrides it.
   static const int resident_env = std::getenv("VSF_FAST_RESIDENT") ? std::atoi(std::getenv("VSF_FAST_RESIDENT")) : -1;
   int resident = 0;
-  bool measure = false;
+  int measure = -1;  // this call is timed as form 0 (grid) / 1 (resident)
   if (beside_ok && ctx->lanes == 1 && st == ctx->stream && i0 == 0 && !own_side) {
     vsf_ctx::FastTune& T = ctx->fast_tune;
     if (ctx->fast_resident >= 0 || resident_env >= 0) {
@@ -848,23 +847,28 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
       if (T.n != im.n) {
         T.n = im.n;
         T.choice = -1;
-        T.pending = false;
         T.calls = 0;
       }
-      if (T.choice < 0 && !T.pending && T.calls++ > 0) {  // (not the first call: its kernels start cold)
-        measure = true;
-        for (hipEvent_t& e : T.ev)
-          if (!e && hipEventCreate(&e) != hipSuccess) measure = false;
-      } else if (T.choice < 0 && T.pending && hipEventQuery(T.ev[2]) == hipSuccess) {
-        float t_select = 0.f, t_blur = 0.f;
-        if (hipEventElapsedTime(&t_select, T.ev[0], T.ev[1]) == hipSuccess &&
-            hipEventElapsedTime(&t_blur, T.ev[1], T.ev[2]) == hipSuccess)
-          T.choice = (im.n >= 384 && t_blur > 1.1f * t_select) ? 3 : 0;
+      if (T.choice < 0) {
+        const int call = T.calls++;
+        if (call == 1 || call == 2) {  // (not the first call: its kernels start cold)
+          measure = call - 1;
+          for (hipEvent_t& e : T.ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) measure = -1;
+          if (measure < 0) T.choice = 0;
+        } else if (call > 2) {
+          float t_grid = 0.f, t_res = 0.f;
+          if (hipEventElapsedTime(&t_grid, T.ev[0], T.ev[1]) == hipSuccess &&
+              hipEventElapsedTime(&t_res, T.ev[2], T.ev[3]) == hipSuccess)
+            T.choice = t_res < t_grid ? 3 : 0;
+          else
+            T.choice = 0;
+        }
       }
-      resident = T.choice > 0 ? T.choice : 0;
+      resident = measure >= 0 ? 3 * measure : (T.choice > 0 ? T.choice : 0);
     }
   }
-  const bool blur_beside = beside_ok && !measure;
+  const bool blur_beside = beside_ok;
   auto launch_blur = [&](hipStream_t bs) {
     StageTimer t(ctx, bs, VSF_STAGE_BLUR, 1);
     // VSF_BLUR=march: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
@@ -884,6 +888,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     (void)hipEventRecord(ctx->ev_blur_done, ctx->blur_stream);
   };
   if (blur_beside) fork_blur();
+  if (measure >= 0) (void)hipEventRecord(ctx->fast_tune.ev[2 * measure], st);
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
     vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
@@ -892,26 +897,23 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     (void)hipEventRecord(ctx->ev_fast_done, st);
     ctx->fast_done_valid = true;
   }
-  if (measure) (void)hipEventRecord(ctx->fast_tune.ev[0], st);
   {
     StageTimer t(ctx, st, VSF_STAGE_SELECT, 1);
     vsf_launch_select(d, g, ctx->orb.levels.data(), im, st);
   }
-  if (measure) (void)hipEventRecord(ctx->fast_tune.ev[1], st);
   if (blur_beside)
     (void)hipStreamWaitEvent(st, ctx->ev_blur_done, 0);
   else
     launch_blur(st);
-  if (measure) {
-    (void)hipEventRecord(ctx->fast_tune.ev[2], st);
-    ctx->fast_tune.pending = true;
-    // the one call that blocks: nothing of the NEXT call (its pipelined pyramid) may run beside the two timed kernels
-    (void)hipStreamSynchronize(st);
-  }
   {
     StageTimer t(ctx, st, VSF_STAGE_DESCRIBE, 1);
     vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp + i0 * K, d_desc + i0 * K * VSF_DESC_BYTES, d_counts + i0,
                         st);
+  }
+  if (measure >= 0) {
+    (void)hipEventRecord(ctx->fast_tune.ev[2 * measure + 1], st);
+    // the two calls that block: nothing of the NEXT call (its pipelined pyramid) may run beside the timed kernels
+    (void)hipStreamSynchronize(st);
   }
   if (pipe) {  // every reader of this pyramid buffer is queued: the call after the next may overwrite it
     const int buf = ctx->pyr_flip;
