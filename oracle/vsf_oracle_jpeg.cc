@@ -29,18 +29,21 @@ struct Huff {  // T.81 Annex C / F.2.2.3: code lengths -> MINCODE / MAXCODE / VA
   uint8_t bits[17] = {0};
   uint8_t vals[256] = {0};
   int32_t mincode[17], maxcode[18], valptr[17];
-  void derive() {
+  bool derive() {  // false: the counts oversubscribe the code space (libjpeg jdhuff.c: JERR_BAD_HUFF_TABLE)
     int32_t code = 0;
     int k = 0;
+    bool ok = true;
     for (int l = 1; l <= 16; l++) {
       valptr[l] = k;
       mincode[l] = code;
       code += bits[l];
       k += bits[l];
       maxcode[l] = bits[l] ? code - 1 : -1;
+      if (bits[l] && code >= (1 << l)) ok = false;
       code <<= 1;
     }
     maxcode[17] = 0x7FFFFFFF;
+    return ok;
   }
 };
 
@@ -223,7 +226,7 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
         std::memcpy(h.vals, s + i, total);
         i += total;
         h.present = true;
-        h.derive();
+        if (!h.derive()) return -1;
       }
     } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: sequential DCT, Huffman
       if (n < 6 || s[0] != 8) return -2;

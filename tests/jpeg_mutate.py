@@ -1,11 +1,59 @@
 """Seeded mutators for JPEG robustness tests (the five of round 2's one-off fuzz script): bit flips, truncation and stray
-markers in the entropy-coded data, damage to the headers, garbage behind the headers."""
+markers in the entropy-coded data, damage to the headers, garbage behind the headers -- and, since round 4, a sixth that
+rewrites the code-length counts of a DHT segment while keeping every segment length CONSISTENT (plain header damage leaves
+the lengths inconsistent, so the parser refuses the file before it ever builds a table from it)."""
 import numpy as np
+
+
+def segments(data: bytes):
+    """(marker, offset of the marker's 0xFF, total length incl. the two marker bytes) for the header segments up to SOS."""
+    out, pos = [], 2
+    while pos + 4 <= len(data) and data[pos] == 0xFF:
+        m = data[pos + 1]
+        ln = (data[pos + 2] << 8) | data[pos + 3]
+        out.append((m, pos, ln + 2))
+        if m == 0xDA:
+            break
+        pos += ln + 2
+    return out
+
+
+def rewrite_dht(data: bytes, rng: np.random.Generator, counts=None, which=None) -> bytes:
+    """Replaces the counts (and as many values as they call for) of one table of one DHT segment; the segment's length
+    field is recomputed, so the file stays well-formed up to the meaning of the counts themselves."""
+    dht = [(pos, ln) for m, pos, ln in segments(data) if m == 0xC4]
+    if not dht:
+        return data
+    pos, ln = dht[int(rng.integers(len(dht))) if which is None else which]
+    body = bytearray(data[pos + 4:pos + ln])
+    tables, i = [], 0
+    while i + 17 <= len(body):
+        total = sum(body[i + 1:i + 17])
+        tables.append((i, 17 + total))
+        i += 17 + total
+    if not tables:
+        return data
+    t0, tl = tables[int(rng.integers(len(tables)))]
+    if counts is None:
+        counts = [0] * 16
+        budget = int(rng.integers(1, 257))
+        while budget > 0:  # a few lengths get large counts: most draws oversubscribe the code space
+            l = int(rng.integers(16))
+            c = min(budget, int(rng.integers(1, 256)), 255 - counts[l])
+            counts[l] += c
+            budget -= max(c, 1)
+    total = sum(counts)
+    new_table = bytes([body[t0]]) + bytes(counts) + bytes(rng.integers(0, 256, total, dtype=np.uint8))
+    body[t0:t0 + tl] = new_table
+    seg = b"\xFF\xC4" + (len(body) + 2).to_bytes(2, "big") + bytes(body)
+    return data[:pos] + seg + data[pos + ln:]
 
 
 def mutate(data: bytes, rng: np.random.Generator, kind: int | None = None) -> bytes:
     f = bytearray(data)
-    kind = int(rng.integers(5)) if kind is None else kind
+    kind = int(rng.integers(6)) if kind is None else kind
+    if kind == 5:      # DHT counts rewritten, lengths kept consistent
+        return rewrite_dht(data, rng)
     sos = f.find(b"\xFF\xDA")
     body = max(sos, 0) + 12
     if len(f) <= body + 4:  # nothing behind the scan header: fall back to header damage

@@ -1,8 +1,9 @@
 """SURVEY section 5 (sanitizers) for the one place where the product parses UNTRUSTED bytes on the host: the JPEG marker /
 table parser and upload planner (csrc/vsf_jpeg_host.cc; reference counterpart: cv::imdecode at slam_frontend_main.cc:98-100).
 `make -C vision_slam_frontend_amd/csrc asan` builds that translation unit alone with -fsanitize=address,undefined (plain
-g++, no GPU code); a child process preloads the sanitizer runtime, runs the 16 fixture files and 2000 seeded mutations of
-them (bit flips, truncation, stray markers, header damage, garbage) through vsf_jpeg_plan + vsf_jpeg_fill, and must exit
+g++, no GPU code); a child process preloads the sanitizer runtime, runs the 16 fixture files, hand-made files whose DHT
+counts oversubscribe the code space and 2000 seeded mutations (bit flips, truncation, stray markers, header damage, garbage,
+DHT counts rewritten with consistent lengths) through vsf_jpeg_plan + vsf_jpeg_fill, and must exit
 cleanly: any out-of-bounds access, overflow or misaligned access aborts it with a report.  No GPU involved."""
 import os
 import subprocess
@@ -22,7 +23,8 @@ import ctypes as C, sys
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, sys.argv[3])
-from jpeg_mutate import mutate
+from jpeg_mutate import mutate, rewrite_dht
+import jpeg_craft
 lib = C.CDLL(sys.argv[1])
 lib.vsf_jpeg_host_check.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
@@ -49,6 +51,23 @@ for name, data in files.items():
         assert st == 0 and total > len(data) // 2, (name, st, total)
     st, _ = check([data], w + 1, h)
     assert st == 1, ("wrong size must be refused", name, st)
+# regression (round-3 review): a DHT whose counts oversubscribe the code space -- 200 codes of length 1 -- with CONSISTENT
+# segment lengths used to index ~100 KB past the lookup tables in build_dev_huff; it must be refused (as libjpeg does:
+# JERR_BAD_HUFF_TABLE), for the DC and for the AC table, for every length the first-level table covers and beyond
+rng = np.random.Generator(np.random.PCG64(7))
+small = jpeg_craft.write_gray_jpeg(jpeg_craft.random_coefficients(rng, 1, 1), [16] * 64,
+                                   (jpeg_craft.STD_DC_BITS, jpeg_craft.STD_DC_VALS), jpeg_craft.flat_ac_table())
+assert check([small], 8, 8)[0] == 0
+for which in (0, 1):
+    for length in range(1, 17):
+        for count in (200, 255, (1 << min(length, 7)) + 1):
+            counts = [0] * 16
+            counts[length - 1] = count
+            st, _ = check([rewrite_dht(small, rng, counts, which)], 8, 8)
+            assert st == (1 if count >= (1 << length) else 0), (which, length, count, st)
+full = [0] * 16
+full[7] = 255                       # 255 codes of length 8 leave the all-ones code free: a legal table
+assert check([rewrite_dht(small, rng, full, 0)], 8, 8)[0] == 0
 rng = np.random.Generator(np.random.PCG64(20261004))
 names = [n for n in files if not n.startswith("progressive")]
 for it in range(2000):

@@ -40,8 +40,22 @@ struct HostTableSet {  // what one file's scan uses, as read from its DQT / DHT 
   }
 };
 
-void build_dev_huff(const HostHuff& h, DevHuff* d) {
+// BITS[1..16] must describe a prefix code (T.81 Annex C): after the codes of length l the next free code must still fit in
+// l bits -- libjpeg's jdhuff.c test (`code >= 1 << si` => JERR_BAD_HUFF_TABLE; the all-ones code stays unused), so a file
+// cv::imdecode refuses is refused here as well.  Without it an oversubscribed table indexes far past the lookup tables.
+bool huff_counts_ok(const uint8_t bits[17]) {
+  int32_t code = 0;
+  for (int l = 1; l <= 16; l++) {
+    code += bits[l];
+    if (bits[l] && code >= (1 << l)) return false;
+    code <<= 1;
+  }
+  return true;
+}
+
+bool build_dev_huff(const HostHuff& h, DevHuff* d) {
   std::memset(d, 0, sizeof(*d));
+  if (!huff_counts_ok(h.bits)) return false;  // (parse_jpeg has refused such a table already: second line of defence)
   for (auto& e : d->look) e = kNoCode;
   for (auto& t : d->sub)
     for (auto& e : t) e = kNoCode;
@@ -72,6 +86,7 @@ void build_dev_huff(const HostHuff& h, DevHuff* d) {
   d->maxcode[17] = 0x7FFFFFFF;
   d->valoff[0] = 0;
   std::memcpy(d->vals, h.vals, 256);
+  return true;
 }
 
 }  // namespace
@@ -118,7 +133,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         int total = 0;
         for (int l = 1; l <= 16; l++) total += (h.bits[l] = s[i + l]);
         i += 17;
-        if (total > 256 || i + total > n) return VSF_ERR_INVALID_ARG;
+        if (total > 256 || i + total > n || !huff_counts_ok(h.bits)) return VSF_ERR_INVALID_ARG;
         std::memset(h.vals, 0, sizeof(h.vals));
         std::memcpy(h.vals, s + i, (size_t)total);
         i += total;
@@ -229,7 +244,7 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
         HostHuff h;
         std::memcpy(h.bits, t.bits[k], 17);
         std::memcpy(h.vals, t.vals[k], 256);
-        build_dev_huff(h, &d.huff[k]);
+        if (!build_dev_huff(h, &d.huff[k])) return VSF_ERR_INVALID_ARG;
         if (d.huff[k].nsub > (uint32_t)kMaxSub) ok = 0;
       }
       std::memcpy(d.qt_luma, t.qt_luma, sizeof(d.qt_luma));
