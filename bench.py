@@ -337,13 +337,10 @@ def main() -> int:
             sf.step(ingest.next_batch())   # waits (on the GPU) for this step's decode, starts the next step's
             ingest.release()               # the buffer may be overwritten once this step's extraction has read it
 
-    # Set-up, not warm-up: the library decides between its two FAST forms by timing its 2nd and 3rd batched call of a batch
-    # size (vsf_set_fast_resident); those calls wait for themselves and must not fall into the timed steps when the driver
-    # asks for little warm-up.  Steps here run until the choice is made (4 at most), then the W warm-up steps follow.
-    setup_steps = 0
-    while setup_steps < 4 and ctx.get_fast_resident() < 0 and 2 * B >= 32 and not args.blur_inline:
-        run_step()
-        setup_steps += 1
+    # Set-up, not warm-up: ONE explicit, blocking measurement of the two FAST launch forms on this rank's batch
+    # (vsf_tune_fast_resident: median of three runs each), made common over the ranks by one all-reduce -- every rank issues
+    # the same collective whatever it measured, and no library call inside the timed steps measures or waits for anything.
+    tune = sf.tune(d_imgs[0]) if (ingest is None and not args.blur_inline) else None
     for _ in range(args.warmup):
         run_step()
     sf.drain()
@@ -497,10 +494,11 @@ def main() -> int:
                        "input_rotation": "3 distinct %d-frame batches in turn (%.0f MB of input; the Infinity Cache holds 256 MB)"
                                          % (B, 3 * B * 2 * W * H / 1e6)
                                          if args.ingest == "hbm" else "per-step decode",
-                       "fast_resident": ("measured choice: %s" % ("one resident workgroup per CU, %d waves per SIMD (the blur "
+                       "fast_resident": ("%s: %s" % ("measured before the run (vsf_tune_fast_resident), same on every rank" if tune
+                                         else "default", "one resident workgroup per CU, %d waves per SIMD (the blur "
                                          "finishes inside the FAST pass)" % fast_waves if fast_waves > 0 else
-                                         "one workgroup per four cells" if fast_waves == 0 else "open")) if blur_beside else "off",
-                       "setup_steps": setup_steps,
+                                         "one workgroup per four cells")) if blur_beside else "off",
+                       "fast_tune": tune,
                        "pipeline": "step s + 1's pyramid beside step s's selection / descriptors / matcher (vsf_set_pipeline)"
                                    if pipeline else "off",
                        "tail_overlap": "step s's tail + collectives on a second stream beside step s+1's extraction"

@@ -12,8 +12,11 @@
  * Plain pointers and sizes only; every function returns a vsf_status (never aborts, never throws;
  * the reference's glog CHECK / cv::Exception / exit(1) paths become status codes).  A context owns one
  * GPU's device memory and stream and is used by one host thread at a time.  Host-pointer entry points
- * are synchronous; *_dev entry points take device pointers, are asynchronous on the context's stream and
- * are what the batched / multi-GPU path uses.
+ * are synchronous; *_dev entry points take device pointers, are asynchronous on the context's stream (none of them waits
+ * for the GPU: the one measuring call, vsf_tune_fast_resident, is explicit and says so) and are what the batched /
+ * multi-GPU path uses.  A HIP failure inside an asynchronous call (a launch, an event record or wait) is returned by that
+ * call as VSF_ERR_HIP -- or, if it could only be noticed later, by the next call on the context that checks (every
+ * entry point that launches, and vsf_sync).
  *
  * Output record layouts are the reference's: vsf_keypoint == cv::KeyPoint (28 B), vsf_dmatch ==
  * cv::DMatch (16 B), descriptors are row-major N x 32 uint8 (cv::Mat CV_8U, 256 bit).
@@ -100,7 +103,8 @@ void vsf_destroy(vsf_ctx* ctx);
 const char* vsf_status_string(vsf_status s);
 int vsf_last_hip_error(const vsf_ctx* ctx);
 vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out);
-/* Use an existing hipStream_t (e.g. the caller's framework stream) instead of the context's own. NULL restores it. */
+/* Use an existing hipStream_t (e.g. the caller's framework stream) instead of the context's own. NULL restores it.  The
+ * handle must be a live stream of the context's device (the HIP runtime does not validate stream handles). */
 vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream);
 /* Batched entry points split a batch in `lanes` halves (1 or 2, default 1) that run concurrently: one on the context's
  * stream, one on an internal stream forked from / joined back into it with events, so the caller still sees ONE
@@ -121,13 +125,37 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
 vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on);
 /* With the blur beside it, FAST can run as one RESIDENT workgroup per CU (`waves` = 2..4 waves per SIMD, fed with cells
  * through a counter) instead of a grid that fills every register of the chip for as long as cells are left, so that the
- * blur's workgroups find room beside it.  -1 (default): of each batch size's eligible calls the library times the second in
- * the grid form and the third in the resident form (3 waves; these two calls wait for their own completion) and keeps
- * the faster; 0: never; 2..4: always.  Speed only: results do not depend on it. */
+ * blur's workgroups find room beside it.  -1 (default): the form vsf_tune_fast_resident measured for this batch size, the
+ * grid form for a size it has not measured; 0: always the grid form; 2..4: always resident.  Speed only: results do not
+ * depend on it. */
 vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves);
-/* What the batched calls currently do: *waves = 0 (grid form), 2..4 (resident, waves per SIMD), or -1 while the measured
- * choice for the last batch size is still open. */
+/* What a batched call of the last tuned size does now: *waves = 0 (grid form) or 2..4 (resident, waves per SIMD). */
 vsf_status vsf_get_fast_resident(const vsf_ctx* ctx, int* waves);
+/* BLOCKING (the one *_dev-shaped call that is): runs vsf_extract_batch_dev on the given images 1 + 2 * samples times
+ * (samples >= 1, 3 is a good value) -- one warm-up, then the grid form and the resident form of FAST alternately, each run
+ * timed by itself between two events and waited for -- and keeps the form with the smaller MEDIAN for batches of n_images
+ * images (vsf_set_fast_resident(ctx, -1) semantics).  *ms_grid / *ms_resident receive the two medians, so that the ranks of
+ * a multi-GPU job can agree on one form (all-reduce the pair, then vsf_set_fast_resident with the common winner).  Batches
+ * the blur does not run beside (fewer than 32 images, vsf_set_blur_overlap(ctx, 0), two lanes) are left on the grid form
+ * and report 0 / 0.  No other entry point measures anything or waits for the GPU behind the caller's back. */
+vsf_status vsf_tune_fast_resident(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
+                                  size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
+                                  int samples, float* ms_grid, float* ms_resident);
+/* Launch choices of a context (speed / A-B measurements only: results never depend on them).  Nothing in the library
+ * reads the environment.  vsf_set_option waits for the context's stream first. */
+typedef enum {
+  VSF_OPT_BLUR_MARCH = 0,    /* 0 (default): matrix-core blur kernel; 1: round 2's vector-ALU kernel */
+  VSF_OPT_FAST_BOTH_MAX = 1, /* 16: largest batch (images) whose full and half-wave FAST cells share one launch */
+  VSF_OPT_SORT_SERIAL = 2,   /* 0: workgroup-parallel introsort of GetFeatureMatches; 1: the one-lane kernel */
+  VSF_OPT_SELECT_WIDE = 3,   /* 1: a frame or two takes the 1024-thread whole-level selection class; 0: never */
+  VSF_OPT_JPEG_SERIAL = 4,   /* 0: self-synchronising parallel JPEG decode; 1: one wave per image for every file */
+  VSF_OPT_PYRAMID_FEW = 5,   /* 16: largest batch (images) whose pyramid is built by the slab kernel */
+  VSF_OPT_PYRAMID_CHAIN = 6, /* 8: levels per slab launch; 0: per-level launches even for a frame or two */
+  VSF_OPT_PYRAMID_ROWS = 7,  /* 6: rows of a chain's last level per slab */
+  VSF_OPT_COUNT = 8
+} vsf_option;
+vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
+vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
 
@@ -339,6 +367,9 @@ vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, in
 
 /* ---------------- introspection for kernel-level parity tests and the roofline model ---------------- */
 
+/* Test hook for the error plumbing: the next entry point that launches returns VSF_ERR_HIP (vsf_last_hip_error == code),
+ * as if one of its event records / waits had failed; the call after that works again. */
+vsf_status vsf_debug_inject_hip_error(vsf_ctx* ctx, int code);
 /* Copies level `level` of image `image` from the last extract to host (blurred: 0 = FAST/Harris/angle input,
  * 1 = descriptor input).  out has `ostride` bytes per row. */
 vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t ostride);

@@ -88,12 +88,53 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_gloo_gather_and_threshold_exchange():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_gather_and_threshold_exchange(world):
+    """World of two, and of EIGHT (BASELINE configs[3]'s rank count: the handshake must see ranks 0..7, the means and the
+    payloads must arrive rank-major): real processes, gloo, no GPU."""
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
-    assert dict(results) == {0: True, 1: True}
+    assert dict(results) == {r: True for r in range(world)}
+
+
+def test_thread_world_carries_the_same_exchanges():
+    """distributed.ThreadComm (ranks = threads of one process: the vehicle of the eight-rank GPU rehearsal) against the
+    definitions: all-gather is rank-major, the gather lands on the root only, the all-reduce is a maximum -- for eight
+    ranks, repeated so that slot reuse is exercised."""
+    import threading
+    world = 8
+    shared = vd.ThreadWorld(world)
+    ok = [False] * world
+
+    class _Stream:  # (ThreadComm synchronises the producer's stream before it reads: nothing to wait for on the CPU)
+        def synchronize(self):
+            pass
+
+    def main(r):
+        comm = vd.ThreadComm(shared, r)
+        good = True
+        for it in range(5):
+            inp = torch.arange(3, dtype=torch.float32) + 10 * r + 100 * it
+            out = torch.zeros(world * 3)
+            comm.all_gather(out, inp, _Stream())
+            want = torch.cat([torch.arange(3, dtype=torch.float32) + 10 * q + 100 * it for q in range(world)])
+            good &= bool(torch.equal(out, want))
+            send = torch.full((4,), r + it, dtype=torch.uint8)
+            recv = [torch.zeros(4, dtype=torch.uint8) for _ in range(world)] if r == 0 else None
+            work, _ = comm.gather_async(send, recv, dst=0)
+            work.wait()
+            if r == 0:
+                good &= all(int(recv[q][0]) == q + it for q in range(world))
+            good &= comm.all_reduce_max([float(r), float(-r)], "cpu") == [float(world - 1), 0.0]
+        ok[r] = good
+
+    threads = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(ok)
 
 
 def test_handshake_without_a_process_group():
@@ -119,7 +160,7 @@ def test_stereo_threshold_chain():
     assert vd.stereo_thresholds([m, m])[1] == np.float32(m + np.float32(2.0))
 
 
-@pytest.mark.parametrize("world,B,W", [(1, 4, 2), (2, 3, 2), (3, 2, 2), (4, 5, 1), (2, 4, 4)])
+@pytest.mark.parametrize("world,B,W", [(1, 4, 2), (2, 3, 2), (3, 2, 2), (4, 5, 1), (2, 4, 4), (8, 1, 1), (8, 2, 2)])
 def test_temporal_pair_schedule_reaches_the_right_frames(world, B, W):
     """The static (query set, train set) schedule of ShardedStereoFrontend resolves, on every rank and step, to the
     global frames (g - w, g) of slam_frontend.cc:424-434 -- through local sets, the previous rank's tail of the same

@@ -121,7 +121,7 @@ def test_ingest_chain_jpeg_bayer_extract(ctx, oracle):
 
 
 def test_parallel_and_serial_decoders_agree(oracle, monkeypatch):
-    """Files without restart intervals take the self-synchronising parallel decoder, the others (and VSF_JPEG_SERIAL=1)
+    """Files without restart intervals take the self-synchronising parallel decoder, the others (and VSF_OPT_JPEG_SERIAL = 1)
     the one-wave-per-image decoder: both against the oracle on a batch of different images, gray and colour."""
     PIL = pytest.importorskip("PIL.Image")
     import io
@@ -142,13 +142,13 @@ def test_parallel_and_serial_decoders_agree(oracle, monkeypatch):
             PIL.fromarray(img, "L").save(b, "JPEG", quality=int(rng.integers(5, 101)), optimize=bool(i & 2))
         files.append(b.getvalue())
     want = [oracle.jpeg_decode_gray(f) for f in files]
-    for serial in ("0", "1"):
-        monkeypatch.setenv("VSF_JPEG_SERIAL", serial)
+    for serial in (0, 1):
         c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500))
+        c.set_option(capi.OPT_JPEG_SERIAL, serial)
         got = _decode(c, files, 328, 200)
         c.close()
         for i in range(len(files)):
-            np.testing.assert_array_equal(got[i, :, :328], want[i], err_msg="file %d, VSF_JPEG_SERIAL=%s" % (i, serial))
+            np.testing.assert_array_equal(got[i, :, :328], want[i], err_msg="file %d, VSF_OPT_JPEG_SERIAL=%d" % (i, serial))
 
 
 def test_random_sizes_and_qualities(ctx, oracle):

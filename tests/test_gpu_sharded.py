@@ -28,7 +28,7 @@ def _calibration():
     return frontend.default_calibration().set("fundamental", F_RECT)
 
 
-def _run(frames, frames_per_rank, rank, world, overlap=True):
+def _run(frames, frames_per_rank, rank, world, overlap=True, force_collectives=False):
     """All steps of one rank; returns the ShardedStereoFrontend (drained).  overlap: the tail of a step on a second
     stream beside the next step's extraction (the default) or everything on one stream."""
     from vision_slam_frontend_amd import capi
@@ -36,7 +36,7 @@ def _run(frames, frames_per_rank, rank, world, overlap=True):
     dev = torch.device("cuda", 0)
     ctx = capi.Context(capi.default_params(W_IMG, H_IMG, max_images=2 * frames_per_rank, nfeatures=NF))
     sf = vd.ShardedStereoFrontend(ctx, frames_per_rank, W_IMG, H_IMG, _calibration(), window=WINDOW, device=dev,
-                                  overlap=overlap)
+                                  overlap=overlap, force_collectives=force_collectives)
     local = []
     for s in range(STEPS):
         idx = list(vd.frame_block(s, frames_per_rank, world, rank))
@@ -122,7 +122,6 @@ def _rccl_worker(rank: int, port: int, frames_path: str, out_path: str):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["VSF_FORCE_COLLECTIVES"] = "1"
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -132,7 +131,7 @@ def _rccl_worker(rank: int, port: int, frames_path: str, out_path: str):
         hs = vd.collective_handshake(torch.device("cuda", 0))  # what bench.py prints as "rccl" for the first 8-GPU run
         assert hs["backend"].startswith("nccl") and hs["world"] == 1 and hs["ranks_seen"] == [0] and hs["nccl_version"]
         frames = np.load(frames_path)
-        sf, _, ctx = _run(frames, WORLD * B, 0, 1, overlap=False)  # (the one-stream form of the step, for coverage)
+        sf, _, ctx = _run(frames, WORLD * B, 0, 1, overlap=False, force_collectives=True)  # (the one-stream form, for coverage)
         assert sf.dist_on and not sf.host_detour and [c[0] for c in sf.completed] == list(range(STEPS))
         assert sf.blocked_s >= 0.0
         np.savez(out_path, **{"s%d" % st: per[0].cpu().numpy() for st, per in sf.completed})
@@ -259,3 +258,91 @@ def test_sharded_outputs_follow_the_reference_sequence(oracle):
         thr = np.float32(thr_next)
     assert sizes[1] == 0 and sizes[2] == 0 and sizes[3] > 20 and sizes[0] > 20
     assert sum(len(v) for v in got_m.values()) > 5
+
+
+def _run_rank(frames, w, h, nf, frames_per_rank, window, steps, rank, world, comm=None, tune=False):
+    """All steps of one rank of a `world`-rank job at any geometry; returns (ShardedStereoFrontend, local payloads, tune)."""
+    from vision_slam_frontend_amd import capi
+    from vision_slam_frontend_amd import distributed as vd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = capi.Context(capi.default_params(w, h, max_images=2 * frames_per_rank, nfeatures=nf))
+    sf = vd.ShardedStereoFrontend(ctx, frames_per_rank, w, h, _calibration(), window=window, device=dev, comm=comm)
+    local, tuned = [], None
+    if tune:
+        idx = list(vd.frame_block(0, frames_per_rank, world, rank))
+        tuned = sf.tune(torch.from_numpy(np.ascontiguousarray(frames[idx])).to(dev), samples=1)
+    for s in range(steps):
+        idx = list(vd.frame_block(s, frames_per_rank, world, rank))
+        d_img = torch.from_numpy(np.ascontiguousarray(frames[idx])).to(dev)
+        sf.step(d_img)
+        if world == 1:
+            sf.synchronize()
+            local.append((s, [sf.local_payload(s).cpu().clone()]))
+    sf.drain()
+    assert all(c.sync() == capi.VSF_OK for c in sf.contexts())
+    sf.close()
+    completed = list(sf.completed)
+    ctx.close()
+    return sf, local, tuned, completed
+
+
+def test_eight_ranks_one_frame_per_gpu():
+    """BASELINE configs[3] literally -- "640x480 stereo batch sharded one-frame-per-GPU", eight ranks -- as far as one GPU
+    allows: a world of EIGHT with ONE frame per rank and step, 640x480 / 2000 features, window 1, three steps (24 frames),
+    real kernels, byte-identical to a single process over the same 24 frames.  A GPU box admits at most six processes on
+    its card, so the eight ranks are eight THREADS of this process, each with its own context, streams and
+    ShardedStereoFrontend, exchanging through distributed.ThreadComm (the class takes whatever carries its bytes; the
+    torch.distributed carriers are covered by the 2- and 3-process tests above and by the RCCL world of one).  Reference
+    dependencies being sharded: the static threshold of RemoveAmbigStereo crossing EVERY frame boundary = rank boundary
+    (slam_frontend.cc:353, 392-394), a frame without stereo matches inside a step and at a step's end (its NaN threshold
+    lands on the next rank / on rank 0 of the next step, quirk Q3), the temporal predecessor that always lives on another
+    rank (cc:424-434).  The explicit tune call takes part as in bench.py: every rank issues its one all-reduce."""
+    import threading
+
+    from vision_slam_frontend_amd import distributed as vd
+    from vision_slam_frontend_amd import synth
+
+    world, per, window, steps, w, h, nf = 8, 1, 1, 3, 640, 480, 2000
+    n = world * per * steps
+    frames = synth.stereo_stream(n, w, h, n_objects=400)
+    frames[2, 1] = 128   # rank 2, step 0: no stereo match -> rank 3's frame of step 0 meets the NaN threshold
+    frames[15, 1] = 128  # rank 7, step 1 -> rank 0's frame of step 2 meets it (across the step boundary)
+    _, local, _, _ = _run_rank(frames, w, h, nf, world * per, window, steps, 0, 1)
+    want_f, want_m = vd.assemble_outputs(local, 1, world * per, window)
+    assert sorted(want_f) == list(range(n))
+
+    shared = vd.ThreadWorld(world)
+    shared.barrier = threading.Barrier(world, timeout=300)  # (a rank that dies must not leave seven waiting for ever)
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            results[r] = _run_rank(frames, w, h, nf, per, window, steps, r, world, comm=vd.ThreadComm(shared, r), tune=True)
+        except BaseException as e:  # noqa: BLE001 -- reported below, on the main thread
+            errors.append((r, repr(e)))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    tunes = [results[r][2] for r in range(world)]
+    assert len({t["fast_resident"] for t in tunes}) == 1 and all(t["agreed_over_ranks"] == world for t in tunes)
+    for r in range(1, world):
+        assert not results[r][3], "only rank 0 receives payloads"
+    completed = results[0][3]
+    assert [c[0] for c in completed] == list(range(steps)) and all(len(per_rank) == world for _, per_rank in completed)
+    got_f, got_m = vd.assemble_outputs(completed, world, per, window)
+    assert sorted(got_f) == list(range(n)) and sorted(got_m) == sorted(want_m)
+    for g in range(n):
+        assert got_f[g].tobytes() == want_f[g].tobytes(), "VisionFeature records of global frame %d" % g
+    for key in want_m:
+        assert got_m[key].tobytes() == want_m[key].tobytes(), "FeatureMatch records of factor %s" % (key,)
+    sizes = [len(want_f[g]) for g in range(n)]
+    assert sizes[2] == 0 and sizes[3] == 0 and sizes[4] > 20, "empty frame, NaN-threshold frame on the next rank, then normal"
+    assert sizes[15] == 0 and sizes[16] == 0 and sizes[17] > 20, "the same across the step boundary (rank 7 -> rank 0)"
+    assert all(k[1] - k[0] == 1 for k in want_m) and len(want_m) == n - 1, "every temporal pair crosses a rank boundary"
+    assert sum(len(v) for v in want_m.values()) > 200

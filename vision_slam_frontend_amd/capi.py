@@ -35,8 +35,11 @@ EXPORTS = [
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
-    "vsf_jpeg_decode_gray_batch",
+    "vsf_jpeg_decode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error",
 ]
+# vsf_option (include/vsf.h)
+(OPT_BLUR_MARCH, OPT_FAST_BOTH_MAX, OPT_SORT_SERIAL, OPT_SELECT_WIDE, OPT_JPEG_SERIAL, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN,
+ OPT_PYRAMID_ROWS) = range(8)
 STAGE_COUNT = 8
 
 
@@ -115,6 +118,10 @@ def lib() -> C.CDLL:
         L.vsf_set_blur_overlap.argtypes = [vp, i32]
         L.vsf_set_fast_resident.argtypes = [vp, i32]
         L.vsf_get_fast_resident.argtypes = [vp, C.POINTER(C.c_int)]
+        L.vsf_tune_fast_resident.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vsf_set_option.argtypes = [vp, i32, i32]
+        L.vsf_get_option.argtypes = [vp, i32, ip]
+        L.vsf_debug_inject_hip_error.argtypes = [vp, i32]
         L.vsf_remove_ambig_stereo_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.c_float, vp, vp, vp, vp, vp, vp]
         L.vsf_feature_matches_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, C.c_float, vp, vp]
         L.vsf_bayer_bg_to_gray_batch_dev.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, sz, sz]
@@ -232,8 +239,26 @@ class Context:
         self._check(lib().vsf_set_blur_overlap(self._h, int(on)), "vsf_set_blur_overlap")
 
     def set_fast_resident(self, waves: int):
-        """-1: measured choice (default); 0: FAST as one workgroup per four cells; 2..4: resident, that many waves per SIMD."""
+        """-1 (default): what tune_fast_resident measured for the batch size, the grid form otherwise; 0: FAST as one
+        workgroup per four cells; 2..4: resident, that many waves per SIMD."""
         self._check(lib().vsf_set_fast_resident(self._h, int(waves)), "vsf_set_fast_resident")
+
+    def tune_fast_resident(self, d_imgs: int, n_images: int, image_stride: int, row_stride: int, d_kp: int, d_desc: int,
+                           d_counts: int, samples: int = 3):
+        """vsf_tune_fast_resident: BLOCKING; returns (median ms of the grid form, median ms of the resident form)."""
+        g, r = C.c_float(), C.c_float()
+        self._check(lib().vsf_tune_fast_resident(self._h, C.c_void_p(d_imgs), n_images, image_stride, row_stride,
+                                                 C.c_void_p(d_kp), C.c_void_p(d_desc), C.c_void_p(d_counts), samples,
+                                                 C.byref(g), C.byref(r)), "vsf_tune_fast_resident")
+        return g.value, r.value
+
+    def set_option(self, option: int, value: int):
+        self._check(lib().vsf_set_option(self._h, int(option), int(value)), "vsf_set_option")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int()
+        self._check(lib().vsf_get_option(self._h, int(option), C.byref(v)), "vsf_get_option")
+        return v.value
 
     def get_fast_resident(self) -> int:
         w = C.c_int(-1)

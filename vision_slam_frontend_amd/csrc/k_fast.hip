@@ -510,7 +510,7 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
   a.threshold = threshold;
   a.nms = nms;
   if (resident_waves_per_simd > 0 && resident_waves_per_simd <= 4 && nms && d_cell_counters) {
-    (void)hipMemsetAsync(d_cell_counters, 0, 2 * sizeof(uint32_t), s);
+    vsf_note(hipMemsetAsync(d_cell_counters, 0, 2 * sizeof(uint32_t), s));
     const dim3 block(256 * resident_waves_per_simd);
     if (g.nwork_full > 0)
       hipLaunchKernelGGL((fast_march_resident_kernel<false, true>), dim3(n_cus), block, 0, s, a, 0, g.nwork_full, im.n,
@@ -521,7 +521,7 @@ void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int
     return;
   }
   const dim3 gf((g.nwork_full + 3) / 4, im.n), gh((g.nwork_half + 3) / 4, im.n);
-  static const int both_max = std::getenv("VSF_FAST_BOTH") ? std::atoi(std::getenv("VSF_FAST_BOTH")) : 16;
+  const int both_max = d.tune ? d.tune->fast_both_max : 16;
   if (im.n <= both_max && g.nwork_full > 0 && g.nwork_half > 0) {
     const dim3 gb((g.nwork_full + g.nwork_half + 3) / 4, im.n);
     if (nms)

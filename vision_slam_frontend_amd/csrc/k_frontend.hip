@@ -528,9 +528,10 @@ void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, c
 
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
                           float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
-                          int32_t* d_npairs, hipStream_t s, bool force_serial) {
-  // VSF_SORT=serial: the one-lane kernel (A/B measurements, and pairs beyond the parallel kernel's LDS layout)
-  static const bool serial = std::getenv("VSF_SORT") && !strcmp(std::getenv("VSF_SORT"), "serial");
+                          int32_t* d_npairs, hipStream_t s, bool force_serial, int lds_limit) {
+  // force_serial: the one-lane kernel (VSF_OPT_SORT_SERIAL, A/B measurements); it also takes the pairs beyond the parallel
+  // kernel's LDS layout and every pair on a device whose workgroups cannot have that much LDS (lds_limit: queried at
+  // vsf_create, where vsf_prepare_sort_kernels raised the kernel's limit -- checked -- to it)
   constexpr int NT = 256;
   const int cap = max_rows;
   const size_t maxw = (size_t)(cap + 63) / 64;
@@ -538,17 +539,7 @@ void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches
                      (size_t)cap * 2 * sizeof(uint16_t) + 16 + sizeof(SortShared) +
                      (size_t)(NT / 64) * (vsf_par::kWaveTable + kSortWaveStack * sizeof(SortRange) +
                                          kSortWaveBlocks * 2 * sizeof(uint16_t));
-  if (!serial && !force_serial && cap < 65536 && lds <= 160 * 1024) {
-    {  // the kernel's dynamic LDS exceeds the default limit: raised once per device (a process may drive several)
-      static bool raised[64] = {false};
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      if (dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_trim_par_kernel<NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised[dev] = true;
-      }
-    }
+  if (!force_serial && cap < 65536 && lds <= (size_t)std::max(lds_limit, 0)) {
     hipLaunchKernelGGL((sort_trim_par_kernel<NT>), dim3(n_pairs), dim3(NT), lds, s, d_matches, d_nmatches, max_rows, cap,
                        best_percent, d_best_percent_of, d_pairs, d_npairs);
     return;
@@ -556,6 +547,11 @@ void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches
   hipLaunchKernelGGL(sort_trim_kernel, dim3(n_pairs), dim3(64), VSF_SORT_LDS_ROWS * sizeof(SortKey), s, d_matches,
                      d_nmatches, max_rows, best_percent, d_best_percent_of, reinterpret_cast<SortKey*>(d_scratch), d_pairs,
                      d_npairs);
+}
+
+hipError_t vsf_prepare_sort_kernels(int lds_limit) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_trim_par_kernel<256>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit);
 }
 
 void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s) {

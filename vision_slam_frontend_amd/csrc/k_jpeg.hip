@@ -929,6 +929,13 @@ size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par) {
   return n_par > 0 ? 2 * linear + (size_t)n_par * kTransSlack : linear;
 }
 
+// The parallel decoder's static + dynamic LDS exceed the default 64 KB for colour files: raised (checked) at vsf_create.
+hipError_t vsf_prepare_jpeg_kernels(int lds_limit) {
+  const int need = (int)(kMaxSlots * sizeof(DevHuff));
+  if (need > lds_limit) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(jpeg_par_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, need);
+}
+
 // Both decoders over one upload: the files without restart intervals (n_par of them, listed first in the index array
 // at off_index) take the self-synchronising parallel decode, the others the one-wave-per-image decode.  d_clean has
 // vsf_jpeg_clean_bytes(total - off_stream, n_par) bytes, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
@@ -941,16 +948,7 @@ void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off
   const DevTables* tables = reinterpret_cast<const DevTables*>(d_blob + off_tables);
   const uint32_t* index = reinterpret_cast<const uint32_t*>(d_blob + off_index);
   if (n_par > 0) {
-    {  // static + dynamic LDS exceed 64 KB for colour files: the limit is raised once per device
-      static bool raised[64] = {false};
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      if (dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jpeg_par_decode_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxSlots * sizeof(DevHuff)));
-        raised[dev] = true;
-      }
-    }
+    // (static + dynamic LDS exceed 64 KB for colour files: vsf_prepare_jpeg_kernels raised the limit at vsf_create)
     hipLaunchKernelGGL(jpeg_par_decode_kernel, dim3(n_par), dim3(kParThreads), (size_t)max_slots * sizeof(DevHuff), s, images, index, tables, d_blob + off_stream,
                        reinterpret_cast<uint32_t*>(d_clean),
                        reinterpret_cast<uint32_t*>(d_clean + vsf_jpeg_clean_bytes(total - off_stream, 0)), d_coef, coef_stride,

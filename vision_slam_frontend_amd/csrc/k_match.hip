@@ -322,7 +322,7 @@ void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_
                        d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
     return;
   }
-  (void)hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s);
+  vsf_note(hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s));
   hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
                      d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
   hipLaunchKernelGGL(knn2_finalize_kernel, dim3((max_rows + 255) / 256, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set,

@@ -567,6 +567,12 @@ size_t slab_chain_bytes(const VsfLevel* lv, int la, int lb, int nslabs) {
 
 }  // namespace
 
+hipError_t vsf_prepare_pyramid_kernels(int lds_limit) {
+  if (lds_limit < 160 * 1024 - 2048) return hipSuccess;  // (the slab kernel is then never launched)
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_slab_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024 - 2048);
+}
+
 void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                         hipStream_t s, const VsfSideStream* side) {
   // Level l depends on level l - 1 of the same image only, so the chain of 49 small dependent launches is issued once
@@ -577,40 +583,25 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   // one-band levels to the image-major tail kernel; `side` doubles as the permission (the cross-call prefetch on the aux
   // stream keeps the plain chain).
   // A batch of a frame or two (vsf_observe_stereo, the host-pointer calls) is bound by the LATENCY of the level chain,
-  // not by throughput: it takes pyramid_slab_kernel for every level (VSF_PYRAMID_CHAIN=0 keeps the launches + tail kernel;
-  // VSF_PYRAMID_CHAIN / VSF_PYRAMID_ROWS: levels per launch and rows per slab, for experiments).
+  // not by throughput: it takes pyramid_slab_kernel for every level (VSF_OPT_PYRAMID_CHAIN 0 keeps the launches + tail kernel;
+  // VSF_OPT_PYRAMID_CHAIN / _ROWS: levels per launch and rows per slab, for experiments).
   int l_tail = g.nlevels;
-  static const int few_max = [] {
-    const char* e = std::getenv("VSF_PYRAMID_FEW");
-    return e ? std::atoi(e) : 16;  // images: 2 -> 105 us (335 as launches), 8 -> 137 (335), 16 -> 212 (348), 32 -> 386 (341)
-  }();
+  // images: 2 -> 105 us (335 as launches), 8 -> 137 (335), 16 -> 212 (348), 32 -> 386 (341)
+  const int few_max = d.tune ? d.tune->pyramid_few : 16;
   const bool few = side && im.n <= few_max;
   if (few && g.nlevels > 1) {
     bool ok = true;
     for (int l = 1; l < g.nlevels; l++) ok = ok && h_levels[l].resize_any8 && h_levels[l].w <= 256 * kSlabBands;
-    static const int chain_env = [] {
-      const char* e = std::getenv("VSF_PYRAMID_CHAIN");
-      return e ? std::atoi(e) : 8;
-    }();
-    if (ok && chain_env > 0) {
-      {  // the kernel's dynamic LDS exceeds the default limit: raised once per device (a process may drive several)
-        static bool raised[64] = {false};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !raised[dev]) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_slab_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-          raised[dev] = true;
-        }
-      }
+    // (the slab kernel's dynamic LDS exceeds the default limit: vsf_prepare_pyramid_kernels raised it at vsf_create; a
+    // device that cannot give a workgroup that much keeps the per-level launches)
+    const int chain_env = d.tune ? d.tune->pyramid_chain : 8;
+    const int lds_limit = d.tune ? d.tune->lds_limit : 160 * 1024;
+    if (ok && chain_env > 0 && lds_limit >= 160 * 1024 - 2048) {
       const size_t fixed = kSlabFixedBytes;
       const size_t budget = 144 * 1024;
       for (int la = 1; la < g.nlevels;) {
         int lb = std::min({la + chain_env, la + kSlabMaxLevels, g.nlevels});
-        static const int rows_env = [] {
-          const char* e = std::getenv("VSF_PYRAMID_ROWS");
-          return e ? std::max(1, std::atoi(e)) : 6;
-        }();
+        const int rows_env = d.tune ? std::max(1, d.tune->pyramid_rows) : 6;
         int nslabs = std::max(1, std::min(64, h_levels[lb - 1].h / rows_env));
         size_t need = slab_chain_bytes(h_levels, la, lb, nslabs);
         while (2 * need + fixed > budget && (nslabs < 64 || lb > la + 1)) {  // thinner slabs, then a shorter chain
@@ -660,8 +651,8 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
   hipStream_t st[VSF_SIDE_STREAMS + 1] = {s};
   for (int c = 1; c < nchains; c++) st[c] = side->stream[c - 1];
   if (nchains > 1) {
-    (void)hipEventRecord(side->fork, s);
-    for (int c = 1; c < nchains; c++) (void)hipStreamWaitEvent(st[c], side->fork, 0);
+    vsf_note(hipEventRecord(side->fork, s));
+    for (int c = 1; c < nchains; c++) vsf_note(hipStreamWaitEvent(st[c], side->fork, 0));
   }
   for (int l = 1; l < l_tail; l++) {
     const VsfLevel& L = h_levels[l];
@@ -704,8 +695,8 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
     }
   }
   for (int c = 1; c < nchains; c++) {
-    (void)hipEventRecord(side->join[c - 1], st[c]);
-    (void)hipStreamWaitEvent(s, side->join[c - 1], 0);
+    vsf_note(hipEventRecord(side->join[c - 1], st[c]));
+    vsf_note(hipStreamWaitEvent(s, side->join[c - 1], 0));
   }
   if (l_tail < g.nlevels) {
     PyramidArgs p;

@@ -652,7 +652,7 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   // A frame or two leaves the chip nearly empty and the stage lasts as long as its slowest workgroup -- level 0 of a
   // 640x480 image: 8 500 candidates, 92 us of selection passes with 256 threads on an HBM-resident array, 39 us with 1 024
   // threads on an LDS array that holds the whole level (105 KB, one workgroup per CU: at most 256 of them).
-  static const bool wide_off = std::getenv("VSF_SELECT_WIDE") && std::atoi(std::getenv("VSF_SELECT_WIDE")) == 0;
+  const bool wide_off = d.tune && !d.tune->select_wide;
   if (ntiny0 > 0 && !wide_off && (long)ntiny0 * im.n <= 256) {
     if ((long)g.nlevels * im.n <= 256) ntiny0 = g.nlevels;  // ... and the small top levels ride along (one launch)
     a.level0 = 0;

@@ -14,6 +14,8 @@
 
 #include "vsf_internal.h"
 
+thread_local int vsf_tls_hip_error = 0;
+
 namespace {
 
 // ---- OpenCV scalar helpers (core/fast_math.hpp) ----
@@ -146,8 +148,7 @@ void build_blur_mma_tables(Geometry* G) {
     // steps per unit 0.93 ms per 512 images, 4: 1.01, 2: 1.29), short ones for a frame or two (parallelism).
     const int nsteps = (L.h + VSF_BLUR_MMA_ROWS - 1) / VSF_BLUR_MMA_ROWS, ndsteps = (nsteps + 1) / 2;
     for (int pass = 0; pass < 2; pass++) {
-      static const int env_steps = std::getenv("VSF_BLUR_MMA_STEPS") ? std::max(1, std::atoi(std::getenv("VSF_BLUR_MMA_STEPS"))) : 0;
-      const int per_unit = pass == 0 ? (env_steps ? env_steps : VSF_BLUR_MMA_STEPS) : VSF_BLUR_MMA_STEPS_SMALL;
+      const int per_unit = pass == 0 ? VSF_BLUR_MMA_STEPS : VSF_BLUR_MMA_STEPS_SMALL;
       std::vector<uint32_t>& units = pass == 0 ? G->blur_mma_units : G->blur_mma_units_small;
       const int nstrips = (ndsteps + per_unit - 1) / per_unit;
       for (int st = 0; st < nstrips; st++) {
@@ -325,8 +326,7 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
       // (<= 120 columns) is walked two strips per wave (k_blur.hip: bit 15)
       const int nb = (L.w + VSF_BLUR_BAND_COLS - 1) / VSF_BLUR_BAND_COLS;
       const int ns = (L.h + VSF_BLUR_STRIP_ROWS - 1) / VSF_BLUR_STRIP_ROWS;
-      static const bool half_off = std::getenv("VSF_BLUR_HALF") && std::atoi(std::getenv("VSF_BLUR_HALF")) == 0;
-      const bool half_last = !half_off && ns >= 2 && L.w - VSF_BLUR_BAND_COLS * (nb - 1) <= 120;
+      const bool half_last = ns >= 2 && L.w - VSF_BLUR_BAND_COLS * (nb - 1) <= 120;
       for (int st = 0; st < ns; st++)
         for (int b = 0; b < nb; b++) {
           if (half_last && b == nb - 1) {
@@ -435,15 +435,20 @@ struct vsf_ctx {
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int blur_overlap = 1;  // the blur on blur_stream beside FAST / selection (vsf_set_blur_overlap)
   int fast_resident = -1;  // vsf_set_fast_resident
+  int fast_force = -1;     // vsf_tune_fast_resident only: the form of the run it is timing
+  VsfTuning tuning;        // vsf_set_option
   int last_hip = 0;
   Geometry orb, fast;
   DevSet dorb, dfast;
   int gauss[4] = {0, 0, 0, 0};
-  int32_t* d_status = nullptr;
+  // Status words (bit 0: capacity overflow, bit 1: a JPEG stream broke off): word 0 belongs to the context's own stream
+  // (batched and host-pointer calls, vsf_sync), words 1..3 to the three frames that may be in flight (vsf_observe_submit) --
+  // a frame's kernels run on its slot's stream beside another frame's, so each frame sets, copies and clears its own word.
+  int32_t* d_status = nullptr;     // [4]
   uint32_t* fast_cells = nullptr;  // [2] cell counters of the resident FAST kernels (k_fast.hip)
-  struct FastTune {  // resident FAST or one workgroup per four cells: measured once per batch size (extract_on)
-    int n = 0, choice = -1, calls = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // grid form: [0] .. [1], resident form: [2] .. [3]
+  struct FastTune {  // resident FAST or one workgroup per four cells: what vsf_tune_fast_resident measured, per batch size
+    int n = 0, choice = -1;
+    hipEvent_t ev[2] = {nullptr, nullptr};
   } fast_tune;
   int32_t* h_status = nullptr;  // pinned
   // staging for the host-pointer entry points
@@ -519,7 +524,6 @@ struct vsf_ctx {
   size_t jp_clean_cap = 0;
   int16_t* jp_coef = nullptr;    // ... and the luminance coefficients of the batch
   size_t jp_coef_cap = 0;
-  int jp_serial = -1;            // VSF_JPEG_SERIAL=1 forces the one-wave-per-image decoder (tests, comparison)
   uint8_t* mh_desc = nullptr;  // host-API descriptor staging: 2 sets
   int32_t* mh_counts = nullptr;
   vsf_dmatch* mh_matches = nullptr;
@@ -553,6 +557,18 @@ namespace {
       ctx->last_hip = (int)e_;            \
       return VSF_ERR_HIP;                 \
     }                                     \
+  } while (0)
+// End of an entry point that launched: a failed launch (hipGetLastError) or anything a launcher / stream helper noted
+// (vsf_note: event records and waits, memsets) becomes this call's VSF_ERR_HIP.
+#define VSF_STICKY()                                               \
+  do {                                                             \
+    hipError_t e_ = hipGetLastError();                             \
+    if (e_ == hipSuccess) e_ = (hipError_t)vsf_tls_hip_error;      \
+    vsf_tls_hip_error = 0;                                         \
+    if (e_ != hipSuccess) {                                        \
+      ctx->last_hip = (int)e_;                                     \
+      return VSF_ERR_HIP;                                          \
+    }                                                              \
   } while (0)
 
 template <class T>
@@ -589,6 +605,7 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   VSF_HIP(hipMalloc((void**)&d.rowstart, rs_bytes));
   VSF_HIP(hipMemset(d.rowstart, 0, rs_bytes));
   d.status = ctx->d_status;
+  d.tune = &ctx->tuning;
   ds->ready = true;
   return VSF_OK;
 }
@@ -699,6 +716,7 @@ vsf_status check_status_word(vsf_ctx* ctx) {
   VSF_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   VSF_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
+  VSF_STICKY();
   if (*ctx->h_status & 2) return VSF_ERR_INVALID_ARG;  // a JPEG stream broke off inside its entropy-coded data
   return (*ctx->h_status & 1) ? VSF_ERR_CAPACITY : VSF_OK;
 }
@@ -722,11 +740,14 @@ void prof_fold(vsf_ctx* ctx) {  // stream must be idle
 }
 
 void sync_all_streams(vsf_ctx* ctx) {  // every stream the context launches on
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
-  if (ctx->blur_stream) (void)hipStreamSynchronize(ctx->blur_stream);
+  if (ctx->stream) vsf_note(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->own_stream != ctx->stream) vsf_note(hipStreamSynchronize(ctx->own_stream));
+  if (ctx->aux_stream) vsf_note(hipStreamSynchronize(ctx->aux_stream));
+  if (ctx->blur_stream) vsf_note(hipStreamSynchronize(ctx->blur_stream));
+  for (int i = 1; i < ctx->side.n; i++)
+    if (ctx->side.stream[i]) vsf_note(hipStreamSynchronize(ctx->side.stream[i]));
   for (int i = 0; i < 3; i++)
-    if (ctx->ob.ex_stream[i] && ctx->ob.ex_stream[i] != ctx->stream) (void)hipStreamSynchronize(ctx->ob.ex_stream[i]);
+    if (ctx->ob.ex_stream[i] && ctx->ob.ex_stream[i] != ctx->stream) vsf_note(hipStreamSynchronize(ctx->ob.ex_stream[i]));
 }
 
 struct StageTimer {  // records an event pair around one stage when profiling is on
@@ -743,7 +764,7 @@ struct StageTimer {  // records an event pair around one stage when profiling is
     slot = ctx->ev_used++;
     while (ctx->ev_pool.size() < 2 * (slot + 1)) {
       hipEvent_t e = nullptr;
-      (void)hipEventCreate(&e);
+      vsf_note(hipEventCreate(&e));
       ctx->ev_pool.push_back(e);
     }
     if (ctx->ev_stage.size() <= slot) {
@@ -752,10 +773,10 @@ struct StageTimer {  // records an event pair around one stage when profiling is
     }
     ctx->ev_stage[slot] = stage;
     ctx->ev_launches[slot] = launches;
-    (void)hipEventRecord(ctx->ev_pool[2 * slot], st);
+    vsf_note(hipEventRecord(ctx->ev_pool[2 * slot], st));
   }
   ~StageTimer() {
-    if (on) (void)hipEventRecord(ctx->ev_pool[2 * slot + 1], st);
+    if (on) vsf_note(hipEventRecord(ctx->ev_pool[2 * slot + 1], st));
   }
 };
 
@@ -773,11 +794,14 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
   return o;
 }
 
-// detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.
+// detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.  `status`: the status word the kernels report capacity
+// overflows into (the context's, or the word of the frame in flight that owns this extraction).
 void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp,
-                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete = false, const VsfSideStream* own_side = nullptr) {
+                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete = false, const VsfSideStream* own_side = nullptr,
+                int32_t* status = nullptr) {
   const VsfGeom& g = ctx->orb.g;
   VsfDev d = shifted(ctx->dorb.d, g, i0);
+  if (status) d.status = status;
   VsfImages im = im_all;
   im.base += (size_t)i0 * im.image_stride;
   im.n = n;
@@ -793,18 +817,18 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     // (ROCm multiplexes streams onto a few hardware queues; the context's aux stream is known to run beside the
     // main one, so the chain goes there, as a single chain)
     hipStream_t ps = ctx->aux_stream;
-    if (ctx->pyr_free_valid[buf]) (void)hipStreamWaitEvent(ps, ctx->ev_pyr_free[buf], 0);
+    if (ctx->pyr_free_valid[buf]) vsf_note(hipStreamWaitEvent(ps, ctx->ev_pyr_free[buf], 0));
     // ... and not before the previous call's FAST kernel has finished: FAST fills every register of the chip, the
     // stages after it (selection, descriptors, matcher) are latency-bound and leave room for the resize chain
-    if (ctx->fast_done_valid) (void)hipStreamWaitEvent(ps, ctx->ev_fast_done, 0);
+    if (ctx->fast_done_valid) vsf_note(hipStreamWaitEvent(ps, ctx->ev_fast_done, 0));
     // ... and not before images this library itself is still producing on the context's stream are complete
-    if (ctx->ingest_done_valid) (void)hipStreamWaitEvent(ps, ctx->ev_ingest_done, 0);
+    if (ctx->ingest_done_valid) vsf_note(hipStreamWaitEvent(ps, ctx->ev_ingest_done, 0));
     {
       StageTimer t(ctx, ps, VSF_STAGE_PYRAMID, g.nlevels - 1);
       vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ps, nullptr);
     }
-    (void)hipEventRecord(ctx->ev_pyr_done, ps);
-    (void)hipStreamWaitEvent(st, ctx->ev_pyr_done, 0);
+    vsf_note(hipEventRecord(ctx->ev_pyr_done, ps));
+    vsf_note(hipStreamWaitEvent(st, ctx->ev_pyr_done, 0));
   } else {
     StageTimer t(ctx, st, VSF_STAGE_PYRAMID, g.nlevels - 1);
     // one lane: the aux stream is idle, the pyramid chain of the second half of the batch runs on it
@@ -813,18 +837,17 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, st, own_side ? own_side : (ctx->lanes == 1 ? &ctx->side : nullptr));
   }
   ctx->last_pyr = d.pyr - (size_t)i0 * g.pyr_bytes;
-  // The blur needs the pyramid only.  It lives on the matrix cores and on memory bandwidth, FAST on the vector ALU (93 % of
-  // its issue rate) and the selection on latency: forked behind the pyramid onto its own stream, the blur's workgroups
-  // fill in as FAST drains and run beside the selection (7.61 -> 7.25 ms per 256-frame step).  Measured and left out:
-  // forking behind FAST instead (7.52: the overlap with FAST's tail is lost); making room beside FAST with an LDS
-  // reservation that caps FAST at four workgroups per CU (7.46: the reservation is LDS the blur needs; the resident
-  // kernel below caps FAST without it); a high- or low-priority blur stream (7.39 / 7.65); slices of the blur forked from INSIDE
-  // the pyramid's launch chain as soon as their levels exist (marks after level 6 / 14, 8, 3 / 8 / 16, ...: the chain's
-  // dependent launches stretch from 1.28 to 1.8-2.2 ms beside the blur's memory traffic, 7.37-7.46 ms per step against
-  // 7.31); the first 3 / 6 / 10 / 16 levels blurred in line in front of FAST and only the rest beside it (7.25-7.36: noise).
-  static const int overlap_env = std::getenv("VSF_BLUR_OVERLAP") ? std::atoi(std::getenv("VSF_BLUR_OVERLAP")) : 1;
-  static const bool march = std::getenv("VSF_BLUR") && !strcmp(std::getenv("VSF_BLUR"), "march");
-  const bool beside_ok = overlap_env && ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
+  // The blur needs the pyramid only.  It lives on the matrix cores and on memory bandwidth, FAST on the vector ALU (at its
+  // issue ceiling: profiles/r04/valu_ceiling.json) and the selection on latency: forked behind the pyramid onto its own
+  // stream, the blur's workgroups fill in as FAST drains and run beside the selection (7.61 -> 7.25 ms per 256-frame step).
+  // Measured and left out: forking behind FAST instead (7.52: the overlap with FAST's tail is lost); making room beside
+  // FAST with an LDS reservation that caps FAST at four workgroups per CU (7.46: the reservation is LDS the blur needs; the
+  // resident kernel below caps FAST without it); a high- or low-priority blur stream (7.39 / 7.65); slices of the blur
+  // forked from INSIDE the pyramid's launch chain as soon as their levels exist (the chain's dependent launches stretch from
+  // 1.28 to 1.8-2.2 ms beside the blur's memory traffic, 7.37-7.46 ms per step against 7.31); the first 3 / 6 / 10 / 16
+  // levels blurred in line in front of FAST and only the rest beside it (7.25-7.36: noise).
+  const bool march = ctx->tuning.blur_march != 0;
+  const bool beside_ok = ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
   // With the blur beside it FAST can run as ONE resident workgroup per CU (k_fast.hip): three waves per SIMD keep 92 % of
   // its own rate and leave the other 224 of a SIMD's 512 registers -- which a grid of one workgroup per four cells fills
   // for as long as cells are left -- to the blur, which then finishes INSIDE the FAST pass instead of after it.  Whether
@@ -832,46 +855,22 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   // resident; 640x480 / 2000 features: 512 frames per step 35.4 -> 37.5 k, 256 frames 35.0 -> 36.4 k, 128 frames equal,
   // 64 frames 31.3 -> 29.8 k, 32 frames 25.7 -> 24.3 k; 1920x1080 / 8000: 32 frames 4 900 -> 4 700, 96 frames
   // 5 000 -> 5 140, 192 frames 5 030 -> 5 320; four waves per SIMD at 256 VGA frames 7.09-7.12 ms against 7.03, two 8.0).
-  // So the library measures: of a batch size's eligible calls the second runs the grid form and the third the resident
-  // form between two timed events (FAST ... descriptors), each waiting for itself so that nothing of the next call runs
-  // beside it, and the calls after them take the faster one.  vsf_set_fast_resident (or VSF_FAST_RESIDENT=0 / 2..4)
-  // overrides it.
-  static const int resident_env = std::getenv("VSF_FAST_RESIDENT") ? std::atoi(std::getenv("VSF_FAST_RESIDENT")) : -1;
+  // No rule on batch size got all of these right, so the caller may have it MEASURED: vsf_tune_fast_resident (explicit,
+  // blocking) times both forms on the caller's own batch and this call takes what it found for this batch size -- the grid
+  // form for a size nobody measured.  vsf_set_fast_resident overrides.  Nothing is measured, and nothing waits, in here.
   int resident = 0;
-  int measure = -1;  // this call is timed as form 0 (grid) / 1 (resident)
   if (beside_ok && ctx->lanes == 1 && st == ctx->stream && i0 == 0 && !own_side) {
-    vsf_ctx::FastTune& T = ctx->fast_tune;
-    if (ctx->fast_resident >= 0 || resident_env >= 0) {
-      resident = ctx->fast_resident >= 0 ? ctx->fast_resident : resident_env;
-    } else {
-      if (T.n != im.n) {
-        T.n = im.n;
-        T.choice = -1;
-        T.calls = 0;
-      }
-      if (T.choice < 0) {
-        const int call = T.calls++;
-        if (call == 1 || call == 2) {  // (not the first call: its kernels start cold)
-          measure = call - 1;
-          for (hipEvent_t& e : T.ev)
-            if (!e && hipEventCreate(&e) != hipSuccess) measure = -1;
-          if (measure < 0) T.choice = 0;
-        } else if (call > 2) {
-          float t_grid = 0.f, t_res = 0.f;
-          if (hipEventElapsedTime(&t_grid, T.ev[0], T.ev[1]) == hipSuccess &&
-              hipEventElapsedTime(&t_res, T.ev[2], T.ev[3]) == hipSuccess)
-            T.choice = t_res < t_grid ? 3 : 0;
-          else
-            T.choice = 0;
-        }
-      }
-      resident = measure >= 0 ? 3 * measure : (T.choice > 0 ? T.choice : 0);
-    }
+    if (ctx->fast_force >= 0)
+      resident = ctx->fast_force;
+    else if (ctx->fast_resident >= 0)
+      resident = ctx->fast_resident;
+    else if (ctx->fast_tune.n == im.n && ctx->fast_tune.choice > 0)
+      resident = ctx->fast_tune.choice;
   }
   const bool blur_beside = beside_ok;
   auto launch_blur = [&](hipStream_t bs) {
     StageTimer t(ctx, bs, VSF_STAGE_BLUR, 1);
-    // VSF_BLUR=march: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
+    // VSF_OPT_BLUR_MARCH: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
     if (march)
       vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, bs);
     else if (im.n >= 32)
@@ -882,19 +881,18 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
                           ctx->dorb.blur_tcol, ctx->dorb.blur_tv, ctx->orb.blur_bias, bs);
   };
   auto fork_blur = [&]() {
-    (void)hipEventRecord(ctx->ev_blur_fork, st);
-    (void)hipStreamWaitEvent(ctx->blur_stream, ctx->ev_blur_fork, 0);
+    vsf_note(hipEventRecord(ctx->ev_blur_fork, st));
+    vsf_note(hipStreamWaitEvent(ctx->blur_stream, ctx->ev_blur_fork, 0));
     launch_blur(ctx->blur_stream);
-    (void)hipEventRecord(ctx->ev_blur_done, ctx->blur_stream);
+    vsf_note(hipEventRecord(ctx->ev_blur_done, ctx->blur_stream));
   };
   if (blur_beside) fork_blur();
-  if (measure >= 0) (void)hipEventRecord(ctx->fast_tune.ev[2 * measure], st);
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
     vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
   }
   if (pipe) {
-    (void)hipEventRecord(ctx->ev_fast_done, st);
+    vsf_note(hipEventRecord(ctx->ev_fast_done, st));
     ctx->fast_done_valid = true;
   }
   {
@@ -902,7 +900,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     vsf_launch_select(d, g, ctx->orb.levels.data(), im, st);
   }
   if (blur_beside)
-    (void)hipStreamWaitEvent(st, ctx->ev_blur_done, 0);
+    vsf_note(hipStreamWaitEvent(st, ctx->ev_blur_done, 0));
   else
     launch_blur(st);
   {
@@ -910,14 +908,9 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     vsf_launch_describe(d, g, im, ctx->p.max_keypoints, d_kp + i0 * K, d_desc + i0 * K * VSF_DESC_BYTES, d_counts + i0,
                         st);
   }
-  if (measure >= 0) {
-    (void)hipEventRecord(ctx->fast_tune.ev[2 * measure + 1], st);
-    // the two calls that block: nothing of the NEXT call (its pipelined pyramid) may run beside the timed kernels
-    (void)hipStreamSynchronize(st);
-  }
   if (pipe) {  // every reader of this pyramid buffer is queued: the call after the next may overwrite it
     const int buf = ctx->pyr_flip;
-    (void)hipEventRecord(ctx->ev_pyr_free[buf], st);
+    vsf_note(hipEventRecord(ctx->ev_pyr_free[buf], st));
     ctx->pyr_free_valid[buf] = true;
     ctx->pyr_flip ^= 1;
   }
@@ -926,7 +919,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
 // knnMatch(k = 2) + ratio test for pairs [p0, p0 + n) on stream `st`.
 void match_on(vsf_ctx* ctx, hipStream_t st, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
               const int32_t* d_q_set, const int32_t* d_t_set, int p0, int n, int32_t* d_idx2, int32_t* d_dist2,
-              vsf_dmatch* d_matches, int32_t* d_nmatches) {
+              vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* status = nullptr) {
   const int rows = ctx->p.max_keypoints;
   const size_t R = (size_t)rows;
   // implicit pairing (set 2p vs 2p + 1) is relative to the descriptor base: shift the base instead of the indices
@@ -947,7 +940,7 @@ void match_on(vsf_ctx* ctx, hipStream_t st, const uint8_t* d_desc, const int32_t
     StageTimer t(ctx, st, VSF_STAGE_RATIO, 1);
     vsf_launch_ratio_compact(counts, d_q_set ? d_q_set + p0 : nullptr, d_t_set ? d_t_set + p0 : nullptr, n, rows, idx2,
                              dist2, ctx->p.ratio_num, ctx->p.ratio_shift, d_matches + (size_t)p0 * R, d_nmatches + p0,
-                             ctx->d_status, st);
+                             status ? status : ctx->d_status, st);
   }
 }
 
@@ -991,7 +984,7 @@ vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, 
   if (st != VSF_OK) return st;
   ctx->last_images = im;
   ctx->last_valid = true;
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1099,8 +1092,30 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
     if (hipEventCreateWithFlags(&ctx->side.join[i], hipEventDisableTiming) != hipSuccess) return fail(VSF_ERR_HIP);
     ctx->side.n = i + 1;
   }
-  if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
-  if (hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMalloc((void**)&ctx->d_status, 4 * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMemset(ctx->d_status, 0, 4 * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  {
+    // Three kernels ask for more dynamic LDS than the default 64 KB (the parallel sort of GetFeatureMatches, the slab
+    // pyramid, the parallel JPEG decode): how much a workgroup of this device may have is asked once, their limits are
+    // raised here -- checked -- and the launchers fall back to their plain forms where it is not enough.
+    int per_block = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) per_block = 0;
+    if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess) per_cu = 0;
+    int limit = std::min(std::max(std::max(per_block, per_cu), 64 * 1024), 160 * 1024);
+    if (vsf_prepare_sort_kernels(limit) != hipSuccess) {
+      (void)hipGetLastError();
+      limit = 64 * 1024;  // (nothing above the default was granted: the one-lane sort and the per-level pyramid launches)
+    }
+    ctx->tuning.lds_limit = limit;
+    if (vsf_prepare_pyramid_kernels(limit) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->tuning.pyramid_chain = 0;
+    }
+    if (vsf_prepare_jpeg_kernels(limit) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->tuning.jpeg_serial = 1;
+    }
+  }
   if (hipMalloc((void**)&ctx->fast_cells, 2 * sizeof(uint32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   if (hipHostMalloc((void**)&ctx->h_status, sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
     return fail(VSF_ERR_HIP);
@@ -1123,9 +1138,10 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
 void vsf_destroy(vsf_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
-  if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
-  if (ctx->blur_stream) hipStreamSynchronize(ctx->blur_stream);
+  // every stream the context ever launched on -- the slots' streams of frames still in flight included: their kernels
+  // write device buffers and pinned host memory that is freed below
+  sync_all_streams(ctx);
+  vsf_tls_hip_error = 0;
   if (ctx->ev_pyr_done) {
     hipEventDestroy(ctx->ev_pyr_done);
     hipEventDestroy(ctx->ev_fast_done);
@@ -1202,7 +1218,18 @@ vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   prof_fold(ctx);
+  // (The handle must be a live stream of this device: the HIP runtime of ROCm 7 dereferences a stream handle without
+  // looking it up -- hipStreamQuery and the launch path alike crashed on a destroyed one in the round-4 test runs -- so a
+  // stale handle cannot be refused here, as with any HIP call that takes a stream.)
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return VSF_OK;
+}
+
+// Test hook: makes the context's thread behave as if a launcher had just noted HIP error `code` (vsf_note): the next entry
+// point that launches must return VSF_ERR_HIP with that code, and the one after it must work again.
+vsf_status vsf_debug_inject_hip_error(vsf_ctx* ctx, int code) {
+  if (!ctx || code <= 0) return VSF_ERR_INVALID_ARG;
+  vsf_note((hipError_t)code);
   return VSF_OK;
 }
 
@@ -1229,7 +1256,61 @@ vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves) {
 
 vsf_status vsf_get_fast_resident(const vsf_ctx* ctx, int* waves) {
   if (!ctx || !waves) return VSF_ERR_INVALID_ARG;
-  *waves = ctx->fast_resident >= 0 ? ctx->fast_resident : ctx->fast_tune.choice;
+  *waves = ctx->fast_resident >= 0 ? ctx->fast_resident : std::max(ctx->fast_tune.choice, 0);
+  return VSF_OK;
+}
+
+vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
+  if (!ctx || option < 0 || option >= VSF_OPT_COUNT) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  VsfTuning& t = ctx->tuning;
+  switch (option) {
+    case VSF_OPT_BLUR_MARCH: t.blur_march = value != 0; break;
+    case VSF_OPT_FAST_BOTH_MAX:
+      if (value < 0) return VSF_ERR_INVALID_ARG;
+      t.fast_both_max = value;
+      break;
+    case VSF_OPT_SORT_SERIAL: t.sort_serial = value != 0; break;
+    case VSF_OPT_SELECT_WIDE: t.select_wide = value != 0; break;
+    case VSF_OPT_JPEG_SERIAL:
+      if (!value && vsf_prepare_jpeg_kernels(t.lds_limit) != hipSuccess) {  // (the parallel decoder's LDS was refused)
+        (void)hipGetLastError();
+        return VSF_ERR_UNSUPPORTED;
+      }
+      t.jpeg_serial = value != 0;
+      break;
+    case VSF_OPT_PYRAMID_FEW:
+      if (value < 0) return VSF_ERR_INVALID_ARG;
+      t.pyramid_few = value;
+      break;
+    case VSF_OPT_PYRAMID_CHAIN:
+      if (value < 0 || value > 64) return VSF_ERR_INVALID_ARG;
+      if (value > 0 && t.lds_limit < 160 * 1024 - 2048) return VSF_ERR_UNSUPPORTED;
+      t.pyramid_chain = value;
+      break;
+    case VSF_OPT_PYRAMID_ROWS:
+      if (value < 1) return VSF_ERR_INVALID_ARG;
+      t.pyramid_rows = value;
+      break;
+    default: return VSF_ERR_INVALID_ARG;
+  }
+  return VSF_OK;
+}
+
+vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
+  if (!ctx || !value) return VSF_ERR_INVALID_ARG;
+  const VsfTuning& t = ctx->tuning;
+  switch (option) {
+    case VSF_OPT_BLUR_MARCH: *value = t.blur_march; break;
+    case VSF_OPT_FAST_BOTH_MAX: *value = t.fast_both_max; break;
+    case VSF_OPT_SORT_SERIAL: *value = t.sort_serial; break;
+    case VSF_OPT_SELECT_WIDE: *value = t.select_wide; break;
+    case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
+    case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
+    case VSF_OPT_PYRAMID_CHAIN: *value = t.pyramid_chain; break;
+    case VSF_OPT_PYRAMID_ROWS: *value = t.pyramid_rows; break;
+    default: return VSF_ERR_INVALID_ARG;
+  }
   return VSF_OK;
 }
 
@@ -1291,6 +1372,55 @@ vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_imag
   return extract_async(ctx, im, d_kp, d_desc, d_counts, true);
 }
 
+vsf_status vsf_tune_fast_resident(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
+                                  size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
+                                  int samples, float* ms_grid, float* ms_resident) {
+  if (!ctx || !d_kp || !d_desc || !d_counts || samples < 1 || samples > 64 || !ms_grid || !ms_resident)
+    return VSF_ERR_INVALID_ARG;
+  *ms_grid = *ms_resident = 0.f;
+  vsf_status st = validate_images(ctx, d_imgs, n_images, image_stride, row_stride);
+  if (st != VSF_OK) return st;
+  VSF_HIP(hipSetDevice(ctx->device));
+  vsf_ctx::FastTune& T = ctx->fast_tune;
+  T.n = n_images;
+  T.choice = 0;
+  // batches the blur does not run beside have one form only
+  if (!(ctx->blur_overlap && !ctx->tuning.blur_march && n_images >= 32 && ctx->blur_stream && ctx->lanes == 1)) return VSF_OK;
+  for (hipEvent_t& e : T.ev)
+    if (!e) VSF_HIP(hipEventCreate(&e));
+  const VsfImages im{d_imgs, image_stride, row_stride, n_images};
+  sync_all_streams(ctx);  // nothing of an earlier call beside the timed runs
+  std::vector<float> ms[2];
+  vsf_status out = VSF_OK;
+  for (int run = 0; run < 1 + 2 * samples && out == VSF_OK; run++) {
+    const int form = run == 0 ? 0 : (run - 1) & 1;  // warm-up (grid), then grid / resident alternately on the SAME input
+    ctx->fast_force = form ? 3 : 0;
+    hipError_t e = hipEventRecord(T.ev[0], ctx->stream);
+    // (inputs_complete = false: no cross-call pipelining inside the measurement, every run is the whole extraction)
+    extract_on(ctx, ctx->stream, im, 0, n_images, d_kp, d_desc, d_counts, false);
+    if (e == hipSuccess) e = hipEventRecord(T.ev[1], ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(T.ev[1]);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, T.ev[0], T.ev[1]);
+    if (e != hipSuccess) {
+      ctx->last_hip = (int)e;
+      out = VSF_ERR_HIP;
+    } else if (run > 0) {
+      ms[form].push_back(t);
+    }
+  }
+  ctx->fast_force = -1;
+  ctx->last_images = im;
+  ctx->last_valid = true;
+  if (out != VSF_OK) return out;
+  VSF_STICKY();
+  for (auto& v : ms) std::sort(v.begin(), v.end());
+  *ms_grid = ms[0][ms[0].size() / 2];
+  *ms_resident = ms[1][ms[1].size() / 2];
+  T.choice = *ms_resident < *ms_grid ? 3 : 0;
+  return VSF_OK;
+}
+
 vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
                                const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs, int32_t* d_idx2,
                                int32_t* d_dist2, vsf_dmatch* d_matches, int32_t* d_nmatches) {
@@ -1310,7 +1440,7 @@ vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_
     match_on(ctx, s, d_desc, d_counts, set_stride, d_q_set, d_t_set, p0, n, d_idx2, d_dist2, d_matches, d_nmatches);
   });
   if (st != VSF_OK) return st;
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1362,7 +1492,7 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
   if (st != VSF_OK) return st;
   ctx->last_images = im;
   ctx->last_valid = true;
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1385,7 +1515,7 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
   VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, ctx->f_F, ctx->p.residual_order, d_thr_override, thr_in,
                            ctx->f_residual, d_means, d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1401,7 +1531,7 @@ vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp
     vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_F, ctx->p.residual_order, ctx->f_residual,
                                 d_means, ctx->stream);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1412,7 +1542,7 @@ vsf_status vsf_stereo_thresholds_dev(vsf_ctx* ctx, const float* d_means, int n, 
     StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
     vsf_launch_stereo_thresholds(d_means, n, d_thr_state, d_thr, ctx->stream);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1430,7 +1560,7 @@ vsf_status vsf_stereo_filter_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, c
     vsf_launch_stereo_filter_only(d_kp, d_desc, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_residual,
                                   d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1472,7 +1602,7 @@ vsf_status vsf_vision_features_batch_dev(vsf_ctx* ctx, const vsf_calibration* ca
     vsf_launch_vision_features(d_kp, d_counts, ctx->v_pairs, ctx->v_npairs, n_frames, (int)K, *calib, d_features,
                                d_nfeatures, d_npoints, ctx->stream);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1505,7 +1635,7 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
     vsf_launch_pack_outputs(d_features, d_nfeatures, n_frames, d_pairs, d_npairs, n_pairs, ctx->p.max_keypoints,
                             d_payload, cap, ctx->pk_offsets, ctx->d_status, ctx->stream);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1523,7 +1653,7 @@ vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, in
   VSF_HIP(hipSetDevice(ctx->device));
   vsf_launch_bayer_bg_gray(d_src, n_images, width, height, src_image_stride, (int)src_row_stride, d_dst,
                            dst_image_stride, (int)dst_row_stride, ctx->stream);
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   // a pipelined extract that follows (vsf_set_pipeline) builds its pyramid off this stream: give it something to wait for
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));
@@ -1543,12 +1673,8 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   for (int i = 0; i < n_images; i++)
     if (!jpeg[i] || nbytes[i] < 4 || nbytes[i] > 0x40000000u) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
-  if (ctx->jp_serial < 0) {
-    const char* env = std::getenv("VSF_JPEG_SERIAL");
-    ctx->jp_serial = (env && env[0] == '1') ? 1 : 0;
-  }
   VsfJpegPlan plan;
-  vsf_status st = vsf_jpeg_plan(jpeg, nbytes, n_images, width, height, ctx->jp_serial != 0, &plan);
+  vsf_status st = vsf_jpeg_plan(jpeg, nbytes, n_images, width, height, ctx->tuning.jpeg_serial != 0, &plan);
   if (st != VSF_OK) return st;
   const int b = ctx->jp_flip;
   ctx->jp_flip ^= 1;
@@ -1597,7 +1723,7 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   vsf_launch_jpeg_decode(ctx->jp_dev[b], plan.off_images, plan.off_index, plan.off_tables, plan.off_stream, plan.total,
                          plan.n_par, n_images - plan.n_par, plan.max_luma_blocks, plan.max_slots, width, height, ctx->jp_clean, ctx->jp_coef,
                          coef_stride, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)
   ctx->ingest_done_valid = true;
@@ -1621,9 +1747,9 @@ vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, co
   {
     StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
     vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, nullptr, ctx->t_sortkeys,
-                         d_pairs, d_npairs, ctx->stream);
+                         d_pairs, d_npairs, ctx->stream, ctx->tuning.sort_serial != 0, ctx->tuning.lds_limit);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   return VSF_OK;
 }
 
@@ -1754,7 +1880,9 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   vsf_keypoint* kp_raw = ctx->st_kp + (size_t)(2 * slot) * K;
   uint8_t* desc_raw = ctx->st_desc + (size_t)(2 * slot) * K * VSF_DESC_BYTES;
   int32_t* counts_raw = ctx->st_counts + 2 * slot;
-  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts, false, o.slots > 1 ? &o.side[slot] : nullptr);
+  int32_t* status_word = ctx->d_status + 1 + slot;  // this frame's own (see vsf_ctx::d_status)
+  extract_on(ctx, ex, im, 2 * slot, 2, ctx->st_kp, ctx->st_desc, ctx->st_counts, false, o.slots > 1 ? &o.side[slot] : nullptr,
+             status_word);
   ctx->last_images = VsfImages{d_img, ctx->st_img_stride, ctx->st_img_pitch, 2};
   ctx->last_valid = true;
   int32_t* nmatches = o.ints + slot;
@@ -1762,7 +1890,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   {
     const size_t scratch = (size_t)(frame_life + 1 + slot) * K * 2;
     match_on(ctx, ex, desc_raw, counts_raw, K * VSF_DESC_BYTES, nullptr, nullptr, 0, 1, ctx->m_idx2 + scratch,
-             ctx->m_dist2 + scratch, raw_matches, nmatches);
+             ctx->m_dist2 + scratch, raw_matches, nmatches, status_word);
   }
   // the tails run in frame order: this frame's waits for the previous frame's (on another slot's stream)
   if (o.slots > 1 && o.next_ticket > 0) {
@@ -1789,12 +1917,12 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   {
     StageTimer t(ctx, s, VSF_STAGE_RATIO, 1);
     vsf_launch_ratio_compact(o.ring_counts, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
-                             ctx->p.ratio_shift, ctx->t_matches, ctx->t_nmatches, ctx->d_status, s);
+                             ctx->p.ratio_shift, ctx->t_matches, ctx->t_nmatches, status_word, s);
   }
   {
     StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
     vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, Kc, best_percent, M.best_percent, ctx->t_sortkeys,
-                         o.pairs, o.npairs, s);
+                         o.pairs, o.npairs, s, ctx->tuning.sort_serial != 0, ctx->tuning.lds_limit);
     // ---- Calculate3DPoints + VisionFeature + UndistortFeaturePoints (cc:437-443) ----
     int32_t *nfeat = o.ints + 4, *npoints = o.ints + 5;
     vsf_launch_vision_features(o.kpf, cur_counts, o.pairs + (size_t)n_past * K * 2, o.npairs + n_past, 1, Kc, *calib,
@@ -1838,12 +1966,12 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
       o.order.push_back(ring_slot);
     }
   }
-  // the status word of everything up to here, then "this frame is done"
-  VSF_HIP(hipMemcpyAsync(o.h_status[slot], ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  VSF_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), s));
+  // the frame's own status word (everything the frame ran wrote into it, nothing else did), then "this frame is done"
+  VSF_HIP(hipMemcpyAsync(o.h_status[slot], status_word, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  VSF_HIP(hipMemsetAsync(status_word, 0, sizeof(int32_t), s));
   VSF_HIP(hipEventRecord(o.ev_done[slot], s));
   o.done_valid[slot] = true;
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   o.ticket_of[slot] = o.next_ticket;
   *ticket = o.next_ticket++;
   return VSF_OK;
@@ -2030,7 +2158,7 @@ static vsf_status match_host(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8
     vsf_launch_ratio_compact(ctx->mh_counts, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
                              ctx->p.ratio_shift, ctx->mh_matches, ctx->mh_nmatches, ctx->d_status, ctx->stream);
   }
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   if (idx2) {
     VSF_HIP(hipMemcpyAsync(idx2, ctx->m_idx2, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     VSF_HIP(hipMemcpyAsync(dist2, ctx->m_dist2, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2104,7 +2232,7 @@ vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const in
                   ctx->stream);
   vsf_launch_ratio_compact(ctx->mm_counts, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
                            ctx->p.ratio_shift, ctx->mm_matches, ctx->mm_nmatches, ctx->d_status, ctx->stream);
-  VSF_HIP(hipGetLastError());
+  VSF_STICKY();
   std::vector<int32_t> nm(S);
   VSF_HIP(hipMemcpyAsync(nm.data(), ctx->mm_nmatches, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
@@ -2187,7 +2315,8 @@ vsf_status vsf_debug_sort_trim(vsf_ctx* ctx, const vsf_dmatch* matches, int n_li
   for (int i = 0; i < n_lists && e == hipSuccess && n > 0; i++)
     e = hipMemcpy(dm + (size_t)i * K, matches + (size_t)i * n, (size_t)n * sizeof(vsf_dmatch), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    vsf_launch_sort_trim(dm, dn, n_lists, (int)K, best_percent, nullptr, dscratch, dp, dc, ctx->stream, serial != 0);
+    vsf_launch_sort_trim(dm, dn, n_lists, (int)K, best_percent, nullptr, dscratch, dp, dc, ctx->stream, serial != 0,
+                         ctx->tuning.lds_limit);
     e = hipStreamSynchronize(ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpy(counts_out, dc, (size_t)n_lists * sizeof(int32_t), hipMemcpyDeviceToHost);

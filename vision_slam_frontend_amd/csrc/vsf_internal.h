@@ -83,6 +83,34 @@ struct VsfGeom {
   uint64_t pyramid_pixels;
 };
 
+// Per-context launch choices (vsf_set_option / vsf_get_option; the defaults are what the measurements of DESIGN.md
+// section 6 settled on).  Nothing in the library reads the environment: a switch is a call on a context.
+struct VsfTuning {
+  int blur_march = 0;      // VSF_OPT_BLUR_MARCH: 1 = round 2's vector-ALU blur kernel instead of the matrix-core one (A/B runs)
+  int fast_both_max = 16;  // VSF_OPT_FAST_BOTH_MAX: largest batch (images) whose full and half-wave FAST cells share one launch
+  int sort_serial = 0;     // VSF_OPT_SORT_SERIAL: 1 = sort_trim's one-lane kernel
+  int select_wide = 1;     // VSF_OPT_SELECT_WIDE: 1 = a frame or two takes the 1024-thread whole-level selection class
+  int jpeg_serial = 0;     // VSF_OPT_JPEG_SERIAL: 1 = every file through the one-wave-per-image decoder
+  int pyramid_few = 16;    // VSF_OPT_PYRAMID_FEW: largest batch (images) that takes the slab kernel for every level
+  int pyramid_chain = 8;   // VSF_OPT_PYRAMID_CHAIN: levels per slab launch (0: keep the per-level launches)
+  int pyramid_rows = 6;    // VSF_OPT_PYRAMID_ROWS: rows of the chain's last level per slab
+  int lds_limit = 0;       // largest dynamic LDS a workgroup may ask for on this device (queried at vsf_create)
+};
+
+// First HIP error a launcher or a stream-plumbing helper met since the last check (host thread-local: a context is driven
+// by one host thread at a time).  Launchers return void; they hand failures to vsf_note() and the entry point that called
+// them turns the noted error into VSF_ERR_HIP (VSF_STICKY in vsf_api.hip) -- a failed event wait would otherwise silently
+// remove an ordering edge between two kernels.
+extern thread_local int vsf_tls_hip_error;
+inline void vsf_note(hipError_t e) {
+  if (e != hipSuccess && vsf_tls_hip_error == 0) vsf_tls_hip_error = (int)e;
+}
+// Raises the dynamic-LDS limit of the kernels that need more than the default 64 KB (k_frontend / k_pyramid / k_jpeg);
+// called once per context creation, checked.
+hipError_t vsf_prepare_sort_kernels(int lds_limit);
+hipError_t vsf_prepare_pyramid_kernels(int lds_limit);
+hipError_t vsf_prepare_jpeg_kernels(int lds_limit);
+
 // Kernel launchers (implemented in the k_*.hip files). All asynchronous on `s`.
 struct VsfDev {
   const VsfLevel* levels;   // [nlevels]
@@ -96,6 +124,7 @@ struct VsfDev {
   const uint2* ic_table;    // [4][VSF_IC_ITEMS] ICAngles byte weights (k_describe.hip)
   int32_t* lvl_count;       // [max_images][nlevels]
   int32_t* status;          // device status word (bit 0: capacity overflow)
+  const VsfTuning* tune;    // the context's launch choices (host memory)
 };
 
 struct VsfImages {
@@ -163,7 +192,7 @@ void vsf_launch_pack_outputs(const vsf_vision_feature* d_features, const int32_t
                              hipStream_t s);
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
                           float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
-                          int32_t* d_npairs, hipStream_t s, bool force_serial = false);
+                          int32_t* d_npairs, hipStream_t s, bool force_serial = false, int lds_limit = 160 * 1024);
 // vsf_observe_stereo's output kernel (k_frontend.hip)
 #define VSF_OBSERVE_MAX_PAIRS 64
 struct VsfObserveArgs {

@@ -15,7 +15,6 @@ CPU tensors in the CPU test-suite.
 """
 from __future__ import annotations
 
-import os
 import time
 from typing import Dict, List, Optional, Sequence
 
@@ -181,6 +180,90 @@ def collective_handshake(device=None) -> dict:
             "nccl_version": version, "ranks_seen": [int(v) for v in seen.cpu().tolist()]}
 
 
+class _Done:
+    """A finished collective (interface of torch's Work object)."""
+
+    def wait(self):
+        return True
+
+
+class TorchComm:
+    """The step's exchanges on torch.distributed: "nccl" (= RCCL over xGMI, device tensors, stream-ordered) in production,
+    "gloo" (tensors take a detour through the host) for one-GPU rehearsals and the CPU-side tests."""
+
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.host_detour = dist.get_backend() == "gloo"
+        self.name = "torch.distributed/" + dist.get_backend()
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, stream):
+        if self.host_detour:
+            stream.synchronize()
+            h_in = inp.contiguous().cpu().reshape(-1)
+            parts = [torch.empty_like(h_in) for _ in range(self.world)]
+            dist.all_gather(parts, h_in)
+            out.view(-1).copy_(torch.cat(parts).to(out.device))
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().reshape(-1))
+
+    def gather_async(self, send: torch.Tensor, recv, dst: int = 0):
+        """recv: per-rank receive tensors on dst, None elsewhere.  Returns (work, the tensor that must stay alive)."""
+        if self.host_detour:
+            send = send.cpu()
+        return dist.gather(send, recv, dst=dst, async_op=True), send
+
+    def all_reduce_max(self, values, device):
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.host_detour else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+
+class ThreadWorld:
+    """Shared state of a world whose ranks are THREADS of one process (ThreadComm): a barrier and one slot per rank."""
+
+    def __init__(self, world: int):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class ThreadComm:
+    """The same exchanges between ranks that are threads of ONE process on ONE GPU -- a rehearsal vehicle: a GPU box admits
+    only a handful of processes on its card, so a world of eight cannot be eight processes there, but the sharding logic
+    (frame blocks, threshold chain, tail exchange, sized gather) does not care what carries the bytes.  Every exchange is
+    a rendezvous through host memory: publish, barrier, read, barrier."""
+
+    def __init__(self, shared: ThreadWorld, rank: int):
+        self.shared, self.world, self.rank = shared, shared.world, rank
+        self.host_detour = True
+        self.name = "threads of one process (rehearsal)"
+
+    def _exchange(self, mine):
+        sh = self.shared
+        sh.slots[self.rank] = mine
+        sh.barrier.wait()
+        every = list(sh.slots)
+        sh.barrier.wait()
+        return every
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, stream):
+        stream.synchronize()
+        parts = self._exchange(inp.contiguous().cpu().reshape(-1))
+        out.view(-1).copy_(torch.cat(parts).to(out.device))
+
+    def gather_async(self, send: torch.Tensor, recv, dst: int = 0):
+        parts = self._exchange(send.cpu())
+        if self.rank == dst:
+            for r, part in zip(recv, parts):
+                r.copy_(part)
+        return _Done(), send
+
+    def all_reduce_max(self, values, device):
+        every = self._exchange(list(values))
+        return [max(col) for col in zip(*every)]
+
+
 class ShardedStereoFrontend:
     """One rank's share of a time-ordered stereo stream, one step = `frames_per_rank` frames on this GPU.
 
@@ -212,19 +295,24 @@ class ShardedStereoFrontend:
     PAYLOAD_SLOTS = 3
 
     def __init__(self, ctx, frames_per_rank: int, width: int, height: int, calib, *, window: int = 1,
-                 best_percent: float = 0.3, device=None, stream=None, overlap: bool = True):
+                 best_percent: float = 0.3, device=None, stream=None, overlap: bool = True,
+                 force_collectives: bool = False, comm=None):
         from . import capi  # (ctx is a capi.Context)
 
         self.ctx, self.B, self.W = ctx, int(frames_per_rank), int(window)
         self.width, self.height = int(width), int(height)
         self.calib = calib
         self.best_percent = float(np.float32(best_percent))
-        # (VSF_FORCE_COLLECTIVES=1 runs every collective even in a world of one: the RCCL code path on a one-GPU box)
-        self.dist_on = dist.is_available() and dist.is_initialized() and (
-            dist.get_world_size() > 1 or bool(os.environ.get("VSF_FORCE_COLLECTIVES")))
-        self.world = dist.get_world_size() if self.dist_on else 1
-        self.rank = dist.get_rank() if self.dist_on else 0
-        self.host_detour = self.dist_on and dist.get_backend() == "gloo"
+        # What carries the exchanges: `comm` (TorchComm, ThreadComm, or the C-ABI route CapiComm) -- by default
+        # torch.distributed when a process group of more than one rank exists (force_collectives runs every collective even
+        # in a world of one: the RCCL code path on a one-GPU box).
+        if comm is None and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives):
+            comm = TorchComm()
+        self.comm = comm
+        self.dist_on = comm is not None
+        self.world = comm.world if comm else 1
+        self.rank = comm.rank if comm else 0
+        self.host_detour = bool(comm and comm.host_detour)
         if not 0 <= self.W <= self.B:
             raise ValueError("window must be in [0, frames_per_rank]")
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -316,6 +404,26 @@ class ShardedStereoFrontend:
             self.tail_ctx.close()
             self.tail_ctx = None
 
+    # ---- the one measured launch choice, made the same on every rank ----
+    def tune(self, d_img: torch.Tensor, samples: int = 3) -> dict:
+        """Explicit and blocking (set-up, never inside a timed region): vsf_tune_fast_resident times the two forms of the
+        FAST launch on this rank's own batch (median of `samples` runs each), then ONE all-reduce (max over ranks) of the
+        two medians makes the choice common: the step time of the job is its slowest rank's, and ranks that ran different
+        forms would hand each other a persistent per-step skew through the means all-gather.  Every rank issues exactly
+        this one collective whatever its own measurement returned (no rank-dependent control flow)."""
+        raw = self.raw[0]
+        with torch.cuda.stream(self.stream):
+            g, r = self.ctx.tune_fast_resident(d_img.data_ptr(), 2 * self.B, self.width * self.height, self.width,
+                                               raw["kp"].data_ptr(), raw["desc"].data_ptr(), raw["counts"].data_ptr(),
+                                               samples)
+        mine = (g, r)
+        if self.dist_on:
+            g, r = self.comm.all_reduce_max([g, r], self.dev)
+        choice = 3 if (r > 0.0 and r < g) else 0
+        self.ctx.set_fast_resident(choice)
+        return {"ms_grid": g, "ms_resident": r, "this_rank_ms": list(mine), "fast_resident": choice, "samples": samples,
+                "agreed_over_ranks": self.world}
+
     # ---- static schedule of the temporal pairs ----
     def _pair_sets(self, parity: int, first_step: bool):
         q, t = temporal_pair_sets(self.B, self.W, self.world, self.rank, parity, first_step)
@@ -337,14 +445,7 @@ class ShardedStereoFrontend:
         if not self.dist_on:
             out.view(-1).copy_(inp.reshape(-1))
             return
-        if self.host_detour:
-            self.tail_stream.synchronize()
-            h_in = inp.contiguous().cpu().reshape(-1)
-            parts = [torch.empty_like(h_in) for _ in range(self.world)]
-            dist.all_gather(parts, h_in)
-            out.view(-1).copy_(torch.cat(parts).to(out.device))
-        else:
-            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().reshape(-1))
+        self.comm.all_gather(out, inp, self.tail_stream)
 
     # ---- one step ----
     def step(self, d_img: torch.Tensor):
@@ -400,13 +501,10 @@ class ShardedStereoFrontend:
         self.blocked_s += time.perf_counter() - t0
         nbytes = int(self.sizes_host[slot].max())
         nbytes = min((nbytes + 15) & ~15, self.cap)
-        send = self.payload[slot][:nbytes]
-        recv = None
+        recv = [b[:nbytes] for b in self.recv[slot]] if self.rank == 0 else None
         if self.host_detour:
-            send = send.cpu()
-        if self.rank == 0:
-            recv = [b[:nbytes] for b in self.recv[slot]]
-        work = dist.gather(send, recv, dst=0, async_op=True)
+            self.tail_stream.synchronize()  # (the payload is about to be read by the host)
+        work, send = self.comm.gather_async(self.payload[slot][:nbytes], recv, dst=0)
         self.inflight.append((step, work, send, recv))
         self.next_gather = step + 1
 

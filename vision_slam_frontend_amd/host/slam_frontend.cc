@@ -227,13 +227,22 @@ Frontend::Frontend(const std::string& /*config_path*/, const FrontendConfig& con
   if (config_.image_width > 0 && config_.image_height > 0) EnsureContext(config_.image_width, config_.image_height);
 }
 
-Frontend::~Frontend() { vsf_destroy(ctx_); }
+// Frames still in flight (pipelined mode) are dropped, not booked: nobody can read the problem any more.  vsf_destroy
+// waits for every stream of the context -- the slots' included -- before it frees what their kernels write.
+Frontend::~Frontend() {
+  pending_.clear();
+  vsf_destroy(ctx_);
+}
 
 bool Frontend::EnsureContext(int width, int height) {
   if (ctx_) {
     vsf_params p;
     vsf_get_params(ctx_, &p);
     if (p.width == width && p.height == height && p.max_images >= (pipelined_ ? 6 : 2)) return true;
+    // the context is replaced (another image size, or pipelining switched on): the frames still in flight belong to the
+    // old one and are booked first, in order; whatever that returns, their tickets die with the context
+    Flush();
+    pending_.clear();
     vsf_destroy(ctx_);
     ctx_ = nullptr;
   }
