@@ -73,37 +73,33 @@ __device__ __forceinline__ T uniform_copy(const T* p) {
   return out;
 }
 
-// One image row as seen by a lane: its own 4 pixels (d) and the neighbouring lanes' (p = left, n = right).
-struct Row3 {
-  uint32_t p, d, n;
+// One image row as a lane holds it while the row is inside the 7-row window.  The lane's 4 pixels are bytes 4..7 of the
+// 12-byte run {previous lane's dword, own dword, next lane's dword}; b<B> is the pair (byte B, byte B + 2) zero-extended
+// into the two 16-bit halves -- the layout the score works on: pixel pairs (x, x + 2) and (x + 1, x + 3), so that the
+// second pair's circle pixel at column offset dx IS the first pair's at dx + 1.  Over its seven steps in the window a row
+// is asked for exactly the eight pairs b1 .. b8 (as row y +- 3: b3..b6, y +- 2: b2, b3, b6, b7, y +- 1 and y: b1, b2, b7, b8
+// and, as the centre row, b4 / b5 themselves), so they are made ONCE when the row enters -- 3 mask / shift operations, 4
+// DPP moves and 4 v_alignbit -- instead of one v_perm_b32 per use (34 per step in round 3's kernel: profiles/r04/).
+struct RowP {
+  uint32_t d;                            // the raw dword (row pre-check)
+  v2s b1, b2, b3, b4, b5, b6, b7, b8;
 };
 
-// Bytes B and B+1 of the 12-byte run {p, d, n}, zero-extended into the two 16-bit halves.
-template <int B>
-__device__ __forceinline__ v2s pick2(const Row3& r) {
-  static_assert(B >= 0 && B + 1 <= 11, "byte range");
-  if constexpr (B + 1 <= 7) {
-    constexpr uint32_t sel = (uint32_t)B | 0x0C000C00u | ((uint32_t)(B + 1) << 16);
-    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.d, r.p, sel));
-  } else {
-    constexpr uint32_t sel = (uint32_t)(B - 4) | 0x0C000C00u | ((uint32_t)(B - 3) << 16);
-    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.n, r.d, sel));
-  }
-}
+__device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
 
-// Bytes B and B+2 of the same run: the pixel pairs the score works on are (x, x+2) and (x+1, x+3), so that the second
-// pair's circle pixel at column offset dx IS the first pair's at dx + 1 -- four of the 34 picks of a lane-row coincide
-// (the three-pixel rows y +- 3 of the circle) and are computed once.
-template <int B>
-__device__ __forceinline__ v2s pick2s(const Row3& r) {
-  static_assert(B >= 0 && B + 2 <= 11, "byte range");
-  if constexpr (B + 2 <= 7) {
-    constexpr uint32_t sel = (uint32_t)B | 0x0C000C00u | ((uint32_t)(B + 2) << 16);
-    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.d, r.p, sel));
-  } else {
-    constexpr uint32_t sel = (uint32_t)(B - 4) | 0x0C000C00u | ((uint32_t)(B - 2) << 16);
-    return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(r.n, r.d, sel));
-  }
+__device__ __forceinline__ void prep_row(RowP& r) {
+  const uint32_t e = r.d & 0x00FF00FFu, o = (r.d >> 8) & 0x00FF00FFu;  // (byte 4, byte 6), (byte 5, byte 7)
+  const uint32_t ep = wave_shr1(e), op = wave_shr1(o);                 // (0, 2), (1, 3)
+  const uint32_t en = wave_shl1(e), on = wave_shl1(o);                 // (8, 10), (9, 11)
+  r.b1 = as_v2s(op);
+  r.b2 = as_v2s(__builtin_amdgcn_alignbit(e, ep, 16));                 // (2, 4)
+  r.b3 = as_v2s(__builtin_amdgcn_alignbit(o, op, 16));                 // (3, 5)
+  r.b4 = as_v2s(e);
+  r.b5 = as_v2s(o);
+  r.b6 = as_v2s(__builtin_amdgcn_alignbit(en, e, 16));                 // (6, 8)
+  r.b7 = as_v2s(__builtin_amdgcn_alignbit(on, o, 16));                 // (7, 9)
+  r.b8 = as_v2s(en);
 }
 
 __device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
@@ -119,33 +115,20 @@ __device__ __forceinline__ v2s vmax3(v2s a, v2s b, v2s c) {
   asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// max(a - b, 0) per half (v_pk_sub_u16 with clamp): a, b in 0 .. 255
+__device__ __forceinline__ v2s vsubsat(v2s a, v2s b) {
+  typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
+}
 
-// Scores of the two pixels at bytes 4+J0, 6+J0 of the centre row R3 (J0 = 0: the lane's pixels 0 and 2, J0 = 1: pixels 1
-// and 3); R0..R6 are rows y-3..y+3.
-// Returns the two scores (0 = not a corner; a marker 1 when nms == 0) in the two 16-bit halves.
-template <int J0, bool NMS>
-__device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3,
-                                          const Row3& R4, const Row3& R5, const Row3& R6, v2s tt) {
-  const v2s v = pick2s<4 + J0>(R3);
-  v2s d[16];  // circle pixels p_k; min / max commute with the subtraction of v, which is applied once at the end
-  // Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
-  // (-3,0)(-3,1)(-2,2)(-1,3); window row = R[3 + dy].
-  d[0] = pick2s<4 + J0 + 0>(R6);
-  d[1] = pick2s<4 + J0 + 1>(R6);
-  d[2] = pick2s<4 + J0 + 2>(R5);
-  d[3] = pick2s<4 + J0 + 3>(R4);
-  d[4] = pick2s<4 + J0 + 3>(R3);
-  d[5] = pick2s<4 + J0 + 3>(R2);
-  d[6] = pick2s<4 + J0 + 2>(R1);
-  d[7] = pick2s<4 + J0 + 1>(R0);
-  d[8] = pick2s<4 + J0 + 0>(R0);
-  d[9] = pick2s<4 + J0 - 1>(R0);
-  d[10] = pick2s<4 + J0 - 2>(R1);
-  d[11] = pick2s<4 + J0 - 3>(R2);
-  d[12] = pick2s<4 + J0 - 3>(R3);
-  d[13] = pick2s<4 + J0 - 3>(R4);
-  d[14] = pick2s<4 + J0 - 2>(R5);
-  d[15] = pick2s<4 + J0 - 1>(R6);
+// Scores of two pixels of the centre row R3 from the 16 circle pixel pairs d[k] and the centre pair v.
+// Returns, per 16-bit half, max(cornerScore + 1 - offs, 0) with offs = max(t, 1): zero for a pixel that is no corner (or,
+// at t = 0, a corner of score 0, which can never win the strict suppression: cv::FAST_t compares against neighbours >= 0),
+// cornerScore - (offs - 1) >= 1 otherwise -- an order-preserving offset, so the suppression compares these values as it
+// would the scores and the emitter adds offs - 1 back.  (NMS == false: a marker 1 for every corner, as cv::FAST_t leaves
+// the response at 0 then; `toff` = t in that instance.)
+template <bool NMS>
+__device__ __forceinline__ v2s score_from_circle(const v2s (&d)[16], v2s v, v2s toff) {
   // Arc k = d[k .. k+8] (indices mod 16).  Arcs 2j and 2j+1 share the eight pixels C = d[2j+1 .. 2j+8]:
   //   max(min(d[2j], C), min(C, d[2j+9])) = min(C, max(d[2j], d[2j+9]))                       (distributive lattice)
   // and C is four pixel pairs E_i = min(d[2i+1], d[2i+2]), i = j .. j+3, i.e. two quads F_i = min(E_i, E_{i+1}):
@@ -173,37 +156,47 @@ __device__ __forceinline__ v2s score_pair(const Row3& R0, const Row3& R1, const 
   }
   const v2s A = vmax(vmax3(vmax3(ta[0], ta[1], ta[2]), vmax3(ta[3], ta[4], ta[5]), ta[6]), ta[7]);
   const v2s Bm = vmin(vmin3(vmin3(tb[0], tb[1], tb[2]), vmin3(tb[3], tb[4], tb[5]), tb[6]), tb[7]);
-  // cornerScore<16> = max(t, A, -Bm) - 1; a corner iff that maximum exceeds t.  With NMS a corner of score 0 can
-  // never win (cv::FAST_t compares strictly against neighbours >= 0); without NMS only a corner marker is kept
-  // (cv::FAST_t leaves the response at 0 then).
+  // cornerScore<16> = max(t, A - v, v - Bm) - 1; a corner iff max(A - v, v - Bm) > t.  Saturating subtractions: 4 ops.
+  const v2s sc = vsubsat(vmax(vsubsat(A, v), vsubsat(v, Bm)), toff);
   const v2s one = {1, 1};
-  const v2s sc = vmax(A - v, v - Bm);
-  const v2s m = (tt - sc) >> 15;  // all ones where sc > t
-  return NMS ? ((sc - one) & m) : (m & one);
+  return NMS ? sc : vmin(sc, one);
 }
 
-// One score row as the NMS needs it: the 4 score bytes, the centre pairs, and the horizontal maxima.
+// Pixels 0 and 2 (J0 = 0) or 1 and 3 (J0 = 1) of the lane; R0..R6 are rows y-3 .. y+3.
+// Bresenham circle, OpenCV order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
+// (-3,0)(-3,1)(-2,2)(-1,3); window row = R[3 + dy]; pair index = 4 + J0 + dx.
+template <bool NMS>
+__device__ __forceinline__ v2s score_pair0(const RowP& R0, const RowP& R1, const RowP& R2, const RowP& R3, const RowP& R4,
+                                           const RowP& R5, const RowP& R6, v2s toff) {
+  const v2s d[16] = {R6.b4, R6.b5, R5.b6, R4.b7, R3.b7, R2.b7, R1.b6, R0.b5, R0.b4, R0.b3, R1.b2, R2.b1, R3.b1, R4.b1, R5.b2, R6.b3};
+  return score_from_circle<NMS>(d, R3.b4, toff);
+}
+template <bool NMS>
+__device__ __forceinline__ v2s score_pair1(const RowP& R0, const RowP& R1, const RowP& R2, const RowP& R3, const RowP& R4,
+                                           const RowP& R5, const RowP& R6, v2s toff) {
+  const v2s d[16] = {R6.b5, R6.b6, R5.b7, R4.b8, R3.b8, R2.b8, R1.b7, R0.b6, R0.b5, R0.b4, R1.b3, R2.b2, R3.b2, R4.b2, R5.b3, R6.b4};
+  return score_from_circle<NMS>(d, R3.b5, toff);
+}
+
+// One score row as the NMS needs it, in the same pair layout: s02 = (s0, s2), s13 = (s1, s3) of the lane's pixels and
+// the horizontal maxima of their neighbours.
 struct ScoreRow {
-  uint32_t s;       // score bytes of the lane's 4 pixels
-  v2s c01, c23;     // the same as 16-bit pairs
-  v2s h3a, h3b;     // max(s[x-1], s[x], s[x+1]) for pixel pairs (0,1) and (2,3)
+  v2s s02, s13;
+  v2s h3a, h3b;     // max(s[x-1], s[x], s[x+1]) for pixels (0, 2) and (1, 3)
   v2s h2a, h2b;     // max(s[x-1], s[x+1])
 };
 
-__device__ __forceinline__ ScoreRow make_score_row(uint32_t S) {
-  Row3 r;
-  r.d = S;
-  r.p = wave_shr1(S);
-  r.n = wave_shl1(S);
+__device__ __forceinline__ ScoreRow make_score_row(v2s s02, v2s s13) {
   ScoreRow o;
-  o.s = S;
-  const v2s b3 = pick2<3>(r), b5 = pick2<5>(r), b7 = pick2<7>(r);
-  o.c01 = pick2<4>(r);
-  o.c23 = pick2<6>(r);
-  o.h2a = vmax(b3, b5);
-  o.h2b = vmax(b5, b7);
-  o.h3a = vmax(o.h2a, o.c01);
-  o.h3b = vmax(o.h2b, o.c23);
+  o.s02 = s02;
+  o.s13 = s13;
+  // left / right neighbours of pixels (0, 2) are (prev lane's s3, s1) and (s1, s3); of pixels (1, 3): (s0, s2) and (s2, next s0)
+  const v2s x = as_v2s(__builtin_amdgcn_alignbit(as_u32(s13), wave_shr1(as_u32(s13)), 16));
+  const v2s y = as_v2s(__builtin_amdgcn_alignbit(wave_shl1(as_u32(s02)), as_u32(s02), 16));
+  o.h2a = vmax(x, s13);
+  o.h2b = vmax(s02, y);
+  o.h3a = vmax3(x, s13, s02);
+  o.h3b = vmax3(s02, y, s13);
   return o;
 }
 
@@ -234,8 +227,9 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
     pitch = L.pitch;
   }
   const int t = a.threshold;
-  constexpr bool nms = NMS;
-  const v2s tt = {(short)t, (short)t};
+  // score offset (see score_from_circle): the emitter adds offs - 1 back
+  const int offs = NMS ? max(t, 1) : t;
+  const v2s toff = {(short)offs, (short)offs};
   constexpr int HL = HALF ? 32 : 64;                        // lanes per cell
   const int half = HALF ? (lane >> 5) : 0, hl = lane & (HL - 1);
   const int strip = strip0 + half;
@@ -248,20 +242,33 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
   const int nrows0 = min(SR, L.y_hi - (L.y_lo + strip0 * SR));  // rows of the first cell (>= the second's): uniform
   // Pixels that may carry a score: FAST's 3-pixel rim and one column beyond the keypoint rectangle (for the NMS).
   const int sx_lo = max(L.x_lo - 1, 3), sx_hi = min(L.x_hi + 1, L.w - 3);
-  uint32_t smask = 0, emask = 0;  // per-pixel byte masks: may be scored / may be emitted
+  uint32_t sm02 = 0, sm13 = 0, em02 = 0, em13 = 0;  // per-pixel 16-bit masks in the pair layout: may be scored / emitted
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int x = c0 + j;
-    if (hl >= 1 && hl <= HL - 2 && x >= sx_lo && x < sx_hi) smask |= 0xFFu << (8 * j);
-    if (hl >= 2 && hl <= HL - 3 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS) emask |= 0xFFu << (8 * j);
+    const uint32_t bit = 0xFFFFu << (16 * (j >> 1));
+    const bool sc_ok = hl >= 1 && hl <= HL - 2 && x >= sx_lo && x < sx_hi;
+    const bool em_ok = hl >= 2 && hl <= HL - 3 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS;
+    if (j & 1) {
+      if (sc_ok) sm13 |= bit;
+      if (em_ok) em13 |= bit;
+    } else {
+      if (sc_ok) sm02 |= bit;
+      if (em_ok) em02 |= bit;
+    }
   }
-  if (!valid) smask = emask = 0;
-  const v2s em01 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, emask, 0x0C010C00u));
-  const v2s em23 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, emask, 0x0C030C02u));
+  if (!valid) sm02 = sm13 = em02 = em13 = 0;
   const int unit_local = (valid ? strip : strip0) * L.nbands + band;
-  uint32_t* seg = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)unit_local * L.seg_cap;
   uint16_t* rs = a.rowstart + ((size_t)image * a.nunits + L.unit0 + unit_local) * VSF_FAST_RS_STRIDE;
   const int seg_cap = L.seg_cap, hrow = L.h;
+  // Candidate stores go through a buffer descriptor over the cell's segment: an entry beyond the segment's capacity is
+  // dropped by the range check of the store itself (no compare, no 64-bit address arithmetic per store).  HALF: one
+  // descriptor from the first cell's segment to the end of the second's (L.nbands segments further), the second cell's
+  // lanes add that distance -- and check their capacity themselves, since a first-cell overflow would still be in range.
+  uint32_t* seg0 = a.cand + (size_t)image * a.cand_entries + L.cand_offset + (size_t)(strip0 * L.nbands + band) * L.seg_cap;
+  const __amdgpu_buffer_rsrc_t seg_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(seg0, 0, (HALF ? L.nbands + 1 : 1) * seg_cap * 4, 0x00020000);
+  const uint32_t seg_off = (HALF && half && valid) ? (uint32_t)(L.nbands * seg_cap * 4) : 0u;
 
   // buffer loads: a lane's column offset sits in a VGPR, the row offset in an SGPR (per lane when HALF); reads outside
   // the level return 0
@@ -270,69 +277,79 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
   // (a lane outside the row gets an offset beyond the buffer instead of a branch around the load: no divergent control
   // flow, so the row offset stays in an SGPR)
   const uint32_t col_off = loadable ? (uint32_t)c0 : 0xFFFFFFF0u;
-  auto load_row = [&](int q) -> Row3 {  // row ys - 1 + q of this lane's cell
-    Row3 r;
+  auto load_row = [&](int q) -> uint32_t {  // row ys - 1 + q of this lane's cell
     const int yc = min(max(ys - 1 + q, 0), hrow - 1);
     if (HALF)
-      r.d = __builtin_amdgcn_raw_buffer_load_b32(
+      return __builtin_amdgcn_raw_buffer_load_b32(
           src_rsrc, loadable ? __umul24((uint32_t)yc, (uint32_t)pitch) + (uint32_t)c0 : 0xFFFFFFF0u, 0u, 0);  // (full-rate multiply)
-    else
-      r.d = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, col_off, (uint32_t)(yc * pitch), 0);
-    r.p = wave_shr1(r.d);
-    r.n = wave_shl1(r.d);
-    return r;
+    return __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, col_off, (uint32_t)(yc * pitch), 0);
   };
 
-  ScoreRow S0 = make_score_row(0u), S1 = S0, S2 = S0;  // score rows rotate through three sets: q-2, q-1, q
+  const unsigned long long scorable = __builtin_amdgcn_ballot_w64((sm02 | sm13) != 0u);
+  const v2s zero2 = {0, 0};
+  ScoreRow S0 = make_score_row(zero2, zero2), S1 = S0, S2 = S0;  // score rows rotate through three sets: q-2, q-1, q
   int count_lo = 0, count_hi = 0;  // candidates emitted so far by the cell(s) (wave-uniform)
-  int my_rs = 0;                   // lane hl keeps rowstart[hl] of its cell
+  uint32_t my_rs = 0;              // lane hl keeps rowstart[hl] of its cell
+  // (cell row, first column, score offset) of an emitted candidate: score << 24 | y << 12 | x
+  const uint32_t yx0 = ((uint32_t)ys << 12) + (uint32_t)c0 + ((uint32_t)(NMS ? offs - 1 : 0) << 24);
 
   // One step: scores of cell row q - 1 (image row ys - 1 + q) from the window R0..R6 = image rows ys - 4 + q .. ys + 2 + q,
   // then NMS + emission of cell row q - 2.
-  auto step = [&](int q, const Row3& R0, const Row3& R1, const Row3& R2, const Row3& R3, const Row3& R4,
-                  const Row3& R5, const Row3& R6, const ScoreRow& S_up, const ScoreRow& S_mid, ScoreRow& S_dn) {
-    uint32_t S = 0;
+  auto step = [&](int q, const RowP& R0, const RowP& R1, const RowP& R2, const RowP& R3, const RowP& R4,
+                  const RowP& R5, RowP& R6, const ScoreRow& S_up, const ScoreRow& S_mid, ScoreRow& S_dn) {
+    prep_row(R6);  // the row that has just entered the window
+    v2s s02 = zero2, s13 = zero2;
     const int sy = ys - 1 + q;
     const bool row_ok = sy >= 3 && sy < hrow - 3;  // (wave-uniform unless HALF)
     // a 9-arc contains circle pixel 0 (row sy+3) or 8 (row sy-3), both in the centre pixel's column
     const uint32_t far = max(__builtin_amdgcn_sad_u8(R0.d, R3.d, 0u), __builtin_amdgcn_sad_u8(R6.d, R3.d, 0u));
-    if (__any(row_ok && smask != 0 && far > (uint32_t)t)) {
-      const v2s r02 = score_pair<0, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);  // pixels 0 and 2
-      const v2s r13 = score_pair<1, NMS>(R0, R1, R2, R3, R4, R5, R6, tt);  // pixels 1 and 3
-      S = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, r13), __builtin_bit_cast(uint32_t, r02), 0x06020400u);
-      S &= row_ok ? smask : 0u;
+    // (one v_cmp; the lanes that may score at all are a ballot taken once, the row test is scalar unless HALF)
+    const unsigned long long want = __builtin_amdgcn_ballot_w64(far > (uint32_t)t) & scorable &
+                                    (HALF ? __builtin_amdgcn_ballot_w64(row_ok) : (row_ok ? ~0ull : 0ull));
+    if (want != 0ull) {
+      s02 = score_pair0<NMS>(R0, R1, R2, R3, R4, R5, R6, toff);  // pixels 0 and 2
+      s13 = score_pair1<NMS>(R0, R1, R2, R3, R4, R5, R6, toff);  // pixels 1 and 3
+      s02 = as_v2s(as_u32(s02) & ((!HALF || row_ok) ? sm02 : 0u));
+      s13 = as_v2s(as_u32(s13) & ((!HALF || row_ok) ? sm13 : 0u));
     }
-    S_dn = make_score_row(S);
+    S_dn = make_score_row(s02, s13);
     const int r = q - 2;  // cell row to emit
     if (r >= 0 && r < nrows0) {
-      const uint32_t em = r < nrows ? emask : 0u;  // (the second cell may have fewer rows)
-      if (__any((S_mid.s & em) != 0)) {
-        // keep iff score > every 8-neighbour (strict); without NMS every marked corner is kept
-        const v2s zero = {0, 0};
-        const v2s nb01 = nms ? vmax3(S_up.h3a, S_dn.h3a, S_mid.h2a) : zero;  // (scores are 0..255 as well)
-        const v2s nb23 = nms ? vmax3(S_up.h3b, S_dn.h3b, S_mid.h2b) : zero;
-        uint32_t k01 = __builtin_bit_cast(uint32_t, ((nb01 - S_mid.c01) >> 15) & em01);
-        uint32_t k23 = __builtin_bit_cast(uint32_t, ((nb23 - S_mid.c23) >> 15) & em23);
-        if (r >= nrows) k01 = k23 = 0;
+      if (__any((as_u32(S_mid.s02) | as_u32(S_mid.s13)) != 0)) {
+        // keep iff score > every 8-neighbour (strict); without NMS every marked corner is kept.  k02 / k13: the score (or
+        // marker) of a survivor, 0 elsewhere.
+        uint32_t k02, k13;
+        if (NMS) {
+          const v2s nb02 = vmax3(S_up.h3a, S_dn.h3a, S_mid.h2a), nb13 = vmax3(S_up.h3b, S_dn.h3b, S_mid.h2b);
+          k02 = as_u32((nb02 - S_mid.s02) >> 15) & as_u32(S_mid.s02) & em02;  // (all ones where the score exceeds nb)
+          k13 = as_u32((nb13 - S_mid.s13) >> 15) & as_u32(S_mid.s13) & em13;
+        } else {
+          k02 = as_u32(S_mid.s02) & em02;
+          k13 = as_u32(S_mid.s13) & em13;
+        }
+        if (HALF && r >= nrows) k02 = k13 = 0;  // (the second cell may have fewer rows)
         // rank among the cell's lanes: v_mbcnt counts the set bits below this lane (two instructions per ballot, chained
         // through the accumulator); the upper cell of a half-wave pair subtracts the lower cell's bits (scalar)
         auto below = [](unsigned long long b, int acc) -> int {
           return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)acc));
         };
-        const uint32_t yx = ((uint32_t)(ys + r) << 12) | (uint32_t)c0;
-        if (nms) {
-          // Strict NMS: two neighbouring pixels cannot both survive, so a lane emits at most TWO of its four pixels --
-          // two ballots / ranks / stores instead of four.  m = survivor bits of the lane's pixels 0..3.
-          const uint32_t m = (k01 & 1u) | ((k01 >> 15) & 2u) | ((k23 & 1u) << 2) | ((k23 >> 13) & 8u);
-          const uint32_t m2 = m & (m - 1u);  // without its lowest bit
-          const unsigned long long bA = __ballot(m != 0u), bB = __ballot(m2 != 0u);
-          if (bA != 0ull) {  // wave-uniform
+        const uint32_t yx = yx0 + ((uint32_t)r << 12);
+        if (NMS) {
+          // Strict NMS: two neighbouring pixels cannot both survive, so at most one of pixels 0 / 1 and at most one of
+          // pixels 2 / 3 -- slot A (the low halves) and slot B (the high halves), in raster order: two ballots / ranks /
+          // stores instead of four.  kk = (score of slot A, score of slot B).
+          const uint32_t kk = k02 | k13;
+          const bool hasA = (kk & 0xFFFFu) != 0u, hasB = (kk >> 16) != 0u;
+          const unsigned long long bA = __ballot(hasA), bB = __ballot(hasB);
+          if ((bA | bB) != 0ull) {  // wave-uniform
             int pos = below(bB, below(bA, half ? count_hi : count_lo));
             if (HALF) pos -= half ? __popc((uint32_t)bA) + __popc((uint32_t)bB) : 0;
-            const uint32_t j1 = (uint32_t)__builtin_ctz(m | 16u), j2 = (uint32_t)__builtin_ctz(m2 | 16u);
-            const uint32_t sc = S_mid.s;
-            if (m != 0u && pos < seg_cap) seg[pos] = (((sc >> (8u * j1)) & 255u) << 24) | (yx + j1);
-            if (m2 != 0u && pos + 1 < seg_cap) seg[pos + 1] = (((sc >> (8u * j2)) & 255u) << 24) | (yx + j2);
+            // entry = (score + offs - 1) << 24 | y << 12 | x;  x = c0 + (0 or 1) for slot A, c0 + 2 + (0 or 1) for slot B
+            const uint32_t eA = (kk << 24) + yx + ((k13 & 0xFFFFu) != 0u ? 1u : 0u);
+            const uint32_t eB = ((kk & 0xFFFF0000u) << 8) + yx + 2u + ((k13 >> 16) != 0u ? 1u : 0u);
+            const int posB = pos + (hasA ? 1 : 0);
+            if (hasA && (!HALF || pos < seg_cap)) __builtin_amdgcn_raw_buffer_store_b32(eA, seg_rsrc, seg_off + 4u * (uint32_t)pos, 0, 0);
+            if (hasB && (!HALF || posB < seg_cap)) __builtin_amdgcn_raw_buffer_store_b32(eB, seg_rsrc, seg_off + 4u * (uint32_t)posB, 0, 0);
             if (HALF) {
               count_lo += __popc((uint32_t)bA) + __popc((uint32_t)bB);
               count_hi += __popc((uint32_t)(bA >> 32)) + __popc((uint32_t)(bB >> 32));
@@ -341,7 +358,7 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
             }
           }
         } else {
-          const bool k0 = (k01 & 0xFFFFu) != 0, k1 = (k01 >> 16) != 0, k2 = (k23 & 0xFFFFu) != 0, k3 = (k23 >> 16) != 0;
+          const bool k0 = (k02 & 0xFFFFu) != 0, k1 = (k13 & 0xFFFFu) != 0, k2 = (k02 >> 16) != 0, k3 = (k13 >> 16) != 0;
           const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
           if ((b0 | b1 | b2 | b3) != 0ull) {  // wave-uniform
             int pos = below(b3, below(b2, below(b1, below(b0, half ? count_hi : count_lo))));
@@ -349,20 +366,21 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
               const int lower = __popc((uint32_t)b0) + __popc((uint32_t)b1) + __popc((uint32_t)b2) + __popc((uint32_t)b3);
               pos -= half ? lower : 0;
             }
+            // (without NMS cv::FAST_t leaves the response at 0)
             if (k0) {
-              if (pos < seg_cap) seg[pos] = yx;  // (without NMS cv::FAST_t leaves the response at 0)
+              if (!HALF || pos < seg_cap) __builtin_amdgcn_raw_buffer_store_b32(yx, seg_rsrc, seg_off + 4u * (uint32_t)pos, 0, 0);
               ++pos;
             }
             if (k1) {
-              if (pos < seg_cap) seg[pos] = yx + 1;
+              if (!HALF || pos < seg_cap) __builtin_amdgcn_raw_buffer_store_b32(yx + 1, seg_rsrc, seg_off + 4u * (uint32_t)pos, 0, 0);
               ++pos;
             }
             if (k2) {
-              if (pos < seg_cap) seg[pos] = yx + 2;
+              if (!HALF || pos < seg_cap) __builtin_amdgcn_raw_buffer_store_b32(yx + 2, seg_rsrc, seg_off + 4u * (uint32_t)pos, 0, 0);
               ++pos;
             }
             if (k3) {
-              if (pos < seg_cap) seg[pos] = yx + 3;
+              if (!HALF || pos < seg_cap) __builtin_amdgcn_raw_buffer_store_b32(yx + 3, seg_rsrc, seg_off + 4u * (uint32_t)pos, 0, 0);
             }
             if (HALF) {
               count_lo += __popcll(b0 & 0xFFFFFFFFull) + __popcll(b1 & 0xFFFFFFFFull) + __popcll(b2 & 0xFFFFFFFFull) +
@@ -374,21 +392,30 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
           }
         }
       }
-      if (hl > r) my_rs = min(half ? count_hi : count_lo, seg_cap);
+      // rowstart[r + 1] of the cell(s): the running count goes into lane r + 1 of the cell (v_writelane: one instruction;
+      // lane 0 keeps rowstart[0] = 0, rowstart[SR] is written from the final count)
+      if (r + 1 < SR) {
+        // (lane select through M0: the value already takes the instruction's one constant-bus slot)
+        asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(my_rs) : "s"(min(count_lo, seg_cap)), "s"(r + 1));
+        if (HALF)
+          asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(my_rs) : "s"(min(count_hi, seg_cap)), "s"(32 + r + 1));
+      }
     }
   };
 
   // NINE rotating register sets hold image rows: step q reads rows (ys - 4 + q) .. (ys + 2 + q) from sets q .. q + 6
-  // (mod 9), set q + 7 already holds the next row and the row after that is requested into set q + 8 -- the set whose row
-  // the previous step used last.  The loop body is nine steps, a multiple of the three score-row sets' period, so neither
-  // the image rows nor the score rows are ever copied between registers (a period of seven cost 17 v_mov per step).
+  // (mod 9), set q + 7 already holds the next row's dword and the row after that is requested into set q + 8 -- the set
+  // whose row the previous step used last.  The loop body is nine steps, a multiple of the three score-row sets' period, so
+  // neither the image rows nor the score rows are ever copied between registers (a period of seven cost 17 v_mov per step).
   // q runs over 0 .. nrows0 + 1 (score rows ys - 1 .. ys + nrows0).
-  Row3 A0 = load_row(-3), A1 = load_row(-2), A2 = load_row(-1), A3 = load_row(0), A4 = load_row(1), A5 = load_row(2),
-       A6 = load_row(3), A7 = load_row(4), A8;
+  RowP A0, A1, A2, A3, A4, A5, A6, A7, A8;
+  A0.d = load_row(-3), A1.d = load_row(-2), A2.d = load_row(-1), A3.d = load_row(0), A4.d = load_row(1), A5.d = load_row(2),
+  A6.d = load_row(3), A7.d = load_row(4);
+  prep_row(A0), prep_row(A1), prep_row(A2), prep_row(A3), prep_row(A4), prep_row(A5);
   const int qe = nrows0 + 1;
 #define VSF_FAST_STEP(j, r0, r1, r2, r3, r4, r5, r6, ld, su, sm, sd) \
   if (q + (j) > qe) break;                                             \
-  ld = load_row(q + (j) + 5);                                          \
+  ld.d = load_row(q + (j) + 5);                                        \
   step(q + (j), r0, r1, r2, r3, r4, r5, r6, su, sm, sd);
   for (int q = 0;; q += 9) {
     VSF_FAST_STEP(0, A0, A1, A2, A3, A4, A5, A6, A8, S0, S1, S2)
