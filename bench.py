@@ -247,6 +247,10 @@ def main() -> int:
     ap.add_argument("--blur-inline", action="store_true",
                     help="keep the Gaussian blur on the extraction's stream (vsf_set_blur_overlap(0)); default: it runs on its "
                          "own stream beside FAST and the keypoint selection")
+    ap.add_argument("--collectives", choices=["torch", "capi"], default="torch",
+                    help="what carries the step's exchanges: torch.distributed (nccl = RCCL; the default, what the driver's "
+                         "scaling run uses) or the C ABI's own vsf_allgather_dev / vsf_gather_payload_dev on librccl (the route "
+                         "of a C++ host; in a world of one every exchange still runs, through RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
@@ -314,8 +318,22 @@ def main() -> int:
     calib = frontend.default_calibration()
     # the synthetic pairs are rectified (pure horizontal disparity): l^T F r = y_r - y_l
     calib.set("fundamental", [0, 0, 0, 0, 0, -1, 0, 1, 0])
+    comm = None
+    if args.collectives == "capi":
+        if rehearsal:
+            print("bench.py: --collectives capi needs one GPU per rank (RCCL refuses two ranks on a device)", file=sys.stderr)
+            return 2
+        cid = [vd.CapiComm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(cid, src=0)  # (the 128 bytes of ncclGetUniqueId travel over the process group)
+        comm = vd.CapiComm(ctx, cid[0], rank, world)
+        seen = comm.ranks_seen(dev)
+        if sorted(seen) != list(range(world)):
+            print("bench.py: vsf_allgather_dev of the rank ids returned %s in a world of %d" % (seen, world), file=sys.stderr)
+            return 3
+        handshake = dict(handshake, backend=comm.name, ranks_seen=seen, nccl_version=str(comm.rccl_version))
     sf = vd.ShardedStereoFrontend(ctx, B, W, H, calib, window=args.window, device=dev, stream=stream,
-                                  overlap=not args.no_overlap)
+                                  overlap=not args.no_overlap, comm=comm)
     sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
     ctx.set_lanes(args.lanes)
     ctx.set_blur_overlap(not args.blur_inline)
@@ -558,6 +576,8 @@ def main() -> int:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     sf.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

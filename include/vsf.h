@@ -162,6 +162,30 @@ vsf_status vsf_sync(vsf_ctx* ctx);
 /* Pyramid geometry the context derived (cv::ORB layer sizes / scales / per-level feature budgets). */
 vsf_status vsf_level_info(const vsf_ctx* ctx, int level, int* w, int* h, float* scale, int* nfeatures);
 
+/* ---------------- multi-GPU exchange (BASELINE configs[3]; SURVEY.md 8(b): "vsf_gather_* for multi-GPU") ----------------
+ * One process (or thread) per GPU, one context and one communicator each.  What has to cross GPUs is what the reference's
+ * algorithm forces: the per-frame mean residuals (the static threshold of RemoveAmbigStereo crosses frames,
+ * slam_frontend.cc:353, 392-394), every rank's last frames for the temporal GetFeatureMatches (cc:424-434) and the packed
+ * VisionFeature / FeatureMatch payloads one process assembles into the SLAMProblem (cc:498-503; caller
+ * slam_frontend_main.cc:251, 132).  RCCL is loaded at run time by the first of these calls (VSF_ERR_UNSUPPORTED if there is
+ * none); both transfers are asynchronous, ordered on the context's stream like any *_dev call. */
+#define VSF_COMM_ID_BYTES 128
+typedef struct vsf_comm vsf_comm;
+/* ncclGetUniqueId: called by ONE rank; the caller carries the 128 bytes to the other ranks (shared memory between the
+ * threads of a process, a file, MPI, the launcher's own process group ...). */
+vsf_status vsf_comm_unique_id(uint8_t* id);
+/* ncclCommInitRank on the context's device: collective over the `world` ranks that hold the same id. */
+vsf_status vsf_comm_create(vsf_ctx* ctx, const uint8_t* id, int rank, int world, vsf_comm** out);
+void vsf_comm_destroy(vsf_comm* comm);
+vsf_status vsf_comm_info(const vsf_comm* comm, int* rank, int* world, int* rccl_version);
+/* d_recv[r * bytes_per_rank ...] = rank r's d_send[0 .. bytes_per_rank) on every rank (ncclAllGather of bytes). */
+vsf_status vsf_allgather_dev(vsf_ctx* ctx, vsf_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* Every rank sends `bytes` bytes of d_send to `root`; on the root rank r's bytes land at d_recv + r * recv_stride (d_recv is
+ * ignored elsewhere).  One group of point-to-point transfers: over xGMI each peer -> root copy rides its own link.  `bytes`
+ * is the same on all ranks (the payload sizes are exchanged first: vsf_pack_outputs_dev writes them into the header). */
+vsf_status vsf_gather_payload_dev(vsf_ctx* ctx, vsf_comm* comm, const uint8_t* d_send, size_t bytes, uint8_t* d_recv,
+                                  size_t recv_stride, int root);
+
 /* ---------------- host-pointer, synchronous: one call == one reference call ---------------- */
 
 /* detectAndCompute(image, noArray(), kps, desc)  (slam_frontend.cc:274-277).  kp_out/desc_out hold `cap`

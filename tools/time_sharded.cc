@@ -1,0 +1,297 @@
+// time_sharded.cc -- the sharded hot path of BASELINE configs[3] WITHOUT Python: one thread per GPU, one vsf context and
+// one vsf_comm (RCCL) each, DESIGN.md section 7's ten steps through the C ABI of include/vsf.h only.  What the drop-in for
+// the reference's driver (slam_frontend_main.cc:251, 132) would run on an 8-GPU node.
+//
+//   build:  make -C tools time_sharded
+//   run:    tools/time_sharded frames.raw W H NFRAMES nfeatures frames_per_rank window steps [payloads.bin] [gpus]
+//
+// frames.raw = NFRAMES x 2 x H x W bytes in global frame order (step-major, rank-major: frame_block() of
+// vision_slam_frontend_amd/distributed.py); every rank cycles through its own blocks.  With `payloads.bin` rank 0 writes, per
+// step and rank, a u32 byte count and the gathered payload -- the bytes tests/test_gpu_comm.py compares with the Python
+// path's.  Prints one JSON object (frames/s over the timed steps, per-rank times, the RCCL version, ranks seen).
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/vsf.h"
+
+extern "C" void vsfh_default_calibration(vsf_calibration* out);
+
+using Clock = std::chrono::steady_clock;
+
+#define CK(call)                                                                                   \
+  do {                                                                                             \
+    const int st_ = (int)(call);                                                                   \
+    if (st_ != 0) {                                                                                \
+      std::fprintf(stderr, "rank %d: %s failed with %d (%s:%d)\n", rank, #call, st_, __FILE__, __LINE__); \
+      failed->store(true);                                                                         \
+      return;                                                                                      \
+    }                                                                                              \
+  } while (0)
+
+struct Barrier {  // (C++17: no std::barrier)
+  std::mutex m;
+  std::condition_variable cv;
+  int n, count = 0, gen = 0;
+  explicit Barrier(int n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    const int g = gen;
+    if (++count == n) {
+      count = 0;
+      gen++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != g; });
+    }
+  }
+};
+
+struct Shared {
+  int W, H, nf, B, window, steps, world, nframes;
+  const uint8_t* frames;
+  uint8_t id[VSF_COMM_ID_BYTES];
+  Barrier* bar;
+  std::vector<double> rank_seconds;
+  std::vector<int> ranks_seen;
+  int rccl_version = 0;
+  std::vector<std::vector<uint8_t>> payloads;  // rank 0: [step * world + r]
+  bool keep = false;
+};
+
+template <class T>
+static T* dmalloc(size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+  (void)hipMemset(p, 0, n * sizeof(T));
+  return static_cast<T*>(p);
+}
+
+static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
+  const int B = S->B, Wn = S->window, world = S->world, W = S->W, H = S->H;
+  CK(hipSetDevice(rank));
+  vsf_params p;
+  CK(vsf_params_default(&p, W, H, 2 * B));
+  p.nfeatures = S->nf;
+  vsf_ctx* ctx = nullptr;
+  CK(vsf_create(&p, rank, &ctx));
+  CK(vsf_get_params(ctx, &p));
+  const size_t K = (size_t)p.max_keypoints;
+  vsf_comm* comm = nullptr;
+  CK(vsf_comm_create(ctx, S->id, rank, world, &comm));
+  vsf_calibration calib;
+  vsfh_default_calibration(&calib);
+  const float F[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};  // rectified synthetic pairs: l^T F r = y_r - y_l
+  std::memcpy(calib.fundamental, F, sizeof(F));
+
+  // ---- device buffers (the layout of ShardedStereoFrontend, one stream) ----
+  const size_t img_bytes = (size_t)W * H;
+  uint8_t* d_img = dmalloc<uint8_t>((size_t)2 * B * img_bytes);
+  vsf_keypoint* d_kp = dmalloc<vsf_keypoint>(2 * B * K);
+  uint8_t* d_desc = dmalloc<uint8_t>(2 * B * K * 32);
+  int32_t* d_counts = dmalloc<int32_t>(2 * B);
+  vsf_dmatch* d_matches = dmalloc<vsf_dmatch>(B * K);
+  int32_t* d_nmatches = dmalloc<int32_t>(B);
+  float* d_means = dmalloc<float>(B);
+  float* d_means_all = dmalloc<float>((size_t)world * B);
+  float* d_thr_all = dmalloc<float>((size_t)world * B);
+  float* d_thr_state = dmalloc<float>(1);
+  const int nsets = 2 * B + 2 * world * Wn + 1, empty_set = nsets - 1;
+  vsf_keypoint* d_kpf = dmalloc<vsf_keypoint>(2 * B * K);
+  uint8_t* d_descf = dmalloc<uint8_t>((size_t)nsets * K * 32);
+  int32_t* d_countsf = dmalloc<int32_t>(nsets);
+  uint8_t* d_tail_desc = dmalloc<uint8_t>((size_t)std::max(Wn, 1) * K * 32);
+  int32_t* d_tail_counts = dmalloc<int32_t>(std::max(Wn, 1));
+  vsf_vision_feature* d_feat = dmalloc<vsf_vision_feature>(B * K);
+  int32_t* d_nfeat = dmalloc<int32_t>(B);
+  const int NP = B * Wn;
+  uint64_t* d_pairs = dmalloc<uint64_t>((size_t)std::max(NP, 1) * K * 2);
+  int32_t* d_npairs = dmalloc<int32_t>(std::max(NP, 1));
+  int32_t* d_qset = dmalloc<int32_t>(std::max(NP, 1));
+  int32_t* d_tset = dmalloc<int32_t>(std::max(NP, 1));
+  const size_t cap = vsf_packed_outputs_capacity(ctx, B, NP);
+  uint8_t* d_payload = dmalloc<uint8_t>(cap);
+  int32_t* d_sizes = dmalloc<int32_t>(world);
+  int32_t* d_rank_ids = dmalloc<int32_t>(world + 1);
+  uint8_t* d_recv = rank == 0 ? dmalloc<uint8_t>((size_t)world * cap) : nullptr;
+  if (!d_img || !d_kp || !d_desc || !d_descf || !d_payload || (rank == 0 && !d_recv)) CK(1);
+  const float thr0 = 10000.0f;  // cc:353
+  CK(hipMemcpy(d_thr_state, &thr0, 4, hipMemcpyHostToDevice));
+
+  // ---- handshake: the ranks that really take part, through the backend that carries the step's exchanges ----
+  {
+    const int32_t me = rank;
+    CK(hipMemcpy(d_rank_ids + world, &me, 4, hipMemcpyHostToDevice));
+    CK(vsf_allgather_dev(ctx, comm, d_rank_ids + world, d_rank_ids, 4));
+    CK(vsf_sync(ctx));
+    if (rank == 0) {
+      S->ranks_seen.resize(world);
+      CK(hipMemcpy(S->ranks_seen.data(), d_rank_ids, 4 * world, hipMemcpyDeviceToHost));
+      CK(vsf_comm_info(comm, nullptr, nullptr, &S->rccl_version));
+    }
+  }
+
+  // static schedule of the temporal pairs (distributed.temporal_pair_sets): per step parity and "first step"
+  auto pair_sets = [&](int parity, bool first, std::vector<int32_t>* q, std::vector<int32_t>* t) {
+    q->clear();
+    t->clear();
+    auto region = [&](int par) { return 2 * B + par * world * Wn; };
+    for (int i = 0; i < B; i++)
+      for (int w = Wn; w > 0; w--) {
+        const int past = i - w;
+        int qs;
+        if (past >= 0) qs = 2 * past;
+        else if (rank > 0) qs = region(parity) + (rank - 1) * Wn + (Wn + past);
+        else if (first) qs = empty_set;
+        else qs = region(1 - parity) + (world - 1) * Wn + (Wn + past);
+        q->push_back(qs);
+        t->push_back(2 * i);
+      }
+  };
+
+  std::vector<int32_t> hq, ht, sizes(world);
+  const int blocks = S->nframes / (world * B);  // steps' worth of input (cycled)
+  const int warm = S->keep ? 0 : 2;
+  S->bar->wait();
+  Clock::time_point t0 = Clock::now();
+  for (int s = 0; s < S->steps + warm; s++) {
+    if (s == warm && warm > 0) {
+      CK(vsf_sync(ctx));
+      S->bar->wait();
+      t0 = Clock::now();
+    }
+    const int parity = s & 1;
+    const size_t first_frame = ((size_t)(s % blocks) * world + rank) * B;
+    CK(hipMemcpy(d_img, S->frames + first_frame * 2 * img_bytes, (size_t)2 * B * img_bytes, hipMemcpyHostToDevice));
+    // 1: extract(L), extract(R), GetMatches (cc:411-416)
+    CK(vsf_stereo_batch_dev(ctx, d_img, B, img_bytes, W, d_kp, d_desc, d_counts, d_matches, d_nmatches));
+    // 2-5: RemoveAmbigStereo with the threshold chain over ALL ranks' frames (cc:353-398)
+    CK(vsf_stereo_residuals_batch_dev(ctx, d_kp, d_matches, d_nmatches, B, F, d_means));
+    CK(vsf_allgather_dev(ctx, comm, d_means, d_means_all, (size_t)B * 4));
+    CK(vsf_stereo_thresholds_dev(ctx, d_means_all, world * B, d_thr_state, d_thr_all));
+    CK(vsf_stereo_filter_batch_dev(ctx, d_kp, d_desc, d_matches, d_nmatches, B, d_thr_all + (size_t)rank * B, d_kpf, d_descf,
+                                   d_countsf));
+    if (Wn > 0) {
+      // 6: every rank's last `window` filtered LEFT frames: the temporal predecessors of the next rank's first frames
+      CK(vsf_sync(ctx));  // (the tool copies on the null stream; the library runs on the context's)
+      for (int j = 0; j < Wn; j++) {
+        const int set = 2 * (B - Wn + j);
+        CK(hipMemcpyAsync(d_tail_desc + (size_t)j * K * 32, d_descf + (size_t)set * K * 32, K * 32, hipMemcpyDeviceToDevice,
+                          nullptr));
+        CK(hipMemcpyAsync(d_tail_counts + j, d_countsf + set, 4, hipMemcpyDeviceToDevice, nullptr));
+      }
+      CK(hipStreamSynchronize(nullptr));
+      const int r0 = 2 * B + parity * world * Wn;
+      CK(vsf_allgather_dev(ctx, comm, d_tail_desc, d_descf + (size_t)r0 * K * 32, (size_t)Wn * K * 32));
+      CK(vsf_allgather_dev(ctx, comm, d_tail_counts, d_countsf + r0, (size_t)Wn * 4));
+      // 7: GetFeatureMatches(past, current) (cc:424-434)
+      pair_sets(parity, s == 0, &hq, &ht);
+      CK(vsf_sync(ctx));
+      CK(hipMemcpy(d_qset, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(d_tset, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+      CK(vsf_feature_matches_batch_dev(ctx, d_descf, d_countsf, K * 32, d_qset, d_tset, NP, 0.3f, d_pairs, d_npairs));
+    } else {
+      CK(vsf_sync(ctx));  // (keeps the tool's null-stream copies of the next step behind this step's reads)
+    }
+    // 8-9: Calculate3DPoints + UndistortFeaturePoints (cc:437-443), the compact payload
+    CK(vsf_vision_features_batch_dev(ctx, &calib, d_kpf, d_descf, d_countsf, B, d_feat, d_nfeat, nullptr));
+    CK(vsf_pack_outputs_dev(ctx, d_feat, d_nfeat, B, d_pairs, d_npairs, NP, d_payload, cap));
+    // 10: payload sizes to every rank, then the sized gather to rank 0
+    CK(vsf_allgather_dev(ctx, comm, d_payload + 12, d_sizes, 4));
+    CK(vsf_sync(ctx));
+    CK(hipMemcpy(sizes.data(), d_sizes, 4 * world, hipMemcpyDeviceToHost));
+    size_t nbytes = 0;
+    for (int r = 0; r < world; r++) nbytes = std::max(nbytes, (size_t)sizes[r]);
+    nbytes = std::min((nbytes + 15) & ~(size_t)15, cap);
+    CK(vsf_gather_payload_dev(ctx, comm, d_payload, nbytes, d_recv, cap, 0));
+    if (rank == 0 && S->keep) {
+      CK(vsf_sync(ctx));
+      for (int r = 0; r < world; r++) {
+        std::vector<uint8_t> pl((size_t)sizes[r]);
+        CK(hipMemcpy(pl.data(), d_recv + (size_t)r * cap, pl.size(), hipMemcpyDeviceToHost));
+        S->payloads.push_back(std::move(pl));
+      }
+    }
+  }
+  CK(vsf_sync(ctx));
+  S->rank_seconds[rank] = std::chrono::duration<double>(Clock::now() - t0).count();
+  S->bar->wait();
+  vsf_comm_destroy(comm);
+  vsf_destroy(ctx);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 9) {
+    std::fprintf(stderr, "usage: %s frames.raw W H NFRAMES nfeatures frames_per_rank window steps [payloads.bin] [gpus]\n", argv[0]);
+    return 2;
+  }
+  Shared S;
+  S.W = std::atoi(argv[2]);
+  S.H = std::atoi(argv[3]);
+  S.nframes = std::atoi(argv[4]);
+  S.nf = std::atoi(argv[5]);
+  S.B = std::atoi(argv[6]);
+  S.window = std::atoi(argv[7]);
+  S.steps = std::atoi(argv[8]);
+  const std::string out = argc > 9 ? argv[9] : "";
+  int ngpu = 0;
+  if (hipGetDeviceCount(&ngpu) != hipSuccess || ngpu < 1) {
+    std::fprintf(stderr, "no GPU\n");
+    return 2;
+  }
+  S.world = argc > 10 ? std::min(std::atoi(argv[10]), ngpu) : ngpu;
+  S.keep = !out.empty();
+  if (S.window > S.B || S.nframes < S.world * S.B || S.steps < 1) {
+    std::fprintf(stderr, "need window <= frames_per_rank and at least world * frames_per_rank frames\n");
+    return 2;
+  }
+  std::vector<uint8_t> raw((size_t)S.nframes * 2 * S.W * S.H);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(raw.data(), 1, raw.size(), f) != raw.size()) {
+    std::fprintf(stderr, "cannot read %zu bytes from %s\n", raw.size(), argv[1]);
+    return 2;
+  }
+  std::fclose(f);
+  S.frames = raw.data();
+  if (vsf_comm_unique_id(S.id) != VSF_OK) {
+    std::fprintf(stderr, "no RCCL (vsf_comm_unique_id)\n");
+    return 3;
+  }
+  Barrier bar(S.world);
+  S.bar = &bar;
+  S.rank_seconds.assign(S.world, 0.0);
+  std::atomic<bool> failed(false);
+  std::vector<std::thread> th;
+  for (int r = 0; r < S.world; r++) th.emplace_back(rank_main, r, &S, &failed);
+  for (auto& t : th) t.join();
+  if (failed.load()) return 1;
+  double slowest = 0;
+  for (double v : S.rank_seconds) slowest = std::max(slowest, v);
+  if (S.keep) {
+    FILE* o = std::fopen(out.c_str(), "wb");
+    if (!o) return 2;
+    for (const auto& pl : S.payloads) {
+      const uint32_t n = (uint32_t)pl.size();
+      std::fwrite(&n, 4, 1, o);
+      std::fwrite(pl.data(), 1, pl.size(), o);
+    }
+    std::fclose(o);
+  }
+  std::printf("{\"what\": \"sharded hot path through the C ABI, one thread per GPU (tools/time_sharded.cc)\", \"n_gpus\": %d, "
+              "\"frames_per_rank\": %d, \"window\": %d, \"steps\": %d, \"stereo_frames_per_s\": %.1f, \"ms_per_step\": %.3f, "
+              "\"rccl_version\": %d, \"ranks_seen\": [",
+              S.world, S.B, S.window, S.steps, (double)S.world * S.B * S.steps / slowest, 1e3 * slowest / S.steps, S.rccl_version);
+  for (int r = 0; r < (int)S.ranks_seen.size(); r++) std::printf("%s%d", r ? ", " : "", S.ranks_seen[r]);
+  std::printf("], \"note\": \"one stream per rank, input uploaded from host memory every step (PCIe inclusive); bench.py is the "
+              "HBM-resident, overlapped measurement\"}\n");
+  return 0;
+}

@@ -35,7 +35,8 @@ EXPORTS = [
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
-    "vsf_jpeg_decode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error",
+    "vsf_jpeg_decode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error", "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_destroy", "vsf_comm_info",
+    "vsf_allgather_dev", "vsf_gather_payload_dev",
 ]
 # vsf_option (include/vsf.h)
 (OPT_BLUR_MARCH, OPT_FAST_BOTH_MAX, OPT_SORT_SERIAL, OPT_SELECT_WIDE, OPT_JPEG_SERIAL, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN,
@@ -122,6 +123,13 @@ def lib() -> C.CDLL:
         L.vsf_set_option.argtypes = [vp, i32, i32]
         L.vsf_get_option.argtypes = [vp, i32, ip]
         L.vsf_debug_inject_hip_error.argtypes = [vp, i32]
+        L.vsf_comm_unique_id.argtypes = [vp]
+        L.vsf_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.vsf_comm_destroy.argtypes = [vp]
+        L.vsf_comm_destroy.restype = None
+        L.vsf_comm_info.argtypes = [vp, ip, ip, ip]
+        L.vsf_allgather_dev.argtypes = [vp, vp, vp, vp, sz]
+        L.vsf_gather_payload_dev.argtypes = [vp, vp, vp, sz, vp, sz, i32]
         L.vsf_remove_ambig_stereo_batch_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.c_float, vp, vp, vp, vp, vp, vp]
         L.vsf_feature_matches_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, i32, C.c_float, vp, vp]
         L.vsf_bayer_bg_to_gray_batch_dev.argtypes = [vp, vp, i32, i32, i32, sz, sz, vp, sz, sz]

@@ -990,6 +990,9 @@ vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, 
 
 }  // namespace
 
+hipStream_t vsf_ctx_stream(const vsf_ctx* ctx) { return ctx->stream; }
+int vsf_ctx_device(const vsf_ctx* ctx) { return ctx->device; }
+
 extern "C" {
 
 vsf_status vsf_params_default(vsf_params* p, int width, int height, int max_images) {

@@ -105,6 +105,9 @@ extern thread_local int vsf_tls_hip_error;
 inline void vsf_note(hipError_t e) {
   if (e != hipSuccess && vsf_tls_hip_error == 0) vsf_tls_hip_error = (int)e;
 }
+// What vsf_comm.hip needs of a context (vsf_ctx is private to vsf_api.hip).
+hipStream_t vsf_ctx_stream(const vsf_ctx* ctx);
+int vsf_ctx_device(const vsf_ctx* ctx);
 // Raises the dynamic-LDS limit of the kernels that need more than the default 64 KB (k_frontend / k_pyramid / k_jpeg);
 // called once per context creation, checked.
 hipError_t vsf_prepare_sort_kernels(int lds_limit);

@@ -218,6 +218,88 @@ class TorchComm:
         return [float(v) for v in t.cpu()]
 
 
+class CapiComm:
+    """The same exchanges through the C ABI (include/vsf.h: vsf_comm_create / vsf_allgather_dev / vsf_gather_payload_dev),
+    i.e. on librccl directly, stream-ordered on the stream of the context that issues them -- the route a C++ host (the
+    reference's driver, slam_frontend_main.cc:251, 132) takes; tools/time_sharded.cc is that host.  `comm_id`: the 128 bytes
+    of vsf_comm_unique_id() of ONE rank, carried to the others by the caller (here: torch.distributed's broadcast)."""
+
+    def __init__(self, ctx, comm_id: bytes, rank: int, world: int):
+        import ctypes as C
+
+        from . import capi
+        self._capi, self._C = capi, C
+        self.world, self.rank, self.host_detour = int(world), int(rank), False
+        self.ctx = ctx
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(comm_id)
+        st = capi.lib().vsf_comm_create(ctx._h, buf, self.rank, self.world, C.byref(h))
+        if st != capi.VSF_OK:
+            raise capi.VsfError(st, "vsf_comm_create")
+        self._h = h
+        v = C.c_int()
+        capi.lib().vsf_comm_info(self._h, None, None, C.byref(v))
+        self.rccl_version = v.value
+        self.name = "C ABI (vsf_allgather_dev / vsf_gather_payload_dev on librccl %d)" % v.value
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import capi
+        buf = (C.c_uint8 * 128)()
+        st = capi.lib().vsf_comm_unique_id(buf)
+        if st != capi.VSF_OK:
+            raise capi.VsfError(st, "vsf_comm_unique_id")
+        return bytes(buf)
+
+    def bind(self, ctx):
+        """The context whose stream orders the exchanges (ShardedStereoFrontend binds its tail context)."""
+        self.ctx = ctx
+
+    def close(self):
+        if self._h:
+            self._capi.lib().vsf_comm_destroy(self._h)
+            self._h = None
+
+    def _check(self, st, where):
+        if st != self._capi.VSF_OK:
+            raise self._capi.VsfError(st, where, self._capi.lib().vsf_last_hip_error(self.ctx._h))
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, stream):
+        inp = inp.contiguous()
+        self._check(self._capi.lib().vsf_allgather_dev(self.ctx._h, self._h, inp.data_ptr(), out.data_ptr(),
+                                                       inp.numel() * inp.element_size()), "vsf_allgather_dev")
+        self._keep = inp  # (alive until the next exchange has been queued behind it on the same stream)
+
+    def gather_async(self, send: torch.Tensor, recv, dst: int = 0):
+        nbytes = send.numel() * send.element_size()
+        base, stride = 0, nbytes
+        if self.rank == dst:
+            base = recv[0].data_ptr()
+            stride = recv[1].data_ptr() - base if self.world > 1 else nbytes
+            assert all(r.data_ptr() == base + i * stride for i, r in enumerate(recv)), "receive views must be equally spaced"
+        self._check(self._capi.lib().vsf_gather_payload_dev(self.ctx._h, self._h, send.data_ptr(), nbytes, base, stride, dst),
+                    "vsf_gather_payload_dev")
+        return _Done(), send
+
+    def all_reduce_max(self, values, device):
+        mine = torch.tensor(list(values), dtype=torch.float64, device=device)
+        every = torch.zeros(self.world * len(mine), dtype=torch.float64, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        self.all_gather(every, mine, None)
+        self.ctx.sync()
+        return [float(v) for v in every.view(self.world, -1).max(0).values.cpu()]
+
+    def ranks_seen(self, device):
+        mine = torch.tensor([self.rank], dtype=torch.int32, device=device)
+        every = torch.full((self.world,), -1, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        self.all_gather(every, mine, None)
+        self.ctx.sync()
+        return [int(v) for v in every.cpu()]
+
+
 class ThreadWorld:
     """Shared state of a world whose ranks are THREADS of one process (ThreadComm): a barrier and one slot per rank."""
 
@@ -365,9 +447,10 @@ class ShardedStereoFrontend:
         self.raw_free = [torch.cuda.Event() for _ in range(self.NRAW)]   # the tail has read it: may be overwritten
         self.recv = None
         if self.rank == 0 and self.dist_on:
-            # receive buffers sized by the largest possible payload; each gather uses a prefix sized by the counts
+            # receive buffers sized by the largest possible payload (one allocation per slot, a row per rank: the C-ABI
+            # gather takes a base and a stride); each gather uses a prefix sized by the counts
             rdev = "cpu" if self.host_detour else dev
-            self.recv = [[torch.empty(self.cap, dtype=u8, device=rdev) for _ in range(world)]
+            self.recv = [list(torch.empty((world, self.cap), dtype=u8, device=rdev).unbind(0))
                          for _ in range(self.PAYLOAD_SLOTS)]
         self.step_idx = 0
         self.next_gather = 0  # first step whose payload has not been handed to a gather yet
@@ -378,6 +461,8 @@ class ShardedStereoFrontend:
         ctx.set_stream(self.stream.cuda_stream)
         if self.overlap:
             self.tail_ctx.set_stream(self.tail_stream.cuda_stream)
+        if comm is not None and hasattr(comm, "bind"):
+            comm.bind(self.tail_ctx)  # the exchanges are ordered on the tail's stream
         self.stream.synchronize()
 
     # the raw outputs of the most recent step (bench.py reports their counts)
