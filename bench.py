@@ -29,7 +29,8 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4  # 1024 SIMDs x 2.4 GHz, one wave64 VALU instruction per 4 cycles = 614.4 G wave-inst/s
+VALU_PEAK_GINST = 545.0      # measured: a stream of 4-cycle wave64 VALU instructions chip-wide (profiles/r04/valu_issue_table.json;
+                             # 1024 SIMDs x ~2.2 GHz under that load / 4.1 cycles); per kernel: valu_ceilings()
 MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 = the fp8 rate (MI355X_MICROARCH.md: ~5 PFLOP/s fp8 dense)
 
 CONFIGS = {
@@ -57,18 +58,33 @@ def stage_algorithmic_bytes(ctx, n_images: int, n_pairs: int, nfeatures: int) ->
 
 
 def committed_counters(width: int, height: int, nfeatures: int, batch: int):
-    """Per-stage counters of the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE, WRITE_SIZE and
-    SQ_INSTS_VALU collected in their own runs), if they were taken on this configuration; {} otherwise.  PMC counters
-    cannot be collected inside the timed run."""
-    for name in ("traffic.json", "traffic_1080p.json"):  # one file per profiled configuration
+    """(per-stage counters, stale) of the committed rocprofv3 --pmc passes (profiles/traffic*.json: FETCH_SIZE, WRITE_SIZE
+    and SQ_INSTS_VALU collected in their own runs) taken on this configuration; ({}, False) if there are none.  PMC counters
+    cannot be collected inside the timed run, so the file carries a digest of the kernel sources it was taken from
+    (tools/make_traffic.py): `stale` says the sources have changed since -- the numbers are then NOT published."""
+    from vision_slam_frontend_amd.buildinfo import kernel_source_hash
+    for path in sorted((ROOT / "profiles").glob("traffic*.json")):  # one file per profiled configuration
         try:
-            t = json.loads((ROOT / "profiles" / name).read_text())
+            t = json.loads(path.read_text())
         except (OSError, ValueError):
             continue
         c = t.get("config", {})
         if (c.get("width"), c.get("height"), c.get("nfeatures"), c.get("batch")) == (width, height, nfeatures, batch):
-            return t.get("stages", {})
-    return {}
+            return t.get("stages", {}), t.get("source_hash") != kernel_source_hash()
+    return {}, False
+
+
+def valu_ceilings():
+    """Per-stage VALU issue ceilings in G wave-inst/s (profiles/r04/valu_ceiling.json: the kernel's own opcode mix priced with
+    the measured issue table; tools/valu_ceiling.py), and whether the file is stale against the sources.  The fallback is the
+    measured rate of a stream of 4-cycle instructions."""
+    from vision_slam_frontend_amd.buildinfo import kernel_source_hash
+    try:
+        t = json.loads((ROOT / "profiles" / "r04" / "valu_ceiling.json").read_text())
+    except (OSError, ValueError):
+        return {}, VALU_PEAK_GINST, True
+    return ({k: v["ceiling_mix_g_wave_inst_per_s"] for k, v in t["kernels"].items()}, t["rate_all4_g_wave_inst_per_s"],
+            t.get("source_hash") != kernel_source_hash())
 
 
 def host_cores():
@@ -428,7 +444,10 @@ def main() -> int:
         total_frames = world * B * args.steps
         value = total_frames / elapsed
         alg = stage_algorithmic_bytes(ctx, 2 * B, B, NF)
-        pmc = committed_counters(W, H, NF, B)
+        pmc, pmc_stale = committed_counters(W, H, NF, B)
+        if pmc_stale:
+            pmc = {}  # (counters of other kernels than the ones that just ran are not published)
+        ceilings, valu_rate_all4, ceilings_stale = valu_ceilings()
         concurrent = (["gauss_blur7"] if blur_beside else []) + (["pyramid_resize"] if pipeline else [])
         # the dominant stage by its OWN duration (the in-line pass when stages share the chip in the timed steps)
         if inline_stages:
@@ -452,11 +471,16 @@ def main() -> int:
         insts = pmc.get(dom, {}).get("valu_wave_insts_per_step")
         if insts:
             a = float(insts) * args.steps / (dom_ms * 1e-3) / 1e9
-            valu = {"bound": "valu", "kernel": dom, "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
-                    "frac": a / VALU_PEAK_GINST, "valu_wave_insts_per_launch": float(insts) * args.steps / max(dom_launches, 1),
-                    "source": "profiles/traffic*.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass) / stage time of this run"}
+            peak = ceilings.get(dom, valu_rate_all4)
+            valu = {"bound": "valu", "kernel": dom, "achieved": a, "peak": peak, "unit": "G wave-inst/s",
+                    "frac": a / peak, "valu_wave_insts_per_launch": float(insts) * args.steps / max(dom_launches, 1),
+                    "peak_source": "profiles/r04/valu_ceiling.json: this kernel's opcode mix priced with the issue table "
+                                   "measured on MI355X (valu_issue_table.json); %.0f G/s if none of its 2-cycle-class "
+                                   "instructions pair up%s" % (valu_rate_all4, " -- STALE against csrc/" if ceilings_stale else ""),
+                    "source": "profiles/traffic*.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass, same source digest) / stage "
+                              "time of this run"}
             if inline_stages:  # the kernel by itself (see roofline.in_line)
-                valu["frac_in_line"] = float(insts) / (inline_stages[dom] * 1e-3) / 1e9 / VALU_PEAK_GINST
+                valu["frac_in_line"] = float(insts) / (inline_stages[dom] * 1e-3) / 1e9 / peak
         hbm_frac = achieved / HBM_PEAK_GBS
         bound = "valu" if valu and valu["frac"] > hbm_frac else "hbm"
         # matcher (K9): pair distances per second of the stereo knn2 launches and the int8 matrix-core rate they imply
@@ -482,8 +506,8 @@ def main() -> int:
                                              "frac": tr / step_s / 1e9 / HBM_PEAK_GBS}
             step_rooflines["valu"] = {"achieved": vi / step_s / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                                       "frac": vi / step_s / 1e9 / VALU_PEAK_GINST,
-                                      "note": "what the step is closest to: FAST by itself issues at 92 % of this peak, "
-                                              "the other stages wait on latency with the vector ALU half idle (DESIGN 6)"}
+                                      "note": "against the measured rate of 4-cycle instructions; FAST by itself issues at "
+                                              "its mix ceiling, the other stages wait on latency (DESIGN 6)"}
         device_ms = sum(v[0] for k, v in stages.items() if k not in concurrent)
         out = {
             "metric": ("stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
@@ -528,7 +552,7 @@ def main() -> int:
             # "bound" names the roofline this object is measured against (the contract knows "hbm" and "mfma");
             # "limited_by" says what the counters show the kernel is actually limited by (see "roofline_valu")
             "roofline": {"bound": "hbm", "limited_by": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": hbm_frac, "traffic": traffic,
+                         "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_stale": bool(pmc_stale),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "launches": dom_launches, "shares_the_chip_with": shares,
                          "in_line": None if not inline_stages else {

@@ -12,6 +12,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from vision_slam_frontend_amd.buildinfo import kernel_source_hash  # noqa: E402
 STAGE_OF = {"fast_march": "fast_score_nms", "blur_march": "gauss_blur7", "blur_mma": "gauss_blur7",
             "pyramid_slab": "pyramid_resize", "orb_orient_describe": "orb_describe",
             "knn2": "hamming_knn2", "ratio_compact": "ratio_compact", "orb_select": "select_harris_angle",
@@ -42,9 +44,11 @@ out = {
             "stage's kernels, per step (= per launch for single-launch stages).  gfx950 FETCH_SIZE reports half the bytes of a "
             "coalesced stream (MI355X_MICROARCH.md, HBM); calibrated on the blur kernel, whose 4-byte-per-lane reads of ~1.12x "
             "its algorithmic bytes read 0.54x: hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB units).  valu_wave_insts = "
-            "SQ_INSTS_VALU: wave64 VALU instructions issued (one occupies a SIMD for 4 cycles: SQ_ACTIVE_INST_VALU, in "
-            "quad-cycles, equals it); the VALU roofline is 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-inst/s.  mfma_busy_cycles = "
+            "SQ_INSTS_VALU: wave64 VALU instructions issued (SQ_ACTIVE_INST_VALU, in quad-cycles, equals it); what one costs a "
+            "SIMD, per opcode, is measured in profiles/r04/valu_issue_table.json and priced per kernel in valu_ceiling.json.  mfma_busy_cycles = "
             "SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs (a 32x32 MFMA of 8 passes holds its SIMD's matrix pipe 32 cycles).",
+    # the kernels these counters belong to: bench.py publishes them only while csrc/ still hashes to this
+    "source_hash": kernel_source_hash(),
     "config": {"width": w, "height": h, "nfeatures": nf, "batch": batch},
     "stages": {st: {"FETCH_SIZE_KiB": round(fetch[st], 1), "WRITE_SIZE_KiB": round(write[st], 1),
                     "hbm_bytes_per_step": int((2 * fetch[st] + write[st]) * 1024),

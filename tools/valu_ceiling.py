@@ -28,6 +28,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "vision_slam_frontend_amd" / "csrc"
+sys.path.insert(0, str(ROOT))
+from vision_slam_frontend_amd.buildinfo import kernel_source_hash  # noqa: E402
 TABLE = ROOT / "profiles" / "r04" / "valu_issue_table.json"
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result"]
@@ -89,7 +91,7 @@ def main():
     cyc8 = ops["rcp_f32"]["w4"]["cycles_per_inst_per_simd"]
     rate4 = ops["pk_min_i16"]["w4"]["g_wave_inst_per_s"]   # measured chip-wide, at the clock the chip holds under that load
     clock_ghz = rate4 * cyc4 / (table["cus"] * 4)
-    out = {"table": str(TABLE.relative_to(ROOT)), "cycles": {"two": cyc2, "four": cyc4, "eight": cyc8},
+    out = {"table": str(TABLE.relative_to(ROOT)), "source_hash": kernel_source_hash(), "cycles": {"two": cyc2, "four": cyc4, "eight": cyc8},
            "rate_all4_g_wave_inst_per_s": rate4, "clock_ghz_under_valu_load": clock_ghz, "kernels": {}}
     cache = {}
     for stage, (src, needle) in KERNELS.items():

@@ -360,6 +360,89 @@ __device__ __forceinline__ int par_partition(T* A, int lo, int hi, Pred pred, co
   return r;
 }
 
+// std::partition(A + lo, A + hi, pred) when only the TRUE side survives -- retainBest truncates the array at the returned
+// split, so nothing behind it is ever read again.  libstdc++'s bidirectional partition swaps the k-th false element from the
+// left with the k-th true element from the right while they have not crossed; with T true elements in [lo, hi) the split
+// is lo + T, the K false elements inside the prefix [lo, lo + T) are exactly the ones that get swapped, and their partners
+// are the K rightmost true elements, all of them behind the prefix.  So: one READ pass for the flags (ballot masks + a
+// block scan of their popcounts, no rank -> position tables), then every false position of the prefix fetches its partner
+// (the true element of 0-based rank T - k from the left: a binary search in the prefix counts + a 64-bit rank select) --
+// K reads and K writes instead of a full Hoare pass with its table writes and both-way swaps.  On the HBM-resident
+// levels this pass alone moved a fifth of the selection's traffic (profiles/traffic.json, round 3).
+// Returns the split (all threads, after a barrier).
+template <int NT, class T, class Pred, class PM>
+__device__ __forceinline__ int par_partition_keep_true(T* A, int lo, int hi, Pred pred, const PM& s) {
+  PassCtl& c = *s.c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = hi - lo, nw = (m + 63) >> 6;
+  if (m <= kWaveCutoff || nw > s.maxw) return par_partition<NT>(A, lo, hi, pred, s);
+  constexpr int U = 4;
+  for (int base = 0; base < m; base += NT * U) {
+    T x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + u * NT + tid;
+      if (i < m) x[u] = A[lo + i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + u * NT + tid;
+      const unsigned long long bt = __ballot(i < m && pred(x[u]));
+      const int w = ((base + u * NT) >> 6) + wave;
+      if (lane == 0 && w < nw) s.maskR[w] = bt;
+    }
+  }
+  __syncthreads();
+  const int wpt = (nw + NT - 1) / NT, w0 = tid * wpt;
+  int mine = 0;
+  for (int j = 0; j < wpt; j++)
+    if (w0 + j < nw) mine += __popcll(s.maskR[w0 + j]);
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) c.wsum[wave] = (unsigned long long)inc;
+  __syncthreads();
+  int base_sum = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) {
+    if (w < wave) base_sum += (int)c.wsum[w];
+    total += (int)c.wsum[w];
+  }
+  int run = base_sum + inc - mine;
+  for (int j = 0; j < wpt; j++)
+    if (w0 + j < nw) {
+      s.preR[w0 + j] = run;
+      run += __popcll(s.maskR[w0 + j]);
+    }
+  __syncthreads();
+  // the prefix [0, total): a false element at offset i is the k-th false from the left, k = i - (true elements before i) + 1
+  for (int base = 0; base < total; base += NT) {
+    const int i = base + tid;
+    if (i < total) {
+      const int w = i >> 6, b = i & 63;
+      const unsigned long long mk = s.maskR[w];
+      if (!((mk >> b) & 1ull)) {
+        const int k = i - (s.preR[w] + __popcll(mk & ((1ull << b) - 1ull))) + 1;
+        const int rho = total - k;  // 0-based rank, from the left, of the k-th true element from the right
+        int a = 0, e = nw - 1;      // last word whose prefix count is <= rho
+        while (a < e) {
+          const int mid = (a + e + 1) >> 1;
+          if (s.preR[mid] <= rho)
+            a = mid;
+          else
+            e = mid - 1;
+        }
+        A[lo + i] = A[lo + a * 64 + select64(s.maskR[a], rho - s.preR[a])];  // (the partner lies behind the prefix)
+      }
+    }
+  }
+  __syncthreads();
+  return lo + total;
+}
+
 // cv::KeyPointsFilter::retainBest(A[0..n), n_points); returns the new size -- all threads call this.
 template <int NT, class T, class Greater, class GreaterEq, class PM>
 __device__ __forceinline__ int par_retain_best(T* A, int n, int n_points, Greater greater, GreaterEq ge, const PM& s,
@@ -387,7 +470,7 @@ __device__ __forceinline__ int par_retain_best(T* A, int n, int n_points, Greate
     }
     par_nth_element<NT>(A, n, n_points, greater, s, stage);
     const T ambiguous = A[n_points - 1];
-    return par_partition<NT>(
+    return par_partition_keep_true<NT>(
         A, n_points, n, [&](const T& x) { return ge(x, ambiguous); }, s);
   }
   return n;
