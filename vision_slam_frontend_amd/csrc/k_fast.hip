@@ -7,7 +7,7 @@
 // KeyPointsFilter::runByImageBorder(31) which is folded into the evaluated rectangle.
 //
 // Streaming march kernel -- no LDS, no barriers, no divergent corner/score phases:
-//  * a wave owns a band of 240 keypoint columns x a strip of 32 rows of one level of one image and walks down the
+//  * a wave owns a band of 248 keypoint columns x a strip of 32 rows of one level of one image and walks down the
 //    rows; each lane holds 4 adjacent pixels per row (one coalesced 32-bit load) in a 7-row register window (nine
 //    rotating register sets incl. two rows of read-ahead, no copies) and gets its neighbours' dwords by DPP wave shifts;
 //  * corner test and score are ONE dense computation: with d_k = p_k - v on the 16-pixel circle,
@@ -200,9 +200,9 @@ __device__ __forceinline__ ScoreRow make_score_row(v2s s02, v2s s13) {
   return o;
 }
 
-// HALF = false: the wave is one unit (cell) of 240 keypoint columns x 32 rows.
-// HALF = true : the two 32-lane halves of the wave are two cells of the level's LAST, narrow band (<= 112 keypoint
-//               columns = 28 lanes + 2 x 2 halo lanes) in two consecutive strips; each half keeps its own candidate
+// HALF = false: the wave is one unit (cell) of 248 keypoint columns x 32 rows.
+// HALF = true : the two 32-lane halves of the wave are two cells of the level's LAST, narrow band (<= 120 keypoint
+//               columns = 30 lanes + 2 halo lanes) in two consecutive strips; each half keeps its own candidate
 //               segment, row-start table and counter, so downstream nothing changes.  (The pyramid's 50 levels leave a
 //               narrow remainder band almost everywhere: 510 -> 446 waves per 640x480 image.)
 // NMS = false (standalone FAST without suppression only) keeps every corner and a zero response.
@@ -235,7 +235,7 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
   const int strip = strip0 + half;
   const bool valid = strip < L.nstrips;                     // (the second half of the last odd strip has no cell)
   const int bx0 = L.fast_a0 + VSF_FAST_BAND_COLS * band;
-  const int c0 = bx0 - 8 + 4 * hl;  // first column of this lane's 4 pixels
+  const int c0 = bx0 - 4 + 4 * hl;  // first column of this lane's 4 pixels (lane 1 starts the band)
   const bool loadable = c0 >= 0 && c0 + 3 < pitch;
   const int ys = L.y_lo + strip * SR;                       // per lane when HALF
   const int nrows = valid ? min(SR, L.y_hi - ys) : 0;       // rows of this lane's cell
@@ -247,8 +247,9 @@ __device__ __forceinline__ void fast_march_body(const FastArgs& a, int work, int
   for (int j = 0; j < 4; j++) {
     const int x = c0 + j;
     const uint32_t bit = 0xFFFFu << (16 * (j >> 1));
-    const bool sc_ok = hl >= 1 && hl <= HL - 2 && x >= sx_lo && x < sx_hi;
-    const bool em_ok = hl >= 2 && hl <= HL - 3 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS;
+    // lanes 1 .. HL-2 score and emit; lane 0 scores its last pixel only, lane HL-1 its first (the columns next to the band)
+    const bool sc_ok = ((hl >= 1 && hl <= HL - 2) || (hl == 0 && j == 3) || (hl == HL - 1 && j == 0)) && x >= sx_lo && x < sx_hi;
+    const bool em_ok = hl >= 1 && hl <= HL - 2 && x >= L.x_lo && x < L.x_hi && x < bx0 + VSF_FAST_BAND_COLS;
     if (j & 1) {
       if (sc_ok) sm13 |= bit;
       if (em_ok) em13 |= bit;

@@ -7,10 +7,12 @@
 
 #include "../../include/vsf.h"
 
-// FAST march kernel: a wave owns a band of 240 keypoint columns (lanes 2..61 x 4 px; lanes 1 and 62 add one
-// scored column block each side for the NMS, lanes 0 and 63 carry raw halo pixels) x a strip of 32 rows.
-#define VSF_FAST_BAND_COLS 240
-#define VSF_FAST_HALF_COLS 112   // a last band of at most this many columns is walked two strips per wave
+// FAST march kernel: a wave owns a band of 248 keypoint columns (lanes 1..62 x 4 px; lanes 0 and 63 carry the raw halo
+// pixels and score the ONE pixel next to the band -- lane 0's last, lane 63's first: their circles reach no further than
+// the lane's own dword and its inner neighbour's -- which is all the NMS of the band's edge columns needs) x a strip of 32
+// rows.  (Rounds 1-3: 240 columns, lanes 1 and 62 scored four pixels each for the sake of one.)
+#define VSF_FAST_BAND_COLS 248
+#define VSF_FAST_HALF_COLS 120   // a last band of at most this many columns is walked two strips per wave (30 lanes x 4)
 #define VSF_FAST_STRIP_ROWS 32
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
 #define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
