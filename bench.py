@@ -551,7 +551,7 @@ def main() -> int:
                        "capacity_overflow": bool(overflow_ranks)},
             # "bound" names the roofline this object is measured against (the contract knows "hbm" and "mfma");
             # "limited_by" says what the counters show the kernel is actually limited by (see "roofline_valu")
-            "roofline": {"bound": "hbm", "limited_by": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "limited_by": None if (pmc_stale or not pmc) else bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_stale": bool(pmc_stale),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "launches": dom_launches, "shares_the_chip_with": shares,

@@ -175,7 +175,10 @@ class Orb:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vsfo_orb_destroy(self._h)
+            try:
+                lib().vsfo_orb_destroy(self._h)
+            except TypeError:  # interpreter shutdown: the module's globals are gone already
+                pass
             self._h = None
 
     def run(self, img: np.ndarray) -> int:
