@@ -267,6 +267,9 @@ def main() -> int:
                     help="what carries the step's exchanges: torch.distributed (nccl = RCCL; the default, what the driver's "
                          "scaling run uses) or the C ABI's own vsf_allgather_dev / vsf_gather_payload_dev on librccl (the route "
                          "of a C++ host; in a world of one every exchange still runs, through RCCL)")
+    ap.add_argument("--fast-resident", type=int, default=None,
+                    help="force the FAST launch form (0 = grid, 2..4 = resident with that many waves per SIMD) instead of "
+                         "measuring it (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
@@ -372,9 +375,14 @@ def main() -> int:
             ingest.release()               # the buffer may be overwritten once this step's extraction has read it
 
     # Set-up, not warm-up: ONE explicit, blocking measurement of the two FAST launch forms on this rank's batch
-    # (vsf_tune_fast_resident: median of three runs each), made common over the ranks by one all-reduce -- every rank issues
-    # the same collective whatever it measured, and no library call inside the timed steps measures or waits for anything.
-    tune = sf.tune(d_imgs[0]) if (ingest is None and not args.blur_inline) else None
+    # (vsf_tune_fast_resident, then four whole steps per form: the form's worth shows in the composed step), made common
+    # over the ranks by one all-reduce -- every rank issues the same collectives whatever it measured, and no library call
+    # inside the timed steps measures or waits for anything.
+    tune = None
+    if args.fast_resident is not None:
+        ctx.set_fast_resident(args.fast_resident)
+    elif ingest is None and not args.blur_inline:
+        tune = sf.tune(d_imgs[0], steps=4)
     for _ in range(args.warmup):
         run_step()
     sf.drain()

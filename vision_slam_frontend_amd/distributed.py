@@ -490,24 +490,42 @@ class ShardedStereoFrontend:
             self.tail_ctx = None
 
     # ---- the one measured launch choice, made the same on every rank ----
-    def tune(self, d_img: torch.Tensor, samples: int = 3) -> dict:
+    def tune(self, d_img: torch.Tensor, samples: int = 3, steps: int = 0) -> dict:
         """Explicit and blocking (set-up, never inside a timed region): vsf_tune_fast_resident times the two forms of the
         FAST launch on this rank's own batch (median of `samples` runs each), then ONE all-reduce (max over ranks) of the
         two medians makes the choice common: the step time of the job is its slowest rank's, and ranks that ran different
         forms would hand each other a persistent per-step skew through the means all-gather.  Every rank issues exactly
-        this one collective whatever its own measurement returned (no rank-dependent control flow)."""
+        the same collectives whatever its own measurement returned (no rank-dependent control flow).
+        steps > 0 (bench.py): the two forms are timed on whole STEPS of this class instead -- one untimed step, then `steps`
+        timed ones per form, on `d_img` -- because what the form is worth shows in the composed, pipelined step (the blur
+        beside FAST, the next step's pyramid beside this step's tail), where it is twice what an extraction by itself shows;
+        an ineligible batch (the library reports 0 / 0: fewer than 32 images, blur in line) runs no steps."""
         raw = self.raw[0]
         with torch.cuda.stream(self.stream):
             g, r = self.ctx.tune_fast_resident(d_img.data_ptr(), 2 * self.B, self.width * self.height, self.width,
                                                raw["kp"].data_ptr(), raw["desc"].data_ptr(), raw["counts"].data_ptr(),
                                                samples)
+        extraction_ms = (g, r)
+        if steps > 0 and g > 0.0 and r > 0.0:
+            per_form = []
+            for form in (0, 3):
+                self.ctx.set_fast_resident(form)
+                self.step(d_img)
+                self.drain()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.step(d_img)
+                self.drain()
+                per_form.append(1e3 * (time.perf_counter() - t0) / steps)
+            g, r = per_form
         mine = (g, r)
         if self.dist_on:
             g, r = self.comm.all_reduce_max([g, r], self.dev)
         choice = 3 if (r > 0.0 and r < g) else 0
         self.ctx.set_fast_resident(choice)
         return {"ms_grid": g, "ms_resident": r, "this_rank_ms": list(mine), "fast_resident": choice, "samples": samples,
-                "agreed_over_ranks": self.world}
+                "timed_on": "%d whole steps per form" % steps if (steps > 0 and extraction_ms[0] > 0.0) else "the extraction by itself",
+                "extraction_ms": list(extraction_ms), "agreed_over_ranks": self.world}
 
     # ---- static schedule of the temporal pairs ----
     def _pair_sets(self, parity: int, first_step: bool):
