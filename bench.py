@@ -375,14 +375,14 @@ def main() -> int:
             ingest.release()               # the buffer may be overwritten once this step's extraction has read it
 
     # Set-up, not warm-up: ONE explicit, blocking measurement of the two FAST launch forms on this rank's batch
-    # (vsf_tune_fast_resident, then four whole steps per form: the form's worth shows in the composed step), made common
+    # (vsf_tune_fast_resident, then six whole steps per form on the rotating batches: the form's worth shows in the composed step), made common
     # over the ranks by one all-reduce -- every rank issues the same collectives whatever it measured, and no library call
     # inside the timed steps measures or waits for anything.
     tune = None
     if args.fast_resident is not None:
         ctx.set_fast_resident(args.fast_resident)
     elif ingest is None and not args.blur_inline:
-        tune = sf.tune(d_imgs[0], steps=4)
+        tune = sf.tune(d_imgs, steps=6)
     for _ in range(args.warmup):
         run_step()
     sf.drain()

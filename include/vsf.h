@@ -152,7 +152,8 @@ typedef enum {
   VSF_OPT_PYRAMID_FEW = 5,   /* 16: largest batch (images) whose pyramid is built by the slab kernel */
   VSF_OPT_PYRAMID_CHAIN = 6, /* 8: levels per slab launch; 0: per-level launches even for a frame or two */
   VSF_OPT_PYRAMID_ROWS = 7,  /* 6: rows of a chain's last level per slab */
-  VSF_OPT_COUNT = 8
+  VSF_OPT_SELECT_BIG_CLASS = 8, /* 1: a batch's widest levels keep their candidate array in LDS (9 216 entries, tables in HBM) */
+  VSF_OPT_COUNT = 9
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);

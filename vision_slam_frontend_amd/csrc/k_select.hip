@@ -525,10 +525,15 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
 }
 
 // ENTRIES: stage-1 candidates kept in LDS; STAGE2: stage-2 pairs kept in LDS; MAXW: mask words of a parallel pass.
-template <int NT, int ENTRIES, int STAGE2, int MAXW>
-__global__ __launch_bounds__(NT, NT == 256 ? 5 : 1) void orb_select_kernel(SelectArgs a) {
+// LDS_TABLES = false (round 4, the class of the widest levels): the ARRAY of a level with up to ENTRIES candidates lives in
+// LDS from the gather on, and only the rank -> position tables of its passes (16-bit, written once and read once per pass)
+// go through the level's HBM scratch -- instead of the array itself, its masks and 32-bit tables living there until the
+// selection range has shrunk to the common class's 3 072 entries (two or three passes over 4 ... 8 000 elements each).
+template <int NT, int ENTRIES, int STAGE2, int MAXW, bool LDS_TABLES = true, int WGS = (NT == 256 ? 5 : 1)>
+__global__ __launch_bounds__(NT, WGS) void orb_select_kernel(SelectArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t sA[ENTRIES];
-  __shared__ uint16_t sPos[2 * ENTRIES];  // rank -> position tables of the LDS-resident passes
+  constexpr int POS16 = LDS_TABLES ? 2 * ENTRIES : 4096;  // 16-bit words of sPos
+  __shared__ uint16_t sPos[POS16];  // rank -> position tables of the LDS-resident passes (and the gather's scratch)
   __shared__ __attribute__((aligned(16))) uint2 sB[STAGE2];
   __shared__ unsigned long long sMask[2 * MAXW];
   __shared__ int sPre[2 * MAXW];
@@ -536,7 +541,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 5 : 1) void orb_select_kernel(Selec
   __shared__ int lds4[16];
   static_assert(ENTRIES <= 65536 && ENTRIES / 64 <= MAXW && STAGE2 <= ENTRIES && ENTRIES >= 1025, "scratch sizes");
   // the gather borrows the position tables: three quarters for the cell prefix array, one for the row-start tables
-  constexpr int kCellCap = ENTRIES * 3 / 4, kRsUnits = (ENTRIES / 4) * 2 / VSF_FAST_RS_STRIDE;
+  constexpr int kCellCap = (POS16 / 2) * 3 / 4, kRsUnits = (POS16 / 8) * 2 / VSF_FAST_RS_STRIDE;
+  static_assert(kCellCap >= VSF_FAST_STRIP_ROWS * 16 + 1 && kRsUnits >= 8, "gather scratch");
   int* cellpre = reinterpret_cast<int*>(sPos);
   uint16_t* rs_lds = reinterpret_cast<uint16_t*>(cellpre + kCellCap);
   const int tid = threadIdx.x;
@@ -569,7 +575,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 5 : 1) void orb_select_kernel(Selec
   static_assert(sizeof(uint2) * STAGE2 >= kWaveScratch && sizeof(uint32_t) * ENTRIES >= kWaveScratch, "wave scratch");
   uint8_t* wbuf1 = reinterpret_cast<uint8_t*>(sB);
   uint8_t* wbuf2 = reinterpret_cast<uint8_t*>(sA);
-  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, sPos, sPos + ENTRIES, ENTRIES / 64, &ctl, wbuf1};
+  // (LDS_TABLES = false: the two 16-bit tables sit in the level's slices of scratch blocks 3 and 4 -- level_cap 32-bit
+  // words each, i.e. room for 2 level_cap positions -- where the HBM-resident passes keep their 32-bit ones)
+  uint16_t* tabL = LDS_TABLES ? sPos : reinterpret_cast<uint16_t*>(gscratch + 3 * a.cand_entries + L.cand_offset);
+  uint16_t* tabR = LDS_TABLES ? sPos + ENTRIES : reinterpret_cast<uint16_t*>(gscratch + 4 * a.cand_entries + L.cand_offset);
+  const PassMem<uint16_t> pm_lds{sMask, sMask + MAXW, sPre, sPre + MAXW, tabL, tabR, ENTRIES / 64, &ctl, wbuf1};
   // HBM-resident passes keep their masks in HBM as well (24 bytes per 64 elements, carved from the level's slice of
   // the sixth scratch block), so a level of any candidate count runs the parallel passes
   const int level_cap = L.seg_cap * L.nbands * L.nstrips, hbm_w = (level_cap + 63) / 64;
@@ -742,9 +752,36 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
     a.nlv = ntiny0;
     hipLaunchKernelGGL((orb_select_kernel<1024, 12288, 512, 192>), dim3(a.nlv * n8), dim3(1024), 0, s, a);
   } else if (ntiny0 > 0) {
-    a.level0 = 0;
-    a.nlv = ntiny0;
-    hipLaunchKernelGGL((orb_select_kernel<256, 3072, 512, 64>), dim3(a.nlv * n8), dim3(256), 0, s, a);
+    // Levels whose area holds more than 3 072 but (on a busy scene: one candidate per ~30 pixels) no more than 9 216
+    // candidates take the 9 216-entry class, three per CU: their array lives in LDS from the gather on.  Larger levels
+    // (1920x1080's first twenty-odd: up to 70 000 candidates) would fall back to HBM-resident passes in ANY class and keep
+    // the common one, whose five workgroups per CU hide those passes' latency better (1080p, 96 frames per step: 2.03 ms
+    // against 2.40 ms with every wide level in the 9 216-entry class).
+    int nhuge = 0;
+    while (nhuge < ntiny0) {
+      const VsfLevel& L = h_levels[nhuge];
+      if ((long)(L.x_hi - L.x_lo) * (L.y_hi - L.y_lo) <= 300000) break;
+      ++nhuge;
+    }
+    // ... and only when there are enough of them to fill its three slots per CU a few times over (64 images at 1080p are
+    // 900 such workgroups for 768 slots: one round and a long tail -- 5 450 -> 5 090 frames/s)
+    int nwide_end = (d.tune && !d.tune->select_big_class) ? nhuge : std::max(nhuge, std::min(nbig, ntiny0));
+    if ((long)(nwide_end - nhuge) * im.n < 1536) nwide_end = nhuge;
+    auto common = [&](int l0, int l1) {
+      if (l1 <= l0) return;
+      a.level0 = l0;
+      a.nlv = l1 - l0;
+      hipLaunchKernelGGL((orb_select_kernel<256, 3072, 512, 64>), dim3(a.nlv * n8), dim3(256), 0, s, a);
+    };
+    if (nwide_end == nhuge) nhuge = nwide_end = 0;  // (no wide class this time: ONE launch of the common class, as before)
+    common(0, nhuge);
+    if (nwide_end > nhuge) {
+      a.level0 = nhuge;
+      a.nlv = nwide_end - nhuge;
+      hipLaunchKernelGGL((orb_select_kernel<256, 9216, 512, 144, false, 3>), dim3(a.nlv * n8), dim3(256), 0, s, a);
+    }
+    // (one after the other on the stream: beside each other on two streams the pair took 0.4 ms longer per step)
+    common(nwide_end, ntiny0);
   }
   if (ntiny0 < g.nlevels) {
     a.level0 = ntiny0;

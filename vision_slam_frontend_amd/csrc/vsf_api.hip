@@ -1275,6 +1275,7 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
       break;
     case VSF_OPT_SORT_SERIAL: t.sort_serial = value != 0; break;
     case VSF_OPT_SELECT_WIDE: t.select_wide = value != 0; break;
+    case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
     case VSF_OPT_JPEG_SERIAL:
       if (!value && vsf_prepare_jpeg_kernels(t.lds_limit) != hipSuccess) {  // (the parallel decoder's LDS was refused)
         (void)hipGetLastError();
@@ -1308,6 +1309,7 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
     case VSF_OPT_FAST_BOTH_MAX: *value = t.fast_both_max; break;
     case VSF_OPT_SORT_SERIAL: *value = t.sort_serial; break;
     case VSF_OPT_SELECT_WIDE: *value = t.select_wide; break;
+    case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
     case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
     case VSF_OPT_PYRAMID_CHAIN: *value = t.pyramid_chain; break;

@@ -92,6 +92,7 @@ struct VsfTuning {
   int fast_both_max = 16;  // VSF_OPT_FAST_BOTH_MAX: largest batch (images) whose full and half-wave FAST cells share one launch
   int sort_serial = 0;     // VSF_OPT_SORT_SERIAL: 1 = sort_trim's one-lane kernel
   int select_wide = 1;     // VSF_OPT_SELECT_WIDE: 1 = a frame or two takes the 1024-thread whole-level selection class
+  int select_big_class = 1;  // VSF_OPT_SELECT_BIG_CLASS: 1 = the widest levels of a batch take the 9 216-entry class
   int jpeg_serial = 0;     // VSF_OPT_JPEG_SERIAL: 1 = every file through the one-wave-per-image decoder
   int pyramid_few = 16;    // VSF_OPT_PYRAMID_FEW: largest batch (images) that takes the slab kernel for every level
   int pyramid_chain = 8;   // VSF_OPT_PYRAMID_CHAIN: levels per slab launch (0: keep the per-level launches)

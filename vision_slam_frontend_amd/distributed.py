@@ -490,16 +490,19 @@ class ShardedStereoFrontend:
             self.tail_ctx = None
 
     # ---- the one measured launch choice, made the same on every rank ----
-    def tune(self, d_img: torch.Tensor, samples: int = 3, steps: int = 0) -> dict:
+    def tune(self, d_img, samples: int = 3, steps: int = 0) -> dict:
         """Explicit and blocking (set-up, never inside a timed region): vsf_tune_fast_resident times the two forms of the
         FAST launch on this rank's own batch (median of `samples` runs each), then ONE all-reduce (max over ranks) of the
         two medians makes the choice common: the step time of the job is its slowest rank's, and ranks that ran different
         forms would hand each other a persistent per-step skew through the means all-gather.  Every rank issues exactly
         the same collectives whatever its own measurement returned (no rank-dependent control flow).
         steps > 0 (bench.py): the two forms are timed on whole STEPS of this class instead -- one untimed step, then `steps`
-        timed ones per form, on `d_img` -- because what the form is worth shows in the composed, pipelined step (the blur
-        beside FAST, the next step's pyramid beside this step's tail), where it is twice what an extraction by itself shows;
-        an ineligible batch (the library reports 0 / 0: fewer than 32 images, blur in line) runs no steps."""
+        timed ones per form, on `d_img` (a batch, or a list of batches taken in turn as the caller's own loop will) -- because
+        what the form is worth shows in the composed, pipelined step (the blur beside FAST, the next step's pyramid beside
+        this step's tail), where it is twice what an extraction by itself shows; an ineligible batch (the library reports
+        0 / 0: fewer than 32 images, blur in line) runs no steps."""
+        batches = list(d_img) if isinstance(d_img, (list, tuple)) else [d_img]
+        d_img = batches[0]
         raw = self.raw[0]
         with torch.cuda.stream(self.stream):
             g, r = self.ctx.tune_fast_resident(d_img.data_ptr(), 2 * self.B, self.width * self.height, self.width,
@@ -510,11 +513,11 @@ class ShardedStereoFrontend:
             per_form = []
             for form in (0, 3):
                 self.ctx.set_fast_resident(form)
-                self.step(d_img)
+                self.step(batches[-1])
                 self.drain()
                 t0 = time.perf_counter()
-                for _ in range(steps):
-                    self.step(d_img)
+                for i in range(steps):
+                    self.step(batches[i % len(batches)])
                 self.drain()
                 per_form.append(1e3 * (time.perf_counter() - t0) / steps)
             g, r = per_form
