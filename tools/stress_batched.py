@@ -48,6 +48,10 @@ for c in range(n_cases):
     h = int(rng.integers(90, 560))
     nf = int(rng.choice([100, 500, 1000, 2000, 4000]))
     B = int(rng.integers(16, 28))
+    if c % 4 == 3:  # a large batch of a wide geometry: the batched selection's 9 216-entry class (>= 1 536 wide-level workgroups)
+        w = 16 * int(rng.integers(36, 50))
+        h = int(rng.integers(430, 560))
+        B = int(rng.integers(72, 100))
     resident = int(rng.choice([2, 3, 3, 4]))
     pipeline = bool(rng.integers(0, 2))
     repeats = int(rng.integers(1, 4))

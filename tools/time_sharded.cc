@@ -28,13 +28,16 @@ extern "C" void vsfh_default_calibration(vsf_calibration* out);
 
 using Clock = std::chrono::steady_clock;
 
+// A failed call ends the PROCESS: the other ranks' threads are waiting in a barrier or inside an RCCL collective for this one
+// and would wait for ever.
 #define CK(call)                                                                                   \
   do {                                                                                             \
     const int st_ = (int)(call);                                                                   \
     if (st_ != 0) {                                                                                \
       std::fprintf(stderr, "rank %d: %s failed with %d (%s:%d)\n", rank, #call, st_, __FILE__, __LINE__); \
-      failed->store(true);                                                                         \
-      return;                                                                                      \
+      std::fflush(stderr);                                                                         \
+      (void)failed;                                                                                \
+      std::_Exit(1);                                                                               \
     }                                                                                              \
   } while (0)
 
