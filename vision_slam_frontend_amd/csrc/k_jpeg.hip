@@ -10,7 +10,7 @@
 // threads per image decode 256 segments of the stream speculatively and iterate until their states agree, or -- files
 // with restart intervals -- decode the intervals, whose start states are known, side by side.  Files whose Huffman
 // tables need more second-level lookup tables than DevHuff holds, files with more restart intervals than the scratch
-// has room to list -- and everything under VSF_JPEG_SERIAL=1 -- take the one described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
+// has room to list -- and everything under VSF_OPT_JPEG_SERIAL -- take the one described here: the entropy-coded segment is walked serially, ONE WAVE PER IMAGE -- its SCALAR unit walks the Huffman
 // codes (wave-uniform code: state in SGPRs, stream words and 9-bit lookahead tables through scalar loads, T.81 F.2.2.3
 // for longer codes; FF00 unstuffing; RSTn / DC-prediction resets), drops chroma blocks and parks up to 16 luminance
 // blocks of coefficients in LDS; then the 64 lanes dequantise and run the two IDCT passes (lane = block x column, then
