@@ -12,14 +12,13 @@ F_RECT = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
 POINT_RTOL, PIXEL_ATOL = 1e-5, 1e-4
 
 
-def test_observe_stereo_follows_the_reference_sequence(oracle):
-    from vision_slam_frontend_amd import capi, frontend, synth
-    sc = synth.Scene(320, 240, n_objects=400)
-    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(7)]
-    frames[3] = (frames[3][0], np.full_like(frames[3][1], 128))  # no stereo match in frame 3
+def _follow_reference_sequence(oracle, frames, width, height, NF, LIFE):
+    """Runs `frames` [(left, right)] through vsf_observe_stereo and through the reference's sequence on the oracle, frame by
+    frame; returns the context (still open), the calibration and the per-frame feature counts."""
+    from vision_slam_frontend_amd import capi, frontend
     calib = frontend.default_calibration().set("fundamental", F_RECT)
     bp = float(np.float32(0.3))
-    ctx = capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF))
+    ctx = capi.Context(capi.default_params(width, height, max_images=2, nfeatures=NF))
     thr = np.float32(10000.0)
     window = []  # filtered left descriptors of the kept frames, oldest first
     sizes = []
@@ -64,12 +63,41 @@ def test_observe_stereo_follows_the_reference_sequence(oracle):
             window.pop(0)
         window.append(dl2)
         sizes.append(len(kl2))
+    return ctx, calib, sizes
+
+
+def test_observe_stereo_follows_the_reference_sequence(oracle):
+    from vision_slam_frontend_amd import synth
+    sc = synth.Scene(320, 240, n_objects=400)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(7)]
+    frames[3] = (frames[3][0], np.full_like(frames[3][1], 128))  # no stereo match in frame 3
+    ctx, calib, sizes = _follow_reference_sequence(oracle, frames, 320, 240, NF, LIFE)
     assert sizes[3] == 0 and sizes[4] == 0 and sizes[5] > 20  # no match; NaN threshold; filtering resumes
     # a reset forgets the window and the threshold
     ctx.observe_reset()
-    again = ctx.observe_stereo(*frames[0], calib, best_percent=bp, frame_life=LIFE)
+    again = ctx.observe_stereo(*frames[0], calib, best_percent=float(np.float32(0.3)), frame_life=LIFE)
     assert again["threshold"] == np.float32(10000.0) and len(again["factors"]) == 0
     ctx.close()
+
+
+def test_observe_stereo_on_photographs(oracle):
+    """The same frame-by-frame comparison on photographs at 640x480 / 2000 features (tests/golden/real/): a real rectified
+    stereo pair (Middlebury motorcycle) that drifts 3 pixels per frame, then a cameraman seen 7 pixels right and 2 pixels
+    down by the right camera (a constant epipolar residual of 2: the adaptive threshold of RemoveAmbigStereo settles on
+    mean + 2 = 4), a gravel texture with a pure horizontal disparity, and the stereo pair again -- a window of 3 that fills,
+    slides and matches across a scene change."""
+    from pathlib import Path
+
+    from PIL import Image
+    real = Path(__file__).resolve().parent / "golden" / "real"
+    img = {n: np.asarray(Image.open(real / (n + ".png"))) for n in ("motorcycle_left", "motorcycle_right", "camera", "camera_shift", "gravel")}
+    roll = lambda a, dx: np.ascontiguousarray(np.roll(a, dx, 1))  # noqa: E731
+    frames = [(roll(img["motorcycle_left"], 3 * k), roll(img["motorcycle_right"], 3 * k)) for k in range(3)]
+    frames += [(roll(img["camera"], 2 * k), roll(img["camera_shift"], 2 * k)) for k in range(2)]
+    frames += [(img["gravel"], roll(img["gravel"], 5)), (img["motorcycle_left"], img["motorcycle_right"])]
+    ctx, _, sizes = _follow_reference_sequence(oracle, frames, 640, 480, 2000, 3)
+    ctx.close()
+    assert min(sizes[:3]) > 30 and sizes[3] > 300 and sizes[5] > 100, sizes
 
 
 def _same_observation(a: dict, b: dict):
