@@ -109,3 +109,37 @@ def test_synthetic_generator_is_deterministic():
     assert d.shape == (100, 32) and synth.sha256(d) == synth.sha256(synth.random_descriptors(100))
     a = synth.adversarial_descriptors(500)
     assert len(np.unique(a, axis=0)) < 450  # many exact duplicates
+
+
+def test_counter_files_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """profiles/traffic*.json and profiles/r04/valu_ceiling.json carry a digest of csrc's CODE (comments and white space do
+    not count); bench.py publishes their numbers only while the sources it runs still hash to it (round-3 review: nothing
+    tied the committed counters to the kernels that ran)."""
+    import json
+    import shutil
+    import sys
+
+    from vision_slam_frontend_amd import buildinfo
+    h = buildinfo.kernel_source_hash()
+    assert len(h) == 64
+    # (whether the committed files are fresh is a fact about the last profiling run, not a test: a kernel edit without a
+    # counter refresh must only make bench.py say so)
+    committed = json.loads((ROOT / "profiles" / "traffic.json").read_text())["source_hash"]
+    # a copy of csrc: a reworded comment keeps the digest, a changed token does not
+    copy = tmp_path / "csrc"
+    shutil.copytree(ROOT / "vision_slam_frontend_amd" / "csrc", copy, ignore=shutil.ignore_patterns("*.o", "*.inc"))
+    monkeypatch.setattr(buildinfo, "CSRC", copy)
+    assert buildinfo.kernel_source_hash() == h
+    f = copy / "k_fast.hip"
+    f.write_text("// a new remark\n" + f.read_text().replace("FAST-9/16 segment test", "FAST 9 of 16"))
+    assert buildinfo.kernel_source_hash() == h
+    f.write_text(f.read_text().replace("constexpr int SR = VSF_FAST_STRIP_ROWS;", "constexpr int SR = VSF_FAST_STRIP_ROWS + 0;"))
+    assert buildinfo.kernel_source_hash() != h
+    sys.argv = ["bench.py"]
+    sys.path.insert(0, str(ROOT))
+    import bench
+    stages, stale = bench.committed_counters(640, 480, 2000, 256)
+    assert stale and stages  # (bench.py then prints roofline.traffic: null and traffic_stale: true)
+    monkeypatch.setattr(buildinfo, "CSRC", ROOT / "vision_slam_frontend_amd" / "csrc")
+    stages, stale = bench.committed_counters(640, 480, 2000, 256)
+    assert stale == (committed != h) and stages["fast_score_nms"]["valu_wave_insts_per_step"] > 1e9
