@@ -143,3 +143,21 @@ def test_counter_files_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     monkeypatch.setattr(buildinfo, "CSRC", ROOT / "vision_slam_frontend_amd" / "csrc")
     stages, stale = bench.committed_counters(640, 480, 2000, 256)
     assert stale == (committed != h) and stages["fast_score_nms"]["valu_wave_insts_per_step"] > 1e9
+
+
+def test_comm_entry_points_check_their_arguments(capi):
+    """The multi-GPU exchange of include/vsf.h without a GPU: every entry point refuses null / out-of-range arguments with a
+    status (never a crash), and vsf_comm_destroy(NULL) is a no-op."""
+    L = capi.lib()
+    h = ctypes.c_void_p()
+    buf = (ctypes.c_uint8 * 128)()
+    assert L.vsf_comm_unique_id(None) == capi.VSF_ERR_INVALID_ARG
+    assert L.vsf_comm_create(None, buf, 0, 1, ctypes.byref(h)) == capi.VSF_ERR_INVALID_ARG
+    assert L.vsf_comm_info(None, None, None, None) == capi.VSF_ERR_INVALID_ARG
+    assert L.vsf_allgather_dev(None, None, None, None, 4) == capi.VSF_ERR_INVALID_ARG
+    assert L.vsf_gather_payload_dev(None, None, None, 16, None, 16, 0) == capi.VSF_ERR_INVALID_ARG
+    L.vsf_comm_destroy(None)
+    assert L.vsf_set_option(None, 0, 0) == capi.VSF_ERR_INVALID_ARG and L.vsf_get_option(None, 0, None) == capi.VSF_ERR_INVALID_ARG
+    g, r = ctypes.c_float(), ctypes.c_float()
+    assert L.vsf_tune_fast_resident(None, None, 64, 0, 0, None, None, None, 3, ctypes.byref(g), ctypes.byref(r)) == capi.VSF_ERR_INVALID_ARG
+    assert L.vsf_debug_inject_hip_error(None, 1) == capi.VSF_ERR_INVALID_ARG
