@@ -70,6 +70,8 @@ struct Shared {
   int rccl_version = 0;
   std::vector<std::vector<uint8_t>> payloads;  // rank 0: [step * world + r]
   bool keep = false;
+  int fast_form = 0;
+  float tune_ms[2] = {0.f, 0.f};
 };
 
 template <class T>
@@ -204,18 +206,13 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
       CK(vsf_comm_info(comm, nullptr, nullptr, &S->rccl_version));
     }
   }
-  // ---- the one measured launch choice, made common: medians of both FAST forms, max over the ranks ----
+  // (which batches have two FAST forms at all is the library's knowledge: its tune call reports 0 / 0 for one that has not)
+  bool fast_eligible = false;
+  int fast_form = 0;
   if (!S->keep) {
     float ms[2] = {0.f, 0.f};
-    CK(vsf_tune_fast_resident(ctx, d_img, 2 * B, img_bytes, W, d_kp[0], d_desc[0], d_counts[0], 3, &ms[0], &ms[1]));
-    CK(hipMemcpy(d_tune + 2 * world, ms, 8, hipMemcpyHostToDevice));
-    CK(vsf_allgather_dev(tctx, comm, d_tune + 2 * world, d_tune, 8));
-    CK(vsf_sync(tctx));
-    std::vector<float> every(2 * world);
-    CK(hipMemcpy(every.data(), d_tune, 8 * world, hipMemcpyDeviceToHost));
-    float g = 0.f, r = 0.f;
-    for (int k = 0; k < world; k++) g = std::max(g, every[2 * k]), r = std::max(r, every[2 * k + 1]);
-    CK(vsf_set_fast_resident(ctx, (r > 0.f && r < g) ? 3 : 0));
+    CK(vsf_tune_fast_resident(ctx, d_img, 2 * B, img_bytes, W, d_kp[0], d_desc[0], d_counts[0], 1, &ms[0], &ms[1]));
+    fast_eligible = ms[0] > 0.f && ms[1] > 0.f;
   }
 
   int next_gather = 0;  // first step whose payload has not been handed to the gather yet
@@ -237,17 +234,7 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
     next_gather = step + 1;
   };
 
-  const int warm = S->keep ? 0 : 3;
-  S->bar->wait();
-  Clock::time_point t0 = Clock::now();
-  for (int s = 0; s < S->steps + warm; s++) {
-    if (s == warm && warm > 0) {
-      while (next_gather < s) issue_gather(next_gather);
-      CK(vsf_sync(ctx));
-      CK(vsf_sync(tctx));
-      S->bar->wait();
-      t0 = Clock::now();
-    }
+  auto run_step = [&](int s) {
     const int parity = s & 1, b = s & 1, slot = s % SLOTS;
     const uint8_t* img = d_img + (size_t)(s % blocks) * 2 * B * img_bytes;
     // 1: extract(L), extract(R), GetMatches (cc:411-416) on the main stream, into raw buffer b
@@ -285,10 +272,45 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
     CK(hipMemcpyAsync(h_sizes[slot], d_sizes[slot], 4 * world, hipMemcpyDeviceToHost, s_tail));
     CK(hipEventRecord(ev_sizes[slot], s_tail));
     while (next_gather < s) issue_gather(next_gather);
+  };
+  int step = 0;  // global step counter (payload slots, raw buffers and the temporal window follow it)
+  auto drain = [&]() {
+    while (next_gather < step) issue_gather(next_gather);
+    CK(vsf_sync(ctx));
+    CK(vsf_sync(tctx));
+  };
+  // ---- the one measured launch choice, on whole steps (bench.py's ShardedStereoFrontend.tune): per FAST form one untimed
+  // step and four timed ones on the rotating batches; the two times go through ONE all-gather, the maximum over the ranks
+  // decides, every rank sets the same form ----
+  if (!S->keep && fast_eligible) {
+    float ms[2] = {0.f, 0.f};
+    for (int form = 0; form < 2; form++) {
+      CK(vsf_set_fast_resident(ctx, form ? 3 : 0));
+      run_step(step++);
+      drain();
+      const Clock::time_point a = Clock::now();
+      for (int k = 0; k < 4; k++) run_step(step++);
+      drain();
+      ms[form] = (float)(1e3 * std::chrono::duration<double>(Clock::now() - a).count() / 4);
+    }
+    CK(hipMemcpy(d_tune + 2 * world, ms, 8, hipMemcpyHostToDevice));
+    CK(vsf_allgather_dev(tctx, comm, d_tune + 2 * world, d_tune, 8));
+    CK(vsf_sync(tctx));
+    std::vector<float> every(2 * world);
+    CK(hipMemcpy(every.data(), d_tune, 8 * world, hipMemcpyDeviceToHost));
+    float g = 0.f, r = 0.f;
+    for (int k = 0; k < world; k++) g = std::max(g, every[2 * k]), r = std::max(r, every[2 * k + 1]);
+    fast_form = (r > 0.f && r < g) ? 3 : 0;
+    CK(vsf_set_fast_resident(ctx, fast_form));
+    if (rank == 0) S->fast_form = fast_form, S->tune_ms[0] = g, S->tune_ms[1] = r;
   }
-  while (next_gather < S->steps + warm) issue_gather(next_gather);
-  CK(vsf_sync(ctx));
-  CK(vsf_sync(tctx));
+  const int warm = S->keep ? 0 : 3;
+  for (int k = 0; k < warm; k++) run_step(step++);
+  drain();
+  S->bar->wait();
+  const Clock::time_point t0 = Clock::now();
+  for (int k = 0; k < S->steps; k++) run_step(step++);
+  drain();
   S->rank_seconds[rank] = std::chrono::duration<double>(Clock::now() - t0).count();
   S->bar->wait();
   vsf_comm_destroy(comm);
@@ -355,8 +377,9 @@ int main(int argc, char** argv) {
   }
   std::printf("{\"what\": \"sharded hot path through the C ABI, one thread per GPU (tools/time_sharded.cc)\", \"n_gpus\": %d, "
               "\"frames_per_rank\": %d, \"window\": %d, \"steps\": %d, \"stereo_frames_per_s\": %.1f, \"ms_per_step\": %.3f, "
-              "\"rccl_version\": %d, \"ranks_seen\": [",
-              S.world, S.B, S.window, S.steps, (double)S.world * S.B * S.steps / slowest, 1e3 * slowest / S.steps, S.rccl_version);
+              "\"fast_resident\": %d, \"tune_ms_grid\": %.3f, \"tune_ms_resident\": %.3f, \"rccl_version\": %d, \"ranks_seen\": [",
+              S.world, S.B, S.window, S.steps, (double)S.world * S.B * S.steps / slowest, 1e3 * slowest / S.steps, S.fast_form,
+              S.tune_ms[0], S.tune_ms[1], S.rccl_version);
   for (int r = 0; r < (int)S.ranks_seen.size(); r++) std::printf("%s%d", r ? ", " : "", S.ranks_seen[r]);
   std::printf("], \"note\": \"frames resident in HBM, the step's tail and every exchange on a second stream beside the next "
               "step's extraction, the FAST form measured and agreed over the ranks before the timed steps: the composition of "
