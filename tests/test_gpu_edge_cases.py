@@ -179,3 +179,19 @@ def test_bayer_bg_to_gray_batch(capi, oracle, w, h, n):
         got = d_dst.cpu().numpy()
     for i in range(n):
         np.testing.assert_array_equal(got[i, :, :w], oracle.bayer_bg_to_gray(src[i, :, :w]), err_msg="image %d" % i)
+
+
+@pytest.mark.parametrize("w,h,nf", [(3840, 2160, 8000), (4000, 120, 1000), (96, 3000, 500), (2048, 2048, 4000)])
+def test_extreme_geometries(oracle, w, h, nf):
+    """Image sizes at the ends of what the geometry tables hold (level width <= 4095, 12-bit candidate coordinates): 4K, a
+    strip 4000 wide and 120 high (sixteen FAST bands, two strips), a strip 96 wide and 3000 high, a 2048 square --
+    keypoints and descriptors of vsf_extract bit for bit against the oracle."""
+    from vision_slam_frontend_amd import capi, synth
+    left, _ = synth.stereo_pair(w, h, 1, n_objects=max(50, w * h // 4000))
+    o = oracle.Orb(nfeatures=nf)
+    o.run(left)
+    rk, rd = o.result()
+    with capi.Context(capi.default_params(w, h, max_images=1, nfeatures=nf)) as ctx:
+        kp, desc = ctx.extract(left, cap=len(rk) + 64)
+    assert len(kp) == len(rk) > 100 and kp.tobytes() == rk.tobytes()
+    np.testing.assert_array_equal(desc, rd)
