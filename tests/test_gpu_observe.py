@@ -149,3 +149,54 @@ def test_frames_in_flight_equal_the_synchronous_calls(slots):
     for g, w in zip(got, want):
         _same_observation(w, g)
     assert sum(len(f["features"]) for f in want) > 100
+
+
+def test_capacity_overflow_is_reported_on_its_own_ticket():
+    """Three frames in flight, each on its slot's stream (vsf_observe_submit): a frame whose keypoints overflow the output
+    capacity must get VSF_ERR_CAPACITY on ITS ticket, and a frame that does not must get VSF_OK -- whatever its neighbours
+    in flight did.  (Round-3 review: all slots shared one device status word; a frame's tail copied and cleared it while
+    the next frame's extraction, on another stream, was still setting it -- an overflow could land on the wrong ticket or be
+    wiped.)  Busy and flat frames alternate in every order of arrival over 18 frames."""
+    from vision_slam_frontend_amd import capi, frontend, synth
+    w, h = 320, 240
+    busy = synth.stereo_pair(w, h, 0, n_objects=400)          # > 400 keypoints per image at nfeatures 500
+    flat = (np.full((h, w), 90, np.uint8), np.full((h, w), 90, np.uint8))
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    p = capi.default_params(w, h, max_images=6, nfeatures=500, max_keypoints=200)   # 6 images: three slots
+    pattern = [1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 0, 0, 0, 1, 0, 1, 1]              # 1 = busy frame
+    with capi.Context(p) as ctx:
+        tickets, got = [], []
+
+        def collect(t):
+            try:
+                ctx.observe_collect(t, frame_life=2)
+                got.append(capi.VSF_OK)
+            except capi.VsfError as e:
+                got.append(e.status)
+
+        for k, b in enumerate(pattern):
+            if len(tickets) == 3:
+                collect(tickets.pop(0))
+            tickets.append(ctx.observe_submit(*(busy if b else flat), calib, frame_life=2))
+        while tickets:
+            collect(tickets.pop(0))
+    want = [capi.VSF_ERR_CAPACITY if b else capi.VSF_OK for b in pattern]
+    assert got == want, list(zip(pattern, got))
+
+
+def test_destroy_with_frames_still_in_flight():
+    """vsf_destroy waits for every stream the context launched on -- the slots' streams of frames that were submitted and never
+    collected included -- before it frees what their kernels write (device buffers, the pinned result and status words);
+    and a context created afterwards works (round-3 review: only three of the streams were synchronised)."""
+    from vision_slam_frontend_amd import capi, frontend, synth
+    w, h = 320, 240
+    left, right = synth.stereo_pair(w, h, 0, n_objects=400)
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    for _ in range(3):
+        ctx = capi.Context(capi.default_params(w, h, max_images=6, nfeatures=500))
+        for _k in range(3):
+            ctx.observe_submit(left, right, calib, frame_life=2)
+        ctx.close()  # three frames pending
+    with capi.Context(capi.default_params(w, h, max_images=6, nfeatures=500)) as ctx:
+        r = ctx.observe_stereo(left, right, calib, frame_life=2)
+        assert r["n_left"] > 300 and r["n_stereo_matches"] > 20
