@@ -9,6 +9,12 @@
 // integer arithmetic) followed by the range limit; chroma components are parsed and dropped.  Both are restated here
 // from the standard and from the published libjpeg algorithm.
 //
+// PROGRESSIVE files (SOF2; T.81 Annex G, libjpeg jdphuff.c) take decode_progressive() below: the scans that carry the
+// luminance component are decoded into one coefficient array (DC first / DC refinement / AC first with end-of-band runs /
+// AC refinement with correction bits), scans of chroma alone are stepped over, and when the last scan has brought every
+// luminance coefficient to full precision the same dequantisation + inverse DCT follows.  A file whose scans stop short
+// of that is answered with -2: libjpeg would show an approximation (with its block smoothing) that is not restated.
+//
 // PINNED (unlike the rest of the oracle): tests/golden/jpeg/ holds JPEG files and their JCS_GRAYSCALE decode by
 // libjpeg-turbo (through Pillow, which happens to be in the image; tools/make_jpeg_golden.py); this file reproduces
 // every one of them bit for bit (tests/test_jpeg_oracle.py).
@@ -173,12 +179,316 @@ void idct_islow(const int32_t* in, uint8_t* out, size_t ostride) {
   }
 }
 
+// ---- progressive (SOF2) -------------------------------------------------------------------------------------------
+// End of an entropy-coded segment: the first 0xFF followed by anything but 0x00 (a stuffed FF), RSTn, or another 0xFF
+// (fill byte).  T.81 B.1.1.2 / B.1.1.5.
+size_t ecs_end(const uint8_t* d, size_t pos, size_t n) {
+  while (pos + 1 < n) {
+    const uint8_t* q = (const uint8_t*)std::memchr(d + pos, 0xFF, n - 1 - pos);
+    if (!q) return n;
+    pos = (size_t)(q - d);
+    const uint8_t b = d[pos + 1];
+    if (b == 0x00 || (b >= 0xD0 && b <= 0xD7)) {
+      pos += 2;
+    } else if (b == 0xFF) {
+      pos += 1;
+    } else {
+      return pos;
+    }
+  }
+  return n;
+}
+
+int parse_dqt(const uint8_t* s, size_t n, uint16_t qt[4][64], bool present[4]) {
+  size_t i = 0;
+  while (i < n) {
+    const int pq = s[i] >> 4, tq = s[i] & 15;
+    i++;
+    if (tq > 3 || pq > 1 || i + 64 * (size_t)(pq + 1) > n) return -1;
+    for (int k = 0; k < 64; k++) {
+      qt[tq][kZigzag[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];
+      i += pq + 1;
+    }
+    present[tq] = true;
+  }
+  return 0;
+}
+
+int parse_dht(const uint8_t* s, size_t n, Huff dc[4], Huff ac[4]) {
+  size_t i = 0;
+  while (i < n) {
+    if (i + 17 > n) return -1;
+    const int tc = s[i] >> 4, th = s[i] & 15;
+    if (tc > 1 || th > 3) return -1;
+    Huff& h = tc ? ac[th] : dc[th];
+    int total = 0;
+    for (int l = 1; l <= 16; l++) total += (h.bits[l] = s[i + l]);
+    i += 17;
+    if (total > 256 || i + total > n) return -1;
+    std::memset(h.vals, 0, sizeof(h.vals));
+    std::memcpy(h.vals, s + i, total);
+    i += total;
+    h.present = true;
+    if (!h.derive()) return -1;
+  }
+  return 0;
+}
+
+struct ScanComp {
+  int ci, td, ta;
+};
+
+// One scan of a progressive file that carries the luminance component (frame component 0).  jdphuff.c:
+// decode_mcu_DC_first / decode_mcu_DC_refine / decode_mcu_AC_first / decode_mcu_AC_refine, process_restart.
+// `coef`: the luminance coefficients, blocks in raster order over a grid `bw` blocks wide, natural order inside a block.
+int decode_prog_scan(const uint8_t* ecs, const uint8_t* ecs_stop, const std::vector<Comp>& comps,
+                     const std::vector<ScanComp>& sc, const Huff dc[4], const Huff ac[4], int Ss, int Se, int Ah, int Al,
+                     int restart_interval, int W, int H, int hmax, int vmax, int mcus_x, int mcus_y, int bw,
+                     std::vector<int16_t>& coef) {
+  BitReader br{ecs, ecs_stop};
+  int pred[4] = {0, 0, 0, 0};
+  int eobrun = 0;
+  int until_restart = restart_interval;
+  const bool interleaved = sc.size() > 1;
+  int units_x, units_y;  // MCUs of this scan
+  if (interleaved) {
+    units_x = mcus_x;
+    units_y = mcus_y;
+  } else {  // T.81 A.2.2: one block per MCU, the component's own block grid (not padded to whole frame MCUs)
+    const Comp& c = comps[sc[0].ci];
+    units_x = ((W * c.h + hmax - 1) / hmax + 7) / 8;
+    units_y = ((H * c.v + vmax - 1) / vmax + 7) / 8;
+  }
+  const int p1 = 1 << Al, m1 = -(1 << Al);
+  auto one_block = [&](int16_t* blk, const ScanComp& s, int slot) {
+    if (Ss == 0) {
+      if (Ah == 0) {  // DC first: the difference coded as in the sequential process, stored shifted left by Al
+        const int t = br.decode(dc[s.td]);
+        pred[slot] += extend(br.receive(t), t);
+        if (blk) blk[0] = (int16_t)(pred[slot] * (1 << Al));
+      } else if (br.get_bit()) {  // DC refinement: one more bit of every DC value
+        if (blk) blk[0] = (int16_t)(blk[0] | p1);
+      }
+      return;
+    }
+    const Huff& h = ac[s.ta];
+    if (Ah == 0) {  // AC first
+      if (eobrun > 0) {
+        eobrun--;
+        return;
+      }
+      for (int k = Ss; k <= Se; k++) {
+        const int rs = br.decode(h);
+        int r = rs >> 4;
+        const int sz = rs & 15;
+        if (sz) {
+          k += r;
+          const int v = extend(br.receive(sz), sz);
+          if (k > 63) break;  // corrupt
+          blk[kZigzag[k]] = (int16_t)(v * (1 << Al));
+        } else if (r == 15) {
+          k += 15;
+        } else {  // EOBr: this band is finished in this and the next 2^r + extra - 1 blocks
+          eobrun = 1 << r;
+          if (r) eobrun += br.receive(r);
+          eobrun--;
+          break;
+        }
+      }
+      return;
+    }
+    // AC refinement: new coefficients enter with magnitude 1 << Al, every coefficient that is already non-zero gets a
+    // correction bit as the decoder passes it
+    auto correct = [&](int16_t& c) {
+      if (br.get_bit() && (c & p1) == 0) c = (int16_t)(c >= 0 ? c + p1 : c + m1);
+    };
+    int k = Ss;
+    if (eobrun == 0) {
+      for (; k <= Se; k++) {
+        const int rs = br.decode(h);
+        int r = rs >> 4;
+        int sz = rs & 15;
+        int val = 0;
+        if (sz) {
+          val = br.get_bit() ? p1 : m1;  // (size must be 1; libjpeg warns and carries on the same way)
+        } else if (r != 15) {
+          eobrun = 1 << r;
+          if (r) eobrun += br.receive(r);
+          break;  // the rest of the block is handled by the end-of-band logic
+        }
+        while (k <= Se) {
+          int16_t& c = blk[kZigzag[k]];
+          if (c != 0) {
+            correct(c);
+          } else if (--r < 0) {
+            break;  // the target zero-valued coefficient
+          }
+          k++;
+        }
+        if (val && k <= 63) blk[kZigzag[k]] = (int16_t)val;
+      }
+    }
+    if (eobrun > 0) {
+      for (; k <= Se; k++) {
+        int16_t& c = blk[kZigzag[k]];
+        if (c != 0) correct(c);
+      }
+      eobrun--;
+    }
+  };
+  for (int uy = 0; uy < units_y; uy++)
+    for (int ux = 0; ux < units_x; ux++) {
+      if (restart_interval && until_restart == 0) {
+        if (!br.restart()) return -1;
+        pred[0] = pred[1] = pred[2] = pred[3] = 0;
+        eobrun = 0;
+        until_restart = restart_interval;
+      }
+      if (interleaved) {
+        for (size_t si = 0; si < sc.size(); si++) {
+          const Comp& c = comps[sc[si].ci];
+          for (int by = 0; by < c.v; by++)
+            for (int bx = 0; bx < c.h; bx++) {
+              int16_t* blk = sc[si].ci == 0 ? &coef[((size_t)(uy * c.v + by) * bw + (size_t)(ux * c.h + bx)) * 64] : nullptr;
+              one_block(blk, sc[si], (int)si);
+            }
+        }
+      } else {
+        one_block(&coef[((size_t)uy * bw + ux) * 64], sc[0], 0);
+      }
+      if (restart_interval) until_restart--;
+    }
+  return 0;
+}
+
+int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w, int cap_h, int* w_out,
+                       int* h_out) {
+  uint16_t qt[4][64], yq[64];
+  bool qt_present[4] = {false, false, false, false};
+  bool yq_latched = false;
+  Huff dc[4], ac[4];
+  std::vector<Comp> comps;
+  int W = 0, H = 0, restart_interval = 0, hmax = 1, vmax = 1, mcus_x = 0, mcus_y = 0, bw = 0, bh = 0;
+  bool have_sof = false;
+  std::vector<int16_t> coef;
+  int cbits[64];  // precision still missing per luminance coefficient (jdphuff.c coef_bits): -1 = nothing received yet
+  for (int& b : cbits) b = -1;
+  size_t pos = 2;
+  while (pos + 2 <= nbytes) {
+    if (data[pos] != 0xFF) return -1;
+    while (pos < nbytes && data[pos] == 0xFF) pos++;
+    if (pos >= nbytes) break;
+    const int m = data[pos++];
+    if (m == 0xD9) break;
+    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (pos + 2 > nbytes) return -1;
+    const size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
+    if (len < 2 || pos + len > nbytes) return -1;
+    const uint8_t* s = data + pos + 2;
+    const size_t n = len - 2;
+    if (m == 0xDB) {
+      if (parse_dqt(s, n, qt, qt_present)) return -1;
+    } else if (m == 0xC4) {
+      if (parse_dht(s, n, dc, ac)) return -1;
+    } else if (m == 0xC2) {
+      if (have_sof) return -1;
+      if (n < 6 || s[0] != 8) return -2;
+      H = (s[1] << 8) | s[2];
+      W = (s[3] << 8) | s[4];
+      const int nf = s[5];
+      if (W < 1 || H < 1 || (nf != 1 && nf != 3) || n < (size_t)(6 + 3 * nf)) return nf == 4 ? -2 : -1;
+      comps.resize(nf);
+      for (int c = 0; c < nf; c++) {
+        comps[c].id = s[6 + 3 * c];
+        comps[c].h = s[7 + 3 * c] >> 4;
+        comps[c].v = s[7 + 3 * c] & 15;
+        comps[c].tq = s[8 + 3 * c];
+        if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) return -1;
+        hmax = comps[c].h > hmax ? comps[c].h : hmax;
+        vmax = comps[c].v > vmax ? comps[c].v : vmax;
+      }
+      if (comps[0].h != hmax || comps[0].v != vmax) return -2;  // luminance would need upsampling
+      if (w_out) *w_out = W;
+      if (h_out) *h_out = H;
+      if (W > cap_w || H > cap_h || !out) return -3;
+      mcus_x = (W + 8 * hmax - 1) / (8 * hmax);
+      mcus_y = (H + 8 * vmax - 1) / (8 * vmax);
+      bw = mcus_x * hmax;
+      bh = mcus_y * vmax;
+      coef.assign((size_t)bw * bh * 64, 0);
+      have_sof = true;
+    } else if (m >= 0xC0 && m <= 0xCF && m != 0xC8 && m != 0xCC) {
+      return have_sof ? -1 : -2;
+    } else if (m == 0xDD) {
+      if (n < 2) return -1;
+      restart_interval = (s[0] << 8) | s[1];
+    } else if (m == 0xDA) {
+      if (!have_sof || n < 1) return -1;
+      const int ns = s[0];
+      if (ns < 1 || ns > (int)comps.size() || n < (size_t)(4 + 2 * ns)) return -1;
+      std::vector<ScanComp> sc((size_t)ns);
+      bool has_luma = false;
+      for (int c = 0; c < ns; c++) {
+        int ci = -1;
+        for (size_t f = 0; f < comps.size(); f++)
+          if (comps[f].id == s[1 + 2 * c]) ci = (int)f;
+        if (ci < 0) return -1;
+        for (int e = 0; e < c; e++)
+          if (sc[e].ci >= ci) return -1;  // components of a scan follow the frame's order (B.2.3)
+        sc[c] = {ci, s[2 + 2 * c] >> 4, s[2 + 2 * c] & 15};
+        if (sc[c].td > 3 || sc[c].ta > 3) return -1;
+        has_luma |= ci == 0;
+      }
+      const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
+      if (Ss == 0 ? Se != 0 : (ns != 1 || Se < Ss || Se > 63)) return -1;
+      if ((Ah != 0 && Al != Ah - 1) || Al > 13) return -1;
+      const size_t begin = pos + len, end = ecs_end(data, begin, nbytes);
+      if (has_luma) {
+        for (int k = Ss; k <= Se; k++) {  // every scan must continue where the previous one over this coefficient stopped
+          if (Ah != (cbits[k] < 0 ? 0 : cbits[k]) || (cbits[k] >= 0 && Ah == 0)) return -2;
+          cbits[k] = Al;
+        }
+        if (Ss > 0 && cbits[0] < 0) return -2;  // AC before any DC scan
+        for (const ScanComp& c : sc)
+          if (Ss == 0 ? (Ah == 0 && !dc[c.td].present) : !ac[c.ta].present) return -1;
+        if (!yq_latched) {  // jdinput.c latch_quant_tables: the table in force at the component's first scan
+          if (!qt_present[comps[0].tq]) return -1;
+          std::memcpy(yq, qt[comps[0].tq], sizeof(yq));
+          yq_latched = true;
+        }
+        const int rc = decode_prog_scan(data + begin, data + end, comps, sc, dc, ac, Ss, Se, Ah, Al, restart_interval, W, H,
+                                        hmax, vmax, mcus_x, mcus_y, bw, coef);
+        if (rc) return rc;
+      }
+      pos = end;
+      continue;
+    }
+    pos += len;
+  }
+  if (!have_sof || !yq_latched) return -1;
+  for (int k = 0; k < 64; k++)
+    if (cbits[k] != 0) return -2;  // the scans stop short of full precision
+  const int pw = bw * 8, ph = bh * 8;
+  std::vector<uint8_t> plane((size_t)pw * ph);
+  for (int by = 0; by < bh; by++)
+    for (int bx = 0; bx < bw; bx++) {
+      int32_t deq[64];
+      const int16_t* blk = &coef[((size_t)by * bw + bx) * 64];
+      for (int k = 0; k < 64; k++) deq[k] = (int32_t)blk[k] * (int32_t)yq[k];
+      idct_islow(deq, &plane[(size_t)by * 8 * pw + (size_t)bx * 8], (size_t)pw);
+    }
+  for (int y = 0; y < H; y++) std::memcpy(out + (size_t)y * ostride, &plane[(size_t)y * pw], (size_t)W);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w,
                                      int cap_h, int* w_out, int* h_out) {
-  // returns 0 ok; -1 malformed; -2 a JPEG process this decoder does not restate (progressive, arithmetic, 12 bit,
-  // non-interleaved multi-scan); -3 the image does not fit cap_w x cap_h
+  // returns 0 ok; -1 malformed; -2 a JPEG process this decoder does not restate (arithmetic, 12 bit, lossless, sequential
+  // files in several scans, progressive files whose scans stop short of full precision); -3 the image does not fit
+  // cap_w x cap_h
   if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
   uint16_t qt[4][64];
   bool qt_present[4] = {false, false, false, false};
@@ -243,8 +553,10 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
         if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) return -1;
       }
       have_sof = true;
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      return -2;  // progressive, lossless, arithmetic, hierarchical
+    } else if (m == 0xC2) {
+      return have_sof ? -1 : decode_progressive(data, nbytes, out, ostride, cap_w, cap_h, w_out, h_out);
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      return -2;  // lossless, arithmetic, hierarchical
     } else if (m == 0xDD) {  // DRI
       if (n < 2) return -1;
       restart_interval = (s[0] << 8) | s[1];

@@ -18,6 +18,35 @@ def segments(data: bytes):
     return out
 
 
+def all_segments(data: bytes):
+    """Like segments(), but through every scan of a multi-scan file (the entropy-coded data behind an SOS is stepped over:
+    it ends at the first 0xFF followed by anything but 0x00, RSTn or 0xFF)."""
+    out, pos = [], 2
+    while pos + 4 <= len(data) and data[pos] == 0xFF:
+        m = data[pos + 1]
+        if m == 0xD9:
+            break
+        ln = (data[pos + 2] << 8) | data[pos + 3]
+        out.append((m, pos, ln + 2))
+        pos += ln + 2
+        if m == 0xDA:
+            while pos + 1 < len(data) and not (data[pos] == 0xFF and data[pos + 1] not in (0x00, 0xFF) and
+                                               not 0xD0 <= data[pos + 1] <= 0xD7):
+                pos += 1
+    return out
+
+
+def drop_last_scans(data: bytes, n: int) -> bytes:
+    """A multi-scan (progressive) file without its last `n` scans (and the tables defined for them), EOI appended."""
+    segs = all_segments(data)
+    sos = [i for i, (m, _, _) in enumerate(segs) if m == 0xDA]
+    assert len(sos) > n, (len(sos), n)
+    cut = sos[len(sos) - n]
+    while cut > 0 and segs[cut - 1][0] in (0xC4, 0xDD, 0xDB):  # the DHT / DRI / DQT segments in front of that scan
+        cut -= 1
+    return data[:segs[cut][1]] + b"\xff\xd9"
+
+
 def rewrite_dht(data: bytes, rng: np.random.Generator, counts=None, which=None) -> bytes:
     """Replaces the counts (and as many values as they call for) of one table of one DHT segment; the segment's length
     field is recomputed, so the file stays well-formed up to the meaning of the counts themselves."""

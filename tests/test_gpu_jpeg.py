@@ -1,4 +1,4 @@
-"""SURVEY 8(f) row f4, the decode: vsf_jpeg_decode_gray_batch == cv::imdecode(data, IMREAD_GRAYSCALE) for baseline JPEG
+"""SURVEY 8(f) row f4, the decode: vsf_jpeg_decode_gray_batch == cv::imdecode(data, IMREAD_GRAYSCALE) for baseline and progressive JPEG
 (slam_frontend_main.cc:99-100), bit for bit against (1) what libjpeg-turbo decoded (tests/golden/jpeg: real
 third-party vectors) and (2) the CPU oracle on freshly encoded images, incl. the whole ingest chain
 JPEG -> Bayer mosaic -> gray image -> keypoints."""
@@ -13,7 +13,7 @@ torch = pytest.importorskip("torch")
 
 GOLD = Path(__file__).resolve().parent / "golden" / "jpeg"
 EXPECTED = np.load(GOLD / "expected_gray.npz")
-NAMES = sorted(k for k in EXPECTED.files if not k.startswith("progressive"))
+NAMES = sorted(EXPECTED.files)
 
 
 @pytest.fixture(scope="module")
@@ -72,9 +72,14 @@ def test_refusals_and_truncation(ctx, oracle):
     dev = torch.device("cuda", 0)
     d = torch.zeros((1, 48, 64), dtype=torch.uint8, device=dev)
     good = (GOLD / "gray_64x48_noise_q80.jpg").read_bytes()
+    from jpeg_mutate import drop_last_scans
     prog = (GOLD / "progressive_64x48.jpg").read_bytes()
     call = lambda f, w=64, h=48: ctx.jpeg_decode_gray_batch([f], w, h, d.data_ptr(), 48 * 64, 64, allow_status=range(1, 6))
-    assert call(prog) == capi.VSF_ERR_UNSUPPORTED
+    # a progressive file whose scans stop short of full precision: libjpeg shows an approximation, this library refuses
+    assert call(drop_last_scans(prog, 1)) == capi.VSF_ERR_UNSUPPORTED
+    assert call(drop_last_scans(prog, 3)) == capi.VSF_ERR_UNSUPPORTED
+    assert call(prog) == capi.VSF_OK and ctx.sync() == capi.VSF_OK
+    np.testing.assert_array_equal(d.cpu().numpy()[0], EXPECTED["progressive_64x48"])
     assert call(good, 48, 64) == capi.VSF_ERR_INVALID_ARG      # not the announced size
     assert call(good[:100]) == capi.VSF_ERR_INVALID_ARG        # cut inside the headers
     assert call(b"\x89PNG\r\n" + good) == capi.VSF_ERR_INVALID_ARG
@@ -178,6 +183,51 @@ def test_random_sizes_and_qualities(ctx, oracle):
         np.testing.assert_array_equal(got[0, :, :w], oracle.jpeg_decode_gray(f), err_msg="case %d: %dx%d kind %d %r" % (case, w, h, kind, kw))
 
 
+def test_progressive_files(ctx, oracle):
+    """40 random progressive files (tests/test_jpeg_oracle.py: the oracle equals libjpeg-turbo on each), one call per file,
+    and one call over a batch that mixes progressive, baseline and restart-interval files of one size: all three decoders
+    in one upload."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    from test_jpeg_oracle import progressive_files
+    from vision_slam_frontend_amd import synth
+    for desc, f, w, h in progressive_files():
+        got = _decode(ctx, [f], w, h)
+        np.testing.assert_array_equal(got[0, :, :w], oracle.jpeg_decode_gray(f), err_msg=desc)
+    rng = np.random.default_rng(77)
+    files = []
+    for i in range(18):
+        img = synth.stereo_pair(232, 152, 900 + i, n_objects=int(rng.integers(20, 300)))[i & 1]
+        kw = dict(quality=int(rng.integers(20, 99)))
+        if i % 3 != 1:
+            kw["progressive"] = True
+        if i % 4 == 2:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 12))
+        b = io.BytesIO()
+        if i % 5 == 0:
+            rgb = np.stack([img, np.roll(img, 5, 0), 255 - img], 2)
+            PIL.fromarray(rgb, "RGB").save(b, "JPEG", subsampling=int(rng.integers(0, 3)), **kw)
+        else:
+            PIL.fromarray(img, "L").save(b, "JPEG", **kw)
+        files.append(b.getvalue())
+    got = _decode(ctx, files, 232, 152)
+    for i, f in enumerate(files):
+        np.testing.assert_array_equal(got[i, :, :232], oracle.jpeg_decode_gray(f), err_msg="file %d" % i)
+
+
+def test_crafted_progressive_scripts(ctx, oracle):
+    """Scan scripts libjpeg's encoder never writes (tests/jpeg_craft.py: spectral selection alone, four refinement passes,
+    DC scans per component with AC bands cut in odd places, an interleaved DC scan of two of three components, restart
+    intervals with long end-of-band runs, an end-of-band run of more than 32767 blocks in a 1600 x 1408 image); the oracle
+    equals libjpeg-turbo on each (tests/test_jpeg_oracle.py)."""
+    import jpeg_craft as jc
+    for name, data, w, h in jc.progressive_cases():
+        got = _decode(ctx, [data, data], w, h)
+        want = oracle.jpeg_decode_gray(data)
+        np.testing.assert_array_equal(got[0, :, :w], want, err_msg=name)
+        np.testing.assert_array_equal(got[1, :, :w], want, err_msg=name)
+
+
 def test_crafted_huffman_tables(ctx, oracle):
     """AC tables with scores of long codes (tests/jpeg_craft.py): 80 distinct 9-bit prefixes of 10-bit codes are more than
     the parallel decoder's second-level tables hold, so that file must fall to the one-wave decoder; the 13- and 16-bit
@@ -192,8 +242,8 @@ def test_crafted_huffman_tables(ctx, oracle):
 
 
 def test_corrupted_batches_return_and_never_fault():
-    """Robustness of the device half: 400 batches of 8 damaged files (tests/jpeg_mutate.py: bit flips, truncation, stray
-    markers, header damage, garbage behind the headers; gray, optimised tables, restart intervals, 4:2:0) through
+    """Robustness of the device half: 400 batches of 1..8 damaged files (tests/jpeg_mutate.py: bit flips, truncation, stray
+    markers, header damage, garbage behind the headers; gray, optimised tables, restart intervals, 4:2:0, progressive) through
     vsf_jpeg_decode_gray_batch.  Every call returns -- VSF_OK (libjpeg too decodes damaged entropy data to SOMETHING),
     invalid argument or unsupported -- the device never faults, and a good batch decodes bit-exactly afterwards."""
     import io
@@ -206,21 +256,23 @@ def test_corrupted_batches_return_and_never_fault():
     W, H = 160, 120
     img = synth.stereo_pair(W, H, 5, n_objects=60)[0]
     base = []
-    for kw in (dict(quality=85), dict(quality=40, optimize=True), dict(quality=90, restart_marker_blocks=5)):
+    for kw in (dict(quality=85), dict(quality=40, optimize=True), dict(quality=90, restart_marker_blocks=5),
+               dict(quality=80, progressive=True), dict(quality=60, progressive=True, restart_marker_blocks=7)):
         b = io.BytesIO()
         Image.fromarray(img, "L").save(b, "JPEG", **kw)
         base.append(b.getvalue())
     rgb = np.stack([img, img[::-1], img[:, ::-1]], 2)
-    b = io.BytesIO()
-    Image.fromarray(rgb, "RGB").save(b, "JPEG", quality=75, subsampling=2)
-    base.append(b.getvalue())
+    for kw in (dict(quality=75, subsampling=2), dict(quality=75, subsampling=2, progressive=True)):
+        b = io.BytesIO()
+        Image.fromarray(rgb, "RGB").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
     rng = np.random.Generator(np.random.PCG64(20261004))
     dev = torch.device("cuda", 0)
     d = torch.zeros((8, H, W), dtype=torch.uint8, device=dev)
     outcomes = {}
     with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
         for it in range(400):
-            files = [mutate(base[int(rng.integers(len(base)))], rng) for _ in range(8)]
+            files = [mutate(base[int(rng.integers(len(base)))], rng) for _ in range(int(rng.integers(1, 9)))]
             try:
                 ctx.jpeg_decode_gray_batch(files, W, H, d.data_ptr(), W * H, W)
                 ctx.sync(allow_capacity=True)

@@ -1,5 +1,5 @@
-"""SURVEY 8(f) row f4, the decode in front of the Bayer conversion: cv::imdecode(data, IMREAD_GRAYSCALE) for baseline
-JPEG (slam_frontend_main.cc:99-100).  Here, for once, the oracle is PINNED by a real third-party implementation:
+"""SURVEY 8(f) row f4, the decode in front of the Bayer conversion: cv::imdecode(data, IMREAD_GRAYSCALE) for baseline and
+progressive JPEG (slam_frontend_main.cc:99-100).  Here, for once, the oracle is PINNED by a real third-party implementation:
 tests/golden/jpeg/ holds JPEG files and what libjpeg-turbo (via Pillow, tools/make_jpeg_golden.py) decodes them to
 with JCS_GRAYSCALE, the same library family and settings OpenCV's reader uses.  The oracle must reproduce every byte."""
 from pathlib import Path
@@ -9,7 +9,7 @@ import pytest
 
 GOLD = Path(__file__).resolve().parent / "golden" / "jpeg"
 EXPECTED = np.load(GOLD / "expected_gray.npz")
-NAMES = sorted(k for k in EXPECTED.files if not k.startswith("progressive"))
+NAMES = sorted(EXPECTED.files)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -21,14 +21,20 @@ def test_oracle_equals_libjpeg_turbo(oracle, name):
 
 
 def test_cases_cover_the_format():
-    assert len(NAMES) == 15
+    assert len(NAMES) == 24
     assert {"gray_33x17_q95", "gray_1x1_q75", "ycc420_71x53_q75", "ycc422_71x53_q75", "ycc444_40x40_q90",
-            "gray_160x120_restart4", "gray_160x120_optimized", "ycc420_restart_64x64"} <= set(NAMES)
+            "gray_160x120_restart4", "gray_160x120_optimized", "ycc420_restart_64x64", "progressive_64x48",
+            "prog_gray_160x120_restart5", "prog_ycc420_200x136_q75", "prog_ycc422_71x53_q60", "prog_ycc444_40x40_q92",
+            "prog_ycc420_restart_rows_100x60"} <= set(NAMES)
 
 
 def test_unsupported_and_malformed(oracle):
+    from jpeg_mutate import drop_last_scans
+    prog = (GOLD / "prog_ycc420_200x136_q75.jpg").read_bytes()
+    with pytest.raises(NotImplementedError):  # the last scan is missing: libjpeg would show an approximation
+        oracle.jpeg_decode_gray(drop_last_scans(prog, 1))
     with pytest.raises(NotImplementedError):
-        oracle.jpeg_decode_gray((GOLD / "progressive_64x48.jpg").read_bytes())
+        oracle.jpeg_decode_gray(drop_last_scans(prog, 6))
     good = (GOLD / "gray_64x48_noise_q80.jpg").read_bytes()
     with pytest.raises(ValueError):
         oracle.jpeg_decode_gray(good[:100])          # cut inside the headers
@@ -83,6 +89,49 @@ def test_random_files_against_pillow_when_present(oracle):
         np.testing.assert_array_equal(oracle.jpeg_decode_gray(f), want, err_msg="case %d: %dx%d kind %d %r" % (case, w, h, kind, kw))
 
 
+def progressive_files(n=40, seed=4242):
+    """Random PROGRESSIVE files as libjpeg writes them (its default scan script: spectral selection and successive
+    approximation, interleaved DC scans for colour): sizes 1..300, gray / 4:4:4 / 4:2:2 / 4:2:0, qualities 1..100, with and
+    without restart intervals.  -> [(description, bytes, w, h)]"""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n):
+        w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        kind = int(rng.integers(0, 4))
+        base = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        if rng.random() < 0.6:
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = ((np.sin(xx / 7.0) * np.cos(yy / 11.0)) * 90 + 128 + rng.integers(-6, 7, (h, w))).clip(0, 255).astype(np.uint8)
+        kw = dict(quality=int(rng.integers(1, 101)), progressive=True)
+        r = rng.random()
+        if r < 0.25:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 20))
+        elif r < 0.4:
+            kw["restart_marker_rows"] = int(rng.integers(1, 3))
+        b = io.BytesIO()
+        if kind == 0:
+            Image.fromarray(base, "L").save(b, "JPEG", **kw)
+        else:
+            rgb = np.stack([base, np.roll(base, 1, 0), 255 - base], 2)
+            Image.fromarray(rgb, "RGB").save(b, "JPEG", subsampling=kind - 1, **kw)
+        out.append(("case %d: %dx%d kind %d %r" % (case, w, h, kind, kw), b.getvalue(), w, h))
+    return out
+
+
+def test_progressive_files_against_pillow_when_present(oracle):
+    """The files tests/test_gpu_jpeg.py feeds the GPU: oracle == libjpeg-turbo (JCS_GRAYSCALE) on every one."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    for desc, f, w, h in progressive_files():
+        assert b"\xff\xc2" in f[:700], desc
+        im = PIL.open(io.BytesIO(f))
+        im.draft("L", im.size)
+        want = np.asarray(im.convert("L") if im.mode != "L" else im)
+        np.testing.assert_array_equal(oracle.jpeg_decode_gray(f), want, err_msg=desc)
+
+
 def crafted_files():
     """Files libjpeg's encoder would never write (tests/jpeg_craft.py): AC tables with 160 codes of 10 bits (80 distinct
     9-bit prefixes) or of 16 bits, coefficients chosen at random."""
@@ -102,4 +151,20 @@ def test_crafted_huffman_tables_against_pillow(oracle):
     for name, data in crafted_files():
         want = np.asarray(PIL.open(io.BytesIO(data)))
         assert want.ndim == 2 and want.std() > 5, name
+        np.testing.assert_array_equal(oracle.jpeg_decode_gray(data), want, err_msg=name)
+
+
+def test_crafted_progressive_scripts_against_pillow(oracle):
+    """Scan scripts libjpeg's own encoder never writes (tests/jpeg_craft.py progressive_cases): the oracle must still equal
+    what libjpeg-turbo decodes."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    import jpeg_craft as jc
+    cases = jc.progressive_cases()
+    assert len(cases) == 6
+    for name, data, w, h in cases:
+        im = PIL.open(io.BytesIO(data))
+        im.draft("L", im.size)
+        want = np.asarray(im.convert("L") if im.mode != "L" else im)
+        assert want.shape == (h, w) and want.std() > 3, name
         np.testing.assert_array_equal(oracle.jpeg_decode_gray(data), want, err_msg=name)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/jpeg/: small baseline JPEG files and what libjpeg-turbo (through Pillow, present in this image)
+"""Writes tests/golden/jpeg/: small baseline and progressive JPEG files and what libjpeg-turbo (through Pillow, present in this image)
 decodes them to with out_color_space = JCS_GRAYSCALE -- the decode cv::imdecode(..., IMREAD_GRAYSCALE) performs
 (slam_frontend_main.cc:99-100; OpenCV's grfmt_jpeg.cpp sets JCS_GRAYSCALE for a gray read, default JDCT_ISLOW).
 
@@ -45,7 +45,19 @@ def cases():
     yield "ycc444_40x40_q90", rgb[:40, :40], "RGB", dict(quality=90, subsampling=0)
     yield ("ycc420_restart_64x64", np.stack([scene(64, 64, 12)] * 3, 2), "RGB",
            dict(quality=80, subsampling=2, restart_marker_blocks=3))
-    yield "progressive_64x48", g320[:48, :64], "L", dict(quality=80, progressive=True)  # must be refused
+    # progressive files (SOF2): libjpeg's default scan script -- spectral selection AND successive approximation, end-of-band
+    # runs, AC refinement with correction bits; for colour files the DC scans interleave all three components
+    yield "progressive_64x48", g320[:48, :64], "L", dict(quality=80, progressive=True)
+    yield "prog_gray_320x240_q85", g320, "L", dict(quality=85, progressive=True)
+    yield "prog_gray_33x17_q30", scene(33, 17, 13), "L", dict(quality=30, progressive=True)
+    yield "prog_gray_160x120_restart5", scene(160, 120, 14), "L", dict(quality=80, progressive=True, restart_marker_blocks=5)
+    yield "prog_noise_64x48_q95", rng.integers(0, 256, (48, 64), dtype=np.uint8), "L", dict(quality=95, progressive=True)
+    rgb2 = np.stack([scene(200, 136, 15), scene(200, 136, 16), scene(200, 136, 17)], 2)
+    yield "prog_ycc420_200x136_q75", rgb2, "RGB", dict(quality=75, subsampling=2, progressive=True)
+    yield "prog_ycc422_71x53_q60", rgb, "RGB", dict(quality=60, subsampling=1, progressive=True)
+    yield "prog_ycc444_40x40_q92", rgb[:40, :40], "RGB", dict(quality=92, subsampling=0, progressive=True)
+    yield ("prog_ycc420_restart_rows_100x60", rgb2[:60, :100], "RGB",
+           dict(quality=70, subsampling=2, progressive=True, restart_marker_rows=1))
 
 
 def main():

@@ -19,8 +19,13 @@
 // a stream of its own BESIDE the extraction of earlier batches.  Markers and tables are parsed on the host (the
 // compressed bytes come from host memory anyway), which also builds the lookahead tables once per distinct table set.
 //
+// PROGRESSIVE files (SOF2: what a web service or an image library writes, not a camera driver) take a third kernel,
+// jpeg_prog_kernel below: one wave per file walks the luminance scans one after the other into the coefficient buffer
+// (T.81 Annex G as libjpeg's jdphuff.c decodes it), and the IDCT kernel of the parallel decoder finishes the job.
+//
 // Checked bit for bit against JPEG files decoded by libjpeg-turbo (tests/golden/jpeg, tests/test_gpu_jpeg.py).
-// Progressive / arithmetic / 12-bit / multi-scan files are refused (VSF_ERR_UNSUPPORTED).
+// Arithmetic / 12-bit / lossless files, sequential files in several scans and progressive files whose scans stop short of
+// full precision are refused (VSF_ERR_UNSUPPORTED).
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -52,7 +57,7 @@ struct BitReader {
   int n;
   bool marker;            // a marker has been met: zero bits are fed from here on (until restart())
   __device__ __forceinline__ uint32_t at(uint32_t p) const { return (words[p >> 2] >> (8u * (p & 3u))) & 255u; }
-  __device__ __forceinline__ void fill() {  // >= 25 bits available afterwards (a code + its extra bits need <= 16 + 15)
+  __device__ __forceinline__ void fill() {  // >= 33 bits available afterwards (a code + its extra bits need <= 16 + 15)
     if (n <= 32 && !marker && pos + 4u <= len) {
       // four raw bytes at once unless one of them is 0xFF (stuffing or a marker: the byte-wise path sorts it out)
       const uint64_t two = (uint64_t)words[pos >> 2] | ((uint64_t)words[(pos >> 2) + 1] << 32);
@@ -66,7 +71,7 @@ struct BitReader {
         return;
       }
     }
-    while (n <= 24) {
+    while (n <= 32) {
       uint32_t b = 0;
       if (!marker) {
         if (pos < len) {
@@ -313,6 +318,221 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
       __syncthreads();
     }
     if (done) break;
+  }
+  if (lane == 0 && broken) atomicOr(status, 2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Progressive files (T.81 Annex G; libjpeg jdphuff.c decode_mcu_DC_first / _DC_refine / _AC_first / _AC_refine).
+// One wave per file.  The host lists the scans that carry the luminance component (chroma-only scans cannot change a gray
+// read); the wave decodes them in file order into the file's slot of the coefficient buffer -- blocks in the order of the
+// frame's interleaved MCUs, natural order inside a block: what jpeg_idct_kernel reads -- and that kernel turns them into
+// pixels afterwards.  The bit parsing is WAVE-UNIFORM as in the one-wave sequential decoder above (state in SGPRs, scalar
+// loads); the 64 lanes are the 64 coefficients of the block at hand, lane k owning zigzag position k:
+//   DC first        the difference is decoded as in the sequential process; lane 0 stores prediction << Al.
+//   DC refinement   one raw bit per block; a set bit goes into the coefficient with a fire-and-forget atomic OR.
+//   AC first        run / size symbols place values << Al at zigzag positions: `lane == k` keeps each in its lane's
+//                   register, non-zero lanes store once per block; end-of-band runs skip whole blocks.
+//   AC refinement   the lanes load the block (the NEXT block's load is issued before this block is parsed, so that its
+//                   latency hides behind the parse); a ballot gives the map of non-zero coefficients the scalar parse needs
+//                   (every non-zero coefficient it passes costs one correction bit, zero ones count down the run); the
+//                   parse collects three 64-bit maps -- corrections, new +1 << Al, new -1 << Al -- and the lanes apply them.
+// Scans are separated by a device-scope fence: a scan reads what earlier scans wrote through other lanes.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restrict__ images,
+                                                        const uint32_t* __restrict__ index,
+                                                        const DevScan* __restrict__ scans,
+                                                        const DevHuff* __restrict__ huffs,
+                                                        const uint8_t* __restrict__ stream, int16_t* __restrict__ coef_all,
+                                                        size_t coef_stride, int slot0, int width, int height,
+                                                        int32_t* __restrict__ status) {
+  const int lane = threadIdx.x;
+  const uint32_t image = index[blockIdx.x];
+  const DevImage& im = images[image];
+  int16_t* coef = coef_all + (size_t)(slot0 + blockIdx.x) * (coef_stride / sizeof(int16_t));
+  const int h0 = im.h[0], v0 = im.v[0], lum = h0 * v0, mcus_x = im.mcus_x;
+  const int nlb = mcus_x * im.mcus_y * lum;
+  {  // nothing is known yet
+    uint32_t* c32 = reinterpret_cast<uint32_t*>(coef);
+    for (int i = lane; i < nlb * 32; i += 64) c32[i] = 0u;
+  }
+  const int nat = c_zigzag[lane];  // where this lane's coefficient sits inside a block
+  bool broken = false;
+  for (int si = 0; si < im.n_scans && !broken; si++) {
+    __threadfence();
+    const DevScan& sc = scans[im.first_scan + si];
+    const int Ss = sc.Ss, Se = sc.Se, Ah = sc.Ah, Al = sc.Al, ns = sc.ncomp, restart_interval = sc.restart_interval;
+    const uint32_t o = im.stream_off + sc.off;
+    BitReader br{reinterpret_cast<const uint32_t*>(stream + (o & ~3u)), o & 3u, (o & 3u) + sc.len, 0ull, 0, false};
+    auto get_bit = [&]() -> int {
+      br.fill();
+      const int b = (int)br.peek(1);
+      br.drop(1);
+      return b;
+    };
+    auto receive = [&](int n) -> int {  // n <= 15 raw bits
+      if (n == 0) return 0;
+      br.fill();
+      const int v = (int)br.peek(n);
+      br.drop(n);
+      return v;
+    };
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int eobrun = 0, until_restart = restart_interval;
+    // the MCUs of this scan: the frame's interleaved MCUs, or -- a scan of the luminance alone -- its own blocks in raster
+    // order over ceil(W / 8) x ceil(H / 8) (T.81 A.2.2; the luminance is sampled at the full rate)
+    const bool interleaved = ns > 1;
+    const int units_x = interleaved ? mcus_x : (width + 7) >> 3, units_y = interleaved ? im.mcus_y : (height + 7) >> 3;
+    auto block_of = [&](int by, int bx) -> int {  // a luminance block's place in the coefficient buffer
+      const int my = by / v0, mx = bx / h0;
+      return (my * mcus_x + mx) * lum + (by - my * v0) * h0 + (bx - mx * h0);
+    };
+    if (Ss == 0) {
+      // ---- DC scans ----
+      const DevHuff *t0 = huffs + sc.huff[0], *t1 = huffs + sc.huff[ns > 1 ? 1 : 0], *t2 = huffs + sc.huff[ns > 2 ? 2 : 0];
+      auto dc_block = [&](const DevHuff* t, int& pred, int16_t* blk) {  // blk: a luminance block, or null
+        if (Ah == 0) {
+          br.fill();
+          const int s = br.decode(t);
+          br.fill();
+          pred += br.receive_extend(s);
+          if (blk && lane == 0) blk[0] = (int16_t)(pred * p1);
+        } else if (get_bit()) {
+          if (blk && lane == 0) atomicOr(reinterpret_cast<unsigned int*>(blk), (unsigned int)p1);  // coefficient 0: low half
+        }
+      };
+      for (int uy = 0; uy < units_y && !broken; uy++)
+        for (int ux = 0; ux < units_x; ux++) {
+          if (restart_interval && until_restart == 0) {
+            if (!br.restart()) {
+              broken = true;
+              break;
+            }
+            pred0 = pred1 = pred2 = 0;
+            until_restart = restart_interval;
+          }
+          if (!interleaved) {
+            dc_block(t0, pred0, coef + (size_t)block_of(uy, ux) * 64);
+          } else {
+            for (int c = 0; c < ns; c++) {
+              const int ci = sc.comp[c], hh = im.h[ci], vv = im.v[ci];
+              const DevHuff* t = c == 0 ? t0 : (c == 1 ? t1 : t2);
+              int& pred = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+              for (int b = 0; b < hh * vv; b++)
+                dc_block(t, pred, ci == 0 ? coef + ((size_t)(uy * mcus_x + ux) * lum + b) * 64 : nullptr);
+            }
+          }
+          if (restart_interval) until_restart--;
+        }
+    } else {
+      // ---- AC scans: the luminance alone, block after block in raster order ----
+      const DevHuff* t = huffs + sc.huff[0];
+      const int nblocks = units_x * units_y;
+      int bx = 0, by = 0;
+      int16_t* blk = coef + (size_t)block_of(0, 0) * 64;
+      int16_t next = Ah ? blk[nat] : (int16_t)0;
+      for (int b = 0; b < nblocks; b++) {
+        if (restart_interval && until_restart == 0) {
+          if (!br.restart()) {
+            broken = true;
+            break;
+          }
+          eobrun = 0;
+          until_restart = restart_interval;
+        }
+        int16_t c = next;
+        int16_t* const here = blk;
+        if (++bx == units_x) {
+          bx = 0;
+          by++;
+        }
+        if (b + 1 < nblocks) {
+          blk = coef + (size_t)block_of(by, bx) * 64;
+          if (Ah) next = blk[nat];
+        }
+        if (Ah == 0) {
+          // AC first
+          if (eobrun > 0) {
+            eobrun--;
+          } else {
+            int mine = 0;
+            for (int k = Ss; k <= Se; k++) {
+              br.fill();
+              const int rs = br.decode(t);
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz) {
+                k += r;
+                br.fill();
+                const int v = br.receive_extend(sz);
+                if (k > 63) break;  // corrupt
+                if (lane == k) mine = v * p1;
+              } else if (r == 15) {
+                k += 15;
+              } else {
+                eobrun = 1 << r;
+                if (r) eobrun += receive(r);
+                eobrun--;
+                break;
+              }
+            }
+            if (mine != 0) here[nat] = (int16_t)mine;
+          }
+        } else {
+          // AC refinement
+          const uint64_t nz = __ballot(c != 0);
+          uint64_t corr = 0, newp = 0, newn = 0;
+          int k = Ss;
+          if (eobrun == 0) {
+            for (; k <= Se; k++) {
+              br.fill();
+              const int rs = br.decode(t);
+              int r = rs >> 4;
+              const int sz = rs & 15;
+              int sign = 0;
+              if (sz) {
+                sign = get_bit() ? 1 : -1;  // (the size must be 1; libjpeg warns and carries on the same way)
+              } else if (r != 15) {
+                eobrun = 1 << r;
+                if (r) eobrun += receive(r);
+                break;
+              }
+              while (k <= Se) {
+                if ((nz >> k) & 1ull) {
+                  if (get_bit()) corr |= 1ull << k;
+                } else if (--r < 0) {
+                  break;
+                }
+                k++;
+              }
+              if (sign > 0 && k <= 63) newp |= 1ull << k;
+              if (sign < 0 && k <= 63) newn |= 1ull << k;
+            }
+          }
+          if (eobrun > 0) {
+            for (; k <= Se; k++)
+              if (((nz >> k) & 1ull) && get_bit()) corr |= 1ull << k;
+            eobrun--;
+          }
+          int cv = c;
+          bool changed = false;
+          if (((corr >> lane) & 1ull) && (cv & p1) == 0) {
+            cv = cv >= 0 ? cv + p1 : cv + m1;
+            changed = true;
+          }
+          if ((newp >> lane) & 1ull) {
+            cv = p1;
+            changed = true;
+          }
+          if ((newn >> lane) & 1ull) {
+            cv = m1;
+            changed = true;
+          }
+          if (changed) here[nat] = (int16_t)cv;
+        }
+        if (restart_interval) until_restart--;
+      }
+    }
   }
   if (lane == 0 && broken) atomicOr(status, 2);
 }
@@ -940,8 +1160,9 @@ hipError_t vsf_prepare_jpeg_kernels(int lds_limit) {
 // at off_index) take the self-synchronising parallel decode, the others the one-wave-per-image decode.  d_clean has
 // vsf_jpeg_clean_bytes(total - off_stream, n_par) bytes, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
 // largest padded image): every luminance block is written whole.
-void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_stream,
-                            size_t total, int n_par, int n_ser, int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
+void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_scans,
+                            size_t off_prog_huff, size_t off_stream, size_t total, int n_par, int n_prog, int n_ser,
+                            int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
                             int32_t* d_status, hipStream_t s) {
   const DevImage* images = reinterpret_cast<const DevImage*>(d_blob + off_images);
@@ -953,11 +1174,16 @@ void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off
                        reinterpret_cast<uint32_t*>(d_clean),
                        reinterpret_cast<uint32_t*>(d_clean + vsf_jpeg_clean_bytes(total - off_stream, 0)), d_coef, coef_stride,
                        max_slots, d_status);
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n_par), dim3(64), 0, s, images, index, tables, d_coef,
-                       coef_stride, width, height, d_dst, dst_image_stride, dst_pitch);
   }
+  if (n_prog > 0)  // progressive files: their slots of the coefficient buffer follow the parallel decoder's
+    hipLaunchKernelGGL(jpeg_prog_kernel, dim3(n_prog), dim3(64), 0, s, images, index + n_par,
+                       reinterpret_cast<const DevScan*>(d_blob + off_scans), reinterpret_cast<const DevHuff*>(d_blob + off_prog_huff),
+                       d_blob + off_stream, d_coef, coef_stride, n_par, width, height, d_status);
+  if (n_par + n_prog > 0)
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n_par + n_prog), dim3(64), 0, s, images, index, tables,
+                       d_coef, coef_stride, width, height, d_dst, dst_image_stride, dst_pitch);
   if (n_ser > 0)
-    hipLaunchKernelGGL(jpeg_gray_kernel, dim3(n_ser), dim3(64), 0, s, images, index + n_par, tables, d_blob + off_stream,
+    hipLaunchKernelGGL(jpeg_gray_kernel, dim3(n_ser), dim3(64), 0, s, images, index + n_par + n_prog, tables, d_blob + off_stream,
                        (uint32_t)((total - off_stream) & ~(size_t)3), width, height, d_dst, dst_image_stride, dst_pitch,
                        d_status);
 }

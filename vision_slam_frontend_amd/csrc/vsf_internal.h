@@ -225,12 +225,14 @@ void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s);
 // k_jpeg.hip (cv::imdecode(IMREAD_GRAYSCALE) for baseline JPEG)
 #ifdef __cplusplus
 #include <vector>
-struct VsfJpegPlan {  // layout of one upload: [image descriptors | decode order | table sets | entropy-coded segments]
-  size_t off_images = 0, off_index = 0, off_tables = 0, off_stream = 0, total = 0;
+struct VsfJpegPlan {  // layout of one upload: [image descriptors | decode order | table sets | progressive scans | their
+                      // Huffman tables | entropy-coded segments]
+  size_t off_images = 0, off_index = 0, off_tables = 0, off_scans = 0, off_prog_huff = 0, off_stream = 0, total = 0;
   std::vector<uint8_t> head;                // everything in front of the segments
   std::vector<size_t> scan_begin;           // per file: where its entropy-coded segment starts
   std::vector<uint32_t> stream_off, stream_len;
   int n_par = 0;             // files without restart intervals: they take the self-synchronising parallel decode
+  int n_prog = 0;            // progressive files: scan after scan into the coefficient buffer, one wave per file
   int max_luma_blocks = 0;   // luminance blocks of the (padded) image, largest over the batch
   int max_slots = 1;         // Huffman tables one file's scan uses, largest over the batch
 };
@@ -239,8 +241,9 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
 void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, uint8_t* dst);
 #endif
 size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par);
-void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_stream,
-                            size_t total, int n_par, int n_ser, int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
+void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_scans,
+                            size_t off_prog_huff, size_t off_stream, size_t total, int n_par, int n_prog, int n_ser,
+                            int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
                             int32_t* d_status, hipStream_t s);
 

@@ -1,5 +1,5 @@
-// vsf_jpeg_host.cc -- host half of vsf_jpeg_decode_gray_batch (cv::imdecode(IMREAD_GRAYSCALE) for baseline JPEG,
-// slam_frontend_main.cc:98-100): parses the markers and tables of every file (ITU-T T.81 Annex B), builds the decoders'
+// vsf_jpeg_host.cc -- host half of vsf_jpeg_decode_gray_batch (cv::imdecode(IMREAD_GRAYSCALE) for baseline and
+// progressive JPEG, slam_frontend_main.cc:98-100): parses the markers and tables of every file (ITU-T T.81 Annex B), builds the decoders'
 // lookup tables once per distinct table set and lays out ONE upload.  The bytes come from a ROS bag or a network topic,
 // i.e. they are UNTRUSTED: every length is checked against the file's end before it is used.  Plain C++ (no HIP code), so
 // that the same translation unit builds with -fsanitize=address,undefined (make asan) and runs the fixtures and a few
@@ -89,26 +89,62 @@ bool build_dev_huff(const HostHuff& h, DevHuff* d) {
   return true;
 }
 
+// End of an entropy-coded segment (T.81 B.1.1.2, B.1.1.5): the first 0xFF that is followed by anything but 0x00 (a stuffed
+// FF), RSTn or another 0xFF (a fill byte); `n` when the data runs out first.
+size_t ecs_end(const uint8_t* d, size_t pos, size_t n) {
+  while (pos + 1 < n) {
+    const uint8_t* q = static_cast<const uint8_t*>(std::memchr(d + pos, 0xFF, n - 1 - pos));
+    if (!q) return n;
+    pos = (size_t)(q - d);
+    const uint8_t b = d[pos + 1];
+    if (b == 0x00 || (b >= 0xD0 && b <= 0xD7)) {
+      pos += 2;
+    } else if (b == 0xFF) {
+      pos += 1;
+    } else {
+      return pos;
+    }
+  }
+  return n;
+}
+
+struct ProgFile {                 // what a progressive file adds to its image descriptor
+  std::vector<DevScan> scans;     // (off = offset in the FILE until vsf_jpeg_plan rebases it; huff = index into `huffs`)
+  std::vector<HostHuff> huffs;    // the tables those scans use, each as it stood when its scan began
+};
+
 }  // namespace
 
 // Parses one JPEG file; fills the image descriptor (without stream_off / tables) and the table set it needs.
 // Returns VSF_OK, VSF_ERR_INVALID_ARG (malformed, or not width x height) or VSF_ERR_UNSUPPORTED.
+// Progressive files (SOF2, T.81 Annex G; libjpeg jdphuff.c): every scan that carries the luminance component is listed in
+// `prog` with the Huffman tables in force when it starts; scans of chroma alone are stepped over.  The progression must be
+// the orderly one (each scan continues where the last one over the same coefficients stopped) and must end with every
+// luminance coefficient at full precision: anything else libjpeg answers with an approximation, and is refused here.
 static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int height, DevImage* im, HostTableSet* tab,
-                             size_t* scan_begin) {
+                             size_t* scan_begin, ProgFile* prog) {
   if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return VSF_ERR_INVALID_ARG;
   uint16_t qt[4][64];
   bool qt_present[4] = {false, false, false, false};
   HostHuff dc[4], ac[4];
   int ncomp = 0, cid[3], ch[3], cv[3], ctq[3], W = 0, H = 0, restart_interval = 0;
-  bool have_sof = false;
+  bool have_sof = false, progressive = false, yq_latched = false;
+  uint16_t yq[64];
+  int cbits[64];  // progressive: precision still missing per luminance coefficient (-1: nothing received yet)
+  for (int& b : cbits) b = -1;
   size_t pos = 2;
   std::memset(im, 0, sizeof(*im));
+  prog->scans.clear();
+  prog->huffs.clear();
   while (pos + 4 <= nbytes) {
     if (data[pos] != 0xFF) return VSF_ERR_INVALID_ARG;
     while (pos < nbytes && data[pos] == 0xFF) pos++;
     if (pos >= nbytes) return VSF_ERR_INVALID_ARG;
     const int m = data[pos++];
-    if (m == 0xD9) return VSF_ERR_INVALID_ARG;
+    if (m == 0xD9) {
+      if (progressive) break;
+      return VSF_ERR_INVALID_ARG;
+    }
     if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
     if (pos + 2 > nbytes) return VSF_ERR_INVALID_ARG;
     const size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
@@ -139,7 +175,9 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         i += total;
         h.present = true;
       }
-    } else if (m == 0xC0 || m == 0xC1) {
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      if (have_sof) return VSF_ERR_INVALID_ARG;
+      progressive = m == 0xC2;
       if (n < 6 || s[0] != 8) return VSF_ERR_UNSUPPORTED;
       H = (s[1] << 8) | s[2];
       W = (s[3] << 8) | s[4];
@@ -154,11 +192,70 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         if (ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4 || ctq[c] > 3) return VSF_ERR_INVALID_ARG;
       }
       have_sof = true;
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      return VSF_ERR_UNSUPPORTED;  // progressive, lossless, arithmetic, hierarchical
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      return VSF_ERR_UNSUPPORTED;  // lossless, arithmetic, hierarchical
     } else if (m == 0xDD) {
       if (n < 2) return VSF_ERR_INVALID_ARG;
       restart_interval = (s[0] << 8) | s[1];
+    } else if (m == 0xDA && progressive) {
+      if (!have_sof || n < 1) return VSF_ERR_INVALID_ARG;
+      const int ns = s[0];
+      if (ns < 1 || ns > ncomp || n < (size_t)(4 + 2 * ns)) return VSF_ERR_INVALID_ARG;
+      DevScan sc;
+      std::memset(&sc, 0, sizeof(sc));
+      int td[3], ta[3];
+      bool has_luma = false;
+      for (int c = 0; c < ns; c++) {
+        int ci = -1;
+        for (int f = 0; f < ncomp; f++)
+          if (cid[f] == s[1 + 2 * c]) ci = f;
+        if (ci < 0 || (c > 0 && sc.comp[c - 1] >= ci)) return VSF_ERR_INVALID_ARG;  // frame order (T.81 B.2.3)
+        sc.comp[c] = (uint8_t)ci;
+        td[c] = s[2 + 2 * c] >> 4;
+        ta[c] = s[2 + 2 * c] & 15;
+        if (td[c] > 3 || ta[c] > 3) return VSF_ERR_INVALID_ARG;
+        has_luma |= ci == 0;
+      }
+      const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
+      if (Ss == 0 ? Se != 0 : (ns != 1 || Se < Ss || Se > 63)) return VSF_ERR_INVALID_ARG;
+      if ((Ah != 0 && Al != Ah - 1) || Al > 13) return VSF_ERR_INVALID_ARG;
+      const size_t begin = pos + len, end = ecs_end(data, begin, nbytes);
+      if (has_luma) {
+        for (int k = Ss; k <= Se; k++) {
+          if (Ah != (cbits[k] < 0 ? 0 : cbits[k]) || (cbits[k] >= 0 && Ah == 0)) return VSF_ERR_UNSUPPORTED;
+          cbits[k] = Al;
+        }
+        if (Ss > 0 && cbits[0] < 0) return VSF_ERR_UNSUPPORTED;  // AC before any DC scan
+        if (!yq_latched) {  // jdinput.c latch_quant_tables: the table in force at the component's first scan
+          if (!qt_present[ctq[0]]) return VSF_ERR_INVALID_ARG;
+          std::memcpy(yq, qt[ctq[0]], sizeof(yq));
+          yq_latched = true;
+        }
+        sc.off = (uint32_t)begin;
+        sc.len = (uint32_t)(end - begin);
+        sc.restart_interval = restart_interval;
+        sc.ncomp = (uint8_t)ns;
+        sc.Ss = (uint8_t)Ss;
+        sc.Se = (uint8_t)Se;
+        sc.Ah = (uint8_t)Ah;
+        sc.Al = (uint8_t)Al;
+        for (int c = 0; c < ns; c++) {
+          sc.huff[c] = 0;
+          if (Ss == 0 && Ah != 0) continue;  // DC refinement: raw bits
+          const HostHuff& h = Ss == 0 ? dc[td[c]] : ac[ta[c]];
+          if (!h.present) return VSF_ERR_INVALID_ARG;
+          size_t found = prog->huffs.size();
+          for (size_t i = 0; i < prog->huffs.size() && found == prog->huffs.size(); i++)
+            if (std::memcmp(prog->huffs[i].bits, h.bits, 17) == 0 && std::memcmp(prog->huffs[i].vals, h.vals, 256) == 0) found = i;
+          if (found == prog->huffs.size()) prog->huffs.push_back(h);
+          sc.huff[c] = (uint32_t)found;
+        }
+        if (prog->scans.size() >= 1024) return VSF_ERR_INVALID_ARG;  // (64 coefficients x 14 bits bound an orderly file far below)
+        prog->scans.push_back(sc);
+      }
+      pos = end;
+      continue;
     } else if (m == 0xDA) {
       if (!have_sof || n < 1) return VSF_ERR_INVALID_ARG;
       const int ns = s[0];
@@ -209,7 +306,36 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
     }
     pos += len;
   }
-  return VSF_ERR_INVALID_ARG;
+  if (!progressive || !have_sof || prog->scans.empty() || !yq_latched) return VSF_ERR_INVALID_ARG;
+  for (int k = 0; k < 64; k++)
+    if (cbits[k] != 0) return VSF_ERR_UNSUPPORTED;  // the scans stop short of full precision
+  {
+    int hmax = 1, vmax = 1;
+    for (int c = 0; c < ncomp; c++) {
+      hmax = std::max(hmax, ch[c]);
+      vmax = std::max(vmax, cv[c]);
+    }
+    if (ch[0] != hmax || cv[0] != vmax) return VSF_ERR_UNSUPPORTED;  // luminance would need upsampling
+    if (W != width || H != height) return VSF_ERR_INVALID_ARG;
+    // the coefficient buffer is laid out as the frame's interleaved MCUs (what the IDCT kernel walks): for a gray frame that
+    // is one block per MCU whatever its sampling factors say
+    const bool single = ncomp == 1;
+    const int mw = single ? 8 : 8 * hmax, mh = single ? 8 : 8 * vmax;
+    im->ncomp = ncomp;
+    im->restart_interval = 0;
+    im->mcus_x = (W + mw - 1) / mw;
+    im->mcus_y = (H + mh - 1) / mh;
+    for (int c = 0; c < ncomp; c++) {
+      im->h[c] = single ? 1 : ch[c];
+      im->v[c] = single ? 1 : cv[c];
+    }
+    im->n_scans = (int32_t)prog->scans.size();
+    tab->nslots = 0;
+    std::memcpy(tab->qt_luma, yq, sizeof(tab->qt_luma));
+    *scan_begin = prog->scans[0].off;
+    for (DevScan& sc : prog->scans) sc.off -= (uint32_t)*scan_begin;
+  }
+  return VSF_OK;
 }
 
 // Host half of vsf_jpeg_decode_gray_batch, step 1: parses every file and lays out ONE upload -- image descriptors,
@@ -221,14 +347,30 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   std::vector<DevTables> tables;
   std::vector<HostTableSet> sets;
   std::vector<int> set_par_ok;
+  std::vector<DevScan> scans;      // progressive files: their luminance scans, file after file
+  std::vector<DevHuff> prog_huff;  // ... and the tables of those scans
+  ProgFile prog;
   plan->scan_begin.assign((size_t)n, 0);
   plan->max_luma_blocks = 0;
   plan->max_slots = 1;
   size_t stream_bytes = 0;
   for (int i = 0; i < n; i++) {
     HostTableSet t;
-    const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &plan->scan_begin[i]);
+    const vsf_status st = parse_jpeg(jpeg[i], nbytes[i], width, height, &images[i], &t, &plan->scan_begin[i], &prog);
     if (st != VSF_OK) return st;
+    if (images[i].n_scans > 0) {
+      images[i].first_scan = (uint32_t)scans.size();
+      const uint32_t huff0 = (uint32_t)prog_huff.size();
+      for (const HostHuff& h : prog.huffs) {
+        prog_huff.emplace_back();
+        if (!build_dev_huff(h, &prog_huff.back())) return VSF_ERR_INVALID_ARG;
+      }
+      for (DevScan sc : prog.scans) {
+        for (int c = 0; c < sc.ncomp; c++) sc.huff[c] += huff0;
+        scans.push_back(sc);
+      }
+      if (prog_huff.size() * sizeof(DevHuff) > 0x40000000u) return VSF_ERR_INVALID_ARG;
+    }
     int found = -1;
     for (int k = (int)sets.size() - 1; k >= 0 && found < 0; k--)
       if (sets[k].same(t)) found = k;
@@ -258,30 +400,38 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
     plan->max_luma_blocks = std::max(plan->max_luma_blocks, images[i].mcus_x * images[i].mcus_y * images[i].h[0] * images[i].v[0]);
     if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
   }
-  // which decoder takes which file: those without restart intervals first
+  // which decoder takes which file: those without restart intervals first, progressive files next
   std::vector<uint32_t> index;
   auto parallel = [&](int i) {
     const DevImage& im = images[i];
-    if (!im.par_ok || force_serial) return false;
+    if (!im.par_ok || force_serial || im.n_scans > 0) return false;
     if (im.restart_interval == 0) return true;
     // restart intervals: the table of their start offsets must fit the scratch behind the clean stream
     const size_t intervals = ((size_t)im.mcus_x * im.mcus_y + im.restart_interval - 1) / im.restart_interval;
     return 4 * (intervals + 2) <= (size_t)im.stream_len + kTransSlack;
   };
-  for (int pass = 0; pass < 2; pass++)
+  auto decoder = [&](int i) { return parallel(i) ? 0 : (images[i].n_scans > 0 ? 1 : 2); };
+  plan->n_par = plan->n_prog = 0;
+  for (int pass = 0; pass < 3; pass++)
     for (int i = 0; i < n; i++)
-      if (parallel(i) == (pass == 0)) index.push_back((uint32_t)i);
-  plan->n_par = 0;
-  for (int i = 0; i < n; i++) plan->n_par += parallel(i);
+      if (decoder(i) == pass) {
+        index.push_back((uint32_t)i);
+        plan->n_par += pass == 0;
+        plan->n_prog += pass == 1;
+      }
   plan->off_images = 0;
   plan->off_index = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
   plan->off_tables = (plan->off_index + index.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
-  plan->off_stream = (plan->off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
+  plan->off_scans = (plan->off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
+  plan->off_prog_huff = (plan->off_scans + scans.size() * sizeof(DevScan) + 15) & ~(size_t)15;
+  plan->off_stream = (plan->off_prog_huff + prog_huff.size() * sizeof(DevHuff) + 15) & ~(size_t)15;
   plan->total = plan->off_stream + stream_bytes + 16;
   plan->head.assign(plan->off_stream, 0);
   std::memcpy(plan->head.data() + plan->off_images, images.data(), images.size() * sizeof(DevImage));
   std::memcpy(plan->head.data() + plan->off_index, index.data(), index.size() * sizeof(uint32_t));
   std::memcpy(plan->head.data() + plan->off_tables, tables.data(), tables.size() * sizeof(DevTables));
+  if (!scans.empty()) std::memcpy(plan->head.data() + plan->off_scans, scans.data(), scans.size() * sizeof(DevScan));
+  if (!prog_huff.empty()) std::memcpy(plan->head.data() + plan->off_prog_huff, prog_huff.data(), prog_huff.size() * sizeof(DevHuff));
   plan->stream_off.resize((size_t)n);
   plan->stream_len.resize((size_t)n);
   for (int i = 0; i < n; i++) {

@@ -39,7 +39,21 @@ struct DevImage {
   int32_t h[3], v[3];            // blocks per MCU of each component (1 x 1 for a single-component scan)
   int32_t dc_slot[3], ac_slot[3];
   int32_t par_ok;                // every Huffman table in use fits its second-level tables (the parallel decoder's need)
+  int32_t n_scans;               // progressive files: the scans that carry the luminance component (0: a sequential file)
+  uint32_t first_scan;           // ... and where they start in the upload's scan list
 };
+
+// One scan of a progressive file (T.81 Annex G) as the device walks it.  Only scans with the luminance component are
+// listed: scans of chroma alone never touch what a gray read returns.
+struct DevScan {
+  uint32_t off, len;             // its entropy-coded segment, relative to the image's stream_off
+  int32_t restart_interval;      // as the last DRI in front of the scan set it
+  uint8_t ncomp, Ss, Se, Ah, Al; // components in the scan; spectral selection; successive approximation
+  uint8_t comp[3];               // frame component (0 = luminance) of each scan component
+  uint32_t huff[3];              // each scan component's Huffman table (DC scans: its DC table, AC scans: its AC table) in the
+                                 // upload's list of progressive tables; unused in DC refinement scans
+};
+static_assert(sizeof(DevScan) == 32, "DevScan layout");
 
 constexpr int kParThreads = 256;  // threads (= segments) of the parallel decoder per image
 constexpr int kOverlap = 8;       // rows every segment's column carries past its end: the first rows of the next segment
