@@ -55,6 +55,6 @@ for label, mode, kw in (("baseline gray q80", "L", dict(quality=80)),
         host += time.perf_counter() - h0
     ctx.sync()
     dt = (time.perf_counter() - t0) / reps
-    print("%-24s (%.0f KB per image): %d images in %.2f ms = %.0f images/s = %.0f stereo frames/s (host parse + staging "
-          "%.2f ms of it); first 4 == libjpeg-turbo" % (label, kb, N, dt * 1e3, N / dt, N / dt / 2, host / reps * 1e3), flush=True)
+    print("%-24s (%.0f KB per image): %d images in %.2f ms = %.0f images/s = %.0f stereo frames/s (inside the calls "
+          "%.2f ms of it, waits for the staging buffer included); first 4 == libjpeg-turbo" % (label, kb, N, dt * 1e3, N / dt, N / dt / 2, host / reps * 1e3), flush=True)
     ctx.close()

@@ -103,9 +103,14 @@ struct BitReader {
     drop(s);
     return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
   }
-  __device__ __forceinline__ int decode(const DevHuff* h) {
+  template <class Table>
+  __device__ __forceinline__ int decode(const Table* h) {
     const uint32_t p = peek(kLookBits);
-    const uint32_t e = (reinterpret_cast<const uint32_t*>(h->look)[p >> 1] >> (16u * (p & 1u))) & 0xFFFFu;
+    return finish(h, (reinterpret_cast<const uint32_t*>(h->look)[p >> 1] >> (16u * (p & 1u))) & 0xFFFFu);
+  }
+  // the rest of a decode once the lookahead entry `e` of the next 9 bits is at hand
+  template <class Table>
+  __device__ __forceinline__ int finish(const Table* h, uint32_t e) {
     if (!(e & kLongCode)) {
       drop((int)(e >> 8));
       return (int)(e & 255u);
@@ -339,10 +344,54 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 //                   parse collects three 64-bit maps -- corrections, new +1 << Al, new -1 << Al -- and the lanes apply them.
 // Scans are separated by a device-scope fence: a scan reads what earlier scans wrote through other lanes.
 // ---------------------------------------------------------------------------------------------------------------------
+// Expands the Huffman tables of progressive scans (BITS / HUFFVAL as in the file -> the 9-bit lookahead table and the
+// MAXCODE / VALPTR arrays of T.81 F.2.2.3), one wave per table.
+__global__ __launch_bounds__(64) void jpeg_expand_huff_kernel(const DevHuffSrc* __restrict__ src, DevHuffLite* __restrict__ dst) {
+  const DevHuffSrc& in = src[blockIdx.x];
+  DevHuffLite& out = dst[blockIdx.x];
+  const int lane = threadIdx.x;
+  int32_t maxcode[17], valoff[17];
+  int32_t code = 0;
+  int k = 0;
+#pragma unroll
+  for (int l = 1; l <= 16; l++) {
+    const int n = in.bits[l];
+    valoff[l] = k - code;
+    code += n;
+    k += n;
+    maxcode[l] = n ? code - 1 : -1;
+    code <<= 1;
+  }
+  if (lane == 0) {
+    out.maxcode[0] = -1;
+    out.valoff[0] = 0;
+#pragma unroll
+    for (int l = 1; l <= 16; l++) {
+      out.maxcode[l] = maxcode[l];
+      out.valoff[l] = valoff[l];
+    }
+    out.maxcode[17] = 0x7FFFFFFF;
+  }
+  for (int p = lane; p < (1 << kLookBits); p += 64) {
+    uint32_t e = kLongCode;  // a longer code (or none at all: the MAXCODE walk sorts that out)
+    bool found = false;
+#pragma unroll
+    for (int l = 1; l <= kLookBits; l++) {  // F.2.2.3: the shortest length whose MAXCODE holds the prefix
+      const int32_t c = p >> (kLookBits - l);
+      if (!found && c <= maxcode[l]) {
+        e = ((uint32_t)l << 8) | in.vals[(valoff[l] + c) & 255];
+        found = true;
+      }
+    }
+    out.look[p] = (uint16_t)e;
+  }
+  reinterpret_cast<uint32_t*>(out.vals)[lane] = reinterpret_cast<const uint32_t*>(in.vals)[lane];
+}
+
 __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restrict__ images,
                                                         const uint32_t* __restrict__ index,
                                                         const DevScan* __restrict__ scans,
-                                                        const DevHuff* __restrict__ huffs,
+                                                        const DevHuffLite* __restrict__ huffs,
                                                         const uint8_t* __restrict__ stream, int16_t* __restrict__ coef_all,
                                                         size_t coef_stride, int slot0, int width, int height,
                                                         int32_t* __restrict__ status) {
@@ -377,7 +426,10 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
       br.drop(n);
       return v;
     };
+    auto decode = [&](int, const DevHuffLite* t) -> int { return br.decode(t); };  // (after br.fill())
     const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto below = [](int n) -> uint64_t { return n >= 64 ? ~0ull : (1ull << n) - 1ull; };  // positions 0 .. n - 1
+    const uint64_t band = below(Se + 1) & ~below(Ss);
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int eobrun = 0, until_restart = restart_interval;
     // the MCUs of this scan: the frame's interleaved MCUs, or -- a scan of the luminance alone -- its own blocks in raster
@@ -390,11 +442,11 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
     };
     if (Ss == 0) {
       // ---- DC scans ----
-      const DevHuff *t0 = huffs + sc.huff[0], *t1 = huffs + sc.huff[ns > 1 ? 1 : 0], *t2 = huffs + sc.huff[ns > 2 ? 2 : 0];
-      auto dc_block = [&](const DevHuff* t, int& pred, int16_t* blk) {  // blk: a luminance block, or null
+      const DevHuffLite *t0 = huffs + sc.huff[0], *t1 = huffs + sc.huff[ns > 1 ? 1 : 0], *t2 = huffs + sc.huff[ns > 2 ? 2 : 0];
+      auto dc_block = [&](int slot, const DevHuffLite* t, int& pred, int16_t* blk) {  // blk: a luminance block, or null
         if (Ah == 0) {
           br.fill();
-          const int s = br.decode(t);
+          const int s = decode(slot, t);
           br.fill();
           pred += br.receive_extend(s);
           if (blk && lane == 0) blk[0] = (int16_t)(pred * p1);
@@ -402,32 +454,45 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
           if (blk && lane == 0) atomicOr(reinterpret_cast<unsigned int*>(blk), (unsigned int)p1);  // coefficient 0: low half
         }
       };
-      for (int uy = 0; uy < units_y && !broken; uy++)
-        for (int ux = 0; ux < units_x; ux++) {
-          if (restart_interval && until_restart == 0) {
-            if (!br.restart()) {
-              broken = true;
-              break;
-            }
-            pred0 = pred1 = pred2 = 0;
-            until_restart = restart_interval;
+      if (Ah != 0 && !interleaved && restart_interval == 0) {
+        // one raw bit per block and nothing else in the stream: 16 blocks per read, a lane each
+        const int nblocks = units_x * units_y;
+        for (int b0 = 0; b0 < nblocks; b0 += 16) {
+          const int cnt = nblocks - b0 < 16 ? nblocks - b0 : 16;
+          const uint32_t got = (uint32_t)receive(cnt);
+          if (lane < cnt && ((got >> (cnt - 1 - lane)) & 1u)) {
+            const int b = b0 + lane, by = b / units_x;
+            atomicOr(reinterpret_cast<unsigned int*>(coef + (size_t)block_of(by, b - by * units_x) * 64), (unsigned int)p1);
           }
-          if (!interleaved) {
-            dc_block(t0, pred0, coef + (size_t)block_of(uy, ux) * 64);
-          } else {
-            for (int c = 0; c < ns; c++) {
-              const int ci = sc.comp[c], hh = im.h[ci], vv = im.v[ci];
-              const DevHuff* t = c == 0 ? t0 : (c == 1 ? t1 : t2);
-              int& pred = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-              for (int b = 0; b < hh * vv; b++)
-                dc_block(t, pred, ci == 0 ? coef + ((size_t)(uy * mcus_x + ux) * lum + b) * 64 : nullptr);
-            }
-          }
-          if (restart_interval) until_restart--;
         }
+      } else {
+        for (int uy = 0; uy < units_y && !broken; uy++)
+          for (int ux = 0; ux < units_x; ux++) {
+            if (restart_interval && until_restart == 0) {
+              if (!br.restart()) {
+                broken = true;
+                break;
+              }
+              pred0 = pred1 = pred2 = 0;
+              until_restart = restart_interval;
+            }
+            if (!interleaved) {
+              dc_block(0, t0, pred0, coef + (size_t)block_of(uy, ux) * 64);
+            } else {
+              for (int c = 0; c < ns; c++) {
+                const int ci = sc.comp[c], hh = im.h[ci], vv = im.v[ci];
+                const DevHuffLite* t = c == 0 ? t0 : (c == 1 ? t1 : t2);
+                int& pred = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+                for (int b = 0; b < hh * vv; b++)
+                  dc_block(c, t, pred, ci == 0 ? coef + ((size_t)(uy * mcus_x + ux) * lum + b) * 64 : nullptr);
+              }
+            }
+            if (restart_interval) until_restart--;
+          }
+      }
     } else {
       // ---- AC scans: the luminance alone, block after block in raster order ----
-      const DevHuff* t = huffs + sc.huff[0];
+      const DevHuffLite* t = huffs + sc.huff[0];
       const int nblocks = units_x * units_y;
       int bx = 0, by = 0;
       int16_t* blk = coef + (size_t)block_of(0, 0) * 64;
@@ -459,7 +524,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
             int mine = 0;
             for (int k = Ss; k <= Se; k++) {
               br.fill();
-              const int rs = br.decode(t);
+              const int rs = decode(0, t);
               const int r = rs >> 4, sz = rs & 15;
               if (sz) {
                 k += r;
@@ -479,16 +544,29 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
             if (mine != 0) here[nat] = (int16_t)mine;
           }
         } else {
-          // AC refinement
-          const uint64_t nz = __ballot(c != 0);
-          uint64_t corr = 0, newp = 0, newn = 0;
+          // AC refinement.  `nz`: the coefficients of the band that are non-zero so far.  A symbol (run r, new value of
+          // magnitude 1 << Al) moves the decoder to the (r + 1)-th ZERO coefficient from k on; every non-zero one it
+          // passes on the way owes a correction bit.  Both are answered from the map: the target by clearing r low
+          // bits of the zero map, the passed ones 16 positions at a time -- their bits are read together and each lane
+          // picks its own by its rank among them.
+          const uint64_t nz = __ballot(c != 0) & band;
+          int my_corr = 0, my_new = 0;
+          auto corrections = [&](uint64_t P) {
+            while (P) {
+              const int lo = __builtin_ctzll(P);
+              const uint64_t Wn = P & (0xFFFFull << lo);
+              const int cnt = __builtin_popcountll(Wn);
+              const uint32_t got = (uint32_t)receive(cnt);
+              if ((Wn >> lane) & 1ull) my_corr = (int)(got >> (cnt - 1 - __builtin_popcountll(Wn & below(lane)))) & 1;
+              P &= ~Wn;
+            }
+          };
           int k = Ss;
           if (eobrun == 0) {
-            for (; k <= Se; k++) {
+            while (k <= Se) {
               br.fill();
-              const int rs = br.decode(t);
-              int r = rs >> 4;
-              const int sz = rs & 15;
+              const int rs = decode(0, t);
+              const int r = rs >> 4, sz = rs & 15;
               int sign = 0;
               if (sz) {
                 sign = get_bit() ? 1 : -1;  // (the size must be 1; libjpeg warns and carries on the same way)
@@ -497,35 +575,27 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
                 if (r) eobrun += receive(r);
                 break;
               }
-              while (k <= Se) {
-                if ((nz >> k) & 1ull) {
-                  if (get_bit()) corr |= 1ull << k;
-                } else if (--r < 0) {
-                  break;
-                }
-                k++;
-              }
-              if (sign > 0 && k <= 63) newp |= 1ull << k;
-              if (sign < 0 && k <= 63) newn |= 1ull << k;
+              const uint64_t ahead = band & ~below(k);
+              uint64_t zeros = ~nz & ahead;
+              for (int i = 0; i < r && zeros; i++) zeros &= zeros - 1ull;
+              const int pos = zeros ? __builtin_ctzll(zeros) : Se + 1;  // (no such zero: the run ends behind the band)
+              corrections(nz & ahead & below(pos));
+              if (sign && lane == pos) my_new = sign;
+              k = pos + 1;
             }
           }
           if (eobrun > 0) {
-            for (; k <= Se; k++)
-              if (((nz >> k) & 1ull) && get_bit()) corr |= 1ull << k;
+            if (k <= Se) corrections(nz & ~below(k));
             eobrun--;
           }
           int cv = c;
           bool changed = false;
-          if (((corr >> lane) & 1ull) && (cv & p1) == 0) {
+          if (my_corr && (cv & p1) == 0) {
             cv = cv >= 0 ? cv + p1 : cv + m1;
             changed = true;
           }
-          if ((newp >> lane) & 1ull) {
-            cv = p1;
-            changed = true;
-          }
-          if ((newn >> lane) & 1ull) {
-            cv = m1;
+          if (my_new) {
+            cv = my_new > 0 ? p1 : m1;
             changed = true;
           }
           if (changed) here[nat] = (int16_t)cv;
@@ -1149,6 +1219,8 @@ size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par) {
   return n_par > 0 ? 2 * linear + (size_t)n_par * kTransSlack : linear;
 }
 
+size_t vsf_jpeg_prog_huff_bytes(int n_tables) { return (size_t)n_tables * sizeof(DevHuffLite); }
+
 // The parallel decoder's static + dynamic LDS exceed the default 64 KB for colour files: raised (checked) at vsf_create.
 hipError_t vsf_prepare_jpeg_kernels(int lds_limit) {
   const int need = (int)(kMaxSlots * sizeof(DevHuff));
@@ -1161,8 +1233,9 @@ hipError_t vsf_prepare_jpeg_kernels(int lds_limit) {
 // vsf_jpeg_clean_bytes(total - off_stream, n_par) bytes, d_coef holds n_par * coef_stride bytes (coef_stride = 128 * luminance blocks of the
 // largest padded image): every luminance block is written whole.
 void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_scans,
-                            size_t off_prog_huff, size_t off_stream, size_t total, int n_par, int n_prog, int n_ser,
-                            int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
+                            size_t off_prog_huff, size_t off_stream, size_t total, int n_par, int n_prog, int n_prog_huff,
+                            void* d_prog_huff, int n_ser, int max_luma_blocks, int max_slots, int width, int height,
+                            uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
                             int32_t* d_status, hipStream_t s) {
   const DevImage* images = reinterpret_cast<const DevImage*>(d_blob + off_images);
@@ -1175,10 +1248,14 @@ void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off
                        reinterpret_cast<uint32_t*>(d_clean + vsf_jpeg_clean_bytes(total - off_stream, 0)), d_coef, coef_stride,
                        max_slots, d_status);
   }
-  if (n_prog > 0)  // progressive files: their slots of the coefficient buffer follow the parallel decoder's
+  if (n_prog > 0) {  // progressive files: their slots of the coefficient buffer follow the parallel decoder's
+    if (n_prog_huff > 0)
+      hipLaunchKernelGGL(jpeg_expand_huff_kernel, dim3(n_prog_huff), dim3(64), 0, s,
+                         reinterpret_cast<const DevHuffSrc*>(d_blob + off_prog_huff), static_cast<DevHuffLite*>(d_prog_huff));
     hipLaunchKernelGGL(jpeg_prog_kernel, dim3(n_prog), dim3(64), 0, s, images, index + n_par,
-                       reinterpret_cast<const DevScan*>(d_blob + off_scans), reinterpret_cast<const DevHuff*>(d_blob + off_prog_huff),
+                       reinterpret_cast<const DevScan*>(d_blob + off_scans), static_cast<const DevHuffLite*>(d_prog_huff),
                        d_blob + off_stream, d_coef, coef_stride, n_par, width, height, d_status);
+  }
   if (n_par + n_prog > 0)
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_luma_blocks + 7) / 8, n_par + n_prog), dim3(64), 0, s, images, index, tables,
                        d_coef, coef_stride, width, height, d_dst, dst_image_stride, dst_pitch);

@@ -1704,7 +1704,8 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   const size_t coef_stride = (size_t)plan.max_luma_blocks * 64 * sizeof(int16_t);
   if (plan.n_par + plan.n_prog > 0) {
     const size_t clean_need = plan.n_par > 0 ? vsf_jpeg_clean_bytes(plan.total - plan.off_stream, plan.n_par) : 0,
-                 coef_need = (size_t)(plan.n_par + plan.n_prog) * coef_stride;
+                 coef_need = (size_t)(plan.n_par + plan.n_prog) * coef_stride + vsf_jpeg_prog_huff_bytes(plan.n_prog_huff);
+    // (the expanded Huffman tables of progressive scans live behind the coefficients)
     if (clean_need > ctx->jp_clean_cap || coef_need > ctx->jp_coef_cap) {
       VSF_HIP(hipStreamSynchronize(ctx->stream));
       if (clean_need > ctx->jp_clean_cap) {
@@ -1727,8 +1728,9 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
   VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
   vsf_launch_jpeg_decode(ctx->jp_dev[b], plan.off_images, plan.off_index, plan.off_tables, plan.off_scans, plan.off_prog_huff,
-                         plan.off_stream, plan.total, plan.n_par, plan.n_prog, n_images - plan.n_par - plan.n_prog,
-                         plan.max_luma_blocks, plan.max_slots, width, height, ctx->jp_clean, ctx->jp_coef,
+                         plan.off_stream, plan.total, plan.n_par, plan.n_prog, plan.n_prog_huff,
+                         reinterpret_cast<uint8_t*>(ctx->jp_coef) + (size_t)(plan.n_par + plan.n_prog) * coef_stride,
+                         n_images - plan.n_par - plan.n_prog, plan.max_luma_blocks, plan.max_slots, width, height, ctx->jp_clean, ctx->jp_coef,
                          coef_stride, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
   VSF_STICKY();
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));

@@ -233,6 +233,7 @@ struct VsfJpegPlan {  // layout of one upload: [image descriptors | decode order
   std::vector<uint32_t> stream_off, stream_len;
   int n_par = 0;             // files without restart intervals: they take the self-synchronising parallel decode
   int n_prog = 0;            // progressive files: scan after scan into the coefficient buffer, one wave per file
+  int n_prog_huff = 0;       // ... and the Huffman tables of their scans (expanded on the device)
   int max_luma_blocks = 0;   // luminance blocks of the (padded) image, largest over the batch
   int max_slots = 1;         // Huffman tables one file's scan uses, largest over the batch
 };
@@ -241,9 +242,11 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
 void vsf_jpeg_fill(const VsfJpegPlan& plan, const uint8_t* const* jpeg, int n, uint8_t* dst);
 #endif
 size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par);
+size_t vsf_jpeg_prog_huff_bytes(int n_tables);  // device scratch for the expanded tables of progressive scans
 void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_scans,
-                            size_t off_prog_huff, size_t off_stream, size_t total, int n_par, int n_prog, int n_ser,
-                            int max_luma_blocks, int max_slots, int width, int height, uint8_t* d_clean,
+                            size_t off_prog_huff, size_t off_stream, size_t total, int n_par, int n_prog, int n_prog_huff,
+                            void* d_prog_huff, int n_ser, int max_luma_blocks, int max_slots, int width, int height,
+                            uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
                             int32_t* d_status, hipStream_t s);
 

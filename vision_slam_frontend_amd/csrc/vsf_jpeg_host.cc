@@ -348,7 +348,7 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   std::vector<HostTableSet> sets;
   std::vector<int> set_par_ok;
   std::vector<DevScan> scans;      // progressive files: their luminance scans, file after file
-  std::vector<DevHuff> prog_huff;  // ... and the tables of those scans
+  std::vector<DevHuffSrc> prog_huff;  // ... and the tables of those scans, as the files define them
   ProgFile prog;
   plan->scan_begin.assign((size_t)n, 0);
   plan->max_luma_blocks = 0;
@@ -361,15 +361,17 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
     if (images[i].n_scans > 0) {
       images[i].first_scan = (uint32_t)scans.size();
       const uint32_t huff0 = (uint32_t)prog_huff.size();
-      for (const HostHuff& h : prog.huffs) {
+      for (const HostHuff& h : prog.huffs) {  // (parse_jpeg has checked the counts: huff_counts_ok)
         prog_huff.emplace_back();
-        if (!build_dev_huff(h, &prog_huff.back())) return VSF_ERR_INVALID_ARG;
+        std::memset(prog_huff.back().bits, 0, sizeof(prog_huff.back().bits));
+        std::memcpy(prog_huff.back().bits, h.bits, 17);
+        std::memcpy(prog_huff.back().vals, h.vals, 256);
       }
       for (DevScan sc : prog.scans) {
         for (int c = 0; c < sc.ncomp; c++) sc.huff[c] += huff0;
         scans.push_back(sc);
       }
-      if (prog_huff.size() * sizeof(DevHuff) > 0x40000000u) return VSF_ERR_INVALID_ARG;
+      if (prog_huff.size() * sizeof(DevHuffLite) > 0x40000000u) return VSF_ERR_INVALID_ARG;
     }
     int found = -1;
     for (int k = (int)sets.size() - 1; k >= 0 && found < 0; k--)
@@ -424,14 +426,15 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
   plan->off_tables = (plan->off_index + index.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
   plan->off_scans = (plan->off_tables + tables.size() * sizeof(DevTables) + 15) & ~(size_t)15;
   plan->off_prog_huff = (plan->off_scans + scans.size() * sizeof(DevScan) + 15) & ~(size_t)15;
-  plan->off_stream = (plan->off_prog_huff + prog_huff.size() * sizeof(DevHuff) + 15) & ~(size_t)15;
+  plan->off_stream = (plan->off_prog_huff + prog_huff.size() * sizeof(DevHuffSrc) + 15) & ~(size_t)15;
+  plan->n_prog_huff = (int)prog_huff.size();
   plan->total = plan->off_stream + stream_bytes + 16;
   plan->head.assign(plan->off_stream, 0);
   std::memcpy(plan->head.data() + plan->off_images, images.data(), images.size() * sizeof(DevImage));
   std::memcpy(plan->head.data() + plan->off_index, index.data(), index.size() * sizeof(uint32_t));
   std::memcpy(plan->head.data() + plan->off_tables, tables.data(), tables.size() * sizeof(DevTables));
   if (!scans.empty()) std::memcpy(plan->head.data() + plan->off_scans, scans.data(), scans.size() * sizeof(DevScan));
-  if (!prog_huff.empty()) std::memcpy(plan->head.data() + plan->off_prog_huff, prog_huff.data(), prog_huff.size() * sizeof(DevHuff));
+  if (!prog_huff.empty()) std::memcpy(plan->head.data() + plan->off_prog_huff, prog_huff.data(), prog_huff.size() * sizeof(DevHuffSrc));
   plan->stream_off.resize((size_t)n);
   plan->stream_len.resize((size_t)n);
   for (int i = 0; i < n; i++) {

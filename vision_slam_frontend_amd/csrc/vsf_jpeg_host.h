@@ -43,6 +43,20 @@ struct DevImage {
   uint32_t first_scan;           // ... and where they start in the upload's scan list
 };
 
+// Progressive files bring Huffman tables of their own with every scan (an encoder must optimise them: T.81 has no default
+// progressive tables), ~5 per file: they travel as written in the DHT segment and a kernel expands them on the device.
+struct DevHuffSrc {
+  uint8_t bits[20];              // BITS[1..16] at [1..16]
+  uint8_t vals[256];
+};
+struct DevHuffLite {             // what the one-wave decoders read of a table (no second-level tables)
+  uint16_t look[1 << kLookBits];
+  int32_t maxcode[18];
+  int32_t valoff[17];
+  uint8_t vals[256];
+};
+static_assert(sizeof(DevHuffSrc) == 276 && sizeof(DevHuffLite) == 1024 + 72 + 68 + 256, "progressive table layouts");
+
 // One scan of a progressive file (T.81 Annex G) as the device walks it.  Only scans with the luminance component are
 // listed: scans of chroma alone never touch what a gray read returns.
 struct DevScan {
