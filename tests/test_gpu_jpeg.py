@@ -90,6 +90,11 @@ def test_refusals_and_truncation(ctx, oracle):
     np.testing.assert_array_equal(d.cpu().numpy()[0], oracle.jpeg_decode_gray(half))
     assert st == capi.VSF_OK  # (a stream that merely ends early is not "broken": only a missing restart marker is)
     assert call(good) == capi.VSF_OK and ctx.sync() == capi.VSF_OK
+    # a progressive file cut inside its LAST scan (every scan header has been seen): the same zero bits
+    for cut in (len(prog) - 40, len(prog) - 150):
+        assert call(prog[:cut]) == capi.VSF_OK
+        ctx.sync(allow_capacity=True)
+        np.testing.assert_array_equal(d.cpu().numpy()[0], oracle.jpeg_decode_gray(prog[:cut]))
 
 
 def test_ingest_chain_jpeg_bayer_extract(ctx, oracle):
