@@ -207,7 +207,10 @@ class Context:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except TypeError:  # interpreter shutdown: the module's globals are gone already (the process ends anyway)
+            pass
 
     def __enter__(self):
         return self
