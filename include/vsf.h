@@ -369,10 +369,10 @@ vsf_status vsf_observe_reset(vsf_ctx* ctx);
  * (slam_frontend_main.cc:99-100) for n JPEG files in HOST memory (the CompressedImage payloads), all of width x height:
  * ITU-T T.81 Huffman decoding + libjpeg's ISLOW inverse DCT of the luminance component, which is what OpenCV's reader
  * computes for a gray read (JCS_GRAYSCALE; chroma is parsed and dropped).  Baseline files (SOF0 / SOF1: what a camera
- * driver writes) and progressive files (SOF2; any scan script that brings every luminance coefficient to full precision),
- * gray and YCbCr with sampling factors up to 4, restart intervals, custom tables.  Arithmetic-coded, 12-bit and lossless
- * files, sequential files in several scans and progressive files whose scans stop short of full precision (libjpeg shows
- * an approximation of those) return VSF_ERR_UNSUPPORTED, files of another size or with malformed headers
+ * driver writes; also when their components come in several scans) and progressive files (SOF2; any scan script that
+ * brings every luminance coefficient to full precision), gray and YCbCr with sampling factors up to 4, restart intervals,
+ * custom tables.  Arithmetic-coded, 12-bit and lossless files and progressive files whose scans stop short of full
+ * precision (libjpeg shows an approximation of those) return VSF_ERR_UNSUPPORTED, files of another size or with malformed headers
  * VSF_ERR_INVALID_ARG (nothing is launched then).
  * The images land at d_dst + i * dst_image_stride (DEVICE memory, rows dst_row_stride apart; base and strides multiples
  * of 4) -- the input of vsf_bayer_bg_to_gray_batch_dev or of the extraction.  The files are copied before the call

@@ -261,6 +261,26 @@ int decode_prog_scan(const uint8_t* ecs, const uint8_t* ecs_stop, const std::vec
   }
   const int p1 = 1 << Al, m1 = -(1 << Al);
   auto one_block = [&](int16_t* blk, const ScanComp& s, int slot) {
+    if (Ss == 0 && Se == 63) {  // a scan of a SEQUENTIAL file (several scans, each component in one of them): F.2.2.1, F.2.2.2
+      const int t = br.decode(dc[s.td]);
+      pred[slot] += extend(br.receive(t), t);
+      if (blk) blk[0] = (int16_t)pred[slot];
+      for (int k = 1; k < 64;) {
+        const int rs = br.decode(ac[s.ta]);
+        const int r = rs >> 4, sz = rs & 15;
+        if (sz == 0) {
+          if (r != 15) break;
+          k += 16;
+          continue;
+        }
+        k += r;
+        const int v = extend(br.receive(sz), sz);
+        if (k > 63) break;  // corrupt
+        if (blk) blk[kZigzag[k]] = (int16_t)v;
+        k++;
+      }
+      return;
+    }
     if (Ss == 0) {
       if (Ah == 0) {  // DC first: the difference coded as in the sequential process, stored shifted left by Al
         const int t = br.decode(dc[s.td]);
@@ -361,8 +381,10 @@ int decode_prog_scan(const uint8_t* ecs, const uint8_t* ecs_stop, const std::vec
   return 0;
 }
 
+// `sequential`: the frame is SOF0 / SOF1 and its components come in several scans (full-band scans, Ss = 0, Se = 63, no
+// successive approximation) -- libjpeg reads those through the same coefficient buffer (jdcoefct.c, has_multiple_scans).
 int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w, int cap_h, int* w_out,
-                       int* h_out) {
+                       int* h_out, bool sequential = false) {
   uint16_t qt[4][64], yq[64];
   bool qt_present[4] = {false, false, false, false};
   bool yq_latched = false;
@@ -390,7 +412,7 @@ int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t 
       if (parse_dqt(s, n, qt, qt_present)) return -1;
     } else if (m == 0xC4) {
       if (parse_dht(s, n, dc, ac)) return -1;
-    } else if (m == 0xC2) {
+    } else if (m == (sequential ? 0xC0 : 0xC2) || (sequential && m == 0xC1)) {
       if (have_sof) return -1;
       if (n < 6 || s[0] != 8) return -2;
       H = (s[1] << 8) | s[2];
@@ -440,9 +462,12 @@ int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t 
         has_luma |= ci == 0;
       }
       const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
-      // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
-      if (Ss == 0 ? Se != 0 : (ns != 1 || Se < Ss || Se > 63)) return -1;
-      if ((Ah != 0 && Al != Ah - 1) || Al > 13) return -1;
+      if (sequential) {
+        if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return -1;
+      } else {  // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
+        if (Ss == 0 ? Se != 0 : (ns != 1 || Se < Ss || Se > 63)) return -1;
+        if ((Ah != 0 && Al != Ah - 1) || Al > 13) return -1;
+      }
       const size_t begin = pos + len, end = ecs_end(data, begin, nbytes);
       if (has_luma) {
         for (int k = Ss; k <= Se; k++) {  // every scan must continue where the previous one over this coefficient stopped
@@ -451,7 +476,9 @@ int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t 
         }
         if (Ss > 0 && cbits[0] < 0) return -2;  // AC before any DC scan
         for (const ScanComp& c : sc)
-          if (Ss == 0 ? (Ah == 0 && !dc[c.td].present) : !ac[c.ta].present) return -1;
+          if (sequential ? (!dc[c.td].present || !ac[c.ta].present)
+                         : (Ss == 0 ? (Ah == 0 && !dc[c.td].present) : !ac[c.ta].present))
+            return -1;
         if (!yq_latched) {  // jdinput.c latch_quant_tables: the table in force at the component's first scan
           if (!qt_present[comps[0].tq]) return -1;
           std::memcpy(yq, qt[comps[0].tq], sizeof(yq));
@@ -486,9 +513,8 @@ int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t 
 
 extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w,
                                      int cap_h, int* w_out, int* h_out) {
-  // returns 0 ok; -1 malformed; -2 a JPEG process this decoder does not restate (arithmetic, 12 bit, lossless, sequential
-  // files in several scans, progressive files whose scans stop short of full precision); -3 the image does not fit
-  // cap_w x cap_h
+  // returns 0 ok; -1 malformed; -2 a JPEG process this decoder does not restate (arithmetic, 12 bit, lossless,
+  // progressive files whose scans stop short of full precision); -3 the image does not fit cap_w x cap_h
   if (!data || nbytes < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
   uint16_t qt[4][64];
   bool qt_present[4] = {false, false, false, false};
@@ -563,7 +589,8 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
     } else if (m == 0xDA) {  // SOS: the one scan
       if (!have_sof || n < 1) return -1;
       const int ns = s[0];
-      if (ns != (int)comps.size()) return -2;  // non-interleaved multi-scan files are not restated
+      if (ns != (int)comps.size())  // the components come in several scans
+        return decode_progressive(data, nbytes, out, ostride, cap_w, cap_h, w_out, h_out, true);
       if (n < (size_t)(4 + 2 * ns)) return -1;
       for (int c = 0; c < ns; c++) {
         if (s[1 + 2 * c] != comps[c].id) return -2;

@@ -320,3 +320,107 @@ def progressive_cases():
     big = [((0,), 0, 0, 0, 0), ((0,), 1, 63, 0, 1), ((0,), 1, 63, 1, 0)]
     out.append(("eob_run_beyond_32767_blocks", write_progressive_jpeg(1600, 1408, [(1, 1, qt(), sparse)], big), 1600, 1408))
     return out
+
+
+def write_multiscan_sequential_jpeg(width, height, comps, scans, restart_interval=0):
+    """A SEQUENTIAL (SOF0) file whose components come in several scans -- e.g. [(0,), (1, 2)] or [(0, 1), (2,)] -- which
+    libjpeg's encoder writes only on request (cjpeg -scans).  comps as for write_progressive_jpeg."""
+    seg = lambda marker, body: bytes([0xFF, marker]) + (len(body) + 2).to_bytes(2, "big") + bytes(body)
+    hmax, vmax = max(c[0] for c in comps), max(c[1] for c in comps)
+    mcus_x, mcus_y = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    out = bytearray(b"\xFF\xD8")
+    for i, (_, _, qt, _) in enumerate(comps):
+        out += seg(0xDB, [i] + [int(qt[z]) for z in ZIGZAG])
+    sof = [8, height >> 8, height & 255, width >> 8, width & 255, len(comps)]
+    for i, (h, v, _, _) in enumerate(comps):
+        sof += [i + 1, (h << 4) | v, i]
+    out += seg(0xC0, sof)
+    if restart_interval:
+        out += seg(0xDD, [restart_interval >> 8, restart_interval & 255])
+    for cidx in scans:
+        items, freq = [], {}   # ('s', cls, slot, symbol) / ('b', value, nbits) / ('r',)
+
+        def sym(cls, slot, s):
+            items.append(("s", cls, slot, s))
+            freq.setdefault((cls, slot), {})
+            freq[(cls, slot)][s] = freq[(cls, slot)].get(s, 0) + 1
+
+        if len(cidx) == 1:
+            h, v, _, coef = comps[cidx[0]]
+            bw, bh = -(-(-(-width * h // hmax)) // 8), -(-(-(-height * v // vmax)) // 8)
+            units = [[(0, coef[y, x])] for y in range(bh) for x in range(bw)]
+        else:
+            units = []
+            for my in range(mcus_y):
+                for mx in range(mcus_x):
+                    u = []
+                    for slot, ci in enumerate(cidx):
+                        h, v, _, coef = comps[ci]
+                        u += [(slot, coef[my * v + y, mx * h + x]) for y in range(v) for x in range(h)]
+                    units.append(u)
+        pred = [0] * len(cidx)
+        for n, unit in enumerate(units):
+            if restart_interval and n and n % restart_interval == 0:
+                items.append(("r",))
+                pred = [0] * len(cidx)
+            for slot, blk in unit:
+                zz = [int(t) for t in blk[ZIGZAG]]
+                s, extra = _size_bits(zz[0] - pred[slot])
+                pred[slot] = zz[0]
+                sym(0, slot, s)
+                if s:
+                    items.append(("b", extra & ((1 << s) - 1), s))
+                run = 0
+                last = max([i for i in range(1, 64) if zz[i]] or [0])
+                for i in range(1, last + 1):
+                    if zz[i] == 0:
+                        run += 1
+                        continue
+                    while run > 15:
+                        sym(1, slot, 0xF0)
+                        run -= 16
+                    s, extra = _size_bits(zz[i])
+                    sym(1, slot, (run << 4) | s)
+                    items.append(("b", extra & ((1 << s) - 1), s))
+                    run = 0
+                if last < 63:
+                    sym(1, slot, 0x00)
+        codes = {}
+        for (cls, slot), f in sorted(freq.items()):
+            bits, vals = skewed_table(f)
+            out += seg(0xC4, [(cls << 4) | slot] + bits + vals)
+            codes[(cls, slot)] = canonical_codes(bits, vals)
+        sos = [len(cidx)]
+        for slot, ci in enumerate(cidx):
+            sos += [ci + 1, (slot << 4) | slot]
+        out += seg(0xDA, sos + [0, 63, 0])
+        w_, rst = _Bits(), 0
+        for it in items:
+            if it[0] == "s":
+                w_.put(*codes[(it[1], it[2])][it[3]])
+            elif it[0] == "b":
+                w_.put(it[1], it[2])
+            else:
+                w_.flush()
+                w_.out += bytes([0xFF, 0xD0 + (rst & 7)])
+                rst += 1
+        w_.flush()
+        out += w_.out
+    return bytes(out + b"\xFF\xD9")
+
+
+def multiscan_sequential_cases():
+    """-> [(name, bytes, width, height)]: the luminance in a scan of its own (before and after the chroma scans), the
+    luminance interleaved with one chroma component, with restart intervals."""
+    rng = np.random.default_rng(4321)
+    qt = lambda: rng.integers(1, 5, 64)
+    comp = lambda h, v, by, bx: (h, v, qt(), random_coefficients(rng, by, bx))
+    out = []
+    c420 = [comp(2, 2, 8, 10), comp(1, 1, 4, 5), comp(1, 1, 4, 5)]
+    out.append(("y_then_cb_then_cr", write_multiscan_sequential_jpeg(75, 61, c420, [(0,), (1,), (2,)]), 75, 61))
+    out.append(("chroma_first_restarts", write_multiscan_sequential_jpeg(75, 61, c420, [(1, 2), (0,)], restart_interval=4), 75, 61))
+    c444 = [comp(1, 1, 5, 7), comp(1, 1, 5, 7), comp(1, 1, 5, 7)]
+    out.append(("y_with_cb_then_cr", write_multiscan_sequential_jpeg(50, 37, c444, [(0, 1), (2,)]), 50, 37))
+    c422 = [comp(2, 1, 6, 10), comp(1, 1, 6, 5), comp(1, 1, 6, 5)]
+    out.append(("cr_then_y_with_cb_422", write_multiscan_sequential_jpeg(77, 45, c422, [(2,), (0, 1)], restart_interval=2), 77, 45))
+    return out

@@ -233,6 +233,17 @@ def test_crafted_progressive_scripts(ctx, oracle):
         np.testing.assert_array_equal(got[1, :, :w], want, err_msg=name)
 
 
+def test_sequential_files_in_several_scans(ctx, oracle):
+    """SOF0 files whose components come in several scans (tests/jpeg_craft.py; the oracle equals libjpeg-turbo on each):
+    they take the scan-list kernel, a block decoded whole per visit."""
+    import jpeg_craft as jc
+    for name, data, w, h in jc.multiscan_sequential_cases():
+        got = _decode(ctx, [data, data], w, h)
+        want = oracle.jpeg_decode_gray(data)
+        np.testing.assert_array_equal(got[0, :, :w], want, err_msg=name)
+        np.testing.assert_array_equal(got[1, :, :w], want, err_msg=name)
+
+
 def test_crafted_huffman_tables(ctx, oracle):
     """AC tables with scores of long codes (tests/jpeg_craft.py): 80 distinct 9-bit prefixes of 10-bit codes are more than
     the parallel decoder's second-level tables hold, so that file must fall to the one-wave decoder; the 13- and 16-bit

@@ -67,6 +67,16 @@ for which in (0, 1):
 full = [0] * 16
 full[7] = 255                       # 255 codes of length 8 leave the all-ones code free: a legal table
 assert check([rewrite_dht(small, rng, full, 0)], 8, 8)[0] == 0
+# crafted scan scripts (progressive, and sequential files in several scans): planned, and their mutations survive the parser
+crafted = [(d, w, h) for _, d, w, h in jpeg_craft.progressive_cases()[:5] + jpeg_craft.multiscan_sequential_cases()]
+for data, w, h in crafted:
+    st, total = check([data], w, h)
+    assert st == 0 and total > len(data) // 2, (st, total)
+rng = np.random.Generator(np.random.PCG64(99))
+for it in range(300):
+    data, w, h = crafted[int(rng.integers(len(crafted)))]
+    st, _ = check([mutate(data, rng)], w, h)
+    assert st in (0, 1, 4), st
 rng = np.random.Generator(np.random.PCG64(20261004))
 names = sorted(files)
 for it in range(2000):

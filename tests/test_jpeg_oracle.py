@@ -168,3 +168,19 @@ def test_crafted_progressive_scripts_against_pillow(oracle):
         want = np.asarray(im.convert("L") if im.mode != "L" else im)
         assert want.shape == (h, w) and want.std() > 3, name
         np.testing.assert_array_equal(oracle.jpeg_decode_gray(data), want, err_msg=name)
+
+
+def test_sequential_files_in_several_scans_against_pillow(oracle):
+    """SOF0 files whose components come in several scans (cjpeg -scans; tests/jpeg_craft.py writes them): luminance in a
+    scan of its own, before or after the chroma scans, or interleaved with one chroma component, with restart intervals."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    import jpeg_craft as jc
+    cases = jc.multiscan_sequential_cases()
+    assert len(cases) == 4
+    for name, data, w, h in cases:
+        im = PIL.open(io.BytesIO(data))
+        im.draft("L", im.size)
+        want = np.asarray(im.convert("L") if im.mode != "L" else im)
+        assert want.shape == (h, w) and want.std() > 3, name
+        np.testing.assert_array_equal(oracle.jpeg_decode_gray(data), want, err_msg=name)

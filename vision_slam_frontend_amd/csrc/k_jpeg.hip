@@ -24,8 +24,9 @@
 // (T.81 Annex G as libjpeg's jdphuff.c decodes it), and the IDCT kernel of the parallel decoder finishes the job.
 //
 // Checked bit for bit against JPEG files decoded by libjpeg-turbo (tests/golden/jpeg, tests/test_gpu_jpeg.py).
-// Arithmetic / 12-bit / lossless files, sequential files in several scans and progressive files whose scans stop short of
-// full precision are refused (VSF_ERR_UNSUPPORTED).
+// Sequential files whose components come in several scans take that kernel too (a scan then decodes a block whole).
+// Arithmetic / 12-bit / lossless files and progressive files whose scans stop short of full precision are refused
+// (VSF_ERR_UNSUPPORTED).
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
 // frame's interleaved MCUs, natural order inside a block: what jpeg_idct_kernel reads -- and that kernel turns them into
 // pixels afterwards.  The bit parsing is WAVE-UNIFORM as in the one-wave sequential decoder above (state in SGPRs, scalar
 // loads); the 64 lanes are the 64 coefficients of the block at hand, lane k owning zigzag position k:
+//   sequential      (a SOF0 / SOF1 file whose components come in several scans: Ss = 0, Se = 63) a block whole, as below.
 //   DC first        the difference is decoded as in the sequential process; lane 0 stores prediction << Al.
 //   DC refinement   one raw bit per block; a set bit goes into the coefficient with a fire-and-forget atomic OR.
 //   AC first        run / size symbols place values << Al at zigzag positions: `lane == k` keeps each in its lane's
@@ -426,7 +428,6 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
       br.drop(n);
       return v;
     };
-    auto decode = [&](int, const DevHuffLite* t) -> int { return br.decode(t); };  // (after br.fill())
     const int p1 = 1 << Al, m1 = -(1 << Al);
     auto below = [](int n) -> uint64_t { return n >= 64 ? ~0ull : (1ull << n) - 1ull; };  // positions 0 .. n - 1
     const uint64_t band = below(Se + 1) & ~below(Ss);
@@ -443,10 +444,36 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
     if (Ss == 0) {
       // ---- DC scans ----
       const DevHuffLite *t0 = huffs + sc.huff[0], *t1 = huffs + sc.huff[ns > 1 ? 1 : 0], *t2 = huffs + sc.huff[ns > 2 ? 2 : 0];
+      const DevHuffLite *a0 = huffs + sc.huff_ac[0], *a1 = huffs + sc.huff_ac[ns > 1 ? 1 : 0], *a2 = huffs + sc.huff_ac[ns > 2 ? 2 : 0];
       auto dc_block = [&](int slot, const DevHuffLite* t, int& pred, int16_t* blk) {  // blk: a luminance block, or null
-        if (Ah == 0) {
+        if (Se == 63) {
+          // a scan of a SEQUENTIAL file whose components come in several scans: the whole block, F.2.2.1 + F.2.2.2
+          const DevHuffLite* ta = slot == 0 ? a0 : (slot == 1 ? a1 : a2);
           br.fill();
-          const int s = decode(slot, t);
+          const int s = br.decode(t);
+          br.fill();
+          pred += br.receive_extend(s);
+          int mine = lane == 0 ? pred : 0;
+          for (int k = 1; k < 64;) {
+            br.fill();
+            const int rs = br.decode(ta);
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+              if (r != 15) break;
+              k += 16;
+              continue;
+            }
+            k += r;
+            br.fill();
+            const int v = br.receive_extend(sz);
+            if (k > 63) break;  // corrupt
+            if (lane == k) mine = v;
+            k++;
+          }
+          if (blk && mine != 0) blk[nat] = (int16_t)mine;
+        } else if (Ah == 0) {
+          br.fill();
+          const int s = br.decode(t);
           br.fill();
           pred += br.receive_extend(s);
           if (blk && lane == 0) blk[0] = (int16_t)(pred * p1);
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
             int mine = 0;
             for (int k = Ss; k <= Se; k++) {
               br.fill();
-              const int rs = decode(0, t);
+              const int rs = br.decode(t);
               const int r = rs >> 4, sz = rs & 15;
               if (sz) {
                 k += r;
@@ -565,7 +592,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
           if (eobrun == 0) {
             while (k <= Se) {
               br.fill();
-              const int rs = decode(0, t);
+              const int rs = br.decode(t);
               const int r = rs >> 4, sz = rs & 15;
               int sign = 0;
               if (sz) {

@@ -129,6 +129,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
   HostHuff dc[4], ac[4];
   int ncomp = 0, cid[3], ch[3], cv[3], ctq[3], W = 0, H = 0, restart_interval = 0;
   bool have_sof = false, progressive = false, yq_latched = false;
+  bool multiscan = false;  // a sequential frame whose components come in several scans: its scans are listed like progressive ones
   uint16_t yq[64];
   int cbits[64];  // progressive: precision still missing per luminance coefficient (-1: nothing received yet)
   for (int& b : cbits) b = -1;
@@ -142,7 +143,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
     if (pos >= nbytes) return VSF_ERR_INVALID_ARG;
     const int m = data[pos++];
     if (m == 0xD9) {
-      if (progressive) break;
+      if (progressive || multiscan) break;
       return VSF_ERR_INVALID_ARG;
     }
     if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
@@ -151,6 +152,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
     if (len < 2 || pos + len > nbytes) return VSF_ERR_INVALID_ARG;
     const uint8_t* s = data + pos + 2;
     const size_t n = len - 2;
+    if (m == 0xDA && have_sof && !progressive && n >= 1 && s[0] != ncomp) multiscan = true;
     if (m == 0xDB) {
       for (size_t i = 0; i < n;) {
         const int pq = s[i] >> 4, tq = s[i] & 15;
@@ -197,7 +199,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
     } else if (m == 0xDD) {
       if (n < 2) return VSF_ERR_INVALID_ARG;
       restart_interval = (s[0] << 8) | s[1];
-    } else if (m == 0xDA && progressive) {
+    } else if (m == 0xDA && (progressive || multiscan)) {
       if (!have_sof || n < 1) return VSF_ERR_INVALID_ARG;
       const int ns = s[0];
       if (ns < 1 || ns > ncomp || n < (size_t)(4 + 2 * ns)) return VSF_ERR_INVALID_ARG;
@@ -217,9 +219,12 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         has_luma |= ci == 0;
       }
       const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
-      // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
-      if (Ss == 0 ? Se != 0 : (ns != 1 || Se < Ss || Se > 63)) return VSF_ERR_INVALID_ARG;
-      if ((Ah != 0 && Al != Ah - 1) || Al > 13) return VSF_ERR_INVALID_ARG;
+      if (multiscan) {  // a sequential scan: the whole band at full precision
+        if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return VSF_ERR_INVALID_ARG;
+      } else {  // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
+        if (Ss == 0 ? Se != 0 : (ns != 1 || Se < Ss || Se > 63)) return VSF_ERR_INVALID_ARG;
+        if ((Ah != 0 && Al != Ah - 1) || Al > 13) return VSF_ERR_INVALID_ARG;
+      }
       const size_t begin = pos + len, end = ecs_end(data, begin, nbytes);
       if (has_luma) {
         for (int k = Ss; k <= Se; k++) {
@@ -240,16 +245,21 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         sc.Se = (uint8_t)Se;
         sc.Ah = (uint8_t)Ah;
         sc.Al = (uint8_t)Al;
+        auto table_index = [&](const HostHuff& h) -> int {  // in prog->huffs (a table is listed once per file)
+          if (!h.present) return -1;
+          for (size_t i = 0; i < prog->huffs.size(); i++)
+            if (std::memcmp(prog->huffs[i].bits, h.bits, 17) == 0 && std::memcmp(prog->huffs[i].vals, h.vals, 256) == 0) return (int)i;
+          prog->huffs.push_back(h);
+          return (int)prog->huffs.size() - 1;
+        };
         for (int c = 0; c < ns; c++) {
-          sc.huff[c] = 0;
+          sc.huff[c] = sc.huff_ac[c] = 0;
           if (Ss == 0 && Ah != 0) continue;  // DC refinement: raw bits
-          const HostHuff& h = Ss == 0 ? dc[td[c]] : ac[ta[c]];
-          if (!h.present) return VSF_ERR_INVALID_ARG;
-          size_t found = prog->huffs.size();
-          for (size_t i = 0; i < prog->huffs.size() && found == prog->huffs.size(); i++)
-            if (std::memcmp(prog->huffs[i].bits, h.bits, 17) == 0 && std::memcmp(prog->huffs[i].vals, h.vals, 256) == 0) found = i;
-          if (found == prog->huffs.size()) prog->huffs.push_back(h);
-          sc.huff[c] = (uint32_t)found;
+          const int first = table_index(Ss == 0 ? dc[td[c]] : ac[ta[c]]);
+          const int second = multiscan ? table_index(ac[ta[c]]) : 0;
+          if (first < 0 || second < 0) return VSF_ERR_INVALID_ARG;
+          sc.huff[c] = (uint32_t)first;
+          sc.huff_ac[c] = (uint32_t)second;
         }
         if (prog->scans.size() >= 1024) return VSF_ERR_INVALID_ARG;  // (64 coefficients x 14 bits bound an orderly file far below)
         prog->scans.push_back(sc);
@@ -306,7 +316,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
     }
     pos += len;
   }
-  if (!progressive || !have_sof || prog->scans.empty() || !yq_latched) return VSF_ERR_INVALID_ARG;
+  if (!(progressive || multiscan) || !have_sof || prog->scans.empty() || !yq_latched) return VSF_ERR_INVALID_ARG;
   for (int k = 0; k < 64; k++)
     if (cbits[k] != 0) return VSF_ERR_UNSUPPORTED;  // the scans stop short of full precision
   {
@@ -368,7 +378,10 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
         std::memcpy(prog_huff.back().vals, h.vals, 256);
       }
       for (DevScan sc : prog.scans) {
-        for (int c = 0; c < sc.ncomp; c++) sc.huff[c] += huff0;
+        for (int c = 0; c < sc.ncomp; c++) {
+          sc.huff[c] += huff0;
+          sc.huff_ac[c] += huff0;
+        }
         scans.push_back(sc);
       }
       if (prog_huff.size() * sizeof(DevHuffLite) > 0x40000000u) return VSF_ERR_INVALID_ARG;

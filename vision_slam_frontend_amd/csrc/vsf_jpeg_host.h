@@ -57,8 +57,9 @@ struct DevHuffLite {             // what the one-wave decoders read of a table (
 };
 static_assert(sizeof(DevHuffSrc) == 276 && sizeof(DevHuffLite) == 1024 + 72 + 68 + 256, "progressive table layouts");
 
-// One scan of a progressive file (T.81 Annex G) as the device walks it.  Only scans with the luminance component are
-// listed: scans of chroma alone never touch what a gray read returns.
+// One scan of a progressive file (T.81 Annex G) -- or of a sequential file whose components come in several scans: then
+// Ss = 0, Se = 63 and a block is decoded whole (F.2.2) -- as the device walks it.  Only scans with the luminance component
+// are listed: scans of chroma alone never touch what a gray read returns.
 struct DevScan {
   uint32_t off, len;             // its entropy-coded segment, relative to the image's stream_off
   int32_t restart_interval;      // as the last DRI in front of the scan set it
@@ -66,8 +67,10 @@ struct DevScan {
   uint8_t comp[3];               // frame component (0 = luminance) of each scan component
   uint32_t huff[3];              // each scan component's Huffman table (DC scans: its DC table, AC scans: its AC table) in the
                                  // upload's list of progressive tables; unused in DC refinement scans
+  uint32_t huff_ac[3];           // sequential scans (Ss = 0, Se = 63): the AC tables, huff[] holding the DC tables
+  uint32_t pad_;
 };
-static_assert(sizeof(DevScan) == 32, "DevScan layout");
+static_assert(sizeof(DevScan) == 48, "DevScan layout");
 
 constexpr int kParThreads = 256;  // threads (= segments) of the parallel decoder per image
 constexpr int kOverlap = 8;       // rows every segment's column carries past its end: the first rows of the next segment
