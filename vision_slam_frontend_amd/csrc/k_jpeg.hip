@@ -45,6 +45,20 @@ __constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+// Everything the entropy decoders READ -- stream words, Huffman tables, image and scan descriptors -- was written before the
+// kernel started and never changes under it.  Read through the CONSTANT address space, a wave-uniform address is fetched
+// by a scalar load whatever else the kernel does; through ordinary global pointers a kernel that also fences or uses
+// atomics (the progressive one) gets vector loads + v_readfirstlane for the same reads.  (What DOES cost a factor is
+// reader state that ends up in scratch memory -- a closure indexed at run time, a reference picked by a run-time select:
+// private loads count as different per lane, and the whole bit walk then runs on the vector unit under exec masks.  The
+// progressive kernel below is written to avoid that: 23 VGPRs, no scratch.)
+template <class T>
+using cptr = const __attribute__((address_space(4))) T*;
+template <class T>
+__device__ __forceinline__ cptr<T> in_constant(const T* p) {
+  return (cptr<T>)(uintptr_t)p;
+}
+
 // ---- lane 0's view of the entropy-coded segment ----
 // ---- the entropy decoder's view of the segment.  Everything in here is WAVE-UNIFORM: all 64 lanes run the same decode
 // with the same values, so the compiler keeps the state in SGPRs, the bit arithmetic on the scalar ALU (one cycle per
@@ -57,11 +71,11 @@ struct BitReader {
   uint64_t acc;           // the next `n` bits of the de-stuffed stream sit in the low n bits, oldest on top
   int n;
   bool marker;            // a marker has been met: zero bits are fed from here on (until restart())
-  __device__ __forceinline__ uint32_t at(uint32_t p) const { return (words[p >> 2] >> (8u * (p & 3u))) & 255u; }
+  __device__ __forceinline__ uint32_t at(uint32_t p) const { return (in_constant(words)[p >> 2] >> (8u * (p & 3u))) & 255u; }
   __device__ __forceinline__ void fill() {  // >= 33 bits available afterwards (a code + its extra bits need <= 16 + 15)
     if (n <= 32 && !marker && pos + 4u <= len) {
       // four raw bytes at once unless one of them is 0xFF (stuffing or a marker: the byte-wise path sorts it out)
-      const uint64_t two = (uint64_t)words[pos >> 2] | ((uint64_t)words[(pos >> 2) + 1] << 32);
+      const uint64_t two = (uint64_t)in_constant(words)[pos >> 2] | ((uint64_t)in_constant(words)[(pos >> 2) + 1] << 32);
       const uint32_t v = (uint32_t)(two >> (8u * (pos & 3u)));
       const uint32_t nv = ~v;
       if ((((nv - 0x01010101u) & ~nv) & 0x80808080u) == 0u) {  // no byte of v is 0xFF
@@ -98,6 +112,19 @@ struct BitReader {
   }
   __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (n - k)) & ((1u << k) - 1u); }
   __device__ __forceinline__ void drop(int k) { n -= k; }
+  __device__ __forceinline__ int get_bit() {  // one raw bit
+    fill();
+    const int b = (int)peek(1);
+    drop(1);
+    return b;
+  }
+  __device__ __forceinline__ int receive(int k) {  // k <= 16 raw bits
+    if (k == 0) return 0;
+    fill();
+    const int v = (int)peek(k);
+    drop(k);
+    return v;
+  }
   __device__ __forceinline__ int receive_extend(int s) {  // T.81 F.2.2.1 RECEIVE + EXTEND
     if (s == 0) return 0;
     const int v = (int)peek(s);
@@ -107,7 +134,7 @@ struct BitReader {
   template <class Table>
   __device__ __forceinline__ int decode(const Table* h) {
     const uint32_t p = peek(kLookBits);
-    return finish(h, (reinterpret_cast<const uint32_t*>(h->look)[p >> 1] >> (16u * (p & 1u))) & 0xFFFFu);
+    return finish(h, (in_constant(reinterpret_cast<const uint32_t*>(h->look))[p >> 1] >> (16u * (p & 1u))) & 0xFFFFu);
   }
   // the rest of a decode once the lookahead entry `e` of the next 9 bits is at hand
   template <class Table>
@@ -118,7 +145,7 @@ struct BitReader {
     }
     int l = kLookBits + 1;
     int32_t code = (int32_t)peek(l);
-    while (l <= 16 && code > h->maxcode[l]) {
+    while (l <= 16 && code > in_constant(h->maxcode)[l]) {
       l++;
       code = (int32_t)peek(l <= 16 ? l : 16);
     }
@@ -127,10 +154,10 @@ struct BitReader {
       return 0;
     }
     drop(l);
-    const uint32_t vi = (uint32_t)(h->valoff[l] + code) & 255u;
-    return (int)((reinterpret_cast<const uint32_t*>(h->vals)[vi >> 2] >> (8u * (vi & 3u))) & 255u);
+    const uint32_t vi = (uint32_t)(in_constant(h->valoff)[l] + code) & 255u;
+    return (int)((in_constant(reinterpret_cast<const uint32_t*>(h->vals))[vi >> 2] >> (8u * (vi & 3u))) & 255u);
   }
-  __device__ bool restart() {  // drop the remaining bits, step over RSTn
+  __device__ __forceinline__ bool restart() {  // drop the remaining bits, step over RSTn
     // (fill() never pulls bytes from beyond a marker, so `pos` is at the marker when the interval's data is used up)
     acc = 0;
     n = 0;
@@ -398,8 +425,8 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
                                                         size_t coef_stride, int slot0, int width, int height,
                                                         int32_t* __restrict__ status) {
   const int lane = threadIdx.x;
-  const uint32_t image = index[blockIdx.x];
-  const DevImage& im = images[image];
+  const uint32_t image = in_constant(index)[blockIdx.x];
+  const auto& im = *in_constant(images + image);
   int16_t* coef = coef_all + (size_t)(slot0 + blockIdx.x) * (coef_stride / sizeof(int16_t));
   const int h0 = im.h[0], v0 = im.v[0], lum = h0 * v0, mcus_x = im.mcus_x;
   const int nlb = mcus_x * im.mcus_y * lum;
@@ -411,25 +438,12 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
   bool broken = false;
   for (int si = 0; si < im.n_scans && !broken; si++) {
     __threadfence();
-    const DevScan& sc = scans[im.first_scan + si];
+    const auto& sc = *in_constant(scans + (im.first_scan + si));
     const int Ss = sc.Ss, Se = sc.Se, Ah = sc.Ah, Al = sc.Al, ns = sc.ncomp, restart_interval = sc.restart_interval;
     const uint32_t o = im.stream_off + sc.off;
     BitReader br{reinterpret_cast<const uint32_t*>(stream + (o & ~3u)), o & 3u, (o & 3u) + sc.len, 0ull, 0, false};
-    auto get_bit = [&]() -> int {
-      br.fill();
-      const int b = (int)br.peek(1);
-      br.drop(1);
-      return b;
-    };
-    auto receive = [&](int n) -> int {  // n <= 15 raw bits
-      if (n == 0) return 0;
-      br.fill();
-      const int v = (int)br.peek(n);
-      br.drop(n);
-      return v;
-    };
     const int p1 = 1 << Al, m1 = -(1 << Al);
-    auto below = [](int n) -> uint64_t { return n >= 64 ? ~0ull : (1ull << n) - 1ull; };  // positions 0 .. n - 1
+    auto below = [](int n) __attribute__((always_inline)) -> uint64_t { return n >= 64 ? ~0ull : (1ull << n) - 1ull; };  // positions 0 .. n - 1
     const uint64_t band = below(Se + 1) & ~below(Ss);
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int eobrun = 0, until_restart = restart_interval;
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
     // order over ceil(W / 8) x ceil(H / 8) (T.81 A.2.2; the luminance is sampled at the full rate)
     const bool interleaved = ns > 1;
     const int units_x = interleaved ? mcus_x : (width + 7) >> 3, units_y = interleaved ? im.mcus_y : (height + 7) >> 3;
-    auto block_of = [&](int by, int bx) -> int {  // a luminance block's place in the coefficient buffer
+    auto block_of = [&](int by, int bx) __attribute__((always_inline)) -> int {  // a luminance block's place in the coefficient buffer
       const int my = by / v0, mx = bx / h0;
       return (my * mcus_x + mx) * lum + (by - my * v0) * h0 + (bx - mx * h0);
     };
@@ -445,10 +459,11 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
       // ---- DC scans ----
       const DevHuffLite *t0 = huffs + sc.huff[0], *t1 = huffs + sc.huff[ns > 1 ? 1 : 0], *t2 = huffs + sc.huff[ns > 2 ? 2 : 0];
       const DevHuffLite *a0 = huffs + sc.huff_ac[0], *a1 = huffs + sc.huff_ac[ns > 1 ? 1 : 0], *a2 = huffs + sc.huff_ac[ns > 2 ? 2 : 0];
-      auto dc_block = [&](int slot, const DevHuffLite* t, int& pred, int16_t* blk) {  // blk: a luminance block, or null
+      // (the tables are ARGUMENTS: picked from captured references by a run-time index they would pin the closure, and with
+      // it the whole reader state, in scratch memory -- the bit walk then runs on the vector unit under exec masks)
+      auto dc_block = [&](const DevHuffLite* t, const DevHuffLite* ta, int& pred, int16_t* blk) __attribute__((always_inline)) {  // blk: a luminance block, or null
         if (Se == 63) {
           // a scan of a SEQUENTIAL file whose components come in several scans: the whole block, F.2.2.1 + F.2.2.2
-          const DevHuffLite* ta = slot == 0 ? a0 : (slot == 1 ? a1 : a2);
           br.fill();
           const int s = br.decode(t);
           br.fill();
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
           br.fill();
           pred += br.receive_extend(s);
           if (blk && lane == 0) blk[0] = (int16_t)(pred * p1);
-        } else if (get_bit()) {
+        } else if (br.get_bit()) {
           if (blk && lane == 0) atomicOr(reinterpret_cast<unsigned int*>(blk), (unsigned int)p1);  // coefficient 0: low half
         }
       };
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
         const int nblocks = units_x * units_y;
         for (int b0 = 0; b0 < nblocks; b0 += 16) {
           const int cnt = nblocks - b0 < 16 ? nblocks - b0 : 16;
-          const uint32_t got = (uint32_t)receive(cnt);
+          const uint32_t got = (uint32_t)br.receive(cnt);
           if (lane < cnt && ((got >> (cnt - 1 - lane)) & 1u)) {
             const int b = b0 + lane, by = b / units_x;
             atomicOr(reinterpret_cast<unsigned int*>(coef + (size_t)block_of(by, b - by * units_x) * 64), (unsigned int)p1);
@@ -504,14 +519,18 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
               until_restart = restart_interval;
             }
             if (!interleaved) {
-              dc_block(0, t0, pred0, coef + (size_t)block_of(uy, ux) * 64);
+              dc_block(t0, a0, pred0, coef + (size_t)block_of(uy, ux) * 64);
             } else {
               for (int c = 0; c < ns; c++) {
                 const int ci = sc.comp[c], hh = im.h[ci], vv = im.v[ci];
                 const DevHuffLite* t = c == 0 ? t0 : (c == 1 ? t1 : t2);
-                int& pred = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-                for (int b = 0; b < hh * vv; b++)
-                  dc_block(c, t, pred, ci == 0 ? coef + ((size_t)(uy * mcus_x + ux) * lum + b) * 64 : nullptr);
+                const DevHuffLite* ta = c == 0 ? a0 : (c == 1 ? a1 : a2);
+                int pred = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);  // (by value: a reference picked at run time would
+                for (int b = 0; b < hh * vv; b++)                      //  put the three predictions into scratch memory)
+                  dc_block(t, ta, pred, ci == 0 ? coef + ((size_t)(uy * mcus_x + ux) * lum + b) * 64 : nullptr);
+                pred0 = c == 0 ? pred : pred0;
+                pred1 = c == 1 ? pred : pred1;
+                pred2 = c == 2 ? pred : pred2;
               }
             }
             if (restart_interval) until_restart--;
@@ -563,7 +582,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
                 k += 15;
               } else {
                 eobrun = 1 << r;
-                if (r) eobrun += receive(r);
+                if (r) eobrun += br.receive(r);
                 eobrun--;
                 break;
               }
@@ -578,12 +597,12 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
           // picks its own by its rank among them.
           const uint64_t nz = __ballot(c != 0) & band;
           int my_corr = 0, my_new = 0;
-          auto corrections = [&](uint64_t P) {
+          auto corrections = [&](uint64_t P) __attribute__((always_inline)) {
             while (P) {
               const int lo = __builtin_ctzll(P);
               const uint64_t Wn = P & (0xFFFFull << lo);
               const int cnt = __builtin_popcountll(Wn);
-              const uint32_t got = (uint32_t)receive(cnt);
+              const uint32_t got = (uint32_t)br.receive(cnt);
               if ((Wn >> lane) & 1ull) my_corr = (int)(got >> (cnt - 1 - __builtin_popcountll(Wn & below(lane)))) & 1;
               P &= ~Wn;
             }
@@ -596,10 +615,10 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
               const int r = rs >> 4, sz = rs & 15;
               int sign = 0;
               if (sz) {
-                sign = get_bit() ? 1 : -1;  // (the size must be 1; libjpeg warns and carries on the same way)
+                sign = br.get_bit() ? 1 : -1;  // (the size must be 1; libjpeg warns and carries on the same way)
               } else if (r != 15) {
                 eobrun = 1 << r;
-                if (r) eobrun += receive(r);
+                if (r) eobrun += br.receive(r);
                 break;
               }
               const uint64_t ahead = band & ~below(k);
