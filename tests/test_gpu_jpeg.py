@@ -282,6 +282,13 @@ def test_corrupted_batches_return_and_never_fault():
         b = io.BytesIO()
         Image.fromarray(rgb, "RGB").save(b, "JPEG", **kw)
         base.append(b.getvalue())
+    import jpeg_craft as jc
+    crng = np.random.default_rng(3)
+    comp = lambda h, v, by, bx: (h, v, crng.integers(1, 5, 64), jc.random_coefficients(crng, by, bx))
+    c420 = [comp(2, 2, 16, 20), comp(1, 1, 8, 10), comp(1, 1, 8, 10)]
+    base.append(jc.write_multiscan_sequential_jpeg(W, H, c420, [(1, 2), (0,)], restart_interval=5))  # sequential, several scans
+    base.append(jc.write_progressive_jpeg(W, H, c420, [((0, 1, 2), 0, 0, 0, 1), ((0,), 1, 63, 0, 0), ((0,), 0, 0, 1, 0),
+                                                       ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)]))
     rng = np.random.Generator(np.random.PCG64(20261004))
     dev = torch.device("cuda", 0)
     d = torch.zeros((8, H, W), dtype=torch.uint8, device=dev)
