@@ -234,6 +234,192 @@ class JpegIngest:
         self.consumed[self.current].record(self.consumer)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# `python3 bench.py --gpus N` WITHOUT a launcher: the parent starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------------
+
+STAGE_ENV = "VSF_BENCH_STAGE_FILE"  # a rank writes the stage it has reached into this file (the parent's watchdog reads it)
+
+
+def report_stage(name: str) -> None:
+    """One line `<unix time> <stage>` into the rank's stage file, when a launching parent asked for one."""
+    path = os.environ.get(STAGE_ENV)
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write("%.3f %s\n" % (time.time(), name))
+        except OSError:
+            pass
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv, *, child_cmd=None, deadline_s: float = 900.0, stall_s: float = 420.0,
+                 grace_s: float = 20.0, extra_env=None, out=sys.stdout, err=sys.stderr, result=None) -> int:
+    """Starts `n` ranks of this script as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT in their environment: what torch.distributed.run would set), relays rank 0's standard output (the ONE JSON
+    line) and every rank's standard error, and returns the worst exit code.  This process never imports torch and never
+    touches a GPU, and nothing is exec'ed over a process that has.
+
+    Watchdog: a rank that exits non-zero takes the others with it after `grace_s` (they would wait for it in a rendezvous
+    forever); no stage change on any rank for `stall_s`, or no end after `deadline_s`, kills every child (each in its own
+    session: the exact process groups started here) and returns 124 after printing the stage each rank last reported --
+    a hang inside ncclCommInitRank must not eat the caller's timeout silently."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    import threading
+
+    cmd = list(child_cmd) if child_cmd else [sys.executable, str(Path(__file__).resolve())]
+    port = _free_port()
+    stage_dir = tempfile.mkdtemp(prefix="vsf_bench_")
+    procs, pumps = [], []
+    json_lines = []
+
+    def pump(stream, sink, keep=None):
+        # rank 0's standard output carries the result; anything else a library prints there (gloo's "[Gloo] Rank 0 is
+        # connected to ..." goes to stdout) is passed on as diagnostics, so the parent's stdout is the JSON line alone
+        for line in iter(stream.readline, ""):
+            to = sink
+            if keep is not None:
+                if line.lstrip().startswith("{"):
+                    keep.append(line)
+                else:
+                    to = err
+            to.write(line)
+            to.flush()
+        stream.close()
+
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VSF_BENCH_CHILD": "1",
+                        STAGE_ENV: os.path.join(stage_dir, "rank%d" % r)})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("OMP_NUM_THREADS", "4")
+            env.update(extra_env or {})
+            p = subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                 start_new_session=True)
+            procs.append(p)
+            # rank 0's stdout is the result; the other ranks print nothing there (anything they do goes to stderr)
+            t1 = threading.Thread(target=pump, args=(p.stdout, out if r == 0 else err, json_lines if r == 0 else None), daemon=True)
+            t2 = threading.Thread(target=pump, args=(p.stderr, err), daemon=True)
+            t1.start(), t2.start()
+            pumps += [t1, t2]
+
+        def stages():
+            out_ = []
+            for r in range(n):
+                try:
+                    ts, name = open(os.path.join(stage_dir, "rank%d" % r)).read().split(None, 1)
+                    out_.append((float(ts), name.strip()))
+                except (OSError, ValueError):
+                    out_.append((0.0, "(no stage reported)"))
+            return out_
+
+        def kill_all():
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGTERM)
+                    except (ProcessLookupError, PermissionError):
+                        pass
+            t_end = time.time() + 10.0
+            for p in procs:
+                try:
+                    p.wait(max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except (ProcessLookupError, PermissionError):
+                        pass
+                    p.wait()
+
+        t_start = time.time()
+        last_change, last_seen = t_start, None
+        first_failure = None
+        verdict = None
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            now = time.time()
+            seen = stages()
+            if seen != last_seen:
+                last_seen, last_change = seen, now
+            if first_failure is None and any(c not in (None, 0) for c in codes):
+                first_failure = now
+            if first_failure is not None and now - first_failure > grace_s:
+                verdict = "rank(s) %s exited non-zero; the others were still running %.0f s later" % (
+                    [r for r, c in enumerate(codes) if c not in (None, 0)], grace_s)
+            elif now - t_start > deadline_s:
+                verdict = "no end after %.0f s" % deadline_s
+            elif now - last_change > stall_s:
+                verdict = "no rank reported a new stage for %.0f s" % stall_s
+            if verdict:
+                err.write("bench.py launcher: %s -- killing the ranks.  Last stage per rank:\n" % verdict)
+                for r, (ts, name) in enumerate(seen):
+                    err.write("  rank %d: %s%s (exit code %s)\n" % (r, name, " at +%.0f s" % (ts - t_start) if ts else "", codes[r]))
+                err.flush()
+                kill_all()
+                break
+            time.sleep(0.2)
+        for t in pumps:
+            t.join(5.0)
+        codes = [p.returncode for p in procs]
+        if result is not None:
+            result.update(codes=codes, verdict=verdict, printed_json=bool(json_lines))
+        if verdict:
+            bad = [c for c in codes if c not in (None, 0) and c > 0]
+            return max(bad) if (bad and first_failure is not None) else 124
+        if any(c != 0 for c in codes):
+            err.write("bench.py launcher: exit codes per rank %s\n" % codes)
+            return max((c if c > 0 else 128 - c) for c in codes if c != 0)
+        if not json_lines:
+            err.write("bench.py launcher: every rank returned 0 but rank 0 printed no JSON line\n")
+            return 5
+        return 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        shutil.rmtree(stage_dir, ignore_errors=True)
+
+
+def start_rank_watchdog(seconds: float):
+    """Inside a rank: if the set-up (process group, handshake, communicator) has not finished after `seconds`, say which
+    stage it hangs in and leave with code 124 instead of waiting for the caller's timeout.  Returns the cancel function."""
+    import threading
+    state = {"stage": "start"}
+
+    def fire():
+        sys.stderr.write("bench.py rank %s: set-up did not finish within %.0f s (stage: %s) -- giving up\n"
+                         % (os.environ.get("RANK", "0"), seconds, state["stage"]))
+        sys.stderr.flush()
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+
+    def mark(stage=None):
+        if stage is None:
+            t.cancel()
+        else:
+            state["stage"] = stage
+    return mark
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +459,17 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
+    ap.add_argument("--no-sustained", action="store_true",
+                    help="skip the sustained-throughput leg (>= 600 further steps, ~5 s, after the timed region)")
+    ap.add_argument("--sustained-steps", type=int, default=700)
+    ap.add_argument("--launch-deadline", type=float, default=900.0,
+                    help="bare `--gpus N` form: seconds after which the launching parent kills its ranks")
+    ap.add_argument("--launch-stall", type=float, default=420.0,
+                    help="bare `--gpus N` form: seconds without any rank reporting a new stage before the parent kills them")
+    ap.add_argument("--setup-timeout", type=float, default=360.0,
+                    help="N > 1: a rank whose process group / handshake has not come up after this many seconds exits 124")
+    ap.add_argument("--no-gloo-retry", action="store_true",
+                    help="bare `--gpus N` form: do not repeat a run whose RCCL set-up failed with the collectives on gloo")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     W = args.width or cfg["width"]
@@ -280,6 +477,38 @@ def main() -> int:
     NF = args.nfeatures or cfg["nfeatures"]
     B = args.batch or cfg["batch"]
 
+    # `python3 bench.py --gpus N` with no launcher around it (no WORLD_SIZE / RANK in the environment): this process becomes
+    # the launcher -- N fresh children, one per GPU, BEFORE torch is imported or any GPU call is made here.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        child = json.loads(os.environ["VSF_BENCH_CHILD_CMD"]) if os.environ.get("VSF_BENCH_CHILD_CMD") else None
+        res = {}
+        rc = launch_ranks(args.gpus, sys.argv[1:], child_cmd=child, deadline_s=args.launch_deadline,
+                          stall_s=args.launch_stall, result=res)
+        if (rc != 0 and not res.get("printed_json") and not args.no_gloo_retry and not os.environ.get("VSF_BENCH_ONE_GPU")
+                and os.environ.get("VSF_BENCH_BACKEND", "nccl") == "nccl"):
+            # The RCCL run did not produce a line.  One labelled second attempt with the step's exchanges on gloo (tensors
+            # take a detour through the host; each rank still on its own GPU): a measured curve with its backend named
+            # beats no record -- the line says `rccl.backend: gloo` and why.
+            sys.stderr.write("bench.py launcher: the RCCL run failed (rc %d, %s); ONE retry with the collectives on gloo\n"
+                             % (rc, res.get("verdict") or "exit codes %s" % res.get("codes")))
+            rc2 = launch_ranks(args.gpus, sys.argv[1:], child_cmd=child, deadline_s=args.launch_deadline,
+                               stall_s=args.launch_stall,
+                               extra_env={"VSF_BENCH_BACKEND": "gloo",
+                                          "VSF_BENCH_FALLBACK_REASON": "RCCL attempt: rc %d, %s" % (
+                                              rc, res.get("verdict") or "exit codes %s" % res.get("codes"))})
+            return rc2
+        return rc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    mark = start_rank_watchdog(args.setup_timeout) if world > 1 else (lambda stage=None: None)
+
+    def stage(name):
+        report_stage(name)
+        mark(name)
+
+    stage("import torch")
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
@@ -287,13 +516,11 @@ def main() -> int:
     from vision_slam_frontend_amd import capi, frontend, synth
     from vision_slam_frontend_amd import distributed as vd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         # a run that was asked for N GPUs and got another world size must not pass for an N-GPU measurement
-        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run --nnodes=1 "
-              "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`" % (args.gpus, world, args.gpus, args.gpus),
+        print("bench.py: --gpus %d but WORLD_SIZE=%d in the environment: either start it bare (`python3 bench.py --gpus %d`, "
+              "which launches its own ranks) or under `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+              "--master-addr 127.0.0.1 bench.py --gpus %d ...`" % (args.gpus, world, args.gpus, args.gpus, args.gpus),
               file=sys.stderr)
         return 2
     if not torch.cuda.is_available():
@@ -302,17 +529,26 @@ def main() -> int:
     rehearsal = bool(os.environ.get("VSF_BENCH_ONE_GPU"))  # N > 1 control flow on a one-GPU box: ranks share device 0
     if rehearsal:                                          # and talk over gloo (RCCL refuses two ranks on one GPU)
         local_rank = 0
+    # VSF_BENCH_BACKEND=gloo: every rank on its own GPU, the exchanges on gloo (the launcher's labelled fallback)
+    on_gloo = rehearsal or os.environ.get("VSF_BENCH_BACKEND", "nccl") == "gloo"
+    if not rehearsal and local_rank >= torch.cuda.device_count():
+        print("bench.py: rank %d wants GPU %d, the node shows %d" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
+        stage("init_process_group")
+        if on_gloo:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     # the ranks that really take part, seen through the backend that carries the step's collectives (part of the setup)
+    stage("handshake")
     handshake = vd.collective_handshake(dev)
+    if os.environ.get("VSF_BENCH_FALLBACK_REASON"):
+        handshake["fallback_reason"] = os.environ["VSF_BENCH_FALLBACK_REASON"]
     if sorted(handshake["ranks_seen"]) != list(range(world)):
         print("bench.py: the all-gather of rank ids returned %s in a world of %d" % (handshake["ranks_seen"], world),
               file=sys.stderr)
@@ -338,8 +574,9 @@ def main() -> int:
     # the synthetic pairs are rectified (pure horizontal disparity): l^T F r = y_r - y_l
     calib.set("fundamental", [0, 0, 0, 0, 0, -1, 0, 1, 0])
     comm = None
+    stage("communicator")
     if args.collectives == "capi":
-        if rehearsal:
+        if on_gloo:
             print("bench.py: --collectives capi needs one GPU per rank (RCCL refuses two ranks on a device)", file=sys.stderr)
             return 2
         cid = [vd.CapiComm.unique_id() if rank == 0 else None]
@@ -351,6 +588,8 @@ def main() -> int:
             print("bench.py: vsf_allgather_dev of the rank ids returned %s in a world of %d" % (seen, world), file=sys.stderr)
             return 3
         handshake = dict(handshake, backend=comm.name, ranks_seen=seen, nccl_version=str(comm.rccl_version))
+    mark()  # the process group and the communicator are up: the set-up watchdog is off
+    report_stage("frontend set-up")
     sf = vd.ShardedStereoFrontend(ctx, B, W, H, calib, window=args.window, device=dev, stream=stream,
                                   overlap=not args.no_overlap, comm=comm)
     sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
@@ -379,13 +618,16 @@ def main() -> int:
     # over the ranks by one all-reduce -- every rank issues the same collectives whatever it measured, and no library call
     # inside the timed steps measures or waits for anything.
     tune = None
+    report_stage("tune")
     if args.fast_resident is not None:
         ctx.set_fast_resident(args.fast_resident)
     elif ingest is None and not args.blur_inline:
         tune = sf.tune(d_imgs, steps=6)
+    report_stage("warm-up")
     for _ in range(args.warmup):
         run_step()
     sf.drain()
+    report_stage("timed steps")
     for c in sf.contexts():
         c.sync(allow_capacity=True)
         c.profile_enable(True)
@@ -400,6 +642,7 @@ def main() -> int:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    report_stage("after the timed steps")
     # `stages`: the stream that carries the extraction and the stereo matcher (the step's critical path);
     # `tail_stages`: the tail's own stream when it overlaps the next step (wall intervals under contention with the
     # extraction kernels, so they add up to more than the step -- reported separately, never summed into it)
@@ -434,7 +677,7 @@ def main() -> int:
     rank_ms = [1e3 * elapsed / args.steps]
     blocked_ms, overflow_ranks = 1e3 * sf.blocked_s, [0] if status == capi.VSF_ERR_CAPACITY else []
     if world > 1:
-        cdev = "cpu" if rehearsal else dev
+        cdev = "cpu" if on_gloo else dev
         mine = torch.tensor([elapsed, sf.blocked_s, float(status == capi.VSF_ERR_CAPACITY)], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -443,6 +686,48 @@ def main() -> int:
         elapsed = float(every[:, 0].max())  # the step time of the job is its slowest rank's
         blocked_ms = 1e3 * float(every[:, 1].max())
         overflow_ranks = [r for r in range(world) if every[r, 2] > 0]
+
+    # Sustained leg: the timed region above is a fraction of a second of GPU time (the contract's K steps); here >= 600
+    # further steps (~5 s) of the SAME loop show what the clocks and the power limit leave of it.  Same count on every
+    # rank (derived from the slowest rank's step time, which every rank holds), same barriers, max over ranks.
+    sustained = None
+    if not args.no_sustained:
+        report_stage("sustained leg")
+        step_s = elapsed / args.steps
+        n_sus = 600 if 600 * step_s > 5.0 else max(600, min(args.sustained_steps, int(5.0 / step_s)))
+        for _ in range(3):
+            run_step()
+        sf.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus // 100 + 1)]
+        ts0 = time.perf_counter()
+        marks[0].record(stream)
+        for i in range(n_sus):
+            run_step()
+            if (i + 1) % 100 == 0:
+                marks[(i + 1) // 100].record(stream)
+        sf.drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        sus_elapsed = time.perf_counter() - ts0
+        per100 = [marks[i].elapsed_time(marks[i + 1]) / 100.0 for i in range(len(marks) - 1)]
+        if world > 1:
+            mine = torch.tensor([sus_elapsed, per100[0], per100[-1]], dtype=torch.float64, device="cpu" if on_gloo else dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            every = torch.stack(every).cpu()
+            sus_elapsed, first100, last100 = (float(every[:, k].max()) for k in range(3))
+        else:
+            first100, last100 = per100[0], per100[-1]
+        sustained = {"steps": n_sus, "seconds": sus_elapsed, "value": world * B * n_sus / sus_elapsed,
+                     "ms_per_step": 1e3 * sus_elapsed / n_sus, "first_100_ms": first100, "last_100_ms": last100,
+                     "ms_per_step_by_100": per100,
+                     "note": "the timed loop continued for %d more steps after the headline's region (same settings, drained "
+                             "inside the clock); first/last_100_ms: ms per step over the first / last 100 steps (HIP events on "
+                             "the extraction's stream, rank 0%s)" % (n_sus, "; max over ranks for the scalars" if world > 1 else "")}
 
     counts = sf.counts.cpu().numpy()
     nm = sf.nmatches.cpu().numpy()
@@ -572,6 +857,7 @@ def main() -> int:
             # saw on that backend, every rank's own step time, the longest any rank's host waited inside a gather
             "rccl": dict(handshake, per_rank_ms_per_step={"min": min(rank_ms), "max": max(rank_ms)},
                          max_rank_blocked_in_gather_ms=blocked_ms, capacity_overflow_ranks=overflow_ranks),
+            "sustained": sustained,
             "roofline_valu": valu,
             # the whole step against the two rooflines: every stage's algorithmic bytes (and counted HBM bytes, and wave64
             # VALU instructions from the committed counter passes) over the step time of this run
@@ -592,6 +878,7 @@ def main() -> int:
         # (Frontend::set_pipelined), at 2000 features and at the reference's own 10000; driven from Python here (ctypes,
         # ~10 % slower than tools/time_frontend.cc, whose record is profiles/r03/observe_image.json).
         out["observe_image"] = None
+        report_stage("observe_image leg")
         if world == 1 and not args.no_observe and (W, H) == (640, 480):
             sys.path.insert(0, str(ROOT / "tools"))
             import time_frontend as tf
@@ -602,11 +889,13 @@ def main() -> int:
                 obs["nfeatures_%d" % nf] = {"observe_image_ms": ms, "observe_image_pipelined_fps": fps}
             obs["note"] = "640x480, frame_life 10, window full; per stereo frame through slam::Frontend (host/slam_frontend.cc)"
             out["observe_image"] = obs
+        report_stage("cpu_baseline leg")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, synth.BASE_SEED)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    report_stage("teardown")
     sf.close()
     if comm is not None:
         comm.close()

@@ -346,3 +346,65 @@ def test_eight_ranks_one_frame_per_gpu():
     assert sizes[15] == 0 and sizes[16] == 0 and sizes[17] > 20, "the same across the step boundary (rank 7 -> rank 0)"
     assert all(k[1] - k[0] == 1 for k in want_m) and len(want_m) == n - 1, "every temporal pair crosses a rank boundary"
     assert sum(len(v) for v in want_m.values()) > 200
+
+
+def test_bench_bare_form_two_ranks_on_one_gpu():
+    """`python3 bench.py --gpus 2 ...` started EXACTLY like that (no torch.distributed.run, no WORLD_SIZE in the
+    environment): the parent launches its two ranks as fresh children before it touches torch or the GPU, relays rank 0's
+    one JSON line and returns 0.  On this one-GPU box the ranks share device 0 and talk over gloo (VSF_BENCH_ONE_GPU=1);
+    the launch path is the one an 8-GPU node takes.  The sustained leg runs with a small count."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VSF_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "3", "--warmup", "1",
+                        "--width", "320", "--height", "240", "--nfeatures", "600", "--sustained-steps", "600"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl"]["ranks_seen"] == [0, 1] and out["rccl"]["world"] == 2
+    assert out["config"]["global_frames_per_step"] == 16 and out["value"] > 0
+    sus = out["sustained"]
+    assert sus["steps"] >= 600 and sus["value"] > 0 and sus["first_100_ms"] > 0 and sus["last_100_ms"] > 0
+    assert out["config"]["capacity_overflow"] is False
+
+
+def test_tune_steps_leave_no_trace():
+    """ShardedStereoFrontend.tune(steps > 0) runs real steps on the object (bench.py's set-up); afterwards the threshold
+    chain must start at 10000 again (slam_frontend.cc:353), the first step must have no temporal predecessors and rank 0's
+    bookkeeping must be empty: the payloads of the run that follows are byte-identical to a run without tune.  A batch of
+    32 images makes the tuning eligible (fewer: the library reports 0 / 0 and runs no steps)."""
+    from vision_slam_frontend_amd import capi, synth
+    from vision_slam_frontend_amd import distributed as vd
+    w, h, nf, per, window, steps = 320, 240, 600, 16, 2, 3
+    frames = synth.stereo_stream(per * steps, w, h, n_objects=300)
+    frames[5, 1] = 128  # a frame without stereo matches: the NaN threshold must land where it does without tune
+    dev = torch.device("cuda", 0)
+
+    def run(tune_steps):
+        ctx = capi.Context(capi.default_params(w, h, max_images=2 * per, nfeatures=nf))
+        sf = vd.ShardedStereoFrontend(ctx, per, w, h, _calibration(), window=window, device=dev, force_collectives=False)
+        tuned = None
+        if tune_steps:
+            other = torch.from_numpy(np.ascontiguousarray(frames[per:2 * per][::-1])).to(dev)  # NOT the run's first batch
+            tuned = sf.tune([other], samples=1, steps=tune_steps)
+            assert sf.step_idx == 0 and not sf.completed and not sf.inflight and sf.next_gather == 0
+            assert float(sf.thr_state.item()) == vd.INITIAL_STEREO_AMBIG_CONSTRAINT
+        out = []
+        for s in range(steps):
+            sf.step(torch.from_numpy(np.ascontiguousarray(frames[s * per:(s + 1) * per])).to(dev))
+            sf.synchronize()
+            pl = sf.local_payload(s).cpu().clone()
+            out.append(pl[:int(pl[12:16].view(torch.int32).item())].numpy().tobytes())
+        sf.drain()
+        assert all(c.sync() == capi.VSF_OK for c in sf.contexts())
+        sf.close()
+        ctx.close()
+        return out, tuned
+
+    plain, _ = run(0)
+    tuned_run, tuned = run(2)
+    assert tuned["timed_on"].startswith("2 whole steps"), tuned
+    assert plain == tuned_run

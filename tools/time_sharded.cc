@@ -42,6 +42,35 @@ using Clock = std::chrono::steady_clock;
     }                                                                                              \
   } while (0)
 
+// Watchdog: every rank notes the stage it has reached; when NO rank reaches a new one for VSF_SHARDED_STALL_S seconds
+// (default 300) the process prints each rank's stage and leaves with 124 -- a rank stuck inside ncclCommInitRank or a
+// collective must not eat the caller's timeout silently (the same rule as bench.py's launcher).
+static std::atomic<const char*> g_stage[64];
+static std::atomic<long> g_stage_gen(0);
+static std::atomic<bool> g_finished(false);
+static void at_stage(int rank, const char* name) {
+  if (rank >= 0 && rank < 64) g_stage[rank].store(name);
+  g_stage_gen.fetch_add(1);
+}
+static void watchdog_main(int world, double stall_s) {
+  long seen = -1;
+  Clock::time_point last = Clock::now();
+  while (!g_finished.load()) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(200));
+    const long g = g_stage_gen.load();
+    if (g != seen) seen = g, last = Clock::now();
+    if (std::chrono::duration<double>(Clock::now() - last).count() > stall_s) {
+      std::fprintf(stderr, "time_sharded: no rank reached a new stage for %.0f s -- giving up.  Last stage per rank:\n", stall_s);
+      for (int r = 0; r < world && r < 64; r++) {
+        const char* st = g_stage[r].load();
+        std::fprintf(stderr, "  rank %d: %s\n", r, st ? st : "(not started)");
+      }
+      std::fflush(stderr);
+      std::_Exit(124);
+    }
+  }
+}
+
 struct Barrier {  // (C++17: no std::barrier)
   std::mutex m;
   std::condition_variable cv;
@@ -84,6 +113,7 @@ static T* dmalloc(size_t n) {
 
 static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
   const int B = S->B, Wn = S->window, world = S->world, W = S->W, H = S->H;
+  at_stage(rank, "hipSetDevice / vsf_create");
   CK(hipSetDevice(rank));
   // Two contexts, two streams (as ShardedStereoFrontend): the extraction of step s + 1 on the main stream beside the tail
   // of step s -- RemoveAmbigStereo, temporal matches, 3-D points, payload, every exchange -- on a high-priority stream.
@@ -105,12 +135,14 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
   CK(vsf_set_stream(tctx, s_tail));
   const size_t K = (size_t)p.max_keypoints;
   vsf_comm* comm = nullptr;
+  at_stage(rank, "vsf_comm_create (ncclCommInitRank)");
   CK(vsf_comm_create(tctx, S->id, rank, world, &comm));
   vsf_calibration calib;
   vsfh_default_calibration(&calib);
   const float F[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};  // rectified synthetic pairs: l^T F r = y_r - y_l
   std::memcpy(calib.fundamental, F, sizeof(F));
 
+  at_stage(rank, "device buffers and uploads");
   // ---- device buffers (the layout of ShardedStereoFrontend) ----
   const size_t img_bytes = (size_t)W * H;
   const int blocks = S->nframes / (world * B);  // steps' worth of input; resident in HBM, taken in turn
@@ -195,6 +227,7 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
   CK(vsf_set_pipeline(ctx, 1));  // every step's input is complete in HBM: the next step's pyramid beside this step's later stages
 
   // ---- handshake: the ranks that really take part, through the backend that carries the step's exchanges ----
+  at_stage(rank, "handshake (first vsf_allgather_dev)");
   {
     const int32_t me = rank;
     CK(hipMemcpy(d_rank_ids + world, &me, 4, hipMemcpyHostToDevice));
@@ -207,6 +240,7 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
     }
   }
   // (which batches have two FAST forms at all is the library's knowledge: its tune call reports 0 / 0 for one that has not)
+  at_stage(rank, "tune");
   bool fast_eligible = false;
   int fast_form = 0;
   if (!S->keep) {
@@ -304,15 +338,20 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
     CK(vsf_set_fast_resident(ctx, fast_form));
     if (rank == 0) S->fast_form = fast_form, S->tune_ms[0] = g, S->tune_ms[1] = r;
   }
+  at_stage(rank, "warm-up steps");
   const int warm = S->keep ? 0 : 3;
   for (int k = 0; k < warm; k++) run_step(step++);
   drain();
+  at_stage(rank, "barrier before the timed steps");
   S->bar->wait();
+  at_stage(rank, "timed steps");
   const Clock::time_point t0 = Clock::now();
   for (int k = 0; k < S->steps; k++) run_step(step++);
   drain();
   S->rank_seconds[rank] = std::chrono::duration<double>(Clock::now() - t0).count();
+  at_stage(rank, "barrier after the timed steps");
   S->bar->wait();
+  at_stage(rank, "teardown");
   vsf_comm_destroy(comm);
   vsf_destroy(tctx);
   vsf_destroy(ctx);
@@ -359,9 +398,14 @@ int main(int argc, char** argv) {
   S.bar = &bar;
   S.rank_seconds.assign(S.world, 0.0);
   std::atomic<bool> failed(false);
+  const char* stall_env = std::getenv("VSF_SHARDED_STALL_S");
+  const double stall_s = stall_env && std::atof(stall_env) > 0 ? std::atof(stall_env) : 300.0;
+  std::thread dog(watchdog_main, S.world, stall_s);
   std::vector<std::thread> th;
   for (int r = 0; r < S.world; r++) th.emplace_back(rank_main, r, &S, &failed);
   for (auto& t : th) t.join();
+  g_finished.store(true);
+  dog.join();
   if (failed.load()) return 1;
   double slowest = 0;
   for (double v : S.rank_seconds) slowest = std::max(slowest, v);

@@ -500,7 +500,9 @@ class ShardedStereoFrontend:
         timed ones per form, on `d_img` (a batch, or a list of batches taken in turn as the caller's own loop will) -- because
         what the form is worth shows in the composed, pipelined step (the blur beside FAST, the next step's pyramid beside
         this step's tail), where it is twice what an extraction by itself shows; an ineligible batch (the library reports
-        0 / 0: fewer than 32 images, blur in line) runs no steps."""
+        0 / 0: fewer than 32 images, blur in line) runs no steps.  The tuning steps are real step() calls; reset() afterwards
+        puts the threshold chain, the step counter and the gather bookkeeping back, so the run that follows produces the
+        same bytes as one without tune (tests/test_gpu_sharded.py::test_tune_steps_leave_no_trace)."""
         batches = list(d_img) if isinstance(d_img, (list, tuple)) else [d_img]
         d_img = batches[0]
         raw = self.raw[0]
@@ -521,6 +523,7 @@ class ShardedStereoFrontend:
                 self.drain()
                 per_form.append(1e3 * (time.perf_counter() - t0) / steps)
             g, r = per_form
+            self.reset()  # the tuning steps must leave no trace: the caller's first step is step 0 of the stream
         mine = (g, r)
         if self.dist_on:
             g, r = self.comm.all_reduce_max([g, r], self.dev)
@@ -529,6 +532,22 @@ class ShardedStereoFrontend:
         return {"ms_grid": g, "ms_resident": r, "this_rank_ms": list(mine), "fast_resident": choice, "samples": samples,
                 "timed_on": "%d whole steps per form" % steps if (steps > 0 and extraction_ms[0] > 0.0) else "the extraction by itself",
                 "extraction_ms": list(extraction_ms), "agreed_over_ranks": self.world}
+
+    def reset(self):
+        """Back to the state of a fresh object (everything issued so far is drained first): RemoveAmbigStereo's static
+        threshold at its initial 10000 (slam_frontend.cc:353), the next step is step 0 again (no temporal predecessors, first
+        payload slot), nothing gathered, nothing in flight.  tune(steps > 0) ends with it, so set-up steps cannot shift the
+        reference sequence of the run that follows.  Every rank calls it at the same point (it issues no collective)."""
+        self.drain()
+        with torch.cuda.stream(self.tail_stream):
+            self.thr_state.fill_(INITIAL_STEREO_AMBIG_CONSTRAINT)
+            self.countsf.zero_()
+        self.tail_stream.synchronize()
+        self.step_idx = 0
+        self.next_gather = 0
+        self.inflight.clear()
+        self.completed.clear()
+        self.blocked_s = 0.0
 
     # ---- static schedule of the temporal pairs ----
     def _pair_sets(self, parity: int, first_step: bool):
