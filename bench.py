@@ -224,11 +224,14 @@ class JpegIngest:
         self.issued += 1
 
     def next_batch(self):
+        """(this step's frames, the event behind their producer): the extraction is handed the event (vsf_set_input_event)
+        -- its pipelined pyramid, which is ordered after nothing else, waits for it on the GPU -- and the next step's decode
+        is started."""
         slot = (self.issued - 1) & 1
         self.consumer.wait_event(self.ready[slot])
         self._issue(slot ^ 1)
         self.current = slot
-        return self.d_in[slot]
+        return self.d_in[slot], self.ready[slot]
 
     def release(self):
         self.consumed[self.current].record(self.consumer)
@@ -434,7 +437,8 @@ def main() -> int:
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches per step (vsf_set_lanes)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap a step's pyramid with the previous step's latency-bound stages (vsf_set_pipeline); "
-                         "default: on when the frames are resident in HBM (the call's promise: inputs complete in device memory)")
+                         "default: on (frames resident in HBM are complete before the call; the JPEG ingest hands the call an "
+                         "event behind its decode: vsf_set_input_event)")
     ap.add_argument("--pipeline", action="store_true", help="(accepted for compatibility: now the default)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run a step's tail (RemoveAmbigStereo ... payload, collectives) on the extraction's stream instead of "
@@ -595,9 +599,9 @@ def main() -> int:
     sf.keep_outputs = False  # rank 0 receives every payload; the bench does not retain them
     ctx.set_lanes(args.lanes)
     ctx.set_blur_overlap(not args.blur_inline)
-    # cross-call pipelining: legal when every step's input is complete in HBM before the call (the rotating synthetic
-    # batches are; frames arriving from the JPEG ingest stream are only ORDERED before the call, so it stays off there)
-    pipeline = not args.no_pipeline and args.ingest == "hbm"
+    # cross-call pipelining: every step's input is complete in HBM before the call (the rotating synthetic batches), or
+    # the call is handed the event behind its producer (the JPEG ingest: vsf_set_input_event)
+    pipeline = not args.no_pipeline
     ctx.set_pipeline(pipeline)
     torch.cuda.synchronize()
 
@@ -610,8 +614,9 @@ def main() -> int:
             sf.step(d_imgs[step_no[0] % len(d_imgs)])
             step_no[0] += 1
         else:
-            sf.step(ingest.next_batch())   # waits (on the GPU) for this step's decode, starts the next step's
-            ingest.release()               # the buffer may be overwritten once this step's extraction has read it
+            batch, ready = ingest.next_batch()  # starts the next step's decode
+            sf.step(batch, input_event=ready)   # waits (on the GPU) for this step's decode
+            ingest.release()                    # the buffer may be overwritten once this step's extraction has read it
 
     # Set-up, not warm-up: ONE explicit, blocking measurement of the two FAST launch forms on this rank's batch
     # (vsf_tune_fast_resident, then six whole steps per form on the rotating batches: the form's worth shows in the composed step), made common
@@ -621,7 +626,7 @@ def main() -> int:
     report_stage("tune")
     if args.fast_resident is not None:
         ctx.set_fast_resident(args.fast_resident)
-    elif ingest is None and not args.blur_inline:
+    elif not args.blur_inline:
         tune = sf.tune(d_imgs, steps=6)
     report_stage("warm-up")
     for _ in range(args.warmup):

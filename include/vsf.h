@@ -117,6 +117,16 @@ vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes);
  * into the second of two pyramid buffers while the previous call's later stages are still running; all other stages
  * and all outputs stay ordered on the context's stream as before. */
 vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
+/* Input readiness as an explicit event, for ANY producer (a decoder on another context or stream, the caller's own
+ * kernel, a copy engine; slam_frontend_main.cc:98-132 is where frames arrive): hip_event is a hipEvent_t the caller
+ * recorded behind the last operation that writes the images of the NEXT vsf_extract_batch_dev / vsf_stereo_batch_dev
+ * call.  That call -- including its pipelined pyramid, which is otherwise not ordered after anything (vsf_set_pipeline)
+ * -- waits for the event ON THE GPU; the host never does.  With it the promise of vsf_set_pipeline relaxes to "complete
+ * when the event fires".  One-shot: the call that follows consumes it (the wait captures the event's state at that
+ * moment, so the caller may record the same event again afterwards); NULL withdraws it.  The way back is ordinary
+ * stream order: whatever the caller records on the context's stream after the call fires once the call has read its
+ * inputs. */
+vsf_status vsf_set_input_event(vsf_ctx* ctx, void* hip_event);
 /* Batched entry points (>= 32 images per call) run the Gaussian blur of a call -- matrix cores and memory -- on an
  * internal stream forked behind the pyramid and joined in front of the descriptors, i.e. beside FAST and the keypoint
  * selection, which live on the vector ALU and on latency (default: on; the caller still sees ONE stream-ordered
@@ -159,6 +169,14 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);
 /* Waits for the stream and returns VSF_ERR_CAPACITY if any kernel since the last sync overflowed. */
 vsf_status vsf_sync(vsf_ctx* ctx);
+/* BLOCKING set-up call: sizes the scratch the batched *_dev calls keep inside the context (2-NN tables, residuals, the
+ * temporal pairs' matches and sort keys, Calculate3DPoints' pair lists, the pack offsets) for batches of up to n_frames
+ * stereo frames and n_pairs (past, current) pairs.  vsf_create reserves for max_images / 2 frames and as many pairs; a
+ * context that serves larger batches than its own max_images suggests (the tail context of the multi-GPU composition:
+ * max_images = 2, B frames, B x window pairs) calls this once.  A *_dev call beyond the reservation still works and
+ * still does not wait for the GPU: it takes a new allocation (the host time of a hipMalloc) and the outgrown buffer,
+ * which kernels already queued may be using, is released by the next vsf_sync / vsf_reserve / vsf_destroy. */
+vsf_status vsf_reserve(vsf_ctx* ctx, int n_frames, int n_pairs);
 
 /* Pyramid geometry the context derived (cv::ORB layer sizes / scales / per-level feature budgets). */
 vsf_status vsf_level_info(const vsf_ctx* ctx, int level, int* w, int* h, float* scale, int* nfeatures);

@@ -51,6 +51,15 @@ struct Huff {  // T.81 Annex C / F.2.2.3: code lengths -> MINCODE / MAXCODE / VA
     maxcode[17] = 0x7FFFFFFF;
     return ok;
   }
+  // jdhuff.c jpeg_make_d_derived_tbl(isDC = TRUE): a DC table's symbols are magnitude categories, 0..15; anything larger
+  // is JERR_BAD_HUFF_TABLE when a scan sets the table up for DC decoding
+  bool dc_symbols_ok() const {
+    int total = 0;
+    for (int l = 1; l <= 16; l++) total += bits[l];
+    for (int k = 0; k < total && k < 256; k++)
+      if (vals[k] > 15) return false;
+    return true;
+  }
 };
 
 struct Comp {
@@ -462,6 +471,14 @@ int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t 
         has_luma |= ci == 0;
       }
       const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      if (ns > 1) {  // jdinput.c per_scan_setup: D_MAX_BLOCKS_IN_MCU = 10 (JERR_BAD_MCU_SIZE)
+        int blocks = 0;
+        for (const ScanComp& c : sc) blocks += comps[(size_t)c.ci].h * comps[(size_t)c.ci].v;
+        if (blocks > 10) return -1;
+      }
+      if (Ss == 0 && Ah == 0)
+        for (const ScanComp& c : sc)
+          if (dc[c.td].present && !dc[c.td].dc_symbols_ok()) return -1;  // JERR_BAD_HUFF_TABLE
       if (sequential) {
         if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return -1;
       } else {  // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
@@ -599,6 +616,12 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
         if (comps[c].td > 3 || comps[c].ta > 3 || !dc[comps[c].td].present || !ac[comps[c].ta].present ||
             !qt_present[comps[c].tq])
           return -1;
+        if (!dc[comps[c].td].dc_symbols_ok()) return -1;  // JERR_BAD_HUFF_TABLE
+      }
+      if (ns > 1) {  // jdinput.c per_scan_setup: D_MAX_BLOCKS_IN_MCU = 10 (JERR_BAD_MCU_SIZE)
+        int blocks = 0;
+        for (const Comp& c : comps) blocks += c.h * c.v;
+        if (blocks > 10) return -1;
       }
       if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return -2;
       pos += len;

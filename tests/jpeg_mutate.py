@@ -47,9 +47,10 @@ def drop_last_scans(data: bytes, n: int) -> bytes:
     return data[:segs[cut][1]] + b"\xff\xd9"
 
 
-def rewrite_dht(data: bytes, rng: np.random.Generator, counts=None, which=None) -> bytes:
-    """Replaces the counts (and as many values as they call for) of one table of one DHT segment; the segment's length
-    field is recomputed, so the file stays well-formed up to the meaning of the counts themselves."""
+def rewrite_dht(data: bytes, rng: np.random.Generator, counts=None, which=None, max_value=255) -> bytes:
+    """Replaces the counts (and as many values as they call for, drawn from 0..max_value) of one table of one DHT segment;
+    the segment's length field is recomputed, so the file stays well-formed up to the meaning of the counts themselves.
+    (A DC table's values must stay <= 15 for the table to be legal: libjpeg refuses larger ones, and so does the parser.)"""
     dht = [(pos, ln) for m, pos, ln in segments(data) if m == 0xC4]
     if not dht:
         return data
@@ -72,7 +73,7 @@ def rewrite_dht(data: bytes, rng: np.random.Generator, counts=None, which=None) 
             counts[l] += c
             budget -= max(c, 1)
     total = sum(counts)
-    new_table = bytes([body[t0]]) + bytes(counts) + bytes(rng.integers(0, 256, total, dtype=np.uint8))
+    new_table = bytes([body[t0]]) + bytes(counts) + bytes(rng.integers(0, max_value + 1, total, dtype=np.uint8))
     body[t0:t0 + tl] = new_table
     seg = b"\xFF\xC4" + (len(body) + 2).to_bytes(2, "big") + bytes(body)
     return data[:pos] + seg + data[pos + ln:]

@@ -193,3 +193,80 @@ def test_residuals_dense_fundamental_both_orders(capi, batch, oracle, order):
         oracle.set_residual_order(0)
     assert g_thr[B].tobytes() == cur.tobytes()
     assert differs
+
+
+def _busy(stream, ms_wanted=400):
+    """Keeps `stream` busy for roughly ms_wanted (plain torch matmuls); returns an event recorded behind the work."""
+    a = torch.randn((4096, 4096), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        t0.record(stream)
+        for _ in range(4):
+            a @ a
+        t1.record(stream)
+    t1.synchronize()
+    per = max(t0.elapsed_time(t1) / 4, 1e-3)
+    done = torch.cuda.Event()
+    with torch.cuda.stream(stream):
+        for _ in range(int(ms_wanted / per) + 1):
+            a @ a
+        done.record(stream)
+    return done
+
+
+def test_no_dev_call_waits_for_the_gpu(capi, batch):
+    """include/vsf.h: "none of the *_dev entry points waits for the GPU".  Behind ~0.4 s of other work on the context's
+    stream every tail entry point is called with a batch size the context has NOT seen (growing past its reservation, then
+    shrinking): each call must return while that work is still running -- a call that outgrows the context's scratch takes a
+    new allocation and retires the old one, it does not synchronise -- and the results must be those of a quiet run."""
+    import time
+    _, t, B, K = batch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=NF))  # reserved for ONE frame, one pair
+    assert ctx.params.max_keypoints == K
+    ctx.set_stream(stream.cuda_stream)
+    z = lambda *shape, dtype=torch.uint8: torch.zeros(shape, dtype=dtype, device=dev)  # noqa: E731
+    kp2, desc2, counts2 = z(2 * B, K, 28), z(2 * B, K, 32), z(2 * B, dtype=torch.int32)
+    means, thr = z(B, dtype=torch.float32), z(B + 1, dtype=torch.float32)
+    feat, nfeat = z(B, K, 28), z(B, dtype=torch.int32)
+    pairs, npairs = z(B, K, 2, dtype=torch.int64), z(B, dtype=torch.int32)
+    q_set = torch.tensor([2 * f for f in range(B)], dtype=torch.int32, device=dev)
+    t_set = torch.tensor([min(2 * f + 2, 2 * B - 2) for f in range(B)], dtype=torch.int32, device=dev)
+    cap = ctx.packed_outputs_capacity(B, B)
+    payload = [z(cap) for _ in range(3)]
+    calib = __import__("vision_slam_frontend_amd.frontend", fromlist=["x"]).default_calibration().set("fundamental", F_RECT)
+    p = lambda x: x.data_ptr()  # noqa: E731
+
+    def tail(ctx, n, slot):
+        ctx.remove_ambig_stereo_batch_dev(p(t["kp"]), p(t["desc"]), p(t["m"]), p(t["nm"]), n, F_RECT, 10000.0, 0, p(means),
+                                          p(thr), p(kp2), p(desc2), p(counts2))
+        ctx.stereo_residuals_batch_dev(p(t["kp"]), p(t["m"]), p(t["nm"]), n, F_RECT, p(means))
+        ctx.feature_matches_batch_dev(p(desc2), p(counts2), K * 32, p(q_set), p(t_set), n, 0.3, p(pairs), p(npairs))
+        ctx.vision_features_batch_dev(calib, p(kp2), p(desc2), p(counts2), n, p(feat), p(nfeat), 0)
+        ctx.pack_outputs_dev(p(feat), p(nfeat), n, p(pairs), p(npairs), n, p(payload[slot]), cap)
+
+    torch.cuda.synchronize()
+    busy_done = _busy(stream)
+    host_ms = []
+    for slot, n in enumerate((2, B, 1)):  # grows past the reservation twice, then shrinks
+        t0 = time.perf_counter()
+        tail(ctx, n, slot)
+        host_ms.append(1e3 * (time.perf_counter() - t0))
+    still_running = not busy_done.query()
+    assert still_running, "the calls returned only after the stream's earlier work had finished: %s ms" % host_ms
+    assert max(host_ms) < 150, host_ms
+    assert ctx.sync() == capi.VSF_OK
+    # the same three batches on a quiet, amply reserved context give the same bytes
+    ref = capi.Context(capi.default_params(640, 480, max_images=2 * B, nfeatures=NF))
+    ref.set_stream(stream.cuda_stream)
+    got = [pl.cpu().numpy().copy() for pl in payload]
+    for slot, n in enumerate((2, B, 1)):
+        tail(ref, n, slot)
+        assert ref.sync() == capi.VSF_OK
+        want = payload[slot].cpu().numpy()
+        size = int(want[12:16].view(np.int32)[0])
+        assert size > 16 and np.array_equal(got[slot][:size], want[:size]), "batch of %d frames" % n
+    ref.close()
+    ctx.close()

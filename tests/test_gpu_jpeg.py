@@ -314,3 +314,77 @@ def test_corrupted_batches_return_and_never_fault():
     for i in range(3):
         np.testing.assert_array_equal(got[i], np.asarray(Image.open(io.BytesIO(base[i]))))
     assert outcomes.get("ok", 0) > 5 and sum(v for k, v in outcomes.items() if k != "ok") > 20
+
+
+def test_ingest_chain_pipelined_with_an_input_event(oracle):
+    """slam_frontend_main.cc:98-132 as a stream of batches with cross-call pipelining ON: every step's frames are produced by
+    ANOTHER context on ANOTHER stream (JPEG decode -> Bayer -> gray, deliberately late: ~0.1 s of other work is queued in
+    front of each decode) and handed to the extraction with nothing but an event (vsf_set_input_event) -- no host wait, no
+    stream-level wait by the caller.  The pipelined pyramid is ordered after nothing else, so without the event it would
+    read the buffer before the decode has written it.  Three steps of four stereo frames, different images each, the two
+    input buffers alternating; keypoints, descriptors and stereo matches of every frame bit-exact against the oracle's
+    DecodeImage + ORB + GetMatches chain."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    from vision_slam_frontend_amd import capi, synth
+    W, H, NFE, B, STEPS = 320, 240, 500, 4, 3
+    dev = torch.device("cuda", 0)
+    frames = synth.stereo_stream(B * STEPS, W, H, n_objects=300)
+    files = []
+    for img in frames.reshape(-1, H, W):
+        b = io.BytesIO()
+        PIL.fromarray(img, "L").save(b, "JPEG", quality=85)
+        files.append(b.getvalue())
+    s_dec, s_ext = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    dec = capi.Context(capi.default_params(W, H, max_images=2, nfeatures=NFE))
+    ext = capi.Context(capi.default_params(W, H, max_images=2 * B, nfeatures=NFE))
+    dec.set_stream(s_dec.cuda_stream)
+    ext.set_stream(s_ext.cuda_stream)
+    ext.set_pipeline(True)
+    K = ext.params.max_keypoints
+    z = lambda *shape, dtype=torch.uint8: torch.zeros(shape, dtype=dtype, device=dev)  # noqa: E731
+    d_mosaic = z(2 * B, H, W)
+    d_in = [z(B, 2, H, W) for _ in range(2)]
+    out = [dict(kp=z(2 * B, K, 28), desc=z(2 * B, K, 32), n=z(2 * B, dtype=torch.int32), m=z(B, K, 16),
+                nm=z(B, dtype=torch.int32)) for _ in range(STEPS)]
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    a = torch.randn((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    for s in range(STEPS):
+        slot = s & 1
+        with torch.cuda.stream(s_dec):
+            if s >= 2:
+                s_dec.wait_event(consumed[slot])       # the extraction of step s - 2 has read this buffer
+            for _ in range(8):
+                a @ a                                  # the decode is LATE
+            d_in[slot].zero_()                         # (what a too-early reader would see)
+        dec.jpeg_decode_gray_batch(files[2 * B * s:2 * B * (s + 1)], W, H, d_mosaic.data_ptr(), W * H, W)
+        dec.bayer_bg_to_gray_batch_dev(d_mosaic.data_ptr(), 2 * B, W, H, W * H, W, d_in[slot].data_ptr(), W * H, W)
+        ready[slot].record(s_dec)
+        ext.set_input_event(ready[slot].cuda_event)
+        o = out[s]
+        ext.stereo_batch_dev(d_in[slot].data_ptr(), B, W * H, W, o["kp"].data_ptr(), o["desc"].data_ptr(), o["n"].data_ptr(),
+                             o["m"].data_ptr(), o["nm"].data_ptr())
+        consumed[slot].record(s_ext)
+    assert ext.sync() == capi.VSF_OK and dec.sync() == capi.VSF_OK
+    for s in range(STEPS):
+        o = {k: v.cpu().numpy() for k, v in out[s].items()}
+        for f in range(B):
+            descs = []
+            for e in range(2):
+                gray = oracle.bayer_bg_to_gray(oracle.jpeg_decode_gray(files[2 * B * s + 2 * f + e]))
+                orb = oracle.Orb(nfeatures=NFE)
+                orb.run(gray)
+                rk, rd = orb.result()
+                i = 2 * f + e
+                n = int(o["n"][i])
+                assert n == len(rk) > 100, "step %d frame %d eye %d" % (s, f, e)
+                assert o["kp"][i, :n].tobytes() == rk.tobytes(), "step %d frame %d eye %d" % (s, f, e)
+                np.testing.assert_array_equal(o["desc"][i, :n], rd)
+                descs.append(rd)
+            rm = oracle.get_matches(descs[0], descs[1])
+            nm = int(o["nm"][f])
+            assert nm == len(rm) and o["m"][f, :nm].tobytes() == rm.tobytes(), "step %d frame %d matches" % (s, f)
+    ext.close()
+    dec.close()

@@ -62,11 +62,43 @@ for which in (0, 1):
         for count in (200, 255, (1 << min(length, 7)) + 1):
             counts = [0] * 16
             counts[length - 1] = count
-            st, _ = check([rewrite_dht(small, rng, counts, which)], 8, 8)
+            st, _ = check([rewrite_dht(small, rng, counts, which, max_value=15 if which == 0 else 255)], 8, 8)
             assert st == (1 if count >= (1 << length) else 0), (which, length, count, st)
 full = [0] * 16
 full[7] = 255                       # 255 codes of length 8 leave the all-ones code free: a legal table
-assert check([rewrite_dht(small, rng, full, 0)], 8, 8)[0] == 0
+assert check([rewrite_dht(small, rng, full, 0, max_value=15)], 8, 8)[0] == 0
+# round-4 advice: a DC table whose symbols exceed 15 (libjpeg: JERR_BAD_HUFF_TABLE when the scan sets it up) is refused --
+# the same counts, one value raised; the AC table may carry any byte
+def with_dc_value(data, value, which=0):
+    pos = data.find(b"\xFF\xC4")
+    assert pos > 0 and data[pos + 4] >> 4 == which
+    b = bytearray(data)
+    b[pos + 4 + 17] = value      # first symbol of the first table of the first DHT segment
+    return bytes(b)
+assert check([with_dc_value(small, 11)], 8, 8)[0] == 0
+for v in (16, 17, 64, 255):
+    assert check([with_dc_value(small, v)], 8, 8)[0] == 1, v
+for name in ("prog_gray_320x240_q85", "gray_320x240_q80", "ycc420_71x53_q75", "prog_ycc420_200x136_q75"):
+    if name in files:
+        hh, ww = expected[name].shape
+        assert check([with_dc_value(files[name], 200)], ww, hh)[0] == 1, name
+# ... and an interleaved scan of more than 10 blocks per MCU (jdinput.c per_scan_setup: JERR_BAD_MCU_SIZE): sampling factors
+# 4x2 + 2x1 + 2x1 = 12
+def with_sampling(data, hv):
+    pos = data.find(b"\xFF\xC0")
+    if pos < 0:
+        pos = data.find(b"\xFF\xC2")
+    b = bytearray(data)
+    assert b[pos + 9] == 3
+    for c, x in enumerate(hv):
+        b[pos + 11 + 3 * c] = x
+    return bytes(b)
+for name in sorted(files):
+    if name.startswith(("ycc", "prog_ycc")):
+        hh, ww = expected[name].shape
+        st, _ = check([with_sampling(files[name], (0x42, 0x21, 0x21))], ww, hh)
+        assert st == 1, (name, st)
+        break
 # crafted scan scripts (progressive, and sequential files in several scans): planned, and their mutations survive the parser
 crafted = [(d, w, h) for _, d, w, h in jpeg_craft.progressive_cases()[:5] + jpeg_craft.multiscan_sequential_cases()]
 for data, w, h in crafted:

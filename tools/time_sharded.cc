@@ -133,6 +133,7 @@ static void rank_main(int rank, Shared* S, std::atomic<bool>* failed) {
   CK(vsf_create(&pt, rank, &tctx));
   CK(vsf_set_stream(ctx, s_main));
   CK(vsf_set_stream(tctx, s_tail));
+  CK(vsf_reserve(tctx, B, std::max(B * Wn, 1)));  // the tail context serves B frames and B x window pairs (set-up, blocking)
   const size_t K = (size_t)p.max_keypoints;
   vsf_comm* comm = nullptr;
   at_stage(rank, "vsf_comm_create (ncclCommInitRank)");

@@ -36,7 +36,7 @@ EXPORTS = [
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
     "vsf_jpeg_decode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error", "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_destroy", "vsf_comm_info",
-    "vsf_allgather_dev", "vsf_gather_payload_dev",
+    "vsf_allgather_dev", "vsf_gather_payload_dev", "vsf_reserve", "vsf_set_input_event",
 ]
 # vsf_option (include/vsf.h)
 (OPT_BLUR_MARCH, OPT_FAST_BOTH_MAX, OPT_SORT_SERIAL, OPT_SELECT_WIDE, OPT_JPEG_SERIAL, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN,
@@ -116,6 +116,8 @@ def lib() -> C.CDLL:
         L.vsf_stereo_batch_dev.argtypes = [vp, vp, i32, sz, sz, vp, vp, vp, vp, vp]
         L.vsf_set_lanes.argtypes = [vp, i32]
         L.vsf_set_pipeline.argtypes = [vp, i32]
+        L.vsf_set_input_event.argtypes = [vp, vp]
+        L.vsf_reserve.argtypes = [vp, i32, i32]
         L.vsf_set_blur_overlap.argtypes = [vp, i32]
         L.vsf_set_fast_resident.argtypes = [vp, i32]
         L.vsf_get_fast_resident.argtypes = [vp, C.POINTER(C.c_int)]
@@ -278,6 +280,15 @@ class Context:
 
     def set_pipeline(self, on: bool):
         self._check(lib().vsf_set_pipeline(self._h, int(on)), "vsf_set_pipeline")
+
+    def set_input_event(self, hip_event):
+        """The next batched call (its pipelined pyramid included) waits on the GPU for this hipEvent_t (an int handle,
+        e.g. torch.cuda.Event.cuda_event after record()); one-shot; None withdraws it."""
+        self._check(lib().vsf_set_input_event(self._h, C.c_void_p(int(hip_event) if hip_event else None)), "vsf_set_input_event")
+
+    def reserve(self, n_frames: int, n_pairs: int):
+        """BLOCKING set-up: scratch of the batched *_dev calls for up to n_frames stereo frames / n_pairs temporal pairs."""
+        self._check(lib().vsf_reserve(self._h, int(n_frames), int(n_pairs)), "vsf_reserve")
 
     def sync(self, allow_capacity: bool = False) -> int:
         return self._check(lib().vsf_sync(self._h), "vsf_sync", allow_capacity)

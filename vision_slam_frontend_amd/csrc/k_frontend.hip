@@ -37,7 +37,8 @@ __device__ __forceinline__ float dot3(int order, float a0, float b0, float a1, f
 __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint* __restrict__ kp,
                                                               const vsf_dmatch* __restrict__ matches,
                                                               const int32_t* __restrict__ nmatches, int max_rows,
-                                                              const float* __restrict__ F,  // 9 floats, row major
+                                                              const float* __restrict__ F,  // 9 floats, row major, or
+                                                              VsfF9 Fv,  // NULL: the matrix by value (batched *_dev calls)
                                                               int order,  // vsf_params::residual_order
                                                               float* __restrict__ residual,  // [frames][max_rows]
                                                               float* __restrict__ mean,      // [frames], NaN if empty
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void stereo_residual_kernel(const vsf_keypoint
   const bool in_lds = lds_rows >= max_rows;
   float Fm[9];
 #pragma unroll
-  for (int i = 0; i < 9; i++) Fm[i] = F[i];
+  for (int i = 0; i < 9; i++) Fm[i] = F ? F[i] : Fv.v[i];
   for (int i = threadIdx.x; i < n; i += 256) {
     const vsf_dmatch dm = m[i];
     const float lx = left[dm.queryIdx].x, ly = left[dm.queryIdx].y;
@@ -500,11 +501,14 @@ __global__ __launch_bounds__(256) void observe_pack_kernel(VsfObserveArgs a) {
 }  // namespace
 
 void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
-                                 int n_frames, int max_rows, const float* d_F, int order, float* d_residual, float* d_mean,
-                                 hipStream_t s) {
+                                 int n_frames, int max_rows, const float* d_F, const float* h_F, int order, float* d_residual,
+                                 float* d_mean, hipStream_t s) {
   const int lds_rows = max_rows <= 16000 ? (max_rows + 3) & ~3 : 0;  // (64 KB of LDS without asking for more)
+  VsfF9 fv = {};
+  if (h_F)  // the matrix rides in the kernel arguments: no copy command, no device buffer shared between calls
+    for (int i = 0; i < 9; i++) fv.v[i] = h_F[i];
   hipLaunchKernelGGL(stereo_residual_kernel, dim3(n_frames), dim3(256), (size_t)lds_rows * sizeof(float), s, d_kp,
-                     d_matches, d_nmatches, max_rows, d_F, order, d_residual, d_mean, lds_rows);
+                     d_matches, d_nmatches, max_rows, h_F ? nullptr : d_F, fv, order, d_residual, d_mean, lds_rows);
 }
 
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
@@ -516,10 +520,10 @@ void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_de
 }
 
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
-                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, int order,
-                              const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
+                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, const float* h_F,
+                              int order, const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
                               vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s) {
-  vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, max_rows, d_F, order, d_residual, d_mean, s);
+  vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, max_rows, d_F, h_F, order, d_residual, d_mean, s);
   if (!d_thr_override)
     hipLaunchKernelGGL(stereo_threshold_chain_kernel, dim3(1), dim3(64), 0, s, d_mean, n_frames, thr_in, d_thr);
   vsf_launch_stereo_filter_only(d_kp, d_desc, d_matches, d_nmatches, n_frames, max_rows, d_residual,

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
   // (LUMA) or nowhere (chroma is parsed only)
   auto block = [&](const DevHuff* hd, const DevHuff* ha, int& pred, int16_t* coef) {
     br.fill();
-    const int t = br.decode(hd);
+    const int t = br.decode(hd) & 15;  // (the host refuses DC tables with symbols above 15, as libjpeg does: second line of defence)
     br.fill();
     pred += br.receive_extend(t);
     if (coef) coef[0] = (int16_t)pred;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
         if (Se == 63) {
           // a scan of a SEQUENTIAL file whose components come in several scans: the whole block, F.2.2.1 + F.2.2.2
           br.fill();
-          const int s = br.decode(t);
+          const int s = br.decode(t) & 15;  // (DC symbols above 15 are refused on the host, as by libjpeg)
           br.fill();
           pred += br.receive_extend(s);
           int mine = lane == 0 ? pred : 0;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
           if (blk && mine != 0) blk[nat] = (int16_t)mine;
         } else if (Ah == 0) {
           br.fill();
-          const int s = br.decode(t);
+          const int s = br.decode(t) & 15;  // (DC symbols above 15 are refused on the host, as by libjpeg)
           br.fill();
           pred += br.receive_extend(s);
           if (blk && lane == 0) blk[0] = (int16_t)(pred * p1);

@@ -288,7 +288,20 @@ __global__ void stereo_thresholds_kernel(const float* __restrict__ mean, int n, 
   }
 }
 
+// ---- the (query, train) set indices of Calculate3DPoints' right -> left matching: q[f] = 2f + 1, t[f] = 2f ----
+__global__ void fill_stereo_sets_kernel(int32_t* __restrict__ sets, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    sets[k] = 2 * k + 1;
+    sets[n + k] = 2 * k;
+  }
+}
+
 }  // namespace
+
+void vsf_launch_fill_stereo_sets(int32_t* d_sets, int n_frames, hipStream_t s) {
+  hipLaunchKernelGGL(fill_stereo_sets_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, d_sets, n_frames);
+}
 
 void vsf_launch_vision_features(const vsf_keypoint* d_kp, const int32_t* d_counts, const uint64_t* d_pairs,
                                 const int32_t* d_npairs, int n_frames, int max_rows, const vsf_calibration& c,

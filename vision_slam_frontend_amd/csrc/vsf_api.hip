@@ -431,6 +431,9 @@ struct vsf_ctx {
   // NOT ordered after that stream's earlier work, waits for it.
   hipEvent_t ev_ingest_done = nullptr;
   bool ingest_done_valid = false;
+  // ... and ANY other producer hands over an event of its own (vsf_set_input_event): the next batched call -- its
+  // pipelined pyramid included -- waits for it; one-shot.
+  hipEvent_t input_event = nullptr;
   const uint8_t* last_pyr = nullptr;
   int lanes = 1;  // 1 = everything on `stream` (default), 2 = two concurrent half batches (vsf_set_lanes)
   int blur_overlap = 1;  // the blur on blur_stream beside FAST / selection (vsf_set_blur_overlap)
@@ -463,7 +466,6 @@ struct vsf_ctx {
   int m_pairs = 0, m_rows = 0;
   // f1 work buffers: residuals [frames][rows], F (9 floats), matches / counts / sort keys of the temporal pairs
   float* f_residual = nullptr;
-  float* f_F = nullptr;
   int f_frames = 0;
   vsf_dmatch* t_matches = nullptr;
   int32_t* t_nmatches = nullptr;
@@ -476,6 +478,10 @@ struct vsf_ctx {
   int v_frames = 0;
   uint32_t* pk_offsets = nullptr;
   int pk_entries = 0;
+  // Scratch a *_dev call has outgrown.  Such a call takes a NEW allocation (hipMalloc does not wait for the GPU) and
+  // parks the old one here, because hipFree would wait for the whole device behind the caller's back; released by
+  // vsf_sync / vsf_reserve / vsf_destroy, when every stream of the context is known to be idle.
+  std::vector<void*> retired;
   // vsf_observe_stereo: temporal ring, per-call device scratch, pinned host staging
   struct ObserveMeta {  // pinned, device-visible: read by the kernels over PCIe (a few words per call, no copy command)
     float F[9];
@@ -629,30 +635,40 @@ void free_devset(DevSet* ds) {
   *ds = DevSet();
 }
 
+// ---- scratch that follows the batch size of the *_dev calls ----
+// Sized at vsf_create for max_images / 2 frames and as many pairs, or by vsf_reserve.  A call that needs more never waits
+// for the GPU: grow_scratch() allocates anew and retires the old buffer (kernels already queued keep using it).
+template <class T>
+vsf_status grow_scratch(vsf_ctx* ctx, T*& ptr, size_t bytes) {
+  void* fresh = nullptr;
+  VSF_HIP(hipMalloc(&fresh, std::max<size_t>(bytes, 16)));
+  if (ptr) ctx->retired.push_back(static_cast<void*>(ptr));
+  ptr = static_cast<T*>(fresh);
+  return VSF_OK;
+}
+
+void free_retired(vsf_ctx* ctx) {  // (callers have waited for every stream of the context)
+  for (void* p : ctx->retired) hipFree(p);
+  ctx->retired.clear();
+}
+
 vsf_status ensure_match_buffers(vsf_ctx* ctx, int pairs, int rows) {
   if (pairs <= ctx->m_pairs && rows <= ctx->m_rows) return VSF_OK;
   pairs = std::max(pairs, ctx->m_pairs);
   rows = std::max(rows, ctx->m_rows);
-  VSF_HIP(hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->m_idx2);
-  hipFree(ctx->m_dist2);
-  ctx->m_idx2 = ctx->m_dist2 = nullptr;
-  VSF_HIP(hipMalloc((void**)&ctx->m_idx2, (size_t)pairs * rows * 2 * sizeof(int32_t)));
-  VSF_HIP(hipMalloc((void**)&ctx->m_dist2, (size_t)pairs * rows * 2 * sizeof(int32_t)));
+  vsf_status st = grow_scratch(ctx, ctx->m_idx2, (size_t)pairs * rows * 2 * sizeof(int32_t));
+  if (st == VSF_OK) st = grow_scratch(ctx, ctx->m_dist2, (size_t)pairs * rows * 2 * sizeof(int32_t));
+  if (st != VSF_OK) return st;
   ctx->m_pairs = pairs;
   ctx->m_rows = rows;
   return VSF_OK;
 }
 
-vsf_status ensure_match_host_staging(vsf_ctx* ctx, int rows) {
+vsf_status ensure_match_host_staging(vsf_ctx* ctx, int rows) {  // (host-pointer, synchronous entry points only)
   if (rows <= ctx->mh_rows) return VSF_OK;
-  VSF_HIP(hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->mh_desc);
-  hipFree(ctx->mh_matches);
-  ctx->mh_desc = nullptr;
-  ctx->mh_matches = nullptr;
-  VSF_HIP(hipMalloc((void**)&ctx->mh_desc, (size_t)2 * rows * VSF_DESC_BYTES));
-  VSF_HIP(hipMalloc((void**)&ctx->mh_matches, (size_t)rows * sizeof(vsf_dmatch)));
+  vsf_status st = grow_scratch(ctx, ctx->mh_desc, (size_t)2 * rows * VSF_DESC_BYTES);
+  if (st == VSF_OK) st = grow_scratch(ctx, ctx->mh_matches, (size_t)rows * sizeof(vsf_dmatch));
+  if (st != VSF_OK) return st;
   if (!ctx->mh_counts) VSF_HIP(hipMalloc((void**)&ctx->mh_counts, 2 * sizeof(int32_t)));
   if (!ctx->mh_nmatches) VSF_HIP(hipMalloc((void**)&ctx->mh_nmatches, sizeof(int32_t)));
   ctx->mh_rows = rows;
@@ -662,14 +678,54 @@ vsf_status ensure_match_host_staging(vsf_ctx* ctx, int rows) {
 vsf_status ensure_residual_buffers(vsf_ctx* ctx, int n_frames) {
   const size_t K = (size_t)ctx->p.max_keypoints;
   if (n_frames > ctx->f_frames) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->f_residual);
-    ctx->f_residual = nullptr;
-    VSF_HIP(hipMalloc((void**)&ctx->f_residual, (size_t)n_frames * K * sizeof(float)));
+    vsf_status st = grow_scratch(ctx, ctx->f_residual, (size_t)n_frames * K * sizeof(float));
+    if (st != VSF_OK) return st;
     ctx->f_frames = n_frames;
   }
-  if (!ctx->f_F) VSF_HIP(hipMalloc((void**)&ctx->f_F, 9 * sizeof(float)));
   return VSF_OK;
+}
+
+vsf_status ensure_temporal_buffers(vsf_ctx* ctx, int n_pairs) {
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_pairs <= ctx->t_pairs) return VSF_OK;
+  vsf_status st = grow_scratch(ctx, ctx->t_matches, (size_t)n_pairs * K * sizeof(vsf_dmatch));
+  if (st == VSF_OK) st = grow_scratch(ctx, ctx->t_nmatches, (size_t)n_pairs * sizeof(int32_t));
+  if (st == VSF_OK) st = grow_scratch(ctx, ctx->t_sortkeys, (size_t)n_pairs * K * 8);
+  if (st != VSF_OK) return st;
+  ctx->t_pairs = n_pairs;
+  return VSF_OK;
+}
+
+vsf_status ensure_vision_buffers(vsf_ctx* ctx, int n_frames) {
+  const size_t K = (size_t)ctx->p.max_keypoints;
+  if (n_frames <= ctx->v_frames) return VSF_OK;
+  vsf_status st = grow_scratch(ctx, ctx->v_pairs, (size_t)n_frames * K * 2 * sizeof(uint64_t));
+  if (st == VSF_OK) st = grow_scratch(ctx, ctx->v_npairs, (size_t)n_frames * sizeof(int32_t));
+  if (st == VSF_OK) st = grow_scratch(ctx, ctx->v_sets, (size_t)2 * n_frames * sizeof(int32_t));
+  if (st != VSF_OK) return st;
+  // q_set[f] = 2f + 1 (right frame, "initial", cc:131), t_set[f] = 2f (left frame, "current"): written by a kernel on the
+  // context's stream, in order before the launches that read it (a hipMemcpy would wait for the stream)
+  vsf_launch_fill_stereo_sets(ctx->v_sets, n_frames, ctx->stream);
+  ctx->v_frames = n_frames;
+  return VSF_OK;
+}
+
+vsf_status ensure_pack_buffers(vsf_ctx* ctx, int n) {
+  if (n <= ctx->pk_entries) return VSF_OK;
+  vsf_status st = grow_scratch(ctx, ctx->pk_offsets, (size_t)n * sizeof(uint32_t));
+  if (st != VSF_OK) return st;
+  ctx->pk_entries = n;
+  return VSF_OK;
+}
+
+vsf_status reserve_scratch(vsf_ctx* ctx, int n_frames, int n_pairs) {
+  const int pairs = std::max(n_frames, n_pairs);
+  vsf_status st = ensure_match_buffers(ctx, pairs, ctx->p.max_keypoints);
+  if (st == VSF_OK) st = ensure_residual_buffers(ctx, n_frames);
+  if (st == VSF_OK) st = ensure_temporal_buffers(ctx, pairs);  // (Calculate3DPoints matches one pair per frame)
+  if (st == VSF_OK) st = ensure_vision_buffers(ctx, n_frames);
+  if (st == VSF_OK) st = ensure_pack_buffers(ctx, n_frames + n_pairs);
+  return st;
 }
 
 void free_observe(vsf_ctx* ctx) {
@@ -692,24 +748,6 @@ void free_observe(vsf_ctx* ctx) {
     if (o.ev_done[i]) hipEventDestroy(o.ev_done[i]);
   }
   o = vsf_ctx::Observe();
-}
-
-vsf_status ensure_temporal_buffers(vsf_ctx* ctx, int n_pairs) {
-  const size_t K = (size_t)ctx->p.max_keypoints;
-  if (n_pairs <= ctx->t_pairs) return VSF_OK;
-  VSF_HIP(hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->t_matches);
-  hipFree(ctx->t_nmatches);
-  hipFree(ctx->t_sortkeys);
-  ctx->t_matches = nullptr;
-  ctx->t_nmatches = nullptr;
-  ctx->t_sortkeys = nullptr;
-  ctx->t_pairs = 0;
-  VSF_HIP(hipMalloc((void**)&ctx->t_matches, (size_t)n_pairs * K * sizeof(vsf_dmatch)));
-  VSF_HIP(hipMalloc((void**)&ctx->t_nmatches, (size_t)n_pairs * sizeof(int32_t)));
-  VSF_HIP(hipMalloc(&ctx->t_sortkeys, (size_t)n_pairs * K * 8));
-  ctx->t_pairs = n_pairs;
-  return VSF_OK;
 }
 
 vsf_status check_status_word(vsf_ctx* ctx) {
@@ -794,6 +832,17 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
   return o;
 }
 
+// vsf_set_input_event: the batched call that follows waits for the caller's event on the context's stream (level 0 of the
+// pyramid IS the input: FAST, Harris and the orientation read it there) -- the pipelined pyramid chain waits for it by
+// itself in extract_on -- and the event is forgotten when the call returns (one-shot).
+struct InputEventScope {
+  vsf_ctx* ctx;
+  explicit InputEventScope(vsf_ctx* c) : ctx(c) {
+    if (ctx->input_event) vsf_note(hipStreamWaitEvent(ctx->stream, ctx->input_event, 0));
+  }
+  ~InputEventScope() { ctx->input_event = nullptr; }
+};
+
 // detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.  `status`: the status word the kernels report capacity
 // overflows into (the context's, or the word of the frame in flight that owns this extraction).
 void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp,
@@ -823,6 +872,8 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     if (ctx->fast_done_valid) vsf_note(hipStreamWaitEvent(ps, ctx->ev_fast_done, 0));
     // ... and not before images this library itself is still producing on the context's stream are complete
     if (ctx->ingest_done_valid) vsf_note(hipStreamWaitEvent(ps, ctx->ev_ingest_done, 0));
+    // ... nor before the caller's own producer has finished them (vsf_set_input_event)
+    if (ctx->input_event) vsf_note(hipStreamWaitEvent(ps, ctx->input_event, 0));
     {
       StageTimer t(ctx, ps, VSF_STAGE_PYRAMID, g.nlevels - 1);
       vsf_launch_pyramid(d, g, ctx->orb.levels.data(), im, ps, nullptr);
@@ -1133,6 +1184,9 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
       hipMalloc((void**)&ctx->st_desc, n * K * VSF_DESC_BYTES) != hipSuccess ||
       hipMalloc((void**)&ctx->st_counts, n * sizeof(int32_t)) != hipSuccess)
     return fail(VSF_ERR_HIP);
+  // scratch of the batched *_dev calls for whole batches of this context (vsf_reserve sizes it for others)
+  if (reserve_scratch(ctx, std::max(1, ctx->p.max_images / 2), std::max(1, ctx->p.max_images / 2)) != VSF_OK)
+    return fail(VSF_ERR_HIP);
   if (hipDeviceSynchronize() != hipSuccess) return fail(VSF_ERR_HIP);
   *out = ctx;
   return VSF_OK;
@@ -1166,7 +1220,6 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->m_idx2);
   hipFree(ctx->m_dist2);
   hipFree(ctx->f_residual);
-  hipFree(ctx->f_F);
   hipFree(ctx->t_matches);
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
@@ -1178,6 +1231,7 @@ void vsf_destroy(vsf_ctx* ctx) {
     hipFree(ctx->jp_dev[i]);
     if (ctx->jp_copied[i]) hipEventDestroy(ctx->jp_copied[i]);
   }
+  free_retired(ctx);
   hipFree(ctx->v_pairs);
   hipFree(ctx->v_npairs);
   hipFree(ctx->v_sets);
@@ -1338,7 +1392,31 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
 
 vsf_status vsf_sync(vsf_ctx* ctx) {
   if (!ctx) return VSF_ERR_INVALID_ARG;
-  return check_status_word(ctx);
+  const vsf_status st = check_status_word(ctx);
+  if (!ctx->retired.empty()) {  // scratch a *_dev call outgrew: nothing can be using it once every stream is idle
+    sync_all_streams(ctx);
+    free_retired(ctx);
+  }
+  return st;
+}
+
+vsf_status vsf_set_input_event(vsf_ctx* ctx, void* hip_event) {
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  ctx->input_event = static_cast<hipEvent_t>(hip_event);
+  return VSF_OK;
+}
+
+vsf_status vsf_reserve(vsf_ctx* ctx, int n_frames, int n_pairs) {
+  if (!ctx || n_frames < 1 || n_pairs < 0) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  sync_all_streams(ctx);
+  free_retired(ctx);
+  vsf_status st = reserve_scratch(ctx, n_frames, n_pairs);
+  if (st != VSF_OK) return st;
+  sync_all_streams(ctx);  // (the set-index fill)
+  free_retired(ctx);
+  VSF_STICKY();
+  return VSF_OK;
 }
 
 vsf_status vsf_level_info(const vsf_ctx* ctx, int level, int* w, int* h, float* scale, int* nfeatures) {
@@ -1374,6 +1452,7 @@ vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_imag
   if (st != VSF_OK) return st;
   VSF_HIP(hipSetDevice(ctx->device));
   VsfImages im{d_imgs, image_stride, row_stride, n_images};
+  InputEventScope input(ctx);
   return extract_async(ctx, im, d_kp, d_desc, d_counts, true);
 }
 
@@ -1487,6 +1566,7 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
   VSF_HIP(hipSetDevice(ctx->device));
   st = ensure_match_buffers(ctx, n_frames, ctx->p.max_keypoints);
   if (st != VSF_OK) return st;
+  InputEventScope input(ctx);
   const VsfImages im{d_imgs, image_stride, row_stride, 2 * n_frames};
   const size_t set_stride = (size_t)ctx->p.max_keypoints * VSF_DESC_BYTES;
   st = run_chunked(ctx, n_frames, [&](hipStream_t s, int fa, int nf) {
@@ -1517,8 +1597,7 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
     vsf_status st = ensure_residual_buffers(ctx, n_frames);
     if (st != VSF_OK) return st;
   }
-  VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, ctx->f_F, ctx->p.residual_order, d_thr_override, thr_in,
+  vsf_launch_stereo_filter(d_kp, d_desc, d_matches, d_nmatches, n_frames, (int)K, nullptr, F, ctx->p.residual_order, d_thr_override, thr_in,
                            ctx->f_residual, d_means, d_thr, d_kp_out, d_desc_out, d_counts_out, ctx->stream);
   VSF_STICKY();
   return VSF_OK;
@@ -1530,10 +1609,9 @@ vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp
   VSF_HIP(hipSetDevice(ctx->device));
   vsf_status st = ensure_residual_buffers(ctx, n_frames);
   if (st != VSF_OK) return st;
-  VSF_HIP(hipMemcpyAsync(ctx->f_F, F, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   {
     StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
-    vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, ctx->f_F, ctx->p.residual_order, ctx->f_residual,
+    vsf_launch_stereo_residuals(d_kp, d_matches, d_nmatches, n_frames, ctx->p.max_keypoints, nullptr, F, ctx->p.residual_order, ctx->f_residual,
                                 d_means, ctx->stream);
   }
   VSF_STICKY();
@@ -1578,25 +1656,9 @@ vsf_status vsf_vision_features_batch_dev(vsf_ctx* ctx, const vsf_calibration* ca
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   const size_t K = (size_t)ctx->p.max_keypoints;
-  if (n_frames > ctx->v_frames) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->v_pairs);
-    hipFree(ctx->v_npairs);
-    hipFree(ctx->v_sets);
-    ctx->v_pairs = nullptr;
-    ctx->v_npairs = nullptr;
-    ctx->v_sets = nullptr;
-    ctx->v_frames = 0;
-    VSF_HIP(hipMalloc((void**)&ctx->v_pairs, (size_t)n_frames * K * 2 * sizeof(uint64_t)));
-    VSF_HIP(hipMalloc((void**)&ctx->v_npairs, (size_t)n_frames * sizeof(int32_t)));
-    VSF_HIP(hipMalloc((void**)&ctx->v_sets, (size_t)2 * n_frames * sizeof(int32_t)));
-    std::vector<int32_t> sets((size_t)2 * n_frames);
-    for (int f = 0; f < n_frames; f++) {
-      sets[f] = 2 * f + 1;         // query  = right frame ("initial", cc:131)
-      sets[n_frames + f] = 2 * f;  // train  = left frame  ("current")
-    }
-    VSF_HIP(hipMemcpy(ctx->v_sets, sets.data(), sets.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    ctx->v_frames = n_frames;
+  {
+    vsf_status st0 = ensure_vision_buffers(ctx, n_frames);
+    if (st0 != VSF_OK) return st0;
   }
   // Calculate3DPoints: best_percent_ forced to 1.0 (cc:129-132)
   vsf_status st = vsf_feature_matches_batch_dev(ctx, d_desc, d_counts, K * VSF_DESC_BYTES, ctx->v_sets,
@@ -1627,12 +1689,9 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   const int n = n_frames + n_pairs;
-  if (n > ctx->pk_entries) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->pk_offsets);
-    ctx->pk_offsets = nullptr;
-    VSF_HIP(hipMalloc((void**)&ctx->pk_offsets, (size_t)n * sizeof(uint32_t)));
-    ctx->pk_entries = n;
+  {
+    vsf_status st0 = ensure_pack_buffers(ctx, n);
+    if (st0 != VSF_OK) return st0;
   }
   const uint32_t cap = (uint32_t)std::min<size_t>(payload_cap, 0xFFFFFFFCu);
   {
@@ -1912,7 +1971,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   int32_t* cur_counts = o.ring_counts + S;
   {
     StageTimer t(ctx, s, VSF_STAGE_TAIL, 3);
-    vsf_launch_stereo_residuals(kp_raw, raw_matches, nmatches, 1, Kc, M.F, ctx->p.residual_order, ctx->f_residual, means, s);
+    vsf_launch_stereo_residuals(kp_raw, raw_matches, nmatches, 1, Kc, M.F, nullptr, ctx->p.residual_order, ctx->f_residual, means, s);
     vsf_launch_stereo_thresholds(means, 1, thr_state, thr, s);
     vsf_launch_stereo_filter_only(kp_raw, desc_raw, raw_matches, nmatches, 1, Kc, ctx->f_residual, thr, o.kpf, cur_desc,
                                   cur_counts, s);

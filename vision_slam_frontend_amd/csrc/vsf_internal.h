@@ -111,6 +111,22 @@ inline void vsf_note(hipError_t e) {
 // What vsf_comm.hip needs of a context (vsf_ctx is private to vsf_api.hip).
 hipStream_t vsf_ctx_stream(const vsf_ctx* ctx);
 int vsf_ctx_device(const vsf_ctx* ctx);
+void vsf_ctx_set_last_error(vsf_ctx* ctx, int code);  // what vsf_last_hip_error returns
+constexpr int VSF_RCCL_ERROR_BASE = 10000;             // vsf_last_hip_error = 10000 + ncclResult_t after a failed RCCL call
+// An error a launcher noted belongs to the CONTEXT whose entry point was running.  Every public entry point holds one of
+// these: on the way out -- early returns included -- whatever is still noted in the thread's slot moves into the context
+// (vsf_ctx::pending_hip) and is returned by that context's next checking call (VSF_STICKY), never by another context that
+// happens to be driven from the same host thread.
+void vsf_ctx_absorb_noted_error(vsf_ctx* ctx);
+struct VsfErrorScope {
+  vsf_ctx* ctx;
+  explicit VsfErrorScope(vsf_ctx* c) : ctx(c) {}
+  ~VsfErrorScope() {
+    if (ctx && vsf_tls_hip_error != 0) vsf_ctx_absorb_noted_error(ctx);
+  }
+  VsfErrorScope(const VsfErrorScope&) = delete;
+  VsfErrorScope& operator=(const VsfErrorScope&) = delete;
+};
 // Raises the dynamic-LDS limit of the kernels that need more than the default 64 KB (k_frontend / k_pyramid / k_jpeg);
 // called once per context creation, checked.
 hipError_t vsf_prepare_sort_kernels(int lds_limit);
@@ -175,20 +191,25 @@ void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, c
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
                               hipStream_t s);
 
-// k_frontend.hip
+// k_frontend.hip.  The fundamental matrix: h_F (host, 9 floats) travels by value in the kernel
+// arguments; with h_F == NULL the kernel reads d_F (device-visible memory: vsf_observe's pinned per-call parameters).
+struct VsfF9 {
+  float v[9];
+};
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
-                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, int order,
-                              const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
+                              const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_F, const float* h_F,
+                              int order, const float* d_thr_override, float thr_in, float* d_residual, float* d_mean, float* d_thr,
                               vsf_keypoint* d_kp_out, uint8_t* d_desc_out, int32_t* d_counts_out, hipStream_t s);
 void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_matches, const int32_t* d_nmatches,
-                                 int n_frames, int max_rows, const float* d_F, int order, float* d_residual, float* d_mean,
-                                 hipStream_t s);
+                                 int n_frames, int max_rows, const float* d_F, const float* h_F, int order, float* d_residual,
+                                 float* d_mean, hipStream_t s);
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
                                    const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_residual,
                                    const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
                                    int32_t* d_counts_out, hipStream_t s);
 // k_points.hip (SURVEY 8(f) row f2 + the compact gather payload)
 void vsf_launch_stereo_thresholds(const float* d_means, int n, float* d_state, float* d_thr, hipStream_t s);
+void vsf_launch_fill_stereo_sets(int32_t* d_sets, int n_frames, hipStream_t s);  // [0..n): 2f + 1, [n..2n): 2f
 void vsf_launch_vision_features(const vsf_keypoint* d_kp, const int32_t* d_counts, const uint64_t* d_pairs,
                                 const int32_t* d_npairs, int n_frames, int max_rows, const vsf_calibration& c,
                                 vsf_vision_feature* d_out, int32_t* d_nfeatures, int32_t* d_npoints, hipStream_t s);

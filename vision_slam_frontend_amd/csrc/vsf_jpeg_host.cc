@@ -53,6 +53,17 @@ bool huff_counts_ok(const uint8_t bits[17]) {
   return true;
 }
 
+// A DC table's symbols are magnitude categories 0..15: jpeg_make_d_derived_tbl (jdhuff.c) answers anything larger with
+// JERR_BAD_HUFF_TABLE when the table is set up for a scan's DC decoding, so cv::imdecode refuses such a file.  (Here a larger
+// symbol would also mean shifts by more than the reader's window in receive_extend.)
+bool dc_symbols_ok(const HostHuff& h) {
+  int total = 0;
+  for (int l = 1; l <= 16; l++) total += h.bits[l];
+  for (int k = 0; k < total && k < 256; k++)
+    if (h.vals[k] > 15) return false;
+  return true;
+}
+
 bool build_dev_huff(const HostHuff& h, DevHuff* d) {
   std::memset(d, 0, sizeof(*d));
   if (!huff_counts_ok(h.bits)) return false;  // (parse_jpeg has refused such a table already: second line of defence)
@@ -219,6 +230,14 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         has_luma |= ci == 0;
       }
       const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      if (ns > 1) {  // jdinput.c per_scan_setup: an interleaved scan holds at most D_MAX_BLOCKS_IN_MCU = 10 blocks per MCU
+        int blocks = 0;
+        for (int c = 0; c < ns; c++) blocks += ch[sc.comp[c]] * cv[sc.comp[c]];
+        if (blocks > 10) return VSF_ERR_INVALID_ARG;  // JERR_BAD_MCU_SIZE
+      }
+      if (Ss == 0 && Ah == 0)  // a scan that decodes DC symbols, luminance or not: libjpeg derives every table the scan names
+        for (int c = 0; c < ns; c++)
+          if (dc[td[c]].present && !dc_symbols_ok(dc[td[c]])) return VSF_ERR_INVALID_ARG;  // JERR_BAD_HUFF_TABLE
       if (multiscan) {  // a sequential scan: the whole band at full precision
         if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return VSF_ERR_INVALID_ARG;
       } else {  // jdphuff.c start_pass_phuff_decoder: the legal shapes of a progressive scan
@@ -282,6 +301,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
         if (s[1 + 2 * c] != cid[c]) return VSF_ERR_UNSUPPORTED;
         const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
         if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !qt_present[ctq[c]]) return VSF_ERR_INVALID_ARG;
+        if (!dc_symbols_ok(dc[td])) return VSF_ERR_INVALID_ARG;  // JERR_BAD_HUFF_TABLE in libjpeg
         im->dc_slot[c] = slot_of(0, td);
         im->ac_slot[c] = slot_of(1, ta);
       }
@@ -296,6 +316,11 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
       const bool single = ncomp == 1;  // T.81 A.2.2: a one-component scan has one block per MCU
       const int mw = single ? 8 : 8 * hmax, mh = single ? 8 : 8 * vmax;
       if (!single && hmax * vmax > kGroupBlocks) return VSF_ERR_UNSUPPORTED;
+      if (!single) {  // jdinput.c per_scan_setup: at most D_MAX_BLOCKS_IN_MCU = 10 blocks per MCU (JERR_BAD_MCU_SIZE)
+        int blocks = 0;
+        for (int c = 0; c < ncomp; c++) blocks += ch[c] * cv[c];
+        if (blocks > 10) return VSF_ERR_INVALID_ARG;
+      }
       im->ncomp = ncomp;
       im->restart_interval = restart_interval;
       im->mcus_x = (W + mw - 1) / mw;

@@ -461,6 +461,8 @@ class ShardedStereoFrontend:
         ctx.set_stream(self.stream.cuda_stream)
         if self.overlap:
             self.tail_ctx.set_stream(self.tail_stream.cuda_stream)
+        # the tail's scratch for B frames and B x W pairs, sized now (set-up) instead of inside the first step
+        self.tail_ctx.reserve(B, max(self.NP, 1))
         if comm is not None and hasattr(comm, "bind"):
             comm.bind(self.tail_ctx)  # the exchanges are ordered on the tail's stream
         self.stream.synchronize()
@@ -573,8 +575,10 @@ class ShardedStereoFrontend:
         self.comm.all_gather(out, inp, self.tail_stream)
 
     # ---- one step ----
-    def step(self, d_img: torch.Tensor):
-        """d_img: (B, 2, H, W) uint8 resident in HBM: this rank's frames of step `step_idx`, in time order."""
+    def step(self, d_img: torch.Tensor, input_event=None):
+        """d_img: (B, 2, H, W) uint8 resident in HBM: this rank's frames of step `step_idx`, in time order.
+        input_event: a recorded torch.cuda.Event (or a raw hipEvent_t handle) behind the producer of d_img -- a decoder on
+        another stream, say; the extraction, its pipelined pyramid included, waits for it on the GPU (vsf_set_input_event)."""
         ctx, tctx, B, W, K, world = self.ctx, self.tail_ctx, self.B, self.W, self.K, self.world
         s = self.step_idx
         parity, slot = s & 1, s % self.PAYLOAD_SLOTS
@@ -583,6 +587,8 @@ class ShardedStereoFrontend:
         with torch.cuda.stream(self.stream):
             if self.overlap and s >= self.NRAW:
                 self.stream.wait_event(self.raw_free[s % self.NRAW])  # the tail of step s - 2 has read this buffer
+            if input_event is not None:
+                ctx.set_input_event(getattr(input_event, "cuda_event", input_event))
             ctx.stereo_batch_dev(p(d_img), B, self.width * self.height, self.width, p(raw["kp"]), p(raw["desc"]),
                                  p(raw["counts"]), p(raw["matches"]), p(raw["nmatches"]))
             if self.overlap:
