@@ -163,7 +163,7 @@ class JpegIngest:
     (vsf_jpeg_decode_gray_batch) and demosaiced (vsf_bayer_bg_to_gray_batch_dev) on a context and stream of their own,
     one step AHEAD of the extraction: two image buffers alternate, two events per buffer order the streams."""
 
-    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream):
+    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream, priority="normal"):
         import ctypes as C
         import io
 
@@ -186,14 +186,15 @@ class JpegIngest:
         # The decode should only fill what the extraction leaves free: the LOWEST stream priority.  torch offers two
         # levels (and the step's tail already has the high one); HIP has a third, so the stream is made with HIP itself.
         self.stream = None
-        if os.environ.get("VSF_BENCH_INGEST_PRIO", "low") == "low":
+        if priority in ("low", "high"):
             try:
                 hip = C.CDLL("libamdhip64.so")
                 least, greatest, h = C.c_int(0), C.c_int(0), C.c_void_p()
                 if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0 and \
-                        hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), least) == 0 and h.value:
+                        hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), least if priority == "low" else greatest) == 0 \
+                        and h.value:
                     self.stream = torch.cuda.ExternalStream(h.value, device=dev)
-                    self.stream_priority = least.value
+                    self.stream_priority = (least if priority == "low" else greatest).value
             except OSError:
                 pass
         if self.stream is None:
@@ -460,6 +461,13 @@ def main() -> int:
     ap.add_argument("--fast-resident", type=int, default=None,
                     help="force the FAST launch form (0 = grid, 2..4 = resident with that many waves per SIMD) instead of "
                          "measuring it (experiments)")
+    ap.add_argument("--pipe-after-fast", type=int, default=None,
+                    help="VSF_OPT_PIPE_AFTER_FAST (experiments): 1 = a step's pipelined pyramid waits for the previous step's "
+                         "FAST, 0 = it starts as soon as its inputs are ready; default 1 with frames in HBM, 0 with --ingest jpeg")
+    ap.add_argument("--pipe-priority", type=int, default=None,
+                    help="VSF_OPT_PIPE_PRIORITY (experiments): stream priority of the pipelined pyramid chain, 0 / 1 low / -1 high")
+    ap.add_argument("--ingest-priority", choices=["low", "normal", "high"], default=None,
+                    help="--ingest jpeg: HIP stream priority of the decode stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
@@ -602,21 +610,32 @@ def main() -> int:
     # cross-call pipelining: every step's input is complete in HBM before the call (the rotating synthetic batches), or
     # the call is handed the event behind its producer (the JPEG ingest: vsf_set_input_event)
     pipeline = not args.no_pipeline
+    if args.pipe_priority is not None:
+        ctx.set_option(capi.OPT_PIPE_PRIORITY, args.pipe_priority)
     ctx.set_pipeline(pipeline)
+    if args.pipe_after_fast is not None:
+        ctx.set_option(capi.OPT_PIPE_AFTER_FAST, args.pipe_after_fast)
     torch.cuda.synchronize()
 
     ingest = None
     if args.ingest == "jpeg":
-        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream)
+        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream, priority=args.ingest_priority or "normal")
+
+    host_s = [0.0, 0.0]  # host wall time inside the ingest call / inside the step's launches (is the host the limit?)
 
     def run_step():
+        h0 = time.perf_counter()
         if ingest is None:
             sf.step(d_imgs[step_no[0] % len(d_imgs)])
             step_no[0] += 1
         else:
             batch, ready = ingest.next_batch()  # starts the next step's decode
+            h1 = time.perf_counter()
+            host_s[0] += h1 - h0
+            h0 = h1
             sf.step(batch, input_event=ready)   # waits (on the GPU) for this step's decode
             ingest.release()                    # the buffer may be overwritten once this step's extraction has read it
+        host_s[1] += time.perf_counter() - h0
 
     # Set-up, not warm-up: ONE explicit, blocking measurement of the two FAST launch forms on this rank's batch
     # (vsf_tune_fast_resident, then six whole steps per form on the rotating batches: the form's worth shows in the composed step), made common
@@ -627,7 +646,9 @@ def main() -> int:
     if args.fast_resident is not None:
         ctx.set_fast_resident(args.fast_resident)
     elif not args.blur_inline:
-        tune = sf.tune(d_imgs, steps=6)
+        # (with --ingest jpeg the two forms are timed on the real steps, decode beside them: what FAST shares the chip with
+        # decides which form wins)
+        tune = sf.tune(d_imgs, steps=6 if ingest is None else 20, step_fn=None if ingest is None else run_step)
     report_stage("warm-up")
     for _ in range(args.warmup):
         run_step()
@@ -640,8 +661,10 @@ def main() -> int:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s[0] = host_s[1] = 0.0
     for _ in range(args.steps):
         run_step()
+    host_ms = {"ingest_call": 1e3 * host_s[0] / args.steps, "step_launches": 1e3 * host_s[1] / args.steps}
     sf.drain()  # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -707,7 +730,7 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus // 100 + 1)]
-        ts0 = time.perf_counter()
+        ts0, ts0_unix = time.perf_counter(), time.time()
         marks[0].record(stream)
         for i in range(n_sus):
             run_step()
@@ -729,7 +752,7 @@ def main() -> int:
             first100, last100 = per100[0], per100[-1]
         sustained = {"steps": n_sus, "seconds": sus_elapsed, "value": world * B * n_sus / sus_elapsed,
                      "ms_per_step": 1e3 * sus_elapsed / n_sus, "first_100_ms": first100, "last_100_ms": last100,
-                     "ms_per_step_by_100": per100,
+                     "ms_per_step_by_100": per100, "unix_time": [ts0_unix, ts0_unix + sus_elapsed],
                      "note": "the timed loop continued for %d more steps after the headline's region (same settings, drained "
                              "inside the clock); first/last_100_ms: ms per step over the first / last 100 steps (HIP events on "
                              "the extraction's stream, rank 0%s)" % (n_sus, "; max over ranks for the scalars" if world > 1 else "")}
@@ -875,6 +898,8 @@ def main() -> int:
             "concurrent_stages": concurrent,
             "stages_ms_per_step_in_line": inline_stages,
             "device_ms_per_step": device_ms / args.steps,
+            # host wall time per step spent issuing work (the step is asynchronous: well below ms_per_step = the GPU is the limit)
+            "host_issue_ms_per_step": host_ms,
             "tail_stream_ms_per_step": None if tail_stages is None else
             {k: v[0] / args.steps for k, v in tail_stages.items()},
         }

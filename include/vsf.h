@@ -101,6 +101,10 @@ vsf_status vsf_params_set_ratio(vsf_params* p, float nn_match_ratio);
 vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out);
 void vsf_destroy(vsf_ctx* ctx);
 const char* vsf_status_string(vsf_status s);
+/* The hipError_t of the context's last VSF_ERR_HIP -- or 10000 + the ncclResult_t when it was an RCCL call that failed
+ * (vsf_comm_create, vsf_allgather_dev, vsf_gather_payload_dev).  An error belongs to the context whose call met it: one
+ * noted inside an asynchronous call is returned by that call or by the same context's next call that checks, never by
+ * another context driven from the same host thread. */
 int vsf_last_hip_error(const vsf_ctx* ctx);
 vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out);
 /* Use an existing hipStream_t (e.g. the caller's framework stream) instead of the context's own. NULL restores it.  The
@@ -163,7 +167,11 @@ typedef enum {
   VSF_OPT_PYRAMID_CHAIN = 6, /* 8: levels per slab launch; 0: per-level launches even for a frame or two */
   VSF_OPT_PYRAMID_ROWS = 7,  /* 6: rows of a chain's last level per slab */
   VSF_OPT_SELECT_BIG_CLASS = 8, /* 1: a batch's widest levels keep their candidate array in LDS (9 216 entries, tables in HBM) */
-  VSF_OPT_COUNT = 9
+  VSF_OPT_PIPE_AFTER_FAST = 9, /* 1: the pipelined pyramid of a call waits for the previous call's FAST kernel; 0: it starts as soon
+                                * as its inputs are ready (a step whose FAST shares the chip with a decoder) */
+  VSF_OPT_PIPE_PRIORITY = 10,  /* stream priority of the pipelined pyramid chain: 0 normal, 1 lowest, -1 highest; set it before
+                                * vsf_set_pipeline(ctx, 1) */
+  VSF_OPT_COUNT = 11
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);

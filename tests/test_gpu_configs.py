@@ -311,7 +311,7 @@ def test_options_and_sticky_hip_errors(capi):
     with capi.Context(capi.default_params(w, h, max_images=2 * B, nfeatures=nf)) as ctx:
         defaults = {capi.OPT_BLUR_MARCH: 0, capi.OPT_FAST_BOTH_MAX: 16, capi.OPT_SORT_SERIAL: 0, capi.OPT_SELECT_WIDE: 1,
                     capi.OPT_JPEG_SERIAL: 0, capi.OPT_PYRAMID_FEW: 16, capi.OPT_PYRAMID_CHAIN: 8, capi.OPT_PYRAMID_ROWS: 6,
-                    capi.OPT_SELECT_BIG_CLASS: 1}
+                    capi.OPT_SELECT_BIG_CLASS: 1, capi.OPT_PIPE_AFTER_FAST: 1, capi.OPT_PIPE_PRIORITY: 0}
         for opt, want in defaults.items():
             assert ctx.get_option(opt) == want, opt
         for opt, bad in ((99, 0), (-1, 0), (capi.OPT_PYRAMID_ROWS, 0), (capi.OPT_FAST_BOTH_MAX, -1), (capi.OPT_PYRAMID_CHAIN, 65)):
@@ -353,6 +353,18 @@ def test_options_and_sticky_hip_errors(capi):
             got = run()  # ... and the context works again
             for nm_, a, b in zip(("kp", "desc", "counts", "matches", "nmatches"), ref, got):
                 np.testing.assert_array_equal(a, b, err_msg="after the failed %s: %s" % (name, nm_))
+        # An error stays with the context whose call met it (round-4 advice: the noted error used to live in a host-thread
+        # slot, so a call that returned early left it for whichever context the thread drove next): noted during a call of
+        # `ctx`, it is not seen by `other`, driven from the same thread in between, and comes back from ctx's next call.
+        with capi.Context(capi.default_params(w, h, max_images=2 * B, nfeatures=nf)) as other:
+            assert capi.lib().vsf_debug_inject_hip_error(ctx._h, 719) == capi.VSF_OK
+            other.stereo_batch_dev(d_img.data_ptr(), B, w * h, w, *[t.data_ptr() for t in bufs])
+            assert other.sync() == capi.VSF_OK and capi.lib().vsf_last_hip_error(other._h) == 0
+            with pytest.raises(capi.VsfError) as ei:
+                ctx.sync()
+            assert ei.value.status == capi.VSF_ERR_HIP and "719" in str(ei.value)
+            assert capi.lib().vsf_last_hip_error(ctx._h) == 719
+            assert ctx.sync() == capi.VSF_OK
         # (a destroyed stream cannot serve as the injected failure: ROCm 7's runtime dereferences stream handles without
         # looking them up -- hipStreamQuery and the launch path both crashed the process on one in round 4)
         ctx.set_stream(None)

@@ -423,6 +423,8 @@ struct vsf_ctx {
   // Cross-call pipelining (vsf_set_pipeline): the pyramid of call k + 1 is built on side streams, into the other of
   // two pyramid buffers, while call k's later stages still run.
   bool pipeline = false;
+  hipStream_t pipe_stream = nullptr;  // the pipelined chain's own stream when VSF_OPT_PIPE_PRIORITY asks for a priority
+  int pipe_stream_priority = 0;
   uint8_t* pyr_alt = nullptr;
   int pyr_flip = 0;
   hipEvent_t ev_pyr_done = nullptr, ev_pyr_free[2] = {nullptr, nullptr}, ev_fast_done = nullptr;
@@ -441,6 +443,7 @@ struct vsf_ctx {
   int fast_force = -1;     // vsf_tune_fast_resident only: the form of the run it is timing
   VsfTuning tuning;        // vsf_set_option
   int last_hip = 0;
+  int pending_hip = 0;  // an error noted during one of THIS context's calls that returned before checking (VsfErrorScope)
   Geometry orb, fast;
   DevSet dorb, dfast;
   int gauss[4] = {0, 0, 0, 0};
@@ -570,7 +573,9 @@ namespace {
   do {                                                             \
     hipError_t e_ = hipGetLastError();                             \
     if (e_ == hipSuccess) e_ = (hipError_t)vsf_tls_hip_error;      \
+    if (e_ == hipSuccess) e_ = (hipError_t)ctx->pending_hip;       \
     vsf_tls_hip_error = 0;                                         \
+    ctx->pending_hip = 0;                                          \
     if (e_ != hipSuccess) {                                        \
       ctx->last_hip = (int)e_;                                     \
       return VSF_ERR_HIP;                                          \
@@ -781,6 +786,7 @@ void sync_all_streams(vsf_ctx* ctx) {  // every stream the context launches on
   if (ctx->stream) vsf_note(hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream && ctx->own_stream != ctx->stream) vsf_note(hipStreamSynchronize(ctx->own_stream));
   if (ctx->aux_stream) vsf_note(hipStreamSynchronize(ctx->aux_stream));
+  if (ctx->pipe_stream) vsf_note(hipStreamSynchronize(ctx->pipe_stream));
   if (ctx->blur_stream) vsf_note(hipStreamSynchronize(ctx->blur_stream));
   for (int i = 1; i < ctx->side.n; i++)
     if (ctx->side.stream[i]) vsf_note(hipStreamSynchronize(ctx->side.stream[i]));
@@ -865,11 +871,11 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
     d.pyr = buf ? ctx->pyr_alt : ctx->dorb.d.pyr;
     // (ROCm multiplexes streams onto a few hardware queues; the context's aux stream is known to run beside the
     // main one, so the chain goes there, as a single chain)
-    hipStream_t ps = ctx->aux_stream;
+    hipStream_t ps = ctx->pipe_stream ? ctx->pipe_stream : ctx->aux_stream;
     if (ctx->pyr_free_valid[buf]) vsf_note(hipStreamWaitEvent(ps, ctx->ev_pyr_free[buf], 0));
     // ... and not before the previous call's FAST kernel has finished: FAST fills every register of the chip, the
     // stages after it (selection, descriptors, matcher) are latency-bound and leave room for the resize chain
-    if (ctx->fast_done_valid) vsf_note(hipStreamWaitEvent(ps, ctx->ev_fast_done, 0));
+    if (ctx->fast_done_valid && ctx->tuning.pipe_after_fast) vsf_note(hipStreamWaitEvent(ps, ctx->ev_fast_done, 0));
     // ... and not before images this library itself is still producing on the context's stream are complete
     if (ctx->ingest_done_valid) vsf_note(hipStreamWaitEvent(ps, ctx->ev_ingest_done, 0));
     // ... nor before the caller's own producer has finished them (vsf_set_input_event)
@@ -1043,6 +1049,11 @@ vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, 
 
 hipStream_t vsf_ctx_stream(const vsf_ctx* ctx) { return ctx->stream; }
 int vsf_ctx_device(const vsf_ctx* ctx) { return ctx->device; }
+void vsf_ctx_set_last_error(vsf_ctx* ctx, int code) { ctx->last_hip = code; }
+void vsf_ctx_absorb_noted_error(vsf_ctx* ctx) {
+  if (ctx->pending_hip == 0) ctx->pending_hip = vsf_tls_hip_error;
+  vsf_tls_hip_error = 0;
+}
 
 extern "C" {
 
@@ -1256,6 +1267,7 @@ void vsf_destroy(vsf_ctx* ctx) {
     }
   }
   if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
+  if (ctx->pipe_stream) hipStreamDestroy(ctx->pipe_stream);
   if (ctx->blur_stream) hipStreamDestroy(ctx->blur_stream);
   if (ctx->ev_blur_fork) hipEventDestroy(ctx->ev_blur_fork);
   if (ctx->ev_blur_done) hipEventDestroy(ctx->ev_blur_done);
@@ -1272,6 +1284,7 @@ vsf_status vsf_get_params(const vsf_ctx* ctx, vsf_params* out) {
 }
 
 vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   prof_fold(ctx);
@@ -1285,12 +1298,14 @@ vsf_status vsf_set_stream(vsf_ctx* ctx, void* hip_stream) {
 // Test hook: makes the context's thread behave as if a launcher had just noted HIP error `code` (vsf_note): the next entry
 // point that launches must return VSF_ERR_HIP with that code, and the one after it must work again.
 vsf_status vsf_debug_inject_hip_error(vsf_ctx* ctx, int code) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || code <= 0) return VSF_ERR_INVALID_ARG;
   vsf_note((hipError_t)code);
   return VSF_OK;
 }
 
 vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || lanes < 1 || lanes > 2) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->lanes = lanes;
@@ -1298,6 +1313,7 @@ vsf_status vsf_set_lanes(vsf_ctx* ctx, int lanes) {
 }
 
 vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->blur_overlap = on ? 1 : 0;
@@ -1305,6 +1321,7 @@ vsf_status vsf_set_blur_overlap(vsf_ctx* ctx, int on) {
 }
 
 vsf_status vsf_set_fast_resident(vsf_ctx* ctx, int waves) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || waves < -1 || waves == 1 || waves > 4) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->fast_resident = waves;
@@ -1318,6 +1335,7 @@ vsf_status vsf_get_fast_resident(const vsf_ctx* ctx, int* waves) {
 }
 
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || option < 0 || option >= VSF_OPT_COUNT) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   VsfTuning& t = ctx->tuning;
@@ -1330,6 +1348,11 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
     case VSF_OPT_SORT_SERIAL: t.sort_serial = value != 0; break;
     case VSF_OPT_SELECT_WIDE: t.select_wide = value != 0; break;
     case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
+    case VSF_OPT_PIPE_AFTER_FAST: t.pipe_after_fast = value != 0; break;
+    case VSF_OPT_PIPE_PRIORITY:
+      if (value < -1 || value > 1) return VSF_ERR_INVALID_ARG;
+      t.pipe_priority = value;  // (takes effect with the next vsf_set_pipeline(ctx, 1))
+      break;
     case VSF_OPT_JPEG_SERIAL:
       if (!value && vsf_prepare_jpeg_kernels(t.lds_limit) != hipSuccess) {  // (the parallel decoder's LDS was refused)
         (void)hipGetLastError();
@@ -1364,6 +1387,8 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
     case VSF_OPT_SORT_SERIAL: *value = t.sort_serial; break;
     case VSF_OPT_SELECT_WIDE: *value = t.select_wide; break;
     case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
+    case VSF_OPT_PIPE_AFTER_FAST: *value = t.pipe_after_fast; break;
+    case VSF_OPT_PIPE_PRIORITY: *value = t.pipe_priority; break;
     case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
     case VSF_OPT_PYRAMID_CHAIN: *value = t.pyramid_chain; break;
@@ -1374,10 +1399,24 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
 }
 
 vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
-  VSF_HIP(hipStreamSynchronize(ctx->aux_stream));  // (the pipelined pyramid chain runs there)
+  VSF_HIP(hipStreamSynchronize(ctx->aux_stream));  // (the pipelined pyramid chain runs there ...
+  if (ctx->pipe_stream) VSF_HIP(hipStreamSynchronize(ctx->pipe_stream));  // ... or on a stream of its own priority)
+  if (on && ctx->tuning.pipe_priority != ctx->pipe_stream_priority) {
+    if (ctx->pipe_stream) VSF_HIP(hipStreamDestroy(ctx->pipe_stream));
+    ctx->pipe_stream = nullptr;
+    ctx->pipe_stream_priority = 0;
+    if (ctx->tuning.pipe_priority != 0) {
+      int least = 0, greatest = 0;
+      VSF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      VSF_HIP(hipStreamCreateWithPriority(&ctx->pipe_stream, hipStreamNonBlocking,
+                                          ctx->tuning.pipe_priority > 0 ? least : greatest));
+      ctx->pipe_stream_priority = ctx->tuning.pipe_priority;
+    }
+  }
   if (on && !ctx->pyr_alt) {
     VSF_HIP(hipMalloc((void**)&ctx->pyr_alt, (size_t)ctx->p.max_images * ctx->orb.g.pyr_bytes));
     VSF_HIP(hipEventCreateWithFlags(&ctx->ev_pyr_done, hipEventDisableTiming));
@@ -1391,6 +1430,7 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
 }
 
 vsf_status vsf_sync(vsf_ctx* ctx) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   const vsf_status st = check_status_word(ctx);
   if (!ctx->retired.empty()) {  // scratch a *_dev call outgrew: nothing can be using it once every stream is idle
@@ -1401,12 +1441,14 @@ vsf_status vsf_sync(vsf_ctx* ctx) {
 }
 
 vsf_status vsf_set_input_event(vsf_ctx* ctx, void* hip_event) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   ctx->input_event = static_cast<hipEvent_t>(hip_event);
   return VSF_OK;
 }
 
 vsf_status vsf_reserve(vsf_ctx* ctx, int n_frames, int n_pairs) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || n_frames < 1 || n_pairs < 0) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   sync_all_streams(ctx);
@@ -1447,6 +1489,7 @@ uint64_t vsf_algorithmic_bytes_per_image(const vsf_ctx* ctx) {
 
 vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
                                  size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_kp || !d_desc || !d_counts) return VSF_ERR_INVALID_ARG;
   vsf_status st = validate_images(ctx, d_imgs, n_images, image_stride, row_stride);
   if (st != VSF_OK) return st;
@@ -1459,6 +1502,7 @@ vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_imag
 vsf_status vsf_tune_fast_resident(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
                                   size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
                                   int samples, float* ms_grid, float* ms_resident) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_kp || !d_desc || !d_counts || samples < 1 || samples > 64 || !ms_grid || !ms_resident)
     return VSF_ERR_INVALID_ARG;
   *ms_grid = *ms_resident = 0.f;
@@ -1508,6 +1552,7 @@ vsf_status vsf_tune_fast_resident(vsf_ctx* ctx, const uint8_t* d_imgs, int n_ima
 vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
                                const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs, int32_t* d_idx2,
                                int32_t* d_dist2, vsf_dmatch* d_matches, int32_t* d_nmatches) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_desc || !d_counts || n_pairs < 1 || !d_matches || !d_nmatches || (set_stride & 15))
     return VSF_ERR_INVALID_ARG;
   if ((d_idx2 == nullptr) != (d_dist2 == nullptr) || (d_q_set == nullptr) != (d_t_set == nullptr))
@@ -1529,6 +1574,7 @@ vsf_status vsf_match_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_
 }
 
 vsf_status vsf_profile_enable(vsf_ctx* ctx, int on) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   sync_all_streams(ctx);
   prof_fold(ctx);
@@ -1537,6 +1583,7 @@ vsf_status vsf_profile_enable(vsf_ctx* ctx, int on) {
 }
 
 vsf_status vsf_profile_read(vsf_ctx* ctx, double* ms_total, int64_t* launches, int reset) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !ms_total || !launches) return VSF_ERR_INVALID_ARG;
   sync_all_streams(ctx);
   prof_fold(ctx);
@@ -1560,6 +1607,7 @@ const char* vsf_stage_name(int stage) {
 vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frames, size_t image_stride,
                                 size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
                                 vsf_dmatch* d_matches, int32_t* d_nmatches) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || n_frames < 1 || !d_kp || !d_desc || !d_counts || !d_matches || !d_nmatches) return VSF_ERR_INVALID_ARG;
   vsf_status st = validate_images(ctx, d_imgs, 2 * n_frames, image_stride, row_stride);
   if (st != VSF_OK) return st;
@@ -1588,6 +1636,7 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
                                              const float* F, float thr_in, const float* d_thr_override,
                                              float* d_means, float* d_thr, vsf_keypoint* d_kp_out,
                                              uint8_t* d_desc_out, int32_t* d_counts_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_kp || !d_desc || !d_matches || !d_nmatches || n_frames < 1 || !F || !d_means || !d_kp_out ||
       !d_desc_out || !d_counts_out || (!d_thr_override && !d_thr))
     return VSF_ERR_INVALID_ARG;
@@ -1605,6 +1654,7 @@ vsf_status vsf_remove_ambig_stereo_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d
 
 vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, const vsf_dmatch* d_matches,
                                           const int32_t* d_nmatches, int n_frames, const float* F, float* d_means) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_kp || !d_matches || !d_nmatches || n_frames < 1 || !F || !d_means) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   vsf_status st = ensure_residual_buffers(ctx, n_frames);
@@ -1619,6 +1669,7 @@ vsf_status vsf_stereo_residuals_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp
 }
 
 vsf_status vsf_stereo_thresholds_dev(vsf_ctx* ctx, const float* d_means, int n, float* d_thr_state, float* d_thr) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_means || n < 1 || !d_thr_state || !d_thr) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   {
@@ -1633,6 +1684,7 @@ vsf_status vsf_stereo_filter_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, c
                                        const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_frames,
                                        const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
                                        int32_t* d_counts_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_kp || !d_desc || !d_matches || !d_nmatches || n_frames < 1 || !d_thr || !d_kp_out || !d_desc_out ||
       !d_counts_out)
     return VSF_ERR_INVALID_ARG;
@@ -1650,6 +1702,7 @@ vsf_status vsf_stereo_filter_batch_dev(vsf_ctx* ctx, const vsf_keypoint* d_kp, c
 vsf_status vsf_vision_features_batch_dev(vsf_ctx* ctx, const vsf_calibration* calib, const vsf_keypoint* d_kp,
                                          const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
                                          vsf_vision_feature* d_features, int32_t* d_nfeatures, int32_t* d_npoints) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !calib || !d_kp || !d_desc || !d_counts || n_frames < 1 || !d_features || !d_nfeatures)
     return VSF_ERR_INVALID_ARG;
   if (calib->triangulate_rows != 0 && calib->triangulate_rows != 4 && calib->triangulate_rows != 6)
@@ -1683,6 +1736,7 @@ size_t vsf_packed_outputs_capacity(const vsf_ctx* ctx, int n_frames, int n_pairs
 vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_features, const int32_t* d_nfeatures,
                                 int n_frames, const uint64_t* d_pairs, const int32_t* d_npairs, int n_pairs,
                                 uint8_t* d_payload, size_t payload_cap) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || n_frames < 0 || n_pairs < 0 || n_frames + n_pairs < 1 || (n_frames > 0 && (!d_features || !d_nfeatures)) ||
       (n_pairs > 0 && (!d_pairs || !d_npairs)) || !d_payload || ((uintptr_t)d_payload & 3) ||
       payload_cap < 16 + 4 * ((size_t)n_frames + n_pairs))
@@ -1706,6 +1760,7 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
 vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, int n_images, int width, int height,
                                           size_t src_image_stride, size_t src_row_stride, uint8_t* d_dst,
                                           size_t dst_image_stride, size_t dst_row_stride) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_src || !d_dst || n_images < 1 || width < 1 || height < 1 || width > 16384 || height > 65535 ||
       n_images > 65535)
     return VSF_ERR_INVALID_ARG;
@@ -1728,6 +1783,7 @@ vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, in
 vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, const size_t* nbytes, int n_images,
                                       int width, int height, uint8_t* d_dst, size_t dst_image_stride,
                                       size_t dst_row_stride) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !jpeg || !nbytes || n_images < 1 || n_images > 65535 || width < 1 || height < 1 || width > 65535 ||
       height > 65535 || !d_dst)
     return VSF_ERR_INVALID_ARG;
@@ -1801,6 +1857,7 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
 vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
                                          size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
                                          int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !d_pairs || !d_npairs || n_pairs < 1 || !(best_percent >= 0.f)) return VSF_ERR_INVALID_ARG;
   if (ctx->p.max_keypoints >= 65536) return VSF_ERR_UNSUPPORTED;  // (query, train) indices are packed 16 + 16 bit
   VSF_HIP(hipSetDevice(ctx->device));
@@ -1886,6 +1943,7 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
 }
 
 vsf_status vsf_observe_reset(vsf_ctx* ctx) {
+  VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   for (int i = 0; i < 3; i++)
@@ -1897,6 +1955,7 @@ vsf_status vsf_observe_reset(vsf_ctx* ctx) {
 
 vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, int64_t* ticket) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !left || !right || !calib || !ticket || !(best_percent >= 0.f) || frame_life < 0 ||
       frame_life + 1 > VSF_OBSERVE_MAX_PAIRS)
     return VSF_ERR_INVALID_ARG;
@@ -2046,6 +2105,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
 }
 
 vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_t cap, size_t* out_bytes) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !out || !out_bytes || ticket < 0) return VSF_ERR_INVALID_ARG;
   *out_bytes = 0;
   vsf_ctx::Observe& o = ctx->ob;
@@ -2071,6 +2131,7 @@ vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_
 vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
                               size_t cap, size_t* out_bytes) {
+  VsfErrorScope scope_(ctx);
   if (!out || !out_bytes) return VSF_ERR_INVALID_ARG;
   *out_bytes = 0;
   int64_t ticket = -1;
@@ -2090,6 +2151,7 @@ static vsf_status upload_image(vsf_ctx* ctx, const uint8_t* img, int w, int h, s
 
 vsf_status vsf_extract(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, vsf_keypoint* kp_out,
                        uint8_t* desc_out, int cap, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n_out || cap < 0 || (cap > 0 && (!kp_out || !desc_out))) return VSF_ERR_INVALID_ARG;
   *n_out = 0;
   VSF_HIP(hipSetDevice(ctx->device));
@@ -2114,6 +2176,7 @@ vsf_status vsf_extract(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t st
 vsf_status vsf_extract_pair(vsf_ctx* ctx, const uint8_t* img0, const uint8_t* img1, int w, int h, size_t stride,
                             vsf_keypoint* kp0, uint8_t* desc0, int* n0, vsf_keypoint* kp1, uint8_t* desc1, int* n1,
                             int cap) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n0 || !n1 || cap < 0 || (cap > 0 && (!kp0 || !desc0 || !kp1 || !desc1))) return VSF_ERR_INVALID_ARG;
   *n0 = *n1 = 0;
   if (ctx->p.max_images < 2) return VSF_ERR_INVALID_ARG;
@@ -2146,6 +2209,7 @@ vsf_status vsf_extract_pair(vsf_ctx* ctx, const uint8_t* img0, const uint8_t* im
 
 vsf_status vsf_fast_detect(vsf_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int threshold, int nms,
                            vsf_keypoint* kp_out, int cap, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n_out || cap < 0 || (cap > 0 && !kp_out)) return VSF_ERR_INVALID_ARG;
   *n_out = 0;
   VSF_HIP(hipSetDevice(ctx->device));
@@ -2245,6 +2309,7 @@ static vsf_status match_host(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8
 
 vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const int* nq, int n_sets, const uint8_t* t,
                                  int nt, vsf_dmatch* out, int cap_per_set, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || n_sets < 1 || !q || !nq || !n_out || cap_per_set < 0 || (cap_per_set > 0 && !out) || nt < 0 ||
       (nt > 0 && !t) || nt >= (1 << 20))
     return VSF_ERR_INVALID_ARG;
@@ -2319,12 +2384,14 @@ vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const in
 
 vsf_status vsf_knn2_hamming(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,
                             int32_t* dist2) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || (nq > 0 && (!idx2 || !dist2))) return VSF_ERR_INVALID_ARG;
   return match_host(ctx, q, nq, t, nt, idx2, dist2, nullptr, 0, nullptr);
 }
 
 vsf_status vsf_get_matches(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, vsf_dmatch* out,
                            int cap, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n_out || cap < 0 || (cap > 0 && !out)) return VSF_ERR_INVALID_ARG;
   vsf_dmatch dummy;
   return match_host(ctx, q, nq, t, nt, nullptr, nullptr, out ? out : &dummy, cap, n_out);
@@ -2334,6 +2401,7 @@ vsf_status vsf_get_matches(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8_t
 
 vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids, int n, int n_points, int use_lds,
                                  int mode, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n_out || n < 0 || (n > 0 && (!key_bits || !ids))) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   std::vector<uint2> h((size_t)std::max(n, 1));
@@ -2365,6 +2433,7 @@ vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids
 
 vsf_status vsf_debug_sort_trim(vsf_ctx* ctx, const vsf_dmatch* matches, int n_lists, int n, float best_percent,
                                int serial, uint64_t* pairs_out, int32_t* counts_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !matches || !pairs_out || !counts_out || n_lists < 1 || n < 0 || n > ctx->p.max_keypoints)
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
@@ -2404,6 +2473,7 @@ vsf_status vsf_debug_sort_trim(vsf_ctx* ctx, const vsf_dmatch* matches, int n_li
 }
 
 vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t ostride) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
       level >= ctx->orb.g.nlevels)
     return VSF_ERR_INVALID_ARG;
@@ -2433,6 +2503,7 @@ vsf_status vsf_debug_level_image(vsf_ctx* ctx, int image, int level, int blurred
 }
 
 vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n_out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
       level >= ctx->orb.g.nlevels)
     return VSF_ERR_INVALID_ARG;
@@ -2470,6 +2541,7 @@ vsf_status vsf_debug_fast_candidates(vsf_ctx* ctx, int image, int level, vsf_key
 }
 
 vsf_status vsf_debug_level_keypoints(vsf_ctx* ctx, int image, int level, vsf_keypoint* kp_out, int cap, int* n_out) {
+  VsfErrorScope scope_(ctx);
   if (!ctx || !n_out || !ctx->last_valid || image < 0 || image >= ctx->last_images.n || level < 0 ||
       level >= ctx->orb.g.nlevels)
     return VSF_ERR_INVALID_ARG;

@@ -92,6 +92,8 @@ struct VsfTuning {
   int fast_both_max = 16;  // VSF_OPT_FAST_BOTH_MAX: largest batch (images) whose full and half-wave FAST cells share one launch
   int sort_serial = 0;     // VSF_OPT_SORT_SERIAL: 1 = sort_trim's one-lane kernel
   int select_wide = 1;     // VSF_OPT_SELECT_WIDE: 1 = a frame or two takes the 1024-thread whole-level selection class
+  int pipe_priority = 0;     // VSF_OPT_PIPE_PRIORITY: stream priority of the pipelined pyramid chain (0 normal, 1 lowest, -1 highest)
+  int pipe_after_fast = 1;   // VSF_OPT_PIPE_AFTER_FAST: the pipelined pyramid of call k + 1 starts behind call k's FAST (1) or at once (0)
   int select_big_class = 1;  // VSF_OPT_SELECT_BIG_CLASS: 1 = the widest levels of a batch take the 9 216-entry class
   int jpeg_serial = 0;     // VSF_OPT_JPEG_SERIAL: 1 = every file through the one-wave-per-image decoder
   int pyramid_few = 16;    // VSF_OPT_PYRAMID_FEW: largest batch (images) that takes the slab kernel for every level

@@ -492,7 +492,7 @@ class ShardedStereoFrontend:
             self.tail_ctx = None
 
     # ---- the one measured launch choice, made the same on every rank ----
-    def tune(self, d_img, samples: int = 3, steps: int = 0) -> dict:
+    def tune(self, d_img, samples: int = 3, steps: int = 0, step_fn=None) -> dict:
         """Explicit and blocking (set-up, never inside a timed region): vsf_tune_fast_resident times the two forms of the
         FAST launch on this rank's own batch (median of `samples` runs each), then ONE all-reduce (max over ranks) of the
         two medians makes the choice common: the step time of the job is its slowest rank's, and ranks that ran different
@@ -502,7 +502,8 @@ class ShardedStereoFrontend:
         timed ones per form, on `d_img` (a batch, or a list of batches taken in turn as the caller's own loop will) -- because
         what the form is worth shows in the composed, pipelined step (the blur beside FAST, the next step's pyramid beside
         this step's tail), where it is twice what an extraction by itself shows; an ineligible batch (the library reports
-        0 / 0: fewer than 32 images, blur in line) runs no steps.  The tuning steps are real step() calls; reset() afterwards
+        0 / 0: fewer than 32 images, blur in line) runs no steps.  step_fn: the caller's own way to run one step (a callable
+        that ends in self.step(...), e.g. with frames arriving from a decoder) instead of self.step(batch).  The tuning steps are real step() calls; reset() afterwards
         puts the threshold chain, the step counter and the gather bookkeeping back, so the run that follows produces the
         same bytes as one without tune (tests/test_gpu_sharded.py::test_tune_steps_leave_no_trace)."""
         batches = list(d_img) if isinstance(d_img, (list, tuple)) else [d_img]
@@ -517,11 +518,13 @@ class ShardedStereoFrontend:
             per_form = []
             for form in (0, 3):
                 self.ctx.set_fast_resident(form)
-                self.step(batches[-1])
+                one = (lambda i: step_fn()) if step_fn is not None else (lambda i: self.step(batches[i % len(batches)]))
+                for i in range(1 if step_fn is None else 3):  # (a decoder in front of the step takes three steps to fill)
+                    one(-1 - i)
                 self.drain()
                 t0 = time.perf_counter()
                 for i in range(steps):
-                    self.step(batches[i % len(batches)])
+                    one(i)
                 self.drain()
                 per_form.append(1e3 * (time.perf_counter() - t0) / steps)
             g, r = per_form
