@@ -113,9 +113,9 @@ def _same_observation(a: dict, b: dict):
             assert va == vb, k
 
 
-@pytest.mark.parametrize("slots", [2, 3])
+@pytest.mark.parametrize("slots", [2, 3, 4, 6])
 def test_frames_in_flight_equal_the_synchronous_calls(slots):
-    """vsf_observe_submit / vsf_observe_collect with two / three frames in flight (contexts with max_images = 4 / 6: every
+    """vsf_observe_submit / vsf_observe_collect with two to six frames in flight (contexts with max_images = 2 x slots: every
     frame on its slot's stream, the tails chained by events) return, frame for frame and byte for byte, what the
     synchronous vsf_observe_stereo returns -- across the window filling and sliding, the frame without stereo matches and
     the NaN threshold after it, whose state travels from tail to tail on the device."""

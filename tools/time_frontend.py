@@ -18,7 +18,7 @@ _FRAMES = {}
 
 
 def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 56, width: int = 640, height: int = 480,
-                     pipelined: bool = False):
+                     pipelined: bool = False, in_flight: int = 0):
     """Median ObserveImage time in ms in the steady state (the window of 10 kept frames is full; the first 32 calls are
     left out).  pipelined: the call returns once the frame is queued, so the per-call time is host work only; the
     frames-per-second figure is the wall time of the steady-state calls INCLUDING the final flush."""
@@ -32,6 +32,8 @@ def observe_image_ms(nfeatures: int, fused: bool = True, n_frames: int = 56, wid
     fe = frontend.Frontend(width, height, nfeatures=nfeatures, fundamental=F)
     fe.set_fused(fused)
     fe.set_pipelined(pipelined)
+    if in_flight:
+        fe.set_frames_in_flight(in_flight)
     q = np.array([1, 0, 0, 0], np.float32)
     fe.observe_odometry([0, 0, 0], q, 0.0)
     ts = []

@@ -509,16 +509,16 @@ struct vsf_ctx {
     // previous frame's tail (an event), so the tails -- which carry the threshold and the temporal window from frame to
     // frame -- run in frame order and their buffers exist once.
     int slots = 1;
-    uint8_t* h_img[3] = {nullptr, nullptr, nullptr};       // pinned: both images at the staging pitch
-    uint8_t* h_out[3] = {nullptr, nullptr, nullptr};       // pinned, written by observe_pack_kernel
+    uint8_t* h_img[VSF_OBSERVE_MAX_SLOTS] = {};       // pinned: both images at the staging pitch
+    uint8_t* h_out[VSF_OBSERVE_MAX_SLOTS] = {};       // pinned, written by observe_pack_kernel
     size_t out_cap = 0;
-    ObserveMeta* h_meta[3] = {nullptr, nullptr, nullptr};
-    int32_t* h_status[3] = {nullptr, nullptr, nullptr};    // pinned copy of the status word after the frame's last kernel
-    hipStream_t ex_stream[3] = {nullptr, nullptr, nullptr};  // the stream of slot i (a one-slot context: ctx->stream)
-    hipEvent_t ev_done[3] = {nullptr, nullptr, nullptr};
-    VsfSideStream side[3] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
-    bool done_valid[3] = {false, false, false};
-    int64_t ticket_of[3] = {-1, -1, -1};  // submitted and not yet collected
+    ObserveMeta* h_meta[VSF_OBSERVE_MAX_SLOTS] = {};
+    int32_t* h_status[VSF_OBSERVE_MAX_SLOTS] = {};    // pinned copy of the status word after the frame's last kernel
+    hipStream_t ex_stream[VSF_OBSERVE_MAX_SLOTS] = {};  // the stream of slot i (a one-slot context: ctx->stream)
+    hipEvent_t ev_done[VSF_OBSERVE_MAX_SLOTS] = {};
+    VsfSideStream side[VSF_OBSERVE_MAX_SLOTS] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
+    bool done_valid[VSF_OBSERVE_MAX_SLOTS] = {};
+    int64_t ticket_of[VSF_OBSERVE_MAX_SLOTS] = {-1, -1, -1, -1, -1, -1};  // submitted and not yet collected
     int64_t next_ticket = 0;
     std::vector<int> order;         // ring slots of the kept frames, oldest first
   } ob;
@@ -744,7 +744,7 @@ void free_observe(vsf_ctx* ctx) {
   hipFree(o.features);
   hipFree(o.pairs);
   hipFree(o.npairs);
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < VSF_OBSERVE_MAX_SLOTS; i++) {
     if (o.h_img[i]) hipHostFree(o.h_img[i]);
     if (o.h_out[i]) hipHostFree(o.h_out[i]);
     if (o.h_meta[i]) hipHostFree(o.h_meta[i]);
@@ -790,7 +790,7 @@ void sync_all_streams(vsf_ctx* ctx) {  // every stream the context launches on
   if (ctx->blur_stream) vsf_note(hipStreamSynchronize(ctx->blur_stream));
   for (int i = 1; i < ctx->side.n; i++)
     if (ctx->side.stream[i]) vsf_note(hipStreamSynchronize(ctx->side.stream[i]));
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < VSF_OBSERVE_MAX_SLOTS; i++)
     if (ctx->ob.ex_stream[i] && ctx->ob.ex_stream[i] != ctx->stream) vsf_note(hipStreamSynchronize(ctx->ob.ex_stream[i]));
 }
 
@@ -1157,8 +1157,8 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
     if (hipEventCreateWithFlags(&ctx->side.join[i], hipEventDisableTiming) != hipSuccess) return fail(VSF_ERR_HIP);
     ctx->side.n = i + 1;
   }
-  if (hipMalloc((void**)&ctx->d_status, 4 * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
-  if (hipMemset(ctx->d_status, 0, 4 * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMalloc((void**)&ctx->d_status, (1 + VSF_OBSERVE_MAX_SLOTS) * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMemset(ctx->d_status, 0, (1 + VSF_OBSERVE_MAX_SLOTS) * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   {
     // Three kernels ask for more dynamic LDS than the default 64 KB (the parallel sort of GetFeatureMatches, the slab
     // pyramid, the parallel JPEG decode): how much a workgroup of this device may have is asked once, their limits are
@@ -1890,21 +1890,21 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   vsf_ctx::Observe& o = ctx->ob;
   if (o.ring && o.frame_life == frame_life) return VSF_OK;
   VSF_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < VSF_OBSERVE_MAX_SLOTS; i++)
     if (o.ex_stream[i]) VSF_HIP(hipStreamSynchronize(o.ex_stream[i]));
   float thr_state = 10000.0f;  // cc:353
   const bool had = o.floats != nullptr;
   if (had) VSF_HIP(hipMemcpy(&thr_state, o.floats + 2, sizeof(float), hipMemcpyDeviceToHost));
   free_observe(ctx);
   const size_t K = (size_t)ctx->p.max_keypoints, S = (size_t)frame_life + 2;
-  o.slots = ctx->p.max_images >= 6 ? 3 : (ctx->p.max_images >= 4 ? 2 : 1);
+  o.slots = std::max(1, std::min(ctx->p.max_images / 2, VSF_OBSERVE_MAX_SLOTS));
   VSF_HIP(hipMalloc((void**)&o.ring, S * K * VSF_DESC_BYTES));
   VSF_HIP(hipMalloc((void**)&o.ring_counts, S * sizeof(int32_t)));
   VSF_HIP(hipMemset(o.ring_counts, 0, S * sizeof(int32_t)));
   VSF_HIP(hipMalloc((void**)&o.kpf, 2 * K * sizeof(vsf_keypoint)));
-  VSF_HIP(hipMalloc((void**)&o.matches, 3 * K * sizeof(vsf_dmatch)));
-  VSF_HIP(hipMalloc((void**)&o.ints, 8 * sizeof(int32_t)));  // [0..2] raw stereo matches per slot, [4] features, [5] points
-  VSF_HIP(hipMemset(o.ints, 0, 8 * sizeof(int32_t)));
+  VSF_HIP(hipMalloc((void**)&o.matches, VSF_OBSERVE_MAX_SLOTS * K * sizeof(vsf_dmatch)));
+  VSF_HIP(hipMalloc((void**)&o.ints, 16 * sizeof(int32_t)));  // [0..5] raw stereo matches per slot, [8] features, [9] points
+  VSF_HIP(hipMemset(o.ints, 0, 16 * sizeof(int32_t)));
   VSF_HIP(hipMalloc((void**)&o.floats, 4 * sizeof(float)));
   const float f4[4] = {0.f, 0.f, thr_state, 0.f};
   VSF_HIP(hipMemcpy(o.floats, f4, sizeof(f4), hipMemcpyHostToDevice));
@@ -1929,14 +1929,16 @@ static vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
     } else {
       int prio_lo = 0, prio_hi = 0;
       VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      const int prio = i == 0 ? prio_hi : (i == 1 ? prio_lo : (prio_lo + prio_hi) / 2);
+      // (a fourth to sixth slot repeats the three priorities: it may share a hardware queue with an earlier slot -- then
+      // those two take turns -- or land on a queue of its own)
+      const int prio = i % 3 == 0 ? prio_hi : (i % 3 == 1 ? prio_lo : (prio_lo + prio_hi) / 2);
       VSF_HIP(hipStreamCreateWithPriority(&o.ex_stream[i], hipStreamNonBlocking, prio));
     }
     VSF_HIP(hipEventCreateWithFlags(&o.ev_done[i], hipEventDisableTiming));
   }
   o.frame_life = frame_life;
   // matcher scratch: pairs [0, frame_life] belong to the tail, pair frame_life + 1 + slot to the slot's stereo match
-  vsf_status st = ensure_match_buffers(ctx, frame_life + 1 + 3, (int)K);
+  vsf_status st = ensure_match_buffers(ctx, frame_life + 1 + VSF_OBSERVE_MAX_SLOTS, (int)K);
   if (st == VSF_OK) st = ensure_temporal_buffers(ctx, frame_life + 1);
   if (st == VSF_OK) st = ensure_residual_buffers(ctx, 1);
   return st;
@@ -1946,7 +1948,7 @@ vsf_status vsf_observe_reset(vsf_ctx* ctx) {
   VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < VSF_OBSERVE_MAX_SLOTS; i++)
     if (ctx->ob.ex_stream[i]) VSF_HIP(hipStreamSynchronize(ctx->ob.ex_stream[i]));
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   free_observe(ctx);
@@ -1966,7 +1968,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
   if (ctx->ob.ring && ctx->ob.frame_life != frame_life)  // (re-sizing the window drops nothing that is still in flight)
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < VSF_OBSERVE_MAX_SLOTS; i++)
       if (ctx->ob.ticket_of[i] >= 0) return VSF_ERR_INVALID_ARG;
   vsf_status st = ensure_observe(ctx, frame_life);
   if (st != VSF_OK) return st;
@@ -2051,7 +2053,7 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
     vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, Kc, best_percent, M.best_percent, ctx->t_sortkeys,
                          o.pairs, o.npairs, s, ctx->tuning.sort_serial != 0, ctx->tuning.lds_limit);
     // ---- Calculate3DPoints + VisionFeature + UndistortFeaturePoints (cc:437-443) ----
-    int32_t *nfeat = o.ints + 4, *npoints = o.ints + 5;
+    int32_t *nfeat = o.ints + 8, *npoints = o.ints + 9;
     vsf_launch_vision_features(o.kpf, cur_counts, o.pairs + (size_t)n_past * K * 2, o.npairs + n_past, 1, Kc, *calib,
                                o.features, nfeat, npoints, s);
     // ---- the compact result into pinned memory; the filtered left frame into its ring slot (cc:467-470) ----

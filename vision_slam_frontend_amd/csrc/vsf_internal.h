@@ -224,6 +224,7 @@ void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches
                           int32_t* d_npairs, hipStream_t s, bool force_serial = false, int lds_limit = 160 * 1024);
 // vsf_observe_stereo's output kernel (k_frontend.hip)
 #define VSF_OBSERVE_MAX_PAIRS 64
+#define VSF_OBSERVE_MAX_SLOTS 6  // frames vsf_observe_submit may keep in flight (max_images / 2 of them, at most this many)
 struct VsfObserveArgs {
   int n_pairs, max_rows;
   const int32_t* counts_raw;          // [2] keypoints of the left / right image

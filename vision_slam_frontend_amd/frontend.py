@@ -46,6 +46,8 @@ def lib() -> C.CDLL:
         L.vsfh_set_fused.restype = None
         L.vsfh_set_pipelined.argtypes = [vp, i32]
         L.vsfh_set_pipelined.restype = None
+        L.vsfh_set_frames_in_flight.argtypes = [vp, i32]
+        L.vsfh_set_frames_in_flight.restype = None
         L.vsfh_flush.argtypes = [vp]
         _lib = L
     return _lib
@@ -82,6 +84,10 @@ class Frontend:
         are collected and booked, in frame order, two frames later or when the problem is read.  Fused mode; choose before the
         first observe_image."""
         lib().vsfh_set_pipelined(self._h, int(on))
+
+    def set_frames_in_flight(self, n: int):
+        """How many frames a pipelined Frontend keeps in flight (1..6; default 4).  Choose before the first observe_image."""
+        lib().vsfh_set_frames_in_flight(self._h, int(n))
 
     def flush(self) -> bool:
         """Collects and books every frame still in flight."""

@@ -28,6 +28,7 @@ void vsfh_default_calibration(vsf_calibration* out) { *out = slam::MakeCalibrati
 
 void vsfh_set_fused(void* f, int on) { static_cast<Frontend*>(f)->set_fused(on != 0); }
 void vsfh_set_pipelined(void* f, int on) { static_cast<Frontend*>(f)->set_pipelined(on != 0); }
+void vsfh_set_frames_in_flight(void* f, int n) { static_cast<Frontend*>(f)->set_frames_in_flight(n); }
 int vsfh_flush(void* f) { return static_cast<Frontend*>(f)->Flush() ? 1 : 0; }
 
 void vsfh_frontend_destroy(void* f) { delete static_cast<Frontend*>(f); }

@@ -238,7 +238,7 @@ bool Frontend::EnsureContext(int width, int height) {
   if (ctx_) {
     vsf_params p;
     vsf_get_params(ctx_, &p);
-    if (p.width == width && p.height == height && p.max_images >= (pipelined_ ? 6 : 2)) return true;
+    if (p.width == width && p.height == height && p.max_images >= 2 * frames_in_flight()) return true;
     // the context is replaced (another image size, or pipelining switched on): the frames still in flight belong to the
     // old one and are booked first, in order; whatever that returns, their tickets die with the context
     Flush();
@@ -247,7 +247,7 @@ bool Frontend::EnsureContext(int width, int height) {
     ctx_ = nullptr;
   }
   vsf_params p;
-  vsf_params_default(&p, width, height, pipelined_ ? 6 : 2);  // three frames in flight need three slots of buffers
+  vsf_params_default(&p, width, height, 2 * frames_in_flight());  // a slot of buffers (two images) per frame in flight
   p.nfeatures = config_.orb_nfeatures;
   p.residual_order = config_.residual_order;
   last_status_ = vsf_params_set_ratio(&p, config_.nn_match_ratio_);
@@ -542,8 +542,8 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
     return false;
   }
   const vsf_calibration calib = MakeCalibration(config_);
-  // the slot this frame goes into must be free: with three frames in flight, the oldest is collected and booked first
-  while (pending_.size() >= (pipelined_ ? 3u : 1u))
+  // the slot this frame goes into must be free: with every slot in flight, the oldest is collected and booked first
+  while ((int)pending_.size() >= frames_in_flight())
     if (!RetireOldest()) return false;
   PendingFrame pf;
   last_status_ = vsf_observe_submit(ctx_, left_image.data, right_image.data, left_image.cols, left_image.rows,

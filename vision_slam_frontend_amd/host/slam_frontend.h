@@ -119,6 +119,10 @@ class Frontend {
   // when anything reads the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and
   // bytes as the synchronous mode; a GPU failure then surfaces in last_status() one or two calls late.
   void set_pipelined(bool on) { pipelined_ = on; }
+  // How many frames ObserveImage keeps in flight when pipelined (1..6, default 4): each runs its ~25 dependent small
+  // kernels on a stream and a set of buffers of its own; their tails stay in frame order.
+  void set_frames_in_flight(int n) { depth_ = n < 1 ? 1 : (n > 6 ? 6 : n); }
+  int frames_in_flight() const { return pipelined_ ? depth_ : 1; }
   bool Flush();  // collects and books every frame still in flight; false (and last_status()) if one of them failed
   float stereo_ambig_constraint() const { Sync(); return stereo_ambig_constraint_; }
   const std::vector<Frame>& frame_list() const { Sync(); return frame_list_; }
@@ -173,7 +177,8 @@ class Frontend {
   float stereo_ambig_constraint_;
   bool fused_;
   bool pipelined_;
-  std::vector<PendingFrame> pending_;  // oldest first; at most three
+  int depth_ = 4;
+  std::vector<PendingFrame> pending_;  // oldest first; at most frames_in_flight()
   std::vector<uint8_t> observe_buf_;
   vsf_ctx* ctx_;
   int device_;
