@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Step 1 of the OpenCV pin kit (tools/pin_with_opencv.cc): writes every input the kit runs through OpenCV into one
-directory as .npy files, plus cases.txt (`<case> <nfeatures> <left file> <right file>` per line) and the calibration
+directory as .npy files, plus cases.txt (`<case> <nfeatures> <left file> <right file> <full|digest>` per line) and the calibration
 matrices of the default FrontendConfig (slam_frontend.cc:565-634 as vision_slam_frontend_amd/frontend.py holds them).
 
     python3 tools/pin_inputs.py <out dir>
@@ -80,11 +80,13 @@ def main():
     np.save(out / "projection_right.npy", cal["projection_right"].reshape(3, 4))
     np.save(out / "camera_matrix_left.npy", cal["camera_matrix_left"].reshape(3, 3))
     np.save(out / "distortion_left.npy", cal["distortion_left"].reshape(5, 1))
-    lines = ["# case nfeatures left right   (tools/pin_inputs.py)"]
+    lines = ["# case nfeatures left right full|digest   (tools/pin_inputs.py)"]
     for name, nf, left, right in cases():
         np.save(out / (name + "__left.npy"), np.ascontiguousarray(left, np.uint8))
         np.save(out / (name + "__right.npy"), np.ascontiguousarray(right, np.uint8))
-        lines.append("%s %d %s__left.npy %s__right.npy" % (name, nf, name, name))
+        # the small cases keep their whole pyramids in the output (pixel-level diagnosis); the others per-level digests
+        detail = "full" if left.size <= 322 * 242 else "digest"
+        lines.append("%s %d %s__left.npy %s__right.npy %s" % (name, nf, name, name, detail))
         print("%-48s %4dx%-4d nfeatures %d" % (name, left.shape[1], left.shape[0], nf))
     (out / "cases.txt").write_text("\n".join(lines) + "\n")
     print("wrote %d cases to %s" % (len(lines) - 1, out))

@@ -83,10 +83,19 @@ void save_u8_rows(const std::string& path, const cv::Mat& m) {  // 2-D uint8, ro
   pin_npy::write(path, "|u1", {(size_t)m.rows, (size_t)m.cols}, buf.data(), buf.size());
 }
 
+// Position-dependent checksum of a level's bytes (tests/pin_compare.py: level_digest computes the same with numpy): every
+// case stores one per level and image kind, the full bytes only for the cases cases.txt marks `full` (a whole set of
+// pyramids is 60 MB; the digests say WHICH level differs, and whoever has OpenCV can dump that level again).
+uint64_t level_digest(const uint8_t* p, size_t n) {
+  uint64_t d = 0;
+  for (size_t i = 0; i < n; i++) d += ((uint64_t)p[i] + 1u) * (((uint64_t)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull) | 1ull);
+  return d;
+}
+
 // The scale pyramid as cv::ORB::detectAndCompute builds it (orb.cpp: level l is resized from level l - 1, its size comes
 // from the ORIGINAL image's size and the level's float scale), and the blurred copy the descriptors are sampled from.
 void pyramid_and_blur(const cv::Mat& image, int nlevels, double scale_factor, std::vector<uint8_t>* pyr, std::vector<uint8_t>* blur,
-                      std::vector<int32_t>* shapes) {
+                      std::vector<int32_t>* shapes, std::vector<uint64_t>* pyr_digest, std::vector<uint64_t>* blur_digest) {
   cv::Mat prev = image;
   for (int level = 0; level < nlevels; level++) {
     cv::Mat cur;
@@ -101,10 +110,13 @@ void pyramid_and_blur(const cv::Mat& image, int nlevels, double scale_factor, st
     cv::GaussianBlur(cur, blurred, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
     shapes->push_back(cur.rows);
     shapes->push_back(cur.cols);
+    const size_t at = pyr->size();
     for (int y = 0; y < cur.rows; y++) {
       pyr->insert(pyr->end(), cur.ptr<uint8_t>(y), cur.ptr<uint8_t>(y) + cur.cols);
       blur->insert(blur->end(), blurred.ptr<uint8_t>(y), blurred.ptr<uint8_t>(y) + blurred.cols);
     }
+    pyr_digest->push_back(level_digest(pyr->data() + at, pyr->size() - at));
+    blur_digest->push_back(level_digest(blur->data() + at, blur->size() - at));
     prev = cur;
   }
 }
@@ -131,9 +143,9 @@ int main(int argc, char** argv) {
     while (std::getline(cases, line)) {
       if (line.empty() || line[0] == '#') continue;
       std::istringstream ls(line);
-      std::string name, left_file, right_file;
+      std::string name, left_file, right_file, detail;
       int nfeatures = 0;
-      ls >> name >> nfeatures >> left_file >> right_file;
+      ls >> name >> nfeatures >> left_file >> right_file >> detail;  // detail: `full` = keep the pyramid bytes, else digests only
       if (name.empty() || nfeatures < 1 || right_file.empty()) throw std::runtime_error("bad line in cases.txt: " + line);
       const cv::Mat image[2] = {load_u8(in + left_file), load_u8(in + right_file)};
       const std::string pre = out + name + "__";
@@ -159,9 +171,14 @@ int main(int argc, char** argv) {
       {
         std::vector<uint8_t> pyr, blur;
         std::vector<int32_t> shapes;
-        pyramid_and_blur(image[0], 50, (double)1.04f, &pyr, &blur, &shapes);
-        pin_npy::write(pre + "L_pyramid.npy", "|u1", {pyr.size()}, pyr.data(), pyr.size());
-        pin_npy::write(pre + "L_blur.npy", "|u1", {blur.size()}, blur.data(), blur.size());
+        std::vector<uint64_t> pd, bd;
+        pyramid_and_blur(image[0], 50, (double)1.04f, &pyr, &blur, &shapes, &pd, &bd);
+        if (detail == "full") {
+          pin_npy::write(pre + "L_pyramid.npy", "|u1", {pyr.size()}, pyr.data(), pyr.size());
+          pin_npy::write(pre + "L_blur.npy", "|u1", {blur.size()}, blur.data(), blur.size());
+        }
+        pin_npy::write(pre + "L_pyramid_digest.npy", "<u8", {pd.size()}, pd.data(), pd.size() * 8);
+        pin_npy::write(pre + "L_blur_digest.npy", "<u8", {bd.size()}, bd.data(), bd.size() * 8);
         pin_npy::write(pre + "L_level_shapes.npy", "<i4", {shapes.size() / 2, 2}, shapes.data(), shapes.size() * 4);
       }
       // ---- GetMatches (cc:521-538): knnMatch(k = 2) + the ratio test, in the reference's types ----
