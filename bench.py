@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = 545.0      # measured: a stream of 4-cycle wave64 VALU instructions chip-wide (profiles/r04/valu_issue_table.json;
                              # 1024 SIMDs x ~2.2 GHz under that load / 4.1 cycles); per kernel: valu_ceilings()
 MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 = the fp8 rate (MI355X_MICROARCH.md: ~5 PFLOP/s fp8 dense)
+MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4 / FP6 (same guide: ~10 PF dense): the form the matcher runs in since round 5
 
 CONFIGS = {
     "vga": dict(width=640, height=480, nfeatures=2000, batch=256, label="BASELINE configs[1]"),
@@ -468,6 +469,7 @@ def main() -> int:
                     help="VSF_OPT_PIPE_PRIORITY (experiments): stream priority of the pipelined pyramid chain, 0 / 1 low / -1 high")
     ap.add_argument("--ingest-priority", choices=["low", "normal", "high"], default=None,
                     help="--ingest jpeg: HIP stream priority of the decode stream")
+    ap.add_argument("--match-int8", action="store_true", help="VSF_OPT_MATCH_INT8: round 2's int8 form of the matcher (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
@@ -610,6 +612,8 @@ def main() -> int:
     # cross-call pipelining: every step's input is complete in HBM before the call (the rotating synthetic batches), or
     # the call is handed the event behind its producer (the JPEG ingest: vsf_set_input_event)
     pipeline = not args.no_pipeline
+    if args.match_int8:
+        ctx.set_option(capi.OPT_MATCH_INT8, 1)
     if args.pipe_priority is not None:
         ctx.set_option(capi.OPT_PIPE_PRIORITY, args.pipe_priority)
     ctx.set_pipeline(pipeline)
@@ -812,8 +816,11 @@ def main() -> int:
             mean_n = float(counts.mean())
             pairs_per_step = B * mean_n * mean_n  # stereo L->R; the R'->L' and temporal launches are ~1 % of that
             dps = pairs_per_step * args.steps / (knn_ms * 1e-3)
-            matcher = {"pair_distances_per_s": dps, "int8_mfma_tops": dps * 512 / 1e12,
-                       "frac_of_int8_mfma_peak": dps * 512 / 1e12 / MFMA_I8_PEAK_TOPS, "peak_tops": MFMA_I8_PEAK_TOPS,
+            int8_form = bool(ctx.get_option(capi.OPT_MATCH_INT8))
+            peak = MFMA_I8_PEAK_TOPS if int8_form else MFMA_FP4_PEAK_TOPS
+            matcher = {"pair_distances_per_s": dps, "mfma_tops": dps * 512 / 1e12,
+                       "form": "int8 (v_mfma_i32_32x32x32_i8)" if int8_form else "fp4 (v_mfma_scale_f32_32x32x64_f8f6f4, exact)",
+                       "frac_of_mfma_peak": dps * 512 / 1e12 / peak, "peak_tops": peak,
                        "ms_per_step": knn_ms / args.steps,
                        "note": "the stereo L->R launch of each step (B pairs of ~N x N)" if tail_stages is not None else
                                "all knn2 launches of a step (stereo + R'->L' + temporal) over the stereo pair count"}

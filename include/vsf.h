@@ -171,7 +171,8 @@ typedef enum {
                                 * as its inputs are ready (a step whose FAST shares the chip with a decoder) */
   VSF_OPT_PIPE_PRIORITY = 10,  /* stream priority of the pipelined pyramid chain: 0 normal, 1 lowest, -1 highest; set it before
                                 * vsf_set_pipeline(ctx, 1) */
-  VSF_OPT_COUNT = 11
+  VSF_OPT_MATCH_INT8 = 11,     /* 0: the matcher on the FP4 matrix instruction (K = 64 per instruction); 1: round 2's int8 form */
+  VSF_OPT_COUNT = 12
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);

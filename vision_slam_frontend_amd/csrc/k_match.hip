@@ -238,6 +238,201 @@ __global__ __launch_bounds__(256, 4) void knn2_kernel(const uint8_t* __restrict_
   }
 }
 
+// ---- round 5: the same key out of the FP4 matrix instruction ----
+// v_mfma_scale_f32_32x32x64_f8f6f4 with E2M1 operands takes K = 64 per instruction at the cycles v_mfma_i32_32x32x32_i8
+// takes for K = 32 (tools/exp/fp4_probe.hip: 132 against 256 cycles per 256-bit 32 x 32 tile).  A descriptor bit becomes
+// the FP4 code of +4 or -4 (0x6 / 0xE), both block scales are 2^4 (E8M0 131), so a product is +-4096 exactly as with the
+// int8 +-64 operands and the f32 accumulator -- every partial sum a multiple of 4096 below 2^21 -- is exact; 256 bits are
+// FOUR instructions, and the row index needs no instruction at all: it rides in the C operand of the first one (sixteen
+// constant registers, which the halved operands pay for: a query is 16 registers instead of 32).  C also carries 2^20 +
+// 8192, so that a key
+//     8192 (d + 1) + (row inside the tile)          -- 65 536 probe keys, all exact
+// is a POSITIVE float whatever the distance, and stays positive while the running minima are rebased by 32 per tile over a
+// 4096-row chunk: positive floats order like their bit patterns, so the fold is the integer v_min_i32 / v_med3_i32 of the
+// int8 kernel on the accumulator's bits (no float min, whose signalling-NaN quieting the compiler would have to add).
+// An expanded train row is 128 bytes (144 with the pad that keeps ds_read_b128 conflict-free: 36 dwords per row step, 16
+// lanes tile the 64 banks), a thread stages one 16-byte piece per tile.
+constexpr int kTileStride4 = 144;
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// 8 descriptor bits -> 8 FP4 codes (bit i -> nibble i): three spreading steps, then the sign (bit 3 of a nibble)
+__device__ inline uint32_t fp4_spread8(uint32_t b) {
+  uint32_t x = b & 0xFFu;
+  x = (x | (x << 12)) & 0x000F000Fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x << 3;
+}
+// TRAIN: set bit -> +4 (0x6), clear -> -4 (0xE); QUERY: set bit -> -4, clear -> +4
+template <bool TRAIN>
+__device__ inline v4i fp4_expand32(uint32_t bits) {
+  v4i r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t sgn = fp4_spread8(bits >> (8 * k));
+    r[k] = (int)(TRAIN ? (0xEEEEEEEEu ^ sgn) : (0x66666666u | sgn));
+  }
+  return r;
+}
+__device__ inline v8i fp4_operand(v4i v) { return v8i{v[0], v[1], v[2], v[3], 0, 0, 0, 0}; }  // (FP4 reads four registers)
+
+constexpr int kKeyNoneBits = 0x7F000000;  // 1.7e38f: above every key as a float and as an integer
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 4) void knn2_fp4_kernel(const uint8_t* __restrict__ desc,
+                                                          const int32_t* __restrict__ counts, size_t set_stride,
+                                                          const int32_t* __restrict__ q_set,
+                                                          const int32_t* __restrict__ t_set, int max_rows,
+                                                          int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[2][kTile * kTileStride4];
+  // byte of descriptor bits -> dword of eight train-side FP4 codes: the staging of a tile is four table reads per thread
+  // instead of ~20 vector instructions, one of them a quarter-rate v_mul_lo_u32 (the fold, 33 instructions per tile, is
+  // what the vector ALU is for here)
+  __shared__ uint32_t lut[256];
+  lut[threadIdx.x] = 0xEEEEEEEEu ^ fp4_spread8(threadIdx.x);  // (the first barrier below orders it)
+  const int pair = blockIdx.y;
+  const int qs = q_set ? q_set[pair] : 2 * pair, ts = t_set ? t_set[pair] : 2 * pair + 1;
+  const int nq = min(counts[qs], max_rows), nt = min(counts[ts], max_rows);
+  if ((int)blockIdx.x * kWgQueries >= nq) return;  // whole block idle (uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const uint8_t* Q = desc + (size_t)qs * set_stride;
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(desc + (size_t)ts * set_stride);
+  // query operand: column c of the wave's tile; step s takes dword 2 s + h of the descriptor (32 of the step's 64 bits)
+  const int qbase = blockIdx.x * kWgQueries + wave * 32;
+  v4i qf[4];
+  {
+    const int q = min(qbase + c, nq - 1);
+    const uint32_t* qw = reinterpret_cast<const uint32_t*>(Q + (size_t)q * 32);
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = fp4_expand32<false>(qw[2 * s + h]);
+  }
+  // C operand of a tile's first product: the row's index inside the tile + 2^20 + 8192 (see above)
+  v16f row_c;
+#pragma unroll
+  for (int i = 0; i < 16; i++) row_c[i] = (float)((i & 3) + 8 * (i >> 2) + 4 * h + (1 << 20) + 8192);
+  const int scale = 131;  // E8M0: 2^4 on both operands' blocks
+  int t_begin = 0, t_end = nt;
+  if (SPLIT) {
+    const int chunk = ((nt + (int)gridDim.z - 1) / (int)gridDim.z + kSplitAlign - 1) / kSplitAlign * kSplitAlign;
+    t_begin = min((int)blockIdx.z * chunk, nt);
+    t_end = min(t_begin + chunk, nt);
+  }
+  uint32_t g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu;  // distance << 20 | train index
+  // staging: thread tid expands dword (tid & 7) of train row (tid >> 3) of the tile: 16 bytes at row * 144 + 16 * dword.
+  // Rows past the chunk's end are clamped to its last row (never folded: the last tile's fold checks the row index).
+  // (Measured and left out: stages of 64 rows, one barrier per two tiles -- 0.185 against 0.172 ms per 256 pairs of
+  // 2000 x 2000; sched_group_barrier groups of 1 MFMA + 8 / 12 / 16 vector instructions -- 0.181 / 0.173 / 0.176: the
+  // compiler's own interleaving is as good.)
+  const int st_row = tid >> 3, st_s = tid & 7;
+  auto load_bits = [&](int t0, int c_end) -> uint32_t { return T[(size_t)min(t0 + st_row, c_end - 1) * 8 + st_s]; };
+  auto stage = [&](int buf, uint32_t bits) {
+    v4i r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = (int)lut[(bits >> (8 * k)) & 255u];
+    *reinterpret_cast<v4i*>(&tile[buf][st_row * kTileStride4 + 16 * st_s]) = r;
+  };
+  for (int c0 = t_begin; c0 < t_end; c0 += kChunkRows) {
+    const int c_end = min(c0 + kChunkRows, t_end);
+    const int ntiles = (c_end - c0 + kTile - 1) / kTile;
+    float m1 = __int_as_float(kKeyNoneBits), m2 = __int_as_float(kKeyNoneBits);  // key - 32 (tiles since): positive floats
+    auto fold = [&](const v16f& a, int t0, bool check) {
+      m1 -= (float)kTile;  // (exact: integers below 2^24; the "none" key stays 1.7e38)
+      m2 -= (float)kTile;
+      int i1 = __float_as_int(m1), i2 = __float_as_int(m2);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const bool valid = !check || t0 + (i & 3) + 8 * (i >> 2) + 4 * h < c_end;
+        const int k = valid ? __float_as_int(a[i]) : kKeyNoneBits;
+        i2 = imed3(i1, i2, k);
+        i1 = min(i1, k);
+      }
+      m1 = __int_as_float(i1);
+      m2 = __int_as_float(i2);
+    };
+    constexpr int kAhead = 4;
+    uint32_t bits_next[kAhead];
+    // One pipeline step = tile t: its four products (into `n`) run beside the fold of tile t - 1's keys (`p`) and the
+    // expansion of tile t + 1 into the other LDS buffer: matrix core and vector ALU side by side inside one wave.
+    auto step = [&](int t, const v16f& p, v16f& n, bool fold_prev) {
+      const int buf = t & 1;
+      const uint32_t bits_after = load_bits(c0 + (t + 1 + kAhead) * kTile, c_end);
+      const uint8_t* rowp = &tile[buf][c * kTileStride4 + 16 * h];
+      v4i tf[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) tf[s] = *reinterpret_cast<const v4i*>(rowp + 32 * s);
+      n = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(tf[0]), fp4_operand(qf[0]), row_c, 4, 4, 0, scale, 0, scale);
+#pragma unroll
+      for (int s = 1; s < 4; s++)
+        n = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(tf[s]), fp4_operand(qf[s]), n, 4, 4, 0, scale, 0, scale);
+      if (fold_prev) fold(p, 0, false);  // (every tile but a chunk's last is full)
+      stage(buf ^ 1, bits_next[0]);
+#pragma unroll
+      for (int k = 0; k + 1 < kAhead; k++) bits_next[k] = bits_next[k + 1];
+      bits_next[kAhead - 1] = bits_after;
+      __syncthreads();
+    };
+    __syncthreads();  // the previous chunk's last tile has been read
+    stage(0, load_bits(c0, c_end));
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) bits_next[k] = load_bits(c0 + (1 + k) * kTile, c_end);
+    __syncthreads();
+    v16f accA, accB = row_c;  // (B is not folded before it is written)
+    step(0, accB, accA, false);
+    int t = 1;
+    for (; t + 1 < ntiles; t += 2) {
+      step(t, accA, accB, true);
+      step(t + 1, accB, accA, true);
+    }
+    int t_last;  // the tile m1 / m2 are relative to
+    if (t < ntiles) {  // uniform
+      step(t, accA, accB, true);
+      fold(accB, c0 + t * kTile, true);
+      t_last = t;
+    } else {
+      fold(accA, c0 + (t - 1) * kTile, true);
+      t_last = t - 1;
+    }
+    // chunk keys -> global keys:  key + 4096 = 8192 (d + 1) + (row offset + 4096), the row offset being in (-4096, 32)
+    auto global_key = [&](float key) -> uint32_t {
+      if (key > 1e30f) return 0xFFFFFFFFu;
+      const uint32_t y = (uint32_t)((int)key + 4096);
+      return (((y >> 13) - 1u) << 20) | (uint32_t)((int)(y & 8191u) - 4096 + t_last * kTile + c0);
+    };
+    merge_top2(g1, g2, global_key(m1), global_key(m2));
+  }
+  // the two lane halves hold the rows 4 h + ... of every tile: merge them
+  {
+    const uint32_t o1 = __shfl_xor(g1, 32), o2 = __shfl_xor(g2, 32);
+    merge_top2(g1, g2, o1, o2);
+  }
+  if (h != 0) return;
+  const int q = qbase + c;
+  if (q >= nq) return;
+  const uint32_t b1 = g1, b2 = g2;
+  if (SPLIT) {
+    if (t_begin >= t_end) return;
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(dist2) + (size_t)pair * max_rows + q;
+    unsigned long long seen = *slot;
+    while (true) {
+      const uint32_t a1 = (uint32_t)(seen >> 32), a2 = (uint32_t)seen;
+      const uint32_t n1 = min(a1, b1), n2 = min(max(a1, b1), min(a2, b2));
+      const unsigned long long merged = ((unsigned long long)n1 << 32) | n2;
+      if (merged == seen) break;
+      const unsigned long long prev = atomicCAS(slot, seen, merged);
+      if (prev == seen) break;
+      seen = prev;
+    }
+  } else {
+    const size_t o = ((size_t)pair * max_rows + q) * 2;
+    idx2[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFFu);
+    idx2[o + 1] = b2 == 0xFFFFFFFFu ? -1 : (int32_t)(b2 & 0xFFFFFu);
+    dist2[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 20);
+    dist2[o + 1] = b2 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b2 >> 20);
+  }
+}
+
 // Unpacks the key pairs of the split path into idx2 / dist2 (in place: a thread reads its slot before writing it).
 __global__ __launch_bounds__(256) void knn2_finalize_kernel(const int32_t* __restrict__ counts,
                                                             const int32_t* __restrict__ q_set, int max_rows,
@@ -309,7 +504,7 @@ __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __res
 
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                     hipStream_t s) {
+                     hipStream_t s, bool int8_form) {
   const int qtiles = (max_rows + kWgQueries - 1) / kWgQueries;
   // A batch of 128 stereo pairs brings ~2000 workgroups, two full rounds of the chip at four workgroups per CU, and runs
   // unsplit; with fewer (one pair of one frame at a time) the train sets are split until about that many workgroups exist
@@ -318,13 +513,21 @@ void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_
   if ((long)qtiles * n_pairs < 2 * 768) nsplit = (int)std::min<long>(32, 2 * 1024 / ((long)qtiles * n_pairs));
   nsplit = std::max(1, std::min(nsplit, max_rows / (2 * kSplitAlign)));
   if (nsplit <= 1) {
-    hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+    if (int8_form)
+      hipLaunchKernelGGL(knn2_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride,
+                         d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+    else
+      hipLaunchKernelGGL(knn2_fp4_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride,
+                         d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
     return;
   }
   vsf_note(hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s));
-  hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                     d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+  if (int8_form)
+    hipLaunchKernelGGL(knn2_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
+                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+  else
+    hipLaunchKernelGGL(knn2_fp4_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
+                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
   hipLaunchKernelGGL(knn2_finalize_kernel, dim3((max_rows + 255) / 256, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set,
                      max_rows, d_idx2, d_dist2);
 }

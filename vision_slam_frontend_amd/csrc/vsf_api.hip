@@ -991,7 +991,7 @@ void match_on(vsf_ctx* ctx, hipStream_t st, const uint8_t* d_desc, const int32_t
   {
     StageTimer t(ctx, st, VSF_STAGE_KNN2, 1);
     vsf_launch_knn2(desc, counts, set_stride, d_q_set ? d_q_set + p0 : nullptr, d_t_set ? d_t_set + p0 : nullptr, n,
-                    rows, idx2, dist2, st);
+                    rows, idx2, dist2, st, ctx->tuning.match_int8 != 0);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_RATIO, 1);
@@ -1349,6 +1349,7 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
     case VSF_OPT_SELECT_WIDE: t.select_wide = value != 0; break;
     case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
     case VSF_OPT_PIPE_AFTER_FAST: t.pipe_after_fast = value != 0; break;
+    case VSF_OPT_MATCH_INT8: t.match_int8 = value != 0; break;
     case VSF_OPT_PIPE_PRIORITY:
       if (value < -1 || value > 1) return VSF_ERR_INVALID_ARG;
       t.pipe_priority = value;  // (takes effect with the next vsf_set_pipeline(ctx, 1))
@@ -1388,6 +1389,7 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
     case VSF_OPT_SELECT_WIDE: *value = t.select_wide; break;
     case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
     case VSF_OPT_PIPE_AFTER_FAST: *value = t.pipe_after_fast; break;
+    case VSF_OPT_MATCH_INT8: *value = t.match_int8; break;
     case VSF_OPT_PIPE_PRIORITY: *value = t.pipe_priority; break;
     case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
@@ -2041,7 +2043,8 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   // launch, one sort launch (per-pair best_percent) ----
   {
     StageTimer t(ctx, s, VSF_STAGE_KNN2, 1);
-    vsf_launch_knn2(o.ring, o.ring_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, s);
+    vsf_launch_knn2(o.ring, o.ring_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, ctx->m_idx2, ctx->m_dist2, s,
+                    ctx->tuning.match_int8 != 0);
   }
   {
     StageTimer t(ctx, s, VSF_STAGE_RATIO, 1);
@@ -2287,7 +2290,7 @@ static vsf_status match_host(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8
                            ctx->stream));
   // m_idx2/m_dist2 are laid out [pair][m_rows][2]; the kernels are given the same row capacity.
   vsf_launch_knn2(ctx->mh_desc, ctx->mh_counts, set_stride, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2,
-                  ctx->stream);
+                  ctx->stream, ctx->tuning.match_int8 != 0);
   if (out) {
     vsf_launch_ratio_compact(ctx->mh_counts, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
                              ctx->p.ratio_shift, ctx->mh_matches, ctx->mh_nmatches, ctx->d_status, ctx->stream);
@@ -2364,7 +2367,7 @@ vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const in
   // every buffer of this call is laid out with row capacity R: m_idx2 / m_dist2 [S][R][2] (they hold at least
   // m_pairs x m_rows >= S x R entries), mm_matches [S][R]
   vsf_launch_knn2(ctx->mm_desc, ctx->mm_counts, set_stride, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2,
-                  ctx->stream);
+                  ctx->stream, ctx->tuning.match_int8 != 0);
   vsf_launch_ratio_compact(ctx->mm_counts, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
                            ctx->p.ratio_shift, ctx->mm_matches, ctx->mm_nmatches, ctx->d_status, ctx->stream);
   VSF_STICKY();

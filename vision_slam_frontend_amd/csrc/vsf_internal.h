@@ -92,6 +92,7 @@ struct VsfTuning {
   int fast_both_max = 16;  // VSF_OPT_FAST_BOTH_MAX: largest batch (images) whose full and half-wave FAST cells share one launch
   int sort_serial = 0;     // VSF_OPT_SORT_SERIAL: 1 = sort_trim's one-lane kernel
   int select_wide = 1;     // VSF_OPT_SELECT_WIDE: 1 = a frame or two takes the 1024-thread whole-level selection class
+  int match_int8 = 0;        // VSF_OPT_MATCH_INT8: 1 = the int8 form of the matcher (v_mfma_i32_32x32x32_i8) instead of the FP4 one
   int pipe_priority = 0;     // VSF_OPT_PIPE_PRIORITY: stream priority of the pipelined pyramid chain (0 normal, 1 lowest, -1 highest)
   int pipe_after_fast = 1;   // VSF_OPT_PIPE_AFTER_FAST: the pipelined pyramid of call k + 1 starts behind call k's FAST (1) or at once (0)
   int select_big_class = 1;  // VSF_OPT_SELECT_BIG_CLASS: 1 = the widest levels of a batch take the 9 216-entry class
@@ -187,7 +188,7 @@ void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int m
                           int32_t* d_counts, hipStream_t s);
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                     hipStream_t s);
+                     hipStream_t s, bool int8_form = false);  // int8_form: round 2's int8 matrix instruction (VSF_OPT_MATCH_INT8)
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
                               int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
