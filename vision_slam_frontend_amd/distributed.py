@@ -378,7 +378,7 @@ class ShardedStereoFrontend:
 
     def __init__(self, ctx, frames_per_rank: int, width: int, height: int, calib, *, window: int = 1,
                  best_percent: float = 0.3, device=None, stream=None, overlap: bool = True,
-                 force_collectives: bool = False, comm=None):
+                 force_collectives: bool = False, comm=None, match_on_tail: bool = False):
         from . import capi  # (ctx is a capi.Context)
 
         self.ctx, self.B, self.W = ctx, int(frames_per_rank), int(window)
@@ -401,6 +401,9 @@ class ShardedStereoFrontend:
         self.dev = dev
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.overlap = bool(overlap)
+        # the stereo GetMatches (cc:414) as the first kernel of the tail instead of the last of the extraction: its matrix-core
+        # work then runs beside the next step's pyramid and FAST (a choice for many features per frame; needs the tail stream)
+        self.match_on_tail = bool(match_on_tail) and self.overlap
         if self.overlap:
             # the tail's own stream (high priority: its few small workgroups should not queue behind the thousands of
             # the extraction kernels) and context (scratch buffers and stream are per context)
@@ -593,13 +596,19 @@ class ShardedStereoFrontend:
                 self.stream.wait_event(self.raw_free[s % self.NRAW])  # the tail of step s - 2 has read this buffer
             if input_event is not None:
                 ctx.set_input_event(getattr(input_event, "cuda_event", input_event))
-            ctx.stereo_batch_dev(p(d_img), B, self.width * self.height, self.width, p(raw["kp"]), p(raw["desc"]),
-                                 p(raw["counts"]), p(raw["matches"]), p(raw["nmatches"]))
+            if self.match_on_tail:
+                ctx.extract_batch_dev(p(d_img), 2 * B, self.width * self.height, self.width, p(raw["kp"]), p(raw["desc"]),
+                                      p(raw["counts"]))
+            else:
+                ctx.stereo_batch_dev(p(d_img), B, self.width * self.height, self.width, p(raw["kp"]), p(raw["desc"]),
+                                     p(raw["counts"]), p(raw["matches"]), p(raw["nmatches"]))
             if self.overlap:
                 self.raw_ready[s % self.NRAW].record(self.stream)
         with torch.cuda.stream(self.tail_stream):
             if self.overlap:
                 self.tail_stream.wait_event(self.raw_ready[s % self.NRAW])
+            if self.match_on_tail:  # (left, right) of every frame: sets 2 f / 2 f + 1 of the raw descriptors
+                tctx.match_batch_dev(p(raw["desc"]), p(raw["counts"]), K * 32, 0, 0, B, 0, 0, p(raw["matches"]), p(raw["nmatches"]))
             if self.dist_on:  # payload slot `slot` (and the root's receive set) was last used by step s - PAYLOAD_SLOTS
                 self._retire_through(s - self.PAYLOAD_SLOTS)
             tctx.stereo_residuals_batch_dev(p(raw["kp"]), p(raw["matches"]), p(raw["nmatches"]), B, self.F, p(self.means))
