@@ -76,12 +76,12 @@ def committed_counters(width: int, height: int, nfeatures: int, batch: int):
 
 
 def valu_ceilings():
-    """Per-stage VALU issue ceilings in G wave-inst/s (profiles/r04/valu_ceiling.json: the kernel's own opcode mix priced with
+    """Per-stage VALU issue ceilings in G wave-inst/s (profiles/valu_ceiling.json: the kernel's own opcode mix priced with
     the measured issue table; tools/valu_ceiling.py), and whether the file is stale against the sources.  The fallback is the
     measured rate of a stream of 4-cycle instructions."""
     from vision_slam_frontend_amd.buildinfo import kernel_source_hash
     try:
-        t = json.loads((ROOT / "profiles" / "r04" / "valu_ceiling.json").read_text())
+        t = json.loads((ROOT / "profiles" / "valu_ceiling.json").read_text())
     except (OSError, ValueError):
         return {}, VALU_PEAK_GINST, True
     return ({k: v["ceiling_mix_g_wave_inst_per_s"] for k, v in t["kernels"].items()}, t["rate_all4_g_wave_inst_per_s"],
@@ -803,7 +803,7 @@ def main() -> int:
             peak = ceilings.get(dom, valu_rate_all4)
             valu = {"bound": "valu", "kernel": dom, "achieved": a, "peak": peak, "unit": "G wave-inst/s",
                     "frac": a / peak, "valu_wave_insts_per_launch": float(insts) * args.steps / max(dom_launches, 1),
-                    "peak_source": "profiles/r04/valu_ceiling.json: this kernel's opcode mix priced with the issue table "
+                    "peak_source": "profiles/valu_ceiling.json: this kernel's opcode mix priced with the issue table "
                                    "measured on MI355X (valu_issue_table.json); %.0f G/s if none of its 2-cycle-class "
                                    "instructions pair up%s" % (valu_rate_all4, " -- STALE against csrc/" if ceilings_stale else ""),
                     "source": "profiles/traffic*.json (rocprofv3 --pmc SQ_INSTS_VALU, own pass, same source digest) / stage "

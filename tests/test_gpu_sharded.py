@@ -408,3 +408,34 @@ def test_tune_steps_leave_no_trace():
     tuned_run, tuned = run(2)
     assert tuned["timed_on"].startswith("2 whole steps"), tuned
     assert plain == tuned_run
+
+
+def test_stereo_match_on_the_tail_stream_gives_the_same_payloads():
+    """ShardedStereoFrontend(match_on_tail=True): the stereo GetMatches (cc:414) runs as the first kernel of the step's tail
+    (vsf_extract_batch_dev on the extraction's stream, vsf_match_batch_dev on the tail's) instead of inside
+    vsf_stereo_batch_dev -- a scheduling choice for many features per frame; the payloads are byte-identical."""
+    from vision_slam_frontend_amd import capi, synth
+    from vision_slam_frontend_amd import distributed as vd
+    w, h, nf, per, window, steps = 320, 240, 600, 4, 2, 3
+    frames = synth.stereo_stream(per * steps, w, h, n_objects=300)
+    frames[6, 1] = 128
+    dev = torch.device("cuda", 0)
+
+    def run(on_tail):
+        ctx = capi.Context(capi.default_params(w, h, max_images=2 * per, nfeatures=nf))
+        sf = vd.ShardedStereoFrontend(ctx, per, w, h, _calibration(), window=window, device=dev, match_on_tail=on_tail)
+        assert sf.match_on_tail == on_tail
+        out = []
+        for s in range(steps):
+            sf.step(torch.from_numpy(np.ascontiguousarray(frames[s * per:(s + 1) * per])).to(dev))
+            sf.synchronize()
+            pl = sf.local_payload(s).cpu().clone()
+            out.append(pl[:int(pl[12:16].view(torch.int32).item())].numpy().tobytes())
+        sf.drain()
+        assert all(c.sync() == capi.VSF_OK for c in sf.contexts())
+        sf.close()
+        ctx.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert a == b and sum(len(x) for x in a) > 3000

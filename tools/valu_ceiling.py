@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mix-weighted VALU issue ceiling of the hot kernels, from their disassembly and the measured issue table.
 
-    python tools/valu_ceiling.py            # writes profiles/r04/valu_ceiling.json
+    python tools/valu_ceiling.py            # writes profiles/valu_ceiling.json
 
 profiles/r04/valu_issue_table.json (tools/exp/valu_probe.hip, measured on MI355X) says what one wave64 instruction of each
 opcode costs a SIMD: 4.1 cycles for every packed, three-operand, DPP, compare, convert and 24-bit-multiply instruction and
@@ -40,7 +40,7 @@ KERNELS = {  # stage -> (source, substring of the mangled kernel name whose body
     "select_harris_angle": ("k_select.hip", "orb_select_kernelILi256E"),
     "orb_describe": ("k_describe.hip", "orb_orient_describe_kernel"),
     "pyramid_resize": ("k_pyramid.hip", "resize_strip_kernelILi8E"),
-    "hamming_knn2": ("k_match.hip", "knn2_kernel"),
+    "hamming_knn2": ("k_match.hip", "knn2_fp4_kernelILb0E"),
 }
 TWO_CYCLE = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_mov_b32", "v_add_u32",
              "v_sub_u32", "v_subrev_u32", "v_min_u16", "v_max_u16", "v_min_i16", "v_max_i16", "v_add_u16", "v_sub_u16",
@@ -123,7 +123,7 @@ def main():
             "ceiling_mix_g_wave_inst_per_s": rate4 * cyc4 / (cycles / max(n, 1)),
             "top_opcodes": dict(hist.most_common(14)),
         }
-    dst = ROOT / "profiles" / "r04" / "valu_ceiling.json"
+    dst = ROOT / "profiles" / "valu_ceiling.json"  # (beside traffic.json: both follow the sources, not a round)
     dst.write_text(json.dumps(out, indent=1) + "\n")
     for k, v in out["kernels"].items():
         print("%-22s %5d VALU (%4d two-cycle class)  mean %.2f cyc  ceiling %.0f .. %.0f G wave-inst/s" % (

@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256, 4) void knn2_fp4_kernel(const uint8_t* __restr
                                                           int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][kTile * kTileStride4];
   // byte of descriptor bits -> dword of eight train-side FP4 codes: the staging of a tile is four table reads per thread
-  // instead of ~20 vector instructions, one of them a quarter-rate v_mul_lo_u32 (the fold, 33 instructions per tile, is
-  // what the vector ALU is for here)
+  // instead of ~20 vector instructions (the fold, 33 instructions per tile, is what the vector ALU is for here:
+  // 0.188 -> 0.173 ms per 256 pairs of 2000 x 2000)
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = 0xEEEEEEEEu ^ fp4_spread8(threadIdx.x);  // (the first barrier below orders it)
   const int pair = blockIdx.y;
