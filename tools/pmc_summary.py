@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel means of a rocprofv3 --pmc pass (pmc_counter_collection.csv) -> one text line per kernel.
-    python tools/exp/pmc_summary.py <pass dir>  > profiles/rNN/<config>_pmc_<pass>.txt"""
+    python tools/pmc_summary.py <pass dir>  > profiles/rNN/<config>_pmc_<pass>.txt"""
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.OrderedDict()

@@ -1,8 +1,8 @@
-"""ObserveImage at a given nfeatures, pipelined, per depth: python3 tools/exp/obs_once.py 10000 [frames] [depths...]"""
+"""ObserveImage at a given nfeatures, pipelined, per depth: python3 tools/time_observe_depth.py 10000 [frames] [depths...]"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))          # tools/ (time_frontend)
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))   # the repository root
 import numpy as np
 import time_frontend as tf
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
