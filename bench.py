@@ -839,7 +839,7 @@ def main() -> int:
             step_rooflines["valu"] = {"achieved": vi / step_s / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                                       "frac": vi / step_s / 1e9 / VALU_PEAK_GINST,
                                       "note": "against the measured rate of 4-cycle instructions; FAST by itself issues at "
-                                              "its mix ceiling, the other stages wait on latency (DESIGN 6)"}
+                                              "its mix ceiling, the other stages wait on latency (NOTES.md section 6)"}
         device_ms = sum(v[0] for k, v in stages.items() if k not in concurrent)
         out = {
             "metric": ("stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)

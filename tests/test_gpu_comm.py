@@ -5,7 +5,7 @@ run a world of one in which EVERY exchange of the step still goes through RCCL:
 
   * ShardedStereoFrontend with distributed.CapiComm (the Python composition over the C-ABI route) gathers the same payload
     bytes as the collective-free run;
-  * tools/time_sharded.cc -- one thread per GPU, the ten steps of DESIGN.md section 7 through include/vsf.h only, no Python
+  * tools/time_sharded.cc -- one thread per GPU, the steps of DESIGN.md section 7 (NOTES.md section 7 lists all ten) through include/vsf.h only, no Python
     -- gathers the same payload bytes as the Python composition over the same frames."""
 import os
 import socket

@@ -1,5 +1,5 @@
 // time_sharded.cc -- the sharded hot path of BASELINE configs[3] WITHOUT Python: one thread per GPU, one vsf context and
-// one vsf_comm (RCCL) each, DESIGN.md section 7's ten steps through the C ABI of include/vsf.h only.  What the drop-in for
+// one vsf_comm (RCCL) each, the exchange of DESIGN.md section 7 (its ten steps: NOTES.md section 7) through the C ABI of include/vsf.h only.  What the drop-in for
 // the reference's driver (slam_frontend_main.cc:251, 132) would run on an 8-GPU node.
 //
 //   build:  make -C tools time_sharded

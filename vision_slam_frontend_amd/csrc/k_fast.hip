@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void fast_march_both_kernel(FastArgs a, int nf
 // calls that run the blur beside FAST: a grid of one workgroup per four cells occupies every register of the chip for as
 // long as cells are left and whatever else is queued waits behind it; a fixed set of resident waves leaves the rest of each
 // SIMD's registers to the kernel beside it.  Alone, FAST reaches 93 % of the vector ALU's issue rate with five waves per
-// SIMD, the same with four, 92 % of that with three and 76 % with two (occupancy sweep).
+// SIMD, the same with four, 92 % of that with three and 76 % with two (occupancy sweep, NOTES.md section 6).
 template <bool HALF, bool NMS>
 __global__ __launch_bounds__(1024) void fast_march_resident_kernel(FastArgs a, int work0, int nwork, int nimages,
                                                                   uint32_t* next_cell) {

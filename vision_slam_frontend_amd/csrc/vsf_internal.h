@@ -85,7 +85,7 @@ struct VsfGeom {
   uint64_t pyramid_pixels;
 };
 
-// Per-context launch choices (vsf_set_option / vsf_get_option; the defaults are what the measurements of DESIGN.md
+// Per-context launch choices (vsf_set_option / vsf_get_option; the defaults are what the measurements of NOTES.md
 // section 6 settled on).  Nothing in the library reads the environment: a switch is a call on a context.
 struct VsfTuning {
   int blur_march = 0;      // VSF_OPT_BLUR_MARCH: 1 = round 2's vector-ALU blur kernel instead of the matrix-core one (A/B runs)
