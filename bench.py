@@ -517,6 +517,13 @@ def main() -> int:
             return rc2
         return rc
 
+    # Standard output carries the ONE JSON line and nothing else: whatever a library prints there from here on (RCCL's
+    # version banner, gloo's connection notes) goes to standard error instead -- file descriptor 1 is pointed at 2 and the
+    # line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -936,7 +943,8 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, synth.BASE_SEED)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     report_stage("teardown")
     sf.close()
     if comm is not None:

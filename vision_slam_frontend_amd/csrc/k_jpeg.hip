@@ -417,27 +417,40 @@ __global__ __launch_bounds__(64) void jpeg_expand_huff_kernel(const DevHuffSrc* 
   reinterpret_cast<uint32_t*>(out.vals)[lane] = reinterpret_cast<const uint32_t*>(in.vals)[lane];
 }
 
-__global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restrict__ images,
-                                                        const uint32_t* __restrict__ index,
-                                                        const DevScan* __restrict__ scans,
-                                                        const DevHuffLite* __restrict__ huffs,
-                                                        const uint8_t* __restrict__ stream, int16_t* __restrict__ coef_all,
-                                                        size_t coef_stride, int slot0, int width, int height,
-                                                        int32_t* __restrict__ status) {
-  const int lane = threadIdx.x;
-  const uint32_t image = in_constant(index)[blockIdx.x];
-  const auto& im = *in_constant(images + image);
-  int16_t* coef = coef_all + (size_t)(slot0 + blockIdx.x) * (coef_stride / sizeof(int16_t));
+// What a scan of a PIPELINED decode (jpeg_prog_pipe_kernel) must stay behind: block rows completed per scan of the file, in
+// LDS (0x7FFFFFFF: finished), and the up to four earlier scans whose coefficients this one refines (-1: none).
+struct ProgWait {
+  volatile int* progress;
+  int p0, p1, p2, p3;
+};
+
+// One luminance-carrying scan of a progressive (or multi-scan sequential) file into the file's coefficient slot: T.81 Annex G
+// as libjpeg's jdphuff.c decodes it.  Wave-uniform (the reader state lives in SGPRs); the 64 lanes are the 64 coefficients
+// of the block at hand.  PIPE: the scans of a file run in different waves of one workgroup; a refinement scan waits, block
+// row by block row, for the scans it refines (ProgWait) and every scan publishes the rows it has completed.
+template <bool PIPE, class Image>
+__device__ __forceinline__ void prog_scan(const Image& im, int si, const DevScan* __restrict__ scans,
+                                          const DevHuffLite* __restrict__ huffs, const uint8_t* __restrict__ stream,
+                                          int16_t* __restrict__ coef, int width, int height, int lane, int nat, const ProgWait W,
+                                          bool& broken, bool& suspect) {
   const int h0 = im.h[0], v0 = im.v[0], lum = h0 * v0, mcus_x = im.mcus_x;
-  const int nlb = mcus_x * im.mcus_y * lum;
-  {  // nothing is known yet
-    uint32_t* c32 = reinterpret_cast<uint32_t*>(coef);
-    for (int i = lane; i < nlb * 32; i += 64) c32[i] = 0u;
-  }
-  const int nat = c_zigzag[lane];  // where this lane's coefficient sits inside a block
-  bool broken = false;
-  for (int si = 0; si < im.n_scans && !broken; si++) {
-    __threadfence();
+  auto wait_rows = [&](int need) __attribute__((always_inline)) {
+    if (PIPE) {
+      if (W.p0 >= 0) while (W.progress[W.p0] < need) __builtin_amdgcn_s_sleep(2);
+      if (W.p1 >= 0) while (W.progress[W.p1] < need) __builtin_amdgcn_s_sleep(2);
+      if (W.p2 >= 0) while (W.progress[W.p2] < need) __builtin_amdgcn_s_sleep(2);
+      if (W.p3 >= 0) while (W.progress[W.p3] < need) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  };
+  auto publish_rows = [&](int rows) __attribute__((always_inline)) {
+    if (PIPE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (this wave's coefficient stores have landed)
+      if (lane == 0) W.progress[si] = rows;
+    }
+  };
+  {
+    if (!PIPE) __threadfence();  // (pipelined: the row-wise hand-over below orders the scans of a file)
     const auto& sc = *in_constant(scans + (im.first_scan + si));
     const int Ss = sc.Ss, Se = sc.Se, Ah = sc.Ah, Al = sc.Al, ns = sc.ncomp, restart_interval = sc.restart_interval;
     const uint32_t o = im.stream_off + sc.off;
@@ -501,14 +514,17 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
         const int nblocks = units_x * units_y;
         for (int b0 = 0; b0 < nblocks; b0 += 16) {
           const int cnt = nblocks - b0 < 16 ? nblocks - b0 : 16;
+          wait_rows((b0 + cnt - 1) / units_x + 1);
           const uint32_t got = (uint32_t)br.receive(cnt);
           if (lane < cnt && ((got >> (cnt - 1 - lane)) & 1u)) {
             const int b = b0 + lane, by = b / units_x;
             atomicOr(reinterpret_cast<unsigned int*>(coef + (size_t)block_of(by, b - by * units_x) * 64), (unsigned int)p1);
           }
+          publish_rows((b0 + cnt) / units_x);
         }
       } else {
-        for (int uy = 0; uy < units_y && !broken; uy++)
+        for (int uy = 0; uy < units_y && !broken; uy++) {
+          wait_rows(interleaved ? (uy + 1) * v0 : uy + 1);
           for (int ux = 0; ux < units_x; ux++) {
             if (restart_interval && until_restart == 0) {
               if (!br.restart()) {
@@ -535,6 +551,8 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
             }
             if (restart_interval) until_restart--;
           }
+          publish_rows(interleaved ? (uy + 1) * v0 : uy + 1);
+        }
       }
     } else {
       // ---- AC scans: the luminance alone, block after block in raster order ----
@@ -542,6 +560,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
       const int nblocks = units_x * units_y;
       int bx = 0, by = 0;
       int16_t* blk = coef + (size_t)block_of(0, 0) * 64;
+      wait_rows(1);
       int16_t next = Ah ? blk[nat] : (int16_t)0;
       for (int b = 0; b < nblocks; b++) {
         if (restart_interval && until_restart == 0) {
@@ -557,6 +576,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
         if (++bx == units_x) {
           bx = 0;
           by++;
+          if (b + 1 < nblocks) wait_rows(by + 1);  // (the next row's first block is fetched below)
         }
         if (b + 1 < nblocks) {
           blk = coef + (size_t)block_of(by, bx) * 64;
@@ -577,6 +597,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
                 br.fill();
                 const int v = br.receive_extend(sz);
                 if (k > 63) break;  // corrupt
+                if (k > Se) suspect = true;  // (damaged data: a value behind the band -- libjpeg writes it too)
                 if (lane == k) mine = v * p1;
               } else if (r == 15) {
                 k += 15;
@@ -626,6 +647,7 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
               for (int i = 0; i < r && zeros; i++) zeros &= zeros - 1ull;
               const int pos = zeros ? __builtin_ctzll(zeros) : Se + 1;  // (no such zero: the run ends behind the band)
               corrections(nz & ahead & below(pos));
+              if (sign && pos > Se) suspect = true;  // (damaged data: the run ends behind the band)
               if (sign && lane == pos) my_new = sign;
               k = pos + 1;
             }
@@ -647,9 +669,37 @@ __global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restric
           if (changed) here[nat] = (int16_t)cv;
         }
         if (restart_interval) until_restart--;
+        if (bx == 0) publish_rows(by);  // (the block just finished was its row's last)
       }
     }
+    publish_rows(0x7FFFFFFF);
+  
   }
+}
+
+__global__ __launch_bounds__(64) void jpeg_prog_kernel(const DevImage* __restrict__ images,
+                                                        const uint32_t* __restrict__ index,
+                                                        const DevScan* __restrict__ scans,
+                                                        const DevHuffLite* __restrict__ huffs,
+                                                        const uint8_t* __restrict__ stream, int16_t* __restrict__ coef_all,
+                                                        size_t coef_stride, int slot0, int width, int height,
+                                                        int32_t* __restrict__ status) {
+  const int lane = threadIdx.x;
+  const uint32_t image = in_constant(index)[blockIdx.x];
+  const auto& im = *in_constant(images + image);
+  int16_t* coef = coef_all + (size_t)(slot0 + blockIdx.x) * (coef_stride / sizeof(int16_t));
+  const int h0 = im.h[0], v0 = im.v[0], lum = h0 * v0, mcus_x = im.mcus_x;
+  const int nlb = mcus_x * im.mcus_y * lum;
+  {  // nothing is known yet
+    uint32_t* c32 = reinterpret_cast<uint32_t*>(coef);
+    for (int i = lane; i < nlb * 32; i += 64) c32[i] = 0u;
+  }
+  const int nat = c_zigzag[lane];  // where this lane's coefficient sits inside a block
+  bool broken = false;
+  bool suspect = false;
+  const ProgWait none{nullptr, -1, -1, -1, -1};
+  for (int si = 0; si < im.n_scans && !broken; si++)
+    prog_scan<false>(im, si, scans, huffs, stream, coef, width, height, lane, nat, none, broken, suspect);
   if (lane == 0 && broken) atomicOr(status, 2);
 }
 
