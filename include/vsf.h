@@ -162,7 +162,8 @@ typedef enum {
   VSF_OPT_FAST_BOTH_MAX = 1, /* 16: largest batch (images) whose full and half-wave FAST cells share one launch */
   VSF_OPT_SORT_SERIAL = 2,   /* 0: workgroup-parallel introsort of GetFeatureMatches; 1: the one-lane kernel */
   VSF_OPT_SELECT_WIDE = 3,   /* 1: a frame or two takes the 1024-thread whole-level selection class; 0: never */
-  VSF_OPT_JPEG_SERIAL = 4,   /* 0: self-synchronising parallel JPEG decode; 1: one wave per image for every file */
+  VSF_OPT_JPEG_SERIAL = 4,   /* 0: self-synchronising parallel JPEG decode, a progressive file's scans pipelined over the
+                              * waves of a workgroup; 1: one wave per image for every file, scan after scan */
   VSF_OPT_PYRAMID_FEW = 5,   /* 16: largest batch (images) whose pyramid is built by the slab kernel */
   VSF_OPT_PYRAMID_CHAIN = 6, /* 8: levels per slab launch; 0: per-level launches even for a frame or two */
   VSF_OPT_PYRAMID_ROWS = 7,  /* 6: rows of a chain's last level per slab */

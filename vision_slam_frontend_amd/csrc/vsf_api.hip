@@ -524,6 +524,8 @@ struct vsf_ctx {
   } ob;
   // vsf_jpeg_decode_gray_batch: pinned staging + device copy of the packed headers / tables / entropy-coded segments
   // (two sets, used alternately: the host fills one while the previous call's upload / decode still use the other)
+  int32_t* jp_flags = nullptr;  // [jp_flags_cap] per progressive file of a call: damaged, decode again scan after scan
+  int jp_flags_cap = 0;
   uint8_t* jp_host[2] = {nullptr, nullptr};
   uint8_t* jp_dev[2] = {nullptr, nullptr};
   size_t jp_cap[2] = {0, 0};
@@ -1235,6 +1237,7 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_nmatches);
   hipFree(ctx->t_sortkeys);
   free_observe(ctx);
+  hipFree(ctx->jp_flags);
   hipFree(ctx->jp_clean);
   hipFree(ctx->jp_coef);
   for (int i = 0; i < 2; i++) {
@@ -1844,11 +1847,17 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   vsf_jpeg_fill(plan, jpeg, n_images, ctx->jp_host[b]);  // the one pass over the compressed bytes on the host
   VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
   VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
+  if (plan.n_prog > ctx->jp_flags_cap) {  // (no wait: the outgrown buffer is retired)
+    vsf_status gs = grow_scratch(ctx, ctx->jp_flags, (size_t)plan.n_prog * sizeof(int32_t));
+    if (gs != VSF_OK) return gs;
+    ctx->jp_flags_cap = plan.n_prog;
+  }
   vsf_launch_jpeg_decode(ctx->jp_dev[b], plan.off_images, plan.off_index, plan.off_tables, plan.off_scans, plan.off_prog_huff,
                          plan.off_stream, plan.total, plan.n_par, plan.n_prog, plan.n_prog_huff,
                          reinterpret_cast<uint8_t*>(ctx->jp_coef) + (size_t)(plan.n_par + plan.n_prog) * coef_stride,
                          n_images - plan.n_par - plan.n_prog, plan.max_luma_blocks, plan.max_slots, width, height, ctx->jp_clean, ctx->jp_coef,
-                         coef_stride, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream);
+                         coef_stride, d_dst, dst_image_stride, (int)dst_row_stride, ctx->d_status, ctx->stream,
+                         ctx->tuning.jpeg_serial != 0, ctx->jp_flags);
   VSF_STICKY();
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)

@@ -273,6 +273,7 @@ void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off
                             void* d_prog_huff, int n_ser, int max_luma_blocks, int max_slots, int width, int height,
                             uint8_t* d_clean,
                             int16_t* d_coef, size_t coef_stride, uint8_t* d_dst, size_t dst_image_stride, int dst_pitch,
-                            int32_t* d_status, hipStream_t s);
+                            int32_t* d_status, hipStream_t s, bool prog_serial, int32_t* d_prog_flags);
+// prog_serial: progressive files scan after scan in one wave; d_prog_flags [n_prog]: scratch of the pipelined form
 
 #endif  // VSF_INTERNAL_H_
