@@ -388,3 +388,67 @@ def test_ingest_chain_pipelined_with_an_input_event(oracle):
             assert nm == len(rm) and o["m"][f, :nm].tobytes() == rm.tobytes(), "step %d frame %d matches" % (s, f)
     ext.close()
     dec.close()
+
+
+def test_pipelined_progressive_decode_equals_scan_after_scan_on_damaged_files():
+    """jpeg_prog_pipe_kernel runs a file's scans concurrently; on intact files nothing depends on their order.  Damaged
+    entropy data can make it matter (a value placed behind its band, a missing restart marker stops the decode): such files
+    are flagged and decoded again by the one-wave kernel, so both forms must give the SAME bytes and the same status for
+    every file -- 150 progressive files with bit flips and stray markers in their scans (gray and 4:2:0, with and without
+    restart intervals, crafted scan scripts), in batches, VSF_OPT_JPEG_SERIAL 0 against 1."""
+    import io
+
+    from PIL import Image
+    import jpeg_craft as jc
+    from jpeg_mutate import mutate
+    from vision_slam_frontend_amd import capi, synth
+
+    W, H = 160, 120
+    img = synth.stereo_pair(W, H, 9, n_objects=80)[0]
+    base = []
+    for kw in (dict(quality=80, progressive=True), dict(quality=95, progressive=True),
+               dict(quality=60, progressive=True, restart_marker_blocks=7), dict(quality=85, progressive=True, restart_marker_blocks=20)):
+        b = io.BytesIO()
+        Image.fromarray(img, "L").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
+    rgb = np.stack([img, img[::-1], img[:, ::-1]], 2)
+    b = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(b, "JPEG", quality=75, subsampling=2, progressive=True)
+    base.append(b.getvalue())
+    crng = np.random.default_rng(5)
+    comp = lambda h, v, by, bx: (h, v, crng.integers(1, 5, 64), jc.random_coefficients(crng, by, bx))
+    c420 = [comp(2, 2, 16, 20), comp(1, 1, 8, 10), comp(1, 1, 8, 10)]
+    base.append(jc.write_progressive_jpeg(W, H, c420, [((0, 1, 2), 0, 0, 0, 1), ((0,), 1, 63, 0, 1), ((0,), 0, 0, 1, 0),
+                                                       ((0,), 1, 63, 1, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)]))
+    rng = np.random.Generator(np.random.PCG64(77))
+    files = []
+    while len(files) < 150:
+        f = mutate(base[int(rng.integers(len(base)))], rng, kind=int(rng.choice([0, 0, 2])))
+        files.append(f)
+    dev = torch.device("cuda", 0)
+    out = {}
+    for serial in (0, 1):
+        res = []
+        with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
+            ctx.set_option(capi.OPT_JPEG_SERIAL, serial)
+            for i in range(0, len(files), 6):
+                batch = files[i:i + 6]
+                d = torch.full((len(batch), H, W), 7, dtype=torch.uint8, device=dev)
+                try:
+                    ctx.jpeg_decode_gray_batch(batch, W, H, d.data_ptr(), W * H, W)
+                    st = ctx.sync(allow_capacity=True)
+                except capi.VsfError as e:
+                    st = e.status
+                    try:
+                        ctx.sync(allow_capacity=True)
+                    except capi.VsfError:
+                        pass
+                res.append((st, d.cpu().numpy().tobytes() if st in (capi.VSF_OK, capi.VSF_ERR_INVALID_ARG) else b""))
+        out[serial] = res
+    assert len(out[0]) == len(out[1]) == 25
+    decoded = 0
+    for i, (a, b) in enumerate(zip(out[0], out[1])):
+        assert a[0] == b[0], "batch %d: status %d (pipelined) vs %d (scan after scan)" % (i, a[0], b[0])
+        assert a[1] == b[1], "batch %d: the two forms decoded different bytes" % i
+        decoded += a[0] == capi.VSF_OK
+    assert decoded >= 5  # (damaged entropy data still decodes to something, as with libjpeg)

@@ -19,9 +19,11 @@
 // a stream of its own BESIDE the extraction of earlier batches.  Markers and tables are parsed on the host (the
 // compressed bytes come from host memory anyway), which also builds the lookahead tables once per distinct table set.
 //
-// PROGRESSIVE files (SOF2: what a web service or an image library writes, not a camera driver) take a third kernel,
-// jpeg_prog_kernel below: one wave per file walks the luminance scans one after the other into the coefficient buffer
-// (T.81 Annex G as libjpeg's jdphuff.c decodes it), and the IDCT kernel of the parallel decoder finishes the job.
+// PROGRESSIVE files (SOF2: what a web service or an image library writes, not a camera driver) take a third decoder:
+// prog_scan below decodes one luminance scan into the coefficient buffer (T.81 Annex G as libjpeg's jdphuff.c does);
+// jpeg_prog_pipe_kernel runs the scans of a file in the waves of one workgroup, each refinement scan a block row behind
+// the scans it refines, jpeg_prog_kernel one wave per file scan after scan (large batches, and damaged files again); the
+// IDCT kernel of the parallel decoder finishes the job.
 //
 // Checked bit for bit against JPEG files decoded by libjpeg-turbo (tests/golden/jpeg, tests/test_gpu_jpeg.py).
 // Sequential files whose components come in several scans take that kernel too (a scan then decodes a block whole).

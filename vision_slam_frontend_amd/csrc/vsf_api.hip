@@ -448,9 +448,9 @@ struct vsf_ctx {
   DevSet dorb, dfast;
   int gauss[4] = {0, 0, 0, 0};
   // Status words (bit 0: capacity overflow, bit 1: a JPEG stream broke off): word 0 belongs to the context's own stream
-  // (batched and host-pointer calls, vsf_sync), words 1..3 to the three frames that may be in flight (vsf_observe_submit) --
+  // (batched and host-pointer calls, vsf_sync), words 1..6 to the frames that may be in flight (vsf_observe_submit) --
   // a frame's kernels run on its slot's stream beside another frame's, so each frame sets, copies and clears its own word.
-  int32_t* d_status = nullptr;     // [4]
+  int32_t* d_status = nullptr;     // [1 + VSF_OBSERVE_MAX_SLOTS]
   uint32_t* fast_cells = nullptr;  // [2] cell counters of the resident FAST kernels (k_fast.hip)
   struct FastTune {  // resident FAST or one workgroup per four cells: what vsf_tune_fast_resident measured, per batch size
     int n = 0, choice = -1;
