@@ -126,7 +126,8 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on);
  * recorded behind the last operation that writes the images of the NEXT vsf_extract_batch_dev / vsf_stereo_batch_dev
  * call.  That call -- including its pipelined pyramid, which is otherwise not ordered after anything (vsf_set_pipeline)
  * -- waits for the event ON THE GPU; the host never does.  With it the promise of vsf_set_pipeline relaxes to "complete
- * when the event fires".  One-shot: the call that follows consumes it (the wait captures the event's state at that
+ * when the event fires".  One-shot: the call that follows consumes it (a call refused with VSF_ERR_INVALID_ARG launches
+ * nothing and leaves it pending) (the wait captures the event's state at that
  * moment, so the caller may record the same event again afterwards); NULL withdraws it.  The way back is ordinary
  * stream order: whatever the caller records on the context's stream after the call fires once the call has read its
  * inputs. */
