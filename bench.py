@@ -502,7 +502,9 @@ def main() -> int:
         res = {}
         rc = launch_ranks(args.gpus, sys.argv[1:], child_cmd=child, deadline_s=args.launch_deadline,
                           stall_s=args.launch_stall, result=res)
-        if (rc != 0 and not res.get("printed_json") and not args.no_gloo_retry and not os.environ.get("VSF_BENCH_ONE_GPU")
+        # (exit code 2 is this script's own "cannot run here": fewer GPUs than ranks, no GPU, a world-size mismatch -- no
+        # other backend changes that)
+        if (rc not in (0, 2) and not res.get("printed_json") and not args.no_gloo_retry and not os.environ.get("VSF_BENCH_ONE_GPU")
                 and os.environ.get("VSF_BENCH_BACKEND", "nccl") == "nccl"):
             # The RCCL run did not produce a line.  One labelled second attempt with the step's exchanges on gloo (tensors
             # take a detour through the host; each rank still on its own GPU): a measured curve with its backend named
