@@ -38,7 +38,7 @@ KERNELS = {  # stage -> (source, substring of the mangled kernel name whose body
     "fast_score_nms_grid": ("k_fast.hip", "fast_march_kernelILb0ELb1E"),
     "gauss_blur7": ("k_blur.hip", "blur_mma_kernel"),
     "select_harris_angle": ("k_select.hip", "orb_select_kernelILi256E"),
-    "orb_describe": ("k_describe.hip", "orb_orient_describe_kernel"),
+    "orb_describe": ("k_describe.hip", "orb_orient_describe_kernelILi4E"),
     "pyramid_resize": ("k_pyramid.hip", "resize_strip_kernelILi8E"),
     "hamming_knn2": ("k_match.hip", "knn2_fp4_kernelILb0E"),
 }

@@ -101,14 +101,18 @@ __device__ __forceinline__ void sincos_2pi(double x, double* s_out, double* c_ou
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kKpPerWave = 4;  // consecutive output keypoints per wave (per 256-frame step: 2 -> 0.89 ms, 4 -> 0.83, 8 -> 0.85,
-                                // 16 -> 0.89, 32 -> 0.97: the kernel lives on waves in flight, not on amortised prologues)
+// Consecutive output keypoints per wave (template parameter KPW).  At 2000 keypoints per image, per 256-frame step: 2 -> 0.89
+// ms, 4 -> 0.83, 8 -> 0.85, 16 -> 0.89, 32 -> 0.97: the kernel lives on waves in flight, not on amortised prologues -- FOUR.
+// At the reference's 10 000 there are waves enough either way and the prologue counts: 8 -> 3.07 ms against 3.20 (the step
+// 11.77 -> 11.51 ms; at 2000 the step LOSES 2 % with 8) -- EIGHT for large batches of >= 4096 keypoints per image (the
+// launcher decides).
 
 // K6 + K8 + output assembly.  The image's keypoints are numbered in output order (level-major, retainBest order
 // inside a level); wave w of the image takes numbers [4 w, 4 w + 4), whatever levels they belong to: lane k < 4
 // looks up keypoint k's level (binary search in the wave-scanned level counts), record and level geometry once, and
 // the wave then walks its keypoints with v_readlane broadcasts.  (One workgroup per (level, image) left most waves
 // with two or three keypoints and a prologue longer than their work.)
+template <int kKpPerWave>
 __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a) {
   constexpr int kWinRows = 39, kWinPitch = 64, kWinBytes = kWinRows * kWinPitch;
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][2][kWinBytes];
@@ -351,7 +355,13 @@ void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
   a.desc_out = d_desc;
   a.counts = d_counts;
   a.status = d.status;
-  a.nblocks = std::max((max_keypoints + 4 * kKpPerWave - 1) / (4 * kKpPerWave), 1);
+  // (eight per wave needs a launch that still fills the chip with waves: 512 images x 10 000 keypoints; 64-192 images of
+  // 8 000 -- 1920x1080 -- run 1-2 % faster with four)
+  const int kpw = (max_keypoints >= 4096 && (long)im.n * max_keypoints >= 3000000L) ? 8 : 4;
+  a.nblocks = std::max((max_keypoints + 4 * kpw - 1) / (4 * kpw), 1);
   a.nimages = im.n;
-  hipLaunchKernelGGL(orb_orient_describe_kernel, dim3(a.nblocks * ((im.n + 7) / 8 * 8)), dim3(256), 0, s, a);
+  if (kpw == 8)
+    hipLaunchKernelGGL(orb_orient_describe_kernel<8>, dim3(a.nblocks * ((im.n + 7) / 8 * 8)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(orb_orient_describe_kernel<4>, dim3(a.nblocks * ((im.n + 7) / 8 * 8)), dim3(256), 0, s, a);
 }

@@ -115,9 +115,9 @@ class Frontend {
   // ObserveImage's return value is OdomCheck's decision (cc:404-409): nothing in the reference's control flow needs a
   // frame's features before the next frame arrives.  With pipelining on (fused mode; choose before the first
   // ObserveImage) a call queues its frame on the GPU (vsf_observe_submit) and returns; the frame's result is collected
-  // and booked -- in frame order, with the odometry of ITS call -- when its slot is needed again (three frames later) or
+  // and booked -- in frame order, with the odometry of ITS call -- when its slot is needed again (frames_in_flight() frames later) or
   // when anything reads the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and
-  // bytes as the synchronous mode; a GPU failure then surfaces in last_status() one or two calls late.
+  // bytes as the synchronous mode; a GPU failure then surfaces in last_status() a few calls late.
   void set_pipelined(bool on) { pipelined_ = on; }
   // How many frames ObserveImage keeps in flight when pipelined (1..6, default 4): each runs its ~25 dependent small
   // kernels on a stream and a set of buffers of its own; their tails stay in frame order.
