@@ -174,7 +174,9 @@ typedef enum {
   VSF_OPT_PIPE_PRIORITY = 10,  /* stream priority of the pipelined pyramid chain: 0 normal, 1 lowest, -1 highest; set it before
                                 * vsf_set_pipeline(ctx, 1) */
   VSF_OPT_MATCH_INT8 = 11,     /* 0: the matcher on the FP4 matrix instruction (K = 64 per instruction); 1: round 2's int8 form */
-  VSF_OPT_COUNT = 12
+  VSF_OPT_FAST_BITS = 12,      /* FAST as a segment test on bit planes with scores only where it fires (k_fastbits.hip; same
+                                  candidates bit for bit): 0 never, 1 for batches of >= 8 images, 2 for any batch */
+  VSF_OPT_COUNT = 13
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);

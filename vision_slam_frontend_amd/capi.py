@@ -40,7 +40,7 @@ EXPORTS = [
 ]
 # vsf_option (include/vsf.h)
 (OPT_BLUR_MARCH, OPT_FAST_BOTH_MAX, OPT_SORT_SERIAL, OPT_SELECT_WIDE, OPT_JPEG_SERIAL, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN,
- OPT_PYRAMID_ROWS, OPT_SELECT_BIG_CLASS, OPT_PIPE_AFTER_FAST, OPT_PIPE_PRIORITY, OPT_MATCH_INT8) = range(12)
+ OPT_PYRAMID_ROWS, OPT_SELECT_BIG_CLASS, OPT_PIPE_AFTER_FAST, OPT_PIPE_PRIORITY, OPT_MATCH_INT8, OPT_FAST_BITS) = range(13)
 STAGE_COUNT = 8
 
 

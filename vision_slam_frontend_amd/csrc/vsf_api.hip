@@ -36,6 +36,7 @@ struct Geometry {
   VsfGeom g{};
   std::vector<VsfLevel> levels;
   std::vector<uint32_t> units;
+  std::vector<uint2> bits_items;  // k_fastbits.hip work items (empty: the geometry does not fit that kernel)
   std::vector<VsfTap> xt, yt;
   std::vector<uint32_t> blur_tiles;
   // matrix-core blur (k_blur.hip blur_mma_kernel): work units and constant MFMA operands
@@ -266,6 +267,7 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
   G.g.nwork_half = (int)half_items.size();
   G.units.insert(G.units.end(), half_items.begin(), half_items.end());
   if (G.units.empty()) G.units.push_back(0);
+  if (!(orb && nms && vsf_fast_bits_items(G.levels.data(), nlevels, 4, &G.bits_items))) G.bits_items.clear();
   G.g.lvlkp_entries = std::max(kp_off, 1);
   // resize coefficient tables (host only: the kernel evaluates the same arithmetic in place; built here to check
   // that a lane's eight x taps fit the 8-byte source window it loads) + blur tiles (ORB only)
@@ -396,6 +398,8 @@ struct DevSet {  // device copies of one Geometry + its work buffers
   VsfDev d{};
   VsfLevel* levels = nullptr;
   uint32_t* units = nullptr;
+  uint2* bits_items = nullptr;
+  int n_bits_items = 0;
   uint32_t* blur_tiles = nullptr;
   uint32_t* blur_mma_units = nullptr;
   uint32_t* blur_mma_units_small = nullptr;
@@ -594,6 +598,10 @@ hipError_t upload(T** dst, const std::vector<T>& v) {
 vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, int n_images) {
   VSF_HIP(upload(&ds->levels, G.levels));
   VSF_HIP(upload(&ds->units, G.units));
+  if (!G.bits_items.empty()) {
+    VSF_HIP(upload(&ds->bits_items, G.bits_items));
+    ds->n_bits_items = (int)G.bits_items.size();
+  }
   VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
   VSF_HIP(upload(&ds->blur_mma_units, G.blur_mma_units));
   VSF_HIP(upload(&ds->blur_mma_units_small, G.blur_mma_units_small));
@@ -604,6 +612,8 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   d.ic_table = ds->ic_table;
   d.levels = ds->levels;
   d.units = ds->units;
+  d.bits_items = ds->bits_items;
+  d.n_bits_items = ds->n_bits_items;
   const size_t n = (size_t)n_images;
   if (orb) {
     VSF_HIP(hipMalloc((void**)&d.pyr, n * G.g.pyr_bytes));
@@ -626,6 +636,7 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
 void free_devset(DevSet* ds) {
   hipFree(ds->levels);
   hipFree(ds->units);
+  hipFree(ds->bits_items);
   hipFree(ds->blur_tiles);
   hipFree(ds->blur_mma_units);
   hipFree(ds->blur_mma_units_small);
@@ -948,7 +959,12 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   if (blur_beside) fork_blur();
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
-    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
+    // VSF_OPT_FAST_BITS: the segment test on bit planes, scores only where it fires (k_fastbits.hip; the same candidates)
+    const int fb = ctx->tuning.fast_bits;
+    if (d.bits_items && ctx->p.fast_threshold >= 1 && (fb == 2 || (fb == 1 && im.n >= 8)))
+      vsf_launch_fast_bits(d, g, im, d.bits_items, d.n_bits_items, ctx->p.fast_threshold, st);
+    else
+      vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
   }
   if (pipe) {
     vsf_note(hipEventRecord(ctx->ev_fast_done, st));
@@ -1353,6 +1369,10 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
     case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
     case VSF_OPT_PIPE_AFTER_FAST: t.pipe_after_fast = value != 0; break;
     case VSF_OPT_MATCH_INT8: t.match_int8 = value != 0; break;
+    case VSF_OPT_FAST_BITS:
+      if (value < 0 || value > 2) return VSF_ERR_INVALID_ARG;
+      t.fast_bits = value;
+      break;
     case VSF_OPT_PIPE_PRIORITY:
       if (value < -1 || value > 1) return VSF_ERR_INVALID_ARG;
       t.pipe_priority = value;  // (takes effect with the next vsf_set_pipeline(ctx, 1))
@@ -1393,6 +1413,7 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
     case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
     case VSF_OPT_PIPE_AFTER_FAST: *value = t.pipe_after_fast; break;
     case VSF_OPT_MATCH_INT8: *value = t.match_int8; break;
+    case VSF_OPT_FAST_BITS: *value = t.fast_bits; break;
     case VSF_OPT_PIPE_PRIORITY: *value = t.pipe_priority; break;
     case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/vsf.h"
 
 // FAST march kernel: a wave owns a band of 248 keypoint columns (lanes 1..62 x 4 px; lanes 0 and 63 carry the raw halo
@@ -92,6 +94,7 @@ struct VsfTuning {
   int fast_both_max = 16;  // VSF_OPT_FAST_BOTH_MAX: largest batch (images) whose full and half-wave FAST cells share one launch
   int sort_serial = 0;     // VSF_OPT_SORT_SERIAL: 1 = sort_trim's one-lane kernel
   int select_wide = 1;     // VSF_OPT_SELECT_WIDE: 1 = a frame or two takes the 1024-thread whole-level selection class
+  int fast_bits = 0;         // VSF_OPT_FAST_BITS: FAST on bit planes (k_fastbits.hip): 0 never, 1 batches of >= 8 images, 2 any batch
   int match_int8 = 0;        // VSF_OPT_MATCH_INT8: 1 = the int8 form of the matcher (v_mfma_i32_32x32x32_i8) instead of the FP4 one
   int pipe_priority = 0;     // VSF_OPT_PIPE_PRIORITY: stream priority of the pipelined pyramid chain (0 normal, 1 lowest, -1 highest)
   int pipe_after_fast = 1;   // VSF_OPT_PIPE_AFTER_FAST: the pipelined pyramid of call k + 1 starts behind call k's FAST (1) or at once (0)
@@ -140,6 +143,8 @@ hipError_t vsf_prepare_jpeg_kernels(int lds_limit);
 struct VsfDev {
   const VsfLevel* levels;   // [nlevels]
   const uint32_t* units;    // [nwork_full + nwork_half]: level << 24 | band << 16 | (first) strip
+  const uint2* bits_items;  // [n_bits_items] k_fastbits.hip work items, or NULL
+  int n_bits_items;
   uint8_t* pyr;             // [max_images][pyr_bytes]   unblurred levels 1..L-1 (level 0 is the input)
   uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
   uint32_t* cand;           // [max_images][cand_entries]  per-unit candidate segments (unit-local raster order)
@@ -173,6 +178,13 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
 // threshold: FAST threshold; nms == 0 keeps every corner (standalone FAST only).
 void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s,
                      int resident_waves_per_simd = 0, int n_cus = 0, uint32_t* d_cell_counters = nullptr);
+// k_fastbits.hip: the segment test on bit planes + scores only where it fires; same outputs as vsf_launch_fast (NMS on,
+// threshold >= 1).  `d_items` from vsf_fast_bits_items (false: the geometry does not fit).
+#ifdef __cplusplus
+bool vsf_fast_bits_items(const VsfLevel* levels, int nlevels, int chain, std::vector<uint2>* items);
+#endif
+void vsf_launch_fast_bits(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint2* d_items, int nitems,
+                          int threshold, hipStream_t s);
 void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                        hipStream_t s);
 void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n_points, int use_lds, int mode,
