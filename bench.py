@@ -470,6 +470,8 @@ def main() -> int:
     ap.add_argument("--ingest-priority", choices=["low", "normal", "high"], default=None,
                     help="--ingest jpeg: HIP stream priority of the decode stream")
     ap.add_argument("--match-int8", action="store_true", help="VSF_OPT_MATCH_INT8: round 2's int8 form of the matcher (A/B runs)")
+    ap.add_argument("--fast-bits", type=int, default=0, choices=[0, 1, 2],
+                    help="VSF_OPT_FAST_BITS (A/B runs): FAST as a segment test on bit planes (k_fastbits.hip), 1 = for batches of >= 8 images")
     ap.add_argument("--match-on-tail", choices=["auto", "on", "off"], default="auto",
                     help="the stereo GetMatches as the first kernel of the step's tail (its matrix-core work beside the next "
                          "step's pyramid and FAST) instead of the last of the extraction; auto: from 5000 features per frame on "
@@ -627,6 +629,8 @@ def main() -> int:
     pipeline = not args.no_pipeline
     if args.match_int8:
         ctx.set_option(capi.OPT_MATCH_INT8, 1)
+    if args.fast_bits:
+        ctx.set_option(capi.OPT_FAST_BITS, args.fast_bits)
     if args.pipe_priority is not None:
         ctx.set_option(capi.OPT_PIPE_PRIORITY, args.pipe_priority)
     ctx.set_pipeline(pipeline)
