@@ -410,10 +410,23 @@ vsf_status vsf_observe_reset(vsf_ctx* ctx);
  * of 4) -- the input of vsf_bayer_bg_to_gray_batch_dev or of the extraction.  The files are copied before the call
  * returns; the decode is asynchronous on the context's stream (one wave per image: run it on a context / stream of its
  * own beside other work).  A stream that breaks off inside its entropy-coded data decodes as libjpeg does (zero bits) and
- * makes the next vsf_sync return VSF_ERR_INVALID_ARG.  PNG (the other format imdecode reads) is not built. */
+ * makes the next vsf_sync return VSF_ERR_INVALID_ARG.  PNG files take vsf_png_decode_gray_batch. */
 vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, const size_t* nbytes, int n_images,
                                       int width, int height, uint8_t* d_dst, size_t dst_image_stride,
                                       size_t dst_row_stride);
+
+/* The same for n PNG files (the other format a CompressedImage carries: image_transport's lossless setting): chunk walk and
+ * CRC checks on the host (a damaged critical chunk fails the call, as it fails png_read_*; a damaged ancillary chunk is
+ * skipped), RFC 1951 inflate and the PNG row filters on the device.  Built for what a gray read needs no colour arithmetic
+ * for: colour type 0 at 1, 2, 4, 8 and 16 bits and colour type 4 at 8 and 16 bits, non-interlaced -- 16-bit samples keep
+ * their high byte, alpha is dropped, 1 / 2 / 4-bit samples are replicated to 8 bits (grfmt_png.cpp's libpng settings for
+ * IMREAD_GRAYSCALE).  Colour, palette and Adam7 files return VSF_ERR_UNSUPPORTED, files of another size or with malformed
+ * chunks VSF_ERR_INVALID_ARG (nothing is launched then); compressed data that breaks (what libpng answers with png_error)
+ * makes the next vsf_sync return VSF_ERR_INVALID_ARG.  What a file holds behind its last image byte (Adler-32 included) is
+ * not looked at, as libpng only warns about it.  Arguments and the asynchronous contract as for the JPEG call. */
+vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, const size_t* nbytes, int n_images,
+                                     int width, int height, uint8_t* d_dst, size_t dst_image_stride,
+                                     size_t dst_row_stride);
 
 /* SURVEY section 8(f) row f4, the part behind cv::imdecode: DecodeImage's cvtColor(COLOR_BayerBG2BGR) +
  * cvtColor(COLOR_BGR2GRAY) (slam_frontend_main.cc:101-106) for n 8-bit mosaics of width x height resident in HBM, in

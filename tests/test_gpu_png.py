@@ -1,0 +1,277 @@
+"""GPU parity of vsf_png_decode_gray_batch -- cv::imdecode(msg.data, IMREAD_GRAYSCALE) for PNG payloads
+(slam_frontend_main.cc:99-100) -- against the real libpng + zlib (PIL reads every file back; zlib itself says what a damaged
+stream is worth): files written by PIL at every compression level and by tests/png_craft.py with every row filter, every
+deflate block type (stored, fixed, dynamic, run-length matches of distance 1, long-distance matches), IDAT payloads cut
+into pieces, 1 / 2 / 4 / 8 / 16-bit gray and gray + alpha; what libpng refuses is refused (damaged critical chunks, unknown
+critical chunks, wrong size), what it only warns about is read (damaged ancillary chunks, a wrong Adler-32, trailing
+garbage); damaged compressed data never faults and is flagged exactly when zlib gives up before the image's last byte."""
+import io
+import sys
+import zlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+Image = pytest.importorskip("PIL.Image")
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import png_craft as pc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from vision_slam_frontend_amd import capi
+    capi.lib()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500))
+    yield c
+    c.close()
+
+
+def pil_gray(png: bytes) -> np.ndarray:
+    """What cv::imdecode(IMREAD_GRAYSCALE) returns for a grayscale PNG, computed from libpng's own decode (PIL): 8-bit
+    samples as they are, 16-bit samples' high byte (png_set_strip_16), alpha dropped, 1 / 2 / 4-bit replicated."""
+    im = Image.open(io.BytesIO(png))
+    im.load()
+    if im.mode in ("I;16", "I;16B", "I"):
+        return (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)
+    if im.mode in ("LA", "RGBA"):  # (PIL shows 16-bit gray + alpha as 8-bit RGBA: the samples' high bytes)
+        return np.asarray(im)[:, :, 0].copy()
+    if im.mode == "1":
+        return (np.asarray(im).astype(np.uint8) * 255)
+    assert im.mode == "L", im.mode
+    return np.asarray(im).copy()
+
+
+def decode(capi, ctx, files, w, h, allow_status=(), pitch=None):
+    dev = torch.device("cuda", 0)
+    pitch = pitch or (w + 3) // 4 * 4
+    n = len(files)
+    d = torch.full((n, h, pitch), 0xA5, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    st = ctx.png_decode_gray_batch(files, w, h, d.data_ptr(), h * pitch, pitch, allow_status=allow_status)
+    if st != capi.VSF_OK:
+        return st, None, None
+    sync = ctx.sync(allow_capacity=False) if not allow_status else None
+    return st, d.cpu().numpy()[:, :, :w], sync
+
+
+def scene(w, h, seed=0, smooth=True):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (xx * 3 + yy * 2) % 256 if smooth else 0
+    return ((base + rng.integers(0, 24 if smooth else 256, (h, w))) % 256).astype(np.uint8)
+
+
+def test_pil_written_files_every_level(capi, ctx):
+    from vision_slam_frontend_amd import synth
+    left, right = synth.stereo_pair(640, 480, 0)
+    files, want = [], []
+    for img in (left, right, scene(640, 480, 1), np.zeros((480, 640), np.uint8), scene(640, 480, 2, smooth=False)):
+        for level in (0, 1, 6, 9):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="PNG", compress_level=level)
+            files.append(buf.getvalue())
+            want.append(img)
+    st, got, sync = decode(capi, ctx, files, 640, 480)
+    assert st == capi.VSF_OK and sync == capi.VSF_OK
+    for i, (g, wv, f) in enumerate(zip(got, want, files)):
+        np.testing.assert_array_equal(pil_gray(f), wv)
+        np.testing.assert_array_equal(g, wv, err_msg="file %d" % i)
+
+
+@pytest.mark.parametrize("strategy,level", [(zlib.Z_DEFAULT_STRATEGY, 6), (zlib.Z_FIXED, 6), (zlib.Z_RLE, 6),
+                                             (zlib.Z_HUFFMAN_ONLY, 6), (zlib.Z_FILTERED, 9), (zlib.Z_DEFAULT_STRATEGY, 0),
+                                             (zlib.Z_DEFAULT_STRATEGY, 1)])
+def test_crafted_filters_and_block_types(capi, ctx, strategy, level):
+    """Every row filter (one type per row, all five in turn and at random), every deflate block type, IDAT in pieces."""
+    rng = np.random.Generator(np.random.PCG64(42 + strategy * 16 + level))
+    cases = []
+    for w, h in ((640, 480), (67, 41), (1, 1), (5, 300), (300, 3), (64, 64), (65, 129)):
+        img = scene(w, h, int(rng.integers(1 << 30)), smooth=bool(rng.integers(2)))
+        for filters in (np.arange(h) % 5, rng.integers(0, 5, h), np.full(h, 4), np.full(h, 3)):
+            piece = [None, 1 if w * h < 10000 else 4096, 7 if w * h < 10000 else 9000, 8192][int(rng.integers(4))]
+            cases.append((w, h, img, pc.gray8(img, filters=filters, level=level, strategy=strategy, idat_piece=piece)))
+    by_size = {}
+    for w, h, img, f in cases:
+        by_size.setdefault((w, h), []).append((img, f))
+    for (w, h), group in by_size.items():
+        with capi.Context(capi.default_params(max(w, 64), max(h, 64), max_images=2, nfeatures=100)) as c:
+            st, got, sync = decode(capi, c, [f for _, f in group], w, h)
+            assert st == capi.VSF_OK and sync == capi.VSF_OK, (w, h)
+            for i, (img, f) in enumerate(group):
+                np.testing.assert_array_equal(pil_gray(f), img, err_msg="PIL disagrees with the crafted file")
+                np.testing.assert_array_equal(got[i], img, err_msg="%dx%d file %d" % (w, h, i))
+
+
+def test_long_matches_far_distances_and_overlaps(capi, ctx):
+    """Periodic content: matches of length 258 at distances 1 .. 32768, self-overlapping copies, a window that wraps."""
+    w, h = 640, 480
+    files, want = [], []
+    for period in (1, 2, 3, 5, 63, 64, 65, 257, 258, 259, 640, 641 * 3, 32768 // 641 * 641, 32767):
+        flat = (np.arange(w * h) % period * 37 % 251).astype(np.uint8)
+        img = flat.reshape(h, w)
+        files.append(pc.gray8(img, level=9))
+        want.append(img)
+    rng = np.random.Generator(np.random.PCG64(3))
+    tile = rng.integers(0, 256, 32768, dtype=np.uint8)   # incompressible, then repeated: matches at distance exactly 32768
+    img = np.resize(tile, w * h).reshape(h, w)
+    files.append(pc.gray8(img, level=9))
+    want.append(img)
+    st, got, sync = decode(capi, ctx, files, w, h)
+    assert st == capi.VSF_OK and sync == capi.VSF_OK
+    for i in range(len(files)):
+        np.testing.assert_array_equal(pil_gray(files[i]), want[i])
+        np.testing.assert_array_equal(got[i], want[i], err_msg="file %d" % i)
+
+
+def test_bit_depths_and_alpha(capi):
+    rng = np.random.Generator(np.random.PCG64(9))
+    for w, h in ((640, 480), (37, 29), (8, 8), (9, 5)):
+        with capi.Context(capi.default_params(max(w, 64), max(h, 64), max_images=2, nfeatures=100)) as c:
+            files, want = [], []
+            filters = rng.integers(0, 5, h)
+            for depth in (1, 2, 4):
+                v = rng.integers(0, 1 << depth, (h, w)).astype(np.uint8)
+                files.append(pc.write_png(pc.pack_samples(v, depth), w, h, depth, 0, filters=filters))
+                want.append((v * (255 // ((1 << depth) - 1))).astype(np.uint8))
+            v16 = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+            files.append(pc.write_png(pc.pack_samples(v16, 16), w, h, 16, 0, filters=filters))
+            want.append((v16 >> 8).astype(np.uint8))
+            ga = rng.integers(0, 256, (h, w, 2)).astype(np.uint8)
+            files.append(pc.write_png(pc.pack_samples(ga, 8), w, h, 8, 4, filters=filters))
+            want.append(ga[:, :, 0])
+            ga16 = rng.integers(0, 65536, (h, w, 2)).astype(np.uint16)
+            files.append(pc.write_png(pc.pack_samples(ga16, 16), w, h, 16, 4, filters=filters))
+            want.append((ga16[:, :, 0] >> 8).astype(np.uint8))
+            # gray with a tRNS chunk: png_set_tRNS_to_alpha, then the alpha is stripped again
+            v8 = rng.integers(0, 256, (h, w)).astype(np.uint8)
+            files.append(pc.write_png(pc.pack_samples(v8, 8), w, h, 8, 0, filters=filters, extra_before=[pc.chunk(b"tRNS", b"\x00\x07")]))
+            want.append(v8)
+            st, got, sync = decode(capi, c, files, w, h)
+            assert st == capi.VSF_OK and sync == capi.VSF_OK
+            for i in range(len(files)):
+                np.testing.assert_array_equal(pil_gray(files[i]), want[i], err_msg="PIL, %dx%d file %d" % (w, h, i))
+                np.testing.assert_array_equal(got[i], want[i], err_msg="%dx%d file %d" % (w, h, i))
+
+
+def test_what_libpng_refuses_is_refused_and_what_it_warns_about_is_read(capi, ctx):
+    w, h = 96, 64
+    img = scene(w, h, 5)
+    good = pc.gray8(img, filters=np.arange(h) % 5)
+    with capi.Context(capi.default_params(w, h, max_images=2, nfeatures=100)) as c:
+        def status(f, ww=w, hh=h):
+            return c.png_decode_gray_batch([f], ww, hh, torch.zeros((hh, (ww + 3) // 4 * 4), dtype=torch.uint8, device="cuda").data_ptr(),
+                                           hh * ((ww + 3) // 4 * 4), (ww + 3) // 4 * 4,
+                                           allow_status=(capi.VSF_ERR_INVALID_ARG, capi.VSF_ERR_UNSUPPORTED))
+        assert status(good) == capi.VSF_OK and c.sync() == capi.VSF_OK
+        assert status(good, w + 1, h) == capi.VSF_ERR_INVALID_ARG          # another size
+        assert status(pc.gray8(img, bad_idat_crc=True)) == capi.VSF_ERR_INVALID_ARG
+        assert status(good[:-12]) == capi.VSF_ERR_INVALID_ARG               # no IEND
+        assert status(good[:40]) == capi.VSF_ERR_INVALID_ARG
+        assert status(b"\x89PNG\r\n\x1a\n") == capi.VSF_ERR_INVALID_ARG
+        assert status(pc.gray8(img, extra_before=[pc.chunk(b"ABCD", b"xyz")])) == capi.VSF_ERR_INVALID_ARG  # unknown critical chunk
+        rgb = io.BytesIO()
+        Image.fromarray(np.dstack([img, img, img])).save(rgb, format="PNG")
+        assert status(rgb.getvalue()) == capi.VSF_ERR_UNSUPPORTED
+        pal = io.BytesIO()
+        Image.fromarray(img).convert("P").save(pal, format="PNG")
+        assert status(pal.getvalue()) == capi.VSF_ERR_UNSUPPORTED
+        assert status(pc.write_png(pc.pack_samples(img, 8), w, h, 8, 0, interlace=1)) == capi.VSF_ERR_UNSUPPORTED
+        # a wrong Adler-32 in the piece of input that also holds the image's last byte: zlib checks it in the call that
+        # delivers the last row ("incorrect data check"), png_read_IDAT_data raises png_error
+        s = bytearray(pc.idat_stream(good))
+        s[-1] ^= 0xFF
+        wrong_adler = bytes(s)
+        assert status(pc.replace_idat(good, wrong_adler)) == capi.VSF_OK
+        with pytest.raises(capi.VsfError) as ei:
+            c.sync()
+        assert ei.value.status == capi.VSF_ERR_INVALID_ARG
+        assert c.sync() == capi.VSF_OK
+        # warnings only: a damaged ancillary chunk, an ancillary chunk nobody knows, bytes behind the end of the zlib stream
+        # ("Extra compressed data"), and the same wrong Adler-32 when it sits in a chunk of its own -- libpng then reads it
+        # with no row left to fill (png_read_finish_IDAT), where a zlib error is a warning
+        readable = [
+            pc.gray8(img, extra_before=[pc.chunk(b"tEXt", b"Comment\x00hello", bad_crc=True)]),
+            pc.gray8(img, extra_before=[pc.chunk(b"prVt", b"\x01\x02\x03")], extra_after=[pc.chunk(b"tIME", bytes(7))]),
+            pc.replace_idat(good, pc.idat_stream(good) + b"trailing garbage"),
+            pc.write_png(None, w, h, 8, 0, stream=wrong_adler, idat_piece=len(wrong_adler) - 4),
+        ]
+        st, got, sync = decode(capi, c, readable, w, h)
+        assert st == capi.VSF_OK and sync == capi.VSF_OK
+        for i, f in enumerate(readable):
+            np.testing.assert_array_equal(got[i], img, err_msg="file %d" % i)
+        # (PIL's own chunk reader is stricter than libpng here -- it refuses a damaged ancillary chunk -- so these four are
+        # held against libpng's documented behaviour: png_crc_error warns for ancillary chunks, png_read_finish_IDAT reads
+        # what is left of the stream without a row to fill and reports errors as benign)
+
+
+def test_damaged_compressed_data_never_faults_and_is_flagged_as_zlib_flags_it(capi):
+    """400 files whose compressed data is damaged (bit flips, cuts, zeroed runs, insertions -- anywhere, or only near the
+    end), continues behind the image's last byte (further blocks, garbage) or both, with the IDAT payload cut into chunks
+    of various sizes.  For each: zlib, fed as libpng feeds it (tests/png_craft.py zlib_reference), either delivers the
+    image's bytes -- then the decode must match (or, for a filter type above 4, be flagged) -- or gives up: then the flag
+    must be set.  That includes everything zlib still reads behind the last byte in the call that delivers it: the
+    Adler-32, block headers, code tables."""
+    w, h = 160, 120
+    rng = np.random.Generator(np.random.PCG64(2026))
+    expected = (w + 1) * h
+    flagged = clean = 0
+    with capi.Context(capi.default_params(w, h, max_images=2, nfeatures=100)) as c:
+        dev = torch.device("cuda", 0)
+        for it in range(400):
+            k = it % 6
+            img = scene(w, h, 100 + it, smooth=k % 2 == 0)
+            strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED][k]
+            rows = pc.filter_rows(img, 1, rng.integers(0, 5, h))
+            extra = [0, 0, 1, 700, 40000][int(rng.integers(5))]   # the stream goes on behind the image ("Too much image data")
+            tail_bytes = bytes(rng.integers(0, 256, extra, dtype=np.uint8))
+            stream = pc.deflate(rows + tail_bytes, [6, 6, 6, 6, 0, 9][k], strategy)
+            how = int(rng.integers(4))
+            if how == 0:
+                stream = pc.mutate_stream(stream, rng)
+            elif how == 1:  # damage near the end only
+                cut = max(2, len(stream) - int(rng.integers(1, 300)))
+                stream = stream[:cut] + pc.mutate_stream(b"xx" + stream[cut:], rng)[2:]
+            elif how == 2:
+                stream = stream + bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+            if len(stream) < 8:
+                continue
+            piece = [None, len(stream) - 4, len(stream) - 7, 100, 5000, 8192, 9000][int(rng.integers(7))]
+            f = pc.write_png(None, w, h, 8, 0, stream=stream, idat_piece=piece)
+            ref = pc.zlib_reference(pc.idat_pieces(f), expected)
+            d = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+            st = c.png_decode_gray_batch([f], w, h, d.data_ptr(), w * h, w, allow_status=(capi.VSF_ERR_INVALID_ARG,))
+            if st != capi.VSF_OK:   # the host refused it (a zlib header that no longer passes its checks)
+                hdr = pc.idat_stream(f)[:2]
+                assert (hdr[0] & 15) != 8 or (hdr[0] >> 4) > 7 or (hdr[1] & 32) or ((hdr[0] << 8) | hdr[1]) % 31, it
+                continue
+            try:
+                sync = c.sync()
+            except capi.VsfError as e:
+                sync = e.status
+            got_rows = None if ref is None else np.frombuffer(ref, np.uint8).reshape(h, w + 1)
+            if ref is None or got_rows[:, 0].max() > 4:
+                assert sync == capi.VSF_ERR_INVALID_ARG, "file %d: broken data not flagged" % it
+                flagged += 1
+            else:
+                assert sync == capi.VSF_OK, "file %d: flagged although zlib delivers the image" % it
+                np.testing.assert_array_equal(d.cpu().numpy(), pil_unfilter(got_rows, w, h), err_msg="file %d" % it)
+                clean += 1
+    assert flagged > 60 and clean > 60, (flagged, clean)
+
+
+def pil_unfilter(rows, w, h):
+    """Reconstructs 8-bit gray scanlines (filter byte + w bytes per row) with PIL: the rows go back into a stored-block zlib
+    stream inside a fresh PNG."""
+    stream = pc.deflate(rows.tobytes(), 0)
+    return pil_gray(pc.write_png(None, w, h, 8, 0, stream=stream))

@@ -1,0 +1,634 @@
+// k_png.hip -- SURVEY 8(f) row f4, the other format DecodeImage's cv::imdecode(msg.data, IMREAD_GRAYSCALE) reads
+// (slam_frontend_main.cc:99-100): PNG.  Restates zlib's inflate (RFC 1951; the three block types, the canonical Huffman
+// codes, the limits inflate_table enforces) and libpng's row filters (PNG specification section 9: None, Sub, Up, Average,
+// Paeth) for grayscale files; the chunk walk and the CRCs are the host's (vsf_png_host.cc).
+//
+// png_inflate_kernel: one wave per file.  A deflate stream is one serial chain of codes, so -- as in the one-wave JPEG
+// decoders of k_jpeg.hip -- the walk is written wave-uniform: bit buffer, positions and block state live in scalar
+// registers and the stream is fetched by scalar loads.  What is new here is the code lookup.  The tables of a dynamic
+// block are built inside the kernel, so they cannot sit behind the constant cache; instead a canonical code is decoded by
+// its definition with the lanes as the 15 possible lengths: lane L holds the first code of length L, how many there are
+// and where their symbols start in the sorted symbol list; it takes the first L bits of the stream and tests
+// `bits - first < count`; the one lane that answers yes (a prefix code: at most one can) names the length, and the symbol
+// is read out of the sorted list, which lives in vector registers (288 + 32 symbols = 6 registers).  No memory on the
+// path of a symbol.  Output bytes go into a 32 KiB ring in LDS -- deflate's window -- literals by way of a register that
+// collects 64 of them, matches as lane-parallel ring-to-ring copies (a match that overlaps itself reads its period from
+// in front of its start); every completed 16 KiB leave for HBM as whole lines, their Adler-32 taken on the way.  What
+// follows the image's last byte is read as far as zlib reads it in the call that delivers the last row (see the kernel).
+//
+// png_unfilter_kernel: one wave per file, 64 rows at a time as a wavefront (lane k is one byte behind lane k - 1, whose
+// reconstructed byte of one step ago is its "above", of two steps ago its "above left"): every filter type per lane,
+// branch-free.  Only the byte plane a gray read keeps is reconstructed (the filters work per byte plane: a 16-bit
+// sample's low byte and an alpha sample never feed the high byte of the gray sample).
+#include "vsf_internal.h"
+#include "vsf_png_host.h"
+
+namespace {
+
+using namespace vsf_png;
+
+template <class T>
+using cptr = const __attribute__((address_space(4))) T*;
+template <class T>
+__device__ __forceinline__ cptr<T> in_constant(const T* p) {
+  return (cptr<T>)(uintptr_t)p;
+}
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i-1 (lane 0: 0)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+
+constexpr int kMaxLit = 288, kMaxDist = 32, kMaxCodes = kMaxLit + kMaxDist;
+__constant__ uint8_t c_cl_order[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 0};
+
+// ---- the deflate stream, least significant bit first; wave-uniform ----
+struct BitsLsb {
+  const uint32_t* words;
+  uint32_t wpos, nwords;  // next dword; dwords that exist (the upload pads every stream with zeros)
+  uint64_t acc;
+  int n;
+  __device__ __forceinline__ void fill() {  // >= 33 bits afterwards
+    if (n <= 32) {
+      const uint32_t w = wpos < nwords ? in_constant(words)[wpos] : 0u;
+      acc |= (uint64_t)w << n;
+      ++wpos;
+      n += 32;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek() const { return (uint32_t)acc; }
+  __device__ __forceinline__ void drop(int k) {
+    acc >>= k;
+    n -= k;
+  }
+  __device__ __forceinline__ uint32_t take(int k) {  // k <= 16, after fill()
+    const uint32_t v = (uint32_t)acc & ((1u << k) - 1u);
+    drop(k);
+    return v;
+  }
+  // bytes of the stream consumed so far (whole bytes still in the buffer given back)
+  __device__ __forceinline__ uint32_t byte_pos() const { return wpos * 4u - (uint32_t)(n >> 3); }
+};
+
+// One canonical code as the lanes hold it: lane L (1..15) knows the codes of length L.
+struct LaneCode {
+  uint32_t first, cnt, off;
+};
+
+// Decodes one symbol index (position in the sorted symbol list) from the next bits; *len = its length, or 0: no code.
+__device__ __forceinline__ uint32_t decode_index(uint32_t peek, const LaneCode& c, int lane, int* len) {
+  const uint32_t rev = __builtin_bitreverse32(peek);  // the stream's first bit on top
+  const uint32_t top = (lane >= 1 && lane <= 15) ? (rev >> (32 - lane)) : 0u;
+  const uint32_t d = top - c.first;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(d < c.cnt);
+  if (m == 0ull) {
+    *len = 0;
+    return 0u;
+  }
+  const int L = __builtin_ctzll(m);
+  *len = L;
+  return (uint32_t)__builtin_amdgcn_readlane((int)(c.off + d), L);
+}
+
+// Builds a canonical code from nsym lengths at lens[0..nsym) (LDS): per-lane description + the symbols sorted by (length,
+// symbol) into sorted[0..) (LDS).  Returns false for a set of lengths zlib's inflate_table refuses: over-subscribed, or
+// incomplete with anything but a single one-bit code (allow_lone; never for the code-length code).
+template <int REGS>
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int nsym, uint16_t* sorted, int lane, bool allow_lone, LaneCode* out) {
+  uint32_t len_r[REGS];
+  int pos_r[REGS];
+#pragma unroll
+  for (int r = 0; r < REGS; r++) {
+    const int s = r * 64 + lane;
+    len_r[r] = s < nsym ? lens[s] : 0u;
+    pos_r[r] = 0;
+  }
+  LaneCode c{0u, 0u, 0u};
+  int code = 0, offs = 0, left = 1, maxlen = 0;
+  bool ok = true;
+  for (int L = 1; L <= 15; L++) {
+    left <<= 1;
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < REGS; r++) {
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(len_r[r] == (uint32_t)L);
+      const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      if (len_r[r] == (uint32_t)L) pos_r[r] = offs + n + below;
+      n += __popcll(bal);
+    }
+    left -= n;
+    if (left < 0) ok = false;
+    if (n > 0) maxlen = L;
+    if (lane == L) c = LaneCode{(uint32_t)code, (uint32_t)n, (uint32_t)offs};
+    code = (code + n) << 1;
+    offs += n;
+  }
+  // incomplete: inflate_table allows it for a lone one-bit code of the literal / length and distance codes (and for an empty set)
+  if (left > 0 && (!allow_lone || (offs > 0 && maxlen != 1))) ok = false;
+#pragma unroll
+  for (int r = 0; r < REGS; r++)
+    if (len_r[r] != 0u) sorted[pos_r[r]] = (uint16_t)(r * 64 + lane);
+  *out = c;
+  return ok;
+}
+
+struct PngArgs {
+  const uint8_t* blob;
+  size_t off_images, off_pieces, off_stream;
+  uint8_t* filtered;       // [n][filtered_stride]: the inflated scanlines (filter byte + row bytes)
+  size_t filtered_stride;
+  int width, height;
+  uint8_t* dst;
+  size_t dst_image_stride;
+  int dst_pitch;
+  int32_t* status;         // bit 1: a file's data is broken (what libpng answers with png_error)
+  int32_t* file_status;    // [n]: 0 ok, 1 broken: the unfilter kernel leaves such an image alone
+};
+
+__device__ __forceinline__ DevImage load_image(const PngArgs& a, int image) {
+  DevImage im;
+  const uint32_t* iw = reinterpret_cast<const uint32_t*>(a.blob + a.off_images) + kDevImageWords * image;
+  im.stream_off = in_constant(iw)[0];
+  im.stream_len = in_constant(iw)[1];
+  im.row_bytes = in_constant(iw)[2];
+  const uint32_t t = in_constant(iw)[3];
+  im.bpp = (uint8_t)(t & 0xFFu);
+  im.depth = (uint8_t)((t >> 8) & 0xFFu);
+  im.piece_first = in_constant(iw)[4];
+  im.piece_count = in_constant(iw)[5];
+  return im;
+}
+
+// What happens behind the image's last byte is zlib's business too.  libpng asks zlib for the last row with whatever is
+// left of the CURRENT piece of input (at most 8192 bytes of one IDAT chunk: PNG_IDAT_READ_SIZE); having written the last
+// byte, inflate() goes on reading symbols that need no room in the output -- an end-of-block code, block headers, code
+// tables, empty stored blocks, the Adler-32 check -- and an error it meets there fails the read (png_error), exactly as
+// in front of the last byte.  It stops without an error at the first symbol that needs room (after decoding a match's
+// length and distance codes), at the end of that piece of input, or at the end of the stream.  The remainder of the file
+// is read later with no row to fill and errors there are warnings (png_read_finish_IDAT).  So the walk below has two
+// modes: in front of the last byte running out of input is an error ("Not enough image data"); behind it the input ends at
+// the piece boundary and running out ends the walk without one.
+__global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t ring[kWindow];
+  __shared__ uint8_t lens[kMaxCodes + 8];
+  __shared__ uint8_t cl_lens[32];
+  __shared__ uint16_t sorted[kMaxCodes];
+  const int lane = threadIdx.x;
+  const int image = blockIdx.x;
+  const DevImage im = load_image(a, image);
+  const uint32_t expected = (im.row_bytes + 1u) * (uint32_t)a.height;
+  uint8_t* out = a.filtered + (size_t)image * a.filtered_stride;
+  constexpr uint32_t M = kWindow - 1;
+
+  BitsLsb br;
+  br.words = reinterpret_cast<const uint32_t*>(a.blob + a.off_stream + im.stream_off);
+  br.nwords = (im.stream_len + 3u) / 4u + 8u;
+  br.wpos = 0;
+  br.acc = 0;
+  br.n = 0;
+  br.fill();
+  br.drop(16);  // the zlib header (checked on the host)
+
+  uint32_t pos = 0, flushed = 0;  // bytes produced; bytes already in HBM (a multiple of kFlushChunk)
+  uint32_t pend = 0;              // lane k: the k-th literal not yet in the ring
+  int npend = 0;
+  bool bad = false, stop = false, tail = false;
+  uint64_t limit_bits = (uint64_t)im.stream_len * 8u;
+  uint32_t adler_a = 1, adler_b = 0, adler_upto = 0;  // Adler-32 of out[0 .. adler_upto)
+
+  // Adler-32 over ring bytes [adler_upto, upto): at most one flush chunk, starting at a multiple of it
+  auto adler_update = [&](uint32_t upto) {
+    const uint32_t n = upto - adler_upto;
+    if (n == 0u) return;
+    const uint32_t seg = kFlushChunk / 64;  // bytes per lane
+    const uint32_t lo = lane * seg, hi = min(lo + seg, n);
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t i = lo; i < hi; i += 16) {
+      const uint4 q = *reinterpret_cast<const uint4*>(ring + ((adler_upto + i) & M));
+      const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const uint32_t idx = i + (uint32_t)k;
+        const uint32_t d = idx < hi ? (wv[k >> 2] >> (8 * (k & 3))) & 255u : 0u;
+        s1 += d;
+        s2 += (n - idx) * d;  // (a byte counts once for every byte from it to the end)
+      }
+    }
+    uint64_t t1 = s1, t2 = s2;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      t1 += __shfl_xor(t1, o, 64);
+      t2 += __shfl_xor(t2, o, 64);
+    }
+    const uint64_t na = ((uint64_t)adler_a + t1) % 65521u;
+    const uint64_t nb = ((uint64_t)adler_b + (uint64_t)n * adler_a + t2) % 65521u;
+    adler_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)na);
+    adler_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+    adler_upto = upto;
+  };
+  auto flush_chunks = [&]() {  // completed 16 KiB pieces of the ring leave for HBM
+    while (pos - flushed >= (uint32_t)kFlushChunk) {
+      adler_update(flushed + kFlushChunk);
+      const uint4* src = reinterpret_cast<const uint4*>(ring + (flushed & M));
+      uint4* dst = reinterpret_cast<uint4*>(out + flushed);
+#pragma unroll 4
+      for (int i = 0; i < kFlushChunk / 16 / 64; i++) dst[i * 64 + lane] = src[i * 64 + lane];
+      flushed += kFlushChunk;
+    }
+  };
+  auto flush_literals = [&]() {
+    if (npend > 0) {
+      if (lane < npend) ring[(pos + lane) & M] = (uint8_t)pend;
+      pos += (uint32_t)npend;
+      npend = 0;
+      flush_chunks();
+    }
+  };
+  auto bitpos = [&]() -> uint64_t { return (uint64_t)br.wpos * 32u - (uint64_t)br.n; };
+  // k more bits of input?  If not: an error in front of the image's last byte, the end of the walk behind it.
+  auto lacks = [&](int k) -> bool {
+    if (bitpos() + (uint64_t)k <= limit_bits) return false;
+    if (!tail) bad = true;
+    stop = true;
+    return true;
+  };
+  // The image's last byte has been produced: from here on the input ends where libpng's current piece of it ends.
+  auto enter_tail = [&]() {
+    flush_literals();
+    tail = true;
+    const uint32_t last_byte = (uint32_t)((bitpos() + 7u) / 8u) - 1u;  // the last byte zlib has pulled
+    const uint32_t* pe = reinterpret_cast<const uint32_t*>(a.blob + a.off_pieces) + im.piece_first;
+    uint32_t begin = 0, end = im.stream_len;
+    for (uint32_t k = 0; k < im.piece_count; k++) {
+      const uint32_t e = in_constant(pe)[k];
+      if (last_byte < e) {
+        end = e;
+        break;
+      }
+      begin = e;
+    }
+    const uint32_t boundary = min(end, begin + ((last_byte - begin) / kIdatReadSize + 1u) * kIdatReadSize);
+    limit_bits = (uint64_t)min(boundary, im.stream_len) * 8u;
+  };
+
+  bool last = false;
+  while (!stop && !bad) {
+    if (!tail && pos + (uint32_t)npend >= expected) enter_tail();
+    if (last) {  // the end of the stream: to the byte boundary, then the Adler-32 of everything produced, big-endian
+      flush_literals();
+      br.drop(br.n & 7);
+      br.fill();
+      if (lacks(32)) break;
+      const uint32_t v = br.take(16);
+      br.fill();
+      const uint32_t v2 = br.take(16);
+      const uint32_t le = v | (v2 << 16);
+      const uint32_t stored = (le >> 24) | ((le >> 8) & 0xFF00u) | ((le << 8) & 0xFF0000u) | (le << 24);
+      adler_update(pos);
+      if (stored != ((adler_b << 16) | adler_a)) bad = true;  // inflate: "incorrect data check"
+      stop = true;
+      break;
+    }
+    br.fill();
+    if (lacks(3)) break;
+    last = br.take(1) != 0u;
+    const uint32_t btype = br.take(2);
+    if (btype == 3u) {  // inflate: "invalid block type"
+      bad = true;
+      break;
+    }
+    if (btype == 0u) {  // stored: to the byte boundary, LEN, ~LEN, LEN bytes
+      flush_literals();
+      br.drop(br.n & 7);
+      br.fill();
+      if (lacks(32)) break;
+      const uint32_t len = br.take(16);
+      br.fill();
+      const uint32_t nlen = br.take(16);
+      if ((len ^ 0xFFFFu) != nlen) {  // inflate: "invalid stored block lengths"
+        bad = true;
+        break;
+      }
+      if (len == 0u) continue;
+      if (tail) {  // bytes to copy and no room for them: inflate leaves
+        stop = true;
+        break;
+      }
+      const uint32_t src0 = br.byte_pos();
+      const uint32_t want = min(len, expected - pos);
+      if (src0 + want > im.stream_len) {  // the stream ends inside the bytes the image still needs
+        bad = true;
+        break;
+      }
+      const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(br.words);
+      for (uint32_t i = 0; i < want; i += 64) {
+        if (i + lane < want) ring[(pos + lane) & M] = sbytes[src0 + i + lane];
+        pos += min(64u, want - i);
+        flush_chunks();
+      }
+      if (want < len) {  // the image is complete in the middle of the block: inflate leaves
+        stop = true;
+        break;
+      }
+      // the bit buffer continues behind the block's bytes
+      const uint32_t next = src0 + len;
+      br.wpos = next >> 2;
+      br.acc = 0;
+      br.n = 0;
+      br.fill();
+      br.drop((int)(next & 3u) * 8);
+      continue;
+    }
+    // ---- the block's two codes
+    int hlit = kMaxLit, hdist = kMaxDist;
+    if (btype == 1u) {  // fixed (RFC 1951 3.2.6)
+      for (int s = lane; s < kMaxLit; s += 64) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+      if (lane < kMaxDist) lens[kMaxLit + lane] = 5;
+    } else {
+      br.fill();
+      if (lacks(14)) break;
+      hlit = (int)br.take(5) + 257;
+      hdist = (int)br.take(5) + 1;
+      const int hclen = (int)br.take(4) + 4;
+      if (hlit > 286 || hdist > 30) {  // inflate: "too many length or distance symbols"
+        bad = true;
+        break;
+      }
+      // the code-length code: 19 symbols, 3-bit lengths in a fixed order
+      if (lane < 32) cl_lens[lane] = 0;
+      __syncthreads();
+      for (int i = 0; i < hclen && !stop; i++) {
+        br.fill();
+        if (lacks(3)) break;
+        const uint32_t v = br.take(3);
+        const int sym = in_constant(c_cl_order)[i];
+        if (lane == 0) cl_lens[sym] = (uint8_t)v;
+      }
+      if (stop) break;
+      __syncthreads();
+      LaneCode clc;
+      if (!build_code<1>(cl_lens, 19, sorted, lane, false, &clc)) {  // inflate: "invalid code lengths set"
+        bad = true;
+        break;
+      }
+      __syncthreads();
+      const uint32_t clsym = lane < 19 ? sorted[lane] : 0u;
+      __syncthreads();
+      const int total = hlit + hdist;
+      int i = 0;
+      uint32_t prev = 0;
+      while (i < total && !stop && !bad) {
+        br.fill();
+        int L;
+        const uint32_t idx = decode_index(br.peek(), clc, lane, &L);
+        if (L == 0) {  // (a code-length code without a single code: nothing it could decode)
+          if (!lacks(1)) bad = true;
+          break;
+        }
+        const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)clsym, (int)(idx & 63u));
+        const int extra = sym == 16u ? 2 : sym == 17u ? 3 : sym == 18u ? 7 : 0;
+        if (lacks(L + extra)) break;
+        br.drop(L);
+        if (sym < 16u) {
+          if (lane == 0) lens[i] = (uint8_t)sym;
+          prev = sym;
+          ++i;
+        } else {
+          int rep;
+          uint32_t val = 0;
+          if (sym == 16u) {
+            if (i == 0) {  // inflate: "invalid bit length repeat"
+              bad = true;
+              break;
+            }
+            rep = 3 + (int)br.take(2);
+            val = prev;
+          } else if (sym == 17u) {
+            rep = 3 + (int)br.take(3);
+            prev = 0;
+          } else {
+            rep = 11 + (int)br.take(7);
+            prev = 0;
+          }
+          if (i + rep > total) {
+            bad = true;
+            break;
+          }
+          for (int k = lane; k < rep; k += 64) lens[i + k] = (uint8_t)val;
+          i += rep;
+        }
+      }
+      if (bad || stop) break;
+      __syncthreads();
+      if (lens[256] == 0) {  // inflate: "invalid code -- missing end-of-block"
+        bad = true;
+        break;
+      }
+    }
+    __syncthreads();
+    LaneCode lc, dc;
+    const bool ok_l = build_code<5>(lens, hlit, sorted, lane, true, &lc);
+    const bool ok_d = build_code<1>(lens + hlit, hdist, sorted + kMaxLit, lane, true, &dc);
+    if (!ok_l || !ok_d) {  // inflate: "invalid literal/lengths set", "invalid distances set"
+      bad = true;
+      break;
+    }
+    __syncthreads();
+    const uint32_t ls0 = sorted[lane], ls1 = sorted[64 + lane], ls2 = sorted[128 + lane], ls3 = sorted[192 + lane];
+    const uint32_t ls4 = lane < kMaxLit - 256 ? sorted[256 + lane] : 0u;
+    const uint32_t dsy = lane < kMaxDist ? sorted[kMaxLit + lane] : 0u;
+    __syncthreads();
+
+    // ---- the block's symbols
+    while (!stop && !bad) {
+      if (!tail && pos + (uint32_t)npend >= expected) enter_tail();
+      br.fill();
+      int L;
+      const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
+      if (L == 0) {  // no code starts like this (possible only in a code of one symbol)
+        if (!lacks(1)) bad = true;
+        break;
+      }
+      if (lacks(L)) break;
+      br.drop(L);
+      const uint32_t r = idx >> 6;
+      const uint32_t v = r == 0u ? ls0 : r == 1u ? ls1 : r == 2u ? ls2 : r == 3u ? ls3 : ls4;
+      const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u));
+      if (sym < 256u) {
+        if (tail) {  // a literal and no room for it: inflate leaves
+          stop = true;
+          break;
+        }
+        // (lane select through M0: the value already takes the instruction's one constant-bus slot)
+        asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pend) : "s"(sym), "s"(npend));
+        if (++npend == 64) flush_literals();
+        continue;
+      }
+      if (sym == 256u) break;  // end of block
+      const uint32_t l = sym - 257u;
+      if (l > 28u) {  // symbols 286, 287: "invalid literal/length code"
+        bad = true;
+        break;
+      }
+      uint32_t len;
+      if (l < 8u) {
+        len = 3u + l;
+      } else if (l == 28u) {
+        len = 258u;
+      } else {
+        const int eb = (int)(l >> 2) - 1;
+        if (lacks(eb)) break;
+        len = 3u + ((4u + (l & 3u)) << eb) + br.take(eb);
+      }
+      br.fill();
+      int L2;
+      const uint32_t idx2 = decode_index(br.peek(), dc, lane, &L2);
+      if (L2 == 0) {  // "invalid distance code" (a block without distance codes, or a code of one symbol)
+        if (!lacks(1)) bad = true;
+        break;
+      }
+      if (lacks(L2)) break;
+      br.drop(L2);
+      const uint32_t dsym = (uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u));
+      if (dsym > 29u) {  // "invalid distance code"
+        bad = true;
+        break;
+      }
+      uint32_t dist;
+      if (dsym < 4u) {
+        dist = 1u + dsym;
+      } else {
+        const int eb = (int)(dsym >> 1) - 1;
+        if (lacks(eb)) break;
+        dist = 1u + ((2u + (dsym & 1u)) << eb) + br.take(eb);
+      }
+      if (tail) {  // a match and no room for it: inflate leaves (it checks the distance only when it copies)
+        stop = true;
+        break;
+      }
+      flush_literals();
+      if (dist > pos) {  // "invalid distance too far back"
+        bad = true;
+        break;
+      }
+      const uint32_t want = min(len, expected - pos);
+      const float rcp = 1.0f / (float)dist;
+      for (uint32_t i0 = 0; i0 < want; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t off = i;
+        if (dist < want) {  // the match overlaps itself: byte i repeats byte i mod dist (all of them in front of its start)
+          const uint32_t q = (uint32_t)((float)i * rcp);
+          int rr = (int)i - (int)(q * dist);
+          if (rr < 0) rr += (int)dist;
+          if (rr >= (int)dist) rr -= (int)dist;
+          off = (uint32_t)rr;
+        }
+        if (i < want) {
+          const uint8_t b = ring[(pos - dist + off) & M];
+          ring[(pos + i) & M] = b;
+        }
+      }
+      pos += want;
+      flush_chunks();
+      if (want < len) {  // the image is complete in the middle of the match: inflate leaves
+        stop = true;
+        break;
+      }
+    }
+  }
+  flush_literals();
+  if (!bad && pos < expected) bad = true;  // "Not enough image data"
+  // what is left in the ring (less than a flush chunk; whole 16-byte pieces: the image's slot has the slack)
+  for (uint32_t o = flushed + 16u * lane; o < pos; o += 16u * 64u)
+    *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ring + (o & M));
+  if (lane == 0) {
+    a.file_status[image] = bad ? 1 : 0;
+    if (bad) atomicOr(a.status, 2);
+  }
+}
+
+// Filters (PNG specification 9.2), one wave per image, rows r0 .. r0 + 63 as a wavefront.
+__global__ __launch_bounds__(64) void png_unfilter_kernel(PngArgs a) {
+  const int lane = threadIdx.x;
+  const int image = blockIdx.x;
+  if (in_constant(a.file_status)[image] != 0) return;  // (written by the kernel in front on the same stream)
+  const DevImage im = load_image(a, image);
+  uint8_t* filt = a.filtered + (size_t)image * a.filtered_stride;
+  uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
+  const int bpp = im.bpp, depth = im.depth;
+  const int rb1 = (int)im.row_bytes + 1;
+  const int nb = (int)im.row_bytes / bpp;  // bytes of the plane kept: one per pixel (depth >= 8), or the packed row
+  const int w = a.width, h = a.height;
+  bool bad = false;
+  for (int r0 = 0; r0 < h; r0 += 64) {
+    const int row = r0 + lane;
+    const bool rowok = row < h;
+    uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
+    const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
+    const int ftype = rowok ? frow[0] : 0;
+    if (ftype > 4) bad = true;
+    uint32_t ra = 0, rc = 0, last = 0;
+    for (int s0 = 0; s0 < nb + 63; s0 += 8) {
+      uint32_t F[8], U[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = s0 + u - lane;
+        const bool act = rowok && j >= 0 && j < nb;
+        F[u] = act ? frow[1 + j * bpp] : 0u;
+        U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = s0 + u - lane;
+        const bool act = rowok && j >= 0 && j < nb;
+        uint32_t rbv = wave_shr1(last);
+        if (lane == 0) rbv = U[u];
+        const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
+        const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
+        const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
+        const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
+        const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
+        rc = rbv;
+        ra = act ? R : 0u;
+        last = act ? R : 0u;
+        if (act) {
+          if (lane == 63) frow[1 + j * bpp] = (uint8_t)R;  // the next 64 rows' "above"
+          if (depth >= 8) {
+            dst[(size_t)row * a.dst_pitch + j] = (uint8_t)R;
+          } else {  // 1, 2, 4 bits: the samples of a byte, most significant first, replicated to 8 bits
+            const int ppb = 8 / depth;
+            const uint32_t mask = (1u << depth) - 1u, mul = 255u / mask;
+            for (int p = 0; p < ppb; p++) {
+              const int x = j * ppb + p;
+              if (x < w) dst[(size_t)row * a.dst_pitch + x] = (uint8_t)(((R >> (8 - depth * (p + 1))) & mask) * mul);
+            }
+          }
+        }
+      }
+    }
+    __threadfence();  // lane 63's row is the next group's lane 0's "above"
+  }
+  if (bad) atomicOr(a.status, 2);  // "bad adaptive filter value": libpng stops with png_error; the image is not to be used
+}
+
+}  // namespace
+
+void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_pieces, size_t off_stream, int n, int width, int height,
+                           uint8_t* d_filtered, size_t filtered_stride, int32_t* d_file_status, uint8_t* d_dst,
+                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, hipStream_t s) {
+  PngArgs a;
+  a.blob = d_blob;
+  a.off_images = off_images;
+  a.off_pieces = off_pieces;
+  a.off_stream = off_stream;
+  a.filtered = d_filtered;
+  a.filtered_stride = filtered_stride;
+  a.width = width;
+  a.height = height;
+  a.dst = d_dst;
+  a.dst_image_stride = dst_image_stride;
+  a.dst_pitch = dst_pitch;
+  a.status = d_status;
+  a.file_status = d_file_status;
+  hipLaunchKernelGGL(png_inflate_kernel, dim3(n), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_unfilter_kernel, dim3(n), dim3(64), 0, s, a);
+}

@@ -535,6 +535,10 @@ struct vsf_ctx {
   size_t jp_cap[2] = {0, 0};
   hipEvent_t jp_copied[2] = {nullptr, nullptr};  // the last upload out of jp_host[i] has finished
   int jp_flip = 0;
+  uint8_t* png_filtered = nullptr;  // PNG: the inflated scanlines of a batch
+  size_t png_filtered_cap = 0;
+  int32_t* png_file_status = nullptr;
+  int png_file_status_cap = 0;
   uint8_t* jp_clean = nullptr;   // parallel decode: the de-stuffed streams (layout of the upload's stream part)
   size_t jp_clean_cap = 0;
   int16_t* jp_coef = nullptr;    // ... and the luminance coefficients of the batch
@@ -1254,6 +1258,8 @@ void vsf_destroy(vsf_ctx* ctx) {
   hipFree(ctx->t_sortkeys);
   free_observe(ctx);
   hipFree(ctx->jp_flags);
+  hipFree(ctx->png_filtered);
+  hipFree(ctx->png_file_status);
   hipFree(ctx->jp_clean);
   hipFree(ctx->jp_coef);
   for (int i = 0; i < 2; i++) {
@@ -1882,6 +1888,64 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   VSF_STICKY();
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));  // (a pipelined extract waits for its images, as after the Bayer step)
+  ctx->ingest_done_valid = true;
+  return VSF_OK;
+}
+
+// cv::imdecode(IMREAD_GRAYSCALE) for grayscale PNG files (slam_frontend_main.cc:99-100): chunks and CRCs on the host, inflate +
+// filters on the device (k_png.hip).  Same staging and the same asynchronous contract as the JPEG entry point.
+vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, const size_t* nbytes, int n_images,
+                                     int width, int height, uint8_t* d_dst, size_t dst_image_stride,
+                                     size_t dst_row_stride) {
+  VsfErrorScope scope_(ctx);
+  if (!ctx || !png || !nbytes || n_images < 1 || n_images > 65535 || width < 1 || height < 1 || width > 65535 ||
+      height > 65535 || !d_dst)
+    return VSF_ERR_INVALID_ARG;
+  if (((uintptr_t)d_dst & 3) || (dst_image_stride & 3) || (dst_row_stride & 3) || dst_row_stride < (size_t)width ||
+      dst_row_stride > 0x7FFFFFFF || dst_image_stride < dst_row_stride * (size_t)height)
+    return VSF_ERR_INVALID_ARG;
+  for (int i = 0; i < n_images; i++)
+    if (!png[i] || nbytes[i] < 8 || nbytes[i] > 0x40000000u) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipSetDevice(ctx->device));
+  VsfPngPlan plan;
+  vsf_status st = vsf_png_plan(png, nbytes, n_images, width, height, &plan);
+  if (st != VSF_OK) return st;
+  const int b = ctx->jp_flip;
+  ctx->jp_flip ^= 1;
+  if (!ctx->jp_copied[b]) VSF_HIP(hipEventCreateWithFlags(&ctx->jp_copied[b], hipEventDisableTiming));
+  if (plan.total > ctx->jp_cap[b]) {
+    VSF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->jp_host[b]) hipHostFree(ctx->jp_host[b]);
+    hipFree(ctx->jp_dev[b]);
+    ctx->jp_host[b] = ctx->jp_dev[b] = nullptr;
+    ctx->jp_cap[b] = 0;
+    const size_t cap = plan.total + plan.total / 4 + 4096;
+    VSF_HIP(hipHostMalloc((void**)&ctx->jp_host[b], cap, hipHostMallocDefault));
+    VSF_HIP(hipMalloc((void**)&ctx->jp_dev[b], cap));
+    ctx->jp_cap[b] = cap;
+  } else {
+    VSF_HIP(hipEventSynchronize(ctx->jp_copied[b]));  // (the upload of the call before the previous one has left this buffer)
+  }
+  const size_t filtered_need = plan.filtered_stride * (size_t)n_images;
+  if (filtered_need > ctx->png_filtered_cap) {  // (no wait: the outgrown buffer is retired)
+    vsf_status gs = grow_scratch(ctx, ctx->png_filtered, filtered_need + filtered_need / 4);
+    if (gs != VSF_OK) return gs;
+    ctx->png_filtered_cap = filtered_need + filtered_need / 4;
+  }
+  if (n_images > ctx->png_file_status_cap) {
+    vsf_status gs = grow_scratch(ctx, ctx->png_file_status, (size_t)n_images * sizeof(int32_t));
+    if (gs != VSF_OK) return gs;
+    ctx->png_file_status_cap = n_images;
+  }
+  vsf_png_fill(plan, png, n_images, ctx->jp_host[b]);
+  VSF_HIP(hipMemcpyAsync(ctx->jp_dev[b], ctx->jp_host[b], plan.total, hipMemcpyHostToDevice, ctx->stream));
+  VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
+  vsf_launch_png_decode(ctx->jp_dev[b], plan.off_images, plan.off_pieces, plan.off_stream, n_images, width, height, ctx->png_filtered,
+                        plan.filtered_stride, ctx->png_file_status, d_dst, dst_image_stride, (int)dst_row_stride,
+                        ctx->d_status, ctx->stream);
+  VSF_STICKY();
+  if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
+  VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));
   ctx->ingest_done_valid = true;
   return VSF_OK;
 }

@@ -28,3 +28,20 @@ extern "C" int vsf_jpeg_host_check(const uint8_t* const* jpeg, const size_t* nby
   if (checksum_out) *checksum_out = sum;
   return (int)VSF_OK;
 }
+
+// The same for the PNG host half (vsf_png_host.cc): vsf_png_plan + vsf_png_fill into a buffer of exactly plan.total bytes.
+extern "C" int vsf_png_host_check(const uint8_t* const* png, const size_t* nbytes, int n, int width, int height,
+                                  uint64_t* total_out, uint32_t* checksum_out) {
+  VsfPngPlan plan;
+  const vsf_status st = vsf_png_plan(png, nbytes, n, width, height, &plan);
+  if (total_out) *total_out = 0;
+  if (checksum_out) *checksum_out = 0;
+  if (st != VSF_OK) return (int)st;
+  std::vector<uint8_t> blob(plan.total);
+  vsf_png_fill(plan, png, n, blob.data());
+  uint32_t sum = 0;
+  for (uint8_t b : blob) sum = sum * 16777619u ^ b;
+  if (total_out) *total_out = plan.total;
+  if (checksum_out) *checksum_out = sum;
+  return (int)VSF_OK;
+}
