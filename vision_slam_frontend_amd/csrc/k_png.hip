@@ -38,18 +38,45 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
 }
 
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
 constexpr int kMaxLit = 288, kMaxDist = 32, kMaxCodes = kMaxLit + kMaxDist;
 __constant__ uint8_t c_cl_order[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 0};
 
 // ---- the deflate stream, least significant bit first; wave-uniform ----
+// The stream's dwords come 64 at a time, one per lane (a coalesced vector load issued 64 dwords before its first use), and
+// are handed to the scalar bit buffer one v_readlane at a time: no load latency on the path of a symbol.  `left` counts the
+// bits the walk may still take (to the end of the stream, or -- behind the image's last byte -- to the end of the piece of
+// input libpng would have handed zlib).
 struct BitsLsb {
   const uint32_t* words;
-  uint32_t wpos, nwords;  // next dword; dwords that exist (the upload pads every stream with zeros)
+  uint32_t nwords;    // dwords that exist (the upload pads every stream with zeros)
+  uint32_t base;      // `cur` holds dwords base .. base + 63, `nxt` the 64 behind them
+  uint32_t wpos;      // next dword to enter the bit buffer
+  uint32_t cur, nxt;  // (per lane)
   uint64_t acc;
   int n;
+  int64_t left;
+  __device__ __forceinline__ uint32_t load64(uint32_t at) const {
+    const uint32_t i = at + threadIdx.x;
+    return i < nwords ? words[i] : 0u;
+  }
+  __device__ __forceinline__ void start(uint32_t at) {
+    base = wpos = at;
+    acc = 0;
+    n = 0;
+    cur = load64(at);
+    nxt = load64(at + 64u);
+  }
   __device__ __forceinline__ void fill() {  // >= 33 bits afterwards
     if (n <= 32) {
-      const uint32_t w = wpos < nwords ? in_constant(words)[wpos] : 0u;
+      if (wpos - base == 64u) {
+        cur = nxt;
+        base += 64u;
+        nxt = load64(base + 64u);
+      }
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(wpos - base));
       acc |= (uint64_t)w << n;
       ++wpos;
       n += 32;
@@ -59,13 +86,15 @@ struct BitsLsb {
   __device__ __forceinline__ void drop(int k) {
     acc >>= k;
     n -= k;
+    left -= k;
   }
   __device__ __forceinline__ uint32_t take(int k) {  // k <= 16, after fill()
     const uint32_t v = (uint32_t)acc & ((1u << k) - 1u);
     drop(k);
     return v;
   }
-  // bytes of the stream consumed so far (whole bytes still in the buffer given back)
+  // bits / bytes of the stream consumed so far (whole bytes still in the buffer given back)
+  __device__ __forceinline__ uint64_t bit_pos() const { return (uint64_t)wpos * 32u - (uint64_t)n; }
   __device__ __forceinline__ uint32_t byte_pos() const { return wpos * 4u - (uint32_t)(n >> 3); }
 };
 
@@ -77,7 +106,7 @@ struct LaneCode {
 // Decodes one symbol index (position in the sorted symbol list) from the next bits; *len = its length, or 0: no code.
 __device__ __forceinline__ uint32_t decode_index(uint32_t peek, const LaneCode& c, int lane, int* len) {
   const uint32_t rev = __builtin_bitreverse32(peek);  // the stream's first bit on top
-  const uint32_t top = (lane >= 1 && lane <= 15) ? (rev >> (32 - lane)) : 0u;
+  const uint32_t top = rev >> ((32 - lane) & 31);  // (lanes other than 1 .. 15 hold cnt = 0: whatever they see, they say no)
   const uint32_t d = top - c.first;
   const unsigned long long m = __builtin_amdgcn_ballot_w64(d < c.cnt);
   if (m == 0ull) {
@@ -92,8 +121,13 @@ __device__ __forceinline__ uint32_t decode_index(uint32_t peek, const LaneCode& 
 // Builds a canonical code from nsym lengths at lens[0..nsym) (LDS): per-lane description + the symbols sorted by (length,
 // symbol) into sorted[0..) (LDS).  Returns false for a set of lengths zlib's inflate_table refuses: over-subscribed, or
 // incomplete with anything but a single one-bit code (allow_lone; never for the code-length code).
+struct BuiltCode {
+  LaneCode c;
+  bool ok;
+};
 template <int REGS>
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int nsym, uint16_t* sorted, int lane, bool allow_lone, LaneCode* out) {
+__device__ __attribute__((noinline)) BuiltCode build_code(const lds_u8* lens, int nsym, lds_u16* sorted, bool allow_lone) {
+  const int lane = threadIdx.x;
   uint32_t len_r[REGS];
   int pos_r[REGS];
 #pragma unroll
@@ -127,8 +161,45 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int nsym, uint16
 #pragma unroll
   for (int r = 0; r < REGS; r++)
     if (len_r[r] != 0u) sorted[pos_r[r]] = (uint16_t)(r * 64 + lane);
-  *out = c;
-  return ok;
+  return BuiltCode{c, ok};
+}
+
+// Adler-32 (RFC 1950) of ring[from .. from + n) continued from (a, b), returned as a | b << 32 -- n <= kFlushChunk, `from` a multiple of it -- and,
+// with `store`, the same bytes written to out + from in 16-byte pieces (a partial last piece is written whole: the
+// image's slot has the slack).  One copy of this code in the kernel (it is needed at five places of the walk).
+__device__ __attribute__((noinline)) uint64_t ring_chunk(lds_u8* ring, uint8_t* out, uint32_t from, uint32_t n, uint32_t a,
+                                                         uint32_t b, bool store) {
+  const int lane = threadIdx.x;
+  constexpr uint32_t M = kWindow - 1;
+  const uint32_t seg = kFlushChunk / 64;  // bytes per lane
+  const uint32_t lo = lane * seg, hi = min(lo + seg, n);
+  uint32_t s1 = 0, s2 = 0;
+  for (uint32_t i = lo; i < hi; i += 16) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 q = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(ring + ((from + i) & M));
+    if (store) *reinterpret_cast<u32x4*>(out + from + i) = q;
+    const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t idx = i + 4u * k;
+      // bytes behind the end do not count
+      const uint32_t keep = idx + 4u <= hi ? 0xFFFFFFFFu : idx >= hi ? 0u : (1u << (8u * (hi - idx))) - 1u;
+      const uint32_t w = wv[k] & keep;
+      const uint32_t sum4 = __builtin_amdgcn_sad_u8(w, 0u, 0u);
+      s1 += sum4;
+      // a byte counts once for every byte from it to the end: (n - idx) * (d0 + d1 + d2 + d3) - (0 d0 + 1 d1 + 2 d2 + 3 d3)
+      s2 += (n - idx) * sum4 - __builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
+    }
+  }
+  uint64_t t1 = s1, t2 = s2;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    t1 += __shfl_xor(t1, o, 64);
+    t2 += __shfl_xor(t2, o, 64);
+  }
+  const uint64_t na = ((uint64_t)a + t1) % 65521u;
+  const uint64_t nb = ((uint64_t)b + (uint64_t)n * a + t2) % 65521u;
+  return na | (nb << 32);
 }
 
 struct PngArgs {
@@ -182,9 +253,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   BitsLsb br;
   br.words = reinterpret_cast<const uint32_t*>(a.blob + a.off_stream + im.stream_off);
   br.nwords = (im.stream_len + 3u) / 4u + 8u;
-  br.wpos = 0;
-  br.acc = 0;
-  br.n = 0;
+  br.left = (int64_t)im.stream_len * 8;
+  br.start(0);
   br.fill();
   br.drop(16);  // the zlib header (checked on the host)
 
@@ -192,46 +262,14 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   uint32_t pend = 0;              // lane k: the k-th literal not yet in the ring
   int npend = 0;
   bool bad = false, stop = false, tail = false;
-  uint64_t limit_bits = (uint64_t)im.stream_len * 8u;
-  uint32_t adler_a = 1, adler_b = 0, adler_upto = 0;  // Adler-32 of out[0 .. adler_upto)
+  uint32_t adler_a = 1, adler_b = 0;  // Adler-32 of out[0 .. flushed)
 
-  // Adler-32 over ring bytes [adler_upto, upto): at most one flush chunk, starting at a multiple of it
-  auto adler_update = [&](uint32_t upto) {
-    const uint32_t n = upto - adler_upto;
-    if (n == 0u) return;
-    const uint32_t seg = kFlushChunk / 64;  // bytes per lane
-    const uint32_t lo = lane * seg, hi = min(lo + seg, n);
-    uint32_t s1 = 0, s2 = 0;
-    for (uint32_t i = lo; i < hi; i += 16) {
-      const uint4 q = *reinterpret_cast<const uint4*>(ring + ((adler_upto + i) & M));
-      const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const uint32_t idx = i + (uint32_t)k;
-        const uint32_t d = idx < hi ? (wv[k >> 2] >> (8 * (k & 3))) & 255u : 0u;
-        s1 += d;
-        s2 += (n - idx) * d;  // (a byte counts once for every byte from it to the end)
-      }
-    }
-    uint64_t t1 = s1, t2 = s2;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      t1 += __shfl_xor(t1, o, 64);
-      t2 += __shfl_xor(t2, o, 64);
-    }
-    const uint64_t na = ((uint64_t)adler_a + t1) % 65521u;
-    const uint64_t nb = ((uint64_t)adler_b + (uint64_t)n * adler_a + t2) % 65521u;
-    adler_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)na);
-    adler_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
-    adler_upto = upto;
-  };
-  auto flush_chunks = [&]() {  // completed 16 KiB pieces of the ring leave for HBM
+  lds_u8* const ring_lds = (lds_u8*)ring;
+  auto flush_chunks = [&]() {  // completed 16 KiB pieces of the ring leave for HBM, their Adler-32 taken on the way
     while (pos - flushed >= (uint32_t)kFlushChunk) {
-      adler_update(flushed + kFlushChunk);
-      const uint4* src = reinterpret_cast<const uint4*>(ring + (flushed & M));
-      uint4* dst = reinterpret_cast<uint4*>(out + flushed);
-#pragma unroll 4
-      for (int i = 0; i < kFlushChunk / 16 / 64; i++) dst[i * 64 + lane] = src[i * 64 + lane];
+      const uint64_t ab = ring_chunk(ring_lds, out, flushed, kFlushChunk, adler_a, adler_b, true);
+      adler_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ab);
+      adler_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ab >> 32));
       flushed += kFlushChunk;
     }
   };
@@ -243,10 +281,9 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       flush_chunks();
     }
   };
-  auto bitpos = [&]() -> uint64_t { return (uint64_t)br.wpos * 32u - (uint64_t)br.n; };
   // k more bits of input?  If not: an error in front of the image's last byte, the end of the walk behind it.
   auto lacks = [&](int k) -> bool {
-    if (bitpos() + (uint64_t)k <= limit_bits) return false;
+    if ((int64_t)k <= br.left) return false;
     if (!tail) bad = true;
     stop = true;
     return true;
@@ -255,7 +292,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   auto enter_tail = [&]() {
     flush_literals();
     tail = true;
-    const uint32_t last_byte = (uint32_t)((bitpos() + 7u) / 8u) - 1u;  // the last byte zlib has pulled
+    const uint64_t bp = br.bit_pos();
+    const uint32_t last_byte = (uint32_t)((bp + 7u) / 8u) - 1u;  // the last byte zlib has pulled
     const uint32_t* pe = reinterpret_cast<const uint32_t*>(a.blob + a.off_pieces) + im.piece_first;
     uint32_t begin = 0, end = im.stream_len;
     for (uint32_t k = 0; k < im.piece_count; k++) {
@@ -267,7 +305,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       begin = e;
     }
     const uint32_t boundary = min(end, begin + ((last_byte - begin) / kIdatReadSize + 1u) * kIdatReadSize);
-    limit_bits = (uint64_t)min(boundary, im.stream_len) * 8u;
+    br.left = (int64_t)((uint64_t)min(boundary, im.stream_len) * 8u) - (int64_t)bp;
   };
 
   bool last = false;
@@ -283,8 +321,10 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       const uint32_t v2 = br.take(16);
       const uint32_t le = v | (v2 << 16);
       const uint32_t stored = (le >> 24) | ((le >> 8) & 0xFF00u) | ((le << 8) & 0xFF0000u) | (le << 24);
-      adler_update(pos);
-      if (stored != ((adler_b << 16) | adler_a)) bad = true;  // inflate: "incorrect data check"
+      const uint64_t ab = ring_chunk(ring_lds, out, flushed, pos - flushed, adler_a, adler_b, false);
+      const uint32_t fa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ab);
+      const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ab >> 32));
+      if (stored != ((fb << 16) | fa)) bad = true;  // inflate: "incorrect data check"
       stop = true;
       break;
     }
@@ -331,11 +371,13 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
       // the bit buffer continues behind the block's bytes
       const uint32_t next = src0 + len;
-      br.wpos = next >> 2;
-      br.acc = 0;
-      br.n = 0;
-      br.fill();
-      br.drop((int)(next & 3u) * 8);
+      {  // (the bits up to `next` are spent: `left` follows the position)
+        const int64_t spent = (int64_t)next * 8 - (int64_t)br.bit_pos();
+        br.start(next >> 2);
+        br.fill();
+        br.drop((int)(next & 3u) * 8);
+        br.left -= spent - (int64_t)(next & 3u) * 8;
+      }
       continue;
     }
     // ---- the block's two codes
@@ -365,8 +407,9 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
       if (stop) break;
       __syncthreads();
-      LaneCode clc;
-      if (!build_code<1>(cl_lens, 19, sorted, lane, false, &clc)) {  // inflate: "invalid code lengths set"
+      const BuiltCode clb = build_code<1>((const lds_u8*)cl_lens, 19, (lds_u16*)sorted, false);
+      const LaneCode clc = clb.c;
+      if (__builtin_amdgcn_readfirstlane((int)clb.ok) == 0) {  // inflate: "invalid code lengths set"
         bad = true;
         break;
       }
@@ -425,22 +468,139 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
     }
     __syncthreads();
-    LaneCode lc, dc;
-    const bool ok_l = build_code<5>(lens, hlit, sorted, lane, true, &lc);
-    const bool ok_d = build_code<1>(lens + hlit, hdist, sorted + kMaxLit, lane, true, &dc);
-    if (!ok_l || !ok_d) {  // inflate: "invalid literal/lengths set", "invalid distances set"
+    const BuiltCode lb = build_code<5>((const lds_u8*)lens, hlit, (lds_u16*)sorted, true);
+    const BuiltCode db = build_code<1>((const lds_u8*)lens + hlit, hdist, (lds_u16*)sorted + kMaxLit, true);
+    const LaneCode lc = lb.c, dc = db.c;
+    if (__builtin_amdgcn_readfirstlane((int)lb.ok) == 0 || __builtin_amdgcn_readfirstlane((int)db.ok) == 0) {  // inflate: "invalid literal/lengths set", "invalid distances set"
       bad = true;
       break;
     }
     __syncthreads();
-    const uint32_t ls0 = sorted[lane], ls1 = sorted[64 + lane], ls2 = sorted[128 + lane], ls3 = sorted[192 + lane];
-    const uint32_t ls4 = lane < kMaxLit - 256 ? sorted[256 + lane] : 0u;
+    // the sorted symbol lists in registers, two symbols per lane: literal / length indices 0..127, 128..255, 256..287
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(sorted);
+    const uint32_t P0 = sp[lane], P1 = sp[64 + lane], P2 = lane < (kMaxLit - 256) / 2 ? sp[128 + lane] : 0u;
     const uint32_t dsy = lane < kMaxDist ? sorted[kMaxLit + lane] : 0u;
     __syncthreads();
+    // (codes are sorted by length, so the frequent symbols sit in the first register: one v_readlane)
+    auto lit_symbol = [&](uint32_t idx) -> uint32_t {
+      const int li = (int)((idx >> 1) & 63u);
+      uint32_t v;
+      if (idx < 128u) {
+        v = (uint32_t)__builtin_amdgcn_readlane((int)P0, li);
+      } else {
+        const uint32_t v1 = (uint32_t)__builtin_amdgcn_readlane((int)P1, li), v2 = (uint32_t)__builtin_amdgcn_readlane((int)P2, li);
+        v = idx < 256u ? v1 : v2;
+      }
+      return (v >> ((idx & 1u) * 16u)) & 0xFFFFu;
+    };
 
     // ---- the block's symbols
     while (!stop && !bad) {
       if (!tail && pos + (uint32_t)npend >= expected) enter_tail();
+      if (!tail) {
+        // Literals and matches in a loop of their own with nothing but scalar state.  It ends, with the symbol still in the
+        // stream, at anything out of the ordinary -- the end of the block, a code that is none, the end of the input near --
+        // and when the image is complete or a piece of the ring is due in HBM; the general walk below takes over there.
+        int budget = (int)min(br.left, (int64_t)(1 << 30));
+        const int budget0 = budget;
+        int room = (int)min(expected - pos - (uint32_t)npend, 1u << 30);
+        while (true) {
+          br.fill();
+          int L;
+          const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
+          if (L == 0 || budget < 64) break;  // (64 bits: more than a length code, a distance code and their extra bits)
+          const uint32_t sym = lit_symbol(idx);
+          if (sym < 256u) {
+            br.acc >>= L;
+            br.n -= L;
+            budget -= L;
+            asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pend) : "s"(sym), "s"(npend));
+            ++npend;
+            if (--room == 0) break;
+            if (npend == 64) {  // the 64 waiting literals enter the ring
+              ring[(pos + lane) & M] = (uint8_t)pend;
+              pos += 64u;
+              npend = 0;
+              if (pos - flushed >= (uint32_t)kFlushChunk) break;
+            }
+            continue;
+          }
+          if (sym == 256u || sym > 285u) break;
+          // a match: length code (+ extra bits), distance code (+ extra bits)
+          br.acc >>= L;
+          br.n -= L;
+          budget -= L;
+          const uint32_t l = sym - 257u;
+          uint32_t len = 3u + l;
+          if (l >= 8u) {
+            if (l == 28u) {
+              len = 258u;
+            } else {
+              const int eb = (int)(l >> 2) - 1;
+              len = 3u + ((4u + (l & 3u)) << eb) + ((uint32_t)br.acc & ((1u << eb) - 1u));
+              br.acc >>= eb;
+              br.n -= eb;
+              budget -= eb;
+            }
+          }
+          br.fill();
+          int L2;
+          const uint32_t idx2 = decode_index(br.peek(), dc, lane, &L2);
+          const uint32_t dsym = (uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u));
+          if (L2 == 0 || dsym > 29u) {  // "invalid distance code" (the bits were there: budget)
+            bad = true;
+            break;
+          }
+          br.acc >>= L2;
+          br.n -= L2;
+          budget -= L2;
+          uint32_t dist = 1u + dsym;
+          if (dsym >= 4u) {
+            const int eb = (int)(dsym >> 1) - 1;
+            dist = 1u + ((2u + (dsym & 1u)) << eb) + ((uint32_t)br.acc & ((1u << eb) - 1u));
+            br.acc >>= eb;
+            br.n -= eb;
+            budget -= eb;
+          }
+          if (npend > 0) {  // the waiting literals come first
+            if (lane < npend) ring[(pos + lane) & M] = (uint8_t)pend;
+            pos += (uint32_t)npend;
+            npend = 0;
+          }
+          if (dist > pos) {  // "invalid distance too far back"
+            bad = true;
+            break;
+          }
+          const uint32_t want = min(len, (uint32_t)room);
+          if (dist >= want) {
+            for (uint32_t i = lane; i < want; i += 64) {
+              const uint8_t b = ring[(pos - dist + i) & M];
+              ring[(pos + i) & M] = b;
+            }
+          } else {  // the match overlaps itself: byte i repeats byte i mod dist (all of them in front of its start)
+            const float rcp = 1.0f / (float)dist;
+            for (uint32_t i = lane; i < want; i += 64) {
+              const uint32_t q = (uint32_t)((float)i * rcp);
+              int rr = (int)i - (int)(q * dist);
+              if (rr < 0) rr += (int)dist;
+              if (rr >= (int)dist) rr -= (int)dist;
+              const uint8_t b = ring[(pos - dist + (uint32_t)rr) & M];
+              ring[(pos + i) & M] = b;
+            }
+          }
+          pos += want;
+          room -= (int)want;
+          if (want < len) {  // the image is complete in the middle of the match: inflate leaves
+            stop = true;
+            break;
+          }
+          if (room == 0 || pos - flushed >= (uint32_t)kFlushChunk) break;
+        }
+        br.left -= (int64_t)(budget0 - budget);
+        flush_chunks();
+        if (stop || bad) break;
+        if (pos + (uint32_t)npend >= expected) continue;  // (the image is complete: the walk goes on as zlib's does)
+      }
       br.fill();
       int L;
       const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
@@ -450,9 +610,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
       if (lacks(L)) break;
       br.drop(L);
-      const uint32_t r = idx >> 6;
-      const uint32_t v = r == 0u ? ls0 : r == 1u ? ls1 : r == 2u ? ls2 : r == 3u ? ls3 : ls4;
-      const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u));
+      const uint32_t sym = lit_symbol(idx);
       if (sym < 256u) {
         if (tail) {  // a literal and no room for it: inflate leaves
           stop = true;
@@ -537,9 +695,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   }
   flush_literals();
   if (!bad && pos < expected) bad = true;  // "Not enough image data"
-  // what is left in the ring (less than a flush chunk; whole 16-byte pieces: the image's slot has the slack)
-  for (uint32_t o = flushed + 16u * lane; o < pos; o += 16u * 64u)
-    *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ring + (o & M));
+  // what is left in the ring (less than a flush chunk)
+  if (pos > flushed) ring_chunk(ring_lds, out, flushed, pos - flushed, adler_a, adler_b, true);
   if (lane == 0) {
     a.file_status[image] = bad ? 1 : 0;
     if (bad) atomicOr(a.status, 2);
