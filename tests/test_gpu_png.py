@@ -275,3 +275,59 @@ def pil_unfilter(rows, w, h):
     stream inside a fresh PNG."""
     stream = pc.deflate(rows.tobytes(), 0)
     return pil_gray(pc.write_png(None, w, h, 8, 0, stream=stream))
+
+
+def test_committed_fixtures_pinned_by_libpng(capi):
+    """tests/golden/png (tools/make_png_golden.py): files written by PIL's libpng and by png_craft, with what PIL's libpng read
+    out of them when the fixtures were made.  No PIL at test time: the vectors are the reference."""
+    gold = HERE / "golden" / "png"
+    expected = np.load(gold / "expected_gray.npz")
+    by_size = {}
+    for f in sorted(gold.glob("*.png")):
+        by_size.setdefault(expected[f.stem].shape, []).append(f)
+    assert sum(len(v) for v in by_size.values()) >= 20
+    for (h, w), files in by_size.items():
+        with capi.Context(capi.default_params(max(w, 64), max(h, 64), max_images=2, nfeatures=100)) as c:
+            st, got, sync = decode(capi, c, [f.read_bytes() for f in files], w, h)
+            assert st == capi.VSF_OK and sync == capi.VSF_OK
+            for i, f in enumerate(files):
+                np.testing.assert_array_equal(got[i], expected[f.stem], err_msg=f.name)
+
+
+def test_ingest_chain_png_bayer_extract(capi, oracle):
+    """DecodeImage as a whole (slam_frontend_main.cc:98-109) followed by ExtractFeatures, for a PNG payload: a Bayer mosaic
+    stored as a gray PNG -> imdecode -> BayerBG2BGR -> BGR2GRAY -> ORB, against the same chain on the oracle, with the
+    extraction's pyramid pipelined behind the decode (the call is handed the images by the ingest's own event)."""
+    from vision_slam_frontend_amd import synth
+    dev = torch.device("cuda", 0)
+    mosaics = [synth.stereo_pair(640, 480, 5 + k)[k & 1] for k in range(4)]
+    files = []
+    for k, m in enumerate(mosaics):
+        b = io.BytesIO()
+        Image.fromarray(m, "L").save(b, "PNG", compress_level=[1, 6, 9, 0][k])
+        files.append(b.getvalue())
+    with capi.Context(capi.default_params(640, 480, max_images=4, nfeatures=500)) as ctx:
+        ctx.set_pipeline(True)
+        K = ctx.params.max_keypoints
+        d_mosaic = torch.zeros((4, 480, 640), dtype=torch.uint8, device=dev)
+        d_gray = torch.zeros((4, 480, 640), dtype=torch.uint8, device=dev)
+        d_kp = torch.zeros((4, K, 28), dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros((4, K, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for rep in range(2):   # (twice: the second call's pyramid is the pipelined one)
+            ctx.png_decode_gray_batch(files, 640, 480, d_mosaic.data_ptr(), 640 * 480, 640)
+            ctx.bayer_bg_to_gray_batch_dev(d_mosaic.data_ptr(), 4, 640, 480, 640 * 480, 640, d_gray.data_ptr(), 640 * 480, 640)
+            ctx.extract_batch_dev(d_gray.data_ptr(), 4, 640 * 480, 640, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr())
+        assert ctx.sync() == capi.VSF_OK
+        np.testing.assert_array_equal(d_mosaic.cpu().numpy(), np.stack(mosaics))
+        for k in range(4):
+            gray = oracle.bayer_bg_to_gray(mosaics[k])
+            np.testing.assert_array_equal(d_gray.cpu().numpy()[k], gray)
+            o = oracle.Orb(nfeatures=500)
+            o.run(gray)
+            rk, rd = o.result()
+            n = int(d_n.cpu()[k])
+            assert n == len(rk) > 300
+            assert d_kp.cpu().numpy()[k, :n].tobytes() == rk.tobytes()
+            np.testing.assert_array_equal(d_desc.cpu().numpy()[k, :n], rd)

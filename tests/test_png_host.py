@@ -1,0 +1,210 @@
+"""CPU checks of the PNG ingest's host half (csrc/vsf_png_host.cc: chunk walk, CRCs, upload plan; reference counterpart:
+cv::imdecode at slam_frontend_main.cc:98-100) and of the committed fixtures.
+
+* tests/golden/png (tools/make_png_golden.py): every file decodes with the Python standard library alone (zlib + the five
+  filters restated in numpy) to the image PIL = libpng read when the fixture was made -- the vectors are self-consistent
+  and the GPU test's reference for them is a real third party's output.
+* `make asan` builds the parser with -fsanitize=address,undefined; a child process runs the fixtures, hand-made refusals and
+  3000 seeded mutations (bit flips anywhere, cuts, chunk lengths rewritten, chunks reordered / duplicated / dropped) through
+  vsf_png_plan + vsf_png_fill and must exit cleanly."""
+import os
+import subprocess
+import sys
+import zlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "vision_slam_frontend_amd" / "csrc"
+LIB = ROOT / "vision_slam_frontend_amd" / "libvsf_jpeg_host_asan.so"
+GOLD = Path(__file__).resolve().parent / "golden" / "png"
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import png_craft as pc  # noqa: E402
+
+
+def unfilter_numpy(raw: bytes, h: int, row_bytes: int, bpp: int) -> np.ndarray:
+    rows = np.frombuffer(raw, np.uint8).reshape(h, row_bytes + 1)
+    out = np.zeros((h, row_bytes), np.uint8)
+    prev = np.zeros(row_bytes, np.int32)
+    for y in range(h):
+        t = int(rows[y, 0])
+        cur = np.zeros(row_bytes, np.int32)
+        f = rows[y, 1:].astype(np.int32)
+        for x in range(row_bytes):
+            a = cur[x - bpp] if x >= bpp else 0
+            b = prev[x]
+            c = prev[x - bpp] if x >= bpp else 0
+            if t == 0:
+                p = 0
+            elif t == 1:
+                p = a
+            elif t == 2:
+                p = b
+            elif t == 3:
+                p = (a + b) >> 1
+            else:
+                pa, pb, pcc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pcc) else (b if pb <= pcc else c)
+            cur[x] = (f[x] + p) & 255
+        out[y] = cur
+        prev = cur
+    return out
+
+
+def gray_from_rows(rows: np.ndarray, w: int, depth: int, channels: int) -> np.ndarray:
+    if depth == 8:
+        return rows[:, ::channels].copy()
+    if depth == 16:
+        return rows[:, ::2 * channels].copy()
+    ppb = 8 // depth
+    out = np.zeros((rows.shape[0], rows.shape[1] * ppb), np.uint8)
+    mask = (1 << depth) - 1
+    for p in range(ppb):
+        out[:, p::ppb] = ((rows >> (8 - depth * (p + 1))) & mask) * (255 // mask)
+    return out[:, :w]
+
+
+def test_png_fixtures_are_self_consistent():
+    expected = np.load(GOLD / "expected_gray.npz")
+    files = sorted(GOLD.glob("*.png"))
+    assert len(files) == len(expected.files) >= 20
+    for f in files:
+        data = f.read_bytes()
+        want = expected[f.stem]
+        h, w = want.shape
+        depth, ctype = data[24], data[25]
+        channels = 2 if ctype == 4 else 1
+        row_bytes = (w * depth * channels + 7) // 8
+        raw = zlib.decompress(pc.idat_stream(data))
+        assert len(raw) == (row_bytes + 1) * h, f.name
+        rows = unfilter_numpy(raw, h, row_bytes, max(1, depth * channels // 8))
+        np.testing.assert_array_equal(gray_from_rows(rows, w, depth, channels), want, err_msg=f.name)
+
+
+DRIVER = r'''
+import ctypes as C, struct, sys, zlib
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, sys.argv[3])
+import png_craft as pc
+lib = C.CDLL(sys.argv[1])
+lib.vsf_png_host_check.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+gold = Path(sys.argv[2])
+expected = np.load(gold / "expected_gray.npz")
+files = {p.stem: p.read_bytes() for p in sorted(gold.glob("*.png"))}
+
+def check(batch, w, h):
+    n = len(batch)
+    ptrs = (C.c_char_p * n)(*batch)
+    sizes = (C.c_size_t * n)(*[len(b) for b in batch])
+    total, csum = C.c_uint64(), C.c_uint32()
+    return lib.vsf_png_host_check(ptrs, sizes, n, w, h, C.byref(total), C.byref(csum)), total.value
+
+def chunks(data):
+    pos, out = 8, []
+    while pos + 12 <= len(data):
+        n = struct.unpack(">I", data[pos:pos + 4])[0]
+        out.append(data[pos:pos + 12 + n])
+        pos += 12 + n
+    return out
+
+for name, data in files.items():
+    h, w = expected[name].shape
+    st, total = check([data], w, h)
+    assert st == 0 and total >= len(pc.idat_stream(data)), (name, st, total)
+    assert check([data], w + 1, h)[0] == 1 and check([data], w, h + 1)[0] == 1, name
+    assert check([data[:-12]], w, h)[0] == 1, name          # no IEND
+    b = bytearray(data); b[len(data) // 2] ^= 1               # inside IDAT: its CRC no longer matches
+    assert check([bytes(b)], w, h)[0] == 1, name
+img = expected["pil_scene_level6"]
+h, w = img.shape
+good = pc.gray8(img)
+assert check([good], w, h)[0] == 0
+assert check([pc.gray8(img, extra_before=[pc.chunk(b"tEXt", b"k\x00v", bad_crc=True)])], w, h)[0] == 0      # ancillary, damaged: skipped
+assert check([pc.gray8(img, extra_before=[pc.chunk(b"ABCD", b"")])], w, h)[0] == 1                          # unknown critical chunk
+assert check([pc.write_png(pc.pack_samples(img, 8), w, h, 8, 0, interlace=1)], w, h)[0] == 4               # Adam7: unsupported
+assert check([pc.write_png(np.zeros((h, 3 * w), np.uint8), w, h, 8, 2)], w, h)[0] == 4                     # RGB: unsupported
+assert check([pc.write_png(np.zeros((h, w), np.uint8), w, h, 8, 3)], w, h)[0] == 4                         # palette: unsupported
+assert check([pc.write_png(pc.pack_samples(img, 8), w, h, 3, 0)], w, h)[0] == 1                            # 3-bit gray does not exist
+for hdr in (b"\x78\x9d", b"\x88\x1c", b"\x78\xbb", b"\x79\x9c"):                                            # zlib headers that fail their checks
+    assert check([pc.replace_idat(good, hdr + pc.idat_stream(good)[2:])], w, h)[0] == 1, hdr
+c = chunks(good)
+assert check([good[:8] + c[0] + c[1] + pc.chunk(b"tIME", bytes(7)) + c[1] + c[-1]], w, h)[0] == 1          # IDAT, other chunk, IDAT
+assert check([good[:8] + c[0] + c[0] + b"".join(c[1:])], w, h)[0] == 1                                     # IHDR twice
+assert check([good[:8] + b"".join(c[1:])], w, h)[0] == 1                                                   # no IHDR
+assert check([good[:8] + c[0] + c[-1]], w, h)[0] == 1                                                      # no IDAT
+
+def mutate(data, rng):
+    b = bytearray(data)
+    kind = int(rng.integers(10))
+    if kind >= 7:     # framing intact, CRCs right: damage inside the compressed data, IDAT cut anew, ancillary chunks added
+        stream = pc.idat_stream(data)
+        if kind == 7:
+            stream = pc.mutate_stream(stream, rng)
+        cs = chunks(data)
+        extra = [pc.chunk(b"tEXt", bytes(rng.integers(32, 127, int(rng.integers(0, 30)), dtype=np.uint8)), bad_crc=bool(rng.integers(2)))
+                 for _ in range(int(rng.integers(0, 3)))]
+        piece = max(1, int(rng.integers(1, len(stream) + 2)))
+        idat = b"".join(pc.chunk(b"IDAT", stream[i:i + piece]) for i in range(0, len(stream), piece))
+        return data[:8] + cs[0] + b"".join(extra) + idat + cs[-1]
+    if kind == 0:
+        for _ in range(int(rng.integers(1, 5))):
+            b[int(rng.integers(len(b)))] ^= 1 << int(rng.integers(8))
+    elif kind == 1:
+        del b[int(rng.integers(1, len(b))):]
+    elif kind == 2:   # a chunk length rewritten (CRC left alone)
+        cs = chunks(data); k = int(rng.integers(len(cs))); off = 8 + sum(len(x) for x in cs[:k])
+        b[off:off + 4] = struct.pack(">I", int(rng.integers(0, 1 << int(rng.integers(1, 32)))))
+    elif kind == 3:   # chunks shuffled / duplicated / dropped, framing intact
+        cs = chunks(data); order = list(rng.permutation(len(cs)))[:int(rng.integers(1, len(cs) + 2))]
+        b = bytearray(data[:8] + b"".join(cs[i % len(cs)] for i in order))
+    elif kind == 4:   # IHDR fields rewritten with a correct CRC
+        f = bytearray(data[16:29]); f[int(rng.integers(13))] = int(rng.integers(256))
+        b[8:33] = pc.chunk(b"IHDR", bytes(f))
+    elif kind == 5:
+        i = int(rng.integers(len(b))); b[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+    else:
+        b = bytearray(bytes(rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8)))
+    return bytes(b)
+
+rng = np.random.Generator(np.random.PCG64(20261004))
+names = sorted(files)
+ok = bad = 0
+for it in range(3000):
+    name = names[int(rng.integers(len(names)))]
+    h, w = expected[name].shape
+    batch = [mutate(files[name], rng) for _ in range(int(rng.integers(1, 4)))]
+    if it % 7 == 0:
+        batch.append(files[name])
+    st, _ = check(batch, w, h)
+    assert st in (0, 1, 4), st
+    ok += st == 0
+    bad += st != 0
+for junk in (b"", b"\x89", b"\x89PNG\r\n\x1a\n", b"\x89PNG\r\n\x1a\n" + bytes(40), bytes(100)):
+    assert check([junk], 8, 8)[0] == 1
+print("done ok=%d refused=%d" % (ok, bad))
+'''
+
+
+def test_png_host_parser_under_asan_and_ubsan(tmp_path):
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan_rt = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (asan_rt and Path(asan_rt).exists() and ubsan_rt and Path(ubsan_rt).exists()):
+        pytest.skip("no sanitizer runtime in this toolchain")
+    r = subprocess.run(["make", "-s", "-C", str(CSRC), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0 and LIB.exists(), r.stderr[-2000:]
+    script = tmp_path / "drive.py"
+    script.write_text(DRIVER)
+    env = dict(os.environ, LD_PRELOAD="%s %s" % (asan_rt, ubsan_rt),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([sys.executable, str(script), str(LIB), str(GOLD), str(Path(__file__).resolve().parent)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-4000:])
+    assert p.stdout.strip().startswith("done")
+    ok = int(p.stdout.split("ok=")[1].split()[0])
+    refused = int(p.stdout.split("refused=")[1].split()[0])
+    assert ok > 400 and refused > 500, (ok, refused)

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/png/: small grayscale PNG files and what libpng (through PIL) reads out of them -- the pinned
+vectors of vsf_png_decode_gray_batch (cv::imdecode(IMREAD_GRAYSCALE) for PNG, slam_frontend_main.cc:99-100).
+
+Files written by PIL itself (libpng's encoder: adaptive filters, compression levels 0 / 1 / 6 / 9) and by tests/png_craft.py
+(a chosen filter per row, a chosen zlib strategy -> stored / fixed / dynamic / run-length blocks, IDAT payloads in pieces,
+1 / 2 / 4 / 16-bit samples, gray + alpha).  expected_gray.npz holds, per file, the 8-bit gray image a gray read returns,
+computed from PIL's decode of the file: 8-bit samples as they are, the high byte of 16-bit samples (png_set_strip_16),
+alpha dropped (png_set_strip_alpha), 1 / 2 / 4-bit samples replicated (png_set_expand_gray_1_2_4_to_8) -- the libpng
+settings of grfmt_png.cpp for IMREAD_GRAYSCALE.  Run where PIL is installed:  python3 tools/make_png_golden.py"""
+import io
+import sys
+import zlib
+from pathlib import Path
+
+import numpy as np
+from PIL import Image
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
+import png_craft as pc  # noqa: E402
+from vision_slam_frontend_amd import synth  # noqa: E402
+
+OUT = ROOT / "tests" / "golden" / "png"
+
+
+def pil_gray(png: bytes) -> np.ndarray:
+    im = Image.open(io.BytesIO(png))
+    im.load()
+    if im.mode in ("I;16", "I;16B", "I"):
+        return (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)
+    if im.mode in ("LA", "RGBA"):
+        return np.asarray(im)[:, :, 0].copy()
+    if im.mode == "1":
+        return np.asarray(im).astype(np.uint8) * 255
+    assert im.mode == "L", im.mode
+    return np.asarray(im).copy()
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    rng = np.random.Generator(np.random.PCG64(20261004))
+    left, _ = synth.stereo_pair(160, 120, 0, n_objects=120)
+    photo = np.asarray(Image.open(ROOT / "tests" / "golden" / "real" / "camera.png"))[120:240:1, 200:360:1]
+    files = {}
+    for name, img in (("scene", left), ("photo", np.ascontiguousarray(photo))):
+        for level in (0, 1, 6, 9):
+            b = io.BytesIO()
+            Image.fromarray(img, "L").save(b, "PNG", compress_level=level)
+            files["pil_%s_level%d" % (name, level)] = b.getvalue()
+    h, w = left.shape
+    for strat, tag in ((zlib.Z_FIXED, "fixed"), (zlib.Z_RLE, "rle"), (zlib.Z_HUFFMAN_ONLY, "huffman"), (zlib.Z_DEFAULT_STRATEGY, "dynamic")):
+        files["craft_%s_filters_cycled" % tag] = pc.gray8(left, filters=np.arange(h) % 5, strategy=strat, idat_piece=1000)
+    files["craft_stored_paeth"] = pc.gray8(left, filters=np.full(h, 4), level=0)
+    files["craft_average_odd_67x41"] = pc.gray8(left[:41, :67].copy(), filters=np.full(41, 3), idat_piece=7)
+    for depth in (1, 2, 4):
+        v = (left >> (8 - depth)).astype(np.uint8)
+        files["craft_gray%d" % depth] = pc.write_png(pc.pack_samples(v, depth), w, h, depth, 0, filters=rng.integers(0, 5, h))
+    v16 = left.astype(np.uint16) * 257 ^ rng.integers(0, 256, left.shape).astype(np.uint16)
+    files["craft_gray16"] = pc.write_png(pc.pack_samples(v16, 16), w, h, 16, 0, filters=rng.integers(0, 5, h))
+    ga = np.dstack([left, rng.integers(0, 256, left.shape).astype(np.uint8)])
+    files["craft_gray_alpha8"] = pc.write_png(pc.pack_samples(ga, 8), w, h, 8, 4, filters=rng.integers(0, 5, h))
+    ga16 = np.dstack([v16, rng.integers(0, 65536, left.shape).astype(np.uint16)])
+    files["craft_gray_alpha16"] = pc.write_png(pc.pack_samples(ga16, 16), w, h, 16, 4, filters=rng.integers(0, 5, h))
+    expected = {}
+    for name, data in files.items():
+        (OUT / (name + ".png")).write_bytes(data)
+        expected[name] = pil_gray(data)
+    np.savez_compressed(OUT / "expected_gray.npz", **expected)
+    print("%d files, %d bytes" % (len(files), sum(len(d) for d in files.values())))
+
+
+if __name__ == "__main__":
+    main()
