@@ -164,7 +164,7 @@ class JpegIngest:
     (vsf_jpeg_decode_gray_batch) and demosaiced (vsf_bayer_bg_to_gray_batch_dev) on a context and stream of their own,
     one step AHEAD of the extraction: two image buffers alternate, two events per buffer order the streams."""
 
-    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream, priority="normal"):
+    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream, priority="normal", fmt="jpeg"):
         import ctypes as C
         import io
 
@@ -176,9 +176,13 @@ class JpegIngest:
         self.capi, self.C, self.torch = capi, C, torch
         self.W, self.H, self.consumer = width, height, consumer_stream
         self.files = []
+        self.fmt = fmt  # "jpeg": baseline JPEG, quality 80; "png": grayscale PNG, libpng's level 6 (vsf_png_decode_gray_batch)
         for f in frames.reshape(-1, height, width):
             bio = io.BytesIO()
-            Image.fromarray(f, "L").save(bio, "JPEG", quality=80)
+            if fmt == "png":
+                Image.fromarray(f, "L").save(bio, "PNG", compress_level=6)
+            else:
+                Image.fromarray(f, "L").save(bio, "JPEG", quality=80)
             self.files.append(np.frombuffer(bio.getvalue(), np.uint8))
         self.n_files = len(self.files)
         self.avg_kb = sum(len(f) for f in self.files) / self.n_files / 1024
@@ -215,11 +219,11 @@ class JpegIngest:
         C, W, H = self.C, self.W, self.H
         if self.issued >= 2:
             self.stream.wait_event(self.consumed[slot])
-        st = self.capi.lib().vsf_jpeg_decode_gray_batch(self.ctx._h, C.cast(self.ptrs, C.c_void_p),
-                                                        C.cast(self.sizes, C.c_void_p), self.n_files, W, H,
-                                                        C.c_void_p(self.d_mosaic.data_ptr()), W * H, W)
+        decode = self.capi.lib().vsf_png_decode_gray_batch if self.fmt == "png" else self.capi.lib().vsf_jpeg_decode_gray_batch
+        st = decode(self.ctx._h, C.cast(self.ptrs, C.c_void_p), C.cast(self.sizes, C.c_void_p), self.n_files, W, H,
+                    C.c_void_p(self.d_mosaic.data_ptr()), W * H, W)
         if st != self.capi.VSF_OK:
-            raise self.capi.VsfError(st, "vsf_jpeg_decode_gray_batch")
+            raise self.capi.VsfError(st, "vsf_%s_decode_gray_batch" % self.fmt)
         self.ctx.bayer_bg_to_gray_batch_dev(self.d_mosaic.data_ptr(), self.n_files, W, H, W * H, W,
                                             self.d_in[slot].data_ptr(), W * H, W)
         self.ready[slot].record(self.stream)
@@ -447,7 +451,7 @@ def main() -> int:
                          "beside the next step's extraction")
     ap.add_argument("--scene", choices=["bench", "sparse"], default="bench",
                     help="sparse: few objects on a smooth background (~2 %% corner pixels) instead of SURVEY 8(d)'s stream")
-    ap.add_argument("--ingest", choices=["hbm", "jpeg"], default="hbm",
+    ap.add_argument("--ingest", choices=["hbm", "jpeg", "png"], default="hbm",
                     help="hbm (the metric's definition): frames resident in HBM when the timed region starts.  jpeg: every "
                          "step starts from 2*B baseline-JPEG files in HOST memory (the CompressedImage payloads of "
                          "slam_frontend_main.cc:98-109): upload, vsf_jpeg_decode_gray_batch, Bayer->gray, then the step; an "
@@ -639,8 +643,8 @@ def main() -> int:
     torch.cuda.synchronize()
 
     ingest = None
-    if args.ingest == "jpeg":
-        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream, priority=args.ingest_priority or "normal")
+    if args.ingest in ("jpeg", "png"):
+        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream, priority=args.ingest_priority or "normal", fmt=args.ingest)
 
     host_s = [0.0, 0.0]  # host wall time inside the ingest call / inside the step's launches (is the host the limit?)
 
@@ -857,7 +861,7 @@ def main() -> int:
         out = {
             "metric": ("stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
                        else "stereo frames/s (%dx%d, %d kp/frame)" % (W, H, NF)) +
-                      (" from JPEG files in host memory" if args.ingest == "jpeg" else ""),
+                      (" from %s files in host memory" % args.ingest.upper() if args.ingest != "hbm" else ""),
             "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -868,10 +872,11 @@ def main() -> int:
                                       else "custom", W, H, NF, args.window),
                        "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "scene": args.scene,
                        "ingest": "frames resident in HBM" if args.ingest == "hbm" else
-                                 "per step: %d baseline-JPEG files of %.0f KB (quality 80) from host memory -> upload -> "
-                                 "vsf_jpeg_decode_gray_batch -> Bayer->gray, one step ahead on its own stream "
+                                 "per step: %d %s files of %.0f KB from host memory -> upload -> "
+                                 "vsf_%s_decode_gray_batch -> Bayer->gray, one step ahead on its own stream "
                                  "(HIP stream priority %d: it fills what the extraction leaves free)"
-                                 % (ingest.n_files, ingest.avg_kb, ingest.stream_priority),
+                                 % (ingest.n_files, "grayscale PNG (libpng level 6)" if args.ingest == "png" else "baseline-JPEG (quality 80)",
+                                    ingest.avg_kb, args.ingest, ingest.stream_priority),
                        "parallelism": "frames sharded over %d GPU(s)%s" %
                                       (world, ", all-gather of per-frame means + frame tails, compact payload gather to rank 0 "
                                               "(RCCL)" if world > 1 else ""),

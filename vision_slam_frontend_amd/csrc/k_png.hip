@@ -40,6 +40,8 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr int kLitBits = 10, kDistBits = 9;  // direct lookup tables in LDS: codes of up to this many bits
 
 constexpr int kMaxLit = 288, kMaxDist = 32, kMaxCodes = kMaxLit + kMaxDist;
 __constant__ uint8_t c_cl_order[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 0};
@@ -125,9 +127,16 @@ struct BuiltCode {
   LaneCode c;
   bool ok;
 };
+// With `table`: also the direct lookup of the codes of up to `tbits` bits -- entry [the next tbits bits of the stream] =
+// symbol << 4 | length, 0 where a longer code begins (the lanes decode those).
 template <int REGS>
-__device__ __attribute__((noinline)) BuiltCode build_code(const lds_u8* lens, int nsym, lds_u16* sorted, bool allow_lone) {
+__device__ __attribute__((noinline)) BuiltCode build_code(const lds_u8* lens, int nsym, lds_u16* sorted, bool allow_lone,
+                                                          lds_u16* table, int tbits) {
   const int lane = threadIdx.x;
+  if (table) {
+    lds_u32* tw = (lds_u32*)table;
+    for (int i = lane; i < (1 << tbits) / 2; i += 64) tw[i] = 0u;
+  }
   uint32_t len_r[REGS];
   int pos_r[REGS];
 #pragma unroll
@@ -146,7 +155,14 @@ __device__ __attribute__((noinline)) BuiltCode build_code(const lds_u8* lens, in
     for (int r = 0; r < REGS; r++) {
       const unsigned long long bal = __builtin_amdgcn_ballot_w64(len_r[r] == (uint32_t)L);
       const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      if (len_r[r] == (uint32_t)L) pos_r[r] = offs + n + below;
+      if (len_r[r] == (uint32_t)L) {
+        pos_r[r] = offs + n + below;
+        if (table && L <= tbits) {  // (every lane in here has a code of this length: the same number of entries each)
+          const uint32_t rev = __builtin_bitreverse32((uint32_t)(code + n + below)) >> (32 - L);
+          const uint16_t e = (uint16_t)(((r * 64 + lane) << 4) | L);
+          for (int k = 0; k < (1 << (tbits - L)); k++) table[rev | ((uint32_t)k << L)] = e;
+        }
+      }
       n += __popcll(bal);
     }
     left -= n;
@@ -243,6 +259,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   __shared__ uint8_t lens[kMaxCodes + 8];
   __shared__ uint8_t cl_lens[32];
   __shared__ uint16_t sorted[kMaxCodes];
+  __shared__ __attribute__((aligned(4))) uint16_t lit_table[1 << kLitBits];
+  __shared__ __attribute__((aligned(4))) uint16_t dist_table[1 << kDistBits];
   const int lane = threadIdx.x;
   const int image = blockIdx.x;
   const DevImage im = load_image(a, image);
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
       if (stop) break;
       __syncthreads();
-      const BuiltCode clb = build_code<1>((const lds_u8*)cl_lens, 19, (lds_u16*)sorted, false);
+      const BuiltCode clb = build_code<1>((const lds_u8*)cl_lens, 19, (lds_u16*)sorted, false, nullptr, 0);
       const LaneCode clc = clb.c;
       if (__builtin_amdgcn_readfirstlane((int)clb.ok) == 0) {  // inflate: "invalid code lengths set"
         bad = true;
@@ -468,8 +486,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
     }
     __syncthreads();
-    const BuiltCode lb = build_code<5>((const lds_u8*)lens, hlit, (lds_u16*)sorted, true);
-    const BuiltCode db = build_code<1>((const lds_u8*)lens + hlit, hdist, (lds_u16*)sorted + kMaxLit, true);
+    const BuiltCode lb = build_code<5>((const lds_u8*)lens, hlit, (lds_u16*)sorted, true, (lds_u16*)lit_table, kLitBits);
+    const BuiltCode db = build_code<1>((const lds_u8*)lens + hlit, hdist, (lds_u16*)sorted + kMaxLit, true, (lds_u16*)dist_table, kDistBits);
     const LaneCode lc = lb.c, dc = db.c;
     if (__builtin_amdgcn_readfirstlane((int)lb.ok) == 0 || __builtin_amdgcn_readfirstlane((int)db.ok) == 0) {  // inflate: "invalid literal/lengths set", "invalid distances set"
       bad = true;
@@ -506,10 +524,16 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         int room = (int)min(expected - pos - (uint32_t)npend, 1u << 30);
         while (true) {
           br.fill();
-          int L;
-          const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
-          if (L == 0 || budget < 64) break;  // (64 bits: more than a length code, a distance code and their extra bits)
-          const uint32_t sym = lit_symbol(idx);
+          if (budget < 64) break;  // (64 bits: more than a length code, a distance code and their extra bits)
+          // the next ten bits look the symbol up directly; a longer code (entry 0) is decoded by the lanes
+          const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lit_table[br.peek() & ((1u << kLitBits) - 1u)]);
+          int L = (int)(e & 15u);
+          uint32_t sym = e >> 4;
+          if (L == 0) {
+            const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
+            if (L == 0) break;
+            sym = lit_symbol(idx);
+          }
           if (sym < 256u) {
             br.acc >>= L;
             br.n -= L;
@@ -544,9 +568,13 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
             }
           }
           br.fill();
-          int L2;
-          const uint32_t idx2 = decode_index(br.peek(), dc, lane, &L2);
-          const uint32_t dsym = (uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u));
+          const uint32_t e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dist_table[br.peek() & ((1u << kDistBits) - 1u)]);
+          int L2 = (int)(e2 & 15u);
+          uint32_t dsym = e2 >> 4;
+          if (L2 == 0) {
+            const uint32_t idx2 = decode_index(br.peek(), dc, lane, &L2);
+            dsym = (uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u));
+          }
           if (L2 == 0 || dsym > 29u) {  // "invalid distance code" (the bits were there: budget)
             bad = true;
             break;
