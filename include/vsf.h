@@ -428,6 +428,15 @@ vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, co
                                      int width, int height, uint8_t* d_dst, size_t dst_image_stride,
                                      size_t dst_row_stride);
 
+/* cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE) as DecodeImage calls it (slam_frontend_main.cc:99-100), whatever the payloads
+ * are: every file is told by its first bytes (JPEG: FF D8 FF, PNG: its 8-byte signature) and runs of one format go to
+ * vsf_jpeg_decode_gray_batch / vsf_png_decode_gray_batch, whose rules apply; image i lands at d_dst + i * dst_image_stride.
+ * A file of neither format returns VSF_ERR_UNSUPPORTED (imdecode's other decoders are not built); nothing decoded so far is
+ * undone when a later run is refused. */
+vsf_status vsf_imdecode_gray_batch(vsf_ctx* ctx, const uint8_t* const* files, const size_t* nbytes, int n_images,
+                                   int width, int height, uint8_t* d_dst, size_t dst_image_stride,
+                                   size_t dst_row_stride);
+
 /* SURVEY section 8(f) row f4, the part behind cv::imdecode: DecodeImage's cvtColor(COLOR_BayerBG2BGR) +
  * cvtColor(COLOR_BGR2GRAY) (slam_frontend_main.cc:101-106) for n 8-bit mosaics of width x height resident in HBM, in
  * one pass.  d_src / d_dst: image i at base + i * image_stride, rows row_stride bytes apart; bases and strides multiples

@@ -331,3 +331,36 @@ def test_ingest_chain_png_bayer_extract(capi, oracle):
             assert n == len(rk) > 300
             assert d_kp.cpu().numpy()[k, :n].tobytes() == rk.tobytes()
             np.testing.assert_array_equal(d_desc.cpu().numpy()[k, :n], rd)
+
+
+def test_imdecode_tells_jpeg_from_png(capi, oracle):
+    """vsf_imdecode_gray_batch: a batch of mixed payloads, as DecodeImage meets them (slam_frontend_main.cc:99-100): runs of
+    JPEG and PNG files in one call, each image at its own index; a BMP is refused as unsupported."""
+    from vision_slam_frontend_amd import synth
+    dev = torch.device("cuda", 0)
+    w, h = 320, 240
+    imgs = [synth.stereo_pair(w, h, 40 + k, n_objects=200)[k & 1] for k in range(7)]
+    files, want = [], []
+    for k, img in enumerate(imgs):
+        b = io.BytesIO()
+        if k in (0, 1, 4, 6):
+            Image.fromarray(img, "L").save(b, "PNG", compress_level=k % 3 * 3)
+            files.append(b.getvalue())
+            want.append(img)
+        else:
+            Image.fromarray(img, "L").save(b, "JPEG", quality=85)
+            files.append(b.getvalue())
+            want.append(oracle.jpeg_decode_gray(b.getvalue()))
+    with capi.Context(capi.default_params(w, h, max_images=2, nfeatures=100)) as c:
+        d = torch.zeros((7, h, w), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        assert c.imdecode_gray_batch(files, w, h, d.data_ptr(), w * h, w) == capi.VSF_OK
+        assert c.sync() == capi.VSF_OK
+        got = d.cpu().numpy()
+        for k in range(7):
+            np.testing.assert_array_equal(got[k], want[k], err_msg="file %d" % k)
+        bmp = io.BytesIO()
+        Image.fromarray(imgs[0], "L").save(bmp, "BMP")
+        st = c.imdecode_gray_batch([files[0], bmp.getvalue()], w, h, d.data_ptr(), w * h, w, allow_status=(capi.VSF_ERR_UNSUPPORTED,))
+        assert st == capi.VSF_ERR_UNSUPPORTED
+        assert c.sync() == capi.VSF_OK

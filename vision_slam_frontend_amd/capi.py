@@ -35,7 +35,7 @@ EXPORTS = [
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
-    "vsf_jpeg_decode_gray_batch", "vsf_png_decode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error", "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_destroy", "vsf_comm_info",
+    "vsf_jpeg_decode_gray_batch", "vsf_png_decode_gray_batch", "vsf_imdecode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error", "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_destroy", "vsf_comm_info",
     "vsf_allgather_dev", "vsf_gather_payload_dev", "vsf_reserve", "vsf_set_input_event",
 ]
 # vsf_option (include/vsf.h)
@@ -153,6 +153,7 @@ def lib() -> C.CDLL:
         L.vsf_observe_reset.argtypes = [vp]
         L.vsf_jpeg_decode_gray_batch.argtypes = [vp, vp, vp, i32, i32, i32, vp, sz, sz]
         L.vsf_png_decode_gray_batch.argtypes = [vp, vp, vp, i32, i32, i32, vp, sz, sz]
+        L.vsf_imdecode_gray_batch.argtypes = [vp, vp, vp, i32, i32, i32, vp, sz, sz]
         L.vsf_debug_level_image.argtypes = [vp, i32, i32, i32, vp, sz]
         L.vsf_debug_fast_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
         L.vsf_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
@@ -485,6 +486,19 @@ class Context:
                                              height, _p(d_dst), dst_image_stride, dst_row_stride)
         if st != VSF_OK and st not in allow_status:
             raise VsfError(st, "vsf_png_decode_gray_batch", lib().vsf_last_hip_error(self._h))
+        return st
+
+    def imdecode_gray_batch(self, files, width: int, height: int, d_dst: int, dst_image_stride: int,
+                            dst_row_stride: int, allow_status=()):
+        """cv::imdecode(IMREAD_GRAYSCALE) of JPEG and PNG payloads, mixed (slam_frontend_main.cc:99-100)."""
+        n = len(files)
+        bufs = [np.frombuffer(bytes(f), np.uint8) for f in files]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        sizes = (C.c_size_t * n)(*[len(b) for b in bufs])
+        st = lib().vsf_imdecode_gray_batch(self._h, C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), n, width, height,
+                                           _p(d_dst), dst_image_stride, dst_row_stride)
+        if st != VSF_OK and st not in allow_status:
+            raise VsfError(st, "vsf_imdecode_gray_batch", lib().vsf_last_hip_error(self._h))
         return st
 
     def bayer_bg_to_gray_batch_dev(self, d_src: int, n_images: int, width: int, height: int, src_image_stride: int,

@@ -1950,6 +1950,35 @@ vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, co
   return VSF_OK;
 }
 
+// cv::imdecode(msg.data, IMREAD_GRAYSCALE) as the reference calls it (slam_frontend_main.cc:99-100): whatever the payload
+// is.  Files are told apart by their first bytes (as cv::imdecode's findDecoder does: signature match) and handed, run by run
+// of one format, to the JPEG or the PNG entry point; image i lands at d_dst + i * dst_image_stride either way.
+vsf_status vsf_imdecode_gray_batch(vsf_ctx* ctx, const uint8_t* const* files, const size_t* nbytes, int n_images,
+                                   int width, int height, uint8_t* d_dst, size_t dst_image_stride,
+                                   size_t dst_row_stride) {
+  if (!ctx || !files || !nbytes || n_images < 1 || !d_dst) return VSF_ERR_INVALID_ARG;
+  static const uint8_t kPng[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  auto kind = [&](int i) -> int {  // 0 JPEG (SOI), 1 PNG, -1 neither
+    if (!files[i]) return -1;
+    if (nbytes[i] >= 8 && std::memcmp(files[i], kPng, 8) == 0) return 1;
+    if (nbytes[i] >= 3 && files[i][0] == 0xFF && files[i][1] == 0xD8 && files[i][2] == 0xFF) return 0;
+    return -1;
+  };
+  for (int i = 0; i < n_images; i++)
+    if (kind(i) < 0) return VSF_ERR_UNSUPPORTED;  // (imdecode's other formats -- BMP, TIFF, WebP ... -- are not built)
+  for (int i0 = 0; i0 < n_images;) {
+    const int k = kind(i0);
+    int i1 = i0 + 1;
+    while (i1 < n_images && kind(i1) == k) ++i1;
+    uint8_t* dst = d_dst + (size_t)i0 * dst_image_stride;
+    const vsf_status st = k == 1 ? vsf_png_decode_gray_batch(ctx, files + i0, nbytes + i0, i1 - i0, width, height, dst, dst_image_stride, dst_row_stride)
+                                 : vsf_jpeg_decode_gray_batch(ctx, files + i0, nbytes + i0, i1 - i0, width, height, dst, dst_image_stride, dst_row_stride);
+    if (st != VSF_OK) return st;
+    i0 = i1;
+  }
+  return VSF_OK;
+}
+
 vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
                                          size_t set_stride, const int32_t* d_q_set, const int32_t* d_t_set,
                                          int n_pairs, float best_percent, uint64_t* d_pairs, int32_t* d_npairs) {
