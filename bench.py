@@ -164,7 +164,7 @@ class JpegIngest:
     (vsf_jpeg_decode_gray_batch) and demosaiced (vsf_bayer_bg_to_gray_batch_dev) on a context and stream of their own,
     one step AHEAD of the extraction: two image buffers alternate, two events per buffer order the streams."""
 
-    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream, priority="normal", fmt="jpeg"):
+    def __init__(self, frames, width, height, nfeatures, device_index, dev, consumer_stream, priority="normal", fmt="jpeg", depth=1):
         import ctypes as C
         import io
 
@@ -205,42 +205,57 @@ class JpegIngest:
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=dev)
             self.stream_priority = 0
+        # `depth` steps' files per decode call (a PNG decode is one wave per file and far longer than a step: the files of
+        # two steps in one launch put four waves on every CU instead of two); two group buffers take turns
+        self.depth = depth = max(1, int(depth))
         self.ctx = capi.Context(capi.default_params(width, height, max_images=2, nfeatures=nfeatures), device=device_index)
         self.ctx.set_stream(self.stream.cuda_stream)
-        self.d_mosaic = torch.empty((self.n_files, height, width), dtype=torch.uint8, device=dev)
-        self.d_in = [torch.empty((self.n_files // 2, 2, height, width), dtype=torch.uint8, device=dev) for _ in range(2)]
+        if depth > 1:
+            self.files = self.files * depth
+            self.ptrs = (C.c_void_p * len(self.files))(*[f.ctypes.data for f in self.files])
+            self.sizes = (C.c_size_t * len(self.files))(*[len(f) for f in self.files])
+        self.n_call = len(self.files)  # files per decode call
+        self.d_mosaic = torch.empty((self.n_call, height, width), dtype=torch.uint8, device=dev)
+        self.d_in = [torch.empty((depth, self.n_files // 2, 2, height, width), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
-        self.issued = 0
+        self.issued = 0   # decode calls started
+        self.taken = 0    # steps handed out
         self.current = 0
-        self._issue(0)
+        self._issue()
 
-    def _issue(self, slot):
+    def _issue(self):
         C, W, H = self.C, self.W, self.H
+        slot = self.issued & 1
         if self.issued >= 2:
-            self.stream.wait_event(self.consumed[slot])
+            self.stream.wait_event(self.consumed[slot])  # (the last step that read this buffer has been queued)
         decode = self.capi.lib().vsf_png_decode_gray_batch if self.fmt == "png" else self.capi.lib().vsf_jpeg_decode_gray_batch
-        st = decode(self.ctx._h, C.cast(self.ptrs, C.c_void_p), C.cast(self.sizes, C.c_void_p), self.n_files, W, H,
+        st = decode(self.ctx._h, C.cast(self.ptrs, C.c_void_p), C.cast(self.sizes, C.c_void_p), self.n_call, W, H,
                     C.c_void_p(self.d_mosaic.data_ptr()), W * H, W)
         if st != self.capi.VSF_OK:
             raise self.capi.VsfError(st, "vsf_%s_decode_gray_batch" % self.fmt)
-        self.ctx.bayer_bg_to_gray_batch_dev(self.d_mosaic.data_ptr(), self.n_files, W, H, W * H, W,
+        self.ctx.bayer_bg_to_gray_batch_dev(self.d_mosaic.data_ptr(), self.n_call, W, H, W * H, W,
                                             self.d_in[slot].data_ptr(), W * H, W)
         self.ready[slot].record(self.stream)
         self.issued += 1
 
     def next_batch(self):
         """(this step's frames, the event behind their producer): the extraction is handed the event (vsf_set_input_event)
-        -- its pipelined pyramid, which is ordered after nothing else, waits for it on the GPU -- and the next step's decode
-        is started."""
-        slot = (self.issued - 1) & 1
-        self.consumer.wait_event(self.ready[slot])
-        self._issue(slot ^ 1)
+        -- its pipelined pyramid, which is ordered after nothing else, waits for it on the GPU; with the first step of a
+        group the decode of the next group is started."""
+        group, within = divmod(self.taken, self.depth)
+        self.taken += 1
+        slot = group & 1
+        if within == 0:
+            self.consumer.wait_event(self.ready[slot])
+            self._issue()
         self.current = slot
-        return self.d_in[slot], self.ready[slot]
+        self.last_of_group = within == self.depth - 1
+        return self.d_in[slot][within], self.ready[slot]
 
     def release(self):
-        self.consumed[self.current].record(self.consumer)
+        if self.last_of_group:  # the buffer may be overwritten once the group's last step has read it
+            self.consumed[self.current].record(self.consumer)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -471,6 +486,8 @@ def main() -> int:
                          "FAST, 0 = it starts as soon as its inputs are ready; default 1 with frames in HBM, 0 with --ingest jpeg")
     ap.add_argument("--pipe-priority", type=int, default=None,
                     help="VSF_OPT_PIPE_PRIORITY (experiments): stream priority of the pipelined pyramid chain, 0 / 1 low / -1 high")
+    ap.add_argument("--ingest-depth", type=int, default=None,
+                    help="--ingest jpeg / png: steps whose files one decode call takes (default 1 for JPEG, 2 for PNG: four decoder waves per CU)")
     ap.add_argument("--ingest-priority", choices=["low", "normal", "high"], default=None,
                     help="--ingest jpeg: HIP stream priority of the decode stream")
     ap.add_argument("--match-int8", action="store_true", help="VSF_OPT_MATCH_INT8: round 2's int8 form of the matcher (A/B runs)")
@@ -644,7 +661,8 @@ def main() -> int:
 
     ingest = None
     if args.ingest in ("jpeg", "png"):
-        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream, priority=args.ingest_priority or "normal", fmt=args.ingest)
+        ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream, priority=args.ingest_priority or "normal", fmt=args.ingest,
+                            depth=args.ingest_depth or (2 if args.ingest == "png" else 1))
 
     host_s = [0.0, 0.0]  # host wall time inside the ingest call / inside the step's launches (is the host the limit?)
 

@@ -114,18 +114,34 @@ __device__ __forceinline__ v2s arc_max_min(const v2s (&d)[16]) {
   return vmax(vmax3(vmax3(ta[0], ta[1], ta[2]), vmax3(ta[3], ta[4], ta[5]), ta[6]), ta[7]);
 }
 
-__global__ __launch_bounds__(64) void fast_bits_kernel(FastBitsArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t raw[RAW_SLOTS * ROWB];
-  __shared__ __attribute__((aligned(16))) uint8_t smap[3 * ROWB];
-  __shared__ uint16_t list[LIST_CAP];
-  __shared__ uint32_t kmask[64];
+#ifndef VSF_FB_WAVES
+#define VSF_FB_WAVES 1
+#endif
+constexpr int FB_WAVES = VSF_FB_WAVES;  // waves per workgroup; each works alone (its own item, its own LDS): they only share a CU
+constexpr int FB_LDS_PER_WAVE = RAW_SLOTS * ROWB + 3 * ROWB + LIST_CAP * 2 + 64 * 4;
 
-  const int lane = threadIdx.x;
+// (between the lanes of ONE wave LDS operations take effect in program order: what is needed is that the compiler keeps
+// that order)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * FB_WAVES) void fast_bits_kernel(FastBitsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fb_lds[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* const my = fb_lds + wave * FB_LDS_PER_WAVE;
+  uint8_t* const raw = my;
+  uint8_t* const smap = my + RAW_SLOTS * ROWB;
+  uint16_t* const list = reinterpret_cast<uint16_t*>(my + RAW_SLOTS * ROWB + 3 * ROWB);
+  uint32_t* const kmask = reinterpret_cast<uint32_t*>(my + RAW_SLOTS * ROWB + 3 * ROWB + LIST_CAP * 2);
+
+  const int lane = threadIdx.x & 63;
   const uint2 it = uniform_copy(a.items + blockIdx.x);
   const int level = (int)(it.x >> 24), band = (int)((it.x >> 16) & 0xFF), strip0 = (int)(it.x & 0xFFFF);
   const int nstr = (int)(it.y >> 8), nl = (int)(it.y & 0xFF);
   const int G = 64 / nl;
-  const int image0 = (int)blockIdx.y * G;
+  const int image0 = ((int)blockIdx.y * FB_WAVES + wave) * G;
   if (image0 >= a.nimages) return;  // wave-uniform
   const VsfLevel L = uniform_copy(a.levels + level);
   const int t = a.threshold;
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(64) void fast_bits_kernel(FastBitsArgs a) {
               ++idx;
             }
           }
-          __syncthreads();
+          wave_sync();
           const int nround = min(LIST_CAP, total - R);
           for (int p = 0; p < nround; p += 128) {
             const bool v0 = p + lane < nround, v1 = p + 64 + lane < nround;
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(64) void fast_bits_kernel(FastBitsArgs a) {
             if (v0) s_dn[P0] = (uint8_t)(sc & 0xFFu);
             if (v1) s_dn[P1] = (uint8_t)((sc >> 16) & 0xFFu);
           }
-          __syncthreads();
+          wave_sync();
         }
       }
     }
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(64) void fast_bits_kernel(FastBitsArgs a) {
               ++idx;
             }
           }
-          __syncthreads();
+          wave_sync();
           const int nround = min(LIST_CAP, total - R);
           for (int p = 0; p < nround; p += 64) {
             const bool v0 = p + lane < nround;
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(64) void fast_bits_kernel(FastBitsArgs a) {
             const uint32_t nb = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
             if (v0 && own > nb) atomicOr(&kmask[P >> 5], 1u << (P & 31));
           }
-          __syncthreads();
+          wave_sync();
         }
         const uint32_t K = kmask[lane];
         kmask[lane] = 0u;
@@ -431,5 +447,10 @@ void vsf_launch_fast_bits(const VsfDev& d, const VsfGeom& g, const VsfImages& im
   a.rowstart = d.rowstart;
   a.threshold = threshold;
   a.nimages = im.n;
-  hipLaunchKernelGGL(fast_bits_kernel, dim3(nitems, (im.n + 7) / 8), dim3(64), 0, s, a);
+  static bool prepared = false;
+  if (!prepared) {
+    vsf_note(hipFuncSetAttribute(reinterpret_cast<const void*>(fast_bits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_WAVES * FB_LDS_PER_WAVE));
+    prepared = true;
+  }
+  hipLaunchKernelGGL(fast_bits_kernel, dim3(nitems, ((im.n + 7) / 8 + FB_WAVES - 1) / FB_WAVES), dim3(64 * FB_WAVES), FB_WAVES * FB_LDS_PER_WAVE, s, a);
 }
