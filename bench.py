@@ -487,7 +487,7 @@ def main() -> int:
     ap.add_argument("--pipe-priority", type=int, default=None,
                     help="VSF_OPT_PIPE_PRIORITY (experiments): stream priority of the pipelined pyramid chain, 0 / 1 low / -1 high")
     ap.add_argument("--ingest-depth", type=int, default=None,
-                    help="--ingest jpeg / png: steps whose files one decode call takes (default 1 for JPEG, 2 for PNG: four decoder waves per CU)")
+                    help="--ingest jpeg / png: steps whose files one decode call takes (default 1; 2 with PNG puts four decoder waves on every CU, whose LDS the extraction then waits for: no gain, NOTES.md)")
     ap.add_argument("--ingest-priority", choices=["low", "normal", "high"], default=None,
                     help="--ingest jpeg: HIP stream priority of the decode stream")
     ap.add_argument("--match-int8", action="store_true", help="VSF_OPT_MATCH_INT8: round 2's int8 form of the matcher (A/B runs)")
@@ -662,7 +662,7 @@ def main() -> int:
     ingest = None
     if args.ingest in ("jpeg", "png"):
         ingest = JpegIngest(frames, W, H, NF, local_rank, dev, stream, priority=args.ingest_priority or "normal", fmt=args.ingest,
-                            depth=args.ingest_depth or (2 if args.ingest == "png" else 1))
+                            depth=args.ingest_depth or 1)
 
     host_s = [0.0, 0.0]  # host wall time inside the ingest call / inside the step's launches (is the host the limit?)
 
