@@ -523,6 +523,34 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         const int budget0 = budget;
         int room = (int)min(expected - pos - (uint32_t)npend, 1u << 30);
         while (true) {
+          // Runs of literals whose codes the table knows -- most symbols of a photograph -- in the tightest loop of all: no
+          // stream-buffer swap inside (it ends when one is due), nothing but the bit buffer, the counters and one table read.
+          {
+            uint64_t acc = br.acc;
+            int n = br.n, w = (int)(br.wpos - br.base);
+            while (true) {
+              if (n <= 32) {
+                if (w == 64) break;
+                acc |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)br.cur, w) << n;
+                ++w;
+                n += 32;
+              }
+              if (budget < 64) break;
+              const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lit_table[(uint32_t)acc & ((1u << kLitBits) - 1u)]);
+              const int L = (int)(e & 15u);
+              const uint32_t sym = e >> 4;
+              if (L == 0 || sym >= 256u || room <= 1 || npend >= 63) break;
+              acc >>= L;
+              n -= L;
+              budget -= L;
+              asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pend) : "s"(sym), "s"(npend));
+              ++npend;
+              --room;
+            }
+            br.acc = acc;
+            br.n = n;
+            br.wpos = br.base + (uint32_t)w;
+          }
           br.fill();
           if (budget < 64) break;  // (64 bits: more than a length code, a distance code and their extra bits)
           // the next ten bits look the symbol up directly; a longer code (entry 0) is decoded by the lanes
