@@ -447,10 +447,10 @@ void vsf_launch_fast_bits(const VsfDev& d, const VsfGeom& g, const VsfImages& im
   a.rowstart = d.rowstart;
   a.threshold = threshold;
   a.nimages = im.n;
-  static bool prepared = false;
-  if (!prepared) {
-    vsf_note(hipFuncSetAttribute(reinterpret_cast<const void*>(fast_bits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_WAVES * FB_LDS_PER_WAVE));
-    prepared = true;
-  }
+  // (dynamic LDS beyond the default limit needs the attribute -- only builds with several waves per workgroup get there; set
+  // per launch: it is a property of the function on the CURRENT device, and contexts of several devices may share a process)
+  if (FB_WAVES * FB_LDS_PER_WAVE > 64 * 1024)
+    vsf_note(hipFuncSetAttribute(reinterpret_cast<const void*>(fast_bits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 FB_WAVES * FB_LDS_PER_WAVE));
   hipLaunchKernelGGL(fast_bits_kernel, dim3(nitems, ((im.n + 7) / 8 + FB_WAVES - 1) / FB_WAVES), dim3(64 * FB_WAVES), FB_WAVES * FB_LDS_PER_WAVE, s, a);
 }
