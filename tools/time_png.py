@@ -21,15 +21,29 @@ dev = torch.device("cuda", 0)
 root = Path(__file__).resolve().parent.parent / "tests" / "golden" / "real"
 photos = [np.asarray(Image.open(f)) for f in sorted(root.glob("*.png"))]
 photos = np.stack([a for a in photos if a.shape == (H, W) and a.dtype == np.uint8])
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+import zlib
+
+import png_craft as pc
+
 sets = {"synthetic scenes": synth.bench_batch(16, W, H, n_scenes=4).reshape(-1, H, W), "photographs": photos}
 for name, base in sets.items():
-    for level in (1, 6, 9):
+    # levels 1 / 6 / 9: PIL = libpng with adaptive filters and zlib's default strategy; "cv": what cv::imencode writes when no
+    # level is given (grfmt_png.cpp: Z_BEST_SPEED, the Sub filter, Z_RLE -- matches of distance 1 only)
+    for level in (1, 6, 9, "cv"):
         files, srcs = [], []
+        cache = {}
         for i in range(N):
-            b = io.BytesIO()
-            Image.fromarray(base[i % len(base)], "L").save(b, "PNG", compress_level=level)
-            files.append(b.getvalue())
-            srcs.append(i % len(base))
+            k = i % len(base)
+            if k not in cache:
+                if level == "cv":
+                    cache[k] = pc.gray8(base[k], filters=np.full(H, 1), level=1, strategy=zlib.Z_RLE, idat_piece=8192)
+                else:
+                    b = io.BytesIO()
+                    Image.fromarray(base[k], "L").save(b, "PNG", compress_level=level)
+                    cache[k] = b.getvalue()
+            files.append(cache[k])
+            srcs.append(k)
         kb = sum(len(f) for f in files) / N / 1024
         ctx = capi.Context(capi.default_params(W, H, max_images=2, nfeatures=2000))
         s = torch.cuda.Stream(device=dev)
@@ -55,6 +69,6 @@ for name, base in sets.items():
             host += time.perf_counter() - h0
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
-        print("%s, level %d (%.0f KB per image): %d images in %.2f ms = %.0f images/s (host chunk walk + CRC + staging %.2f ms of it)"
+        print("%s, level %s (%.0f KB per image): %d images in %.2f ms = %.0f images/s (host chunk walk + CRC + staging %.2f ms of it)"
               % (name, level, kb, N, dt * 1e3, N / dt, host / reps * 1e3), flush=True)
         ctx.close()
