@@ -422,8 +422,10 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
  * their high byte, alpha is dropped, 1 / 2 / 4-bit samples are replicated to 8 bits (grfmt_png.cpp's libpng settings for
  * IMREAD_GRAYSCALE).  Colour, palette and Adam7 files return VSF_ERR_UNSUPPORTED, files of another size or with malformed
  * chunks VSF_ERR_INVALID_ARG (nothing is launched then); compressed data that breaks (what libpng answers with png_error)
- * makes the next vsf_sync return VSF_ERR_INVALID_ARG.  What a file holds behind its last image byte (Adler-32 included) is
- * not looked at, as libpng only warns about it.  Arguments and the asynchronous contract as for the JPEG call. */
+ * makes the next vsf_sync return VSF_ERR_INVALID_ARG -- that includes what zlib still reads behind the image's last byte in the
+ * call that delivers libpng's last row (the rest of the <= 8192-byte piece of one IDAT chunk it was fed: end-of-block code,
+ * further block headers, the Adler-32); what lies beyond that piece libpng reads with no row to fill and only warns about, and
+ * it is not looked at here either.  Arguments and the asynchronous contract as for the JPEG call. */
 vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, const size_t* nbytes, int n_images,
                                      int width, int height, uint8_t* d_dst, size_t dst_image_stride,
                                      size_t dst_row_stride);
