@@ -573,6 +573,9 @@ __device__ __forceinline__ void prog_scan(const Image& im, int si, const DevScan
       // ---- AC scans: the luminance alone, block after block in raster order ----
       const DevHuffLite* t = huffs + sc.huff[0];
       const int nblocks = units_x * units_y;
+      // (a file's time is its longest chain -- its refinement scans, each a step behind the scans it refines: they go first
+      // on their SIMD.  512 files: 45.1 -> 40.9 ms; priority for every AC scan: 44.1, for the wide refinement scans alone: 41.7)
+      if (PIPE && Ah != 0) __builtin_amdgcn_s_setprio(3);
       int bx = 0, by = 0;
       int16_t* blk = coef + (size_t)block_of(0, 0) * 64;
       wait_rows(1);
@@ -688,7 +691,7 @@ __device__ __forceinline__ void prog_scan(const Image& im, int si, const DevScan
       }
     }
     publish_rows(0x7FFFFFFF);
-  
+    if (PIPE) __builtin_amdgcn_s_setprio(0);
   }
 }
 
