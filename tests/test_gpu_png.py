@@ -127,6 +127,17 @@ def test_long_matches_far_distances_and_overlaps(capi, ctx):
     img = np.resize(tile, w * h).reshape(h, w)
     files.append(pc.gray8(img, level=9))
     want.append(img)
+    # the same at distances a little short of the window, each repetition with a few bytes changed: far matches with literals
+    # and short matches behind them -- bytes whose places in a 32 KiB ring are the far match's source
+    for period, flips in ((32700, 0.02), (32767, 0.005), (32768 - 258, 0.05), (32768 - 64, 0.2), (20000, 0.01)):
+        flat = np.resize(rng.integers(0, 256, period, dtype=np.uint8), w * h)
+        hit = rng.random(w * h) < flips
+        hit[:period] = False
+        flat[hit] = rng.integers(0, 256, int(hit.sum()), dtype=np.uint8)
+        img = flat.reshape(h, w)
+        for level in (1, 9):
+            files.append(pc.gray8(img, level=level))
+            want.append(img)
     st, got, sync = decode(capi, ctx, files, w, h)
     assert st == capi.VSF_OK and sync == capi.VSF_OK
     for i in range(len(files)):

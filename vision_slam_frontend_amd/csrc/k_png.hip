@@ -3,17 +3,20 @@
 // codes, the limits inflate_table enforces) and libpng's row filters (PNG specification section 9: None, Sub, Up, Average,
 // Paeth) for grayscale files; the chunk walk and the CRCs are the host's (vsf_png_host.cc).
 //
-// png_inflate_kernel: one wave per file.  A deflate stream is one serial chain of codes, so -- as in the one-wave JPEG
-// decoders of k_jpeg.hip -- the walk is written wave-uniform: bit buffer, positions and block state live in scalar
-// registers and the stream is fetched by scalar loads.  What is new here is the code lookup.  The tables of a dynamic
-// block are built inside the kernel, so they cannot sit behind the constant cache; instead a canonical code is decoded by
-// its definition with the lanes as the 15 possible lengths: lane L holds the first code of length L, how many there are
-// and where their symbols start in the sorted symbol list; it takes the first L bits of the stream and tests
-// `bits - first < count`; the one lane that answers yes (a prefix code: at most one can) names the length, and the symbol
-// is read out of the sorted list, which lives in vector registers (288 + 32 symbols = 6 registers).  No memory on the
-// path of a symbol.  Output bytes go into a 32 KiB ring in LDS -- deflate's window -- literals by way of a register that
-// collects 64 of them, matches as lane-parallel ring-to-ring copies (a match that overlaps itself reads its period from
-// in front of its start); every completed 16 KiB leave for HBM as whole lines, their Adler-32 taken on the way.  What
+// png_inflate_kernel: one wave per file.  A deflate stream is one serial chain of codes -- where a symbol begins is known
+// only when the one before it has been read -- but what WOULD be read from a bit position does not depend on the chain.
+// So the lanes guess: in a span of 256 stream bits every lane looks up, for four bit positions, the symbol that would
+// begin there (a literal, or a match with its extra bits, distance code and extra bits: two table reads from LDS, 10 and 9
+// bits wide, built in the kernel for every block), and the serial part shrinks to following the symbols' lengths from the
+// span's first bit: one v_readlane, an add, a min and a bit set per symbol, all scalar.  The guesses on that chain are the
+// stream's symbols; their literals enter the ring at once, their matches in order.  What the tables do not hold is done as
+// before: a canonical code is decoded by its definition with the lanes as the 15 possible lengths -- lane L holds the first
+// code of length L, how many there are and where their symbols start in the sorted symbol list; it takes the first L bits
+// and tests `bits - first < count`; the one lane that answers yes (a prefix code: at most one can) names the length -- and
+// the walk outside the spans (block headers, code-length codes, the image's last bytes, everything behind them) is
+// wave-uniform scalar code over a bit buffer fed from a register of stream dwords.  Output bytes go into a 32 KiB ring in
+// LDS -- deflate's window -- matches as lane-parallel ring-to-ring copies (a match that overlaps itself reads its period
+// from in front of its start); every completed 16 KiB leave for HBM as whole lines, their Adler-32 taken on the way.  What
 // follows the image's last byte is read as far as zlib reads it in the call that delivers the last row (see the kernel).
 //
 // png_unfilter_kernel: one wave per file, 64 rows at a time as a wavefront (lane k is one byte behind lane k - 1, whose
@@ -38,9 +41,20 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {  // lane i <- lane i
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
 }
 
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr int kSpanRegs = 4, kSpanBits = 64 * kSpanRegs;  // symbols a lane tries per span; stream bits a span covers
 constexpr int kLitBits = 10, kDistBits = 9;  // direct lookup tables in LDS: codes of up to this many bits
 
 constexpr int kMaxLit = 288, kMaxDist = 32, kMaxCodes = kMaxLit + kMaxDist;
@@ -54,7 +68,7 @@ __constant__ uint8_t c_cl_order[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 struct BitsLsb {
   const uint32_t* words;
   uint32_t nwords;    // dwords that exist (the upload pads every stream with zeros)
-  uint32_t base;      // `cur` holds dwords base .. base + 63, `nxt` the 64 behind them
+  uint32_t base;      // `cur` holds dwords base .. base + 63, `nxt` base + 32 .. base + 95 (the load of a later `cur`)
   uint32_t wpos;      // next dword to enter the bit buffer
   uint32_t cur, nxt;  // (per lane)
   uint64_t acc;
@@ -69,20 +83,32 @@ struct BitsLsb {
     acc = 0;
     n = 0;
     cur = load64(at);
-    nxt = load64(at + 64u);
+    nxt = load64(at + 32u);
+  }
+  // `cur` moves on by 32 dwords.  Every bit still in the buffer stays inside it (34: two dwords of them at most), which is
+  // what lets the span decoder below pick the walk up from `cur` at any time.
+  __device__ __forceinline__ void advance() {
+    cur = nxt;
+    base += 32u;
+    nxt = load64(base + 32u);
   }
   __device__ __forceinline__ void fill() {  // >= 33 bits afterwards
     if (n <= 32) {
-      if (wpos - base == 64u) {
-        cur = nxt;
-        base += 64u;
-        nxt = load64(base + 64u);
-      }
+      if (wpos - base >= 34u) advance();
       const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(wpos - base));
       acc |= (uint64_t)w << n;
       ++wpos;
       n += 32;
     }
+  }
+  // the walk's position in bits from the start of `cur`, and the buffer set up again at such a position (< 63 * 32)
+  __device__ __forceinline__ int rel_pos() const { return (int)(wpos - base) * 32 - n; }
+  __device__ __forceinline__ void restart_at(int rel) {
+    const int r = rel >> 5, b = rel & 31;
+    acc = (uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)cur, r) >> b);
+    n = 32 - b;
+    wpos = base + (uint32_t)r + 1u;
+    fill();
   }
   __device__ __forceinline__ uint32_t peek() const { return (uint32_t)acc; }
   __device__ __forceinline__ void drop(int k) {
@@ -128,15 +154,45 @@ struct BuiltCode {
   bool ok;
 };
 // With `table`: also the direct lookup of the codes of up to `tbits` bits -- entry [the next tbits bits of the stream] =
-// symbol << 4 | length, 0 where a longer code begins (the lanes decode those).
+// what the symbol says (table_entry), 0 where a longer code begins (the lanes decode those).
+// An entry: bits 0-3 the code's length, 4-7 the number of extra bits behind it, 8-23 the value (a literal, or what the extra
+// bits are added to: a match's length from 3, its distance from 1), bit 24: a match's length, bit 31: no literal, length or
+// distance -- the end of the block, a symbol that must not occur, or (kLongCode, the length 0) a code the table does not hold.
+constexpr uint32_t kMatchBit = 1u << 24, kHaltBit = 1u << 31, kLongCode = kHaltBit;
+__device__ __forceinline__ uint32_t table_entry(uint32_t sym, int L, bool distance) {
+  uint32_t eb = 0, value = sym, flags = 0;
+  if (distance) {
+    if (sym >= 30u) {
+      flags = kHaltBit;  // "invalid distance code"
+    } else if (sym < 4u) {
+      value = 1u + sym;
+    } else {
+      eb = (sym >> 1) - 1u;
+      value = 1u + ((2u + (sym & 1u)) << eb);
+    }
+  } else if (sym == 256u || sym > 285u) {
+    flags = kHaltBit;  // the end of the block; 286, 287: "invalid literal/length code"
+    value = 0;
+  } else if (sym > 256u) {
+    const uint32_t l = sym - 257u;
+    flags = kMatchBit;
+    if (l < 8u) {
+      value = 3u + l;
+    } else if (l == 28u) {
+      value = 258u;
+    } else {
+      eb = (l >> 2) - 1u;
+      value = 3u + ((4u + (l & 3u)) << eb);
+    }
+  }
+  return (uint32_t)L | (eb << 4) | (value << 8) | flags;
+}
 template <int REGS>
 __device__ __attribute__((noinline)) BuiltCode build_code(const lds_u8* lens, int nsym, lds_u16* sorted, bool allow_lone,
-                                                          lds_u16* table, int tbits) {
+                                                          lds_u32* table, int tbits, bool distance) {
   const int lane = threadIdx.x;
-  if (table) {
-    lds_u32* tw = (lds_u32*)table;
-    for (int i = lane; i < (1 << tbits) / 2; i += 64) tw[i] = 0u;
-  }
+  if (table)
+    for (int i = lane; i < (1 << tbits); i += 64) table[i] = kLongCode;
   uint32_t len_r[REGS];
   int pos_r[REGS];
 #pragma unroll
@@ -159,7 +215,7 @@ __device__ __attribute__((noinline)) BuiltCode build_code(const lds_u8* lens, in
         pos_r[r] = offs + n + below;
         if (table && L <= tbits) {  // (every lane in here has a code of this length: the same number of entries each)
           const uint32_t rev = __builtin_bitreverse32((uint32_t)(code + n + below)) >> (32 - L);
-          const uint16_t e = (uint16_t)(((r * 64 + lane) << 4) | L);
+          const uint32_t e = table_entry((uint32_t)(r * 64 + lane), L, distance);
           for (int k = 0; k < (1 << (tbits - L)); k++) table[rev | ((uint32_t)k << L)] = e;
         }
       }
@@ -218,6 +274,14 @@ __device__ __attribute__((noinline)) uint64_t ring_chunk(lds_u8* ring, uint8_t* 
   return na | (nb << 32);
 }
 
+// (a -DVSF_PNG_STATS build counts what the span decoder meets: tools/exp/png_stats.py)
+#ifdef VSF_PNG_STATS
+__device__ unsigned long long g_png_stats[16];
+#define PNG_STAT(i, v) do { if (lane == 0) atomicAdd(&g_png_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define PNG_STAT(i, v) do { } while (0)
+#endif
+
 struct PngArgs {
   const uint8_t* blob;
   size_t off_images, off_pieces, off_stream;
@@ -259,8 +323,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   __shared__ uint8_t lens[kMaxCodes + 8];
   __shared__ uint8_t cl_lens[32];
   __shared__ uint16_t sorted[kMaxCodes];
-  __shared__ __attribute__((aligned(4))) uint16_t lit_table[1 << kLitBits];
-  __shared__ __attribute__((aligned(4))) uint16_t dist_table[1 << kDistBits];
+  __shared__ uint32_t lit_table[1 << kLitBits];
+  __shared__ uint32_t dist_table[1 << kDistBits];
   const int lane = threadIdx.x;
   const int image = blockIdx.x;
   const DevImage im = load_image(a, image);
@@ -425,7 +489,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
       if (stop) break;
       __syncthreads();
-      const BuiltCode clb = build_code<1>((const lds_u8*)cl_lens, 19, (lds_u16*)sorted, false, nullptr, 0);
+      const BuiltCode clb = build_code<1>((const lds_u8*)cl_lens, 19, (lds_u16*)sorted, false, nullptr, 0, false);
       const LaneCode clc = clb.c;
       if (__builtin_amdgcn_readfirstlane((int)clb.ok) == 0) {  // inflate: "invalid code lengths set"
         bad = true;
@@ -486,8 +550,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
     }
     __syncthreads();
-    const BuiltCode lb = build_code<5>((const lds_u8*)lens, hlit, (lds_u16*)sorted, true, (lds_u16*)lit_table, kLitBits);
-    const BuiltCode db = build_code<1>((const lds_u8*)lens + hlit, hdist, (lds_u16*)sorted + kMaxLit, true, (lds_u16*)dist_table, kDistBits);
+    const BuiltCode lb = build_code<5>((const lds_u8*)lens, hlit, (lds_u16*)sorted, true, (lds_u32*)lit_table, kLitBits, false);
+    const BuiltCode db = build_code<1>((const lds_u8*)lens + hlit, hdist, (lds_u16*)sorted + kMaxLit, true, (lds_u32*)dist_table, kDistBits, true);
     const LaneCode lc = lb.c, dc = db.c;
     if (__builtin_amdgcn_readfirstlane((int)lb.ok) == 0 || __builtin_amdgcn_readfirstlane((int)db.ok) == 0) {  // inflate: "invalid literal/lengths set", "invalid distances set"
       bad = true;
@@ -522,50 +586,249 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         int budget = (int)min(br.left, (int64_t)(1 << 30));
         const int budget0 = budget;
         int room = (int)min(expected - pos - (uint32_t)npend, 1u << 30);
+        bool spans = true;
         while (true) {
-          // Runs of literals whose codes the table knows -- most symbols of a photograph -- in the tightest loop of all: no
-          // stream-buffer swap inside (it ends when one is due), nothing but the bit buffer, the counters and one table read.
-          {
-            uint64_t acc = br.acc;
-            int n = br.n, w = (int)(br.wpos - br.base);
-            while (true) {
-              if (n <= 32) {
-                if (w == 64) break;
-                acc |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)br.cur, w) << n;
-                ++w;
-                n += 32;
-              }
-              if (budget < 64) break;
-              const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lit_table[(uint32_t)acc & ((1u << kLitBits) - 1u)]);
-              const int L = (int)(e & 15u);
-              const uint32_t sym = e >> 4;
-              if (L == 0 || sym >= 256u || room <= 1 || npend >= 63) break;
-              acc >>= L;
-              n -= L;
-              budget -= L;
-              asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pend) : "s"(sym), "s"(npend));
-              ++npend;
-              --room;
+          // ---- Spans: 256 symbols at a time, four per lane.  Lane i reads the stream from bits i, 64 + i, 128 + i and 192 + i of
+          // the walk's position as if a symbol began there -- a literal, or a match with its extra bits, distance code and extra
+          // bits, all by way of the lookup tables -- and says how many bits that is; the walk then only has to follow those
+          // lengths from bit 0 (one v_readlane per symbol) to know which guesses began where a symbol begins.  Their literals go
+          // into the ring at once, their matches one after the other, each copied by the whole wave.  Anything else -- a code the
+          // tables do not hold, the end of the block, a match reaching in front of the data, the end of the image or of the
+          // input near -- ends the span in front of that symbol and is the business of the code further down.
+          if (spans && budget >= kSpanBits + 128 && room > kSpanBits) {
+            if (npend > 0) {
+              if (lane < npend) ring[(pos + lane) & M] = (uint8_t)pend;
+              pos += (uint32_t)npend;
+              npend = 0;
             }
-            br.acc = acc;
-            br.n = n;
-            br.wpos = br.base + (uint32_t)w;
+            int rel = br.rel_pos();
+            while (true) {
+              if (rel >= 1024) {
+                br.advance();
+                rel -= 1024;
+              }
+              if (budget < kSpanBits + 128 || room <= kSpanBits) break;
+              // every lane's view of the stream: 64 bits from each of its positions
+              const int r = rel >> 5;
+              const int t = (rel & 31) + lane;
+              uint32_t sel[2 * kSpanRegs + 1];
+              {
+                uint32_t w[2 * kSpanRegs + 3];
+#pragma unroll
+                for (int m = 0; m < 2 * kSpanRegs + 3; m++) w[m] = (uint32_t)__builtin_amdgcn_readlane((int)br.cur, r + m);
+#pragma unroll
+                for (int m = 0; m < 2 * kSpanRegs + 1; m++) sel[m] = t < 32 ? w[m] : t < 64 ? w[m + 1] : w[m + 2];
+              }
+              // (three passes, so that the eight table reads are two batches in flight and not eight round trips)
+              uint32_t view[kSpanRegs], high[kSpanRegs], ent[kSpanRegs], ent2[kSpanRegs], behind[kSpanRegs];
+              uint32_t len[kSpanRegs], dist[kSpanRegs], bits[kSpanRegs], hop[kSpanRegs], shift[kSpanRegs];
+              int match_mask[kSpanRegs];  // 0 / -1
+              uint64_t halts[kSpanRegs];
+#pragma unroll
+              for (int k = 0; k < kSpanRegs; k++) {
+                view[k] = __builtin_amdgcn_alignbit(sel[2 * k + 1], sel[2 * k], (uint32_t)t & 31u);
+                high[k] = __builtin_amdgcn_alignbit(sel[2 * k + 2], sel[2 * k + 1], (uint32_t)t & 31u);
+                ent[k] = lit_table[view[k] & ((1u << kLitBits) - 1u)];
+              }
+#pragma unroll
+              for (int k = 0; k < kSpanRegs; k++) {
+                const uint32_t L = ent[k] & 15u, eb = (ent[k] >> 4) & 15u;
+                len[k] = ((ent[k] >> 8) & 0xFFFFu) + __builtin_amdgcn_ubfe(view[k], L, eb);  // (a literal: its value)
+                shift[k] = L + eb;
+                behind[k] = __builtin_amdgcn_alignbit(high[k], view[k], shift[k]);
+                ent2[k] = dist_table[behind[k] & ((1u << kDistBits) - 1u)];
+              }
+#pragma unroll
+              for (int k = 0; k < kSpanRegs; k++) {
+                match_mask[k] = __builtin_amdgcn_sbfe((int)ent[k], 24, 1);
+                const uint32_t L2 = ent2[k] & 15u, eb2 = (ent2[k] >> 4) & 15u;
+                dist[k] = ((ent2[k] >> 8) & 0xFFFFu) + __builtin_amdgcn_ubfe(behind[k], L2, eb2);
+                bits[k] = shift[k] + ((L2 + eb2) & (uint32_t)match_mask[k]);
+                const bool halt = (int)(ent[k] | (ent2[k] & (uint32_t)match_mask[k])) < 0;
+                hop[k] = halt ? 64u : bits[k];
+                halts[k] = __builtin_amdgcn_ballot_w64(halt);
+              }
+              // the positions a symbol really begins at: register after register, from where the one before ended
+              uint64_t active[kSpanRegs];
+              int end = 0;
+              {
+                int entry = 0;
+                bool open = true;
+#pragma unroll
+                for (int k = 0; k < kSpanRegs; k++) {
+                  active[k] = 0ull;
+                  if (open) {
+                    uint64_t chain = 0ull;
+                    uint32_t q = (uint32_t)entry;
+                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(q));
+                    while (true) {
+                      do {  // (behind the register's end q stays 64: lane select 64 reads lane 0, bit 64 is bit 0 -- see below)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                          q = min(q + (uint32_t)__builtin_amdgcn_readlane((int)hop[k], (int)q), 64u);
+                          asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(q));
+                        }
+                      } while (q < 64u);
+                      if (entry != 0) chain &= ~1ull;
+                      const int last = 63 - __builtin_clzll(chain);
+                      if (!((halts[k] >> last) & 1ull)) {
+                        const int e = last + __builtin_amdgcn_readlane((int)bits[k], last);  // (>= 64)
+                        end = 64 * k + e;
+                        entry = e - 64;
+                        break;
+                      }
+                      // The walk has met a symbol the tables do not hold.  A literal with a long code -- the usual case -- is
+                      // decoded here, by the lanes, and entered where the tables' answer would be: the walk goes on.
+                      bool mended = false;
+                      if (((uint32_t)__builtin_amdgcn_readlane((int)ent[k], last) & 15u) == 0u) {
+                        int L;
+                        const uint32_t idx = decode_index((uint32_t)__builtin_amdgcn_readlane((int)view[k], last), lc, lane, &L);
+                        if (L != 0) {
+                          const uint32_t sym = lit_symbol(idx);
+                          if (sym < 256u) {
+                            asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %5, m0"
+                                : "+v"(len[k]), "+v"(bits[k]), "+v"(hop[k])
+                                : "s"(sym), "s"(last), "s"(L));
+                            halts[k] &= ~(1ull << last);
+                            q = (uint32_t)last;
+                            mended = true;
+                          }
+                        }
+                      }
+                      if (!mended) {
+                        end = 64 * k + last;
+                        open = false;
+                        break;
+                      }
+                    }
+                    active[k] = chain & ~halts[k];
+                  }
+                }
+              }
+              if (end == 0) break;  // (the symbol at the walk's position is one for the code below)
+              uint64_t matches[kSpanRegs], any_match = 0ull;
+#pragma unroll
+              for (int k = 0; k < kSpanRegs; k++) {
+                matches[k] = active[k] & __builtin_amdgcn_ballot_w64(match_mask[k] != 0);
+                any_match |= matches[k];
+              }
+              uint32_t offs[kSpanRegs], total = 0;
+              if (any_match == 0ull) {
+#pragma unroll
+                for (int k = 0; k < kSpanRegs; k++) {
+                  offs[k] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(active[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active[k], 0u));
+                  total += (uint32_t)__popcll(active[k]);
+                }
+              } else {
+                int mine[kSpanRegs];
+#pragma unroll
+                for (int k = 0; k < kSpanRegs; k++) {
+                  mine[k] = (active[k] >> lane) & 1ull ? (match_mask[k] ? (int)len[k] : 1) : 0;
+                  const int incl = wave_incl_scan(mine[k]);
+                  offs[k] = total + (uint32_t)(incl - mine[k]);
+                  total += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                }
+                // The span ends in front of a match that reaches in front of the data ("invalid distance too far back"), in front
+                // of one from so far back that its bytes share their places in the ring with the span's later ones, which are
+                // written first (at the full distance of 32 KiB a byte's place is its source's: no harm), and where it would
+                // leave more than 8 KiB in the ring for the next flush.
+                bool cut = false, none = false;
+#pragma unroll
+                for (int k = 0; k < kSpanRegs; k++) {
+                  if (cut) {
+                    active[k] = 0ull;
+                    matches[k] = 0ull;
+                  } else {
+                    const uint64_t far = matches[k] & __builtin_amdgcn_ballot_w64(dist[k] > pos + offs[k] || (dist[k] != (uint32_t)kWindow && dist[k] + (total - offs[k]) > (uint32_t)kWindow) ||
+                                                                                  offs[k] + (uint32_t)mine[k] > 8192u);
+                    if (far != 0ull) {
+                      const int at = __builtin_ctzll(far);
+                      const uint64_t keep = (1ull << at) - 1ull;
+                      active[k] &= keep;
+                      matches[k] &= keep;
+                      end = 64 * k + at;
+                      total = (uint32_t)__builtin_amdgcn_readlane((int)offs[k], at);
+                      cut = true;
+                      none = end == 0;
+                    }
+                  }
+                }
+                if (none) break;
+                if ((int)total >= room) {  // the image ends inside this span: symbol by symbol from here on
+                  spans = false;
+                  break;
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < kSpanRegs; k++)
+                if (((active[k] >> lane) & 1ull) && !match_mask[k]) ring[(pos + offs[k]) & M] = (uint8_t)len[k];
+#pragma unroll
+              for (int k = 0; k < kSpanRegs; k++) {
+                uint64_t todo = matches[k];
+                while (todo != 0ull) {
+                  const int at_lane = __builtin_ctzll(todo);
+                  todo &= todo - 1ull;
+                  const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)len[k], at_lane), mdist = (uint32_t)__builtin_amdgcn_readlane((int)dist[k], at_lane);
+                  const uint32_t at = pos + (uint32_t)__builtin_amdgcn_readlane((int)offs[k], at_lane);
+                  if (mdist >= mlen) {
+                    for (uint32_t i = lane; i < mlen; i += 64) {
+                      const uint8_t bt = ring[(at - mdist + i) & M];
+                      ring[(at + i) & M] = bt;
+                    }
+                  } else {  // the match overlaps itself: byte i repeats byte i mod dist (all of them in front of its start)
+                    const float rcp = 1.0f / (float)mdist;
+                    for (uint32_t i = lane; i < mlen; i += 64) {
+                      const uint32_t qq = (uint32_t)((float)i * rcp);
+                      int rr = (int)i - (int)(qq * mdist);
+                      if (rr < 0) rr += (int)mdist;
+                      if (rr >= (int)mdist) rr -= (int)mdist;
+                      const uint8_t bt = ring[(at - mdist + (uint32_t)rr) & M];
+                      ring[(at + i) & M] = bt;
+                    }
+                  }
+                }
+              }
+#ifdef VSF_PNG_STATS
+              PNG_STAT(0, 1);
+              PNG_STAT(1, total);
+              PNG_STAT(2, end);
+              {
+                int nt = 0, nm = 0;
+                for (int k = 0; k < kSpanRegs; k++) {
+                  nt += __popcll(active[k]);
+                  nm += __popcll(active[k] & __builtin_amdgcn_ballot_w64(match_mask[k] != 0));
+                }
+                PNG_STAT(3, nt);
+                PNG_STAT(4, nm);
+                PNG_STAT(5, end < kSpanBits ? 1 : 0);
+              }
+#endif
+              pos += total;
+              room -= (int)total;
+              budget -= end;
+              rel += end;
+              flush_chunks();
+            }
+            PNG_STAT(6, 1);
+            br.restart_at(rel);
           }
+          PNG_STAT(8, 1);
           br.fill();
           if (budget < 64) break;  // (64 bits: more than a length code, a distance code and their extra bits)
-          // the next ten bits look the symbol up directly; a longer code (entry 0) is decoded by the lanes
-          const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lit_table[br.peek() & ((1u << kLitBits) - 1u)]);
+          // one symbol: the next ten bits look it up directly; a longer code (entry 0) is decoded by the lanes
+          uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit_table[br.peek() & ((1u << kLitBits) - 1u)]);
           int L = (int)(e & 15u);
-          uint32_t sym = e >> 4;
           if (L == 0) {
             const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
             if (L == 0) break;
-            sym = lit_symbol(idx);
+            e = table_entry(lit_symbol(idx), L, false);
           }
-          if (sym < 256u) {
+          if ((int)e < 0) break;  // the end of the block, or a symbol that must not occur: the walk below
+          if ((e & kMatchBit) == 0u) {
             br.acc >>= L;
             br.n -= L;
             budget -= L;
+            const uint32_t sym = (e >> 8) & 0xFFu;
             asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pend) : "s"(sym), "s"(npend));
             ++npend;
             if (--room == 0) break;
@@ -577,47 +840,34 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
             }
             continue;
           }
-          if (sym == 256u || sym > 285u) break;
           // a match: length code (+ extra bits), distance code (+ extra bits)
           br.acc >>= L;
           br.n -= L;
           budget -= L;
-          const uint32_t l = sym - 257u;
-          uint32_t len = 3u + l;
-          if (l >= 8u) {
-            if (l == 28u) {
-              len = 258u;
-            } else {
-              const int eb = (int)(l >> 2) - 1;
-              len = 3u + ((4u + (l & 3u)) << eb) + ((uint32_t)br.acc & ((1u << eb) - 1u));
-              br.acc >>= eb;
-              br.n -= eb;
-              budget -= eb;
-            }
-          }
+          const int eb = (int)((e >> 4) & 15u);
+          const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)br.acc & ((1u << eb) - 1u));
+          br.acc >>= eb;
+          br.n -= eb;
+          budget -= eb;
           br.fill();
-          const uint32_t e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dist_table[br.peek() & ((1u << kDistBits) - 1u)]);
+          uint32_t e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dist_table[br.peek() & ((1u << kDistBits) - 1u)]);
           int L2 = (int)(e2 & 15u);
-          uint32_t dsym = e2 >> 4;
           if (L2 == 0) {
             const uint32_t idx2 = decode_index(br.peek(), dc, lane, &L2);
-            dsym = (uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u));
+            e2 = table_entry((uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u)), L2, true);
           }
-          if (L2 == 0 || dsym > 29u) {  // "invalid distance code" (the bits were there: budget)
+          if (L2 == 0 || (int)e2 < 0) {  // "invalid distance code" (the bits were there: budget)
             bad = true;
             break;
           }
           br.acc >>= L2;
           br.n -= L2;
           budget -= L2;
-          uint32_t dist = 1u + dsym;
-          if (dsym >= 4u) {
-            const int eb = (int)(dsym >> 1) - 1;
-            dist = 1u + ((2u + (dsym & 1u)) << eb) + ((uint32_t)br.acc & ((1u << eb) - 1u));
-            br.acc >>= eb;
-            br.n -= eb;
-            budget -= eb;
-          }
+          const int eb2 = (int)((e2 >> 4) & 15u);
+          const uint32_t dist = ((e2 >> 8) & 0xFFFFu) + ((uint32_t)br.acc & ((1u << eb2) - 1u));
+          br.acc >>= eb2;
+          br.n -= eb2;
+          budget -= eb2;
           if (npend > 0) {  // the waiting literals come first
             if (lane < npend) ring[(pos + lane) & M] = (uint8_t)pend;
             pos += (uint32_t)npend;
@@ -845,3 +1095,13 @@ void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_
   hipLaunchKernelGGL(png_inflate_kernel, dim3(n), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_unfilter_kernel, dim3(n), dim3(64), 0, s, a);
 }
+
+#ifdef VSF_PNG_STATS
+extern "C" int vsf_debug_png_stats(unsigned long long* out16, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_png_stats), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_png_stats), 16 * sizeof(unsigned long long));
+}
+#endif
