@@ -54,7 +54,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-constexpr int kSpanRegs = 4, kSpanBits = 64 * kSpanRegs;  // symbols a lane tries per span; stream bits a span covers
+#ifndef VSF_PNG_SPAN_REGS
+#define VSF_PNG_SPAN_REGS 4
+#endif
+constexpr int kSpanRegs = VSF_PNG_SPAN_REGS, kSpanBits = 64 * kSpanRegs;  // symbols a lane tries per span; stream bits a span covers
 constexpr int kLitBits = 10, kDistBits = 9;  // direct lookup tables in LDS: codes of up to this many bits
 
 constexpr int kMaxLit = 288, kMaxDist = 32, kMaxCodes = kMaxLit + kMaxDist;
