@@ -4,7 +4,8 @@ stream is worth): files written by PIL at every compression level and by tests/p
 deflate block type (stored, fixed, dynamic, run-length matches of distance 1, long-distance matches), IDAT payloads cut
 into pieces, 1 / 2 / 4 / 8 / 16-bit gray and gray + alpha; what libpng refuses is refused (damaged critical chunks, unknown
 critical chunks, wrong size), what it only warns about is read (damaged ancillary chunks, a wrong Adler-32, trailing
-garbage); damaged compressed data never faults and is flagged exactly when zlib gives up before the image's last byte."""
+garbage); damaged compressed data never faults and is refused exactly when the real libpng, driven as cv::imdecode drives
+it (tests/png_ref.py), refuses the file."""
 import io
 import sys
 import zlib
@@ -221,21 +222,41 @@ def test_what_libpng_refuses_is_refused_and_what_it_warns_about_is_read(capi, ct
         assert st == capi.VSF_OK and sync == capi.VSF_OK
         for i, f in enumerate(readable):
             np.testing.assert_array_equal(got[i], img, err_msg="file %d" % i)
-        # (PIL's own chunk reader is stricter than libpng here -- it refuses a damaged ancillary chunk -- so these four are
-        # held against libpng's documented behaviour: png_crc_error warns for ancillary chunks, png_read_finish_IDAT reads
-        # what is left of the stream without a row to fill and reports errors as benign)
+        # (PIL's own chunk reader is stricter than libpng here -- it refuses a damaged ancillary chunk -- so these are held
+        # against the real libpng, driven as cv::imdecode drives it)
+        import png_ref
+        if png_ref.available():
+            for i, f in enumerate(readable):
+                ref_status, ref_img, _ = png_ref.imdecode_gray(f, w, h)
+                assert ref_status == 0, (i, png_ref.last_error())
+                np.testing.assert_array_equal(ref_img, img)
+            for f in (pc.gray8(img, bad_idat_crc=True), good[:-12], good[:40], b"\x89PNG\r\n\x1a\n",
+                      pc.gray8(img, extra_before=[pc.chunk(b"ABCD", b"xyz")]), pc.replace_idat(good, wrong_adler)):
+                assert png_ref.imdecode_gray(f, w, h)[0] != 0
+            # a stream cut inside its last bytes: every pixel is there, png_read_end still fails ("Not enough image data")
+            for cut in (1, 3, 4, 5, 9):
+                f = pc.replace_idat(good, pc.idat_stream(good)[:-cut])
+                assert png_ref.imdecode_gray(f, w, h)[0] == 2 and png_ref.last_error() == "Not enough image data"
+                assert status(f) == capi.VSF_OK
+                with pytest.raises(capi.VsfError) as ei:
+                    c.sync()
+                assert ei.value.status == capi.VSF_ERR_INVALID_ARG
+                assert c.sync() == capi.VSF_OK
 
 
-def test_damaged_compressed_data_never_faults_and_is_flagged_as_zlib_flags_it(capi):
+def test_damaged_compressed_data_never_faults_and_is_refused_as_libpng_refuses_it(capi):
     """400 files whose compressed data is damaged (bit flips, cuts, zeroed runs, insertions -- anywhere, or only near the
     end), continues behind the image's last byte (further blocks, garbage) or both, with the IDAT payload cut into chunks
-    of various sizes.  For each: zlib, fed as libpng feeds it (tests/png_craft.py zlib_reference), either delivers the
-    image's bytes -- then the decode must match (or, for a filter type above 4, be flagged) -- or gives up: then the flag
-    must be set.  That includes everything zlib still reads behind the last byte in the call that delivers it: the
-    Adler-32, block headers, code tables."""
+    of various sizes.  The reference is the real libpng driven as cv::imdecode drives it (tests/png_ref.py: png_read_image
+    and png_read_end): it either delivers an image -- then the decode must be those bytes -- or refuses the file
+    (cv::imdecode returns an empty Mat): then the flag must be set.  That includes everything zlib still reads behind
+    the last byte in the call that delivers it (the Adler-32, block headers, code tables) and the drain of png_read_end:
+    a stream whose IDAT data runs out before it has ended is refused although every pixel was there."""
+    import png_ref
+    if not png_ref.available():
+        pytest.skip("no libpng16.so.16 to build tests/cpp/png_ref.c against")
     w, h = 160, 120
     rng = np.random.Generator(np.random.PCG64(2026))
-    expected = (w + 1) * h
     flagged = clean = 0
     with capi.Context(capi.default_params(w, h, max_images=2, nfeatures=100)) as c:
         dev = torch.device("cuda", 0)
@@ -247,7 +268,7 @@ def test_damaged_compressed_data_never_faults_and_is_flagged_as_zlib_flags_it(ca
             extra = [0, 0, 1, 700, 40000][int(rng.integers(5))]   # the stream goes on behind the image ("Too much image data")
             tail_bytes = bytes(rng.integers(0, 256, extra, dtype=np.uint8))
             stream = pc.deflate(rows + tail_bytes, [6, 6, 6, 6, 0, 9][k], strategy)
-            how = int(rng.integers(4))
+            how = int(rng.integers(5))
             if how == 0:
                 stream = pc.mutate_stream(stream, rng)
             elif how == 1:  # damage near the end only
@@ -255,28 +276,28 @@ def test_damaged_compressed_data_never_faults_and_is_flagged_as_zlib_flags_it(ca
                 stream = stream[:cut] + pc.mutate_stream(b"xx" + stream[cut:], rng)[2:]
             elif how == 2:
                 stream = stream + bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+            elif how == 3:  # cut inside the last bytes: the end-of-block code, the check value
+                stream = stream[:max(2, len(stream) - int(rng.integers(1, 12)))]
             if len(stream) < 8:
                 continue
             piece = [None, len(stream) - 4, len(stream) - 7, 100, 5000, 8192, 9000][int(rng.integers(7))]
             f = pc.write_png(None, w, h, 8, 0, stream=stream, idat_piece=piece)
-            ref = pc.zlib_reference(pc.idat_pieces(f), expected)
+            ref_status, ref_img, _ = png_ref.imdecode_gray(f, w, h)
             d = torch.zeros((h, w), dtype=torch.uint8, device=dev)
             st = c.png_decode_gray_batch([f], w, h, d.data_ptr(), w * h, w, allow_status=(capi.VSF_ERR_INVALID_ARG,))
             if st != capi.VSF_OK:   # the host refused it (a zlib header that no longer passes its checks)
-                hdr = pc.idat_stream(f)[:2]
-                assert (hdr[0] & 15) != 8 or (hdr[0] >> 4) > 7 or (hdr[1] & 32) or ((hdr[0] << 8) | hdr[1]) % 31, it
+                assert ref_status != 0, "file %d: refused by the host, read by libpng" % it
                 continue
             try:
                 sync = c.sync()
             except capi.VsfError as e:
                 sync = e.status
-            got_rows = None if ref is None else np.frombuffer(ref, np.uint8).reshape(h, w + 1)
-            if ref is None or got_rows[:, 0].max() > 4:
-                assert sync == capi.VSF_ERR_INVALID_ARG, "file %d: broken data not flagged" % it
+            if ref_status != 0:
+                assert sync == capi.VSF_ERR_INVALID_ARG, "file %d: not flagged; libpng: %s" % (it, png_ref.last_error())
                 flagged += 1
             else:
-                assert sync == capi.VSF_OK, "file %d: flagged although zlib delivers the image" % it
-                np.testing.assert_array_equal(d.cpu().numpy(), pil_unfilter(got_rows, w, h), err_msg="file %d" % it)
+                assert sync == capi.VSF_OK, "file %d: flagged although libpng delivers the image" % it
+                np.testing.assert_array_equal(d.cpu().numpy(), ref_img, err_msg="file %d" % it)
                 clean += 1
     assert flagged > 60 and clean > 60, (flagged, clean)
 

@@ -6,7 +6,9 @@ cv::imdecode at slam_frontend_main.cc:98-100) and of the committed fixtures.
   and the GPU test's reference for them is a real third party's output.
 * `make asan` builds the parser with -fsanitize=address,undefined; a child process runs the fixtures, hand-made refusals and
   3000 seeded mutations (bit flips anywhere, cuts, chunk lengths rewritten, chunks reordered / duplicated / dropped) through
-  vsf_png_plan + vsf_png_fill and must exit cleanly."""
+  vsf_png_plan + vsf_png_fill and must exit cleanly; 3000 more, one file at a time, are held against the real libpng driven
+  as cv::imdecode drives it (tests/png_ref.py): what it reads the parser accepts, what the parser accepts with the compressed
+  data whole it reads."""
 import os
 import subprocess
 import sys
@@ -183,6 +185,29 @@ for it in range(3000):
     assert st in (0, 1, 4), st
     ok += st == 0
     bad += st != 0
+# The same kinds of damage, one file at a time, held against the real libpng driven as cv::imdecode drives it
+# (tests/png_ref.py): what libpng reads the parser must accept, and what the parser accepts with its compressed data whole
+# libpng must read (a damaged stream is the device's to judge: tests/test_gpu_png.py, tools/stress_png.py).
+import png_ref
+agree = 0
+if png_ref.available():
+    for it in range(3000):
+        name = names[int(rng.integers(len(names)))]
+        h, w = expected[name].shape
+        f = mutate(files[name], rng)
+        st, _ = check([f], w, h)
+        ref, _, _ = png_ref.imdecode_gray(f, w, h)
+        if ref == 0:
+            assert st == 0, (it, name, st, "libpng reads it")
+        if st == 0:
+            try:
+                whole = zlib.decompress(pc.idat_stream(f)) == zlib.decompress(pc.idat_stream(files[name]))
+            except zlib.error:
+                whole = False
+            if whole:
+                assert ref == 0, (it, name, ref, png_ref.last_error())
+                agree += 1
+    print("libpng %s agrees on %d accepted files" % (png_ref.version(), agree))
 for junk in (b"", b"\x89", b"\x89PNG\r\n\x1a\n", b"\x89PNG\r\n\x1a\n" + bytes(40), bytes(100)):
     assert check([junk], 8, 8)[0] == 1
 print("done ok=%d refused=%d" % (ok, bad))
@@ -204,7 +229,9 @@ def test_png_host_parser_under_asan_and_ubsan(tmp_path):
     p = subprocess.run([sys.executable, str(script), str(LIB), str(GOLD), str(Path(__file__).resolve().parent)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-4000:])
-    assert p.stdout.strip().startswith("done")
+    assert p.stdout.strip().splitlines()[-1].startswith("done")
+    if "agrees on" in p.stdout:  # (the real libpng was there to be asked)
+        assert int(p.stdout.split("agrees on")[1].split()[0]) > 300, p.stdout
     ok = int(p.stdout.split("ok=")[1].split()[0])
     refused = int(p.stdout.split("refused=")[1].split()[0])
     assert ok > 400 and refused > 500, (ok, refused)

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Randomised stress of vsf_png_decode_gray_batch (run by hand on a GPU box): random sizes, bit depths (1 / 2 / 4 / 8 / 16, gray
 and gray + alpha), row filters, zlib strategies and levels, IDAT chunkings, and -- for two files in three -- damage: bit flips,
-cuts, zeroed runs and insertions in the compressed data, data that goes on behind the image, trailing garbage.
+cuts, zeroed runs and insertions in the compressed data, data that goes on behind the image, trailing garbage, streams cut
+inside their last bytes.
 
-Reference for every file: zlib itself, fed as libpng feeds it (tests/png_craft.py zlib_reference: at most 8192 bytes of one
-chunk at a time, nothing after the image's last row is complete), then the filters and the gray conversion in numpy; for
-undamaged files PIL (libpng) as well.  A file must be flagged (vsf_sync -> VSF_ERR_INVALID_ARG) exactly when that reference
-has no image for it, and decode to the reference's bytes otherwise.
+Reference for every file: the real libpng, driven as cv::imdecode(IMREAD_GRAYSCALE) drives it (tests/png_ref.py:
+png_read_info ... png_read_image, png_read_end); for undamaged files PIL as well.  A file must be flagged (vsf_sync ->
+VSF_ERR_INVALID_ARG, or refused by the host parser) exactly when libpng refuses it, and decode to libpng's bytes otherwise.
     python tools/stress_png.py [n_cases] [seed]"""
 import io
 import sys
@@ -21,7 +21,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import png_craft as pc  # noqa: E402
-from test_png_host import gray_from_rows, unfilter_numpy  # noqa: E402
+import png_ref  # noqa: E402
 from vision_slam_frontend_amd import capi  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -51,8 +51,8 @@ for c in range(n_cases):
     strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED][int(rng.integers(5))]
     level = int(rng.choice([0, 1, 6, 9]))
     rows = pc.filter_rows(raw, bpp, filters)
-    how = int(rng.integers(6))
-    extra = bytes(rng.integers(0, 256, [0, 0, 0, 1, 500, 70000][int(rng.integers(6))], dtype=np.uint8)) if how >= 3 else b""
+    how = int(rng.integers(7))
+    extra = bytes(rng.integers(0, 256, [0, 0, 0, 1, 500, 70000][int(rng.integers(6))], dtype=np.uint8)) if how in (3, 4, 5) else b""
     stream = pc.deflate(rows + extra, level, strategy)
     if how == 1 or how == 4:
         stream = pc.mutate_stream(stream, rng)
@@ -61,29 +61,28 @@ for c in range(n_cases):
         stream = stream[:cut] + pc.mutate_stream(b"xx" + stream[cut:], rng)[2:]
     elif how == 5:
         stream += bytes(rng.integers(0, 256, int(rng.integers(1, 30)), dtype=np.uint8))
+    elif how == 6:  # cut inside the last bytes: the end-of-block code, the check value
+        stream = stream[:max(2, len(stream) - int(rng.integers(1, 12)))]
     if len(stream) < 8:
         continue
     piece = [None, max(1, len(stream) - 4), max(1, len(stream) - 9), int(rng.integers(1, 400)) if w * h < 20000 else 3000, 8192, 8193, 20000][int(rng.integers(7))]
     f = pc.write_png(None, w, h, depth, ctype, stream=stream, idat_piece=piece)
-    expected = (row_bytes + 1) * h
-    ref = pc.zlib_reference(pc.idat_pieces(f), expected)
-    want = None
-    if ref is not None and np.frombuffer(ref, np.uint8).reshape(h, row_bytes + 1)[:, 0].max() <= 4:
-        want = gray_from_rows(unfilter_numpy(ref, h, row_bytes, bpp), w, depth, channels)
-        if how == 0:  # an undamaged file: libpng itself agrees with the reference
-            im = Image.open(io.BytesIO(f))
-            im.load()
-            a = np.asarray(im)
-            pil = (a.astype(np.uint32) >> 8).astype(np.uint8) if im.mode.startswith("I") else \
-                a[:, :, 0] if a.ndim == 3 else (a.astype(np.uint8) * 255 if im.mode == "1" else a)
-            assert np.array_equal(pil, want), "PIL disagrees with the reference decode (case %d)" % c
+    ref_status, want, _ = png_ref.imdecode_gray(f, w, h)
+    if ref_status != 0:
+        want = None
+    elif how == 0:  # an undamaged file: PIL agrees
+        im = Image.open(io.BytesIO(f))
+        im.load()
+        a = np.asarray(im)
+        pil = (a.astype(np.uint32) >> 8).astype(np.uint8) if im.mode.startswith("I") else \
+            a[:, :, 0] if a.ndim == 3 else (a.astype(np.uint8) * 255 if im.mode == "1" else a)
+        assert np.array_equal(pil, want), "PIL disagrees with libpng (case %d)" % c
     pitch = (w + 3) // 4 * 4
     d = torch.full((h, pitch), 0x5A, dtype=torch.uint8, device=dev)
     st = ctx.png_decode_gray_batch([f], w, h, d.data_ptr(), h * pitch, pitch, allow_status=(capi.VSF_ERR_INVALID_ARG,))
-    if st != capi.VSF_OK:  # the host refused it: only a zlib header that fails its checks can do that here
-        hdr = pc.idat_stream(f)[:2]
-        ok = (hdr[0] & 15) != 8 or (hdr[0] >> 4) > 7 or bool(hdr[1] & 32) or ((hdr[0] << 8) | hdr[1]) % 31 != 0
-        note = "refused by the host"
+    if st != capi.VSF_OK:  # the host refused it
+        ok = want is None
+        note = "refused by the host" if ok else "REFUSED BY THE HOST, READ BY LIBPNG"
     else:
         try:
             sync = ctx.sync()
@@ -102,5 +101,5 @@ for c in range(n_cases):
         print("case %4d %3dx%-3d depth %2d type %d level %d strategy %d piece %s damage %d: %s" %
               (c, w, h, depth, ctype, level, strategy, piece, how, note), flush=True)
 ctx.close()
-print("decoded and equal: %d, flagged as zlib flags them: %d, mismatches: %d of %d" % (clean, flagged, bad, n_cases))
+print("libpng %s; decoded and equal: %d, flagged where libpng refuses: %d, mismatches: %d of %d" % (png_ref.version(), clean, flagged, bad, n_cases))
 sys.exit(1 if bad else 0)

@@ -312,15 +312,46 @@ __device__ __forceinline__ DevImage load_image(const PngArgs& a, int image) {
   return im;
 }
 
+// The end (inside the zlib stream) of the piece of input that holds byte b: libpng hands zlib at most 8192 bytes of ONE chunk.
+__device__ __attribute__((noinline)) uint32_t piece_end_of(const uint8_t* blob, size_t off_pieces, uint32_t piece_first, uint32_t piece_count,
+                                                          uint32_t stream_len, uint32_t b) {
+  const uint32_t* pe = reinterpret_cast<const uint32_t*>(blob + off_pieces) + piece_first;
+  uint32_t begin = 0, end = stream_len;
+  for (uint32_t k = 0; k < piece_count; k++) {
+    const uint32_t e = in_constant(pe)[k];
+    if (b < e) {
+      end = e;
+      break;
+    }
+    begin = e;
+  }
+  return min(min(end, begin + ((b - begin) / kIdatReadSize + 1u) * kIdatReadSize), stream_len);
+}
+// Where the drain (see below) may read to when it begins at bit bp: the end of the piece at hand, or -- zlib having taken all
+// of that (`exhausted`, or the position says so) -- of the piece libpng fetches next (bit 63 of the answer: such a piece);
+// 0: there is nothing left to fetch.
+__device__ __attribute__((noinline)) uint64_t drain_limit(const uint8_t* blob, size_t off_pieces, uint32_t piece_first, uint32_t piece_count,
+                                                          uint32_t stream_len, uint64_t bp, bool exhausted) {
+  const uint32_t pulled = (uint32_t)((bp + 7u) / 8u);  // bytes zlib has taken
+  const uint32_t here = piece_end_of(blob, off_pieces, piece_first, piece_count, stream_len, pulled ? pulled - 1u : 0u);
+  if (!exhausted && pulled < here) return (uint64_t)here * 8u;
+  if (here >= stream_len) return 0ull;
+  return (uint64_t)piece_end_of(blob, off_pieces, piece_first, piece_count, stream_len, here) * 8u | (1ull << 63);
+}
+
 // What happens behind the image's last byte is zlib's business too.  libpng asks zlib for the last row with whatever is
 // left of the CURRENT piece of input (at most 8192 bytes of one IDAT chunk: PNG_IDAT_READ_SIZE); having written the last
 // byte, inflate() goes on reading symbols that need no room in the output -- an end-of-block code, block headers, code
 // tables, empty stored blocks, the Adler-32 check -- and an error it meets there fails the read (png_error), exactly as
 // in front of the last byte.  It stops without an error at the first symbol that needs room (after decoding a match's
-// length and distance codes), at the end of that piece of input, or at the end of the stream.  The remainder of the file
-// is read later with no row to fill and errors there are warnings (png_read_finish_IDAT).  So the walk below has two
-// modes: in front of the last byte running out of input is an error ("Not enough image data"); behind it the input ends at
-// the piece boundary and running out ends the walk without one.
+// length and distance codes), at the end of that piece of input, or at the end of the stream.  If the stream has not
+// ended, cv::imdecode's png_read_end then DRAINS it (png_read_finish_IDAT: the rest of the compressed data is inflated into
+// a scratch buffer piece after piece): what zlib finds wrong there is a warning, and so is a stream that goes on behind
+// the image -- but IDAT data that runs out before the stream has ended is png_error("Not enough image data"): a file cut
+// inside its last bytes, the check value included, is refused although every pixel was there.  (One way out: a piece
+// fetched for the drain that yields no output and no end lets libpng's loop finish quietly.)  So the walk below has three
+// modes: in front of the last byte running out of input is an error; behind it the input ends at the piece boundary and
+// running out starts the drain; in the drain nothing is written, errors end the walk, and running out is an error again.
 __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t ring[kWindow];
   __shared__ uint8_t lens[kMaxCodes + 8];
@@ -347,6 +378,11 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   uint32_t pend = 0;              // lane k: the k-th literal not yet in the ring
   int npend = 0;
   bool bad = false, stop = false, tail = false;
+  // Behind the last row (see the comment above the kernel): `drain` = the rest of the stream is read as png_read_end reads
+  // it, for nothing but its end; `extra`: bytes it would have produced; `refilled`: the piece at hand is one libpng fetched
+  // for that; `whole`: the walk may go on to the end of the stream.
+  bool drain = false, refilled = false, whole = false;
+  uint32_t extra = 0, carry = 0;
   uint32_t adler_a = 1, adler_b = 0;  // Adler-32 of out[0 .. flushed)
 
   lds_u8* const ring_lds = (lds_u8*)ring;
@@ -366,10 +402,48 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       flush_chunks();
     }
   };
-  // k more bits of input?  If not: an error in front of the image's last byte, the end of the walk behind it.
+  // What zlib finds wrong in front of the image's last byte, or behind it in the call that delivers the last row, fails the
+  // read; what it finds wrong while png_read_end drains the rest is a warning and ends the walk.
+  auto fail = [&]() {
+    if (!drain) bad = true;
+    stop = true;
+  };
+  // The last row is out and zlib has stopped -- at the end of its piece of input (`exhausted`), or at a symbol that needs
+  // room.  png_read_end (png_read_finish_IDAT) now inflates what is left into a scratch buffer, piece after piece, until the
+  // stream ends or breaks (fine either way) -- or the IDAT data runs out first: png_error("Not enough image data").  One
+  // way out without either: a piece fetched for this that gives no output at all ends the loop quietly.
+  auto begin_drain = [&](bool exhausted) {
+    drain = true;
+    const uint64_t bp = br.bit_pos();
+    const uint64_t lim = drain_limit(a.blob, a.off_pieces, im.piece_first, im.piece_count, im.stream_len, bp, exhausted);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lim), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lim >> 32));
+    if ((lo | hi) == 0u) {  // nothing left to fetch
+      bad = true;
+      stop = true;
+      return;
+    }
+    refilled = (hi >> 31) != 0u;
+    br.left = (int64_t)(((uint64_t)(hi & 0x7FFFFFFFu) << 32) | lo) - (int64_t)bp;
+  };
+  // k more bits of input?  If not: an error in front of the image's last byte; behind it the end of zlib's call, and the
+  // beginning of the drain; in the drain the end of the input -- an error unless the piece gave nothing.
   auto lacks = [&](int k) -> bool {
     if ((int64_t)k <= br.left) return false;
-    if (!tail) bad = true;
+    if (tail && !drain) {
+      begin_drain(true);
+      if (stop) return true;
+      if ((int64_t)k <= br.left) return false;
+    }
+    if (drain && !whole) {
+      if (refilled && extra == 0u) {  // (libpng's loop ends: no output, no error)
+        stop = true;
+        return true;
+      }
+      whole = true;
+      br.left = (int64_t)im.stream_len * 8 - (int64_t)br.bit_pos();
+      if ((int64_t)k <= br.left) return false;
+    }
+    bad = true;  // "Not enough image data"
     stop = true;
     return true;
   };
@@ -379,18 +453,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
     tail = true;
     const uint64_t bp = br.bit_pos();
     const uint32_t last_byte = (uint32_t)((bp + 7u) / 8u) - 1u;  // the last byte zlib has pulled
-    const uint32_t* pe = reinterpret_cast<const uint32_t*>(a.blob + a.off_pieces) + im.piece_first;
-    uint32_t begin = 0, end = im.stream_len;
-    for (uint32_t k = 0; k < im.piece_count; k++) {
-      const uint32_t e = in_constant(pe)[k];
-      if (last_byte < e) {
-        end = e;
-        break;
-      }
-      begin = e;
-    }
-    const uint32_t boundary = min(end, begin + ((last_byte - begin) / kIdatReadSize + 1u) * kIdatReadSize);
-    br.left = (int64_t)((uint64_t)min(boundary, im.stream_len) * 8u) - (int64_t)bp;
+    const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece_end_of(a.blob, a.off_pieces, im.piece_first, im.piece_count, im.stream_len, last_byte));
+    br.left = (int64_t)((uint64_t)pe * 8u) - (int64_t)bp;
   };
 
   bool last = false;
@@ -401,6 +465,10 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       br.drop(br.n & 7);
       br.fill();
       if (lacks(32)) break;
+      if (drain) {  // (a wrong check value is a warning here, a right one the end)
+        stop = true;
+        break;
+      }
       const uint32_t v = br.take(16);
       br.fill();
       const uint32_t v2 = br.take(16);
@@ -418,7 +486,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
     last = br.take(1) != 0u;
     const uint32_t btype = br.take(2);
     if (btype == 3u) {  // inflate: "invalid block type"
-      bad = true;
+      fail();
       break;
     }
     if (btype == 0u) {  // stored: to the byte boundary, LEN, ~LEN, LEN bytes
@@ -430,15 +498,27 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       br.fill();
       const uint32_t nlen = br.take(16);
       if ((len ^ 0xFFFFu) != nlen) {  // inflate: "invalid stored block lengths"
-        bad = true;
+        fail();
         break;
       }
       if (len == 0u) continue;
-      if (tail) {  // bytes to copy and no room for them: inflate leaves
-        stop = true;
-        break;
-      }
       const uint32_t src0 = br.byte_pos();
+      if (tail) {  // bytes to copy and no room for them: inflate leaves, the drain takes them
+        if (!drain) begin_drain(false);
+        if (stop) break;
+        extra += len;
+        if (src0 + len > im.stream_len) {  // the input ends inside them
+          bad = true;
+          break;
+        }
+        const uint32_t next = src0 + len;
+        br.start(next >> 2);
+        br.fill();
+        br.drop((int)(next & 3u) * 8);
+        whole = true;
+        br.left = (int64_t)im.stream_len * 8 - (int64_t)next * 8;
+        continue;
+      }
       const uint32_t want = min(len, expected - pos);
       if (src0 + want > im.stream_len) {  // the stream ends inside the bytes the image still needs
         bad = true;
@@ -450,9 +530,22 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         pos += min(64u, want - i);
         flush_chunks();
       }
-      if (want < len) {  // the image is complete in the middle of the block: inflate leaves
-        stop = true;
-        break;
+      if (want < len) {  // the image is complete in the middle of the block: inflate leaves, the drain takes the rest
+        enter_tail();
+        begin_drain(false);
+        if (stop) break;
+        extra += len - want;
+        if (src0 + len > im.stream_len) {
+          bad = true;
+          break;
+        }
+        const uint32_t next = src0 + len;
+        br.start(next >> 2);
+        br.fill();
+        br.drop((int)(next & 3u) * 8);
+        whole = true;
+        br.left = (int64_t)im.stream_len * 8 - (int64_t)next * 8;
+        continue;
       }
       // the bit buffer continues behind the block's bytes
       const uint32_t next = src0 + len;
@@ -477,7 +570,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       hdist = (int)br.take(5) + 1;
       const int hclen = (int)br.take(4) + 4;
       if (hlit > 286 || hdist > 30) {  // inflate: "too many length or distance symbols"
-        bad = true;
+        fail();
         break;
       }
       // the code-length code: 19 symbols, 3-bit lengths in a fixed order
@@ -495,7 +588,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       const BuiltCode clb = build_code<1>((const lds_u8*)cl_lens, 19, (lds_u16*)sorted, false, nullptr, 0, false);
       const LaneCode clc = clb.c;
       if (__builtin_amdgcn_readfirstlane((int)clb.ok) == 0) {  // inflate: "invalid code lengths set"
-        bad = true;
+        fail();
         break;
       }
       __syncthreads();
@@ -509,7 +602,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         int L;
         const uint32_t idx = decode_index(br.peek(), clc, lane, &L);
         if (L == 0) {  // (a code-length code without a single code: nothing it could decode)
-          if (!lacks(1)) bad = true;
+          if (!lacks(1)) fail();
           break;
         }
         const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)clsym, (int)(idx & 63u));
@@ -525,7 +618,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
           uint32_t val = 0;
           if (sym == 16u) {
             if (i == 0) {  // inflate: "invalid bit length repeat"
-              bad = true;
+              fail();
               break;
             }
             rep = 3 + (int)br.take(2);
@@ -538,7 +631,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
             prev = 0;
           }
           if (i + rep > total) {
-            bad = true;
+            fail();
             break;
           }
           for (int k = lane; k < rep; k += 64) lens[i + k] = (uint8_t)val;
@@ -548,7 +641,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       if (bad || stop) break;
       __syncthreads();
       if (lens[256] == 0) {  // inflate: "invalid code -- missing end-of-block"
-        bad = true;
+        fail();
         break;
       }
     }
@@ -557,7 +650,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
     const BuiltCode db = build_code<1>((const lds_u8*)lens + hlit, hdist, (lds_u16*)sorted + kMaxLit, true, (lds_u32*)dist_table, kDistBits, true);
     const LaneCode lc = lb.c, dc = db.c;
     if (__builtin_amdgcn_readfirstlane((int)lb.ok) == 0 || __builtin_amdgcn_readfirstlane((int)db.ok) == 0) {  // inflate: "invalid literal/lengths set", "invalid distances set"
-      bad = true;
+      fail();
       break;
     }
     __syncthreads();
@@ -899,8 +992,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
           }
           pos += want;
           room -= (int)want;
-          if (want < len) {  // the image is complete in the middle of the match: inflate leaves
-            stop = true;
+          if (want < len) {  // the image is complete in the middle of the match: inflate leaves, the drain takes the rest
+            carry = len - want;
             break;
           }
           if (room == 0 || pos - flushed >= (uint32_t)kFlushChunk) break;
@@ -908,22 +1001,32 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         br.left -= (int64_t)(budget0 - budget);
         flush_chunks();
         if (stop || bad) break;
+        if (carry != 0u) {
+          enter_tail();
+          begin_drain(false);
+          if (stop) break;
+          extra += carry;
+          carry = 0u;
+          continue;
+        }
         if (pos + (uint32_t)npend >= expected) continue;  // (the image is complete: the walk goes on as zlib's does)
       }
       br.fill();
       int L;
       const uint32_t idx = decode_index(br.peek(), lc, lane, &L);
       if (L == 0) {  // no code starts like this (possible only in a code of one symbol)
-        if (!lacks(1)) bad = true;
+        if (!lacks(1)) fail();
         break;
       }
       if (lacks(L)) break;
       br.drop(L);
       const uint32_t sym = lit_symbol(idx);
       if (sym < 256u) {
-        if (tail) {  // a literal and no room for it: inflate leaves
-          stop = true;
-          break;
+        if (tail) {  // a literal and no room for it: inflate leaves, the drain counts it
+          if (!drain) begin_drain(false);
+          if (stop) break;
+          extra += 1u;
+          continue;
         }
         // (lane select through M0: the value already takes the instruction's one constant-bus slot)
         asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pend) : "s"(sym), "s"(npend));
@@ -933,7 +1036,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       if (sym == 256u) break;  // end of block
       const uint32_t l = sym - 257u;
       if (l > 28u) {  // symbols 286, 287: "invalid literal/length code"
-        bad = true;
+        fail();
         break;
       }
       uint32_t len;
@@ -950,14 +1053,14 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       int L2;
       const uint32_t idx2 = decode_index(br.peek(), dc, lane, &L2);
       if (L2 == 0) {  // "invalid distance code" (a block without distance codes, or a code of one symbol)
-        if (!lacks(1)) bad = true;
+        if (!lacks(1)) fail();
         break;
       }
       if (lacks(L2)) break;
       br.drop(L2);
       const uint32_t dsym = (uint32_t)__builtin_amdgcn_readlane((int)dsy, (int)(idx2 & 31u));
       if (dsym > 29u) {  // "invalid distance code"
-        bad = true;
+        fail();
         break;
       }
       uint32_t dist;
@@ -968,9 +1071,15 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
         if (lacks(eb)) break;
         dist = 1u + ((2u + (dsym & 1u)) << eb) + br.take(eb);
       }
-      if (tail) {  // a match and no room for it: inflate leaves (it checks the distance only when it copies)
-        stop = true;
-        break;
+      if (tail) {  // a match and no room for it: inflate leaves (it checks the distance only when it copies): the drain's
+        if (!drain) begin_drain(false);
+        if (stop) break;
+        if (dist > pos + extra) {  // "invalid distance too far back", a warning there
+          stop = true;
+          break;
+        }
+        extra += len;
+        continue;
       }
       flush_literals();
       if (dist > pos) {  // "invalid distance too far back"
@@ -996,9 +1105,11 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
       }
       pos += want;
       flush_chunks();
-      if (want < len) {  // the image is complete in the middle of the match: inflate leaves
-        stop = true;
-        break;
+      if (want < len) {  // the image is complete in the middle of the match: inflate leaves, the drain takes the rest
+        enter_tail();
+        begin_drain(false);
+        if (stop) break;
+        extra += len - want;
       }
     }
   }
