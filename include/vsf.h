@@ -424,8 +424,11 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
  * chunks VSF_ERR_INVALID_ARG (nothing is launched then); compressed data that breaks (what libpng answers with png_error)
  * makes the next vsf_sync return VSF_ERR_INVALID_ARG -- that includes what zlib still reads behind the image's last byte in the
  * call that delivers libpng's last row (the rest of the <= 8192-byte piece of one IDAT chunk it was fed: end-of-block code,
- * further block headers, the Adler-32); what lies beyond that piece libpng reads with no row to fill and only warns about, and
- * it is not looked at here either.  Arguments and the asynchronous contract as for the JPEG call. */
+ * further block headers, the Adler-32) and what cv::imdecode's png_read_end makes of the rest: it drains the stream with no
+ * row to fill, where zlib's errors and data behind the image are warnings, but IDAT data that runs out before the stream has
+ * ended is png_error("Not enough image data") -- a file cut inside its last bytes is refused although every pixel was there.
+ * Held against the real libpng driven as grfmt_png.cpp drives it (tests/png_ref.py).  Arguments and the asynchronous contract
+ * as for the JPEG call. */
 vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, const size_t* nbytes, int n_images,
                                      int width, int height, uint8_t* d_dst, size_t dst_image_stride,
                                      size_t dst_row_stride);

@@ -168,10 +168,13 @@ def idat_pieces(png: bytes):
 
 
 def zlib_reference(pieces, expected: int, read_size: int = 8192):
-    """What zlib makes of a file's IDAT payloads when libpng asks it for `expected` bytes: libpng hands it at most `read_size`
-    (PNG_IDAT_READ_SIZE) bytes of ONE chunk at a time and stops asking once the last row is complete -- so zlib sees, behind
-    the last byte, exactly the rest of the piece it was working on.  Returns the bytes, or None when zlib reports an error
-    (in front of the last byte, or behind it within that piece) or the data ends before them."""
+    """What zlib makes of a file's IDAT payloads when libpng reads `expected` bytes of image out of them and cv::imdecode then
+    calls png_read_end -- a restatement in terms of zlib calls, kept beside the real libpng (tests/png_ref.py) as the readable
+    statement of the rule.  libpng hands zlib at most `read_size` (PNG_IDAT_READ_SIZE) bytes of ONE chunk at a time.  While
+    rows are wanted, an error or the end of the data is fatal -- and zlib sees, behind the last byte, the rest of the piece it
+    was working on.  Then png_read_finish_IDAT drains what is left into a 1024-byte scratch buffer: errors are warnings, the
+    end of the stream is fine, one piece that yields nothing ends the loop -- but a refill that finds no IDAT data left is
+    png_error("Not enough image data").  Returns the image's bytes, or None when cv::imdecode would return nothing."""
     if isinstance(pieces, (bytes, bytearray)):
         pieces = [bytes(pieces)]
     feed = [c[i:i + read_size] for c in pieces for i in range(0, len(c), read_size)]
@@ -190,4 +193,18 @@ def zlib_reference(pieces, expected: int, read_size: int = 8192):
             pending = d.unconsumed_tail
     except zlib.error:
         return None
+    extra = 0
+    try:
+        while not d.eof:
+            if not pending:
+                if k == len(feed):
+                    return None          # the drain's refill: "Not enough image data"
+                pending = feed[k]
+                k += 1
+            extra += len(d.decompress(pending, 1024))
+            pending = d.unconsumed_tail
+            if extra == 0 and not pending:
+                break                    # (a piece that gave nothing: libpng's loop ends)
+    except zlib.error:
+        pass                             # a warning
     return out

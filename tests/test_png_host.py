@@ -235,3 +235,47 @@ def test_png_host_parser_under_asan_and_ubsan(tmp_path):
     ok = int(p.stdout.split("ok=")[1].split()[0])
     refused = int(p.stdout.split("refused=")[1].split()[0])
     assert ok > 400 and refused > 500, (ok, refused)
+
+
+def test_the_stated_rule_for_damaged_streams_is_libpngs():
+    """tests/png_craft.py zlib_reference (the rule the device decoder follows, written out in zlib calls: fatal while rows are
+    wanted and in the rest of the piece behind the last byte, a drain afterwards in which only running out of IDAT data is
+    fatal) against the real libpng driven as cv::imdecode drives it, on 800 damaged files."""
+    import png_ref
+    if not png_ref.available():
+        pytest.skip("no libpng16.so.16 to build tests/cpp/png_ref.c against")
+    rng = np.random.Generator(np.random.PCG64(77))
+    refused = read = 0
+    for it in range(800):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8) if it % 3 else np.tile(np.arange(w, dtype=np.uint8), (h, 1))
+        rows = pc.filter_rows(img, 1, rng.integers(0, 5, h))
+        extra = [0, 0, 1, 600, 40000][int(rng.integers(5))]
+        stream = pc.deflate(rows + bytes(rng.integers(0, 256, extra, dtype=np.uint8)), int(rng.choice([0, 1, 6, 9])),
+                            [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY][int(rng.integers(4))])
+        how = int(rng.integers(5))
+        if how == 0:
+            stream = pc.mutate_stream(stream, rng)
+        elif how == 1:
+            cut = max(2, len(stream) - int(rng.integers(1, 300)))
+            stream = stream[:cut] + pc.mutate_stream(b"xx" + stream[cut:], rng)[2:]
+        elif how == 2:
+            stream += bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        elif how == 3:
+            stream = stream[:max(2, len(stream) - int(rng.integers(1, 12)))]
+        if len(stream) < 8:
+            continue
+        hdr_ok = (stream[0] & 15) == 8 and (stream[0] >> 4) <= 7 and not (stream[1] & 32) and ((stream[0] << 8) | stream[1]) % 31 == 0
+        piece = [None, max(1, len(stream) - 4), max(1, len(stream) - 7), 100, 5000, 8192, 9000][int(rng.integers(7))]
+        f = pc.write_png(None, w, h, 8, 0, stream=stream, idat_piece=piece)
+        ref_status, ref_img, _ = png_ref.imdecode_gray(f, w, h)
+        mine = pc.zlib_reference(pc.idat_pieces(f), (w + 1) * h) if hdr_ok else None
+        if mine is not None and np.frombuffer(mine, np.uint8).reshape(h, w + 1)[:, 0].max() > 4:
+            mine = None  # a filter type that does not exist: png_error in png_read_row
+        assert (mine is None) == (ref_status != 0), (it, how, piece, ref_status, png_ref.last_error())
+        if mine is not None:
+            np.testing.assert_array_equal(unfilter_numpy(mine, h, w, 1), ref_img, err_msg="file %d" % it)
+            read += 1
+        else:
+            refused += 1
+    assert read > 150 and refused > 150, (read, refused)
