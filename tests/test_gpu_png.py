@@ -192,13 +192,11 @@ def test_what_libpng_refuses_is_refused_and_what_it_warns_about_is_read(capi, ct
         assert status(good[:40]) == capi.VSF_ERR_INVALID_ARG
         assert status(b"\x89PNG\r\n\x1a\n") == capi.VSF_ERR_INVALID_ARG
         assert status(pc.gray8(img, extra_before=[pc.chunk(b"ABCD", b"xyz")])) == capi.VSF_ERR_INVALID_ARG  # unknown critical chunk
-        rgb = io.BytesIO()
-        Image.fromarray(np.dstack([img, img, img])).save(rgb, format="PNG")
-        assert status(rgb.getvalue()) == capi.VSF_ERR_UNSUPPORTED
-        pal = io.BytesIO()
-        Image.fromarray(img).convert("P").save(pal, format="PNG")
-        assert status(pal.getvalue()) == capi.VSF_ERR_UNSUPPORTED
         assert status(pc.write_png(pc.pack_samples(img, 8), w, h, 8, 0, interlace=1)) == capi.VSF_ERR_UNSUPPORTED
+        rgb_rows = np.dstack([img, img // 2, 255 - img]).reshape(h, -1)
+        iccp = pc.chunk(b"iCCP", b"x\x00\x00" + zlib.compress(b"not a profile"))
+        assert status(pc.write_png(rgb_rows, w, h, 8, 2, extra_before=[iccp])) == capi.VSF_ERR_UNSUPPORTED  # colour + iCCP
+        assert status(pc.write_png(np.zeros((h, w), np.uint8), w, h, 8, 3)) == capi.VSF_ERR_INVALID_ARG    # "Missing PLTE before IDAT"
         # a wrong Adler-32 in the piece of input that also holds the image's last byte: zlib checks it in the call that
         # delivers the last row ("incorrect data check"), png_read_IDAT_data raises png_error
         s = bytearray(pc.idat_stream(good))
@@ -395,4 +393,80 @@ def test_imdecode_tells_jpeg_from_png(capi, oracle):
         Image.fromarray(imgs[0], "L").save(bmp, "BMP")
         st = c.imdecode_gray_batch([files[0], bmp.getvalue()], w, h, d.data_ptr(), w * h, w, allow_status=(capi.VSF_ERR_UNSUPPORTED,))
         assert st == capi.VSF_ERR_UNSUPPORTED
+        assert c.sync() == capi.VSF_OK
+
+
+def test_colour_and_palette_files_as_libpngs_rgb_to_gray(capi):
+    """Colour types 2, 3 and 6 -- cv::imdecode(IMREAD_GRAYSCALE) hands them to libpng's rgb_to_gray(0.299, 0.587) -- against the
+    real libpng driven the same way (tests/png_ref.py): 8- and 16-bit RGB / RGBA, palettes of 1, 2, 4 and 8 bits (short
+    palettes, indices behind their end, tRNS), every row filter, no gamma chunk / gAMA at several values / sRGB (the linearised
+    sum through the two tables), cHRM and bKGD beside them; what the restatement leaves out is UNSUPPORTED, never wrong."""
+    import struct
+    import png_ref
+    if not png_ref.available():
+        pytest.skip("no libpng16.so.16 to build tests/cpp/png_ref.c against")
+    rng = np.random.Generator(np.random.PCG64(99))
+    cases = []   # (w, h, file, libpng must read it)
+    srgb_chrm = pc.chunk(b"cHRM", struct.pack(">8I", 31270, 32900, 64000, 33000, 30000, 60000, 15000, 6000))
+    gamma_sets = [[], [pc.chunk(b"gAMA", struct.pack(">I", 45455))], [pc.chunk(b"gAMA", struct.pack(">I", 100000))],
+                  [pc.chunk(b"gAMA", struct.pack(">I", 96000))], [pc.chunk(b"gAMA", struct.pack(">I", 50000))],
+                  [pc.chunk(b"gAMA", struct.pack(">I", 220000))], [pc.chunk(b"gAMA", struct.pack(">I", 94999))],
+                  [pc.chunk(b"sRGB", b"\x01")], [pc.chunk(b"cHRM", bytes(32))],
+                  [srgb_chrm, pc.chunk(b"gAMA", struct.pack(">I", 45455))], [pc.chunk(b"gAMA", struct.pack(">I", 60000)), srgb_chrm],
+                  [pc.chunk(b"sRGB", b"\x00"), pc.chunk(b"gAMA", struct.pack(">I", 45455)), srgb_chrm],
+                  [pc.chunk(b"gAMA", struct.pack(">I", 100000)), pc.chunk(b"sRGB", b"\x03")],
+                  [pc.chunk(b"sRGB", b"\x02"), pc.chunk(b"gAMA", struct.pack(">I", 30000))],
+                  [pc.chunk(b"gAMA", struct.pack(">I", 45455), bad_crc=True)], [pc.chunk(b"bKGD", bytes(6)), pc.chunk(b"gAMA", struct.pack(">I", 31250))]]
+    for w, h in ((96, 64), (67, 41), (1, 1), (5, 130), (200, 3)):
+        for gi, gamma in enumerate(gamma_sets):
+            smooth = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2) % 256).astype(np.uint8)
+            for ctype, channels in ((2, 3), (6, 4)):
+                px = rng.integers(0, 256, (h, w, channels), dtype=np.uint8)
+                if gi % 2:
+                    px[..., 0] = smooth
+                    px[..., 1] = smooth // 2 + px[..., 1] // 8
+                if gi % 3 == 0:
+                    px[::2, ::3, :3] = px[::2, ::3, :1]      # r = g = b pixels take the other branch
+                cases.append((w, h, pc.write_png(px.reshape(h, -1), w, h, 8, ctype, filters=rng.integers(0, 5, h), extra_before=gamma,
+                                                 level=int(rng.choice([1, 6])))))
+                if gi < 4 or gi == 8:  # 16-bit colour: without a gamma that matters
+                    px16 = rng.integers(0, 65536, (h, w, channels)).astype(">u2")
+                    cases.append((w, h, pc.write_png(px16.view(np.uint8).reshape(h, -1), w, h, 16, ctype, filters=rng.integers(0, 5, h),
+                                                     extra_before=gamma if gi != 1 else [])))
+            for depth in (1, 2, 4, 8):
+                entries = int(rng.integers(1, (1 << depth) + 1))
+                pal = rng.integers(0, 256, (entries, 3), dtype=np.uint8)
+                if entries > 2:
+                    pal[1] = pal[1, 0]
+                idx = rng.integers(0, 1 << depth, (h, w), dtype=np.uint8)   # (some indices lie behind the palette's end)
+                extra = list(gamma) + [pc.chunk(b"PLTE", pal.tobytes())] + ([pc.chunk(b"tRNS", bytes(rng.integers(0, 256, entries, dtype=np.uint8)))] if gi % 2 else [])
+                cases.append((w, h, pc.write_png(pc.pack_samples(idx, depth), w, h, depth, 3, filters=rng.integers(0, 5, h), extra_before=extra)))
+    by_size = {}
+    for w, h, f in cases:
+        by_size.setdefault((w, h), []).append(f)
+    checked = 0
+    for (w, h), files in by_size.items():
+        refs = [png_ref.imdecode_gray(f, w, h) for f in files]
+        assert all(r[0] == 0 for r in refs), "libpng refuses a file this test wrote"
+        with capi.Context(capi.default_params(max(w, 64), max(h, 64), max_images=2, nfeatures=100)) as c:
+            st, got, sync = decode(capi, c, files, w, h)
+            assert st == capi.VSF_OK and sync == capi.VSF_OK, (w, h, st, sync)
+            for i, r in enumerate(refs):
+                np.testing.assert_array_equal(got[i], r[1], err_msg="%dx%d file %d" % (w, h, i))
+                checked += 1
+    assert checked == len(cases) and checked > 300
+    # left out on purpose: refused, not guessed
+    w, h = 96, 64
+    px = rng.integers(0, 256, (h, w * 3), dtype=np.uint8)
+    px16 = rng.integers(0, 256, (h, w * 6), dtype=np.uint8)
+    g = pc.chunk(b"gAMA", struct.pack(">I", 45455))
+    with capi.Context(capi.default_params(w, h, max_images=2, nfeatures=100)) as c:
+        def status(f):
+            return c.png_decode_gray_batch([f], w, h, torch.zeros((h, w), dtype=torch.uint8, device="cuda").data_ptr(), h * w, w,
+                                           allow_status=(capi.VSF_ERR_INVALID_ARG, capi.VSF_ERR_UNSUPPORTED))
+        for extra in ([g, g], [pc.chunk(b"cHRM", bytes(32)), g], [pc.chunk(b"sRGB", b"\x00"), pc.chunk(b"cHRM", bytes(32))],
+                      [pc.chunk(b"gAMA", struct.pack(">I", 5))], [pc.chunk(b"sRGB", b"\x09")]):
+            assert status(pc.write_png(px, w, h, 8, 2, extra_before=extra)) == capi.VSF_ERR_UNSUPPORTED
+        assert status(pc.write_png(px16, w, h, 16, 2, extra_before=[g])) == capi.VSF_ERR_UNSUPPORTED
+        assert status(pc.write_png(px16, w, h, 16, 2, extra_before=[pc.chunk(b"gAMA", struct.pack(">I", 100000))])) == capi.VSF_OK
         assert c.sync() == capi.VSF_OK

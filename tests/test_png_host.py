@@ -128,8 +128,11 @@ assert check([good], w, h)[0] == 0
 assert check([pc.gray8(img, extra_before=[pc.chunk(b"tEXt", b"k\x00v", bad_crc=True)])], w, h)[0] == 0      # ancillary, damaged: skipped
 assert check([pc.gray8(img, extra_before=[pc.chunk(b"ABCD", b"")])], w, h)[0] == 1                          # unknown critical chunk
 assert check([pc.write_png(pc.pack_samples(img, 8), w, h, 8, 0, interlace=1)], w, h)[0] == 4               # Adam7: unsupported
-assert check([pc.write_png(np.zeros((h, 3 * w), np.uint8), w, h, 8, 2)], w, h)[0] == 4                     # RGB: unsupported
-assert check([pc.write_png(np.zeros((h, w), np.uint8), w, h, 8, 3)], w, h)[0] == 4                         # palette: unsupported
+assert check([pc.write_png(np.zeros((h, 3 * w), np.uint8), w, h, 8, 2)], w, h)[0] == 0                     # RGB
+assert check([pc.write_png(np.zeros((h, w), np.uint8), w, h, 8, 3)], w, h)[0] == 1                         # palette without a PLTE chunk
+assert check([pc.write_png(np.zeros((h, w), np.uint8), w, h, 8, 3, extra_before=[pc.chunk(b"PLTE", bytes(30))])], w, h)[0] == 0
+assert check([pc.write_png(np.zeros((h, w), np.uint8), w, h, 8, 3, extra_before=[pc.chunk(b"PLTE", bytes(31))])], w, h)[0] == 1
+assert check([pc.write_png(np.zeros((h, 3 * w), np.uint8), w, h, 8, 2, extra_before=[pc.chunk(b"iCCP", b"x")])], w, h)[0] == 4   # colour + iCCP: unsupported
 assert check([pc.write_png(pc.pack_samples(img, 8), w, h, 3, 0)], w, h)[0] == 1                            # 3-bit gray does not exist
 for hdr in (b"\x78\x9d", b"\x88\x1c", b"\x78\xbb", b"\x79\x9c"):                                            # zlib headers that fail their checks
     assert check([pc.replace_idat(good, hdr + pc.idat_stream(good)[2:])], w, h)[0] == 1, hdr

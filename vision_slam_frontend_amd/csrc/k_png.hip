@@ -287,7 +287,7 @@ __device__ unsigned long long g_png_stats[16];
 
 struct PngArgs {
   const uint8_t* blob;
-  size_t off_images, off_pieces, off_stream;
+  size_t off_images, off_pieces, off_tables, off_stream;
   uint8_t* filtered;       // [n][filtered_stride]: the inflated scanlines (filter byte + row bytes)
   size_t filtered_stride;
   int width, height;
@@ -307,8 +307,11 @@ __device__ __forceinline__ DevImage load_image(const PngArgs& a, int image) {
   const uint32_t t = in_constant(iw)[3];
   im.bpp = (uint8_t)(t & 0xFFu);
   im.depth = (uint8_t)((t >> 8) & 0xFFu);
+  im.kind = (uint8_t)((t >> 16) & 0xFFu);
+  im.gamma_tables = (uint8_t)(t >> 24);
   im.piece_first = in_constant(iw)[4];
   im.piece_count = in_constant(iw)[5];
+  im.table = in_constant(iw)[6];
   return im;
 }
 
@@ -1129,6 +1132,8 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(PngArgs a) {
   const int image = blockIdx.x;
   if (in_constant(a.file_status)[image] != 0) return;  // (written by the kernel in front on the same stream)
   const DevImage im = load_image(a, image);
+  if (im.kind == kRgb8 || im.kind == kRgb16) return;  // (png_unfilter_rgb_kernel's)
+  const uint8_t* lut = im.kind == kPalette ? a.blob + a.off_tables + im.table : nullptr;  // palette index -> gray value
   uint8_t* filt = a.filtered + (size_t)image * a.filtered_stride;
   uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
   const int bpp = im.bpp, depth = im.depth;
@@ -1170,13 +1175,14 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(PngArgs a) {
         if (act) {
           if (lane == 63) frow[1 + j * bpp] = (uint8_t)R;  // the next 64 rows' "above"
           if (depth >= 8) {
-            dst[(size_t)row * a.dst_pitch + j] = (uint8_t)R;
-          } else {  // 1, 2, 4 bits: the samples of a byte, most significant first, replicated to 8 bits
+            dst[(size_t)row * a.dst_pitch + j] = lut ? lut[R] : (uint8_t)R;
+          } else {  // 1, 2, 4 bits: the samples of a byte, most significant first -- replicated to 8 bits, or looked up
             const int ppb = 8 / depth;
             const uint32_t mask = (1u << depth) - 1u, mul = 255u / mask;
             for (int p = 0; p < ppb; p++) {
               const int x = j * ppb + p;
-              if (x < w) dst[(size_t)row * a.dst_pitch + x] = (uint8_t)(((R >> (8 - depth * (p + 1))) & mask) * mul);
+              const uint32_t v = (R >> (8 - depth * (p + 1))) & mask;
+              if (x < w) dst[(size_t)row * a.dst_pitch + x] = lut ? lut[v] : (uint8_t)(v * mul);
             }
           }
         }
@@ -1187,15 +1193,100 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(PngArgs a) {
   if (bad) atomicOr(a.status, 2);  // "bad adaptive filter value": libpng stops with png_error; the image is not to be used
 }
 
+// The same for colour files (types 2 and 6): every byte plane the gray value needs is reconstructed IN PLACE -- red, green,
+// blue, both bytes of each for 16-bit samples; alpha is left as it is -- 64 rows at a time as above, one plane after the
+// other; then the 64 rows are weighted pixel by pixel as libpng's png_do_rgb_to_gray weights them with the coefficients
+// grfmt_png.cpp asks for (9797, 19234, 3737 of 32768): 8-bit samples truncated; 16-bit samples rounded, of which the read
+// keeps the high byte (png_set_strip_16 comes behind); with the file's gamma tables (8-bit only: the host refuses the rest)
+// gray = from_linear[(weighted sum of to_linear[r, g, b] + 16384) >> 15] unless r = g = b.
+__global__ __launch_bounds__(64) void png_unfilter_rgb_kernel(PngArgs a) {
+  const int lane = threadIdx.x;
+  const int image = blockIdx.x;
+  if (in_constant(a.file_status)[image] != 0) return;
+  const DevImage im = load_image(a, image);
+  if (im.kind != kRgb8 && im.kind != kRgb16) return;
+  uint8_t* filt = a.filtered + (size_t)image * a.filtered_stride;
+  uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
+  const int bpp = im.bpp;
+  const int planes = im.kind == kRgb16 ? 6 : 3;
+  const int rb1 = (int)im.row_bytes + 1;
+  const int w = a.width, h = a.height;
+  const uint8_t* to_1 = im.gamma_tables ? a.blob + a.off_tables + im.table : nullptr;
+  const uint8_t* from_1 = to_1 ? to_1 + 256 : nullptr;
+  bool bad = false;
+  for (int r0 = 0; r0 < h; r0 += 64) {
+    const int row = r0 + lane;
+    const bool rowok = row < h;
+    uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
+    const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
+    const int ftype = rowok ? frow[0] : 0;
+    if (ftype > 4) bad = true;
+    for (int plane = 0; plane < planes; plane++) {
+      uint32_t ra = 0, rc = 0, last = 0;
+      for (int s0 = 0; s0 < w + 63; s0 += 8) {
+        uint32_t F[8], U[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = s0 + u - lane;
+          const bool act = rowok && j >= 0 && j < w;
+          F[u] = act ? frow[1 + j * bpp + plane] : 0u;
+          U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp + plane] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = s0 + u - lane;
+          const bool act = rowok && j >= 0 && j < w;
+          uint32_t rbv = wave_shr1(last);
+          if (lane == 0) rbv = U[u];
+          const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
+          const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
+          const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
+          const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
+          const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
+          rc = rbv;
+          ra = act ? R : 0u;
+          last = act ? R : 0u;
+          if (act) frow[1 + j * bpp + plane] = (uint8_t)R;
+        }
+      }
+    }
+    __threadfence();  // the rows are read back below by other lanes, lane 63's by the next group's lane 0
+    const int rows = min(64, h - r0);
+    for (int rr = 0; rr < rows; rr++) {
+      const uint8_t* src = filt + (size_t)(r0 + rr) * rb1 + 1;
+      uint8_t* out = dst + (size_t)(r0 + rr) * a.dst_pitch;
+      for (int x = lane; x < w; x += 64) {
+        const uint8_t* px = src + (size_t)x * bpp;
+        uint32_t gray;
+        if (planes == 3) {
+          const uint32_t r = px[0], g = px[1], b = px[2];
+          if (to_1 == nullptr)
+            gray = (9797u * r + 19234u * g + 3737u * b) >> 15;
+          else if (r == g && r == b)
+            gray = r;
+          else
+            gray = from_1[(9797u * to_1[r] + 19234u * to_1[g] + 3737u * to_1[b] + 16384u) >> 15];
+        } else {
+          const uint32_t r = ((uint32_t)px[0] << 8) | px[1], g = ((uint32_t)px[2] << 8) | px[3], b = ((uint32_t)px[4] << 8) | px[5];
+          gray = ((9797u * r + 19234u * g + 3737u * b + 16384u) >> 15) >> 8;
+        }
+        out[x] = (uint8_t)gray;
+      }
+    }
+  }
+  if (bad) atomicOr(a.status, 2);  // "bad adaptive filter value"
+}
+
 }  // namespace
 
-void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_pieces, size_t off_stream, int n, int width, int height,
+void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_pieces, size_t off_tables, size_t off_stream, int n, int width, int height,
                            uint8_t* d_filtered, size_t filtered_stride, int32_t* d_file_status, uint8_t* d_dst,
-                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, hipStream_t s) {
+                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, bool any_rgb, hipStream_t s) {
   PngArgs a;
   a.blob = d_blob;
   a.off_images = off_images;
   a.off_pieces = off_pieces;
+  a.off_tables = off_tables;
   a.off_stream = off_stream;
   a.filtered = d_filtered;
   a.filtered_stride = filtered_stride;
@@ -1208,6 +1299,7 @@ void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_
   a.file_status = d_file_status;
   hipLaunchKernelGGL(png_inflate_kernel, dim3(n), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_unfilter_kernel, dim3(n), dim3(64), 0, s, a);
+  if (any_rgb) hipLaunchKernelGGL(png_unfilter_rgb_kernel, dim3(n), dim3(64), 0, s, a);
 }
 
 #ifdef VSF_PNG_STATS

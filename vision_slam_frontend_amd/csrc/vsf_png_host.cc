@@ -6,13 +6,19 @@
 // i.e. they are UNTRUSTED: every length is checked against the file's end before it is used.  Plain C++ (no HIP code), so
 // that the same translation unit builds with -fsanitize=address,undefined (make asan).
 //
-// Built: grayscale files (colour type 0 at 1, 2, 4, 8, 16 bits, colour type 4 at 8 and 16 bits), non-interlaced -- what a
-// camera driver's image_transport writes for mono8 / mono16 / bayer topics.  A gray read of those needs no colour
-// arithmetic: 16-bit samples keep their high byte (png_set_strip_16), alpha is dropped (png_set_strip_alpha), 1 / 2 / 4-bit
-// samples are replicated to 8 bits (png_set_expand_gray_1_2_4_to_8) -- grfmt_png.cpp's settings for IMREAD_GRAYSCALE.
-// Colour and palette files (libpng's rgb_to_gray, which depends on the file's gamma chunks) and Adam7 files return
-// VSF_ERR_UNSUPPORTED.
+// Built: every colour type, non-interlaced.  Grayscale files (colour type 0 at 1, 2, 4, 8, 16 bits, colour type 4 at 8 and 16
+// bits) are what a camera driver's image_transport writes for mono8 / mono16 / bayer topics; a gray read of those needs no
+// colour arithmetic: 16-bit samples keep their high byte (png_set_strip_16), alpha is dropped (png_set_strip_alpha),
+// 1 / 2 / 4-bit samples are replicated to 8 bits (png_set_expand_gray_1_2_4_to_8) -- grfmt_png.cpp's settings for
+// IMREAD_GRAYSCALE.  Colour files (types 2, 6) and palette files (type 3) go through libpng's rgb_to_gray with the
+// coefficients grfmt_png.cpp passes (0.299, 0.587 -> 9797, 19234, 3737 of 32768), restated here and in k_png.hip from
+// pngrtran.c (png_do_rgb_to_gray, png_build_gamma_table): the integer weighted sum, truncated for 8-bit samples and rounded
+// for 16-bit ones -- or, when the file says its samples are not linear (a gAMA chunk outside 0.95 .. 1.05, or sRGB), the sum of
+// the LINEARISED samples mapped back, through two 256-entry tables built as libpng builds them.  What that restatement does
+// not cover returns VSF_ERR_UNSUPPORTED: Adam7, 16-bit colour with such a gamma, iCCP, more than one gAMA / sRGB, one out of
+// range, primaries (cHRM) other than sRGB's beside a gamma chunk.  (sRGB wins over a gAMA beside it, as in libpng.)
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -61,12 +67,39 @@ struct Piece {
   uint32_t off, len;
 };
 
-vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage* im, std::vector<Piece>* pieces) {
+// ---- libpng's gamma arithmetic (png.c: png_reciprocal, png_gamma_significant, png_gamma_8bit_correct, png_build_8bit_table)
+int32_t png_reciprocal(int32_t a) {
+  const double r = std::floor(1E10 / a + .5);
+  return (r <= 2147483647. && r >= -2147483648.) ? (int32_t)r : 0;
+}
+bool png_gamma_significant(int32_t g) { return g < 95000 || g > 105000; }  // PNG_FP_1 -+ PNG_GAMMA_THRESHOLD_FIXED
+void png_build_8bit_table(uint8_t* table, int32_t gamma_val) {
+  for (int i = 0; i < 256; i++) table[i] = (uint8_t)i;
+  if (png_gamma_significant(gamma_val))
+    for (int i = 1; i < 255; i++) table[i] = (uint8_t)std::floor(255 * std::pow(i / 255., gamma_val * .00001) + .5);
+}
+// png_do_rgb_to_gray for one 8-bit pixel: the coefficients of png_set_rgb_to_gray(1, 0.299, 0.587)
+constexpr uint32_t kRc = 9797, kGc = 19234, kBc = 3737;
+uint8_t rgb_to_gray8(uint32_t r, uint32_t g, uint32_t b, const uint8_t* to_1, const uint8_t* from_1) {
+  if (to_1 == nullptr) return (uint8_t)((kRc * r + kGc * g + kBc * b) >> 15);
+  if (r == g && r == b) return (uint8_t)r;  // (gamma_table is the identity: file gamma x its reciprocal)
+  return from_1[(kRc * to_1[r] + kGc * to_1[g] + kBc * to_1[b] + 16384) >> 15];
+}
+
+vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage* im, std::vector<Piece>* pieces,
+                     std::vector<uint8_t>* table) {
   pieces->clear();
+  table->clear();
   if (n < 8 + 25 + 12 || std::memcmp(f, kSignature, 8) != 0) return VSF_ERR_INVALID_ARG;
   size_t pos = 8;
-  bool have_ihdr = false, have_idat = false, idat_run_over = false, have_iend = false;
-  int channels = 1;
+  bool have_ihdr = false, have_idat = false, idat_run_over = false, have_iend = false, have_plte = false;
+  int channels = 1, ctype = 0, depth = 0;
+  bool colour = false;             // rgb_to_gray has work to do
+  int n_gama = 0, n_srgb = 0, n_chrm = 0, n_iccp = 0;
+  uint32_t gama = 0;
+  bool unsupported_colourspace = false, odd_chrm = false;
+  const uint8_t* plte = nullptr;
+  uint32_t plte_entries = 0;
   uint64_t stream_len = 0;
   while (!have_iend) {
     if (n - pos < 12) return VSF_ERR_INVALID_ARG;
@@ -85,7 +118,9 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
       if (std::memcmp(type, "IHDR", 4) != 0 || len != 13) return VSF_ERR_INVALID_ARG;
       have_ihdr = true;
       const uint32_t w = be32(data), h = be32(data + 4);
-      const int depth = data[8], ctype = data[9], comp = data[10], filt = data[11], lace = data[12];
+      depth = data[8];
+      ctype = data[9];
+      const int comp = data[10], filt = data[11], lace = data[12];
       if (w == 0 || h == 0 || w > 0x7FFFFFFFu || h > 0x7FFFFFFFu || comp != 0 || filt != 0 || lace > 1) return VSF_ERR_INVALID_ARG;
       const bool depth_ok = ctype == 0   ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
                             : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
@@ -93,21 +128,25 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
                                                                        : false;
       if (!depth_ok) return VSF_ERR_INVALID_ARG;
       if (w != (uint32_t)width || h != (uint32_t)height) return VSF_ERR_INVALID_ARG;
-      if (ctype == 2 || ctype == 3 || ctype == 6 || lace == 1) return VSF_ERR_UNSUPPORTED;
-      channels = ctype == 4 ? 2 : 1;
+      if (lace == 1) return VSF_ERR_UNSUPPORTED;
+      colour = ctype == 2 || ctype == 3 || ctype == 6;
+      channels = ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 1;
       const uint64_t row_bits = (uint64_t)w * (uint64_t)(depth * channels);
       const uint64_t row_bytes = (row_bits + 7) / 8;
       if (row_bytes > 0x0FFFFFFFu || (row_bytes + 1) * (uint64_t)h > 0xF0000000u) return VSF_ERR_INVALID_ARG;
       im->row_bytes = (uint32_t)row_bytes;
       im->bpp = (uint8_t)std::max(1, depth * channels / 8);
       im->depth = (uint8_t)depth;
-      im->pad_[0] = im->pad_[1] = 0;
-      im->pad2_[0] = im->pad2_[1] = 0;
+      im->kind = ctype == 3 ? kPalette : (ctype == 2 || ctype == 6) ? (depth == 16 ? kRgb16 : kRgb8) : kGray;
+      im->gamma_tables = 0;
+      im->table = 0;
+      im->pad2_ = 0;
       continue;
     }
     if (std::memcmp(type, "IHDR", 4) == 0) return VSF_ERR_INVALID_ARG;
     if (std::memcmp(type, "IDAT", 4) == 0) {
       if (idat_run_over) return VSF_ERR_INVALID_ARG;  // (IDAT chunks must follow one another)
+      if (ctype == 3 && !have_plte) return VSF_ERR_INVALID_ARG;  // "Missing PLTE before IDAT"
       have_idat = true;
       if (len > 0) {
         pieces->push_back(Piece{(uint32_t)(data - f), len});
@@ -121,7 +160,52 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
       have_iend = true;
       continue;
     }
-    if (std::memcmp(type, "PLTE", 4) == 0) continue;  // ("ignored in grayscale PNG": a benign error, a warning on read)
+    if (std::memcmp(type, "PLTE", 4) == 0) {  // png_handle_PLTE
+      if (have_plte) return VSF_ERR_INVALID_ARG;  // "duplicate"
+      if (have_idat) continue;                     // "out of place": a benign error, the chunk is skipped
+      have_plte = true;
+      if (!colour) continue;                       // "ignored in grayscale PNG"
+      if (len > 3 * 256 || len % 3 != 0) {
+        if (ctype == 3) return VSF_ERR_INVALID_ARG;  // "invalid"
+        continue;
+      }
+      if (ctype == 3) {
+        plte = data;
+        plte_entries = std::min<uint32_t>(len / 3, 1u << depth);  // (more entries than the depth can name are dropped)
+      }
+      continue;
+    }
+    if (colour) {  // what decides whether rgb_to_gray works on the samples as they are (pngrutil.c png_handle_gAMA / sRGB / iCCP)
+      const bool in_place = !have_plte && !have_idat;
+      if (std::memcmp(type, "gAMA", 4) == 0) {
+        if (!in_place || len != 4) continue;  // "out of place" / "invalid": skipped
+        n_gama++;
+        gama = be32(data);
+        if (gama < 16 || gama > 625000000u) unsupported_colourspace = true;  // "gamma value out of range"
+        continue;
+      }
+      if (std::memcmp(type, "sRGB", 4) == 0) {
+        if (!in_place || len != 1) continue;
+        n_srgb++;
+        if (data[0] >= 4) unsupported_colourspace = true;
+        continue;
+      }
+      if (std::memcmp(type, "iCCP", 4) == 0) {
+        n_iccp++;
+        continue;
+      }
+      if (std::memcmp(type, "cHRM", 4) == 0) {
+        if (!in_place || len != 32) continue;
+        // (the primaries do not touch the coefficients asked for by name -- but a cHRM chunk libpng finds fault with makes
+        // it ignore the gamma chunks behind it; the sRGB primaries, which it knows, are let through, others only alone)
+        static const uint32_t srgb_xy[8] = {31270, 32900, 64000, 33000, 30000, 60000, 15000, 6000};
+        bool standard = true;
+        for (int k = 0; k < 8; k++) standard = standard && be32(data + 4 * k) == srgb_xy[k];
+        if (!standard || n_chrm > 0) odd_chrm = true;
+        n_chrm++;
+        continue;
+      }
+    }
     if (critical) return VSF_ERR_INVALID_ARG;          // png_handle_unknown: unhandled critical chunk
   }
   if (!have_idat || stream_len < 6) return VSF_ERR_INVALID_ARG;
@@ -135,6 +219,31 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
   if ((hdr[0] & 0x0F) != 8 || (hdr[0] >> 4) > 7 || (hdr[1] & 0x20) != 0 || (((uint32_t)hdr[0] << 8) | hdr[1]) % 31 != 0)
     return VSF_ERR_INVALID_ARG;
   im->stream_len = (uint32_t)stream_len;
+  if (colour) {
+    if (unsupported_colourspace || n_iccp > 0 || n_gama > 1 || n_srgb > 1 || (odd_chrm && n_gama + n_srgb > 0)) return VSF_ERR_UNSUPPORTED;
+    // png_init_read_transformations: the screen's gamma defaults to the reciprocal of the file's; tables are built when either
+    // is "significant"
+    const int32_t file_gamma = n_srgb ? 45455 : n_gama ? (int32_t)gama : 100000;
+    const int32_t screen_gamma = png_reciprocal(file_gamma);
+    const bool tables = png_gamma_significant(file_gamma) || png_gamma_significant(screen_gamma);
+    uint8_t to_1[256], from_1[256];
+    if (tables) {
+      if (im->kind == kRgb16) return VSF_ERR_UNSUPPORTED;  // (libpng's 16-bit tables are not restated)
+      png_build_8bit_table(to_1, png_reciprocal(file_gamma));
+      png_build_8bit_table(from_1, screen_gamma > 0 ? png_reciprocal(screen_gamma) : file_gamma);
+    }
+    if (im->kind == kPalette) {  // the palette's entries as gray values (entries the file does not define are black)
+      table->assign(256, 0);
+      for (uint32_t i = 0; i < 256; i++) {
+        const uint32_t r = i < plte_entries ? plte[3 * i] : 0, g = i < plte_entries ? plte[3 * i + 1] : 0, b = i < plte_entries ? plte[3 * i + 2] : 0;
+        (*table)[i] = rgb_to_gray8(r, g, b, tables ? to_1 : nullptr, tables ? from_1 : nullptr);
+      }
+    } else if (tables) {
+      im->gamma_tables = 1;
+      table->assign(to_1, to_1 + 256);
+      table->insert(table->end(), from_1, from_1 + 256);
+    }
+  }
   return VSF_OK;
 }
 
@@ -144,11 +253,12 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
 vsf_status vsf_png_plan(const uint8_t* const* png, const size_t* nbytes, int n, int width, int height, VsfPngPlan* plan) {
   std::vector<DevImage> images((size_t)n);
   std::vector<std::vector<Piece>> pieces((size_t)n);
+  std::vector<std::vector<uint8_t>> tables((size_t)n);
   std::vector<vsf_status> status((size_t)n, VSF_OK);
   auto parse_range = [&](int i0, int i1) {
     for (int i = i0; i < i1; i++) {
       std::memset(&images[i], 0, sizeof(DevImage));
-      status[i] = parse_png(png[i], nbytes[i], width, height, &images[i], &pieces[i]);
+      status[i] = parse_png(png[i], nbytes[i], width, height, &images[i], &pieces[i], &tables[i]);
     }
   };
   size_t all = 0;
@@ -195,14 +305,24 @@ vsf_status vsf_png_plan(const uint8_t* const* png, const size_t* nbytes, int n, 
     images[i].piece_first = plan->piece_first[i];
     images[i].piece_count = plan->piece_first[i + 1] - plan->piece_first[i];
   }
+  size_t table_bytes = 0;
+  plan->any_rgb = false;
+  for (int i = 0; i < n; i++) {
+    images[i].table = (uint32_t)table_bytes;
+    table_bytes += tables[i].size();
+    plan->any_rgb = plan->any_rgb || images[i].kind == kRgb8 || images[i].kind == kRgb16;
+  }
   plan->filtered_stride = ((size_t)max_filtered + 15 + 16) & ~(size_t)15;
   plan->off_images = 0;
   plan->off_pieces = (images.size() * sizeof(DevImage) + 15) & ~(size_t)15;
-  plan->off_stream = (plan->off_pieces + piece_end.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
+  plan->off_tables = (plan->off_pieces + piece_end.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
+  plan->off_stream = (plan->off_tables + table_bytes + 15) & ~(size_t)15;
   plan->total = plan->off_stream + stream_bytes + 16;
   plan->head.assign(plan->off_stream, 0);
   std::memcpy(plan->head.data(), images.data(), images.size() * sizeof(DevImage));
   if (!piece_end.empty()) std::memcpy(plan->head.data() + plan->off_pieces, piece_end.data(), piece_end.size() * sizeof(uint32_t));
+  for (int i = 0; i < n; i++)
+    if (!tables[i].empty()) std::memcpy(plan->head.data() + plan->off_tables + images[i].table, tables[i].data(), tables[i].size());
   return VSF_OK;
 }
 

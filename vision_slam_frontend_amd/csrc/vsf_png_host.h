@@ -11,13 +11,17 @@ struct DevImage {
   uint32_t stream_off;   // the zlib stream (the IDAT payloads in file order) inside the packed stream buffer, 4-byte aligned
   uint32_t stream_len;
   uint32_t row_bytes;    // bytes of one filtered row without its filter-type byte
-  uint8_t bpp;           // the filters' pixel distance in bytes: 1 (gray <= 8 bit), 2 (gray 16, gray + alpha 8), 4 (gray + alpha 16)
+  uint8_t bpp;           // the filters' pixel distance in bytes: 1 (gray / palette <= 8 bit), 2 (gray 16, gray + alpha 8), 3, 4, 6, 8
   uint8_t depth;         // bits per sample: 1, 2, 4, 8 or 16
-  uint8_t pad_[2];
+  uint8_t kind;          // kGray: the first byte of a pixel is the answer; kPalette: it indexes a table of 256 gray values;
+                         // kRgb8 / kRgb16: red, green, blue (and alpha, unused) samples weighted as libpng's rgb_to_gray does
+  uint8_t gamma_tables;  // kRgb8: the file's gamma matters -- `table` holds 256 bytes "to linear" and 256 "from linear"
   uint32_t piece_first;  // the file's IDAT payloads: entries [piece_first, piece_first + piece_count) of the upload's list of
   uint32_t piece_count;  // their END offsets inside the zlib stream (libpng hands zlib at most 8192 bytes of ONE chunk at a time)
-  uint32_t pad2_[2];
+  uint32_t table;        // kPalette / gamma_tables: offset of the file's table(s) in the upload's table region
+  uint32_t pad2_;
 };
+constexpr uint8_t kGray = 0, kPalette = 1, kRgb8 = 2, kRgb16 = 3;
 static_assert(sizeof(DevImage) == 32, "DevImage layout");
 constexpr int kDevImageWords = 8;
 constexpr uint32_t kIdatReadSize = 8192;  // PNG_IDAT_READ_SIZE (= PNG_ZBUF_SIZE): bytes of a chunk libpng feeds zlib per refill
