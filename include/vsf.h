@@ -417,12 +417,12 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
 
 /* The same for n PNG files (the other format a CompressedImage carries: image_transport's lossless setting): chunk walk and
  * CRC checks on the host (a damaged critical chunk fails the call, as it fails png_read_*; a damaged ancillary chunk is
- * skipped), RFC 1951 inflate and the PNG row filters on the device.  Every colour type, non-interlaced: colour type 0 at 1, 2,
+ * skipped), RFC 1951 inflate and the PNG row filters on the device.  Every colour type, interlaced (Adam7) or not: colour type 0 at 1, 2,
  * 4, 8 and 16 bits and colour type 4 at 8 and 16 bits -- 16-bit samples keep their high byte, alpha is dropped, 1 / 2 / 4-bit
  * samples are replicated to 8 bits (grfmt_png.cpp's libpng settings for IMREAD_GRAYSCALE) --, colour types 2 and 6 at 8 and 16
  * bits and palettes of 1 to 8 bits as libpng's rgb_to_gray(1, 0.299, 0.587) makes them (the truncated / rounded integer sum,
  * or, with a gAMA outside 0.95 .. 1.05 or an sRGB chunk, the sum of the linearised samples through libpng's two tables).
- * VSF_ERR_UNSUPPORTED, never a guess: Adam7; beside colour samples iCCP, more than one gAMA / sRGB, one out of range, cHRM
+ * VSF_ERR_UNSUPPORTED, never a guess: beside colour samples iCCP, more than one gAMA / sRGB, one out of range, cHRM
  * other than sRGB's primaries next to a gamma chunk, 16-bit samples with a gamma that matters.  Files of another size or with malformed
  * chunks VSF_ERR_INVALID_ARG (nothing is launched then); compressed data that breaks (what libpng answers with png_error)
  * makes the next vsf_sync return VSF_ERR_INVALID_ARG -- that includes what zlib still reads behind the image's last byte in the

@@ -102,6 +102,32 @@ def write_png(raw_rows: np.ndarray, w: int, h: int, depth: int, ctype: int, *, f
     return out + chunk(b"IEND", b"")
 
 
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))   # x0, y0, dx, dy
+
+
+def adam7_filtered(samples: np.ndarray, depth: int, ctype: int, rng: np.random.Generator) -> bytes:
+    """The filtered scanlines of the seven passes (a random filter per row), one after the other: what an interlaced file's
+    zlib stream holds.  samples: (h, w) or (h, w, channels) values of `depth` bits."""
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, depth * channels // 8)
+    data = b""
+    for x0, y0, dx, dy in ADAM7:
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        rows = pack_samples(sub.astype(np.uint16 if depth == 16 else np.uint8), depth)
+        data += filter_rows(rows, bpp, rng.integers(0, 5, sub.shape[0]))
+    return data
+
+
+def write_png_adam7(samples: np.ndarray, depth: int, ctype: int, rng: np.random.Generator, *, level: int = 6,
+                    strategy: int = zlib.Z_DEFAULT_STRATEGY, idat_piece: int | None = None, extra_before=()) -> bytes:
+    """An interlaced file (PNG specification 8.2)."""
+    h, w = samples.shape[:2]
+    return write_png(None, w, h, depth, ctype, stream=deflate(adam7_filtered(samples, depth, ctype, rng), level, strategy),
+                     idat_piece=idat_piece, interlace=1, extra_before=extra_before)
+
+
 def gray8(img: np.ndarray, **kw) -> bytes:
     h, w = img.shape
     return write_png(pack_samples(img, 8), w, h, 8, 0, **kw)

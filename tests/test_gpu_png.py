@@ -192,7 +192,6 @@ def test_what_libpng_refuses_is_refused_and_what_it_warns_about_is_read(capi, ct
         assert status(good[:40]) == capi.VSF_ERR_INVALID_ARG
         assert status(b"\x89PNG\r\n\x1a\n") == capi.VSF_ERR_INVALID_ARG
         assert status(pc.gray8(img, extra_before=[pc.chunk(b"ABCD", b"xyz")])) == capi.VSF_ERR_INVALID_ARG  # unknown critical chunk
-        assert status(pc.write_png(pc.pack_samples(img, 8), w, h, 8, 0, interlace=1)) == capi.VSF_ERR_UNSUPPORTED
         rgb_rows = np.dstack([img, img // 2, 255 - img]).reshape(h, -1)
         iccp = pc.chunk(b"iCCP", b"x\x00\x00" + zlib.compress(b"not a profile"))
         assert status(pc.write_png(rgb_rows, w, h, 8, 2, extra_before=[iccp])) == capi.VSF_ERR_UNSUPPORTED  # colour + iCCP
@@ -317,7 +316,7 @@ def test_committed_fixtures_pinned_by_libpng(capi):
     by_size = {}
     for f in sorted(gold.glob("*.png")):
         by_size.setdefault(expected[f.stem].shape, []).append(f)
-    assert sum(len(v) for v in by_size.values()) >= 31
+    assert sum(len(v) for v in by_size.values()) >= 35
     for (h, w), files in by_size.items():
         with capi.Context(capi.default_params(max(w, 64), max(h, 64), max_images=2, nfeatures=100)) as c:
             st, got, sync = decode(capi, c, [f.read_bytes() for f in files], w, h)
@@ -472,3 +471,41 @@ def test_colour_and_palette_files_as_libpngs_rgb_to_gray(capi):
         assert status(pc.write_png(px16, w, h, 16, 2, extra_before=[g])) == capi.VSF_ERR_UNSUPPORTED
         assert status(pc.write_png(px16, w, h, 16, 2, extra_before=[pc.chunk(b"gAMA", struct.pack(">I", 100000))])) == capi.VSF_OK
         assert c.sync() == capi.VSF_OK
+
+
+def test_interlaced_files(capi):
+    """Adam7: seven passes, each filtered as an image of its own, for every colour type and bit depth and sizes on which passes
+    are empty (1 x 1 ... 9 x 9) -- against the real libpng (png_set_interlace_handling + png_read_image)."""
+    import struct
+    import png_ref
+    if not png_ref.available():
+        pytest.skip("no libpng16.so.16 to build tests/cpp/png_ref.c against")
+    rng = np.random.Generator(np.random.PCG64(7))
+    by_size = {}
+    for w, h in [(a, b) for a in range(1, 10) for b in (1, 2, 3, 5, 8, 9)] + [(96, 64), (67, 41), (640, 480), (5, 300), (300, 3)]:
+        kinds = [(8, 0), (16, 0), (1, 0), (2, 0), (4, 0), (8, 4), (16, 4), (8, 2), (8, 6), (16, 2), (16, 6), (8, 3), (4, 3), (2, 3), (1, 3)]
+        if w * h > 100000:
+            kinds = [(8, 0), (8, 2), (4, 3)]
+        for depth, ctype in kinds:
+            channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+            shape = (h, w) + ((channels,) if channels > 1 else ())
+            samples = rng.integers(0, 1 << depth, shape)
+            extra = []
+            if ctype == 3:
+                extra = [pc.chunk(b"PLTE", bytes(rng.integers(0, 256, 3 * int(rng.integers(1, (1 << depth) + 1)), dtype=np.uint8)))]
+            elif ctype in (2, 6) and depth == 8 and rng.random() < 0.5:
+                extra = [pc.chunk(b"gAMA", struct.pack(">I", 45455))]
+            f = pc.write_png_adam7(samples, depth, ctype, rng, level=int(rng.choice([1, 6])), extra_before=extra,
+                                   idat_piece=[None, 100, 8192][int(rng.integers(3))])
+            by_size.setdefault((w, h), []).append(f)
+    n = 0
+    for (w, h), files in by_size.items():
+        refs = [png_ref.imdecode_gray(f, w, h) for f in files]
+        assert all(r[0] == 0 and r[2][2] == 1 for r in refs), (w, h)
+        with capi.Context(capi.default_params(max(w, 64), max(h, 64), max_images=2, nfeatures=100)) as c:
+            st, got, sync = decode(capi, c, files, w, h)
+            assert st == capi.VSF_OK and sync == capi.VSF_OK, (w, h, st, sync)
+            for i, r in enumerate(refs):
+                np.testing.assert_array_equal(got[i], r[1], err_msg="%dx%d file %d" % (w, h, i))
+                n += 1
+    assert n > 800

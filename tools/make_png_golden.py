@@ -104,6 +104,11 @@ def colour():
         if depth == 8:
             extra = [gam(45455)] + extra + [pc.chunk(b"tRNS", bytes(rng.integers(0, 256, entries, dtype=np.uint8)))]
         files["colour_palette%d" % depth] = pc.write_png(pc.pack_samples(idx, depth), w, h, depth, 3, filters=rng.integers(0, 5, h), extra_before=extra)
+    gray = photo.copy()
+    files["adam7_gray8"] = pc.write_png_adam7(gray, 8, 0, rng, idat_piece=700)
+    files["adam7_gray2"] = pc.write_png_adam7(gray >> 6, 2, 0, rng)
+    files["adam7_rgb8_srgb"] = pc.write_png_adam7(rgb, 8, 2, rng, extra_before=[pc.chunk(b"sRGB", b"\x01")])
+    files["adam7_gray_alpha16"] = pc.write_png_adam7(rng.integers(0, 65536, (h, w, 2)), 16, 4, rng)
     expected = {}
     for name, data in files.items():
         st, img, _ = png_ref.imdecode_gray(data, w, h)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised stress of vsf_png_decode_gray_batch (run by hand on a GPU box): random sizes, colour types (gray, gray + alpha,
-RGB, RGBA, palette) and bit depths (1 / 2 / 4 / 8 / 16), gamma / sRGB / cHRM chunks beside the colour ones, row filters, zlib
+RGB, RGBA, palette) and bit depths (1 / 2 / 4 / 8 / 16), gamma / sRGB / cHRM chunks beside the colour ones, Adam7 for one file in five, row filters, zlib
 strategies and levels, IDAT chunkings, and -- for two files in three -- damage: bit flips,
 cuts, zeroed runs and insertions in the compressed data, data that goes on behind the image, trailing garbage, streams cut
 inside their last bytes.
@@ -56,7 +56,7 @@ for c in range(n_cases):
         gam = lambda v: pc.chunk(b"gAMA", struct.pack(">I", v))
         srgb_chrm = pc.chunk(b"cHRM", struct.pack(">8I", 31270, 32900, 64000, 33000, 30000, 60000, 15000, 6000))
         if depth == 16:
-            before = [[], [gam(100000)], [gam(int(rng.integers(95000, 105001)))], [pc.chunk(b"cHRM", bytes(rng.integers(0, 256, 32, dtype=np.uint8)))]][pick % 4]
+            before = [[], [gam(100000)], [gam(int(rng.integers(95300, 104900)))], [pc.chunk(b"cHRM", bytes(rng.integers(0, 256, 32, dtype=np.uint8)))]][pick % 4]
         else:
             before = [[], [gam(45455)], [gam(int(rng.integers(16, 400000)))], [pc.chunk(b"sRGB", bytes([int(rng.integers(4))]))],
                       [srgb_chrm, gam(int(rng.integers(20000, 300000)))], [pc.chunk(b"sRGB", b"\x00"), gam(int(rng.integers(20000, 300000)))],
@@ -71,7 +71,8 @@ for c in range(n_cases):
     filters = [np.arange(h) % 5, rng.integers(0, 5, h), np.full(h, int(rng.integers(5)))][int(rng.integers(3))]
     strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED][int(rng.integers(5))]
     level = int(rng.choice([0, 1, 6, 9]))
-    rows = pc.filter_rows(raw, bpp, filters)
+    lace = int(rng.random() < 0.2)
+    rows = pc.adam7_filtered(base, depth, ctype, rng) if lace else pc.filter_rows(raw, bpp, filters)
     how = int(rng.integers(7))
     extra = bytes(rng.integers(0, 256, [0, 0, 0, 1, 500, 70000][int(rng.integers(6))], dtype=np.uint8)) if how in (3, 4, 5) else b""
     stream = pc.deflate(rows + extra, level, strategy)
@@ -87,7 +88,7 @@ for c in range(n_cases):
     if len(stream) < 8:
         continue
     piece = [None, max(1, len(stream) - 4), max(1, len(stream) - 9), int(rng.integers(1, 400)) if w * h < 20000 else 3000, 8192, 8193, 20000][int(rng.integers(7))]
-    f = pc.write_png(None, w, h, depth, ctype, stream=stream, idat_piece=piece, extra_before=before)
+    f = pc.write_png(None, w, h, depth, ctype, stream=stream, idat_piece=piece, extra_before=before, interlace=lace)
     ref_status, want, _ = png_ref.imdecode_gray(f, w, h)
     if ref_status != 0:
         want = None
@@ -120,8 +121,8 @@ for c in range(n_cases):
             note = "ok" if ok else ("FLAGGED" if sync != capi.VSF_OK else "WRONG BYTES")
     bad += not ok
     if not ok or c % 50 == 0:
-        print("case %4d %3dx%-3d depth %2d type %d level %d strategy %d piece %s damage %d: %s" %
-              (c, w, h, depth, ctype, level, strategy, piece, how, note), flush=True)
+        print("case %4d %3dx%-3d depth %2d type %d%s level %d strategy %d piece %s damage %d: %s" %
+              (c, w, h, depth, ctype, " Adam7" if lace else "", level, strategy, piece, how, note), flush=True)
 ctx.close()
 print("libpng %s; decoded and equal: %d, flagged where libpng refuses: %d, mismatches: %d of %d" % (png_ref.version(), clean, flagged, bad, n_cases))
 sys.exit(1 if bad else 0)

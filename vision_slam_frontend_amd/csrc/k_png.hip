@@ -308,10 +308,11 @@ __device__ __forceinline__ DevImage load_image(const PngArgs& a, int image) {
   im.bpp = (uint8_t)(t & 0xFFu);
   im.depth = (uint8_t)((t >> 8) & 0xFFu);
   im.kind = (uint8_t)((t >> 16) & 0xFFu);
-  im.gamma_tables = (uint8_t)(t >> 24);
+  im.flags = (uint8_t)(t >> 24);
   im.piece_first = in_constant(iw)[4];
   im.piece_count = in_constant(iw)[5];
   im.table = in_constant(iw)[6];
+  im.expected = in_constant(iw)[7];
   return im;
 }
 
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
   const int lane = threadIdx.x;
   const int image = blockIdx.x;
   const DevImage im = load_image(a, image);
-  const uint32_t expected = (im.row_bytes + 1u) * (uint32_t)a.height;
+  const uint32_t expected = im.expected;  // every scanline (of every pass) with its filter byte
   uint8_t* out = a.filtered + (size_t)image * a.filtered_stride;
   constexpr uint32_t M = kWindow - 1;
 
@@ -1137,58 +1138,68 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(PngArgs a) {
   uint8_t* filt = a.filtered + (size_t)image * a.filtered_stride;
   uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
   const int bpp = im.bpp, depth = im.depth;
-  const int rb1 = (int)im.row_bytes + 1;
-  const int nb = (int)im.row_bytes / bpp;  // bytes of the plane kept: one per pixel (depth >= 8), or the packed row
-  const int w = a.width, h = a.height;
+  const int bits = depth * (im.kind == kPalette ? 1 : bpp >= 2 && depth >= 8 ? bpp * 8 / depth : 1);  // bits per pixel in the file
   bool bad = false;
-  for (int r0 = 0; r0 < h; r0 += 64) {
-    const int row = r0 + lane;
-    const bool rowok = row < h;
-    uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
-    const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
-    const int ftype = rowok ? frow[0] : 0;
-    if (ftype > 4) bad = true;
-    uint32_t ra = 0, rc = 0, last = 0;
-    for (int s0 = 0; s0 < nb + 63; s0 += 8) {
-      uint32_t F[8], U[8];
+  // An interlaced file is seven small images one after the other (a pass without pixels has no bytes); the others one.
+  const int passes = (im.flags & kAdam7) ? 7 : 1;
+  for (int pass = 0; pass < passes; pass++) {
+    const Adam7Pass g = (im.flags & kAdam7) ? adam7_pass(pass) : Adam7Pass{0, 0, 1, 1};
+    const int w = a.width > g.x0 ? (a.width - g.x0 + g.dx - 1) / g.dx : 0, h = a.height > g.y0 ? (a.height - g.y0 + g.dy - 1) / g.dy : 0;
+    if (w == 0 || h == 0) continue;
+    const int row_bytes = (w * bits + 7) / 8;
+    const int rb1 = row_bytes + 1;
+    const int nb = row_bytes / bpp;  // bytes of the plane kept: one per pixel (depth >= 8), or the packed row
+    for (int r0 = 0; r0 < h; r0 += 64) {
+      const int row = r0 + lane;
+      const bool rowok = row < h;
+      uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
+      const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
+      const int ftype = rowok ? frow[0] : 0;
+      if (ftype > 4) bad = true;
+      uint8_t* drow = dst + (size_t)(g.y0 + row * g.dy) * a.dst_pitch + g.x0;
+      uint32_t ra = 0, rc = 0, last = 0;
+      for (int s0 = 0; s0 < nb + 63; s0 += 8) {
+        uint32_t F[8], U[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = s0 + u - lane;
-        const bool act = rowok && j >= 0 && j < nb;
-        F[u] = act ? frow[1 + j * bpp] : 0u;
-        U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp] : 0u;
-      }
+        for (int u = 0; u < 8; u++) {
+          const int j = s0 + u - lane;
+          const bool act = rowok && j >= 0 && j < nb;
+          F[u] = act ? frow[1 + j * bpp] : 0u;
+          U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp] : 0u;
+        }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = s0 + u - lane;
-        const bool act = rowok && j >= 0 && j < nb;
-        uint32_t rbv = wave_shr1(last);
-        if (lane == 0) rbv = U[u];
-        const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
-        const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
-        const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
-        const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
-        const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
-        rc = rbv;
-        ra = act ? R : 0u;
-        last = act ? R : 0u;
-        if (act) {
-          if (lane == 63) frow[1 + j * bpp] = (uint8_t)R;  // the next 64 rows' "above"
-          if (depth >= 8) {
-            dst[(size_t)row * a.dst_pitch + j] = lut ? lut[R] : (uint8_t)R;
-          } else {  // 1, 2, 4 bits: the samples of a byte, most significant first -- replicated to 8 bits, or looked up
-            const int ppb = 8 / depth;
-            const uint32_t mask = (1u << depth) - 1u, mul = 255u / mask;
-            for (int p = 0; p < ppb; p++) {
-              const int x = j * ppb + p;
-              const uint32_t v = (R >> (8 - depth * (p + 1))) & mask;
-              if (x < w) dst[(size_t)row * a.dst_pitch + x] = lut ? lut[v] : (uint8_t)(v * mul);
+        for (int u = 0; u < 8; u++) {
+          const int j = s0 + u - lane;
+          const bool act = rowok && j >= 0 && j < nb;
+          uint32_t rbv = wave_shr1(last);
+          if (lane == 0) rbv = U[u];
+          const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
+          const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
+          const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
+          const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
+          const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
+          rc = rbv;
+          ra = act ? R : 0u;
+          last = act ? R : 0u;
+          if (act) {
+            if (lane == 63) frow[1 + j * bpp] = (uint8_t)R;  // the next 64 rows' "above"
+            if (depth >= 8) {
+              drow[j * g.dx] = lut ? lut[R] : (uint8_t)R;
+            } else {  // 1, 2, 4 bits: the samples of a byte, most significant first -- replicated to 8 bits, or looked up
+              const int ppb = 8 / depth;
+              const uint32_t mask = (1u << depth) - 1u, mul = 255u / mask;
+              for (int p = 0; p < ppb; p++) {
+                const int x = j * ppb + p;
+                const uint32_t v = (R >> (8 - depth * (p + 1))) & mask;
+                if (x < w) drow[x * g.dx] = lut ? lut[v] : (uint8_t)(v * mul);
+              }
             }
           }
         }
       }
+      __threadfence();  // lane 63's row is the next group's lane 0's "above"
     }
-    __threadfence();  // lane 63's row is the next group's lane 0's "above"
+    filt += (size_t)rb1 * h;
   }
   if (bad) atomicOr(a.status, 2);  // "bad adaptive filter value": libpng stops with png_error; the image is not to be used
 }
@@ -1209,70 +1220,76 @@ __global__ __launch_bounds__(64) void png_unfilter_rgb_kernel(PngArgs a) {
   uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
   const int bpp = im.bpp;
   const int planes = im.kind == kRgb16 ? 6 : 3;
-  const int rb1 = (int)im.row_bytes + 1;
-  const int w = a.width, h = a.height;
-  const uint8_t* to_1 = im.gamma_tables ? a.blob + a.off_tables + im.table : nullptr;
+  const uint8_t* to_1 = (im.flags & kGammaTables) ? a.blob + a.off_tables + im.table : nullptr;
   const uint8_t* from_1 = to_1 ? to_1 + 256 : nullptr;
   bool bad = false;
-  for (int r0 = 0; r0 < h; r0 += 64) {
-    const int row = r0 + lane;
-    const bool rowok = row < h;
-    uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
-    const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
-    const int ftype = rowok ? frow[0] : 0;
-    if (ftype > 4) bad = true;
-    for (int plane = 0; plane < planes; plane++) {
-      uint32_t ra = 0, rc = 0, last = 0;
-      for (int s0 = 0; s0 < w + 63; s0 += 8) {
-        uint32_t F[8], U[8];
+  const int passes = (im.flags & kAdam7) ? 7 : 1;
+  for (int pass = 0; pass < passes; pass++) {
+    const Adam7Pass g = (im.flags & kAdam7) ? adam7_pass(pass) : Adam7Pass{0, 0, 1, 1};
+    const int w = a.width > g.x0 ? (a.width - g.x0 + g.dx - 1) / g.dx : 0, h = a.height > g.y0 ? (a.height - g.y0 + g.dy - 1) / g.dy : 0;
+    if (w == 0 || h == 0) continue;
+    const int rb1 = w * bpp + 1;
+    for (int r0 = 0; r0 < h; r0 += 64) {
+      const int row = r0 + lane;
+      const bool rowok = row < h;
+      uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
+      const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
+      const int ftype = rowok ? frow[0] : 0;
+      if (ftype > 4) bad = true;
+      for (int plane = 0; plane < planes; plane++) {
+        uint32_t ra = 0, rc = 0, last = 0;
+        for (int s0 = 0; s0 < w + 63; s0 += 8) {
+          uint32_t F[8], U[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int j = s0 + u - lane;
-          const bool act = rowok && j >= 0 && j < w;
-          F[u] = act ? frow[1 + j * bpp + plane] : 0u;
-          U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp + plane] : 0u;
+          for (int u = 0; u < 8; u++) {
+            const int j = s0 + u - lane;
+            const bool act = rowok && j >= 0 && j < w;
+            F[u] = act ? frow[1 + j * bpp + plane] : 0u;
+            U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp + plane] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int j = s0 + u - lane;
+            const bool act = rowok && j >= 0 && j < w;
+            uint32_t rbv = wave_shr1(last);
+            if (lane == 0) rbv = U[u];
+            const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
+            const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
+            const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
+            const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
+            const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
+            rc = rbv;
+            ra = act ? R : 0u;
+            last = act ? R : 0u;
+            if (act) frow[1 + j * bpp + plane] = (uint8_t)R;
+          }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int j = s0 + u - lane;
-          const bool act = rowok && j >= 0 && j < w;
-          uint32_t rbv = wave_shr1(last);
-          if (lane == 0) rbv = U[u];
-          const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
-          const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
-          const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
-          const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
-          const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
-          rc = rbv;
-          ra = act ? R : 0u;
-          last = act ? R : 0u;
-          if (act) frow[1 + j * bpp + plane] = (uint8_t)R;
+      }
+      __threadfence();  // the rows are read back below by other lanes, lane 63's by the next group's lane 0
+      const int rows = min(64, h - r0);
+      for (int rr = 0; rr < rows; rr++) {
+        const uint8_t* src = filt + (size_t)(r0 + rr) * rb1 + 1;
+        uint8_t* out = dst + (size_t)(g.y0 + (r0 + rr) * g.dy) * a.dst_pitch + g.x0;
+        for (int x = lane; x < w; x += 64) {
+          const uint8_t* px = src + (size_t)x * bpp;
+          uint32_t gray;
+          if (planes == 3) {
+            const uint32_t r = px[0], gr = px[1], b = px[2];
+            if (to_1 == nullptr)
+              gray = (9797u * r + 19234u * gr + 3737u * b) >> 15;
+            else if (r == gr && r == b)
+              gray = r;
+            else
+              gray = from_1[(9797u * to_1[r] + 19234u * to_1[gr] + 3737u * to_1[b] + 16384u) >> 15];
+          } else {
+            const uint32_t r = ((uint32_t)px[0] << 8) | px[1], gr = ((uint32_t)px[2] << 8) | px[3], b = ((uint32_t)px[4] << 8) | px[5];
+            gray = ((9797u * r + 19234u * gr + 3737u * b + 16384u) >> 15) >> 8;
+          }
+          out[x * g.dx] = (uint8_t)gray;
         }
       }
     }
-    __threadfence();  // the rows are read back below by other lanes, lane 63's by the next group's lane 0
-    const int rows = min(64, h - r0);
-    for (int rr = 0; rr < rows; rr++) {
-      const uint8_t* src = filt + (size_t)(r0 + rr) * rb1 + 1;
-      uint8_t* out = dst + (size_t)(r0 + rr) * a.dst_pitch;
-      for (int x = lane; x < w; x += 64) {
-        const uint8_t* px = src + (size_t)x * bpp;
-        uint32_t gray;
-        if (planes == 3) {
-          const uint32_t r = px[0], g = px[1], b = px[2];
-          if (to_1 == nullptr)
-            gray = (9797u * r + 19234u * g + 3737u * b) >> 15;
-          else if (r == g && r == b)
-            gray = r;
-          else
-            gray = from_1[(9797u * to_1[r] + 19234u * to_1[g] + 3737u * to_1[b] + 16384u) >> 15];
-        } else {
-          const uint32_t r = ((uint32_t)px[0] << 8) | px[1], g = ((uint32_t)px[2] << 8) | px[3], b = ((uint32_t)px[4] << 8) | px[5];
-          gray = ((9797u * r + 19234u * g + 3737u * b + 16384u) >> 15) >> 8;
-        }
-        out[x] = (uint8_t)gray;
-      }
-    }
+    filt += (size_t)rb1 * h;
   }
   if (bad) atomicOr(a.status, 2);  // "bad adaptive filter value"
 }

@@ -6,7 +6,7 @@
 // i.e. they are UNTRUSTED: every length is checked against the file's end before it is used.  Plain C++ (no HIP code), so
 // that the same translation unit builds with -fsanitize=address,undefined (make asan).
 //
-// Built: every colour type, non-interlaced.  Grayscale files (colour type 0 at 1, 2, 4, 8, 16 bits, colour type 4 at 8 and 16
+// Built: every colour type, interlaced (Adam7: seven passes, each a small image with filter bytes of its own) or not.  Grayscale files (colour type 0 at 1, 2, 4, 8, 16 bits, colour type 4 at 8 and 16
 // bits) are what a camera driver's image_transport writes for mono8 / mono16 / bayer topics; a gray read of those needs no
 // colour arithmetic: 16-bit samples keep their high byte (png_set_strip_16), alpha is dropped (png_set_strip_alpha),
 // 1 / 2 / 4-bit samples are replicated to 8 bits (png_set_expand_gray_1_2_4_to_8) -- grfmt_png.cpp's settings for
@@ -15,7 +15,7 @@
 // pngrtran.c (png_do_rgb_to_gray, png_build_gamma_table): the integer weighted sum, truncated for 8-bit samples and rounded
 // for 16-bit ones -- or, when the file says its samples are not linear (a gAMA chunk outside 0.95 .. 1.05, or sRGB), the sum of
 // the LINEARISED samples mapped back, through two 256-entry tables built as libpng builds them.  What that restatement does
-// not cover returns VSF_ERR_UNSUPPORTED: Adam7, 16-bit colour with such a gamma, iCCP, more than one gAMA / sRGB, one out of
+// not cover returns VSF_ERR_UNSUPPORTED: 16-bit colour with such a gamma, iCCP, more than one gAMA / sRGB, one out of
 // range, primaries (cHRM) other than sRGB's beside a gamma chunk.  (sRGB wins over a gAMA beside it, as in libpng.)
 #include <algorithm>
 #include <cmath>
@@ -128,7 +128,6 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
                                                                        : false;
       if (!depth_ok) return VSF_ERR_INVALID_ARG;
       if (w != (uint32_t)width || h != (uint32_t)height) return VSF_ERR_INVALID_ARG;
-      if (lace == 1) return VSF_ERR_UNSUPPORTED;
       colour = ctype == 2 || ctype == 3 || ctype == 6;
       channels = ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 1;
       const uint64_t row_bits = (uint64_t)w * (uint64_t)(depth * channels);
@@ -138,9 +137,19 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
       im->bpp = (uint8_t)std::max(1, depth * channels / 8);
       im->depth = (uint8_t)depth;
       im->kind = ctype == 3 ? kPalette : (ctype == 2 || ctype == 6) ? (depth == 16 ? kRgb16 : kRgb8) : kGray;
-      im->gamma_tables = 0;
+      im->flags = lace == 1 ? kAdam7 : 0;
       im->table = 0;
-      im->pad2_ = 0;
+      {  // what the stream must deliver
+        uint64_t total = 0;
+        for (int p = 0; p < (lace == 1 ? 7 : 1); p++) {
+          const Adam7Pass g = lace == 1 ? adam7_pass(p) : Adam7Pass{0, 0, 1, 1};
+          const uint64_t wp = w > (uint32_t)g.x0 ? ((uint64_t)w - g.x0 + g.dx - 1) / g.dx : 0, hp = h > (uint32_t)g.y0 ? ((uint64_t)h - g.y0 + g.dy - 1) / g.dy : 0;
+          if (wp == 0 || hp == 0) continue;
+          total += ((wp * (uint64_t)(depth * channels) + 7) / 8 + 1) * hp;
+        }
+        if (total > 0xF0000000u) return VSF_ERR_INVALID_ARG;
+        im->expected = (uint32_t)total;
+      }
       continue;
     }
     if (std::memcmp(type, "IHDR", 4) == 0) return VSF_ERR_INVALID_ARG;
@@ -239,7 +248,7 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
         (*table)[i] = rgb_to_gray8(r, g, b, tables ? to_1 : nullptr, tables ? from_1 : nullptr);
       }
     } else if (tables) {
-      im->gamma_tables = 1;
+      im->flags |= kGammaTables;
       table->assign(to_1, to_1 + 256);
       table->insert(table->end(), from_1, from_1 + 256);
     }
@@ -292,7 +301,7 @@ vsf_status vsf_png_plan(const uint8_t* const* png, const size_t* nbytes, int n, 
       plan->piece_len.push_back(p.len);
     }
     plan->piece_first[i + 1] = (uint32_t)plan->piece_off.size();
-    max_filtered = std::max(max_filtered, (images[i].row_bytes + 1) * (uint32_t)height);
+    max_filtered = std::max(max_filtered, images[i].expected);
   }
   // the end of every IDAT payload inside its file's zlib stream (the device finds libpng's refill boundaries from them)
   std::vector<uint32_t> piece_end(plan->piece_len.size());
