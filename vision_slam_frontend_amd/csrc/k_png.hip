@@ -22,7 +22,9 @@
 // png_unfilter_kernel: one wave per file, 64 rows at a time as a wavefront (lane k is one byte behind lane k - 1, whose
 // reconstructed byte of one step ago is its "above", of two steps ago its "above left"): every filter type per lane,
 // branch-free.  Only the byte plane a gray read keeps is reconstructed (the filters work per byte plane: a 16-bit
-// sample's low byte and an alpha sample never feed the high byte of the gray sample).
+// sample's low byte and an alpha sample never feed the high byte of the gray sample).  png_unfilter_general_kernel is the
+// same for palette files (indices through 256 gray values) and interlaced ones (seven passes); png_unfilter_rgb_kernel
+// reconstructs the colour planes in place and weights them as libpng's rgb_to_gray does.
 #include "vsf_internal.h"
 #include "vsf_png_host.h"
 
@@ -1128,12 +1130,80 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngArgs a) {
 }
 
 // Filters (PNG specification 9.2), one wave per image, rows r0 .. r0 + 63 as a wavefront.
+// This one: gray and gray + alpha files, not interlaced -- what a camera driver writes.
 __global__ __launch_bounds__(64) void png_unfilter_kernel(PngArgs a) {
   const int lane = threadIdx.x;
   const int image = blockIdx.x;
   if (in_constant(a.file_status)[image] != 0) return;  // (written by the kernel in front on the same stream)
   const DevImage im = load_image(a, image);
-  if (im.kind == kRgb8 || im.kind == kRgb16) return;  // (png_unfilter_rgb_kernel's)
+  if (im.kind != kGray || (im.flags & kAdam7) != 0) return;  // (the kernels below)
+  uint8_t* filt = a.filtered + (size_t)image * a.filtered_stride;
+  uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
+  const int bpp = im.bpp, depth = im.depth;
+  const int rb1 = (int)im.row_bytes + 1;
+  const int nb = (int)im.row_bytes / bpp;  // bytes of the plane kept: one per pixel (depth >= 8), or the packed row
+  const int w = a.width, h = a.height;
+  bool bad = false;
+  for (int r0 = 0; r0 < h; r0 += 64) {
+    const int row = r0 + lane;
+    const bool rowok = row < h;
+    uint8_t* frow = filt + (size_t)(rowok ? row : 0) * rb1;
+    const uint8_t* above_row = filt + (size_t)(r0 > 0 ? r0 - 1 : 0) * rb1;  // lane 0's "above": reconstructed in place by lane 63
+    const int ftype = rowok ? frow[0] : 0;
+    if (ftype > 4) bad = true;
+    uint32_t ra = 0, rc = 0, last = 0;
+    for (int s0 = 0; s0 < nb + 63; s0 += 8) {
+      uint32_t F[8], U[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = s0 + u - lane;
+        const bool act = rowok && j >= 0 && j < nb;
+        F[u] = act ? frow[1 + j * bpp] : 0u;
+        U[u] = (act && lane == 0 && r0 > 0) ? above_row[1 + j * bpp] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = s0 + u - lane;
+        const bool act = rowok && j >= 0 && j < nb;
+        uint32_t rbv = wave_shr1(last);
+        if (lane == 0) rbv = U[u];
+        const int ia = (int)ra, ib = (int)rbv, ic = (int)rc;
+        const int pa = abs(ib - ic), pb = abs(ia - ic), pc = abs(ia + ib - 2 * ic);
+        const int paeth = (pa <= pb && pa <= pc) ? ia : (pb <= pc ? ib : ic);
+        const int pred = ftype == 1 ? ia : ftype == 2 ? ib : ftype == 3 ? ((ia + ib) >> 1) : ftype == 4 ? paeth : 0;
+        const uint32_t R = (F[u] + (uint32_t)pred) & 255u;
+        rc = rbv;
+        ra = act ? R : 0u;
+        last = act ? R : 0u;
+        if (act) {
+          if (lane == 63) frow[1 + j * bpp] = (uint8_t)R;  // the next 64 rows' "above"
+          if (depth >= 8) {
+            dst[(size_t)row * a.dst_pitch + j] = (uint8_t)R;
+          } else {  // 1, 2, 4 bits: the samples of a byte, most significant first, replicated to 8 bits
+            const int ppb = 8 / depth;
+            const uint32_t mask = (1u << depth) - 1u, mul = 255u / mask;
+            for (int p = 0; p < ppb; p++) {
+              const int x = j * ppb + p;
+              if (x < w) dst[(size_t)row * a.dst_pitch + x] = (uint8_t)(((R >> (8 - depth * (p + 1))) & mask) * mul);
+            }
+          }
+        }
+      }
+    }
+    __threadfence();  // lane 63's row is the next group's lane 0's "above"
+  }
+  if (bad) atomicOr(a.status, 2);  // "bad adaptive filter value": libpng stops with png_error; the image is not to be used
+}
+
+// The same for palette files (the index goes through the file's 256 gray values) and interlaced files of either kind: seven
+// passes, each a small image with filter bytes of its own, written to their places (Adam7).
+__global__ __launch_bounds__(64) void png_unfilter_general_kernel(PngArgs a) {
+  const int lane = threadIdx.x;
+  const int image = blockIdx.x;
+  if (in_constant(a.file_status)[image] != 0) return;  // (written by the kernel in front on the same stream)
+  const DevImage im = load_image(a, image);
+  if (im.kind == kRgb8 || im.kind == kRgb16) return;       // (png_unfilter_rgb_kernel's)
+  if (im.kind == kGray && (im.flags & kAdam7) == 0) return;  // (png_unfilter_kernel's)
   const uint8_t* lut = im.kind == kPalette ? a.blob + a.off_tables + im.table : nullptr;  // palette index -> gray value
   uint8_t* filt = a.filtered + (size_t)image * a.filtered_stride;
   uint8_t* dst = a.dst + (size_t)image * a.dst_image_stride;
@@ -1298,7 +1368,7 @@ __global__ __launch_bounds__(64) void png_unfilter_rgb_kernel(PngArgs a) {
 
 void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_pieces, size_t off_tables, size_t off_stream, int n, int width, int height,
                            uint8_t* d_filtered, size_t filtered_stride, int32_t* d_file_status, uint8_t* d_dst,
-                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, bool any_rgb, hipStream_t s) {
+                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, bool any_general, bool any_rgb, hipStream_t s) {
   PngArgs a;
   a.blob = d_blob;
   a.off_images = off_images;
@@ -1316,6 +1386,7 @@ void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_
   a.file_status = d_file_status;
   hipLaunchKernelGGL(png_inflate_kernel, dim3(n), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_unfilter_kernel, dim3(n), dim3(64), 0, s, a);
+  if (any_general) hipLaunchKernelGGL(png_unfilter_general_kernel, dim3(n), dim3(64), 0, s, a);
   if (any_rgb) hipLaunchKernelGGL(png_unfilter_rgb_kernel, dim3(n), dim3(64), 0, s, a);
 }
 

@@ -1942,7 +1942,7 @@ vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, co
   VSF_HIP(hipEventRecord(ctx->jp_copied[b], ctx->stream));
   vsf_launch_png_decode(ctx->jp_dev[b], plan.off_images, plan.off_pieces, plan.off_tables, plan.off_stream, n_images, width, height, ctx->png_filtered,
                         plan.filtered_stride, ctx->png_file_status, d_dst, dst_image_stride, (int)dst_row_stride,
-                        ctx->d_status, plan.any_rgb, ctx->stream);
+                        ctx->d_status, plan.any_general, plan.any_rgb, ctx->stream);
   VSF_STICKY();
   if (!ctx->ev_ingest_done) VSF_HIP(hipEventCreateWithFlags(&ctx->ev_ingest_done, hipEventDisableTiming));
   VSF_HIP(hipEventRecord(ctx->ev_ingest_done, ctx->stream));

@@ -287,13 +287,14 @@ struct VsfPngPlan {  // layout of one upload: [image descriptors | ends of the I
   std::vector<uint32_t> stream_off, stream_len;
   size_t filtered_stride = 0;  // device scratch per image: the inflated scanlines
   bool any_rgb = false;        // a file of colour type 2 or 6 among them (a kernel of its own)
+  bool any_general = false;    // a palette file or an interlaced gray one among them (another)
 };
 vsf_status vsf_png_plan(const uint8_t* const* png, const size_t* nbytes, int n, int width, int height, VsfPngPlan* plan);
 void vsf_png_fill(const VsfPngPlan& plan, const uint8_t* const* png, int n, uint8_t* dst);
 #endif
 void vsf_launch_png_decode(const uint8_t* d_blob, size_t off_images, size_t off_pieces, size_t off_tables, size_t off_stream, int n, int width, int height,
                            uint8_t* d_filtered, size_t filtered_stride, int32_t* d_file_status, uint8_t* d_dst,
-                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, bool any_rgb, hipStream_t s);
+                           size_t dst_image_stride, int dst_pitch, int32_t* d_status, bool any_general, bool any_rgb, hipStream_t s);
 size_t vsf_jpeg_clean_bytes(size_t stream_bytes, int n_par);
 size_t vsf_jpeg_prog_huff_bytes(int n_tables);  // device scratch for the expanded tables of progressive scans
 void vsf_launch_jpeg_decode(const uint8_t* d_blob, size_t off_images, size_t off_index, size_t off_tables, size_t off_scans,

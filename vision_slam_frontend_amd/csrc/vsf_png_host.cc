@@ -315,11 +315,12 @@ vsf_status vsf_png_plan(const uint8_t* const* png, const size_t* nbytes, int n, 
     images[i].piece_count = plan->piece_first[i + 1] - plan->piece_first[i];
   }
   size_t table_bytes = 0;
-  plan->any_rgb = false;
+  plan->any_rgb = plan->any_general = false;
   for (int i = 0; i < n; i++) {
     images[i].table = (uint32_t)table_bytes;
     table_bytes += tables[i].size();
     plan->any_rgb = plan->any_rgb || images[i].kind == kRgb8 || images[i].kind == kRgb16;
+    plan->any_general = plan->any_general || images[i].kind == kPalette || (images[i].kind == kGray && (images[i].flags & kAdam7) != 0);
   }
   plan->filtered_stride = ((size_t)max_filtered + 15 + 16) & ~(size_t)15;
   plan->off_images = 0;
