@@ -25,6 +25,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
 import zlib
 
 import png_craft as pc
+import png_ref
 
 sets = {"synthetic scenes": synth.bench_batch(16, W, H, n_scenes=4).reshape(-1, H, W), "photographs": photos}
 for name, base in sets.items():
@@ -69,6 +70,13 @@ for name, base in sets.items():
             host += time.perf_counter() - h0
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
-        print("%s, level %s (%.0f KB per image): %d images in %.2f ms = %.0f images/s (host chunk walk + CRC + staging %.2f ms of it)"
-              % (name, level, kb, N, dt * 1e3, N / dt, host / reps * 1e3), flush=True)
+        # the same files through the real libpng on one host core, driven as cv::imdecode drives it (tests/png_ref.py)
+        cpu = ""
+        if png_ref.available():
+            t0 = time.perf_counter()
+            for f in files[:32]:
+                assert png_ref.imdecode_gray(f, W, H)[0] == 0
+            cpu = "; libpng %s on one host core: %.0f images/s" % (png_ref.version(), 32 / (time.perf_counter() - t0))
+        print("%s, level %s (%.0f KB per image): %d images in %.2f ms = %.0f images/s (host chunk walk + CRC + staging %.2f ms of it)%s"
+              % (name, level, kb, N, dt * 1e3, N / dt, host / reps * 1e3, cpu), flush=True)
         ctx.close()
