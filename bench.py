@@ -497,6 +497,9 @@ def main() -> int:
                     help="the stereo GetMatches as the first kernel of the step's tail (its matrix-core work beside the next "
                          "step's pyramid and FAST) instead of the last of the extraction; auto: from 5000 features per frame on "
                          "(10 000 features: 21.3 -> 21.9 k frames/s; 2000: 40.8 -> 40.5 k)")
+    ap.add_argument("--tune-steps", type=int, default=16,
+                    help="whole steps timed per FAST launch form by the set-up's tune call (after three untimed ones)")
+    ap.add_argument("--tune-warm", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
@@ -691,7 +694,7 @@ def main() -> int:
     elif not args.blur_inline:
         # (with --ingest jpeg the two forms are timed on the real steps, decode beside them: what FAST shares the chip with
         # decides which form wins)
-        tune = sf.tune(d_imgs, steps=6 if ingest is None else 20, step_fn=None if ingest is None else run_step)
+        tune = sf.tune(d_imgs, steps=args.tune_steps if ingest is None else 20, step_fn=None if ingest is None else run_step, warm=args.tune_warm)
     report_stage("warm-up")
     for _ in range(args.warmup):
         run_step()

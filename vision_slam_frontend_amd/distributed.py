@@ -496,14 +496,15 @@ class ShardedStereoFrontend:
             self.tail_ctx = None
 
     # ---- the one measured launch choice, made the same on every rank ----
-    def tune(self, d_img, samples: int = 3, steps: int = 0, step_fn=None) -> dict:
+    def tune(self, d_img, samples: int = 3, steps: int = 0, step_fn=None, warm: int = 3) -> dict:
         """Explicit and blocking (set-up, never inside a timed region): vsf_tune_fast_resident times the two forms of the
         FAST launch on this rank's own batch (median of `samples` runs each), then ONE all-reduce (max over ranks) of the
         two medians makes the choice common: the step time of the job is its slowest rank's, and ranks that ran different
         forms would hand each other a persistent per-step skew through the means all-gather.  Every rank issues exactly
         the same collectives whatever its own measurement returned (no rank-dependent control flow).
-        steps > 0 (bench.py): the two forms are timed on whole STEPS of this class instead -- one untimed step, then `steps`
-        timed ones per form, on `d_img` (a batch, or a list of batches taken in turn as the caller's own loop will) -- because
+        steps > 0 (bench.py): the two forms are timed on whole STEPS of this class instead -- `warm` untimed steps (three: with
+        one, the form measured first paid for the pipeline filling -- 6.53 against 6.28 ms where both take 6.35 -- and at
+        10 000 features six timed steps could not tell 11.6 from 12.0 ms), then `steps` timed ones per form, on `d_img` (a batch, or a list of batches taken in turn as the caller's own loop will) -- because
         what the form is worth shows in the composed, pipelined step (the blur beside FAST, the next step's pyramid beside
         this step's tail), where it is twice what an extraction by itself shows; an ineligible batch (the library reports
         0 / 0: fewer than 32 images, blur in line) runs no steps.  step_fn: the caller's own way to run one step (a callable
@@ -523,7 +524,7 @@ class ShardedStereoFrontend:
             for form in (0, 3):
                 self.ctx.set_fast_resident(form)
                 one = (lambda i: step_fn()) if step_fn is not None else (lambda i: self.step(batches[i % len(batches)]))
-                for i in range(1 if step_fn is None else 3):  # (a decoder in front of the step takes three steps to fill)
+                for i in range(warm):  # (the pipeline -- and a decoder in front of the step -- take three steps to fill)
                     one(-1 - i)
                 self.drain()
                 t0 = time.perf_counter()
