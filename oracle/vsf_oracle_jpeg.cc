@@ -126,8 +126,9 @@ struct BitReader {  // entropy-coded segment: MSB first, FF00 -> FF, stops feedi
 
 inline int extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }  // F.2.2.1
 
-// libjpeg jidctint.c jpeg_idct_islow on one dequantised 8 x 8 block (natural order), result incl. the range limit.
-#define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+// libjpeg jidctint.c jpeg_idct_islow on one dequantised 8 x 8 block (natural order), result incl. the range limit.  JLONG is
+// `long`: 64 bits wherever the reference runs (LP64), so the sums never overflow and are cut to int at the two DESCALEs --
+// which shows on coefficients no encoder writes (damaged files).
 inline uint8_t range_limit(int32_t x) {
   // sample_range_limit + CENTERJSAMPLE indexed with (x & RANGE_MASK), RANGE_MASK = 1023 (jdmaster.c prepare_range_limit_table)
   const int t = x & 1023;
@@ -137,23 +138,24 @@ inline uint8_t range_limit(int32_t x) {
   return (uint8_t)(t - 896);
 }
 void idct_islow(const int32_t* in, uint8_t* out, size_t ostride) {
-  const int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
-                F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  typedef long long L;
+  const L F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
+          F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
   const int CONST_BITS = 13, PASS1_BITS = 2;
-  int32_t ws[64];
+  int ws[64];
   for (int pass = 0; pass < 2; pass++) {
     for (int i = 0; i < 8; i++) {
-      int32_t d[8];
-      for (int k = 0; k < 8; k++) d[k] = pass == 0 ? in[8 * k + i] : ws[8 * i + k];
-      int32_t z2 = d[2], z3 = d[6];
-      int32_t z1 = (z2 + z3) * F0541;
-      int32_t tmp2 = z1 + z3 * (-F1847);
-      int32_t tmp3 = z1 + z2 * F0765;
+      L d[8];
+      for (int k = 0; k < 8; k++) d[k] = pass == 0 ? (L)in[8 * k + i] : (L)ws[8 * i + k];
+      L z2 = d[2], z3 = d[6];
+      L z1 = (z2 + z3) * F0541;
+      L tmp2 = z1 + z3 * (-F1847);
+      L tmp3 = z1 + z2 * F0765;
       z2 = d[0];
       z3 = d[4];
-      int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << CONST_BITS);
-      int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << CONST_BITS);
-      const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+      L tmp0 = (z2 + z3) * 8192;
+      L tmp1 = (z2 - z3) * 8192;
+      const L tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
       tmp0 = d[7];
       tmp1 = d[5];
       tmp2 = d[3];
@@ -161,8 +163,8 @@ void idct_islow(const int32_t* in, uint8_t* out, size_t ostride) {
       z1 = tmp0 + tmp3;
       z2 = tmp1 + tmp2;
       z3 = tmp0 + tmp2;
-      int32_t z4 = tmp1 + tmp3;
-      const int32_t z5 = (z3 + z4) * F1175;
+      L z4 = tmp1 + tmp3;
+      const L z5 = (z3 + z4) * F1175;
       tmp0 *= F0298;
       tmp1 *= F2053;
       tmp2 *= F3072;
@@ -177,12 +179,15 @@ void idct_islow(const int32_t* in, uint8_t* out, size_t ostride) {
       tmp1 += z2 + z4;
       tmp2 += z2 + z3;
       tmp3 += z1 + z4;
-      const int32_t r[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0,
-                            tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
-      if (pass == 0) {
-        for (int k = 0; k < 8; k++) ws[8 * k + i] = DESCALE(r[k], CONST_BITS - PASS1_BITS);
-      } else {
-        for (int k = 0; k < 8; k++) out[i * ostride + k] = range_limit(DESCALE(r[k], CONST_BITS + PASS1_BITS + 3));
+      const L r[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0,
+                      tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+      const int shift = pass == 0 ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS + 3;
+      for (int k = 0; k < 8; k++) {
+        const int v = (int)((r[k] + (1LL << (shift - 1))) >> shift);
+        if (pass == 0)
+          ws[8 * k + i] = v;
+        else
+          out[i * ostride + k] = range_limit(v);
       }
     }
   }
@@ -284,8 +289,9 @@ int decode_prog_scan(const uint8_t* ecs, const uint8_t* ecs_stop, const std::vec
         }
         k += r;
         const int v = extend(br.receive(sz), sz);
-        if (k > 63) break;  // corrupt
-        if (blk) blk[kZigzag[k]] = (int16_t)v;
+        // (damaged data can run past the block's end: jpeg_natural_order has sixteen spare entries that all say 63 -- the
+        // value lands on the last coefficient, jdhuff.c decode_mcu_slow)
+        if (blk) blk[kZigzag[k > 63 ? 63 : k]] = (int16_t)v;
         k++;
       }
       return;
@@ -313,8 +319,7 @@ int decode_prog_scan(const uint8_t* ecs, const uint8_t* ecs_stop, const std::vec
         if (sz) {
           k += r;
           const int v = extend(br.receive(sz), sz);
-          if (k > 63) break;  // corrupt
-          blk[kZigzag[k]] = (int16_t)(v * (1 << Al));
+          blk[kZigzag[k > 63 ? 63 : k]] = (int16_t)(v * (1 << Al));  // (jdphuff.c decode_mcu_AC_first: the padded order table)
         } else if (r == 15) {
           k += 15;
         } else {  // EOBr: this band is finished in this and the next 2^r + extra - 1 blocks
@@ -354,7 +359,7 @@ int decode_prog_scan(const uint8_t* ecs, const uint8_t* ecs_stop, const std::vec
           }
           k++;
         }
-        if (val && k <= 63) blk[kZigzag[k]] = (int16_t)val;
+        if (val) blk[kZigzag[k > 63 ? 63 : k]] = (int16_t)val;  // (behind a band that ends at 63: natural_order[64] = 63)
       }
     }
     if (eobrun > 0) {
@@ -677,8 +682,7 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
                 continue;
               }
               k += r;
-              if (k > 63) break;  // corrupt
-              const int nat = kZigzag[k];
+              const int nat = kZigzag[k > 63 ? 63 : k];  // (past the block's end: the last coefficient, as libjpeg's padded order table has it)
               coef[nat] = extend(br.receive(sz), sz) * (int32_t)qt[c.tq][nat];
               k++;
             }

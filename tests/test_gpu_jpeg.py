@@ -488,3 +488,54 @@ def test_pipelined_progressive_decode_equals_scan_after_scan_on_damaged_files():
         broke += a[1] and a[0] == capi.VSF_ERR_INVALID_ARG
     # damaged entropy data still decodes to something, as with libjpeg; both outcomes of a launched decode must occur
     assert launched >= 60 and ok >= 30 and broke >= 5, (launched, ok, broke)
+
+
+def test_damaged_files_libjpeg_reads_without_a_warning_decode_to_its_bytes():
+    """The system's libjpeg driven as cv::imdecode drives it (tests/jpeg_ref.py, bound by hand against libjpeg.so.8, its SIMD
+    off: the C code is the reference) on 1000 damaged files (tests/jpeg_mutate.py).  Whatever it decodes without a single
+    warning -- header bytes that changed into other valid headers, entropy bits that flipped into other valid codes, runs
+    that overshoot a block's end (the value lands on coefficient 63) -- must come out of the device byte for byte, and what
+    the device refuses libjpeg must not have read silently.  (Files libjpeg reads WITH warnings or gives up on are the
+    device's own: it may refuse them or fill in differently -- profiles/r05/jpeg_vs_libjpeg.txt has the table.)"""
+    import io
+
+    import torch
+    from PIL import Image
+    import jpeg_ref
+    from jpeg_mutate import mutate
+    from vision_slam_frontend_amd import capi, synth
+    if not jpeg_ref.available():
+        pytest.skip("no libjpeg.so.8 to build tests/cpp/jpeg_ref.c against")
+    W, H = 160, 120
+    img = synth.stereo_pair(W, H, 5, n_objects=60)[0]
+    base = []
+    for kw in (dict(quality=85), dict(quality=40, optimize=True), dict(quality=90, restart_marker_blocks=5), dict(quality=80, progressive=True),
+               dict(quality=60, progressive=True, restart_marker_blocks=7)):
+        b = io.BytesIO()
+        Image.fromarray(img, "L").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
+    rgb = np.stack([img, img[::-1], img[:, ::-1]], 2)
+    for kw in (dict(quality=75, subsampling=2), dict(quality=75, subsampling=2, progressive=True)):
+        b = io.BytesIO()
+        Image.fromarray(rgb, "RGB").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
+    for data in base:  # the binding itself: undamaged files as PIL's libjpeg-turbo reads them
+        st, ref, warn = jpeg_ref.imdecode_gray(data, W, H)
+        im = Image.open(io.BytesIO(data))
+        im.draft("L", im.size)
+        assert st == 0 and warn == 0 and np.array_equal(ref, np.asarray(im.convert("L")))
+    rng = np.random.Generator(np.random.PCG64(11))
+    dev = torch.device("cuda", 0)
+    silent = 0
+    with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
+        for it in range(1000):
+            f = mutate(base[int(rng.integers(len(base)))], rng)
+            st, ref, warn = jpeg_ref.imdecode_gray(f, W, H)
+            if st != 0 or warn != 0:
+                continue
+            d = torch.full((H, W), 0x5A, dtype=torch.uint8, device=dev)
+            ctx.jpeg_decode_gray_batch([f], W, H, d.data_ptr(), W * H, W)   # (a refusal here raises: libjpeg read it silently)
+            assert ctx.sync() == capi.VSF_OK
+            np.testing.assert_array_equal(d.cpu().numpy(), ref, err_msg="damaged file %d" % it)
+            silent += 1
+    assert silent > 50, silent

@@ -151,8 +151,8 @@ struct BitReader {
       l++;
       code = (int32_t)peek(l <= 16 ? l : 16);
     }
-    if (l > 16) {  // corrupt stream
-      drop(16);
+    if (l > 16) {  // no code: libjpeg's walk stops at the 17-bit sentinel, symbol 0 (the fast path without a warning)
+      drop(17);
       return 0;
     }
     drop(l);
@@ -183,18 +183,19 @@ __device__ __forceinline__ uint8_t range_limit(int32_t x) {  // sample_range_lim
 }
 
 // jidctint.c: one 8-point pass on d[0..7]; r[k] are the values before DESCALE
-__device__ __forceinline__ void idct8(const int32_t d[8], int32_t r[8]) {
-  const int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
-                F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
-  int32_t z2 = d[2], z3 = d[6];
-  int32_t z1 = (z2 + z3) * F0541;
-  int32_t tmp2 = z1 + z3 * (-F1847);
-  int32_t tmp3 = z1 + z2 * F0765;
+template <class T>
+__device__ __forceinline__ void idct8_t(const T d[8], T r[8]) {
+  const T F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
+          F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  T z2 = d[2], z3 = d[6];
+  T z1 = (z2 + z3) * F0541;
+  T tmp2 = z1 + z3 * (-F1847);
+  T tmp3 = z1 + z2 * F0765;
   z2 = d[0];
   z3 = d[4];
-  int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << 13);
-  int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << 13);
-  const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  T tmp0 = (z2 + z3) * (T)8192;
+  T tmp1 = (z2 - z3) * (T)8192;
+  const T tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
   tmp0 = d[7];
   tmp1 = d[5];
   tmp2 = d[3];
@@ -202,8 +203,8 @@ __device__ __forceinline__ void idct8(const int32_t d[8], int32_t r[8]) {
   z1 = tmp0 + tmp3;
   z2 = tmp1 + tmp2;
   z3 = tmp0 + tmp2;
-  int32_t z4 = tmp1 + tmp3;
-  const int32_t z5 = (z3 + z4) * F1175;
+  T z4 = tmp1 + tmp3;
+  const T z5 = (z3 + z4) * F1175;
   tmp0 *= F0298;
   tmp1 *= F2053;
   tmp2 *= F3072;
@@ -226,6 +227,31 @@ __device__ __forceinline__ void idct8(const int32_t d[8], int32_t r[8]) {
   r[5] = tmp12 - tmp1;
   r[6] = tmp11 - tmp2;
   r[7] = tmp10 - tmp3;
+}
+// One pass with its DESCALE(., shift), as jidctint.c computes it where JLONG is 64 bits wide (long on every LP64 build of
+// libjpeg): the sums cannot overflow there, and the result is cut to int afterwards.  An output is at most 11363 * sum |d|
+// (the largest row of the 13-bit basis), so with every |d| below 2^14 -- any block an encoder writes -- 32-bit arithmetic
+// gives the same bits (unsigned: wrap-around on the way is harmless, the sums are ring operations); blocks beyond that
+// (damaged files) take the 64-bit path.
+__device__ __forceinline__ void idct8_descaled(const int32_t d[8], int32_t out[8], int shift) {
+  uint32_t most = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) most = max(most, d[k] < 0 ? 0u - (uint32_t)d[k] : (uint32_t)d[k]);
+  if (most < (1u << 14)) {
+    uint32_t u[8], r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) u[k] = (uint32_t)d[k];
+    idct8_t<uint32_t>(u, r);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = (int32_t)(r[k] + (1u << (shift - 1))) >> shift;
+  } else {
+    long long w[8], r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = d[k];
+    idct8_t<long long>(w, r);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = (int32_t)((r[k] + (1ll << (shift - 1))) >> shift);
+  }
 }
 
 // `index`: the images (positions in `images` and in the destination) this launch decodes, one per workgroup
@@ -278,9 +304,10 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
         continue;
       }
       k += r;
-      if (k > 63) break;  // corrupt
       const int val = br.receive_extend(sz);
-      if (coef) coef[(zz32[k >> 2] >> (8 * (k & 3))) & 63u] = (int16_t)val;
+      // (damaged data can run past the block's end: libjpeg's jpeg_natural_order has sixteen spare entries that all say 63,
+      // so the value lands on the last coefficient and the block ends)
+      if (coef) coef[k > 63 ? 63u : (zz32[k >> 2] >> (8 * (k & 3))) & 63u] = (int16_t)val;
       k++;
     }
   };
@@ -323,21 +350,21 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
         int32_t d[8], r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) d[k] = (int32_t)s_coef[b][8 * k + i] * (int32_t)s_qt[8 * k + i];
-        idct8(d, r);
+        idct8_descaled(d, r, 11);  // DESCALE(., CONST_BITS - PASS1_BITS)
 #pragma unroll
-        for (int k = 0; k < 8; k++) s_ws[b][8 * k + i] = (r[k] + (1 << 10)) >> 11;  // DESCALE(., CONST_BITS - PASS1_BITS)
+        for (int k = 0; k < 8; k++) s_ws[b][8 * k + i] = r[k];
       }
       __syncthreads();
       if (b < count) {
         int32_t d[8], r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) d[k] = s_ws[b][8 * i + k];
-        idct8(d, r);
+        idct8_descaled(d, r, 18);  // DESCALE(., 13 + 2 + 3)
         const int x0 = s_dest[b] & 0xFFFF, y = (s_dest[b] >> 16) + i;
         if (y < height && x0 < width) {
           uint8_t px[8];
 #pragma unroll
-          for (int k = 0; k < 8; k++) px[k] = range_limit((r[k] + (1 << 17)) >> 18);  // DESCALE(., 13 + 2 + 3)
+          for (int k = 0; k < 8; k++) px[k] = range_limit(r[k]);
           uint8_t* row = out + (size_t)y * dst_pitch + x0;
           if (x0 + 8 <= width) {
             uint32_t lo, hi;
@@ -509,8 +536,7 @@ __device__ __forceinline__ void prog_scan(const Image& im, int si, const DevScan
             k += r;
             br.fill();
             const int v = br.receive_extend(sz);
-            if (k > 63) break;  // corrupt
-            if (lane == k) mine = v;
+            if (lane == min(k, 63)) mine = v;  // (past the block's end: on the last coefficient, as libjpeg's padded order table has it)
             k++;
           }
           if (blk && mine != 0) blk[nat] = (int16_t)mine;
@@ -614,9 +640,8 @@ __device__ __forceinline__ void prog_scan(const Image& im, int si, const DevScan
                 k += r;
                 br.fill();
                 const int v = br.receive_extend(sz);
-                if (k > 63) break;  // corrupt
-                if (k > Se) suspect = true;  // (damaged data: a value behind the band -- libjpeg writes it too)
-                if (lane == k) mine = v * p1;
+                if (k > Se) suspect = true;  // (damaged data: a value behind the band -- libjpeg writes it too, past the block's end on coefficient 63)
+                if (lane == min(k, 63)) mine = v * p1;
               } else if (r == 15) {
                 k += 15;
               } else {
@@ -666,7 +691,7 @@ __device__ __forceinline__ void prog_scan(const Image& im, int si, const DevScan
               const int pos = zeros ? __builtin_ctzll(zeros) : Se + 1;  // (no such zero: the run ends behind the band)
               corrections(nz & ahead & below(pos));
               if (sign && pos > Se) suspect = true;  // (damaged data: the run ends behind the band)
-              if (sign && lane == pos) my_new = sign;
+              if (sign && lane == min(pos, 63)) my_new = sign;  // (libjpeg writes it there; behind a band that ends at 63: on 63)
               k = pos + 1;
             }
           }
@@ -913,7 +938,7 @@ __device__ __forceinline__ bool par_symbol(const ParGeom& G, ParWin& W, lds_u16 
   const bool stop = !isdc && s == 0;  // EOB (r != 15) or ZRL (r == 15): no coefficient
   const bool zrl = stop && r == 15;
   const int at = k + r;
-  kk = (stop || at > 63) ? -1 : at;  // (at > 63 cannot happen on the true chain)
+  kk = stop ? -1 : min(at, 63);  // (past the block's end -- damaged data -- the value lands on coefficient 63, as libjpeg's padded order table has it)
   k = zrl ? k + 16 : at + 1;
   return (stop && !zrl) || k > 63;
 }
@@ -1380,23 +1405,23 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(const DevImage* __restric
     int32_t d[8], r[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) d[k] = (int32_t)coef[8 * k + i] * (int32_t)qt[8 * k + i];
-    idct8(d, r);
+    idct8_descaled(d, r, 11);
 #pragma unroll
-    for (int k = 0; k < 8; k++) s_ws[lane >> 3][8 * k + i] = (r[k] + (1 << 10)) >> 11;
+    for (int k = 0; k < 8; k++) s_ws[lane >> 3][8 * k + i] = r[k];
   }
   __syncthreads();
   if (b < nlb) {
     int32_t d[8], r[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) d[k] = s_ws[lane >> 3][8 * i + k];
-    idct8(d, r);
+    idct8_descaled(d, r, 18);
     const int mcu = b / lum, c = b - mcu * lum;
     const int my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
     const int x0 = (mx * lum_w + c % lum_w) * 8, y = (my * im.v[0] + c / lum_w) * 8 + i;
     if (y < height && x0 < width) {
       uint8_t px[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) px[k] = range_limit((r[k] + (1 << 17)) >> 18);
+      for (int k = 0; k < 8; k++) px[k] = range_limit(r[k]);
       uint8_t* row = dst + (size_t)image * dst_image_stride + (size_t)y * dst_pitch + x0;
       if (x0 + 8 <= width) {
         uint32_t lo, hi;

@@ -14,7 +14,8 @@ constexpr int kGroupBlocks = 16; // luminance blocks parked in LDS between two I
 constexpr int kSubBits = 16 - kLookBits;  // bits of a code beyond the first lookup
 constexpr int kMaxSub = 12;      // second-level tables per Huffman table (the Annex K tables need 5 or 6)
 constexpr uint32_t kLongCode = 0x8000u;
-constexpr uint16_t kNoCode = 16 << 8;  // a prefix no code starts with: 16 bits, symbol 0 (corrupt streams only)
+constexpr uint16_t kNoCode = 17 << 8;  // a prefix no code starts with: libjpeg's MAXCODE walk ends at its 17-bit sentinel and
+                                       // answers symbol 0 -- seventeen bits are gone (jdhuff.c jpeg_huff_decode; damaged streams only)
 
 struct DevHuff {                 // one Huffman table as the kernels read it
   uint16_t look[1 << kLookBits]; // 9-bit prefix -> (code length << 8 | symbol), or kLongCode | second-level table
