@@ -233,10 +233,23 @@ __device__ __forceinline__ void idct8_t(const T d[8], T r[8]) {
 // (the largest row of the 13-bit basis), so with every |d| below 2^14 -- any block an encoder writes -- 32-bit arithmetic
 // gives the same bits (unsigned: wrap-around on the way is harmless, the sums are ring operations); blocks beyond that
 // (damaged files) take the 64-bit path.
+struct Idct8 {
+  int32_t v[8];
+};
+__device__ __attribute__((noinline)) Idct8 idct8_wide(Idct8 in, int shift) {  // (out of line: damaged files only)
+  long long w[8], r[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = in.v[k];
+  idct8_t<long long>(w, r);
+  Idct8 out;
+#pragma unroll
+  for (int k = 0; k < 8; k++) out.v[k] = (int32_t)((r[k] + (1ll << (shift - 1))) >> shift);
+  return out;
+}
 __device__ __forceinline__ void idct8_descaled(const int32_t d[8], int32_t out[8], int shift) {
   uint32_t most = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) most = max(most, d[k] < 0 ? 0u - (uint32_t)d[k] : (uint32_t)d[k]);
+  for (int k = 0; k < 8; k++) most |= (uint32_t)(d[k] ^ (d[k] >> 31));  // (ones' complement magnitudes: a bound on |d| is all it takes)
   if (most < (1u << 14)) {
     uint32_t u[8], r[8];
 #pragma unroll
@@ -245,12 +258,12 @@ __device__ __forceinline__ void idct8_descaled(const int32_t d[8], int32_t out[8
 #pragma unroll
     for (int k = 0; k < 8; k++) out[k] = (int32_t)(r[k] + (1u << (shift - 1))) >> shift;
   } else {
-    long long w[8], r[8];
+    Idct8 in;
 #pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = d[k];
-    idct8_t<long long>(w, r);
+    for (int k = 0; k < 8; k++) in.v[k] = d[k];
+    const Idct8 o = idct8_wide(in, shift);
 #pragma unroll
-    for (int k = 0; k < 8; k++) out[k] = (int32_t)((r[k] + (1ll << (shift - 1))) >> shift);
+    for (int k = 0; k < 8; k++) out[k] = o.v[k];
   }
 }
 
