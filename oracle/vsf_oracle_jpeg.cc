@@ -72,6 +72,7 @@ struct BitReader {  // entropy-coded segment: MSB first, FF00 -> FF, stops feedi
   uint32_t acc = 0;
   int n = 0;
   bool hit_marker = false;
+  bool starved = false;  // a bit was asked for that the data do not hold: jdhuff.c's insufficient_data
   int get_bit() {
     if (n == 0) {
       uint8_t b = 0;
@@ -83,9 +84,12 @@ struct BitReader {  // entropy-coded segment: MSB first, FF00 -> FF, stops feedi
           } else {  // a marker: leave it in place, feed zero bits (libjpeg does the same with a warning)
             p--;
             hit_marker = true;
+            starved = true;
             b = 0;
           }
         }
+      } else {
+        starved = true;
       }
       acc = b;
       n = 8;
@@ -115,6 +119,7 @@ struct BitReader {  // entropy-coded segment: MSB first, FF00 -> FF, stops feedi
     while (p + 1 < end) {
       if (p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) {
         p += 2;
+        starved = false;  // (process_restart: the marker was there, the next interval has its data)
         return true;
       }
       if (p[0] == 0xFF && p[1] != 0x00 && p[1] != 0xFF) return false;  // another marker: stream is broken
@@ -662,6 +667,9 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
         pred[0] = pred[1] = pred[2] = pred[3] = 0;
         until_restart = restart_interval;
       }
+      // jdhuff.c decode_mcu: "If we've run out of data, just leave the MCU set to zeroes.  This way, we return uniform gray
+      // for the remainder of the segment."  The MCU in which the data ran out was finished on zero bits.
+      const bool skipped = br.starved;
       for (size_t ci = 0; ci < comps.size(); ci++) {
         const Comp& c = comps[ci];
         const int bh = single ? 1 : c.h, bv = single ? 1 : c.v;
@@ -669,6 +677,10 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
           for (int bx = 0; bx < bh; bx++) {
             int32_t coef[64];
             std::memset(coef, 0, sizeof(coef));
+            if (skipped) {
+              if (ci == 0) idct_islow(coef, &plane[(size_t)(my * yv * 8 + by * 8) * pw + (size_t)(mx * yh * 8 + bx * 8)], (size_t)pw);
+              continue;
+            }
             // F.2.2.1 DC, F.2.2.2 AC
             const int t = br.decode(dc[c.td]);
             pred[ci] += extend(br.receive(t), t);

@@ -73,6 +73,7 @@ struct BitReader {
   uint64_t acc;           // the next `n` bits of the de-stuffed stream sit in the low n bits, oldest on top
   int n;
   bool marker;            // a marker has been met: zero bits are fed from here on (until restart())
+  int pad = 0;            // zero bits fed so far: the walk has run out of data once it has taken one of them (starved())
   __device__ __forceinline__ uint32_t at(uint32_t p) const { return (in_constant(words)[p >> 2] >> (8u * (p & 3u))) & 255u; }
   __device__ __forceinline__ void fill() {  // >= 33 bits available afterwards (a code + its extra bits need <= 16 + 15)
     if (n <= 32 && !marker && pos + 4u <= len) {
@@ -108,10 +109,13 @@ struct BitReader {
           marker = true;
         }
       }
+      if (marker) pad += 8;
       acc = (acc << 8) | b;
       n += 8;
     }
   }
+  // jdhuff.c's insufficient_data: a bit has been taken that the data did not hold
+  __device__ __forceinline__ bool starved() const { return n < pad; }
   __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (n - k)) & ((1u << k) - 1u); }
   __device__ __forceinline__ void drop(int k) { n -= k; }
   __device__ __forceinline__ int get_bit() {  // one raw bit
@@ -164,6 +168,7 @@ struct BitReader {
     acc = 0;
     n = 0;
     marker = false;
+    pad = 0;
     while (pos + 1 < len) {
       const uint32_t a = at(pos), b = at(pos + 1);
       if (a == 0xFFu && b >= 0xD0u && b <= 0xD7u) {
@@ -343,14 +348,19 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
         until_restart = restart_interval;
       }
       const int my = mcu / mcus_x, mx = mcu - my * mcus_x;
+      // jdhuff.c decode_mcu: "If we've run out of data, just leave the MCU set to zeroes.  This way, we return uniform gray
+      // for the remainder of the segment."  (The MCU in which the data ran out is finished on zero bits.)
+      const bool skipped = br.starved();
       for (int by = 0; by < v0; by++)
         for (int bx = 0; bx < h0; bx++) {
-          block(dc0, ac0, pred0, s_coef[count]);
+          if (!skipped) block(dc0, ac0, pred0, s_coef[count]);
           s_dest[count] = ((my * v0 * 8 + by * 8) << 16) | (mx * h0 * 8 + bx * 8);
           count++;
         }
-      for (int b = 0; b < nblk1; b++) block(dc1, ac1, pred1, nullptr);
-      for (int b = 0; b < nblk2; b++) block(dc2, ac2, pred2, nullptr);
+      if (!skipped) {
+        for (int b = 0; b < nblk1; b++) block(dc1, ac1, pred1, nullptr);
+        for (int b = 0; b < nblk2; b++) block(dc2, ac2, pred2, nullptr);
+      }
       if (restart_interval) until_restart--;
       mcu++;
     }
@@ -1035,23 +1045,24 @@ __device__ __forceinline__ void par_count(const ParGeom& G, ParWin& W, lds_u16 t
 // sum of the DC differences before the segment) are gathered in the thread's 64-entry block in LDS (`blk`: kBlkStride dwords apart, zero at entry); whenever lanes finish
 // luminance blocks the whole wave copies them out, one 128-byte line per block, to coef[(g / m) * lum + c] and clears
 // them.  ALL lanes of a wave call this (the loop is wave-uniform; lanes that are done idle along).
-// `finish`: the last segment keeps going on zero bits until the image has all its blocks -- what libjpeg does with a
-// stream that breaks off -- and never loops for ever: every symbol consumes at least one bit of at most 2^32.
+// `finish`: the lane also takes what lies behind the end of the data (`data_end`, in bits) as libjpeg takes it (jdhuff.c
+// decode_mcu, insufficient_data): the MCU in which the data run out is decoded to its end on zero bits, every MCU behind it
+// is left zero -- uniform gray -- and never loops for ever: every symbol consumes at least one bit of at most 2^32.
 constexpr int kBlkStride = 33;  // dwords between the LDS blocks of neighbouring threads (32 + 1: the banks spread)
 __device__ __forceinline__ uint32_t par_write(const ParGeom& G, ParWin& W, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave,
                                               int lane, uint32_t limit, uint32_t q, int c, int k, uint32_t g, int pred,
-                                              uint32_t* __restrict__ coef32, uint32_t total_blocks, bool finish) {
+                                              uint32_t* __restrict__ coef32, uint32_t total_blocks, bool finish,
+                                              uint32_t data_end) {
   uint32_t done = 0;
   uint32_t mb = ((g - (uint32_t)c) / (uint32_t)G.m) * (uint32_t)G.lum;  // luminance blocks of the MCUs before
   bool skip = k != 0;                                                    // inside a block somebody else started
   int16_t* mine = reinterpret_cast<int16_t*>(blk_wave + lane * kBlkStride);
   auto has_work = [&]() {
     const bool more = g + done < total_blocks;
-    return q < limit || (k != 0 && more) || (finish && more && q < 0xFFFF0000u);
+    return q < limit || (k != 0 && more) || (finish && more && (c != 0 || q <= data_end) && q < 0xFFFF0000u);
   };
   bool busy = has_work();
-  if (__ballot(busy) == 0ull) return q;
-  W.open(G, q);
+  if (__ballot(busy) != 0ull) W.open(G, q);
   while (__ballot(busy) != 0ull) {
     bool flush = false;
     uint32_t dst = 0;
@@ -1087,6 +1098,16 @@ __device__ __forceinline__ uint32_t par_write(const ParGeom& G, ParWin& W, lds_u
         coef32[(size_t)d * 32 + lane] = *p;
         *p = 0u;
       }
+    }
+  }
+  {  // the MCUs a finishing lane has left out: zero coefficients (the buffer holds the last call's)
+    const uint32_t first = (g + done) / (uint32_t)G.m * (uint32_t)G.lum, last = total_blocks / (uint32_t)G.m * (uint32_t)G.lum;
+    uint64_t todo = __ballot(finish && first < last);
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)first, src) * 32u, hi = (uint32_t)__builtin_amdgcn_readlane((int)last, src) * 32u;
+      for (uint32_t i = lo + (uint32_t)lane; i < hi; i += 64u) coef32[i] = 0u;
     }
   }
   return q;  // (where the lane stopped)
@@ -1287,9 +1308,8 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
       const uint32_t begin = live ? ivl[j] * 8u : 0u, end = live && j + 1u < have ? ivl[j + 1u] * 8u : nbits;
       const uint32_t g = j * (uint32_t)ri * (uint32_t)G.m;
       const uint32_t blocks = live ? min((uint32_t)ri, nmcu - j * (uint32_t)ri) * (uint32_t)G.m : 0u;
-      const uint32_t q = par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, 0u, begin, 0, 0, g, 0, coef32, g + blocks,
-                                   true);
-      broken = broken || (live && q > end);  // the interval's data ran out before its blocks did
+      // (an interval whose data run out before its blocks do: gray MCUs, a warning in libjpeg)
+      (void)par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, 0u, begin, 0, 0, g, 0, coef32, g + blocks, true, end);
     }
     if (broken) atomicOr(status, 2);
     return;
@@ -1395,7 +1415,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
     const uint32_t ck = t == 0 ? 0u : s_ck[t];
     int c = (int)(ck >> 8), k = (int)(ck & 255u);
     (void)par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, limit, q, c, k, g, pred, coef32, total_blocks,
-              t == kParThreads - 1);
+              t == kParThreads - 1, nbits);
   }
 }
 
