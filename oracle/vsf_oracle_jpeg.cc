@@ -538,6 +538,120 @@ int decode_progressive(const uint8_t* data, size_t nbytes, uint8_t* out, size_t 
 
 }  // namespace
 
+namespace {
+// What jpeg_finish_decompress reads behind the data of a file's one scan (jdmarker.c read_markers, jdinput.c
+// consume_markers): every marker from the one the entropy decoder stopped at to EOI.  Most are skipped or parsed quietly; some
+// end the read with a fatal error -- cv::imdecode then returns NOTHING although every row had been decoded: a marker code
+// libjpeg does not know (0x02..0xBF, 0xDE, 0xDF, 0xF0..0xFD: JERR_UNKNOWN_MARKER), another frame or a frame type it does
+// not read, another SOI, another SOS (JERR_EOI_EXPECTED after its header has parsed), a table segment that does not parse.
+// Bytes behind the end of the file read as the memory source supplies them: 0xFF 0xD9 over and over.
+// p[0..n): everything behind the scan header; restart_interval > 0: RSTn markers in the data belong to the decoder.
+// Returns false for a file libjpeg gives up on.
+static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
+  auto at = [&](size_t i) -> int { return i < n ? p[i] : (((i - n) & 1) ? 0xD9 : 0xFF); };
+  size_t i = 0;
+  const size_t hard_end = n + 4096;  // (the virtual tail is EOI after EOI: a walk that gets this far has met one)
+  // where the entropy decoder stops: the first marker in the data
+  int m = -1;
+  while (i < hard_end) {
+    if (at(i) != 0xFF) {
+      i++;
+      continue;
+    }
+    size_t j = i + 1;
+    while (j < hard_end && at(j) == 0xFF) j++;
+    const int c = at(j);
+    i = j + 1;
+    if (c == 0) continue;                                                // a stuffed 0xFF
+    if (restart_interval > 0 && c >= 0xD0 && c <= 0xD7) continue;        // the decoder's own
+    m = c;
+    break;
+  }
+  while (m >= 0 && i < hard_end) {
+    if (m == 0xD9) return true;                                          // EOI
+    if (m == 0xD8) return false;                                         // JERR_SOI_DUPLICATE
+    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) {
+      // (parameterless: traced and passed over)
+    } else if ((m >= 0xC0 && m <= 0xCF) && m != 0xC4 && m != 0xCC) {
+      return false;                                                      // JERR_SOF_DUPLICATE / JERR_SOF_UNSUPPORTED
+    } else if ((m >= 0xE0 && m <= 0xEF) || m == 0xFE || m == 0xDC) {     // APPn, COM, DNL: skip_variable
+      const long length = ((at(i) << 8) | at(i + 1)) - 2;
+      i += 2;
+      if (length > 0) i += (size_t)length;
+    } else if (m == 0xDD) {                                              // DRI
+      if (((at(i) << 8) | at(i + 1)) != 4) return false;                 // JERR_BAD_LENGTH
+      i += 4;
+    } else if (m == 0xC4) {                                              // DHT: get_dht
+      long length = ((at(i) << 8) | at(i + 1)) - 2;
+      i += 2;
+      while (length > 16) {
+        int index = at(i++);
+        long count = 0;
+        for (int k = 0; k < 16; k++) count += at(i++);
+        length -= 1 + 16;
+        if (count > 256 || count > length) return false;                 // JERR_BAD_HUFF_TABLE
+        i += (size_t)count;
+        length -= count;
+        if (index & 0x10) index -= 0x10;
+        if (index < 0 || index >= 4) return false;                       // JERR_DHT_INDEX
+      }
+      if (length != 0) return false;                                     // JERR_BAD_LENGTH
+    } else if (m == 0xDB) {                                              // DQT: get_dqt
+      long length = ((at(i) << 8) | at(i + 1)) - 2;
+      i += 2;
+      while (length > 0) {
+        const int b = at(i++);
+        length--;
+        const int prec = b >> 4;
+        if ((b & 15) >= 4) return false;                                 // JERR_DQT_INDEX
+        long count;
+        if (prec)
+          count = length < 128 ? length >> 1 : 64;
+        else
+          count = length < 64 ? length : 64;
+        i += (size_t)(prec ? 2 * count : count);
+        length -= prec ? 2 * count : count;
+      }
+      if (length != 0) return false;                                     // JERR_BAD_LENGTH
+    } else if (m == 0xCC) {                                              // DAC: get_dac
+      long length = ((at(i) << 8) | at(i + 1)) - 2;
+      i += 2;
+      while (length > 0) {
+        const int index = at(i++), val = at(i++);
+        length -= 2;
+        if (index >= 32) return false;                                   // JERR_DAC_INDEX
+        if (index < 16 && (val & 15) > (val >> 4)) return false;         // JERR_DAC_VALUE
+      }
+      if (length != 0) return false;                                     // JERR_BAD_LENGTH
+    } else if (m == 0xDA) {                                              // SOS: get_sos, then JERR_EOI_EXPECTED
+      return false;  // (whatever its header says: a second scan in a file that announced one is fatal either way)
+    } else if (restart_interval > 0 && m < 0xC0) {
+      // (in a file with restart intervals such a code is mostly met by process_restart, whose jpeg_resync_to_restart
+      // discards "invalid" markers while it looks for the next RSTn; whether one survives to the end cannot be told without
+      // decoding: let through)
+    } else {
+      return false;                                                      // JERR_UNKNOWN_MARKER
+    }
+    // next_marker: on to the next 0xFF that is followed by something
+    m = -1;
+    while (i < hard_end) {
+      if (at(i) != 0xFF) {
+        i++;
+        continue;
+      }
+      size_t j = i + 1;
+      while (j < hard_end && at(j) == 0xFF) j++;
+      const int c = at(j);
+      i = j + 1;
+      if (c == 0) continue;
+      m = c;
+      break;
+    }
+  }
+  return true;
+}
+}  // namespace
+
 extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t* out, size_t ostride, int cap_w,
                                      int cap_h, int* w_out, int* h_out) {
   // returns 0 ok; -1 malformed; -2 a JPEG process this decoder does not restate (arithmetic, 12 bit, lossless,
@@ -640,6 +754,7 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
     pos += len;
   }
   if (!have_sof || comps.empty() || pos >= nbytes) return -1;
+  if (!baseline_tail_ok(data + pos, nbytes - pos, restart_interval)) return -1;
   if (w_out) *w_out = W;
   if (h_out) *h_out = H;
   if (W > cap_w || H > cap_h || !out) return -3;
