@@ -553,11 +553,16 @@ static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
   const size_t hard_end = n + 4096;  // (the virtual tail is EOI after EOI: a walk that gets this far has met one)
   // where the entropy decoder stops: the first marker in the data
   int m = -1;
-  while (i < hard_end) {
-    if (at(i) != 0xFF) {
-      i++;
-      continue;
+  // (the data of an undamaged file are scanned to their end here: memchr from 0xFF to 0xFF, not byte by byte)
+  auto next_ff = [&](size_t from) -> size_t {
+    if (from < n) {
+      const void* f = std::memchr(p + from, 0xFF, n - from);
+      return f ? (size_t)((const uint8_t*)f - p) : n;  // (at n the virtual tail begins: 0xFF 0xD9 ...)
     }
+    return ((from - n) & 1) ? from + 1 : from;
+  };
+  while (i < hard_end) {
+    i = next_ff(i);
     size_t j = i + 1;
     while (j < hard_end && at(j) == 0xFF) j++;
     const int c = at(j);
@@ -635,10 +640,7 @@ static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
     // next_marker: on to the next 0xFF that is followed by something
     m = -1;
     while (i < hard_end) {
-      if (at(i) != 0xFF) {
-        i++;
-        continue;
-      }
+      i = next_ff(i);
       size_t j = i + 1;
       while (j < hard_end && at(j) == 0xFF) j++;
       const int c = at(j);

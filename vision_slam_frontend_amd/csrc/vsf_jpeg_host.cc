@@ -140,11 +140,16 @@ static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
   const size_t hard_end = n + 4096;  // (the virtual tail is EOI after EOI: a walk that gets this far has met one)
   // where the entropy decoder stops: the first marker in the data
   int m = -1;
-  while (i < hard_end) {
-    if (at(i) != 0xFF) {
-      i++;
-      continue;
+  // (the data of an undamaged file are scanned to their end here: memchr from 0xFF to 0xFF, not byte by byte)
+  auto next_ff = [&](size_t from) -> size_t {
+    if (from < n) {
+      const void* f = std::memchr(p + from, 0xFF, n - from);
+      return f ? (size_t)((const uint8_t*)f - p) : n;  // (at n the virtual tail begins: 0xFF 0xD9 ...)
     }
+    return ((from - n) & 1) ? from + 1 : from;
+  };
+  while (i < hard_end) {
+    i = next_ff(i);
     size_t j = i + 1;
     while (j < hard_end && at(j) == 0xFF) j++;
     const int c = at(j);
@@ -222,10 +227,7 @@ static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
     // next_marker: on to the next 0xFF that is followed by something
     m = -1;
     while (i < hard_end) {
-      if (at(i) != 0xFF) {
-        i++;
-        continue;
-      }
+      i = next_ff(i);
       size_t j = i + 1;
       while (j < hard_end && at(j) == 0xFF) j++;
       const int c = at(j);
@@ -449,9 +451,7 @@ static vsf_status parse_jpeg(const uint8_t* data, size_t nbytes, int width, int 
       }
       std::memcpy(tab->qt_luma, qt[ctq[0]], sizeof(tab->qt_luma));
       *scan_begin = pos + len;
-      if (*scan_begin >= nbytes) return VSF_ERR_INVALID_ARG;
-      if (!baseline_tail_ok(data + *scan_begin, nbytes - *scan_begin, restart_interval)) return VSF_ERR_INVALID_ARG;
-      return VSF_OK;
+      return *scan_begin < nbytes ? VSF_OK : VSF_ERR_INVALID_ARG;  // (what lies behind the scan's data: vsf_jpeg_plan, baseline_tail_ok)
     }
     pos += len;
   }
@@ -553,6 +553,28 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
     stream_bytes += (images[i].stream_len + 3u + 32u) & ~(size_t)3;
     plan->max_luma_blocks = std::max(plan->max_luma_blocks, images[i].mcus_x * images[i].mcus_y * images[i].h[0] * images[i].v[0]);
     if (stream_bytes > 0xF0000000u) return VSF_ERR_INVALID_ARG;
+  }
+  {  // What jpeg_finish_decompress makes of the bytes behind every one-scan file's data (baseline_tail_ok): that is a scan of
+     // all of the entropy-coded data for markers -- a few threads when there is enough of it.
+    std::vector<uint8_t> ok((size_t)n, 1);
+    auto walk = [&](int i0, int i1) {
+      for (int i = i0; i < i1; i++)
+        if (images[i].n_scans == 0)
+          ok[i] = baseline_tail_ok(jpeg[i] + plan->scan_begin[i], nbytes[i] - plan->scan_begin[i], images[i].restart_interval) ? 1 : 0;
+    };
+    size_t all = 0;
+    for (int i = 0; i < n; i++) all += nbytes[i];
+    const int workers = (int)std::min<size_t>({(size_t)8, all >> 20, (size_t)n, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (workers <= 1) {
+      walk(0, n);
+    } else {
+      std::vector<std::thread> pool;
+      for (int w = 1; w < workers; w++) pool.emplace_back(walk, (int)((int64_t)n * w / workers), (int)((int64_t)n * (w + 1) / workers));
+      walk(0, n / workers);
+      for (auto& th : pool) th.join();
+    }
+    for (int i = 0; i < n; i++)
+      if (!ok[i]) return VSF_ERR_INVALID_ARG;
   }
   // which decoder takes which file: those without restart intervals first, progressive files next
   std::vector<uint32_t> index;
