@@ -127,6 +127,59 @@ struct BitReader {  // entropy-coded segment: MSB first, FF00 -> FF, stops feedi
     }
     return false;
   }
+  // The same as libjpeg does it for a sequential scan (jdhuff.c process_restart, jdmarker.c read_restart_marker and
+  // jpeg_resync_to_restart): the bits left are dropped; the next marker is looked for (bytes in front of it are passed over);
+  // if it is the restart marker that is due (`next`: 0..7) it is taken and the interval has its data.  If not: a code below
+  // 0xC0 is passed over and the search goes on; any other marker that is no RSTn stays where it is -- and so does an RSTn one
+  // or two numbers AHEAD of the one due: the interval is decoded from no data (its first MCU from zero bits, the rest gray) and
+  // the marker is met again at the next boundary; an RSTn one or two numbers BEHIND is passed over; any other RSTn is taken as
+  // if it were the one due.  Never fails.
+  void restart_as_libjpeg(int& next) {
+    n = 0;
+    hit_marker = false;
+    for (;;) {
+      while (p < end && *p != 0xFF) p++;                // next_marker: up to an 0xFF ...
+      const uint8_t* q = p;
+      while (q < end && *q == 0xFF) q++;                // ... and the byte behind the last of them
+      const int m = q < end ? *q : 0xD9;                // (the memory source ends every file with an EOI of its own)
+      if (q < end && m == 0x00) {                       // a stuffed 0xFF is no marker
+        p = q + 1;
+        continue;
+      }
+      bool take = false, leave = false;
+      if (m == 0xD0 + next) {
+        take = true;
+      } else if (m < 0xC0) {
+        // (invalid: passed over)
+      } else if (m < 0xD0 || m > 0xD7) {
+        leave = true;
+      } else {
+        const int ahead = (m - 0xD0 - next) & 7;
+        if (ahead == 1 || ahead == 2)
+          leave = true;
+        else if (ahead == 7 || ahead == 6) {
+          // (a prior restart: passed over)
+        } else {
+          take = true;
+        }
+      }
+      if (take) {
+        p = q < end ? q + 1 : end;
+        starved = false;  // (insufficient_data is cleared only when no marker is left unread)
+        break;
+      }
+      if (leave) {
+        hit_marker = true;  // (p stays at the marker: no data until it has been dealt with)
+        break;
+      }
+      p = q < end ? q + 1 : end;
+      if (p >= end) {       // (only EOIs from here on: one of them is "left")
+        hit_marker = true;
+        break;
+      }
+    }
+    next = (next + 1) & 7;
+  }
 };
 
 inline int extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }  // F.2.2.1
@@ -776,11 +829,11 @@ extern "C" int vsfo_jpeg_decode_gray(const uint8_t* data, size_t nbytes, uint8_t
   std::vector<uint8_t> plane((size_t)pw * ph);
   BitReader br{data + pos, data + nbytes};
   int pred[4] = {0, 0, 0, 0};
-  int until_restart = restart_interval;
+  int until_restart = restart_interval, next_restart = 0;
   for (int my = 0; my < mcus_y; my++)
     for (int mx = 0; mx < mcus_x; mx++) {
       if (restart_interval && until_restart == 0) {
-        if (!br.restart()) return -1;
+        br.restart_as_libjpeg(next_restart);
         pred[0] = pred[1] = pred[2] = pred[3] = 0;
         until_restart = restart_interval;
       }

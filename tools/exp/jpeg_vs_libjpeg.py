@@ -21,8 +21,8 @@ rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 
 W, H = 160, 120
 img = synth.stereo_pair(W, H, 5, n_objects=60)[0]
 base = []
-for kw in (dict(quality=85), dict(quality=40, optimize=True), dict(quality=90, restart_marker_blocks=5), dict(quality=80, progressive=True),
-           dict(quality=60, progressive=True, restart_marker_blocks=7)):
+for kw in (dict(quality=85), dict(quality=40, optimize=True), dict(quality=90, restart_marker_blocks=5), dict(quality=70, restart_marker_blocks=1),
+           dict(quality=80, progressive=True), dict(quality=60, progressive=True, restart_marker_blocks=7)):
     b = io.BytesIO()
     Image.fromarray(img, "L").save(b, "JPEG", **kw)
     base.append((str(kw), b.getvalue()))
@@ -31,13 +31,37 @@ for kw in (dict(quality=75, subsampling=2), dict(quality=75, subsampling=2, prog
     b = io.BytesIO()
     Image.fromarray(rgb, "RGB").save(b, "JPEG", **kw)
     base.append((str(kw), b.getvalue()))
+
+
+def rst_damage(f, rng):
+    """Damage 6: restart markers renumbered, destroyed, turned into invalid codes or into stuffed bytes (files without any:
+    bit flips instead)."""
+    b = bytearray(f)
+    sos = b.find(b"\xff\xda")
+    idx = [i for i in range(sos, len(b) - 1) if b[i] == 0xFF and 0xD0 <= b[i + 1] <= 0xD7]
+    if not idx:
+        return mutate(f, rng, 0)
+    for _ in range(int(rng.integers(1, 4))):
+        i = idx[int(rng.integers(len(idx)))]
+        how = int(rng.integers(4))
+        if how == 0:
+            b[i + 1] = 0xD0 + int(rng.integers(8))
+        elif how == 1:
+            b[i] = int(rng.integers(255))
+        elif how == 2:
+            b[i + 1] = int(rng.integers(1, 0xC0))
+        else:
+            b[i + 1] = 0x00
+    return bytes(b)
+
+
 dev = torch.device("cuda", 0)
 tab = {}
 with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
     for it in range(n):
         k = int(rng.integers(len(base)))
-        kind = int(rng.integers(6))
-        f = mutate(base[k][1], rng, kind)
+        kind = int(rng.integers(7))
+        f = rst_damage(base[k][1], rng) if kind == 6 else mutate(base[k][1], rng, kind)
         st, ref, warn = jpeg_ref.imdecode_gray(f, W, H)
         d = torch.full((H, W), 0x5A, dtype=torch.uint8, device=dev)
         mine = "read"

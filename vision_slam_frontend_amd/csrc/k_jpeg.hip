@@ -74,6 +74,7 @@ struct BitReader {
   int n;
   bool marker;            // a marker has been met: zero bits are fed from here on (until restart())
   int pad = 0;            // zero bits fed so far: the walk has run out of data once it has taken one of them (starved())
+  bool dry = false;       // ... and stays so over a restart whose marker was not the one due (restart_as_libjpeg)
   __device__ __forceinline__ uint32_t at(uint32_t p) const { return (in_constant(words)[p >> 2] >> (8u * (p & 3u))) & 255u; }
   __device__ __forceinline__ void fill() {  // >= 33 bits available afterwards (a code + its extra bits need <= 16 + 15)
     if (n <= 32 && !marker && pos + 4u <= len) {
@@ -115,7 +116,7 @@ struct BitReader {
     }
   }
   // jdhuff.c's insufficient_data: a bit has been taken that the data did not hold
-  __device__ __forceinline__ bool starved() const { return n < pad; }
+  __device__ __forceinline__ bool starved() const { return dry || n < pad; }
   __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (n - k)) & ((1u << k) - 1u); }
   __device__ __forceinline__ void drop(int k) { n -= k; }
   __device__ __forceinline__ int get_bit() {  // one raw bit
@@ -163,7 +164,61 @@ struct BitReader {
     const uint32_t vi = (uint32_t)(in_constant(h->valoff)[l] + code) & 255u;
     return (int)((in_constant(reinterpret_cast<const uint32_t*>(h->vals))[vi >> 2] >> (8u * (vi & 3u))) & 255u);
   }
-  __device__ __forceinline__ bool restart() {  // drop the remaining bits, step over RSTn
+  // A restart of a sequential scan as libjpeg makes it (jdhuff.c process_restart, jdmarker.c read_restart_marker and
+  // jpeg_resync_to_restart): the bits left are dropped and the next marker is looked for (bytes in front of it are passed
+  // over).  The restart marker that is due (`next`: 0..7) is taken and the interval has its data.  Otherwise: a code below
+  // 0xC0 is passed over and the search goes on; any other marker that is no RSTn stays where it is, and so does an RSTn one
+  // or two numbers AHEAD of the one due -- the interval is decoded from no data and the marker is met again at the next
+  // boundary; an RSTn one or two numbers BEHIND is passed over; any other RSTn is taken as if it were the one due.
+  // "Out of data" (insufficient_data) is cleared only when no marker is left unread.
+  __device__ __forceinline__ void restart_as_libjpeg(int& next) {
+    const bool was = starved();
+    acc = 0;
+    n = 0;
+    pad = 0;
+    marker = false;
+    bool take = false;
+    for (;;) {
+      while (pos < len && at(pos) != 0xFFu) pos++;
+      uint32_t q = pos;
+      while (q < len && at(q) == 0xFFu) q++;
+      const int m = q < len ? (int)at(q) : 0xD9;  // (the memory source ends every file with an EOI of its own)
+      if (q < len && m == 0) {                     // a stuffed 0xFF is no marker
+        pos = q + 1;
+        continue;
+      }
+      bool leave = false;
+      if (m == 0xD0 + next) {
+        take = true;
+      } else if (m < 0xC0) {
+        // (invalid: passed over)
+      } else if (m < 0xD0 || m > 0xD7) {
+        leave = true;
+      } else {
+        const int ahead = (m - 0xD0 - next) & 7;
+        if (ahead == 1 || ahead == 2)
+          leave = true;
+        else if (ahead != 7 && ahead != 6)
+          take = true;
+      }
+      if (take) {
+        pos = q < len ? q + 1 : len;
+        break;
+      }
+      if (leave) {
+        marker = true;  // (pos stays at the marker: no data until it has been dealt with)
+        break;
+      }
+      pos = q < len ? q + 1 : len;
+      if (pos >= len) {  // (only EOIs from here on: one of them is "left")
+        marker = true;
+        break;
+      }
+    }
+    dry = take ? false : was;
+    next = (next + 1) & 7;
+  }
+  __device__ __forceinline__ bool restart() {  // drop the remaining bits, step over RSTn (the progressive decoder's)
     // (fill() never pulls bytes from beyond a marker, so `pos` is at the marker when the interval's data is used up)
     acc = 0;
     n = 0;
@@ -302,7 +357,7 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
   BitReader br{reinterpret_cast<const uint32_t*>(stream + im.stream_off), 0u, im.stream_len, 0ull, 0, false};
   (void)stream_total;
   int pred0 = 0, pred1 = 0, pred2 = 0;
-  int mcu = 0, until_restart = restart_interval;
+  int mcu = 0, until_restart = restart_interval, next_restart = 0;
   bool broken = false;
   // one block: DC difference + AC run / size pairs (T.81 F.2.2.1, F.2.2.2); coefficients go to `coef` in natural order
   // (LUMA) or nowhere (chroma is parsed only)
@@ -340,10 +395,7 @@ __global__ __launch_bounds__(64) void jpeg_gray_kernel(const DevImage* __restric
     int count = 0;
     while (mcu < nmcu && count + luma_per_mcu <= kGroupBlocks && !broken) {
       if (restart_interval && until_restart == 0) {
-        if (!br.restart()) {
-          broken = true;
-          break;
-        }
+        br.restart_as_libjpeg(next_restart);
         pred0 = pred1 = pred2 = 0;
         until_restart = restart_interval;
       }

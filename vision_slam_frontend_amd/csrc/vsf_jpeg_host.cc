@@ -134,12 +134,17 @@ struct ProgFile {                 // what a progressive file adds to its image d
 // Bytes behind the end of the file read as the memory source supplies them: 0xFF 0xD9 over and over.
 // p[0..n): everything behind the scan header; restart_interval > 0: RSTn markers in the data belong to the decoder.
 // Returns false for a file libjpeg gives up on.
-static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
+// *rst_in_step (restart_interval > 0): the data hold exactly `intervals` - 1 restart markers, numbered 0, 1, ... 7, 0 ... in
+// turn, and EOI behind them -- what the parallel decoder's interval table assumes; any other file of the kind goes to the
+// one-wave decoder, which looks for its restart markers as libjpeg does.
+static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval, size_t intervals, bool* rst_in_step) {
   auto at = [&](size_t i) -> int { return i < n ? p[i] : (((i - n) & 1) ? 0xD9 : 0xFF); };
   size_t i = 0;
   const size_t hard_end = n + 4096;  // (the virtual tail is EOI after EOI: a walk that gets this far has met one)
   // where the entropy decoder stops: the first marker in the data
   int m = -1;
+  size_t n_rst = 0;
+  bool in_step = true;
   // (the data of an undamaged file are scanned to their end here: memchr from 0xFF to 0xFF, not byte by byte)
   auto next_ff = [&](size_t from) -> size_t {
     if (from < n) {
@@ -155,10 +160,15 @@ static bool baseline_tail_ok(const uint8_t* p, size_t n, int restart_interval) {
     const int c = at(j);
     i = j + 1;
     if (c == 0) continue;                                                // a stuffed 0xFF
-    if (restart_interval > 0 && c >= 0xD0 && c <= 0xD7) continue;        // the decoder's own
+    if (restart_interval > 0 && c >= 0xD0 && c <= 0xD7) {                // the decoder's own
+      if (c - 0xD0 != (int)(n_rst & 7)) in_step = false;
+      n_rst++;
+      continue;
+    }
     m = c;
     break;
   }
+  if (rst_in_step) *rst_in_step = in_step && n_rst + 1 == intervals && m == 0xD9;
   while (m >= 0 && i < hard_end) {
     if (m == 0xD9) return true;                                          // EOI
     if (m == 0xD8) return false;                                         // JERR_SOI_DUPLICATE
@@ -559,8 +569,13 @@ vsf_status vsf_jpeg_plan(const uint8_t* const* jpeg, const size_t* nbytes, int n
     std::vector<uint8_t> ok((size_t)n, 1);
     auto walk = [&](int i0, int i1) {
       for (int i = i0; i < i1; i++)
-        if (images[i].n_scans == 0)
-          ok[i] = baseline_tail_ok(jpeg[i] + plan->scan_begin[i], nbytes[i] - plan->scan_begin[i], images[i].restart_interval) ? 1 : 0;
+        if (images[i].n_scans == 0) {
+          const int ri = images[i].restart_interval;
+          const size_t intervals = ri > 0 ? ((size_t)images[i].mcus_x * images[i].mcus_y + ri - 1) / ri : 0;
+          bool in_step = true;
+          ok[i] = baseline_tail_ok(jpeg[i] + plan->scan_begin[i], nbytes[i] - plan->scan_begin[i], ri, intervals, &in_step) ? 1 : 0;
+          if (ri > 0 && !in_step) images[i].par_ok = 0;  // (restart markers out of step: the one-wave decoder's)
+        }
     };
     size_t all = 0;
     for (int i = 0; i < n; i++) all += nbytes[i];
