@@ -107,3 +107,24 @@ def mutate(data: bytes, rng: np.random.Generator, kind: int | None = None) -> by
     else:              # random garbage after the headers
         f[body:] = bytes(rng.integers(0, 256, len(f) - body, dtype=np.uint8))
     return bytes(f)
+
+
+def rst_damage(data: bytes, rng: np.random.Generator) -> bytes:
+    """Restart markers renumbered, destroyed, turned into invalid codes or into stuffed bytes (a file without any: bit flips)."""
+    b = bytearray(data)
+    sos = b.find(b"\xFF\xDA")
+    idx = [i for i in range(max(sos, 0), len(b) - 1) if b[i] == 0xFF and 0xD0 <= b[i + 1] <= 0xD7]
+    if not idx:
+        return mutate(data, rng, 0)
+    for _ in range(int(rng.integers(1, 4))):
+        i = idx[int(rng.integers(len(idx)))]
+        how = int(rng.integers(4))
+        if how == 0:
+            b[i + 1] = 0xD0 + int(rng.integers(8))
+        elif how == 1:
+            b[i] = int(rng.integers(255))
+        elif how == 2:
+            b[i + 1] = int(rng.integers(1, 0xC0))
+        else:
+            b[i + 1] = 0x00
+    return bytes(b)

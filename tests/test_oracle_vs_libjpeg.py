@@ -80,3 +80,38 @@ def test_oracle_jpeg_is_libjpegs_also_on_damaged_files(oracle):
     assert silent > 80, silent
     assert gave_up > 300 and refused_too >= 0.98 * gave_up, (gave_up, refused_too)
     assert cut > 60 and cut_equal >= 0.95 * cut, (cut, cut_equal)
+
+
+def test_restart_intervals_as_libjpeg_restarts(oracle):
+    """Baseline files with restart intervals under every kind of damage (bit flips, truncation, stray bytes, restart markers
+    renumbered / destroyed / turned into invalid codes): process_restart and jpeg_resync_to_restart restated -- whatever
+    libjpeg reads, warnings or not, the oracle reads to the same bytes."""
+    import jpeg_ref
+    from jpeg_mutate import mutate, rst_damage
+    from vision_slam_frontend_amd import synth
+    if not jpeg_ref.available():
+        pytest.skip("no libjpeg.so.8 to build tests/cpp/jpeg_ref.c against")
+    W, H = 160, 120
+    img = synth.stereo_pair(W, H, 5, n_objects=60)[0]
+    base = []
+    for kw in (dict(quality=90, restart_marker_blocks=5), dict(quality=70, restart_marker_blocks=20), dict(quality=80, restart_marker_blocks=1)):
+        b = io.BytesIO()
+        Image.fromarray(img, "L").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
+    rgb = np.stack([img, img[::-1], img[:, ::-1]], 2)
+    b = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(b, "JPEG", quality=75, subsampling=2, restart_marker_blocks=3)
+    base.append(b.getvalue())
+    rng = np.random.Generator(np.random.PCG64(8))
+    read = 0
+    for it in range(1200):
+        data = base[int(rng.integers(len(base)))]
+        kind = int(rng.integers(4))
+        f = rst_damage(data, rng) if kind == 3 else mutate(data, rng, kind)
+        st, ref, warn = jpeg_ref.imdecode_gray(f, W, H)
+        if st != 0:
+            continue
+        mine = oracle.jpeg_decode_gray(f)
+        np.testing.assert_array_equal(mine, ref, err_msg="file %d (damage %d)" % (it, kind))
+        read += 1
+    assert read > 800, read

@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import jpeg_ref  # noqa: E402
-from jpeg_mutate import mutate  # noqa: E402
+from jpeg_mutate import mutate, rst_damage  # noqa: E402
 from vision_slam_frontend_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
@@ -31,28 +31,6 @@ for kw in (dict(quality=75, subsampling=2), dict(quality=75, subsampling=2, prog
     b = io.BytesIO()
     Image.fromarray(rgb, "RGB").save(b, "JPEG", **kw)
     base.append((str(kw), b.getvalue()))
-
-
-def rst_damage(f, rng):
-    """Damage 6: restart markers renumbered, destroyed, turned into invalid codes or into stuffed bytes (files without any:
-    bit flips instead)."""
-    b = bytearray(f)
-    sos = b.find(b"\xff\xda")
-    idx = [i for i in range(sos, len(b) - 1) if b[i] == 0xFF and 0xD0 <= b[i + 1] <= 0xD7]
-    if not idx:
-        return mutate(f, rng, 0)
-    for _ in range(int(rng.integers(1, 4))):
-        i = idx[int(rng.integers(len(idx)))]
-        how = int(rng.integers(4))
-        if how == 0:
-            b[i + 1] = 0xD0 + int(rng.integers(8))
-        elif how == 1:
-            b[i] = int(rng.integers(255))
-        elif how == 2:
-            b[i + 1] = int(rng.integers(1, 0xC0))
-        else:
-            b[i + 1] = 0x00
-    return bytes(b)
 
 
 dev = torch.device("cuda", 0)
