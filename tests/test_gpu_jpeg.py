@@ -556,3 +556,47 @@ def test_damaged_files_libjpeg_reads_without_a_warning_decode_to_its_bytes():
     # what libjpeg gives up on (cv::imdecode returns nothing) is not handed on as an image either -- the marker walk of
     # jpeg_finish_decompress is restated on the host; the few files of restart-interval streams it cannot judge are the slack
     assert gave_up > 200 and refused_too >= 0.98 * gave_up, (gave_up, refused_too)
+
+
+def test_damaged_restart_interval_files_as_libjpeg_reads_them():
+    """Baseline files with restart intervals, damaged (bit flips, truncation, stray bytes, restart markers renumbered / destroyed
+    / made invalid): whatever the system's libjpeg reads -- with or without warnings -- the device reads to the same bytes: an
+    interval that runs dry ends gray, restart markers out of step are looked for as jpeg_resync_to_restart looks (such files take
+    the one-wave decoder, the others the parallel one)."""
+    import io
+
+    import torch
+    from PIL import Image
+    import jpeg_ref
+    from jpeg_mutate import mutate, rst_damage
+    from vision_slam_frontend_amd import capi, synth
+    if not jpeg_ref.available():
+        pytest.skip("no libjpeg.so.8 to build tests/cpp/jpeg_ref.c against")
+    W, H = 160, 120
+    img = synth.stereo_pair(W, H, 5, n_objects=60)[0]
+    base = []
+    for kw in (dict(quality=90, restart_marker_blocks=5), dict(quality=70, restart_marker_blocks=20), dict(quality=80, restart_marker_blocks=1)):
+        b = io.BytesIO()
+        Image.fromarray(img, "L").save(b, "JPEG", **kw)
+        base.append(b.getvalue())
+    rgb = np.stack([img, img[::-1], img[:, ::-1]], 2)
+    b = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(b, "JPEG", quality=75, subsampling=2, restart_marker_blocks=3)
+    base.append(b.getvalue())
+    rng = np.random.Generator(np.random.PCG64(8))
+    dev = torch.device("cuda", 0)
+    read = same = 0
+    with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
+        for it in range(800):
+            data = base[int(rng.integers(len(base)))]
+            kind = int(rng.integers(4))
+            f = rst_damage(data, rng) if kind == 3 else mutate(data, rng, kind)
+            st, ref, warn = jpeg_ref.imdecode_gray(f, W, H)
+            if st != 0:
+                continue
+            d = torch.full((H, W), 0x5A, dtype=torch.uint8, device=dev)
+            ctx.jpeg_decode_gray_batch([f], W, H, d.data_ptr(), W * H, W)
+            assert ctx.sync() == capi.VSF_OK
+            read += 1
+            same += bool(np.array_equal(d.cpu().numpy(), ref))
+    assert read > 500 and same >= 0.97 * read, (read, same)
