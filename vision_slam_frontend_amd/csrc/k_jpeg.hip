@@ -985,15 +985,19 @@ struct ParWin {
 // index (0: a DC size comes next) -- read at bit position q.  Straight-line code but for the second table lookup: the
 // lanes of a wave sit at different places of different blocks, so every branch in here would be taken by somebody in
 // every round.  Returns true when the symbol ends its block; kk / val: the coefficient it carries (kk < 0: none).
+// kClip: bits from `clip` on read as zero (an interval of a file with restart intervals: behind its end libjpeg feeds zero
+// bits, while the clean stream goes on with the next interval's data).
+template <bool kClip = false>
 __device__ __forceinline__ bool par_symbol(const ParGeom& G, ParWin& W, lds_u16 tab, uint32_t& q, int c, int& k, int& kk,
-                                           int& val) {
+                                           int& val, uint32_t clip = 0xFFFFFFFFu) {
   // the 32 bits from q on (a code + its extra bits need <= 27, so q moves on by at most one dword per symbol)
   if ((q >> 5) - W.gbase != W.jb) {
     W.jb++;
     W.w0 = W.w1;
     W.w1 = W.row(G, W.jb + 1u);
   }
-  const uint32_t x = (uint32_t)(((((uint64_t)W.w0) << 32) | W.w1) >> (32u - (q & 31u)));
+  uint32_t x = (uint32_t)(((((uint64_t)W.w0) << 32) | W.w1) >> (32u - (q & 31u)));
+  if (kClip && q + 32u > clip) x = q >= clip ? 0u : x & (0xFFFFFFFFu << (32u - (clip - q)));
   const bool is0 = c < G.lum, is1 = c < G.lum + G.n1;
   const bool isdc = k == 0;
   const uint32_t slot = (((isdc ? G.dc_slots : G.ac_slots) >> (is0 ? 0 : (is1 ? 8 : 16))) & 255u) * kHuff16;
@@ -1101,6 +1105,7 @@ __device__ __forceinline__ void par_count(const ParGeom& G, ParWin& W, lds_u16 t
 // decode_mcu, insufficient_data): the MCU in which the data run out is decoded to its end on zero bits, every MCU behind it
 // is left zero -- uniform gray -- and never loops for ever: every symbol consumes at least one bit of at most 2^32.
 constexpr int kBlkStride = 33;  // dwords between the LDS blocks of neighbouring threads (32 + 1: the banks spread)
+template <bool kClip = false>
 __device__ __forceinline__ uint32_t par_write(const ParGeom& G, ParWin& W, lds_u16 tab, lds_u8 zz, uint32_t* blk_wave,
                                               int lane, uint32_t limit, uint32_t q, int c, int k, uint32_t g, int pred,
                                               uint32_t* __restrict__ coef32, uint32_t total_blocks, bool finish,
@@ -1122,7 +1127,7 @@ __device__ __forceinline__ uint32_t par_write(const ParGeom& G, ParWin& W, lds_u
       int kk, val;
       const bool more = g + done < total_blocks;
       const bool lum = c < G.lum;
-      const bool end = par_symbol(G, W, tab, q, c, k, kk, val);
+      const bool end = par_symbol<kClip>(G, W, tab, q, c, k, kk, val, data_end);
       if (lum && !skip && more && kk >= 0) {
         if (kk == 0) val = pred += val;  // (a block's DC symbol is its first: never inside a skipped rest)
         mine[zz[kk]] = (int16_t)val;
@@ -1361,7 +1366,7 @@ __global__ __launch_bounds__(kParThreads) void jpeg_par_decode_kernel(const DevI
       const uint32_t g = j * (uint32_t)ri * (uint32_t)G.m;
       const uint32_t blocks = live ? min((uint32_t)ri, nmcu - j * (uint32_t)ri) * (uint32_t)G.m : 0u;
       // (an interval whose data run out before its blocks do: gray MCUs, a warning in libjpeg)
-      (void)par_write(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, 0u, begin, 0, 0, g, 0, coef32, g + blocks, true, end);
+      (void)par_write<true>(G, W, tab, zz, s_blk + wid * 64 * kBlkStride, lane, 0u, begin, 0, 0, g, 0, coef32, g + blocks, true, end);
     }
     if (broken) atomicOr(status, 2);
     return;
