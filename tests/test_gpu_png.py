@@ -374,7 +374,13 @@ def test_imdecode_tells_jpeg_from_png(capi, oracle):
     files, want = [], []
     for k, img in enumerate(imgs):
         b = io.BytesIO()
-        if k in (0, 1, 4, 6):
+        if k == 4:    # a colour PNG among them: libpng's rgb_to_gray (the integer sum, truncated)
+            rgb = np.dstack([img, np.roll(img, 3, 0), 255 - img])
+            Image.fromarray(rgb, "RGB").save(b, "PNG")
+            files.append(b.getvalue())
+            r, g, bl = (rgb[..., i].astype(np.uint32) for i in range(3))
+            want.append(((9797 * r + 19234 * g + 3737 * bl) >> 15).astype(np.uint8))
+        elif k in (0, 1, 6):
             Image.fromarray(img, "L").save(b, "PNG", compress_level=k % 3 * 3)
             files.append(b.getvalue())
             want.append(img)
