@@ -13,6 +13,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "vision_slam_frontend_amd" / "csrc"
 LIB = ROOT / "vision_slam_frontend_amd" / "libvsf_jpeg_host_asan.so"
@@ -121,6 +123,27 @@ for it in range(2000):
     assert st in (0, 1, 4), st   # VSF_OK, VSF_ERR_INVALID_ARG, VSF_ERR_UNSUPPORTED -- never anything else, never a crash
     ok += st == 0
     bad += st != 0
+# The same damage, one file at a time, against the system's libjpeg driven as cv::imdecode drives it (tests/jpeg_ref.py): what
+# libjpeg reads without a warning the parser accepts; what libjpeg gives up on while decoding or in jpeg_finish_decompress (a
+# marker code it does not know behind the scan's data, a second frame ...) the parser refuses -- the marker walk of
+# vsf_jpeg_host.cc (baseline_tail_ok), here under the sanitizers.
+import jpeg_ref
+agree = gave_up = refused_too = 0
+if jpeg_ref.available():
+    for it in range(1500):
+        name = names[int(rng.integers(len(names)))]
+        h, w = expected[name].shape
+        f = mutate(files[name], rng)
+        st, _ = check([f], w, h)
+        ref, _, warn = jpeg_ref.imdecode_gray(f, w, h)
+        if ref == 0 and warn == 0:
+            assert st == 0, (it, name, st, "libjpeg reads it without a warning")
+            agree += 1
+        elif ref == 2:
+            gave_up += 1
+            refused_too += st != 0
+    assert agree > 50 and gave_up > 200 and refused_too >= 0.97 * gave_up, (agree, gave_up, refused_too)
+    print("libjpeg: %d silent reads accepted, %d of %d give-ups refused" % (agree, refused_too, gave_up))
 for junk in (b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"\xff\xd8\xff\xda\x00", bytes(100), b"\xff\xd8" + b"\xff\xc0" * 50):
     st, _ = check([junk], 8, 8)
     assert st in (1, 4), (junk[:8], st)
@@ -143,10 +166,13 @@ def test_jpeg_host_parser_under_asan_and_ubsan(tmp_path):
     p = subprocess.run([sys.executable, str(script), str(LIB), str(GOLD), str(Path(__file__).resolve().parent)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-4000:])
-    assert p.stdout.strip().startswith("done") and "ok=" in p.stdout
+    assert p.stdout.strip().splitlines()[-1].startswith("done") and "ok=" in p.stdout
     ok = int(p.stdout.split("ok=")[1].split()[0])
     refused = int(p.stdout.split("refused=")[1].split()[0])
     assert ok > 300 and refused > 100  # the mutations reached both the accepting and the refusing paths
+    import jpeg_ref
+    if jpeg_ref.available():  # (then the child has asked libjpeg, too)
+        assert "give-ups refused" in p.stdout, p.stdout[-500:]
     # the instrumentation is live: a deliberate one-byte heap overflow (VSF_ASAN_SELFTEST) aborts the same child
     q = subprocess.run([sys.executable, str(script), str(LIB), str(GOLD), str(Path(__file__).resolve().parent)],
                        capture_output=True, text=True, env=dict(env, VSF_ASAN_SELFTEST="1"), timeout=600)
