@@ -359,42 +359,55 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
                                 int n_frames, const uint64_t* d_pairs, const int32_t* d_npairs, int n_pairs,
                                 uint8_t* d_payload, size_t payload_cap);
 
-/* ---------------- one submission per Frontend::ObserveImage (slam_frontend.cc:400-472) ---------------- */
+/* ---------------- Frontend::ObserveImage (slam_frontend.cc:400-472) as a queue of stereo frames ---------------- */
 
-/* Everything ObserveImage computes between OdomCheck and the node / factor bookkeeping, for ONE stereo frame given as
- * host images, in one submission: upload (pinned staging), ExtractFeatures x 2 (cc:411-412), GetMatches (cc:414),
- * RemoveAmbigStereo (cc:417, the threshold lives in the context like the reference's file-static), GetFeatureMatches
- * against the <= frame_life frames kept from earlier calls (cc:424-434; their filtered descriptors stay resident in HBM),
- * Calculate3DPoints (cc:437), VisionFeature assembly + UndistortFeaturePoints (cc:438-443), one compact result.  The
- * frame then joins the window and the oldest leaves once frame_life are kept (cc:467-470).
+/* Everything ObserveImage computes between OdomCheck and the node / factor bookkeeping, for stereo frames given as host
+ * images: upload (pinned staging), ExtractFeatures x 2 (cc:411-412), GetMatches (cc:414), RemoveAmbigStereo (cc:417, the
+ * threshold lives in the context like the reference's file-static), GetFeatureMatches against the <= frame_life frames kept
+ * from earlier calls (cc:424-434; their filtered descriptors stay resident in HBM), Calculate3DPoints (cc:437),
+ * VisionFeature assembly + UndistortFeaturePoints (cc:438-443), one compact result per frame.  Every frame joins the window
+ * and the oldest leaves once frame_life are kept (cc:467-470).
+ *
+ * vsf_observe_submit copies the two images into pinned staging and returns a ticket; vsf_observe_collect waits for that
+ * frame and hands over its result; vsf_observe_stereo is submit + collect.  Frontend::ObserveImage returns what OdomCheck
+ * decided (cc:404-409), so nothing in the reference's control flow needs a frame's result before the next frame arrives: a
+ * caller may keep up to `depth` frames submitted and not collected.  Frames that wait are COALESCED: they leave for the GPU
+ * as one batched extraction + one batched tail (the threshold chain and the temporal window run through the batch in frame
+ * order) -- a frame's chain of ~30 launch-bound kernels costs the same whether it carries one frame or thirty.  A batch
+ * leaves whenever fewer than `in_flight` batches are on the GPU (a lone frame at once: the synchronous call is a batch of
+ * one), when a full batch (max_images / 2 frames, at most `depth`) waits, or when a waiting frame is collected; while the
+ * GPU is busy frames accumulate, so the batch size follows the caller's rate.  Results are those of one frame at a time, bit
+ * for bit, whatever the batches were (tests/test_gpu_observe.py).
+ * Tickets are collected in the order they were issued; a submit beyond `depth` uncollected frames returns
+ * VSF_ERR_INVALID_ARG.  Consecutive frames with different calibrations or best_percent never share a batch; frame_life
+ * changes only while the queue is empty (the window starts over).
+ *
  * Result (little endian, *out_bytes bytes, at most vsf_observe_capacity()):
  *   u32 magic 'VSFO', n_pairs, nfeat, total_bytes, n_left, n_right (raw keypoints), n_stereo_matches, n_points,
- *   f32 mean residual, threshold applied, threshold in force afterwards, u32 overflow, 4 x u32 reserved     (64 bytes)
+ *   f32 mean residual, threshold applied, threshold in force afterwards, u32 result overflow, u32 extraction overflow
+ *   (either makes the collect return VSF_ERR_CAPACITY -- for THIS frame only), 3 x u32 reserved              (64 bytes)
  *   u32 npairs[n_pairs], padded to a multiple of 4 words
  *   vsf_vision_feature x nfeat
  *   vsf_feature_match x npairs[p], p = 0 .. n_pairs-1: the temporal factors, oldest kept frame first (the order of
  *     frame_list_), and LAST the right->left matches of Calculate3DPoints in sorted order (n_pairs = kept frames + 1)
  *   vsf_keypoint x nfeat, then 32-byte descriptors x nfeat: the left frame as RemoveAmbigStereo rebuilt it (cc:396)
- * Same results as the separate calls (tests/test_gpu_observe.py).  vsf_observe_reset forgets the window and puts the
- * threshold back to 10000 (cc:353). */
+ * vsf_observe_reset forgets the window and puts the threshold back to 10000 (cc:353). */
 size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life);
+/* depth: frames that may be submitted and not collected (0: max_images / 2; up to 1024 -- the staging and result rings are
+ * pinned host memory, depth x (2 images + vsf_observe_capacity)); a batch holds min(depth, max_images / 2) frames at most.
+ * min_batch (0 = 1): while the GPU is busy, fewer waiting frames than this do not leave (throughput over latency; a collect
+ * still sends them).  in_flight (0 = 2, at most 3): batches on the GPU at a time.  Call it before the first submit or while
+ * the queue is empty; changing depth rebuilds the queue (window and threshold start over). */
+vsf_status vsf_observe_configure(vsf_ctx* ctx, int depth, int min_batch, int in_flight);
 vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
                               size_t cap, size_t* out_bytes);
-/* The same, split in two so that the caller need not wait for the GPU between frames: vsf_observe_submit copies the two
- * images into pinned staging, queues the whole chain and returns a ticket; vsf_observe_collect waits for that frame and
- * hands over its result (same layout and status as vsf_observe_stereo, which is submit + collect).  Frontend::ObserveImage
- * returns what OdomCheck decided (slam_frontend.cc:404-409), so nothing in the reference's control flow needs a frame's
- * result before the next frame arrives.  A context keeps max_images / 2 frames in flight (at most six; four is what pays
- * on an MI355X: 5 000 frames/s at the reference's 10 000 features, 7 800 at 2 000 -- beyond four the slots' streams share
- * hardware queues and take turns): every frame runs on its slot's stream and buffers from upload to result, and its tail -- which
- * carries the RemoveAmbigStereo threshold and the temporal window from frame to frame -- first waits for the previous
- * frame's tail, so the tails stay in frame order.
- * Tickets are collected in the order they were issued; a submit whose slot still holds an uncollected frame returns
- * VSF_ERR_INVALID_ARG.  Results are those of the synchronous call, bit for bit. */
 vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, int64_t* ticket);
 vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_t cap, size_t* out_bytes);
+/* The same without the copy: *out points at the result inside the context's pinned result ring; it stays valid until `depth`
+ * further frames have been submitted (the first word, the magic, reads 0 there). */
+vsf_status vsf_observe_collect_view(vsf_ctx* ctx, int64_t ticket, const uint8_t** out, size_t* out_bytes);
 vsf_status vsf_observe_reset(vsf_ctx* ctx);
 
 /* SURVEY section 8(f) row f4, the decode itself: DecodeImage's cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE)

@@ -213,3 +213,53 @@ def test_fused_observe_equals_call_by_call():
         assert ia == ib and ka.tobytes() == kb.tobytes()
         np.testing.assert_array_equal(da, db)
     assert a["wire"] == b["wire"]
+
+
+@pytest.mark.parametrize("depth,batch,min_batch", [(1, 1, 0), (4, 4, 0), (32, 32, 0), (32, 8, 4)])
+def test_queued_observe_image_books_the_synchronous_problem(depth, batch, min_batch):
+    """slam::Frontend with its ObserveImage queue at depths 1, 4 and 32 (frames leave for the GPU in batches, results are
+    booked late with the odometry of their own call): the SLAMProblem -- nodes, features, vision and odometry factors, as
+    ROS wire bytes -- and the kept frames equal the synchronous mode's, over 40 frames with three frames without stereo
+    matches (NaN thresholds behind them), the odometry gate refusing every fifth call, and a read of the problem (which
+    drains the queue) in the middle."""
+    from vision_slam_frontend_amd import frontend, synth
+    sc = synth.Scene(320, 240, n_objects=400)
+    frames = [(sc.render(f % 9, 0), sc.render(f % 9, 1)) for f in range(40)]
+    for k in (2, 21, 22):
+        frames[k] = (frames[k][0], np.full_like(frames[k][1], 128))
+    q = np.array([1, 0, 0, 0], np.float32)
+    runs = []
+    for pipelined in (False, True):
+        fe = frontend.Frontend(320, 240, nfeatures=600, fundamental=F_RECT, frame_life=3)
+        fe.set_pipelined(pipelined)
+        if pipelined:
+            fe.set_queue(depth, batch, min_batch)
+        fe.observe_odometry([0, 0, 0], q, 0.0)
+        mid = None
+        for f, (l, r) in enumerate(frames):
+            fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
+            assert fe.observe_image(l, r) is True
+            if f % 5 == 4:  # the odometry gate holds a frame back while others are still in the queue
+                fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.5 + f)
+                assert fe.observe_image(l, r) is False
+            if f == 25:
+                mid = (fe.num_poses, fe.serialize_problem())
+        runs.append(dict(mid=mid, wire=fe.serialize_problem(), nodes=fe.nodes(), factors=fe.vision_factors(),
+                         frames=[fe.frame(i) for i in range(3)], thr=np.float32(fe.stereo_ambig_constraint)))
+        fe.close()
+    a, c = runs
+    assert a["mid"][0] == c["mid"][0] == 26 and a["mid"][1] == c["mid"][1]
+    assert a["wire"] == c["wire"] and len(a["nodes"]) == len(c["nodes"]) == 40
+    assert a["thr"].tobytes() == c["thr"].tobytes()
+    for na, nc in zip(a["nodes"], c["nodes"]):
+        assert na["node_idx"] == nc["node_idx"] and na["timestamp"] == nc["timestamp"]
+        np.testing.assert_array_equal(na["pose"], nc["pose"])
+        assert na["features"].tobytes() == nc["features"].tobytes()
+    assert len(a["factors"]) == len(c["factors"]) == 0 + 1 + 2 + 3 * 37
+    for (a0, a1, ap), (c0, c1, cp) in zip(a["factors"], c["factors"]):
+        assert (a0, a1) == (c0, c1)
+        np.testing.assert_array_equal(ap, cp)
+    for (ia, ka, da), (ic, kc, dc) in zip(a["frames"], c["frames"]):
+        assert ia == ic and ka.tobytes() == kc.tobytes()
+        np.testing.assert_array_equal(da, dc)
+    assert [len(n["features"]) for n in a["nodes"]][21:24] == [0, 0, 0] and len(a["nodes"][24]["features"]) > 20

@@ -115,8 +115,8 @@ def _same_observation(a: dict, b: dict):
 
 @pytest.mark.parametrize("slots", [2, 3, 4, 6])
 def test_frames_in_flight_equal_the_synchronous_calls(slots):
-    """vsf_observe_submit / vsf_observe_collect with two to six frames in flight (contexts with max_images = 2 x slots: every
-    frame on its slot's stream, the tails chained by events) return, frame for frame and byte for byte, what the
+    """vsf_observe_submit / vsf_observe_collect with two to six frames in the queue (contexts with max_images = 2 x slots:
+    the queue's default depth; waiting frames leave as batches) return, frame for frame and byte for byte, what the
     synchronous vsf_observe_stereo returns -- across the window filling and sliding, the frame without stereo matches and
     the NaN threshold after it, whose state travels from tail to tail on the device."""
     from vision_slam_frontend_amd import capi, frontend, synth
@@ -149,6 +149,97 @@ def test_frames_in_flight_equal_the_synchronous_calls(slots):
     for g, w in zip(got, want):
         _same_observation(w, g)
     assert sum(len(f["features"]) for f in want) > 100
+
+
+def _sequence(n, w=320, h=240):
+    from vision_slam_frontend_amd import synth
+    sc = synth.Scene(w, h, n_objects=400)
+    frames = [(sc.render(f % 11, 0), sc.render(f % 11, 1)) for f in range(n)]
+    for k in (3, 17, 18):  # no stereo match: a NaN threshold for the frame behind it (quirk Q3), twice in a row at 17, 18
+        if k < n:
+            frames[k] = (frames[k][0], np.full_like(frames[k][1], 128))
+    return frames
+
+
+@pytest.mark.parametrize("depth,batch,min_batch", [(1, 1, 0), (4, 4, 0), (32, 32, 0), (32, 8, 0), (32, 32, 12), (7, 3, 3)])
+def test_queue_depths_equal_the_synchronous_calls(depth, batch, min_batch):
+    """The queue at depths 1, 4 and 32 (batches of up to `batch` frames; with min_batch, frames wait for company while the
+    GPU is busy): 45 frames submitted as fast as the queue takes them -- so that batches of every size form, cut across the
+    window filling, the frames without stereo matches and the NaN thresholds behind them -- return byte for byte what the
+    synchronous calls return, on their own tickets."""
+    from vision_slam_frontend_amd import capi, frontend
+    frames = _sequence(45)
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    bp = float(np.float32(0.3))
+    with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
+        want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
+    with capi.Context(capi.default_params(320, 240, max_images=2 * batch, nfeatures=NF)) as ctx:
+        ctx.observe_configure(depth, min_batch, 0)
+        got, tickets = [], []
+        for l, r in frames:
+            if len(tickets) == depth:
+                got.append(ctx.observe_collect(tickets.pop(0), frame_life=LIFE))
+            tickets.append(ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE))
+        with pytest.raises(capi.VsfError):
+            ctx.observe_submit(*frames[0], calib, best_percent=bp, frame_life=LIFE)  # the queue is full
+        while tickets:
+            got.append(ctx.observe_collect(tickets.pop(0), frame_life=LIFE))
+    assert len(got) == len(want) == len(frames)
+    for k, (g, w) in enumerate(zip(got, want)):
+        _same_observation(w, g)
+    assert [len(w["features"]) for w in want][17:20] == [0, 0, 0] and len(want[20]["features"]) > 20
+    assert np.isnan(want[18]["threshold"]) and np.isnan(want[19]["threshold"]) and np.isfinite(want[20]["threshold"])
+
+
+def test_a_batch_is_cut_where_the_parameters_change():
+    """Frames that wait with another best_percent or another calibration than the frame in front of them never share its
+    batch; results equal the synchronous calls with the same per-frame parameters."""
+    from vision_slam_frontend_amd import capi, frontend
+    frames = _sequence(12)
+    F2 = F_RECT.copy()
+    F2[2, 2] = 1.5  # (a constant added to every residual: another threshold chain)
+    calibs = [frontend.default_calibration().set("fundamental", F_RECT if (k // 3) % 2 == 0 else F2) for k in range(12)]
+    bps = [float(np.float32(0.3 if (k // 2) % 2 == 0 else 0.6)) for k in range(12)]
+    with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
+        want = [sync_ctx.observe_stereo(l, r, c, best_percent=b, frame_life=LIFE) for (l, r), c, b in zip(frames, calibs, bps)]
+    with capi.Context(capi.default_params(320, 240, max_images=24, nfeatures=NF)) as ctx:
+        ctx.observe_configure(12, 12, 0)  # while the GPU is busy, nothing leaves before the parameters change or the collect
+        tickets = [ctx.observe_submit(l, r, c, best_percent=b, frame_life=LIFE) for (l, r), c, b in zip(frames, calibs, bps)]
+        got = [ctx.observe_collect(t, frame_life=LIFE) for t in tickets]
+    for g, w in zip(got, want):
+        _same_observation(w, g)
+    assert any(len(w["factors"]) == LIFE and len(w["factors"][0]) > 0 for w in want)
+
+
+def test_capacity_overflow_in_a_batch_stays_on_its_own_ticket():
+    """Batches of up to eight frames: every image has a status word of its own, so a frame whose keypoints overflow the
+    output capacity gets VSF_ERR_CAPACITY on ITS ticket and its neighbours in the same batch VSF_OK."""
+    from vision_slam_frontend_amd import capi, frontend, synth
+    w, h = 320, 240
+    busy = synth.stereo_pair(w, h, 0, n_objects=400)
+    flat = (np.full((h, w), 90, np.uint8), np.full((h, w), 90, np.uint8))
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    p = capi.default_params(w, h, max_images=16, nfeatures=500, max_keypoints=200)
+    pattern = [1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 0, 0, 0, 1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 1, 0, 0, 1, 0, 1]
+    with capi.Context(p) as ctx:
+        ctx.observe_configure(20, 6, 0)
+        tickets, got = [], []
+
+        def collect(t):
+            try:
+                ctx.observe_collect(t, frame_life=2)
+                got.append(capi.VSF_OK)
+            except capi.VsfError as e:
+                got.append(e.status)
+
+        for b in pattern:
+            if len(tickets) == 20:
+                collect(tickets.pop(0))
+            tickets.append(ctx.observe_submit(*(busy if b else flat), calib, frame_life=2))
+        while tickets:
+            collect(tickets.pop(0))
+    want = [capi.VSF_ERR_CAPACITY if b else capi.VSF_OK for b in pattern]
+    assert got == want, list(zip(pattern, got))
 
 
 def test_capacity_overflow_is_reported_on_its_own_ticket():

@@ -43,6 +43,7 @@ struct DescribeArgs {
   uint8_t* desc_out;
   int32_t* counts;
   int32_t* status;
+  int status_stride;  // 0: one word for the call; 1: a word per image (the ObserveImage queue: an overflow stays on its own frame)
   int nblocks, nimages;  // workgroups per image, images
 };
 
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void orb_orient_describe_kernel(DescribeArgs a
   const int total = __shfl(incl, 63, 64);
   if (block == 0 && threadIdx.x == 0) {
     a.counts[image] = total;
-    if (total > a.max_keypoints) atomicOr(a.status, 1);
+    if (total > a.max_keypoints) atomicOr(a.status + (size_t)image * a.status_stride, 1);
   }
   const int n_out = min(total, a.max_keypoints);
   const int o_begin = (block * 4 + wid) * kKpPerWave;
@@ -355,6 +356,7 @@ void vsf_launch_describe(const VsfDev& d, const VsfGeom& g, const VsfImages& im,
   a.desc_out = d_desc;
   a.counts = d_counts;
   a.status = d.status;
+  a.status_stride = d.status_stride;
   // (eight per wave needs a launch that still fills the chip with waves: 512 images x 10 000 keypoints; 64-192 images of
   // 8 000 -- 1920x1080 -- run 1-2 % faster with four)
   const int kpw = (max_keypoints >= 4096 && (long)im.n * max_keypoints >= 3000000L) ? 8 : 4;

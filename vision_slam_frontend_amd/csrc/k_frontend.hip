@@ -112,7 +112,12 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* 
                                                             const float* __restrict__ thr,
                                                             vsf_keypoint* __restrict__ kp_out,   // [2*frames][max_rows]
                                                             uint8_t* __restrict__ desc_out,      // [2*frames][max_rows][32]
-                                                            int32_t* __restrict__ counts_out) {  // [2*frames]
+                                                            int32_t* __restrict__ counts_out,    // [2*frames]
+                                                            // the ObserveImage queue: the rebuilt descriptors of frame f go
+                                                            // to the sets out_sets[2f] (left) / out_sets[2f + 1] (right) of
+                                                            // desc_out, their number to set_counts[set] as well
+                                                            const int32_t* __restrict__ out_sets,
+                                                            int32_t* __restrict__ set_counts) {
   __shared__ int wsum[4];
   __shared__ int s_base;
   const int f = blockIdx.x;
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* 
   const float th = thr[f];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const size_t L = (size_t)(2 * f) * max_rows, R = (size_t)(2 * f + 1) * max_rows;
+  const size_t DL = out_sets ? (size_t)out_sets[2 * f] * max_rows : L, DR = out_sets ? (size_t)out_sets[2 * f + 1] * max_rows : R;
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += 256) {
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* 
       kp_out[R + o] = kp[R + dm.trainIdx];
       const uint4* ls = reinterpret_cast<const uint4*>(desc + (L + dm.queryIdx) * VSF_DESC_BYTES);
       const uint4* rs = reinterpret_cast<const uint4*>(desc + (R + dm.trainIdx) * VSF_DESC_BYTES);
-      uint4* ld = reinterpret_cast<uint4*>(desc_out + (L + o) * VSF_DESC_BYTES);
-      uint4* rd = reinterpret_cast<uint4*>(desc_out + (R + o) * VSF_DESC_BYTES);
+      uint4* ld = reinterpret_cast<uint4*>(desc_out + (DL + o) * VSF_DESC_BYTES);
+      uint4* rd = reinterpret_cast<uint4*>(desc_out + (DR + o) * VSF_DESC_BYTES);
       ld[0] = ls[0];
       ld[1] = ls[1];
       rd[0] = rs[0];
@@ -156,6 +162,10 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* 
   if (threadIdx.x == 0) {
     counts_out[2 * f] = s_base;
     counts_out[2 * f + 1] = s_base;
+    if (out_sets) {
+      set_counts[out_sets[2 * f]] = s_base;
+      set_counts[out_sets[2 * f + 1]] = s_base;
+    }
   }
 }
 
@@ -426,76 +436,81 @@ __global__ __launch_bounds__(NT) void sort_trim_par_kernel(const vsf_dmatch* __r
   if (tid == 0) npairs[p] = good;
 }
 
-// ---- vsf_observe_stereo: everything one ObserveImage returns, compact, written straight into pinned host memory ----
+// ---- the ObserveImage queue: everything one ObserveImage returns, compact, written straight into pinned host memory, for
+// every frame of a batch (blockIdx.z) ----
 // header (16 words) | npairs[n_pairs] padded to 4 words | VisionFeature x nfeat | FeatureMatch x sum(npairs) |
-// cv::KeyPoint x nfeat (the filtered left frame) | descriptors x nfeat; also stores the filtered left frame into its
-// slot of the temporal ring (descriptors + count): the next calls match against it.
+// cv::KeyPoint x nfeat (the filtered left frame) | descriptors x nfeat.  The pairs of frame f in the batch's pair list:
+// its temporal factors at tp0 .. tp0 + n_past - 1 (oldest kept frame first), the right -> left matches of
+// Calculate3DPoints at index f; they leave in the order the reference books them (temporal first, cc:424-437).
 __global__ __launch_bounds__(256) void observe_pack_kernel(VsfObserveArgs a) {
   __shared__ uint32_t s_off[4 + VSF_OBSERVE_MAX_PAIRS];
-  const int K = a.max_rows;
-  const int nfeat = min(max(a.counts_f[0], 0), K);
+  const int K = a.max_rows, f = blockIdx.z;
+  const VsfObserveFrame fm = a.frames[f];
+  const int n_pairs = fm.n_past + 1;
+  const int sec = blockIdx.y;
+  if (sec >= 3 + n_pairs) return;
+  const int nfeat = min(max(a.counts_f[2 * f], 0), K);
+  auto pair_index = [&](int p) { return p < fm.n_past ? fm.tp0 + p : f; };
   if (threadIdx.x == 0) {
-    uint32_t off = 64u + 4u * (uint32_t)((a.n_pairs + 3) & ~3);
+    uint32_t off = 64u + 4u * (uint32_t)((n_pairs + 3) & ~3);
     s_off[0] = off;  // features
     off += (uint32_t)nfeat * 28u;
-    for (int p = 0; p < a.n_pairs; p++) {
+    for (int p = 0; p < n_pairs; p++) {
       s_off[3 + p] = off;
-      off += (uint32_t)min(max(a.npairs[p], 0), K) * 16u;
+      off += (uint32_t)min(max(a.npairs[pair_index(p)], 0), K) * 16u;
     }
     s_off[1] = off;  // keypoints
     off += (uint32_t)nfeat * 28u;
     s_off[2] = off;  // descriptors
     off += (uint32_t)nfeat * 32u;
-    s_off[3 + a.n_pairs] = off;  // total
+    s_off[3 + n_pairs] = off;  // total
   }
   __syncthreads();
-  const uint32_t total = s_off[3 + a.n_pairs];
-  uint32_t* out = reinterpret_cast<uint32_t*>(a.out);
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
+  const uint32_t total = s_off[3 + n_pairs];
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.out + (size_t)fm.out_slot * a.out_stride);
+  if (blockIdx.x == 0 && sec == 0) {
     if (threadIdx.x == 0) {
-      out[0] = 0x4F465356u;  // "VSFO"
-      out[1] = (uint32_t)a.n_pairs;
+      out[1] = (uint32_t)n_pairs;
       out[2] = (uint32_t)nfeat;
       out[3] = total;
-      out[4] = (uint32_t)a.counts_raw[0];
-      out[5] = (uint32_t)a.counts_raw[1];
-      out[6] = (uint32_t)a.nmatches[0];
-      out[7] = (uint32_t)a.npoints[0];
-      out[8] = __float_as_uint(a.means[0]);
-      out[9] = __float_as_uint(a.thr[0]);
-      out[10] = __float_as_uint(a.thr_state[0]);
+      out[4] = (uint32_t)a.counts_raw[2 * f];
+      out[5] = (uint32_t)a.counts_raw[2 * f + 1];
+      out[6] = (uint32_t)a.nmatches[f];
+      out[7] = (uint32_t)a.npoints[f];
+      out[8] = __float_as_uint(a.means[f]);
+      out[9] = __float_as_uint(a.thr[f]);
+      out[10] = __float_as_uint(a.means[f] + 2.0f);  // the static's value after this frame (cc:392-394)
       out[11] = total > a.out_cap ? 1u : 0u;
-      out[12] = out[13] = out[14] = out[15] = 0u;
+      // capacity overflows of THIS frame's two extractions (a status word per image), read and cleared
+      out[12] = (uint32_t)((a.status[2 * f] | a.status[2 * f + 1]) & 1);
+      a.status[2 * f] = 0;
+      a.status[2 * f + 1] = 0;
+      out[13] = out[14] = out[15] = 0u;
+      out[0] = 0x4F465356u;  // "VSFO"
     }
-    if ((int)threadIdx.x < ((a.n_pairs + 3) & ~3))
-      out[16 + threadIdx.x] = (int)threadIdx.x < a.n_pairs ? (uint32_t)min(max(a.npairs[threadIdx.x], 0), K) : 0u;
-    if (threadIdx.x == 0) a.ring_count[0] = nfeat;
+    if ((int)threadIdx.x < ((n_pairs + 3) & ~3))
+      out[16 + threadIdx.x] =
+          (int)threadIdx.x < n_pairs ? (uint32_t)min(max(a.npairs[pair_index((int)threadIdx.x)], 0), K) : 0u;
   }
   if (total > a.out_cap) return;
-  const int sec = blockIdx.y;
   const uint32_t* src;
   uint32_t words;
   if (sec == 0) {
-    src = reinterpret_cast<const uint32_t*>(a.features);
+    src = reinterpret_cast<const uint32_t*>(a.features + (size_t)f * K);
     words = (uint32_t)nfeat * 7u;
   } else if (sec == 1) {
-    src = reinterpret_cast<const uint32_t*>(a.kp_f);
+    src = reinterpret_cast<const uint32_t*>(a.kp_f + (size_t)(2 * f) * K);
     words = (uint32_t)nfeat * 7u;
   } else if (sec == 2) {
-    src = reinterpret_cast<const uint32_t*>(a.desc_f);
+    src = reinterpret_cast<const uint32_t*>(a.desc_sets + (size_t)fm.left_set * K * VSF_DESC_BYTES);
     words = (uint32_t)nfeat * 8u;
   } else {
-    const int p = sec - 3;
+    const int p = pair_index(sec - 3);
     src = reinterpret_cast<const uint32_t*>(a.pairs + (size_t)p * K * 2);
     words = (uint32_t)min(max(a.npairs[p], 0), K) * 4u;
   }
   uint32_t* dst = out + s_off[sec] / 4u;
-  uint32_t* ring = sec == 2 ? reinterpret_cast<uint32_t*>(a.ring_desc) : nullptr;
-  for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < words; w += gridDim.x * 256u) {
-    const uint32_t v = src[w];
-    dst[w] = v;
-    if (ring) ring[w] = v;
-  }
+  for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < words; w += gridDim.x * 256u) dst[w] = src[w];
 }
 
 }  // namespace
@@ -514,9 +529,9 @@ void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_m
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
                                    const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_residual,
                                    const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
-                                   int32_t* d_counts_out, hipStream_t s) {
+                                   int32_t* d_counts_out, hipStream_t s, const int32_t* d_out_sets, int32_t* d_set_counts) {
   hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_desc, d_matches, d_nmatches,
-                     max_rows, d_residual, d_thr, d_kp_out, d_desc_out, d_counts_out);
+                     max_rows, d_residual, d_thr, d_kp_out, d_desc_out, d_counts_out, d_out_sets, d_set_counts);
 }
 
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
@@ -558,7 +573,7 @@ hipError_t vsf_prepare_sort_kernels(int lds_limit) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit);
 }
 
-void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s) {
-  // sections: 0 VisionFeature, 1 cv::KeyPoint, 2 descriptors, 3.. one per pair; up to 16 chunks of workgroups each
-  hipLaunchKernelGGL(observe_pack_kernel, dim3(16, 3 + a.n_pairs), dim3(256), 0, s, a);
+void vsf_launch_observe_pack(const VsfObserveArgs& a, int max_pairs_per_frame, hipStream_t s) {
+  // sections: 0 VisionFeature, 1 cv::KeyPoint, 2 descriptors, 3.. one per pair; up to 16 chunks of workgroups each; z = frame
+  hipLaunchKernelGGL(observe_pack_kernel, dim3(a.n_frames > 8 ? 4 : 16, 3 + max_pairs_per_frame, a.n_frames), dim3(256), 0, s, a);
 }

@@ -50,6 +50,7 @@ struct SelectArgs {
   int level0;  // first level handled by this launch
   int nlv, nimages;  // levels of this launch, images
   int32_t* status;
+  int status_stride;  // 0: one word for the call; 1: a word per image
 };
 
 struct ScoreGreater {
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(NT, WGS) void orb_select_kernel(SelectArgs a) {
   }
   if (tid == 0) {
     a.lvl_count[(size_t)image * a.nlevels + level] = m_out;
-    if (m2 > L.kp_cap) atomicOr(a.status, 1);
+    if (m2 > L.kp_cap) atomicOr(a.status + (size_t)image * a.status_stride, 1);
   }
 }
 
@@ -717,6 +718,7 @@ void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_leve
   a.lvl_count = d.lvl_count;
   a.nlevels = g.nlevels;
   a.status = d.status;
+  a.status_stride = d.status_stride;
   // Levels are split by the area in which keypoints may sit; every class falls back to HBM scratch when a level has
   // more candidates than its LDS array holds, so the split only affects speed.
   int nbig = 0;

@@ -192,8 +192,8 @@ void sync_all_streams(vsf_ctx* ctx) {  // every stream the context launches on
   if (ctx->blur_stream) vsf_note(hipStreamSynchronize(ctx->blur_stream));
   for (int i = 1; i < ctx->side.n; i++)
     if (ctx->side.stream[i]) vsf_note(hipStreamSynchronize(ctx->side.stream[i]));
-  for (int i = 0; i < VSF_OBSERVE_MAX_SLOTS; i++)
-    if (ctx->ob.ex_stream[i] && ctx->ob.ex_stream[i] != ctx->stream) vsf_note(hipStreamSynchronize(ctx->ob.ex_stream[i]));
+  if (ctx->ob.copy_stream) vsf_note(hipStreamSynchronize(ctx->ob.copy_stream));
+  if (ctx->ob.tail_stream) vsf_note(hipStreamSynchronize(ctx->ob.tail_stream));
 }
 
 // The per-image work buffers of images [i0, i0 + n) seen as a batch of their own.
@@ -213,10 +213,14 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0) {
 // detectAndCompute for images [i0, i0 + n) of `im` on stream `st`.  `status`: the status word the kernels report capacity
 // overflows into (the context's, or the word of the frame in flight that owns this extraction).
 void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp,
-                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete, const VsfSideStream* own_side, int32_t* status) {
+                uint8_t* d_desc, int32_t* d_counts, bool inputs_complete, const VsfSideStream* own_side, int32_t* status,
+                int status_stride) {
   const VsfGeom& g = ctx->orb.g;
   VsfDev d = shifted(ctx->dorb.d, g, i0);
-  if (status) d.status = status;
+  if (status) {
+    d.status = status;
+    d.status_stride = status_stride;
+  }
   VsfImages im = im_all;
   im.base += (size_t)i0 * im.image_stride;
   im.n = n;
@@ -503,8 +507,8 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
     if (hipEventCreateWithFlags(&ctx->side.join[i], hipEventDisableTiming) != hipSuccess) return fail(VSF_ERR_HIP);
     ctx->side.n = i + 1;
   }
-  if (hipMalloc((void**)&ctx->d_status, (1 + VSF_OBSERVE_MAX_SLOTS) * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
-  if (hipMemset(ctx->d_status, 0, (1 + VSF_OBSERVE_MAX_SLOTS) * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMalloc((void**)&ctx->d_status, 4 * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
+  if (hipMemset(ctx->d_status, 0, 4 * sizeof(int32_t)) != hipSuccess) return fail(VSF_ERR_HIP);
   {
     // Three kernels ask for more dynamic LDS than the default 64 KB (the parallel sort of GetFeatureMatches, the slab
     // pyramid, the parallel JPEG decode): how much a workgroup of this device may have is asked once, their limits are

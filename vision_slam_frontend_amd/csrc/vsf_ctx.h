@@ -129,43 +129,64 @@ struct vsf_ctx {
   // parks the old one here, because hipFree would wait for the whole device behind the caller's back; released by
   // vsf_sync / vsf_reserve / vsf_destroy, when every stream of the context is known to be idle.
   std::vector<void*> retired;
-  // vsf_observe_stereo: temporal ring, per-call device scratch, pinned host staging
-  struct ObserveMeta {  // pinned, device-visible: read by the kernels over PCIe (a few words per call, no copy command)
-    float F[9];
-    float best_percent[VSF_OBSERVE_MAX_PAIRS];
-    int32_t q_set[VSF_OBSERVE_MAX_PAIRS], t_set[VSF_OBSERVE_MAX_PAIRS];
+  // The ObserveImage queue (vsf_observe.hip): frames wait in pinned staging and leave for the GPU in batches.
+  static constexpr int kObserveBatchSlots = 4;
+  struct ObserveBatchMeta;  // pinned, device-visible: read by the kernels over PCIe (no copy command)
+  struct ObserveBatch {     // what one batch's extraction writes and its tail reads
+    uint8_t* d_img = nullptr;        // [2 bmax] images at the staging pitch
+    vsf_keypoint* kp_raw = nullptr;  // [2 bmax][K]
+    uint8_t* desc_raw = nullptr;     // [2 bmax][K][32]
+    int32_t* counts_raw = nullptr;   // [2 bmax]
+    vsf_dmatch* matches = nullptr;   // [bmax][K] raw stereo matches
+    int32_t* nmatches = nullptr;     // [bmax]
+    int32_t* status = nullptr;       // [2 bmax] a status word per image
+    ObserveBatchMeta* h_meta = nullptr;
+    hipEvent_t ev_uploaded = nullptr, ev_extracted = nullptr, ev_done = nullptr;
+    bool used = false;               // ev_done has been recorded at least once
+    hipStream_t done_stream = nullptr;  // the stream its tail ran on
+  };
+  struct ObserveFrame {  // per frame slot (ticket % depth), host side
+    vsf_calibration calib;
+    float best_percent = 0.f;
+    int batch = -1;  // batch slot it was launched in, -1 while it waits
   };
   struct Observe {
+    bool ready = false;
     int frame_life = 0;
-    uint8_t* ring = nullptr;        // [frame_life + 2][K][32]: kept frames, then the current left / right frame
-    int32_t* ring_counts = nullptr; // [frame_life + 2]
-    vsf_keypoint* kpf = nullptr;    // [2][K]
-    vsf_dmatch* matches = nullptr;  // [slots][K] raw stereo matches
-    int32_t* ints = nullptr;        // [slots] nmatches, then nfeat, npoints
-    float* floats = nullptr;        // mean, thr, thr_state
-    vsf_vision_feature* features = nullptr;
-    uint64_t* pairs = nullptr;      // [frame_life + 1][K][2]
+    int depth = 0;      // frames that may be submitted and not collected
+    int bmax = 0;       // frames per batch at most
+    int ring = 0;       // descriptor sets [0, ring): the kept left frames (frame g in set g % ring); [ring, ring + bmax): the
+                        // right frames of the batch in the tail
+    int max_pairs = 0;  // bmax * (frame_life + 1)
+    uint8_t* sets = nullptr;        // [ring + bmax][K][32]
+    int32_t* set_counts = nullptr;  // [ring + bmax]
+    // the tail's scratch exists once: tails run one after the other (they carry the threshold and the window)
+    float* residual = nullptr;      // [bmax][K]
+    float* floats = nullptr;        // means [bmax] | thr [bmax + 1] | thr_state
+    vsf_keypoint* kpf = nullptr;    // [2 bmax][K]
+    int32_t* ints = nullptr;        // counts_f [2 bmax] | nfeat [bmax] | npoints [bmax]
+    int32_t *ex_idx2 = nullptr, *ex_dist2 = nullptr;  // [bmax][K][2] the extraction side's matcher scratch
+    int32_t *t_idx2 = nullptr, *t_dist2 = nullptr;    // [max_pairs][K][2] the tail's
+    vsf_dmatch* t_matches = nullptr;                  // [max_pairs][K]
+    int32_t* t_nmatches = nullptr;
+    void* t_sortkeys = nullptr;
+    uint64_t* pairs = nullptr;      // [max_pairs][K][2]
     int32_t* npairs = nullptr;
-    // Up to three frames may be in flight (vsf_observe_submit / vsf_observe_collect; two slots with max_images >= 4,
-    // three with >= 6): everything one frame's EXTRACTION writes exists once per slot -- pinned staging, per-call
-    // parameters, result buffer, status word, the slot's two images of every extraction buffer, raw stereo matches.  A
-    // frame runs on its slot's stream from upload to result; its TAIL (RemoveAmbigStereo ... result) first waits for the
-    // previous frame's tail (an event), so the tails -- which carry the threshold and the temporal window from frame to
-    // frame -- run in frame order and their buffers exist once.
-    int slots = 1;
-    uint8_t* h_img[VSF_OBSERVE_MAX_SLOTS] = {};       // pinned: both images at the staging pitch
-    uint8_t* h_out[VSF_OBSERVE_MAX_SLOTS] = {};       // pinned, written by observe_pack_kernel
-    size_t out_cap = 0;
-    ObserveMeta* h_meta[VSF_OBSERVE_MAX_SLOTS] = {};
-    int32_t* h_status[VSF_OBSERVE_MAX_SLOTS] = {};    // pinned copy of the status word after the frame's last kernel
-    hipStream_t ex_stream[VSF_OBSERVE_MAX_SLOTS] = {};  // the stream of slot i (a one-slot context: ctx->stream)
-    hipEvent_t ev_done[VSF_OBSERVE_MAX_SLOTS] = {};
-    VsfSideStream side[VSF_OBSERVE_MAX_SLOTS] = {};  // (n = 0: no second pyramid chain, no shared fork / join events)
-    bool done_valid[VSF_OBSERVE_MAX_SLOTS] = {};
-    int64_t ticket_of[VSF_OBSERVE_MAX_SLOTS] = {-1, -1, -1, -1, -1, -1};  // submitted and not yet collected
-    int64_t next_ticket = 0;
-    std::vector<int> order;         // ring slots of the kept frames, oldest first
+    vsf_vision_feature* features = nullptr;  // [bmax][K]
+    uint8_t* h_img = nullptr;       // pinned [depth][2] images at the staging pitch
+    uint8_t* h_out = nullptr;       // pinned [depth][out_stride], written by observe_pack_kernel
+    size_t out_cap = 0, out_stride = 0;
+    ObserveBatch batch[kObserveBatchSlots];
+    std::vector<ObserveFrame> frames;  // [depth]
+    hipStream_t copy_stream = nullptr, tail_stream = nullptr;
+    int64_t next_ticket = 0;   // tickets issued
+    int64_t next_launch = 0;   // first frame still waiting in staging
+    int64_t next_collect = 0;  // oldest frame not collected
+    int64_t batches = 0;       // batches launched
+    int last_batch = -1;       // slot of the batch launched last
   } ob;
+  // vsf_observe_configure (before the queue is built by the first submit; 0 = defaults)
+  int ob_depth = 0, ob_min_batch = 1, ob_in_flight = 2;
   // vsf_jpeg_decode_gray_batch: pinned staging + device copy of the packed headers / tables / entropy-coded segments
   // (two sets, used alternately: the host fills one while the previous call's upload / decode still use the other)
   int32_t* jp_flags = nullptr;  // [jp_flags_cap] per progressive file of a call: damaged, decode again scan after scan
@@ -316,7 +337,7 @@ struct InputEventScope {
 // overflows into (the context's, or the word of the frame in flight that owns this extraction).
 void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, int n, vsf_keypoint* d_kp, uint8_t* d_desc,
                 int32_t* d_counts, bool inputs_complete = false, const VsfSideStream* own_side = nullptr,
-                int32_t* status = nullptr);
+                int32_t* status = nullptr, int status_stride = 0);
 // knnMatch(k = 2) + ratio test for pairs [p0, p0 + n) on stream `st`.
 void match_on(vsf_ctx* ctx, hipStream_t st, const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride,
               const int32_t* d_q_set, const int32_t* d_t_set, int p0, int n, int32_t* d_idx2, int32_t* d_dist2,

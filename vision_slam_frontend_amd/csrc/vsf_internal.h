@@ -154,6 +154,7 @@ struct VsfDev {
   const uint2* ic_table;    // [4][VSF_IC_ITEMS] ICAngles byte weights (k_describe.hip)
   int32_t* lvl_count;       // [max_images][nlevels]
   int32_t* status;          // device status word (bit 0: capacity overflow)
+  int status_stride;        // 0: that one word; 1: status[image] (a batch of the ObserveImage queue: one word per image)
   const VsfTuning* tune;    // the context's launch choices (host memory)
 };
 
@@ -221,7 +222,8 @@ void vsf_launch_stereo_residuals(const vsf_keypoint* d_kp, const vsf_dmatch* d_m
 void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
                                    const int32_t* d_nmatches, int n_frames, int max_rows, const float* d_residual,
                                    const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
-                                   int32_t* d_counts_out, hipStream_t s);
+                                   int32_t* d_counts_out, hipStream_t s, const int32_t* d_out_sets = nullptr,
+                                   int32_t* d_set_counts = nullptr);
 // k_points.hip (SURVEY 8(f) row f2 + the compact gather payload)
 void vsf_launch_stereo_thresholds(const float* d_means, int n, float* d_state, float* d_thr, hipStream_t s);
 void vsf_launch_fill_stereo_sets(int32_t* d_sets, int n_frames, hipStream_t s);  // [0..n): 2f + 1, [n..2n): 2f
@@ -235,29 +237,35 @@ void vsf_launch_pack_outputs(const vsf_vision_feature* d_features, const int32_t
 void vsf_launch_sort_trim(const vsf_dmatch* d_matches, const int32_t* d_nmatches, int n_pairs, int max_rows,
                           float best_percent, const float* d_best_percent_of, void* d_scratch, uint64_t* d_pairs,
                           int32_t* d_npairs, hipStream_t s, bool force_serial = false, int lds_limit = 160 * 1024);
-// vsf_observe_stereo's output kernel (k_frontend.hip)
+// The ObserveImage queue's output kernel (k_frontend.hip): one compact result per frame of a batch, written into pinned
+// host memory.
 #define VSF_OBSERVE_MAX_PAIRS 64
-#define VSF_OBSERVE_MAX_SLOTS 6  // frames vsf_observe_submit may keep in flight (max_images / 2 of them, at most this many)
+struct VsfObserveFrame {  // per frame of a batch; pinned host memory the kernels read directly
+  int32_t left_set;  // descriptor set that holds the filtered left frame
+  int32_t n_past;    // kept frames it is matched against (temporal factors)
+  int32_t tp0;       // index of its first temporal pair in the batch's pair list (its right -> left pair is pair f)
+  int32_t out_slot;  // result slot: out + out_slot * out_stride
+};
 struct VsfObserveArgs {
-  int n_pairs, max_rows;
-  const int32_t* counts_raw;          // [2] keypoints of the left / right image
-  const int32_t* nmatches;            // [1] raw stereo matches
-  const int32_t* counts_f;            // [1] features of the filtered left frame
-  const int32_t* npoints;             // [1] triangulated points
-  const float* means;                 // [1]
-  const float* thr;                   // [1] threshold applied
-  const float* thr_state;             // [1] threshold in force afterwards
-  const vsf_vision_feature* features; // [max_rows]
-  const vsf_keypoint* kp_f;           // [max_rows] filtered left keypoints
-  const uint8_t* desc_f;              // [max_rows][32] filtered left descriptors
-  const uint64_t* pairs;              // [n_pairs][max_rows][2]
-  const int32_t* npairs;              // [n_pairs]
-  uint8_t* ring_desc;                 // ring slot that receives the filtered left descriptors
-  int32_t* ring_count;                // ... and their number
+  int n_frames, max_rows;
+  const int32_t* counts_raw;          // [2n] keypoints of the left / right images
+  const int32_t* nmatches;            // [n] raw stereo matches
+  const int32_t* counts_f;            // [2n] features of the filtered left / right frames
+  const int32_t* npoints;             // [n] triangulated points
+  const float* means;                 // [n]
+  const float* thr;                   // [n] thresholds applied
+  const vsf_vision_feature* features; // [n][max_rows]
+  const vsf_keypoint* kp_f;           // [2n][max_rows] filtered keypoints (left, right per frame)
+  const uint8_t* desc_sets;           // descriptor sets [..][max_rows][32]
+  const uint64_t* pairs;              // [pairs][max_rows][2]
+  const int32_t* npairs;              // [pairs]
+  int32_t* status;                    // [2n] a status word per image of the batch: read into the header and cleared
+  const VsfObserveFrame* frames;      // [n]
   uint8_t* out;                       // pinned host memory (device-visible)
+  size_t out_stride;
   uint32_t out_cap;
 };
-void vsf_launch_observe_pack(const VsfObserveArgs& a, hipStream_t s);
+void vsf_launch_observe_pack(const VsfObserveArgs& a, int max_pairs_per_frame, hipStream_t s);
 
 // k_jpeg.hip (cv::imdecode(IMREAD_GRAYSCALE) for baseline JPEG)
 #ifdef __cplusplus

@@ -48,6 +48,10 @@ def lib() -> C.CDLL:
         L.vsfh_set_pipelined.restype = None
         L.vsfh_set_frames_in_flight.argtypes = [vp, i32]
         L.vsfh_set_frames_in_flight.restype = None
+        L.vsfh_set_queue.argtypes = [vp, i32, i32, i32]
+        L.vsfh_set_queue.restype = None
+        L.vsfh_time_sequence.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(dbl), C.POINTER(dbl)]
+        L.vsfh_time_sequence.restype = dbl
         L.vsfh_flush.argtypes = [vp]
         _lib = L
     return _lib
@@ -86,8 +90,27 @@ class Frontend:
         lib().vsfh_set_pipelined(self._h, int(on))
 
     def set_frames_in_flight(self, n: int):
-        """How many frames a pipelined Frontend keeps in flight (1..6; default 4).  Choose before the first observe_image."""
+        """How many frames a pipelined Frontend leaves in the context's queue (1..256; default 32).  Choose before the first
+        observe_image."""
         lib().vsfh_set_frames_in_flight(self._h, int(n))
+
+    def set_queue(self, depth: int = 0, batch_frames: int = 0, min_batch: int = 0):
+        """The ObserveImage queue of a pipelined Frontend: frames that may wait uncollected (default 32), frames per batch at
+        most (default 32: sizes the context), fewest waiting frames that leave while the GPU is busy (0: any).  Choose
+        before the first observe_image."""
+        lib().vsfh_set_queue(self._h, int(depth), int(batch_frames), int(min_batch))
+
+    def time_sequence(self, frames: np.ndarray, n_frames: int, warm: int = 32, read_every: int = 0):
+        """The reference's driver loop in C++ (vsfh_time_sequence) over `frames` [n][2][h][w] taken in turn: returns
+        (steady frames per second, mean ms inside ObserveImage, max ms)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.ndim == 4 and frames.shape[1] == 2
+        mean, worst = C.c_double(), C.c_double()
+        fps = lib().vsfh_time_sequence(self._h, _p(frames), frames.shape[0], frames.shape[3], frames.shape[2], int(n_frames),
+                                       int(warm), int(read_every), C.byref(mean), C.byref(worst))
+        if fps < 0:
+            raise capi.VsfError(lib().vsfh_last_status(self._h), "Frontend::ObserveImage (time_sequence)")
+        return float(fps), float(mean.value), float(worst.value)
 
     def flush(self) -> bool:
         """Collects and books every frame still in flight."""

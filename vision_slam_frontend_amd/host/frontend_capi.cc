@@ -1,5 +1,6 @@
 // frontend_capi.cc -- flat C view of slam::Frontend so tests (ctypes) and foreign callers can drive the host
 // class: same call sequence as the reference's driver (slam_frontend_main.cc:132,147,321).
+#include <chrono>
 #include <cstring>
 
 #include "slam_frontend.h"
@@ -28,7 +29,58 @@ void vsfh_default_calibration(vsf_calibration* out) { *out = slam::MakeCalibrati
 
 void vsfh_set_fused(void* f, int on) { static_cast<Frontend*>(f)->set_fused(on != 0); }
 void vsfh_set_pipelined(void* f, int on) { static_cast<Frontend*>(f)->set_pipelined(on != 0); }
-void vsfh_set_frames_in_flight(void* f, int n) { static_cast<Frontend*>(f)->set_frames_in_flight(n); }
+void vsfh_set_frames_in_flight(void* f, int n) { static_cast<Frontend*>(f)->set_queue_depth(n); }
+void vsfh_set_queue(void* f, int depth, int batch_frames, int min_batch) {
+  Frontend* fe = static_cast<Frontend*>(f);
+  if (depth > 0) fe->set_queue_depth(depth);
+  if (batch_frames > 0) fe->set_batch_frames(batch_frames);
+  fe->set_min_batch(min_batch);
+}
+
+// The reference's driver loop (slam_frontend_main.cc:271-328) for n_frames stereo frames taken in turn from `frames`
+// (n_src x 2 x h x w bytes): ObserveOdometry (a pose 0.3 m further on: OdomCheck accepts every frame) + ObserveImage per
+// frame, no Python between the calls.  The clock starts at frame `warm` (after a Flush) and stops behind the final Flush.
+// read_every > 0: GetSLAMProblem after every read_every-th new node, as the reference's driver does after every one
+// (main.cc:320-321) -- that read waits for every frame still in the queue.
+// Returns the steady frames per second; *mean_call_ms / *max_call_ms: time inside ObserveImage; < 0 on failure.
+double vsfh_time_sequence(void* f, const uint8_t* frames, int n_src, int w, int h, int n_frames, int warm, int read_every,
+                          double* mean_call_ms, double* max_call_ms) {
+  using Clock = std::chrono::steady_clock;
+  Frontend* fe = static_cast<Frontend*>(f);
+  const slam::Quaternionf q(1, 0, 0, 0);
+  const int first = fe->GetNumPoses();
+  if (first == 0) fe->ObserveOdometry(slam::Vector3f(0, 0, 0), q, 0.0);
+  Clock::time_point t0 = Clock::now();
+  double sum = 0, worst = 0;
+  for (int k = 0; k < n_frames; k++) {
+    if (k == warm) {
+      fe->Flush();
+      t0 = Clock::now();
+    }
+    const uint8_t* l = frames + (size_t)(k % n_src) * 2 * w * h;
+    fe->ObserveOdometry(slam::Vector3f(0.3f * (first + k + 1), 0, 0), q, 1.0 + first + k);
+    const Clock::time_point a = Clock::now();
+    const bool added = fe->ObserveImage(slam::Image(l, h, w, (size_t)w), slam::Image(l + (size_t)w * h, h, w, (size_t)w),
+                                        1.0 + first + k);
+    const double dt = std::chrono::duration<double>(Clock::now() - a).count();
+    if (!added || fe->last_status() != VSF_OK) return -1.0;
+    if (read_every > 0 && (k + 1) % read_every == 0) {
+      slam_types::SLAMProblem problem;
+      fe->GetSLAMProblem(&problem);
+      if (problem.nodes.empty()) return -1.0;
+    }
+    if (k >= warm) {
+      sum += dt;
+      if (dt > worst) worst = dt;
+    }
+  }
+  if (!fe->Flush()) return -1.0;
+  const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+  const int n = n_frames - warm;
+  if (mean_call_ms) *mean_call_ms = n > 0 ? 1e3 * sum / n : 0;
+  if (max_call_ms) *max_call_ms = 1e3 * worst;
+  return n > 0 && wall > 0 ? n / wall : 0.0;
+}
 int vsfh_flush(void* f) { return static_cast<Frontend*>(f)->Flush() ? 1 : 0; }
 
 void vsfh_frontend_destroy(void* f) { delete static_cast<Frontend*>(f); }

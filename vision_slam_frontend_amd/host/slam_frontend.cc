@@ -230,7 +230,7 @@ Frontend::Frontend(const std::string& /*config_path*/, const FrontendConfig& con
 // Frames still in flight (pipelined mode) are dropped, not booked: nobody can read the problem any more.  vsf_destroy
 // waits for every stream of the context -- the slots' included -- before it frees what their kernels write.
 Frontend::~Frontend() {
-  pending_.clear();
+  pending_count_ = 0;
   vsf_destroy(ctx_);
 }
 
@@ -238,21 +238,27 @@ bool Frontend::EnsureContext(int width, int height) {
   if (ctx_) {
     vsf_params p;
     vsf_get_params(ctx_, &p);
-    if (p.width == width && p.height == height && p.max_images >= 2 * frames_in_flight()) return true;
-    // the context is replaced (another image size, or pipelining switched on): the frames still in flight belong to the
-    // old one and are booked first, in order; whatever that returns, their tickets die with the context
+    if (p.width == width && p.height == height && p.max_images >= 2 * batch_frames() && ctx_depth_ == queue_depth())
+      return true;
+    // the context is replaced (another image size, or pipelining switched on): the frames still in the queue belong to
+    // the old one and are booked first, in order; whatever that returns, their tickets die with the context
     Flush();
-    pending_.clear();
+    pending_count_ = 0;
     vsf_destroy(ctx_);
     ctx_ = nullptr;
   }
   vsf_params p;
-  vsf_params_default(&p, width, height, 2 * frames_in_flight());  // a slot of buffers (two images) per frame in flight
+  vsf_params_default(&p, width, height, 2 * batch_frames());  // extraction buffers for one batch of stereo frames
   p.nfeatures = config_.orb_nfeatures;
   p.residual_order = config_.residual_order;
   last_status_ = vsf_params_set_ratio(&p, config_.nn_match_ratio_);
   if (last_status_ != VSF_OK) return false;
   last_status_ = vsf_create(&p, device_, &ctx_);
+  if (last_status_ != VSF_OK) return false;
+  ctx_depth_ = queue_depth();
+  last_status_ = vsf_observe_configure(ctx_, ctx_depth_, min_batch_, 0);
+  pending_.assign((size_t)ctx_depth_, PendingFrame());
+  pending_head_ = pending_count_ = 0;
   return last_status_ == VSF_OK;
 }
 
@@ -542,10 +548,10 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
     return false;
   }
   const vsf_calibration calib = MakeCalibration(config_);
-  // the slot this frame goes into must be free: with every slot in flight, the oldest is collected and booked first
-  while ((int)pending_.size() >= frames_in_flight())
+  // the queue must have room: when it is full, the oldest frame is collected and booked first
+  while ((int)pending_count_ >= queue_depth())
     if (!RetireOldest()) return false;
-  PendingFrame pf;
+  PendingFrame& pf = pending_[(pending_head_ + pending_count_) % pending_.size()];
   last_status_ = vsf_observe_submit(ctx_, left_image.data, right_image.data, left_image.cols, left_image.rows,
                                     left_image.step, &calib, config_.best_percent_, (int)config_.frame_life_, &pf.ticket);
   if (last_status_ != VSF_OK) return false;
@@ -554,7 +560,7 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
   pf.prev_odom_translation = prev_odom_translation_;
   pf.prev_odom_rotation = prev_odom_rotation_;
   pf.odom_timestamp = odom_timestamp_;
-  pending_.push_back(pf);
+  pending_count_++;
   // cc:457-458: the pose of this frame is what the NEXT call's OdomCheck compares with
   prev_odom_rotation_ = odom_rotation_;
   prev_odom_translation_ = odom_translation_;
@@ -563,7 +569,7 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
 }
 
 bool Frontend::Flush() {
-  while (!pending_.empty())
+  while (pending_count_ > 0)
     if (!RetireOldest()) return false;
   return true;
 }
@@ -571,14 +577,13 @@ bool Frontend::Flush() {
 // The second half of ObserveImageFused for the oldest frame in flight: wait for its result, decode it, and do the
 // reference's bookkeeping (cc:424-470) with the odometry that frame's call saw.
 bool Frontend::RetireOldest() {
-  const PendingFrame pf = pending_.front();
-  pending_.erase(pending_.begin());
-  const size_t cap = vsf_observe_capacity(ctx_, (int)config_.frame_life_);
-  if (observe_buf_.size() < cap) observe_buf_.resize(cap);
+  const PendingFrame pf = pending_[pending_head_];
+  pending_head_ = (pending_head_ + 1) % pending_.size();
+  pending_count_--;
   size_t bytes = 0;
-  last_status_ = vsf_observe_collect(ctx_, pf.ticket, observe_buf_.data(), observe_buf_.size(), &bytes);
+  const uint8_t* b = nullptr;  // the result, read where the GPU wrote it (the context's pinned result ring)
+  last_status_ = vsf_observe_collect_view(ctx_, pf.ticket, &b, &bytes);
   if (last_status_ != VSF_OK) return false;
-  const uint8_t* b = observe_buf_.data();
   uint32_t hdr[16];
   std::memcpy(hdr, b, sizeof(hdr));
   const int n_pairs = (int)hdr[1], nfeat = (int)hdr[2];
@@ -597,14 +602,18 @@ bool Frontend::RetireOldest() {
     pair_bytes[p] = b + off;
     off += (size_t)npairs[p] * sizeof(vsf_feature_match);
   }
-  std::vector<vsf_keypoint> kps((size_t)nfeat);
-  std::vector<uint8_t> desc((size_t)nfeat * VSF_DESC_BYTES);
+  Frame curr_frame;  // Frame(kps, desc, curr_frame_ID_), built in place (cc:511-519)
+  curr_frame.frame_ID_ = curr_frame_ID_;
+  curr_frame.keypoints_.resize((size_t)nfeat);
+  curr_frame.descriptors_.resize((size_t)nfeat * VSF_DESC_BYTES);
   if (nfeat > 0) {
-    std::memcpy(kps.data(), b + off, (size_t)nfeat * sizeof(vsf_keypoint));
-    std::memcpy(desc.data(), b + off + (size_t)nfeat * sizeof(vsf_keypoint), desc.size());
+    std::memcpy(curr_frame.keypoints_.data(), b + off, (size_t)nfeat * sizeof(vsf_keypoint));
+    std::memcpy(curr_frame.descriptors_.data(), b + off + (size_t)nfeat * sizeof(vsf_keypoint), curr_frame.descriptors_.size());
   }
-  Frame curr_frame(kps, desc, curr_frame_ID_);
+  curr_frame.is_initial_.assign((size_t)nfeat, true);
+  curr_frame.initial_ids_.assign((size_t)nfeat, -1);
   auto book = [](const Frame& past_frame, Frame* curr, const uint8_t* bytes, uint32_t n, std::vector<FeatureMatch>* pairs) {
+    if (pairs) pairs->reserve(n);
     for (uint32_t k = 0; k < n; k++) {  // cc:294-306
       vsf_feature_match m;
       std::memcpy(&m, bytes + (size_t)k * sizeof(m), sizeof(m));
@@ -621,7 +630,7 @@ bool Frontend::RetireOldest() {
   for (int p = 0; p + 1 < n_pairs; p++) {  // the temporal loop, cc:424-434
     std::vector<FeatureMatch> pairs;
     book(frame_list_[p], &curr_frame, pair_bytes[p], npairs[p], &pairs);
-    vision_factors_.push_back(VisionFactor(frame_list_[p].frame_ID_, curr_frame.frame_ID_, pairs));
+    vision_factors_.emplace_back(frame_list_[p].frame_ID_, curr_frame.frame_ID_, std::move(pairs));
   }
   {  // Calculate3DPoints' GetFeatureMatches(right, left) (cc:131): every row of the right frame is still `initial`
     Frame right_temp_frame;
@@ -639,7 +648,7 @@ bool Frontend::RetireOldest() {
   // cc:444-470 with the odometry of this frame's call
   const Vector3f loc = init_odom_rotation_.inverse() * (pf.odom_translation - init_odom_translation_);
   const Quaternionf angle = pf.odom_rotation * init_odom_rotation_.inverse();
-  nodes_.push_back(SLAMNode(curr_frame_ID_, pf.odom_timestamp, RobotPose(loc, angle), features));
+  nodes_.emplace_back(curr_frame_ID_, pf.odom_timestamp, RobotPose(loc, angle), std::move(features));
   if (curr_frame_ID_ > 0) {  // AddOdometryFactor, cc:311-321
     const Vector3f translation = pf.prev_odom_rotation.inverse() * (pf.odom_translation - pf.prev_odom_translation);
     const Quaternionf rotation(pf.odom_rotation * pf.prev_odom_rotation.inverse());
@@ -647,7 +656,7 @@ bool Frontend::RetireOldest() {
   }
   curr_frame_ID_++;
   if (frame_list_.size() >= config_.frame_life_ && !frame_list_.empty()) frame_list_.erase(frame_list_.begin());
-  frame_list_.push_back(curr_frame);
+  frame_list_.push_back(std::move(curr_frame));
   return true;
 }
 

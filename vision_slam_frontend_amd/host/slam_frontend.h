@@ -114,15 +114,23 @@ class Frontend {
   void set_fused(bool on) { fused_ = on; }
   // ObserveImage's return value is OdomCheck's decision (cc:404-409): nothing in the reference's control flow needs a
   // frame's features before the next frame arrives.  With pipelining on (fused mode; choose before the first
-  // ObserveImage) a call queues its frame on the GPU (vsf_observe_submit) and returns; the frame's result is collected
-  // and booked -- in frame order, with the odometry of ITS call -- when its slot is needed again (frames_in_flight() frames later) or
-  // when anything reads the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and
-  // bytes as the synchronous mode; a GPU failure then surfaces in last_status() a few calls late.
+  // ObserveImage) a call copies its frame into the GPU context's queue (vsf_observe_submit) and returns; frames that wait
+  // there leave for the GPU as ONE batched extraction + tail, and a frame's result is collected and booked -- in frame
+  // order, with the odometry of ITS call -- when the queue is full (queue_depth() frames later) or when anything reads
+  // the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and bytes as the
+  // synchronous mode; a GPU failure then surfaces in last_status() some calls late.
   void set_pipelined(bool on) { pipelined_ = on; }
-  // How many frames ObserveImage keeps in flight when pipelined (1..6, default 4): each runs its ~25 dependent small
-  // kernels on a stream and a set of buffers of its own; their tails stay in frame order.
-  void set_frames_in_flight(int n) { depth_ = n < 1 ? 1 : (n > 6 ? 6 : n); }
-  int frames_in_flight() const { return pipelined_ ? depth_ : 1; }
+  // Frames ObserveImage may leave in the queue when pipelined (1..256, default 32) and the most frames one batch carries
+  // (default 32; the context's extraction buffers are sized for it: ~25 MB per 640x480 frame).
+  void set_queue_depth(int n) { depth_ = n < 1 ? 1 : (n > 256 ? 256 : n); }
+  void set_frames_in_flight(int n) { set_queue_depth(n); }  // (the name of rounds 3-5)
+  void set_batch_frames(int n) { batch_frames_ = n < 1 ? 1 : (n > 128 ? 128 : n); }
+  // While the GPU is busy, fewer waiting frames than this stay in the queue (0 / 1: whatever waits leaves as soon as fewer
+  // than two batches are on the GPU).
+  void set_min_batch(int n) { min_batch_ = n < 0 ? 0 : n; }
+  int queue_depth() const { return pipelined_ ? depth_ : 1; }
+  int frames_in_flight() const { return queue_depth(); }
+  int batch_frames() const { return pipelined_ ? (depth_ < batch_frames_ ? depth_ : batch_frames_) : 1; }
   bool Flush();  // collects and books every frame still in flight; false (and last_status()) if one of them failed
   float stereo_ambig_constraint() const { Sync(); return stereo_ambig_constraint_; }
   const std::vector<Frame>& frame_list() const { Sync(); return frame_list_; }
@@ -177,9 +185,10 @@ class Frontend {
   float stereo_ambig_constraint_;
   bool fused_;
   bool pipelined_;
-  int depth_ = 4;
-  std::vector<PendingFrame> pending_;  // oldest first; at most frames_in_flight()
-  std::vector<uint8_t> observe_buf_;
+  int depth_ = 32, batch_frames_ = 32, min_batch_ = 0;
+  std::vector<PendingFrame> pending_;  // a ring: pending_head_ is the oldest, pending_count_ frames wait
+  size_t pending_head_ = 0, pending_count_ = 0;
+  int ctx_depth_ = 0;
   vsf_ctx* ctx_;
   int device_;
   vsf_status last_status_;

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace slam_types {
@@ -105,6 +106,8 @@ struct VisionFactor {
   VisionFactor() {}
   VisionFactor(uint64_t pose_initial, uint64_t pose_current, const std::vector<FeatureMatch>& feature_matches)
       : pose_idx_initial(pose_initial), pose_idx_current(pose_current), feature_matches(feature_matches) {}
+  VisionFactor(uint64_t pose_initial, uint64_t pose_current, std::vector<FeatureMatch>&& feature_matches)  // (addition)
+      : pose_idx_initial(pose_initial), pose_idx_current(pose_current), feature_matches(std::move(feature_matches)) {}
 };
 
 // slam_types.h:110-130
@@ -135,6 +138,8 @@ struct SLAMNode {
   SLAMNode() {}
   SLAMNode(uint64_t idx, double timestamp, const RobotPose& pose, const std::vector<VisionFeature>& features)
       : node_idx(idx), timestamp(timestamp), pose(pose), features(features) {}
+  SLAMNode(uint64_t idx, double timestamp, const RobotPose& pose, std::vector<VisionFeature>&& features)  // (addition)
+      : node_idx(idx), timestamp(timestamp), pose(pose), features(std::move(features)) {}
 };
 
 // slam_types.h:171-187
