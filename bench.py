@@ -954,10 +954,13 @@ def main() -> int:
             "tail_stream_ms_per_step": None if tail_stages is None else
             {k: v[0] / args.steps for k, v in tail_stages.items()},
         }
-        # The drop-in API one frame at a time (slam::Frontend::ObserveImage, cc:400-472, through the C++ host class): NOT the
-        # benchmarked value, reported beside it.  Synchronous latency per call and frames/s with two frames in flight
-        # (Frontend::set_pipelined), at 2000 features and at the reference's own 10000; driven from Python here (ctypes,
-        # ~10 % slower than tools/time_frontend.cc, whose record is profiles/r03/observe_image.json).
+        # The drop-in API (slam::Frontend::ObserveImage, cc:400-472, through the C++ host class): NOT the benchmarked value,
+        # reported beside it, at 2000 features and at the reference's own 10000.
+        #   observe_image_ms             synchronous latency per call (median; the call returns with the node booked)
+        #   observe_image_unchanged_fps  the reference's driver unchanged: GetSLAMProblem after every node (main.cc:320-321)
+        #   observe_image_pipelined_fps  Frontend::set_pipelined(true): frames wait in the context's queue (depth 256) and
+        #                                leave for the GPU in batches of up to 128; the reference's driver loop in C++
+        #                                (vsfh_time_sequence), median of three runs, all three listed
         out["observe_image"] = None
         report_stage("observe_image leg")
         if world == 1 and not args.no_observe and (W, H) == (640, 480):
@@ -966,9 +969,12 @@ def main() -> int:
             obs = {}
             for nf in (2000, 10000):
                 ms, _, _, _ = tf.observe_image_ms(nf, True, n_frames=96)
-                _, _, _, fps = tf.observe_image_ms(nf, True, n_frames=232, pipelined=True)
-                obs["nfeatures_%d" % nf] = {"observe_image_ms": ms, "observe_image_pipelined_fps": fps}
-            obs["note"] = "640x480, frame_life 10, window full; per stereo frame through slam::Frontend (host/slam_frontend.cc)"
+                unchanged = tf.queued_fps(nf, n_frames=160, pipelined=False, read_every=1)[0][0]
+                runs = sorted(r[0] for r in tf.queued_fps(nf, repeats=3))
+                obs["nfeatures_%d" % nf] = {"observe_image_ms": ms, "observe_image_unchanged_fps": unchanged,
+                                            "observe_image_pipelined_fps": runs[1], "observe_image_pipelined_runs": runs}
+            obs["note"] = ("640x480, frame_life 10, window full; per stereo frame through slam::Frontend (host/slam_frontend.cc); "
+                           "pipelined: queue depth 256, <= 128 frames per batch, 3200 steady frames per run")
             out["observe_image"] = obs
         report_stage("cpu_baseline leg")
         if world == 1 and not args.no_cpu_baseline:

@@ -176,7 +176,11 @@ typedef enum {
   VSF_OPT_MATCH_INT8 = 11,     /* 0: the matcher on the FP4 matrix instruction (K = 64 per instruction); 1: round 2's int8 form */
   VSF_OPT_FAST_BITS = 12,      /* FAST as a segment test on bit planes with scores only where it fires (k_fastbits.hip; same
                                   candidates bit for bit): 0 never, 1 for batches of >= 8 images, 2 for any batch */
-  VSF_OPT_COUNT = 13
+  VSF_OPT_OBSERVE_THREAD = 13,  /* 1 (default): an ObserveImage queue of depth >= 4 has a launcher thread -- the caller stages
+                                 * frames, the thread sends the batches; 0: the caller launches too.  Read when the queue is built */
+  VSF_OPT_PYRAMID_TAIL_MIN = 14, /* smallest batch (images) whose one-band pyramid levels are one launch (a workgroup per image)
+                                  * even when that fills less than three quarters of the chip; 0: never */
+  VSF_OPT_COUNT = 15
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);
@@ -374,9 +378,9 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
  * caller may keep up to `depth` frames submitted and not collected.  Frames that wait are COALESCED: they leave for the GPU
  * as one batched extraction + one batched tail (the threshold chain and the temporal window run through the batch in frame
  * order) -- a frame's chain of ~30 launch-bound kernels costs the same whether it carries one frame or thirty.  A batch
- * leaves whenever fewer than `in_flight` batches are on the GPU (a lone frame at once: the synchronous call is a batch of
- * one), when a full batch (max_images / 2 frames, at most `depth`) waits, or when a waiting frame is collected; while the
- * GPU is busy frames accumulate, so the batch size follows the caller's rate.  Results are those of one frame at a time, bit
+ * leaves when the GPU is idle (a lone frame at once: the synchronous call is a batch of one), when `min_batch` frames wait
+ * and fewer than `in_flight` batches are on the GPU, when a full batch (max_images / 2 frames, at most `depth`) waits, or
+ * when a waiting frame is collected; while the GPU is busy frames accumulate, so the batch size follows the caller's rate.  Results are those of one frame at a time, bit
  * for bit, whatever the batches were (tests/test_gpu_observe.py).
  * Tickets are collected in the order they were issued; a submit beyond `depth` uncollected frames returns
  * VSF_ERR_INVALID_ARG.  Consecutive frames with different calibrations or best_percent never share a batch; frame_life
@@ -395,8 +399,8 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
 size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life);
 /* depth: frames that may be submitted and not collected (0: max_images / 2; up to 1024 -- the staging and result rings are
  * pinned host memory, depth x (2 images + vsf_observe_capacity)); a batch holds min(depth, max_images / 2) frames at most.
- * min_batch (0 = 1): while the GPU is busy, fewer waiting frames than this do not leave (throughput over latency; a collect
- * still sends them).  in_flight (0 = 2, at most 3): batches on the GPU at a time.  Call it before the first submit or while
+ * min_batch (0 = half a batch): while the GPU is busy, fewer waiting frames than this do not leave -- an idle GPU takes
+ * whatever waits, a collect sends everything -- because a batch costs the host ~45 launches whatever it carries.  in_flight (0 = 2, at most 3): batches on the GPU at a time.  Call it before the first submit or while
  * the queue is empty; changing depth rebuilds the queue (window and threshold start over). */
 vsf_status vsf_observe_configure(vsf_ctx* ctx, int depth, int min_batch, int in_flight);
 vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
@@ -409,6 +413,10 @@ vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_
  * further frames have been submitted (the first word, the magic, reads 0 there). */
 vsf_status vsf_observe_collect_view(vsf_ctx* ctx, int64_t ticket, const uint8_t** out, size_t* out_bytes);
 vsf_status vsf_observe_reset(vsf_ctx* ctx);
+/* What the queue did since it was built: out[0..n) of { frames launched, batches, largest batch, batches of one frame that
+ * ran on one stream, launches forced by a collect or a change of parameters, launches that had to wait for a batch slot,
+ * depth, frames per batch at most, then the host's nanoseconds inside staging copies, batch launches, waits for results }. */
+vsf_status vsf_observe_stats(const vsf_ctx* ctx, int64_t* out, int n);
 
 /* SURVEY section 8(f) row f4, the decode itself: DecodeImage's cv::imdecode(msg.data, cv::IMREAD_GRAYSCALE)
  * (slam_frontend_main.cc:99-100) for n JPEG files in HOST memory (the CompressedImage payloads), all of width x height:

@@ -275,6 +275,40 @@ def test_capacity_overflow_is_reported_on_its_own_ticket():
     assert got == want, list(zip(pattern, got))
 
 
+def test_other_entry_points_beside_a_queue_with_its_launcher_thread():
+    """A queue of depth >= 4 has a launcher thread.  Every other entry point of the context first sends what waits in the
+    queue (the thread is idle afterwards), so a host-pointer extraction, an option and a profile read in the middle of a
+    stream of submits neither race with it nor change a result; and a context is destroyed with frames waiting, in flight
+    and uncollected."""
+    from vision_slam_frontend_amd import capi, frontend
+    frames = _sequence(30)
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    bp = float(np.float32(0.3))
+    with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
+        want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
+        kp_want, desc_want = sync_ctx.extract(frames[5][0])
+    with capi.Context(capi.default_params(320, 240, max_images=16, nfeatures=NF)) as ctx:
+        ctx.observe_configure(30, 8, 0)
+        tickets = []
+        for k, (l, r) in enumerate(frames):
+            tickets.append(ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE))
+            if k == 11:
+                kp, desc = ctx.extract(frames[5][0])  # (the same context's extraction buffers and stream)
+                assert kp.tobytes() == kp_want.tobytes() and np.array_equal(desc, desc_want)
+            if k == 17:
+                ctx.set_option(capi.OPT_SELECT_WIDE, 1)
+                assert ctx.sync() == capi.VSF_OK
+        got = [ctx.observe_collect(t, frame_life=LIFE) for t in tickets]
+    for g, w in zip(got, want):
+        _same_observation(w, g)
+    for _ in range(3):
+        ctx = capi.Context(capi.default_params(320, 240, max_images=8, nfeatures=NF))
+        ctx.observe_configure(12, 0, 0)
+        for l, r in frames[:11]:
+            ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE)
+        ctx.close()  # frames waiting in staging, in flight and uncollected; the launcher thread possibly in a launch
+
+
 def test_destroy_with_frames_still_in_flight():
     """vsf_destroy waits for every stream the context launched on -- the slots' streams of frames that were submitted and never
     collected included -- before it frees what their kernels write (device buffers, the pinned result and status words);

@@ -33,8 +33,18 @@ int main(int argc, char** argv) {
   std::printf("{\"what\": \"slam::Frontend::ObserveImage from C++, %dx%d, frame_life 10 (tools/time_frontend.cc)\", \"results\": {", W, H);
   bool first = true;
   for (int nf : nfs) {
-    struct Mode { const char* name; bool fused, pipelined; int frames; };
-    const Mode modes[] = {{"fused", true, false, 160}, {"call_by_call", false, false, 96}, {"pipelined", true, true, 432}};
+    struct Mode { const char* name; bool fused, pipelined; int frames, depth, batch, min_batch, read_every; int thread = 1; int tail_min = 0; };
+    // read_every 1: the reference's driver unchanged -- GetSLAMProblem after every new node (slam_frontend_main.cc:320-321),
+    // which waits for the queue; queued_*: the queue of host/slam_frontend.h at depth / frames per batch / min_batch
+    // queued_dD_bB: the queue of host/slam_frontend.h at depth D, B frames per batch at most ("queued": the class's defaults)
+    const Mode modes[] = {{"fused", true, false, 160, 1, 1, 0, 0},
+                          {"unchanged_caller", true, false, 160, 1, 1, 0, 1},
+                          {"call_by_call", false, false, 96, 1, 1, 0, 0},
+                          {"queued_d8_b8", true, true, 832, 8, 8, 0, 0},
+                          {"queued_d32_b32", true, true, 1632, 32, 32, 0, 0},
+                          {"queued_d128_b64", true, true, 3232, 128, 64, 0, 0},
+                          {"queued_d256_b128_no_thread", true, true, 3232, 256, 128, 0, 0, 0},
+                          {"queued", true, true, 3232, 0, 0, 0, 0}};
     for (const Mode& m : modes) {
       slam::FrontendConfig cfg;
       cfg.orb_nfeatures = nf;
@@ -45,6 +55,11 @@ int main(int argc, char** argv) {
       slam::Frontend fe("", cfg, 0);
       fe.set_fused(m.fused);
       fe.set_pipelined(m.pipelined);
+      if (m.depth > 0) fe.set_queue_depth(m.depth);
+      if (m.batch > 0) fe.set_batch_frames(m.batch);
+      fe.set_min_batch(m.min_batch);
+      fe.set_queue_thread(m.thread != 0);
+      fe.set_context_option(VSF_OPT_PYRAMID_TAIL_MIN, m.tail_min);
       const slam::Quaternionf q(1, 0, 0, 0);
       fe.ObserveOdometry(slam::Vector3f(0, 0, 0), q, 0.0);
       const int warm = 32;
@@ -64,6 +79,11 @@ int main(int argc, char** argv) {
           std::fprintf(stderr, "ObserveImage failed at frame %d (status %d)\n", k, (int)fe.last_status());
           return 1;
         }
+        if (m.read_every > 0 && (k + 1) % m.read_every == 0) {
+          slam_types::SLAMProblem problem;
+          if (k < 64) fe.GetSLAMProblem(&problem);  // (the copy grows with every node: the reference's O(n^2); bounded here)
+          else fe.Flush();
+        }
         if (k >= warm) {
           sum += dt;
           if (dt > worst) worst = dt;
@@ -72,9 +92,14 @@ int main(int argc, char** argv) {
       fe.Flush();
       const double wall = seconds(t0, Clock::now());
       const int n = m.frames - warm;
+      int64_t qs[11];
+      fe.queue_stats(qs);
       std::printf("%s\"%s_%d\": {\"frames_per_s\": %.1f, \"observe_image_ms_mean\": %.4f, \"observe_image_ms_max\": %.4f, "
-                  "\"steady_frames\": %d, \"nodes\": %d}",
-                  first ? "" : ", ", m.name, nf, n / wall, 1e3 * sum / n, 1e3 * worst, n, fe.GetNumPoses());
+                  "\"steady_frames\": %d, \"nodes\": %d, \"batches\": %lld, \"largest_batch\": %lld, \"forced\": %lld, "
+                  "\"slot_waits\": %lld, \"copy_us_per_frame\": %.1f, \"launch_us_per_frame\": %.1f, \"wait_us_per_frame\": %.1f}",
+                  first ? "" : ", ", m.name, nf, n / wall, 1e3 * sum / n, 1e3 * worst, n, fe.GetNumPoses(), (long long)qs[1],
+                  (long long)qs[2], (long long)qs[4], (long long)qs[5], 1e-3 * qs[8] / m.frames, 1e-3 * qs[9] / m.frames,
+                  1e-3 * qs[10] / m.frames);
       first = false;
     }
   }

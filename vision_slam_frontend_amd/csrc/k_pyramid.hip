@@ -631,7 +631,7 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
       return;
     }
   }
-  if (side && (im.n >= 64 || few)) {
+  if (side && (im.n >= 64 || few || (d.tune && d.tune->pyramid_tail_min > 0 && im.n >= d.tune->pyramid_tail_min))) {
     static int ncu = 0;
     if (ncu == 0) {
       int dev = 0;
@@ -640,7 +640,8 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
       if (ncu <= 0) ncu = 256;
     }
     const int rounds = (im.n + ncu - 1) / ncu;
-    if (few || 4 * im.n >= 3 * rounds * ncu) {
+    const int tail_min = d.tune ? d.tune->pyramid_tail_min : 0;
+    if (few || 4 * im.n >= 3 * rounds * ncu || (tail_min > 0 && im.n >= tail_min)) {
       while (l_tail > 2 && h_levels[l_tail - 1].w <= 256 && h_levels[l_tail - 1].resize_rows >= 8 &&
              h_levels[l_tail - 1].pitch * h_levels[l_tail - 1].h + 16 <= kTailLdsBytes)
         --l_tail;

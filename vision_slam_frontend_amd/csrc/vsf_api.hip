@@ -395,6 +395,16 @@ vsf_status extract_async(vsf_ctx* ctx, const VsfImages& im, vsf_keypoint* d_kp, 
   return VSF_OK;
 }
 
+// The second pyramid buffer and the events of cross-call pipelining (vsf_set_pipeline, the ObserveImage queue).
+vsf_status ensure_pipeline_buffers(vsf_ctx* ctx) {
+  if (ctx->pyr_alt) return VSF_OK;
+  VSF_HIP(hipMalloc((void**)&ctx->pyr_alt, (size_t)ctx->p.max_images * ctx->orb.g.pyr_bytes));
+  VSF_HIP(hipEventCreateWithFlags(&ctx->ev_pyr_done, hipEventDisableTiming));
+  VSF_HIP(hipEventCreateWithFlags(&ctx->ev_fast_done, hipEventDisableTiming));
+  for (hipEvent_t& e : ctx->ev_pyr_free) VSF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return VSF_OK;
+}
+
 }  // namespace vsfi
 
 hipStream_t vsf_ctx_stream(const vsf_ctx* ctx) { return ctx->stream; }
@@ -556,6 +566,7 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
 void vsf_destroy(vsf_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  stop_observe_threads(ctx);  // (the queue's launcher may be in the middle of a batch)
   // every stream the context ever launched on -- the slots' streams of frames still in flight included: their kernels
   // write device buffers and pinned host memory that is freed below
   sync_all_streams(ctx);
@@ -694,6 +705,7 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
     case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
     case VSF_OPT_PIPE_AFTER_FAST: t.pipe_after_fast = value != 0; break;
     case VSF_OPT_MATCH_INT8: t.match_int8 = value != 0; break;
+    case VSF_OPT_OBSERVE_THREAD: t.observe_thread = value != 0; break;  // (read when the queue is built)
     case VSF_OPT_FAST_BITS:
       if (value < 0 || value > 2) return VSF_ERR_INVALID_ARG;
       t.fast_bits = value;
@@ -722,6 +734,10 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
       if (value < 1) return VSF_ERR_INVALID_ARG;
       t.pyramid_rows = value;
       break;
+    case VSF_OPT_PYRAMID_TAIL_MIN:
+      if (value < 0) return VSF_ERR_INVALID_ARG;
+      t.pyramid_tail_min = value;
+      break;
     default: return VSF_ERR_INVALID_ARG;
   }
   return VSF_OK;
@@ -738,12 +754,14 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
     case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
     case VSF_OPT_PIPE_AFTER_FAST: *value = t.pipe_after_fast; break;
     case VSF_OPT_MATCH_INT8: *value = t.match_int8; break;
+    case VSF_OPT_OBSERVE_THREAD: *value = t.observe_thread; break;
     case VSF_OPT_FAST_BITS: *value = t.fast_bits; break;
     case VSF_OPT_PIPE_PRIORITY: *value = t.pipe_priority; break;
     case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
     case VSF_OPT_PYRAMID_CHAIN: *value = t.pyramid_chain; break;
     case VSF_OPT_PYRAMID_ROWS: *value = t.pyramid_rows; break;
+    case VSF_OPT_PYRAMID_TAIL_MIN: *value = t.pyramid_tail_min; break;
     default: return VSF_ERR_INVALID_ARG;
   }
   return VSF_OK;
@@ -768,11 +786,9 @@ vsf_status vsf_set_pipeline(vsf_ctx* ctx, int on) {
       ctx->pipe_stream_priority = ctx->tuning.pipe_priority;
     }
   }
-  if (on && !ctx->pyr_alt) {
-    VSF_HIP(hipMalloc((void**)&ctx->pyr_alt, (size_t)ctx->p.max_images * ctx->orb.g.pyr_bytes));
-    VSF_HIP(hipEventCreateWithFlags(&ctx->ev_pyr_done, hipEventDisableTiming));
-    VSF_HIP(hipEventCreateWithFlags(&ctx->ev_fast_done, hipEventDisableTiming));
-    for (hipEvent_t& e : ctx->ev_pyr_free) VSF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (on) {
+    const vsf_status st = ensure_pipeline_buffers(ctx);
+    if (st != VSF_OK) return st;
   }
   ctx->pipeline = on != 0;
   ctx->pyr_free_valid[0] = ctx->pyr_free_valid[1] = false;

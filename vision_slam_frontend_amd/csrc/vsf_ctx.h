@@ -131,6 +131,7 @@ struct vsf_ctx {
   std::vector<void*> retired;
   // The ObserveImage queue (vsf_observe.hip): frames wait in pinned staging and leave for the GPU in batches.
   static constexpr int kObserveBatchSlots = 4;
+  struct ObserveLauncher;    // the queue's lock and its launcher thread
   struct ObserveBatchMeta;  // pinned, device-visible: read by the kernels over PCIe (no copy command)
   struct ObserveBatch {     // what one batch's extraction writes and its tail reads
     uint8_t* d_img = nullptr;        // [2 bmax] images at the staging pitch
@@ -179,14 +180,18 @@ struct vsf_ctx {
     ObserveBatch batch[kObserveBatchSlots];
     std::vector<ObserveFrame> frames;  // [depth]
     hipStream_t copy_stream = nullptr, tail_stream = nullptr;
+    ObserveLauncher* launcher = nullptr;
     int64_t next_ticket = 0;   // tickets issued
     int64_t next_launch = 0;   // first frame still waiting in staging
     int64_t next_collect = 0;  // oldest frame not collected
     int64_t batches = 0;       // batches launched
+    int64_t last_submit_ns = 0;  // when the last frame arrived
     int last_batch = -1;       // slot of the batch launched last
+    int64_t stat_frames = 0, stat_max_batch = 0, stat_solo = 0, stat_forced = 0, stat_slot_waits = 0;  // vsf_observe_stats
+    int64_t stat_copy_ns = 0, stat_launch_ns = 0, stat_wait_ns = 0;  // host time in staging copies, launches, waits
   } ob;
   // vsf_observe_configure (before the queue is built by the first submit; 0 = defaults)
-  int ob_depth = 0, ob_min_batch = 1, ob_in_flight = 2;
+  int ob_depth = 0, ob_min_batch = 0, ob_in_flight = 2;
   // vsf_jpeg_decode_gray_batch: pinned staging + device copy of the packed headers / tables / entropy-coded segments
   // (two sets, used alternately: the host fills one while the previous call's upload / decode still use the other)
   int32_t* jp_flags = nullptr;  // [jp_flags_cap] per progressive file of a call: damaged, decode again scan after scan
@@ -282,7 +287,9 @@ vsf_status ensure_temporal_buffers(vsf_ctx* ctx, int n_pairs);
 vsf_status ensure_vision_buffers(vsf_ctx* ctx, int n_frames);
 vsf_status ensure_pack_buffers(vsf_ctx* ctx, int n);
 vsf_status reserve_scratch(vsf_ctx* ctx, int n_frames, int n_pairs);
-void free_observe(vsf_ctx* ctx);  // vsf_observe.hip
+vsf_status ensure_pipeline_buffers(vsf_ctx* ctx);
+void free_observe(vsf_ctx* ctx);          // vsf_observe.hip
+void stop_observe_threads(vsf_ctx* ctx);  // ... before anything waits for the context's streams to drain
 
 vsf_status check_status_word(vsf_ctx* ctx);
 vsf_status validate_images(const vsf_ctx* ctx, const uint8_t* d_imgs, int n, size_t image_stride, size_t row_stride);

@@ -103,6 +103,9 @@ struct VsfTuning {
   int pyramid_few = 16;    // VSF_OPT_PYRAMID_FEW: largest batch (images) that takes the slab kernel for every level
   int pyramid_chain = 8;   // VSF_OPT_PYRAMID_CHAIN: levels per slab launch (0: keep the per-level launches)
   int pyramid_rows = 6;    // VSF_OPT_PYRAMID_ROWS: rows of the chain's last level per slab
+  int pyramid_tail_min = 0;  // VSF_OPT_PYRAMID_TAIL_MIN: smallest batch (images) whose one-band levels take the image-major kernel whatever
+                             // share of the chip it fills (0: only batches that fill three quarters of a round of workgroups)
+  int observe_thread = 1;  // VSF_OPT_OBSERVE_THREAD: the launcher thread of an ObserveImage queue of depth >= 4
   int lds_limit = 0;       // largest dynamic LDS a workgroup may ask for on this device (queried at vsf_create)
 };
 
@@ -124,9 +127,14 @@ constexpr int VSF_RCCL_ERROR_BASE = 10000;             // vsf_last_hip_error = 1
 // (vsf_ctx::pending_hip) and is returned by that context's next checking call (VSF_STICKY), never by another context that
 // happens to be driven from the same host thread.
 void vsf_ctx_absorb_noted_error(vsf_ctx* ctx);
+// ... and on the way IN every entry point but the ObserveImage queue's own first sends what waits in that queue, so that
+// nothing else ever runs beside the queue's launcher thread (vsf_observe.hip).
+void vsf_ctx_enter(vsf_ctx* ctx);
 struct VsfErrorScope {
   vsf_ctx* ctx;
-  explicit VsfErrorScope(vsf_ctx* c) : ctx(c) {}
+  explicit VsfErrorScope(vsf_ctx* c, bool enter = true) : ctx(c) {
+    if (ctx && enter) vsf_ctx_enter(ctx);
+  }
   ~VsfErrorScope() {
     if (ctx && vsf_tls_hip_error != 0) vsf_ctx_absorb_noted_error(ctx);
   }

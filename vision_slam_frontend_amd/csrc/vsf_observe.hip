@@ -10,24 +10,57 @@
 //               result per frame written straight into pinned host memory.
 // A frame's launch-bound chain of ~30 small kernels costs the host 5.4 us per launch and the GPU a launch-to-launch latency
 // per kernel whatever the batch holds, so a batch of n frames costs little more than a batch of one until the chip is full.
-// When a batch leaves: whenever fewer than `in_flight` batches are on the GPU (a lone frame leaves at once: the synchronous
-// call is a batch of one), when a whole batch waits, or when somebody collects a frame that still waits.  While the GPU is
-// busy, frames accumulate -- the batch size follows the caller's rate by itself.
+// When a batch leaves: at once when the GPU is idle (a lone frame: the synchronous call is a batch of one); when `min_batch`
+// frames wait (half a batch by default) and fewer than `in_flight` batches are on the GPU; when a whole batch waits; or
+// when somebody collects a frame that still waits.  While the GPU is busy, frames accumulate -- the batch size follows the
+// caller's rate by itself.
 // The kept frames' filtered descriptors live in a ring of descriptor sets in HBM (frame g in set g % ring); the pair list
 // of a batch addresses them by set index, so a frame matches against frames of earlier batches and of its own alike.
 // Results are those of one frame at a time, bit for bit (tests/test_gpu_observe.py).
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "vsf_ctx.h"
 
 using namespace vsfi;
+
+// One row-wise copy of an image into the staging ring (rows at the device pitch): 5-7 us per 640x480 image on one core.
+// (Measured and left out: a second thread that takes the right image while frames stream in -- the copy's share drops from
+// 13 to 7 us per frame and the frame rate does not move: with the launches on their own thread the GPU is what the caller
+// waits for.)
+static void stage_image(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t width, int rows) {
+  if (dst_pitch == src_pitch) {
+    std::memcpy(dst, src, (size_t)(rows - 1) * src_pitch + width);
+  } else {
+    for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * dst_pitch, src + (size_t)y * src_pitch, width);
+  }
+}
+
+// Who launches.  A batch costs the host 0.1 ms (a lone frame) to 0.3 ms (the batched pyramid alone is 50-100 launches):
+// on the caller's thread that was a third of what a queued frame cost.  A queue of depth >= 4 therefore has a LAUNCHER
+// thread: the caller stages frames (10 us each) and the thread sends whatever the policy releases, polling the GPU's state
+// while frames wait.  The caller still launches by itself where waiting for the thread would cost more than it saves: when
+// it collects a frame that still waits (the synchronous call: submit, collect), and for every other entry point of the
+// context, which first sends everything that waits (VsfErrorScope -> vsf_ctx_enter), so that nothing else ever runs beside
+// the thread.  `launching` is the baton: whoever holds it is alone inside launch_batch.
+struct vsf_ctx::ObserveLauncher {
+  std::mutex mu;  // guards next_ticket / next_launch / next_collect, launching, stop, status
+  std::condition_variable cv_thread, cv_caller;
+  bool launching = false, stop = false, has_thread = false;
+  vsf_status status = VSF_OK;  // first failure of a launch: sticky until the queue is rebuilt
+  std::thread th;
+};
 
 struct vsf_ctx::ObserveBatchMeta {
   int32_t n_frames, n_pairs;
@@ -60,14 +93,33 @@ MetaView meta_view(vsf_ctx::ObserveBatchMeta* m, int max_pairs, int bmax) {
   return v;
 }
 
+inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 bool same_calibration(const vsf_calibration& a, const vsf_calibration& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
 }  // namespace
 
 namespace vsfi {
 
+void stop_observe_threads(vsf_ctx* ctx) {
+  vsf_ctx::Observe& o = ctx->ob;
+  if (o.launcher && o.launcher->has_thread) {
+    {
+      std::lock_guard<std::mutex> g(o.launcher->mu);
+      o.launcher->stop = true;
+    }
+    o.launcher->cv_thread.notify_all();
+    o.launcher->th.join();
+    o.launcher->has_thread = false;
+  }
+}
+
 void free_observe(vsf_ctx* ctx) {
   vsf_ctx::Observe& o = ctx->ob;
+  stop_observe_threads(ctx);
+  delete o.launcher;
   hipFree(o.sets);
   hipFree(o.set_counts);
   hipFree(o.residual);
@@ -107,6 +159,8 @@ void free_observe(vsf_ctx* ctx) {
 }  // namespace vsfi
 
 namespace {
+
+void launcher_thread(vsf_ctx* ctx);
 
 vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   vsf_ctx::Observe& o = ctx->ob;
@@ -168,9 +222,19 @@ vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   int prio_lo = 0, prio_hi = 0;
   VSF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   VSF_HIP(hipStreamCreateWithPriority(&o.tail_stream, hipStreamNonBlocking, prio_hi));
-  VSF_HIP(hipStreamCreateWithFlags(&o.copy_stream, hipStreamNonBlocking));
+  // ... and the uploads the LOWEST: with the default priority the copy stream may land on the hardware queue of the
+  // context's stream (HIP hands its few queues out round-robin) and the next batch's upload then waits for this batch's
+  // extraction instead of running beside it -- which it did or did not from one context to the next (17 k or 27 k frames/s)
+  VSF_HIP(hipStreamCreateWithPriority(&o.copy_stream, hipStreamNonBlocking, prio_lo));
   VSF_HIP(hipDeviceSynchronize());
+  o.launcher = new (std::nothrow) vsf_ctx::ObserveLauncher();
+  if (!o.launcher) return VSF_ERR_INVALID_ARG;
   o.ready = true;
+  // the launcher thread of a deep queue (VSF_OPT_OBSERVE_THREAD; without it the caller launches everything)
+  if (o.depth >= 4 && ctx->tuning.observe_thread) {
+    o.launcher->has_thread = true;
+    o.launcher->th = std::thread(launcher_thread, ctx);
+  }
   return VSF_OK;
 }
 
@@ -183,20 +247,24 @@ int batches_on_gpu(vsf_ctx* ctx) {  // launched and not finished (a query costs 
 }
 
 // Queues frames [t0, t0 + n) -- they wait in consecutive staging slots -- as one batch.
-vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n) {
+vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n, bool solo) {
   vsf_ctx::Observe& o = ctx->ob;
+  const int64_t t_begin = now_ns();
   const int bi = (int)(o.batches % vsf_ctx::kObserveBatchSlots);
   vsf_ctx::ObserveBatch& b = o.batch[bi];
   // The slot's previous batch must have left the GPU: its kernels read the pinned parameter block that is rewritten below
   // (with `in_flight` batches on the GPU and four slots it has, long ago).
-  if (b.used) VSF_HIP(hipEventSynchronize(b.ev_done));
+  if (b.used) {
+    if (hipEventQuery(b.ev_done) != hipSuccess) o.stat_slot_waits++;
+    (void)hipGetLastError();
+    VSF_HIP(hipEventSynchronize(b.ev_done));
+  }
   const size_t K = (size_t)ctx->p.max_keypoints;
   const int Kc = (int)K, life = o.frame_life;
   const vsf_ctx::ObserveFrame& f0 = o.frames[(size_t)(t0 % o.depth)];
-  // A lone frame with nothing else on the GPU runs on ONE stream from upload to result (no event hops in its chain);
+  // solo: a lone frame with nothing else on the GPU runs on ONE stream from upload to result (no event hops in its chain);
   // otherwise copy, extraction and tail have a stream each, so that the next batch's upload and extraction run beside
   // this one's tail.
-  const bool solo = n == 1 && batches_on_gpu(ctx) == 0;
   hipStream_t s_copy = solo ? ctx->stream : o.copy_stream, s_ex = ctx->stream, s_tail = solo ? ctx->stream : o.tail_stream;
   // ---- upload: ONE copy command (two when the frames wrap around the staging ring) ----
   {
@@ -240,6 +308,10 @@ vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n) {
   b.h_meta->n_pairs = n_pairs;
   // ---- ExtractFeatures x 2 + GetMatches of every frame (cc:411-416) ----
   const VsfImages im{b.d_img, ctx->st_img_stride, ctx->st_img_pitch, 2 * n};
+  // (Measured and left out: the pyramid of a batch on a side stream beside the previous batch's later stages, the
+  // cross-call pipelining of vsf_set_pipeline -- 27.5 -> 23.4 k frames/s at 64 frames per batch, 31.9 -> 27.5 k at 128: the
+  // single chain of 49 dependent launches is slower than the two chains + image-major kernel it replaces and takes the
+  // vector ALU from the stages it runs beside.)
   extract_on(ctx, s_ex, im, 0, 2 * n, b.kp_raw, b.desc_raw, b.counts_raw, false, nullptr, b.status, 1);
   ctx->last_images = im;
   ctx->last_valid = true;
@@ -308,31 +380,107 @@ vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n) {
   for (int f = 0; f < n; f++) o.frames[(size_t)((t0 + f) % o.depth)].batch = bi;
   o.last_batch = bi;
   o.batches++;
-  o.next_launch = t0 + n;
+  o.stat_frames += n;
+  o.stat_max_batch = std::max<int64_t>(o.stat_max_batch, n);
+  if (solo) o.stat_solo++;
+  o.stat_launch_ns += now_ns() - t_begin;
   VSF_STICKY();
   return VSF_OK;
 }
 
-// Sends waiting frames to the GPU.  force: everything that waits, now (somebody collects one of them).
-vsf_status pump(vsf_ctx* ctx, bool force) {
+// How many of the waiting frames leave now (0: none).  mu held, nobody launching.
+int batch_to_launch(vsf_ctx* ctx, bool force) {
   vsf_ctx::Observe& o = ctx->ob;
-  while (o.next_launch < o.next_ticket) {
-    const int pending = (int)(o.next_ticket - o.next_launch);
-    int n = 0;
-    if (force || pending >= o.bmax) {
-      n = std::min(pending, o.bmax);
-    } else {
-      const int busy = batches_on_gpu(ctx);
-      if (busy < ctx->ob_in_flight && (busy == 0 || pending >= ctx->ob_min_batch)) n = pending;
+  const int pending = (int)(o.next_ticket - o.next_launch);
+  if (pending <= 0) return 0;
+  if (force || pending >= o.bmax) return std::min(pending, o.bmax);
+  // An idle GPU takes whatever waits.  A busy one is in no hurry: frames wait for company -- half a batch by default --
+  // because a batch costs ~50-100 launches whatever it carries (measured on the caller's thread: batches of 1-8 frames
+  // 14 k frames/s, of 32-64 frames 27 k).
+  // ... and "idle" must not be mistaken for "nobody is coming": while frames stream in (the last one arrived less than
+  // 100 us ago) even an idle GPU waits for min_batch of them.  Without that a GPU that once ran dry keeps being fed batches of
+  // a few frames, each gone before the next has gathered (measured: the same queue at 15 k or 32 k frames/s).
+  const int busy = batches_on_gpu(ctx);
+  const int min_batch = ctx->ob_min_batch > 0 ? std::min(ctx->ob_min_batch, o.bmax) : std::max(1, o.bmax / 2);
+  if (busy < ctx->ob_in_flight && pending >= min_batch) return pending;
+  return (busy == 0 && now_ns() - o.last_submit_ns > 100000) ? pending : 0;
+}
+
+// One batch, by whoever holds the lock: takes the baton, launches outside the lock, publishes next_launch.
+vsf_status launch_one(vsf_ctx* ctx, std::unique_lock<std::mutex>& lk, int n) {
+  vsf_ctx::Observe& o = ctx->ob;
+  vsf_ctx::ObserveLauncher& L = *o.launcher;
+  const int64_t t0 = o.next_launch;
+  const bool solo = n == 1 && batches_on_gpu(ctx) == 0;
+  L.launching = true;
+  lk.unlock();
+  const vsf_status st = launch_batch(ctx, t0, n, solo);
+  lk.lock();
+  L.launching = false;
+  if (st == VSF_OK)
+    o.next_launch = t0 + n;
+  else if (L.status == VSF_OK)
+    L.status = st;
+  L.cv_caller.notify_all();
+  if (L.has_thread) L.cv_thread.notify_one();
+  return st;
+}
+
+// The caller's side.  force: everything that waits leaves now (somebody collects one of them, the parameters change, or
+// another entry point of the context is about to run); otherwise whatever the policy releases.  mu held on entry and exit.
+vsf_status caller_pump(vsf_ctx* ctx, std::unique_lock<std::mutex>& lk, bool force) {
+  vsf_ctx::Observe& o = ctx->ob;
+  vsf_ctx::ObserveLauncher& L = *o.launcher;
+  while (true) {
+    if (L.launching) {  // the thread is at it
+      if (!force) return VSF_OK;
+      L.cv_caller.wait(lk);
+      continue;
     }
-    if (n == 0) break;
-    const vsf_status st = launch_batch(ctx, o.next_launch, n);
+    if (L.status != VSF_OK) return L.status;
+    const int n = batch_to_launch(ctx, force);
+    if (n == 0) return VSF_OK;
+    if (force) o.stat_forced++;
+    const vsf_status st = launch_one(ctx, lk, n);
     if (st != VSF_OK) return st;
   }
-  return VSF_OK;
+}
+
+void launcher_thread(vsf_ctx* ctx) {
+  vsf_ctx::Observe& o = ctx->ob;
+  vsf_ctx::ObserveLauncher& L = *o.launcher;
+  if (hipSetDevice(ctx->device) != hipSuccess) {
+    std::lock_guard<std::mutex> g(L.mu);
+    L.status = VSF_ERR_HIP;
+    return;
+  }
+  std::unique_lock<std::mutex> lk(L.mu);
+  while (!L.stop) {
+    if (L.launching || L.status != VSF_OK || o.next_launch >= o.next_ticket) {
+      L.cv_thread.wait(lk);  // (a submit into an empty queue, the end of a launch and stop notify)
+      continue;
+    }
+    const int n = batch_to_launch(ctx, false);
+    if (n == 0) {  // frames wait for company or for the GPU: its state changes without a notification
+      L.cv_thread.wait_for(lk, std::chrono::microseconds(40));
+      continue;
+    }
+    (void)launch_one(ctx, lk, n);
+  }
 }
 
 }  // namespace
+
+// Every entry point of the context except the queue's own comes through here (VsfErrorScope): what waits in the queue
+// leaves first and the launcher thread is idle afterwards -- it only wakes for frames that wait.
+void vsf_ctx_enter(vsf_ctx* ctx) {
+  vsf_ctx::Observe& o = ctx->ob;
+  if (!o.ready || !o.launcher || !o.launcher->has_thread) return;
+  if (hipSetDevice(ctx->device) != hipSuccess) return;
+  std::unique_lock<std::mutex> lk(o.launcher->mu);
+  (void)caller_pump(ctx, lk, true);
+  while (o.launcher->launching) o.launcher->cv_caller.wait(lk);
+}
 
 extern "C" {
 
@@ -343,25 +491,36 @@ size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life) {
 }
 
 vsf_status vsf_observe_configure(vsf_ctx* ctx, int depth, int min_batch, int in_flight) {
-  VsfErrorScope scope_(ctx);
+  VsfErrorScope scope_(ctx);  // (sends what waits; the launcher thread is idle afterwards)
   if (!ctx || depth < 0 || depth > 1024 || min_batch < 0 || in_flight < 0 || in_flight > vsf_ctx::kObserveBatchSlots - 1)
     return VSF_ERR_INVALID_ARG;
   if (ctx->ob.ready && ctx->ob.next_collect != ctx->ob.next_ticket) return VSF_ERR_INVALID_ARG;  // frames in the queue
   if (ctx->ob.ready && depth != ctx->ob_depth) {  // the queue is rebuilt by the next submit; the threshold and the window go
     VSF_HIP(hipSetDevice(ctx->device));
+    stop_observe_threads(ctx);
     sync_all_streams(ctx);
     free_observe(ctx);
   }
   ctx->ob_depth = depth;
-  ctx->ob_min_batch = std::max(1, min_batch);
+  ctx->ob_min_batch = min_batch;
   ctx->ob_in_flight = in_flight > 0 ? in_flight : 2;
   return VSF_OK;
 }
 
+vsf_status vsf_observe_stats(const vsf_ctx* ctx, int64_t* out, int n) {
+  if (!ctx || !out || n < 1) return VSF_ERR_INVALID_ARG;
+  const vsf_ctx::Observe& o = ctx->ob;
+  const int64_t v[11] = {o.stat_frames, o.batches, o.stat_max_batch, o.stat_solo, o.stat_forced, o.stat_slot_waits,
+                         (int64_t)o.depth, (int64_t)o.bmax, o.stat_copy_ns, o.stat_launch_ns, o.stat_wait_ns};
+  for (int i = 0; i < n && i < 11; i++) out[i] = v[i];
+  return VSF_OK;
+}
+
 vsf_status vsf_observe_reset(vsf_ctx* ctx) {
-  VsfErrorScope scope_(ctx);
+  VsfErrorScope scope_(ctx, false);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
+  stop_observe_threads(ctx);  // (frames that still wait are dropped)
   sync_all_streams(ctx);
   free_observe(ctx);
   return VSF_OK;
@@ -369,7 +528,7 @@ vsf_status vsf_observe_reset(vsf_ctx* ctx) {
 
 vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, int64_t* ticket) {
-  VsfErrorScope scope_(ctx);
+  VsfErrorScope scope_(ctx, false);
   if (!ctx || !left || !right || !calib || !ticket || !(best_percent >= 0.f) || frame_life < 0 ||
       frame_life + 1 > VSF_OBSERVE_MAX_PAIRS)
     return VSF_ERR_INVALID_ARG;
@@ -381,36 +540,49 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   VSF_HIP(hipSetDevice(ctx->device));
   vsf_ctx::Observe& o = ctx->ob;
   // (re-sizing the window drops nothing that is still in the queue)
-  if (o.ready && o.frame_life != frame_life && o.next_collect != o.next_ticket) return VSF_ERR_INVALID_ARG;
+  if (o.ready && o.frame_life != frame_life) {
+    if (o.next_collect != o.next_ticket) return VSF_ERR_INVALID_ARG;
+    stop_observe_threads(ctx);
+  }
   vsf_status st = ensure_observe(ctx, frame_life);
   if (st != VSF_OK) return st;
   if (o.next_ticket - o.next_collect >= o.depth) return VSF_ERR_INVALID_ARG;  // collect the oldest frame first
-  // a batch shares one calibration and one best_percent: a frame that brings others starts a new batch
-  if (o.next_launch < o.next_ticket) {
-    const vsf_ctx::ObserveFrame& w0 = o.frames[(size_t)(o.next_launch % o.depth)];
-    if (w0.best_percent != best_percent || !same_calibration(w0.calib, *calib)) {
-      st = pump(ctx, true);
-      if (st != VSF_OK) return st;
-    }
-  }
-  // ---- the two images into the frame's slot of the pinned staging ring, rows at the device pitch ----
+  vsf_ctx::ObserveLauncher& L = *o.launcher;
   const int slot = (int)(o.next_ticket % o.depth);
-  const uint8_t* src[2] = {left, right};
-  uint8_t* h_img = o.h_img + (size_t)slot * 2 * ctx->st_img_stride;
-  for (int i = 0; i < 2; i++) {
-    uint8_t* dst = h_img + (size_t)i * ctx->st_img_stride;
-    if (stride == ctx->st_img_pitch) {  // the caller's rows already sit at the staging pitch: one copy per image
-      std::memcpy(dst, src[i], (size_t)(h - 1) * stride + (size_t)w);
-    } else {
-      for (int y = 0; y < h; y++) std::memcpy(dst + (size_t)y * ctx->st_img_pitch, src[i] + (size_t)y * stride, (size_t)w);
+  {
+    // a batch shares one calibration and one best_percent: a frame that brings others sends what waits first
+    std::unique_lock<std::mutex> lk(L.mu);
+    if (L.status != VSF_OK) return L.status;
+    if (o.next_launch < o.next_ticket) {
+      const vsf_ctx::ObserveFrame& w0 = o.frames[(size_t)((o.next_ticket - 1) % o.depth)];
+      if (w0.best_percent != best_percent || !same_calibration(w0.calib, *calib)) {
+        st = caller_pump(ctx, lk, true);
+        if (st != VSF_OK) return st;
+      }
     }
   }
+  // ---- the two images into the frame's slot of the pinned staging ring, rows at the device pitch (the slot's previous
+  // frame has been collected: its upload is long done) ----
+  uint8_t* h_img = o.h_img + (size_t)slot * 2 * ctx->st_img_stride;
+  const int64_t t_copy = now_ns();
+  stage_image(h_img, ctx->st_img_pitch, left, stride, (size_t)w, h);
+  stage_image(h_img + ctx->st_img_stride, ctx->st_img_pitch, right, stride, (size_t)w, h);
+  o.stat_copy_ns += now_ns() - t_copy;
   vsf_ctx::ObserveFrame& fr = o.frames[(size_t)slot];
   fr.calib = *calib;
   fr.best_percent = best_percent;
   fr.batch = -1;
+  std::unique_lock<std::mutex> lk(L.mu);
+  const bool was_empty = o.next_launch == o.next_ticket;
   *ticket = o.next_ticket++;
-  return pump(ctx, false);
+  o.last_submit_ns = now_ns();
+  if (L.has_thread) {
+    // the thread launches: it sleeps while nothing waits and polls while something does.  (A caller that collects right
+    // away launches the frame itself there -- waking the thread would cost more than the launch.)
+    if (was_empty) L.cv_thread.notify_one();
+    return VSF_OK;
+  }
+  return caller_pump(ctx, lk, false);
 }
 
 // Waits for the frame of `ticket` and points at its result inside the pinned result ring (valid until `depth` further
@@ -421,28 +593,42 @@ static vsf_status observe_wait(vsf_ctx* ctx, int64_t ticket, const uint8_t** vie
   // frames leave in the order they entered (the host's bookkeeping is sequential)
   if (!o.ready || ticket < 0 || ticket != o.next_collect || ticket >= o.next_ticket) return VSF_ERR_INVALID_ARG;
   VSF_HIP(hipSetDevice(ctx->device));
-  if (ticket >= o.next_launch) {  // it still waits in staging: everything that waits leaves now
-    const vsf_status st = pump(ctx, true);
-    if (st != VSF_OK) return st;
-  }
+  vsf_ctx::ObserveLauncher& L = *o.launcher;
   const int slot = (int)(ticket % o.depth);
-  const vsf_ctx::ObserveBatch& b = o.batch[o.frames[(size_t)slot].batch];
-  VSF_HIP(hipEventSynchronize(b.ev_done));
-  o.next_collect = ticket + 1;
+  const vsf_ctx::ObserveBatch* b = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(L.mu);
+    if (ticket >= o.next_launch) {  // it still waits in staging: everything that waits leaves now
+      const vsf_status st = caller_pump(ctx, lk, true);
+      if (st != VSF_OK) return st;
+    }
+    if (ticket >= o.next_launch) return L.status != VSF_OK ? L.status : VSF_ERR_HIP;
+    b = &o.batch[o.frames[(size_t)slot].batch];
+  }
+  {
+    const int64_t t_wait = now_ns();
+    VSF_HIP(hipEventSynchronize(b->ev_done));
+    o.stat_wait_ns += now_ns() - t_wait;
+  }
   const uint8_t* res = o.h_out + (size_t)slot * o.out_stride;
   const uint32_t* hdr = reinterpret_cast<const uint32_t*>(res);
+  vsf_status st = VSF_OK;
+  {
+    std::unique_lock<std::mutex> lk(L.mu);
+    o.next_collect = ticket + 1;
+    if (!L.has_thread) st = caller_pump(ctx, lk, false);  // (the GPU may have room again)
+  }
   if (hdr[0] != 0x4F465356u) return VSF_ERR_HIP;
   const_cast<uint32_t*>(hdr)[0] = 0;  // (the slot's next frame must write its own)
   *view = res;
   *bytes = hdr[3];
-  vsf_status st = pump(ctx, false);  // (the GPU may have room again)
   if (st != VSF_OK) return st;
   if (hdr[11] != 0) return VSF_ERR_CAPACITY;  // the result does not fit its slot
   return hdr[12] != 0 ? VSF_ERR_CAPACITY : VSF_OK;
 }
 
 vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_t cap, size_t* out_bytes) {
-  VsfErrorScope scope_(ctx);
+  VsfErrorScope scope_(ctx, false);
   if (!ctx || !out || !out_bytes) return VSF_ERR_INVALID_ARG;
   const uint8_t* view = nullptr;
   const vsf_status st = observe_wait(ctx, ticket, &view, out_bytes);
@@ -455,7 +641,7 @@ vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_
 }
 
 vsf_status vsf_observe_collect_view(vsf_ctx* ctx, int64_t ticket, const uint8_t** out, size_t* out_bytes) {
-  VsfErrorScope scope_(ctx);
+  VsfErrorScope scope_(ctx, false);
   if (!ctx || !out || !out_bytes) return VSF_ERR_INVALID_ARG;
   *out = nullptr;
   return observe_wait(ctx, ticket, out, out_bytes);
@@ -464,7 +650,7 @@ vsf_status vsf_observe_collect_view(vsf_ctx* ctx, int64_t ticket, const uint8_t*
 vsf_status vsf_observe_stereo(vsf_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                               const vsf_calibration* calib, float best_percent, int frame_life, uint8_t* out,
                               size_t cap, size_t* out_bytes) {
-  VsfErrorScope scope_(ctx);
+  VsfErrorScope scope_(ctx, false);
   if (!out || !out_bytes) return VSF_ERR_INVALID_ARG;
   *out_bytes = 0;
   int64_t ticket = -1;

@@ -90,14 +90,14 @@ class Frontend:
         lib().vsfh_set_pipelined(self._h, int(on))
 
     def set_frames_in_flight(self, n: int):
-        """How many frames a pipelined Frontend leaves in the context's queue (1..256; default 32).  Choose before the first
+        """How many frames a pipelined Frontend leaves in the context's queue (1..1024; default 256).  Choose before the first
         observe_image."""
         lib().vsfh_set_frames_in_flight(self._h, int(n))
 
     def set_queue(self, depth: int = 0, batch_frames: int = 0, min_batch: int = 0):
-        """The ObserveImage queue of a pipelined Frontend: frames that may wait uncollected (default 32), frames per batch at
-        most (default 32: sizes the context), fewest waiting frames that leave while the GPU is busy (0: any).  Choose
-        before the first observe_image."""
+        """The ObserveImage queue of a pipelined Frontend: frames that may wait uncollected (default 256), frames per batch at
+        most (default 128: sizes the context), fewest waiting frames that leave while the GPU is busy (0: half a batch).
+        Choose before the first observe_image."""
         lib().vsfh_set_queue(self._h, int(depth), int(batch_frames), int(min_batch))
 
     def time_sequence(self, frames: np.ndarray, n_frames: int, warm: int = 32, read_every: int = 0):

@@ -256,7 +256,10 @@ bool Frontend::EnsureContext(int width, int height) {
   last_status_ = vsf_create(&p, device_, &ctx_);
   if (last_status_ != VSF_OK) return false;
   ctx_depth_ = queue_depth();
-  last_status_ = vsf_observe_configure(ctx_, ctx_depth_, min_batch_, 0);
+  last_status_ = vsf_set_option(ctx_, VSF_OPT_OBSERVE_THREAD, queue_thread_ ? 1 : 0);
+  for (const auto& ov : ctx_options_)
+    if (last_status_ == VSF_OK) last_status_ = vsf_set_option(ctx_, ov.first, ov.second);
+  if (last_status_ == VSF_OK) last_status_ = vsf_observe_configure(ctx_, ctx_depth_, min_batch_, 0);
   pending_.assign((size_t)ctx_depth_, PendingFrame());
   pending_head_ = pending_count_ = 0;
   return last_status_ == VSF_OK;

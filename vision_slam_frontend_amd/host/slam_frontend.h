@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vsf.h"
@@ -120,14 +121,22 @@ class Frontend {
   // the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and bytes as the
   // synchronous mode; a GPU failure then surfaces in last_status() some calls late.
   void set_pipelined(bool on) { pipelined_ = on; }
-  // Frames ObserveImage may leave in the queue when pipelined (1..256, default 32) and the most frames one batch carries
-  // (default 32; the context's extraction buffers are sized for it: ~25 MB per 640x480 frame).
-  void set_queue_depth(int n) { depth_ = n < 1 ? 1 : (n > 256 ? 256 : n); }
+  // Frames ObserveImage may leave in the queue when pipelined (1..1024, default 256) and the most frames one batch carries
+  // (default 128; the context's extraction buffers are sized for it: ~25 MB of HBM per 640x480 frame; the queue's staging
+  // and result rings are pinned host memory: depth x (two images + vsf_observe_capacity)).  Measured on an MI355X at
+  // 640x480 / 2000 features: depth 32 15 k frames/s, 128 (64 per batch) 27 k, 256 (128 per batch) 32 k.
+  void set_queue_depth(int n) { depth_ = n < 1 ? 1 : (n > 1024 ? 1024 : n); }
   void set_frames_in_flight(int n) { set_queue_depth(n); }  // (the name of rounds 3-5)
-  void set_batch_frames(int n) { batch_frames_ = n < 1 ? 1 : (n > 128 ? 128 : n); }
+  void set_batch_frames(int n) { batch_frames_ = n < 1 ? 1 : (n > 256 ? 256 : n); }
   // While the GPU is busy, fewer waiting frames than this stay in the queue (0 / 1: whatever waits leaves as soon as fewer
   // than two batches are on the GPU).
   void set_min_batch(int n) { min_batch_ = n < 0 ? 0 : n; }
+  // The queue's launcher thread (VSF_OPT_OBSERVE_THREAD; default on).
+  void set_queue_thread(bool on) { queue_thread_ = on; }
+  // Any vsf_option of the context (applied when it is created): launch choices only, results never depend on them.
+  void set_context_option(int option, int value) { ctx_options_.push_back({option, value}); }
+  // vsf_observe_stats of the context (frames, batches, largest batch, ...): how the queue coalesced.
+  void queue_stats(int64_t out[11]) const { for (int i = 0; i < 11; i++) out[i] = 0; if (ctx_) vsf_observe_stats(ctx_, out, 11); }
   int queue_depth() const { return pipelined_ ? depth_ : 1; }
   int frames_in_flight() const { return queue_depth(); }
   int batch_frames() const { return pipelined_ ? (depth_ < batch_frames_ ? depth_ : batch_frames_) : 1; }
@@ -185,7 +194,9 @@ class Frontend {
   float stereo_ambig_constraint_;
   bool fused_;
   bool pipelined_;
-  int depth_ = 32, batch_frames_ = 32, min_batch_ = 0;
+  int depth_ = 256, batch_frames_ = 128, min_batch_ = 0;
+  bool queue_thread_ = true;
+  std::vector<std::pair<int, int>> ctx_options_;
   std::vector<PendingFrame> pending_;  // a ring: pending_head_ is the oldest, pending_count_ frames wait
   size_t pending_head_ = 0, pending_count_ = 0;
   int ctx_depth_ = 0;
