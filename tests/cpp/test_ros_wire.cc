@@ -1,5 +1,6 @@
 // Known-answer test of host/slam_to_ros.h: a hand-built SLAMProblem against bytes assembled
 // field by field from the ROS-1 serialisation rules and msg/*.msg.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -53,6 +54,51 @@ int main() {
   }
   // record sizes quoted in SURVEY.md 8(a) row a8
   if (expect.size() != 12 + (76 + 2 * 56) + 76 + (20 + 2 * 16) + 72) bad = 1;
-  std::printf(bad ? "FAIL\n" : "ok %zu bytes\n", got.size());
+  // ---- CameraIntrinsics.msg: float64 fx, fy, cx, cy (declaration order) ----
+  {
+    slam_types::CameraIntrinsics k;
+    k.fx = 527.873518f, k.cx = 482.823413f, k.fy = 527.276819f, k.cy = 298.033945f;  // main.cc:358-361 assigns fx cx fy cy
+    expect.clear();
+    F64(527.873518f); F64(527.276819f); F64(482.823413f); F64(298.033945f);
+    std::vector<uint8_t> b;
+    slam_to_ros::SerializeIntrinsics(k, &b);
+    if (b.size() != 32 || b != expect) std::printf("intrinsics differ\n"), bad = 1;
+  }
+  // ---- CameraExtrinsics.msg: float64[3] translation, float64[3] rotation, no counts ----
+  {
+    // a quarter turn about z: quaternion (w, x, y, z) = (cos 45, 0, 0, sin 45): angle = 2 atan2(sin 45, cos 45) = pi / 2
+    const float Rz[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, t[3] = {-0.01f, 0.06f, 0.53f};
+    const slam_types::CameraExtrinsics a = slam_to_ros::ExtrinsicsFromAffine(Rz, t);
+    const float half = std::sqrt(0.0f + 1.0f + 0.0f + 0.0f + 1.0f) * 0.5f;  // w = 0.5 sqrt(trace + 1), trace = 1
+    const float zq = (1.0f - (-1.0f)) * (0.5f / std::sqrt(2.0f));           // z = (m10 - m01) * 0.5 / sqrt(trace + 1)
+    const float angle = 2.0f * std::atan2(zq, half);
+    expect.clear();
+    F64(-0.01f); F64(0.06f); F64(0.53f);
+    F64(0.0f); F64(0.0f); F64((zq / zq) / 1.0f * angle);
+    std::vector<uint8_t> b;
+    slam_to_ros::SerializeExtrinsics(a, &b);
+    if (b.size() != 48 || b != expect) std::printf("extrinsics (quarter turn) differ\n"), bad = 1;
+    if (std::fabs(a.rotation[2] - 1.5707964f) > 1e-6f) std::printf("quarter turn is %.8f\n", a.rotation[2]), bad = 1;
+    // the identity: angle 0 <= 1e-8 -> zeros (main.cc:347-351)
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const slam_types::CameraExtrinsics z = slam_to_ros::ExtrinsicsFromAffine(I, t);
+    if (z.rotation[0] != 0.f || z.rotation[1] != 0.f || z.rotation[2] != 0.f) std::printf("identity\n"), bad = 1;
+    // a half turn about x (trace = -1: the other branch of the quaternion construction): (pi, 0, 0)
+    const float Rx[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1};
+    const slam_types::CameraExtrinsics h = slam_to_ros::ExtrinsicsFromAffine(Rx, t);
+    if (std::fabs(h.rotation[0] - 3.14159265f) > 1e-6f || h.rotation[1] != 0.f || h.rotation[2] != 0.f)
+      std::printf("half turn %.8f %.8f %.8f\n", h.rotation[0], h.rotation[1], h.rotation[2]), bad = 1;
+    // the reference's own left_cam_to_robot (cc:613-618) against the angle-axis of that matrix evaluated in double
+    // (log map: angle = acos((trace - 1) / 2), axis ~ (m21 - m12, m02 - m20, m10 - m01))
+    const float RT[9] = {0.009916590468f, -0.2835522866f, 0.9589055021f,  -0.9998698619f, -0.01501486552f,
+                         0.005900269087f, 0.01272480238f, -0.9588392225f, -0.2836642819f};
+    const slam_types::CameraExtrinsics e = slam_to_ros::ExtrinsicsFromAffine(RT, t);
+    const double trd = (double)RT[0] + RT[4] + RT[8], ang = std::acos((trd - 1.0) / 2.0);
+    double ax[3] = {(double)RT[7] - RT[5], (double)RT[2] - RT[6], (double)RT[3] - RT[1]};
+    const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    for (int i = 0; i < 3; i++)
+      if (std::fabs(e.rotation[i] - ax[i] / an * ang) > 2e-5) std::printf("left_cam_to_robot axis %d: %.7f vs %.7f\n", i, e.rotation[i], ax[i] / an * ang), bad = 1;
+  }
+  std::printf(bad ? "FAIL\n" : "ok %zu bytes + intrinsics + extrinsics\n", got.size());
   return bad;
 }

@@ -52,6 +52,10 @@ def lib() -> C.CDLL:
         L.vsfh_set_queue.restype = None
         L.vsfh_time_sequence.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(dbl), C.POINTER(dbl)]
         L.vsfh_time_sequence.restype = dbl
+        L.vsfh_left_cam_to_robot.argtypes = [vp, vp, vp]
+        L.vsfh_left_cam_to_robot.restype = None
+        L.vsfh_serialize_calibration.argtypes = [vp, vp, vp]
+        L.vsfh_serialize_calibration.restype = None
         L.vsfh_flush.argtypes = [vp]
         _lib = L
     return _lib
@@ -180,6 +184,20 @@ class Frontend:
             lib().vsfh_odometry_factor(self._h, i, _p(ij), _p(tq))
             out.append((int(ij[0]), int(ij[1]), tq))
         return out
+
+    @property
+    def left_cam_to_robot(self):
+        """GetConfig().left_cam_to_robot (slam_frontend.h:96): (rotation 3 x 3, translation 3)."""
+        R, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        lib().vsfh_left_cam_to_robot(self._h, _p(R), _p(t))
+        return R.reshape(3, 3), t
+
+    def serialize_calibration(self):
+        """ROS-1 payloads of the CameraExtrinsics (48 B) and CameraIntrinsics (32 B) messages the reference's driver writes
+        beside the problem (slam_frontend_main.cc:341-365)."""
+        e, k = np.zeros(48, np.uint8), np.zeros(32, np.uint8)
+        lib().vsfh_serialize_calibration(self._h, _p(e), _p(k))
+        return e.tobytes(), k.tobytes()
 
     def serialize_problem(self) -> bytes:
         """ROS-1 wire bytes of vision_slam_frontend/SLAMProblem for everything observed so far (host/slam_to_ros.h)."""

@@ -170,6 +170,33 @@ int vsfh_frame(void* f, int i, uint64_t* frame_id, vsf_keypoint* kp, uint8_t* de
 }
 
 
+// FrontendConfig::left_cam_to_robot (h:96, cc:613-618) as the reference's caller reads it through GetConfig(): rotation
+// (row-major 3 x 3) and translation; and the two calibration messages that caller writes into its bag from it
+// (slam_frontend_main.cc:341-365): CameraExtrinsics (48 B) and CameraIntrinsics (32 B) payloads.
+void vsfh_left_cam_to_robot(void* f, float rotation9[9], float translation3[3]) {
+  const FrontendConfig c = static_cast<Frontend*>(f)->GetConfig();
+  std::memcpy(rotation9, c.left_cam_to_robot.rotation().m, 9 * sizeof(float));
+  const slam::Vector3f t = c.left_cam_to_robot.translation();
+  translation3[0] = t.x(), translation3[1] = t.y(), translation3[2] = t.z();
+}
+
+void vsfh_serialize_calibration(void* f, uint8_t extrinsics48[48], uint8_t intrinsics32[32]) {
+  const FrontendConfig c = static_cast<Frontend*>(f)->GetConfig();
+  const slam::Vector3f rT = c.left_cam_to_robot.translation();
+  const float t[3] = {rT.x(), rT.y(), rT.z()};
+  const slam_types::CameraExtrinsics a = slam_to_ros::ExtrinsicsFromAffine(c.left_cam_to_robot.rotation().m, t);
+  slam_types::CameraIntrinsics k;
+  k.fx = c.intrinsics_left.fx;
+  k.cx = c.intrinsics_left.cx;
+  k.fy = c.intrinsics_left.fy;
+  k.cy = c.intrinsics_left.cy;
+  std::vector<uint8_t> b;
+  slam_to_ros::SerializeExtrinsics(a, &b);
+  std::memcpy(extrinsics48, b.data(), 48);
+  slam_to_ros::SerializeIntrinsics(k, &b);
+  std::memcpy(intrinsics32, b.data(), 32);
+}
+
 // ROS-1 wire bytes of the current SLAMProblem (slam_to_ros.h; what the reference writes into its output bag,
 // slam_frontend_main.cc:341-374).  Returns the payload size; copies min(size, cap) bytes.
 size_t vsfh_serialize_problem(void* f, uint8_t* out, size_t cap) {

@@ -166,6 +166,13 @@ FrontendConfig::FrontendConfig() {
       projection_left[4 * i + j] = l;
       projection_right[4 * i + j] = r;
     }
+  {  // cc:613-618: left_cam_to_robot = Eigen::Translation3f(XT) * RT
+    Matrix3f RT;
+    const float rt[9] = {0.009916590468f, -0.2835522866f, 0.9589055021f,  -0.9998698619f, -0.01501486552f,
+                         0.005900269087f, 0.01272480238f, -0.9588392225f, -0.2836642819f};
+    std::memcpy(RT.m, rt, sizeof(rt));
+    left_cam_to_robot = Affine3f(RT, Vector3f(-0.01f, 0.06f, 0.5299999713897705f));
+  }
   // Fundamental matrix (cc:635-644).  The reference builds the cross-product matrix from A[1], A[2], A[3] of a
   // 3-vector (out-of-range read, quirk Q2); the well-formed skew matrix of A is used here instead.
   Matrix3f rotation;

@@ -47,6 +47,25 @@ struct Matrix3f {
   float& operator()(int r, int c) { return m[3 * r + c]; }
 };
 
+// Eigen::Affine3f as the reference uses it (h:96, cc:613-618, slam_frontend_main.cc:341-344): a rotation and a
+// translation, `Translation3f(XT) * RT`.
+struct Affine3f {
+  Matrix3f linear_;  // row-major
+  Vector3f translation_;
+  Affine3f() : linear_{{1, 0, 0, 0, 1, 0, 0, 0, 1}} {}
+  Affine3f(const Matrix3f& rotation, const Vector3f& translation) : linear_(rotation), translation_(translation) {}
+  Vector3f translation() const { return translation_; }
+  // (Eigen's Transform::rotation() of an affine transform takes the closest rotation of the linear part by SVD; the linear
+  // part IS a rotation here -- cc:614-617 -- so it is returned as it is: equal to float rounding)
+  Matrix3f rotation() const { return linear_; }
+  Matrix3f linear() const { return linear_; }
+  Vector3f operator*(const Vector3f& p) const {
+    return Vector3f((linear_(0, 0) * p.x() + linear_(0, 1) * p.y()) + linear_(0, 2) * p.z() + translation_.x(),
+                    (linear_(1, 0) * p.x() + linear_(1, 1) * p.y()) + linear_(1, 2) * p.z() + translation_.y(),
+                    (linear_(2, 0) * p.x() + linear_(2, 1) * p.y()) + linear_(2, 2) * p.z() + translation_.z());
+  }
+};
+
 // src/slam_frontend.h:58-97; defaults are the reference's (cc:550-652) except where noted in the .cc.
 struct FrontendConfig {
   enum class DescriptorExtractorType { AKAZE, ORB, BRISK, SURF, SIFT, FREAK };
@@ -62,6 +81,9 @@ struct FrontendConfig {
   CameraIntrinsics intrinsics_left, intrinsics_right;
   float projection_left[12], projection_right[12];  // 3x4 row-major (cv::Mat CV_32F in the reference)
   Matrix3f fundamental;
+  // Affine transform from the frame of the left camera to the robot (h:96; literals cc:613-618; the reference's caller
+  // reads it through GetConfig() for the CameraExtrinsics message and the point cloud, slam_frontend_main.cc:158, 342).
+  Affine3f left_cam_to_robot;
   // ORB parameters the reference hard-codes in cv::ORB::create (cc:205-213); exposed so BASELINE configs can set
   // nfeatures = 2000 / 8000.
   int orb_nfeatures;
