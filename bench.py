@@ -490,9 +490,6 @@ def main() -> int:
                     help="--ingest jpeg / png: steps whose files one decode call takes (default 1; 2 with PNG puts four decoder waves on every CU, whose LDS the extraction then waits for: no gain, NOTES.md)")
     ap.add_argument("--ingest-priority", choices=["low", "normal", "high"], default=None,
                     help="--ingest jpeg: HIP stream priority of the decode stream")
-    ap.add_argument("--match-int8", action="store_true", help="VSF_OPT_MATCH_INT8: round 2's int8 form of the matcher (A/B runs)")
-    ap.add_argument("--fast-bits", type=int, default=0, choices=[0, 1, 2],
-                    help="VSF_OPT_FAST_BITS (A/B runs): FAST as a segment test on bit planes (k_fastbits.hip), 1 = for batches of >= 8 images")
     ap.add_argument("--match-on-tail", choices=["auto", "on", "off"], default="auto",
                     help="the stereo GetMatches as the first kernel of the step's tail (its matrix-core work beside the next "
                          "step's pyramid and FAST) instead of the last of the extraction; auto: from 5000 features per frame on "
@@ -651,10 +648,6 @@ def main() -> int:
     # cross-call pipelining: every step's input is complete in HBM before the call (the rotating synthetic batches), or
     # the call is handed the event behind its producer (the JPEG ingest: vsf_set_input_event)
     pipeline = not args.no_pipeline
-    if args.match_int8:
-        ctx.set_option(capi.OPT_MATCH_INT8, 1)
-    if args.fast_bits:
-        ctx.set_option(capi.OPT_FAST_BITS, args.fast_bits)
     if args.pipe_priority is not None:
         ctx.set_option(capi.OPT_PIPE_PRIORITY, args.pipe_priority)
     ctx.set_pipeline(pipeline)
@@ -858,10 +851,9 @@ def main() -> int:
             mean_n = float(counts.mean())
             pairs_per_step = B * mean_n * mean_n  # stereo L->R; the R'->L' and temporal launches are ~1 % of that
             dps = pairs_per_step * args.steps / (knn_ms * 1e-3)
-            int8_form = bool(ctx.get_option(capi.OPT_MATCH_INT8))
-            peak = MFMA_I8_PEAK_TOPS if int8_form else MFMA_FP4_PEAK_TOPS
+            peak = MFMA_FP4_PEAK_TOPS
             matcher = {"pair_distances_per_s": dps, "mfma_tops": dps * 512 / 1e12,
-                       "form": "int8 (v_mfma_i32_32x32x32_i8)" if int8_form else "fp4 (v_mfma_scale_f32_32x32x64_f8f6f4, exact)",
+                       "form": "fp4 (v_mfma_scale_f32_32x32x64_f8f6f4, exact)",
                        "frac_of_mfma_peak": dps * 512 / 1e12 / peak, "peak_tops": peak,
                        "ms_per_step": knn_ms / args.steps,
                        "note": "the stereo L->R launch of each step (B pairs of ~N x N)" if tail_stages is not None else

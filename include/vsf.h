@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VSF_VERSION 1
+#define VSF_VERSION 2 /* 2: round 6 -- the ObserveImage queue; five options of retired kernel variants removed */
 #define VSF_DESC_BYTES 32
 #define VSF_MAX_LEVELS 64
 
@@ -159,28 +159,21 @@ vsf_status vsf_tune_fast_resident(vsf_ctx* ctx, const uint8_t* d_imgs, int n_ima
 /* Launch choices of a context (speed / A-B measurements only: results never depend on them).  Nothing in the library
  * reads the environment.  vsf_set_option waits for the context's stream first. */
 typedef enum {
-  VSF_OPT_BLUR_MARCH = 0,    /* 0 (default): matrix-core blur kernel; 1: round 2's vector-ALU kernel */
-  VSF_OPT_FAST_BOTH_MAX = 1, /* 16: largest batch (images) whose full and half-wave FAST cells share one launch */
-  VSF_OPT_SORT_SERIAL = 2,   /* 0: workgroup-parallel introsort of GetFeatureMatches; 1: the one-lane kernel */
-  VSF_OPT_SELECT_WIDE = 3,   /* 1: a frame or two takes the 1024-thread whole-level selection class; 0: never */
-  VSF_OPT_JPEG_SERIAL = 4,   /* 0: self-synchronising parallel JPEG decode, a progressive file's scans pipelined over the
-                              * waves of a workgroup; 1: one wave per image for every file, scan after scan */
-  VSF_OPT_PYRAMID_FEW = 5,   /* 16: largest batch (images) whose pyramid is built by the slab kernel */
-  VSF_OPT_PYRAMID_CHAIN = 6, /* 8: levels per slab launch; 0: per-level launches even for a frame or two */
-  VSF_OPT_PYRAMID_ROWS = 7,  /* 6: rows of a chain's last level per slab */
-  VSF_OPT_SELECT_BIG_CLASS = 8, /* 1: a batch's widest levels keep their candidate array in LDS (9 216 entries, tables in HBM) */
-  VSF_OPT_PIPE_AFTER_FAST = 9, /* 1: the pipelined pyramid of a call waits for the previous call's FAST kernel; 0: it starts as soon
+  VSF_OPT_FAST_BOTH_MAX = 0, /* 16: largest batch (images) whose full and half-wave FAST cells share one launch */
+  VSF_OPT_SELECT_WIDE = 1,   /* 1: a frame or two takes the 1024-thread whole-level selection class; 0: never */
+  VSF_OPT_PYRAMID_FEW = 2,   /* 16: largest batch (images) whose pyramid is built by the slab kernel */
+  VSF_OPT_PYRAMID_CHAIN = 3, /* 8: levels per slab launch; 0: per-level launches even for a frame or two */
+  VSF_OPT_PYRAMID_ROWS = 4,  /* 6: rows of a chain's last level per slab */
+  VSF_OPT_SELECT_BIG_CLASS = 5, /* 1: a batch's widest levels keep their candidate array in LDS (9 216 entries, tables in HBM) */
+  VSF_OPT_PIPE_AFTER_FAST = 6, /* 1: the pipelined pyramid of a call waits for the previous call's FAST kernel; 0: it starts as soon
                                 * as its inputs are ready (a step whose FAST shares the chip with a decoder) */
-  VSF_OPT_PIPE_PRIORITY = 10,  /* stream priority of the pipelined pyramid chain: 0 normal, 1 lowest, -1 highest; set it before
+  VSF_OPT_PIPE_PRIORITY = 7,   /* stream priority of the pipelined pyramid chain: 0 normal, 1 lowest, -1 highest; set it before
                                 * vsf_set_pipeline(ctx, 1) */
-  VSF_OPT_MATCH_INT8 = 11,     /* 0: the matcher on the FP4 matrix instruction (K = 64 per instruction); 1: round 2's int8 form */
-  VSF_OPT_FAST_BITS = 12,      /* FAST as a segment test on bit planes with scores only where it fires (k_fastbits.hip; same
-                                  candidates bit for bit): 0 never, 1 for batches of >= 8 images, 2 for any batch */
-  VSF_OPT_OBSERVE_THREAD = 13,  /* 1 (default): an ObserveImage queue of depth >= 4 has a launcher thread -- the caller stages
-                                 * frames, the thread sends the batches; 0: the caller launches too.  Read when the queue is built */
-  VSF_OPT_PYRAMID_TAIL_MIN = 14, /* smallest batch (images) whose one-band pyramid levels are one launch (a workgroup per image)
-                                  * even when that fills less than three quarters of the chip; 0: never */
-  VSF_OPT_COUNT = 15
+  VSF_OPT_OBSERVE_THREAD = 8,  /* 1 (default): an ObserveImage queue of depth >= 4 has a launcher thread -- the caller stages
+                                * frames, the thread sends the batches; 0: the caller launches too.  Read when the queue is built */
+  VSF_OPT_PYRAMID_TAIL_MIN = 9, /* smallest batch (images) whose one-band pyramid levels are one launch (a workgroup per image)
+                                 * even when that fills less than three quarters of the chip; 0: never */
+  VSF_OPT_COUNT = 10
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);
@@ -503,6 +496,11 @@ vsf_status vsf_debug_retain_best(vsf_ctx* ctx, uint32_t* key_bits, uint32_t* ids
  * in sorted order and counts_out[i] their number.  serial != 0 forces the one-lane kernel. */
 vsf_status vsf_debug_sort_trim(vsf_ctx* ctx, const vsf_dmatch* matches, int n_lists, int n, float best_percent,
                                int serial, uint64_t* pairs_out, int32_t* counts_out);
+
+/* Test hook of the JPEG ingest: on != 0 sends every file through the one-wave-per-image decoder (which otherwise takes the
+ * files with restart intervals and, a second time, damaged progressive files), so that the parallel forms can be held
+ * against it file by file.  Waits for the context's stream. */
+vsf_status vsf_debug_jpeg_serial(vsf_ctx* ctx, int on);
 
 /* Per-stage device timing (hipEvents recorded on the context's stream around every stage of the batched entry
  * points).  vsf_profile_read synchronises the stream, adds the elapsed milliseconds and launch counts of every

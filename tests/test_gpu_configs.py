@@ -309,9 +309,9 @@ def test_options_and_sticky_hip_errors(capi):
     frames = synth.bench_batch(B, w, h, seed=synth.BASE_SEED + 5, n_scenes=2)
     dev = torch.device("cuda", 0)
     with capi.Context(capi.default_params(w, h, max_images=2 * B, nfeatures=nf)) as ctx:
-        defaults = {capi.OPT_BLUR_MARCH: 0, capi.OPT_FAST_BOTH_MAX: 16, capi.OPT_SORT_SERIAL: 0, capi.OPT_SELECT_WIDE: 1,
-                    capi.OPT_JPEG_SERIAL: 0, capi.OPT_PYRAMID_FEW: 16, capi.OPT_PYRAMID_CHAIN: 8, capi.OPT_PYRAMID_ROWS: 6,
-                    capi.OPT_SELECT_BIG_CLASS: 1, capi.OPT_PIPE_AFTER_FAST: 1, capi.OPT_PIPE_PRIORITY: 0, capi.OPT_MATCH_INT8: 0}
+        defaults = {capi.OPT_FAST_BOTH_MAX: 16, capi.OPT_SELECT_WIDE: 1, capi.OPT_PYRAMID_FEW: 16, capi.OPT_PYRAMID_CHAIN: 8,
+                    capi.OPT_PYRAMID_ROWS: 6, capi.OPT_SELECT_BIG_CLASS: 1, capi.OPT_PIPE_AFTER_FAST: 1, capi.OPT_PIPE_PRIORITY: 0,
+                    capi.OPT_OBSERVE_THREAD: 1, capi.OPT_PYRAMID_TAIL_MIN: 0}
         for opt, want in defaults.items():
             assert ctx.get_option(opt) == want, opt
         for opt, bad in ((99, 0), (-1, 0), (capi.OPT_PYRAMID_ROWS, 0), (capi.OPT_FAST_BOTH_MAX, -1), (capi.OPT_PYRAMID_CHAIN, 65)):
@@ -330,9 +330,9 @@ def test_options_and_sticky_hip_errors(capi):
 
         ref = run()
         # every launch choice gives the same bytes
-        for opt, val in ((capi.OPT_BLUR_MARCH, 1), (capi.OPT_FAST_BOTH_MAX, 0), (capi.OPT_SELECT_WIDE, 0),
-                         (capi.OPT_PYRAMID_CHAIN, 0), (capi.OPT_PYRAMID_FEW, 0), (capi.OPT_PYRAMID_ROWS, 3), (capi.OPT_SELECT_BIG_CLASS, 0),
-                         (capi.OPT_MATCH_INT8, 1)):
+        for opt, val in ((capi.OPT_FAST_BOTH_MAX, 0), (capi.OPT_SELECT_WIDE, 0), (capi.OPT_PYRAMID_CHAIN, 0),
+                         (capi.OPT_PYRAMID_FEW, 0), (capi.OPT_PYRAMID_ROWS, 3), (capi.OPT_SELECT_BIG_CLASS, 0),
+                         (capi.OPT_PYRAMID_TAIL_MIN, 2)):
             ctx.set_option(opt, val)
             assert ctx.get_option(opt) == val
             got = run()

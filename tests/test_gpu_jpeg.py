@@ -131,7 +131,7 @@ def test_ingest_chain_jpeg_bayer_extract(ctx, oracle):
 
 
 def test_parallel_and_serial_decoders_agree(oracle, monkeypatch):
-    """Files without restart intervals take the self-synchronising parallel decoder, the others (and VSF_OPT_JPEG_SERIAL = 1)
+    """Files without restart intervals take the self-synchronising parallel decoder, the others (and vsf_debug_jpeg_serial)
     the one-wave-per-image decoder: both against the oracle on a batch of different images, gray and colour."""
     PIL = pytest.importorskip("PIL.Image")
     import io
@@ -154,11 +154,11 @@ def test_parallel_and_serial_decoders_agree(oracle, monkeypatch):
     want = [oracle.jpeg_decode_gray(f) for f in files]
     for serial in (0, 1):
         c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500))
-        c.set_option(capi.OPT_JPEG_SERIAL, serial)
+        c.debug_jpeg_serial(serial)
         got = _decode(c, files, 328, 200)
         c.close()
         for i in range(len(files)):
-            np.testing.assert_array_equal(got[i, :, :328], want[i], err_msg="file %d, VSF_OPT_JPEG_SERIAL=%d" % (i, serial))
+            np.testing.assert_array_equal(got[i, :, :328], want[i], err_msg="file %d, serial=%d" % (i, serial))
 
 
 def test_random_sizes_and_qualities(ctx, oracle):
@@ -395,7 +395,7 @@ def test_pipelined_progressive_decode_equals_scan_after_scan_on_damaged_files():
     entropy data can make it matter (a value placed behind its band, a missing restart marker stops the decode): such files
     are flagged and decoded again by the one-wave kernel, so both forms must give the SAME bytes and the same status for
     every file -- 150 progressive files with bit flips and stray markers in their scans (gray and 4:2:0, with and without
-    restart intervals, crafted scan scripts), in batches, VSF_OPT_JPEG_SERIAL 0 against 1."""
+    restart intervals, crafted scan scripts), in batches, vsf_debug_jpeg_serial 0 against 1."""
     import io
 
     from PIL import Image
@@ -461,7 +461,7 @@ def test_pipelined_progressive_decode_equals_scan_after_scan_on_damaged_files():
     for serial in (0, 1):
         res = []
         with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)) as ctx:
-            ctx.set_option(capi.OPT_JPEG_SERIAL, serial)
+            ctx.debug_jpeg_serial(serial)
             for i in range(0, len(files), 2):
                 batch = files[i:i + 2]
                 d = torch.full((len(batch), H, W), 7, dtype=torch.uint8, device=dev)

@@ -249,11 +249,11 @@ def test_pyramid_of_small_batches_any_size(capi, oracle, size):
                                                       err_msg="%dx%d n=%d image %d level %d %s" % (w, h, n, i, l, kw))
 
 
-def test_knn2_extreme_distances_and_both_matcher_forms(oracle):
-    """The matcher's key comes out of a matrix instruction (FP4 since round 5: 8192 (d + 1) + row as an exact float; int8
-    before: VSF_OPT_MATCH_INT8): the ends of the distance range -- 0 (a row against itself), 256 (against its complement),
+def test_knn2_extreme_distances(oracle):
+    """The matcher's key comes out of a matrix instruction (FP4: 8192 (d + 1) + row as an exact float): the ends of the
+    distance range -- 0 (a row against itself), 256 (against its complement),
     every train row at 256 (the second best is then 256 too), and rows that differ in one bit only -- and 10 300 train rows
-    (three 4096-row key chunks, a last tile of 12 rows) must give the oracle's (index, distance) pairs in both forms."""
+    (three 4096-row key chunks, a last tile of 12 rows) must give the oracle's (index, distance) pairs."""
     from vision_slam_frontend_amd import capi, synth
     t = synth.random_descriptors(10300, seed=5)
     q = np.concatenate([t[[0, 31, 32, 4095, 4096, 8191, 8192, 10299]],          # distance 0, second best random
@@ -267,13 +267,11 @@ def test_knn2_extreme_distances_and_both_matcher_forms(oracle):
     want = oracle.knn2_hamming(q, t)
     want_far = oracle.knn2_hamming(q[:1], all_far_t)
     assert want[1][0, 0] == 0 and want[1][8, 0] < 256 and want_far[1].tolist() == [[256, 256]] and want_far[0].tolist() == [[0, 1]]
-    for int8_form in (0, 1):
-        with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=2000)) as ctx:
-            ctx.set_option(capi.OPT_MATCH_INT8, int8_form)
-            gi, gd = ctx.knn2_hamming(q, t)
-            np.testing.assert_array_equal(gi, want[0], err_msg="int8 form %d" % int8_form)
-            np.testing.assert_array_equal(gd, want[1])
-            fi, fd = ctx.knn2_hamming(q[:1], all_far_t)
-            np.testing.assert_array_equal(fi, want_far[0])
-            np.testing.assert_array_equal(fd, want_far[1])
-            assert ctx.get_matches(q, t).tobytes() == oracle.get_matches(q, t).tobytes()
+    with capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=2000)) as ctx:
+        gi, gd = ctx.knn2_hamming(q, t)
+        np.testing.assert_array_equal(gi, want[0])
+        np.testing.assert_array_equal(gd, want[1])
+        fi, fd = ctx.knn2_hamming(q[:1], all_far_t)
+        np.testing.assert_array_equal(fi, want_far[0])
+        np.testing.assert_array_equal(fd, want_far[1])
+        assert ctx.get_matches(q, t).tobytes() == oracle.get_matches(q, t).tobytes()

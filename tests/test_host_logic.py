@@ -21,17 +21,6 @@ def test_select_restatement_equals_libstdcxx(tmp_path):
     assert int(re.search(r"heap_fallbacks_on_killers=(\d+)", out.stdout).group(1)) > 0
 
 
-def test_bit_plane_segment_test_equals_the_definition(tmp_path):
-    """csrc/vsf_bitslice.h (the FAST-9/16 segment test on bit planes, k_fastbits.hip): transposition, saturating
-    add / subtract, comparison, arc test and the forward scheme over whole images against the per-pixel definition of
-    cv::FAST_t<16>'s test (thresholds 0 .. 255, five image families); v_bitop3_b32 evaluated from its truth table."""
-    exe = tmp_path / "test_bitslice"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-o", str(exe),
-                           str(ROOT / "tests" / "cpp" / "test_bitslice.cc")])
-    out = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert out.returncode == 0 and "bitslice ok" in out.stdout, out.stdout + out.stderr
-
-
 @pytest.fixture(scope="module")
 def capi():
     sys.path.insert(0, str(ROOT))

@@ -18,7 +18,7 @@ b = io.BytesIO(); Image.fromarray(rgb, "RGB").save(b, "JPEG", quality=75, subsam
 rng = np.random.Generator(np.random.PCG64(8))
 ctxs = []
 for serial in (0, 1):
-    c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)); c.set_option(capi.OPT_JPEG_SERIAL, serial); ctxs.append(c)
+    c = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=500)); c.debug_jpeg_serial(serial); ctxs.append(c)
 tab = {}
 for it in range(800):
     k = int(rng.integers(len(base))); kind = int(rng.integers(4))

@@ -8,8 +8,6 @@ from vision_slam_frontend_amd import capi, synth
 n, npairs = 10000, 64
 dev = torch.device("cuda", 0)
 ctx = capi.Context(capi.default_params(640, 480, max_images=2, nfeatures=n))
-if len(sys.argv) > 1 and sys.argv[1] == "int8":
-    ctx.set_option(capi.OPT_MATCH_INT8, 1)
 K = ctx.params.max_keypoints
 d = torch.zeros((2 * npairs, K, 32), dtype=torch.uint8, device=dev)
 rnd = synth.random_descriptors(2 * 16 * n).reshape(32, n, 32)

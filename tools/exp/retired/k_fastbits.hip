@@ -19,8 +19,8 @@
 #include <algorithm>
 #include <vector>
 
-#include "vsf_bitslice.h"
-#include "vsf_internal.h"
+#include "vsf_bitslice.h"  // (beside this file)
+#include "../../../vision_slam_frontend_amd/csrc/vsf_internal.h"
 
 namespace {
 

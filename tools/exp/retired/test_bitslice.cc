@@ -6,7 +6,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../vision_slam_frontend_amd/csrc/vsf_bitslice.h"
+#include "vsf_bitslice.h"
 
 using namespace vsf_bs;
 

@@ -32,8 +32,7 @@ def run(frames, nf, resident, pipeline, repeats, fast_bits=0):
         nm = torch.zeros(B, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         ctx.set_pipeline(pipeline)
-        if fast_bits:
-            ctx.set_option(capi.OPT_FAST_BITS, fast_bits)  # FAST as a segment test on bit planes (k_fastbits.hip)
+        assert not fast_bits, "FAST on bit planes was retired in round 6 (tools/exp/retired/)"
         if resident is not None:
             ctx.set_fast_resident(resident)
         torch.cuda.synchronize()

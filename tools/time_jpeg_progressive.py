@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the progressive-JPEG decode (row f4, SOF2 files): a batch of 640x480 progressive files (libjpeg-turbo's
 default scan script, synthetic scenes) through vsf_jpeg_decode_gray_batch, next to the same images as baseline files.
-python tools/time_jpeg_progressive.py [n_images] [serial]      (serial: VSF_OPT_JPEG_SERIAL = 1, every file scan after scan in one wave)"""
+python tools/time_jpeg_progressive.py [n_images] [serial]      (serial: vsf_debug_jpeg_serial, every file scan after scan in one wave)"""
 import ctypes as C
 import io
 import sys
@@ -33,7 +33,7 @@ for label, mode, kw in (("baseline gray q80", "L", dict(quality=80)),
     kb = sum(len(f) for f in files) / N / 1024
     ctx = capi.Context(capi.default_params(W, H, max_images=2, nfeatures=2000))
     if SERIAL:
-        ctx.set_option(capi.OPT_JPEG_SERIAL, 1)
+        ctx.debug_jpeg_serial(1)
     d = torch.zeros((N, H, W), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     bufs = [np.frombuffer(f, np.uint8) for f in files]

@@ -35,14 +35,13 @@ EXPORTS = [
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
-    "vsf_observe_configure", "vsf_observe_collect_view", "vsf_observe_stats",
+    "vsf_observe_configure", "vsf_observe_collect_view", "vsf_observe_stats", "vsf_debug_jpeg_serial",
     "vsf_jpeg_decode_gray_batch", "vsf_png_decode_gray_batch", "vsf_imdecode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error", "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_destroy", "vsf_comm_info",
     "vsf_allgather_dev", "vsf_gather_payload_dev", "vsf_reserve", "vsf_set_input_event",
 ]
 # vsf_option (include/vsf.h)
-(OPT_BLUR_MARCH, OPT_FAST_BOTH_MAX, OPT_SORT_SERIAL, OPT_SELECT_WIDE, OPT_JPEG_SERIAL, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN,
- OPT_PYRAMID_ROWS, OPT_SELECT_BIG_CLASS, OPT_PIPE_AFTER_FAST, OPT_PIPE_PRIORITY, OPT_MATCH_INT8, OPT_FAST_BITS,
- OPT_OBSERVE_THREAD, OPT_PYRAMID_TAIL_MIN) = range(15)
+(OPT_FAST_BOTH_MAX, OPT_SELECT_WIDE, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN, OPT_PYRAMID_ROWS, OPT_SELECT_BIG_CLASS,
+ OPT_PIPE_AFTER_FAST, OPT_PIPE_PRIORITY, OPT_OBSERVE_THREAD, OPT_PYRAMID_TAIL_MIN) = range(10)
 STAGE_COUNT = 8
 
 
@@ -460,6 +459,11 @@ class Context:
         n = C.c_size_t()
         self._check(lib().vsf_observe_collect(self._h, C.c_int64(ticket), _p(buf), cap, C.byref(n)), "vsf_observe_collect")
         return decode_observation(buf[:n.value])
+
+    def debug_jpeg_serial(self, on: bool):
+        """Test hook: every JPEG file through the one-wave-per-image decoder (vsf_debug_jpeg_serial)."""
+        lib().vsf_debug_jpeg_serial.argtypes = [C.c_void_p, C.c_int]
+        self._check(lib().vsf_debug_jpeg_serial(self._h, int(on)), "vsf_debug_jpeg_serial")
 
     def observe_reset(self):
         self._check(lib().vsf_observe_reset(self._h), "vsf_observe_reset")

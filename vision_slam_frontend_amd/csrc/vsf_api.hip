@@ -21,11 +21,6 @@ namespace vsfi {
 vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, int n_images) {
   VSF_HIP(upload(&ds->levels, G.levels));
   VSF_HIP(upload(&ds->units, G.units));
-  if (!G.bits_items.empty()) {
-    VSF_HIP(upload(&ds->bits_items, G.bits_items));
-    ds->n_bits_items = (int)G.bits_items.size();
-  }
-  VSF_HIP(upload(&ds->blur_tiles, G.blur_tiles));
   VSF_HIP(upload(&ds->blur_mma_units, G.blur_mma_units));
   VSF_HIP(upload(&ds->blur_mma_units_small, G.blur_mma_units_small));
   VSF_HIP(upload(&ds->blur_tcol, G.blur_tcol));
@@ -35,8 +30,6 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
   d.ic_table = ds->ic_table;
   d.levels = ds->levels;
   d.units = ds->units;
-  d.bits_items = ds->bits_items;
-  d.n_bits_items = ds->n_bits_items;
   const size_t n = (size_t)n_images;
   if (orb) {
     VSF_HIP(hipMalloc((void**)&d.pyr, n * G.g.pyr_bytes));
@@ -59,8 +52,6 @@ vsf_status alloc_devset(vsf_ctx* ctx, const Geometry& G, DevSet* ds, bool orb, i
 void free_devset(DevSet* ds) {
   hipFree(ds->levels);
   hipFree(ds->units);
-  hipFree(ds->bits_items);
-  hipFree(ds->blur_tiles);
   hipFree(ds->blur_mma_units);
   hipFree(ds->blur_mma_units_small);
   hipFree(ds->blur_tcol);
@@ -267,8 +258,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   // forked from INSIDE the pyramid's launch chain as soon as their levels exist (the chain's dependent launches stretch from
   // 1.28 to 1.8-2.2 ms beside the blur's memory traffic, 7.37-7.46 ms per step against 7.31); the first 3 / 6 / 10 / 16
   // levels blurred in line in front of FAST and only the rest beside it (7.25-7.36: noise).
-  const bool march = ctx->tuning.blur_march != 0;
-  const bool beside_ok = ctx->blur_overlap && !march && im.n >= 32 && ctx->blur_stream;
+  const bool beside_ok = ctx->blur_overlap && im.n >= 32 && ctx->blur_stream;
   // With the blur beside it FAST can run as ONE resident workgroup per CU (k_fast.hip): three waves per SIMD keep 92 % of
   // its own rate and leave the other 224 of a SIMD's 512 registers -- which a grid of one workgroup per four cells fills
   // for as long as cells are left -- to the blur, which then finishes INSIDE the FAST pass instead of after it.  Whether
@@ -291,10 +281,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   const bool blur_beside = beside_ok;
   auto launch_blur = [&](hipStream_t bs) {
     StageTimer t(ctx, bs, VSF_STAGE_BLUR, 1);
-    // VSF_OPT_BLUR_MARCH: round 2's vector-ALU kernel (A/B measurements); default: the matrix-core kernel
-    if (march)
-      vsf_launch_blur(d, g, im, ctx->dorb.blur_tiles, (int)ctx->orb.blur_tiles.size(), ctx->gauss, bs);
-    else if (im.n >= 32)
+    if (im.n >= 32)
       vsf_launch_blur_mma(d, g, im, ctx->dorb.blur_mma_units, (int)ctx->orb.blur_mma_units.size(), ctx->dorb.blur_tcol,
                           ctx->dorb.blur_tv, ctx->orb.blur_bias, bs);
     else
@@ -310,12 +297,7 @@ void extract_on(vsf_ctx* ctx, hipStream_t st, const VsfImages& im_all, int i0, i
   if (blur_beside) fork_blur();
   {
     StageTimer t(ctx, st, VSF_STAGE_FAST, 1);
-    // VSF_OPT_FAST_BITS: the segment test on bit planes, scores only where it fires (k_fastbits.hip; the same candidates)
-    const int fb = ctx->tuning.fast_bits;
-    if (d.bits_items && ctx->p.fast_threshold >= 1 && (fb == 2 || (fb == 1 && im.n >= 8)))
-      vsf_launch_fast_bits(d, g, im, d.bits_items, d.n_bits_items, ctx->p.fast_threshold, st);
-    else
-      vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
+    vsf_launch_fast(d, g, im, ctx->p.fast_threshold, 1, st, blur_beside ? resident : 0, ctx->n_cus, ctx->fast_cells);
   }
   if (pipe) {
     vsf_note(hipEventRecord(ctx->ev_fast_done, st));
@@ -360,7 +342,7 @@ void match_on(vsf_ctx* ctx, hipStream_t st, const uint8_t* d_desc, const int32_t
   {
     StageTimer t(ctx, st, VSF_STAGE_KNN2, 1);
     vsf_launch_knn2(desc, counts, set_stride, d_q_set ? d_q_set + p0 : nullptr, d_t_set ? d_t_set + p0 : nullptr, n,
-                    rows, idx2, dist2, st, ctx->tuning.match_int8 != 0);
+                    rows, idx2, dist2, st);
   }
   {
     StageTimer t(ctx, st, VSF_STAGE_RATIO, 1);
@@ -498,7 +480,6 @@ vsf_status vsf_create(const vsf_params* p, int device, vsf_ctx** out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
   }
   if (!build_geometry(ctx->p, true, true, &ctx->orb)) return fail(VSF_ERR_INVALID_ARG);
-  gaussian_taps(ctx->gauss);
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(VSF_ERR_HIP);
   ctx->stream = ctx->own_stream;
   if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -695,31 +676,17 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
   VSF_HIP(hipStreamSynchronize(ctx->stream));
   VsfTuning& t = ctx->tuning;
   switch (option) {
-    case VSF_OPT_BLUR_MARCH: t.blur_march = value != 0; break;
     case VSF_OPT_FAST_BOTH_MAX:
       if (value < 0) return VSF_ERR_INVALID_ARG;
       t.fast_both_max = value;
       break;
-    case VSF_OPT_SORT_SERIAL: t.sort_serial = value != 0; break;
     case VSF_OPT_SELECT_WIDE: t.select_wide = value != 0; break;
     case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
     case VSF_OPT_PIPE_AFTER_FAST: t.pipe_after_fast = value != 0; break;
-    case VSF_OPT_MATCH_INT8: t.match_int8 = value != 0; break;
     case VSF_OPT_OBSERVE_THREAD: t.observe_thread = value != 0; break;  // (read when the queue is built)
-    case VSF_OPT_FAST_BITS:
-      if (value < 0 || value > 2) return VSF_ERR_INVALID_ARG;
-      t.fast_bits = value;
-      break;
     case VSF_OPT_PIPE_PRIORITY:
       if (value < -1 || value > 1) return VSF_ERR_INVALID_ARG;
       t.pipe_priority = value;  // (takes effect with the next vsf_set_pipeline(ctx, 1))
-      break;
-    case VSF_OPT_JPEG_SERIAL:
-      if (!value && vsf_prepare_jpeg_kernels(t.lds_limit) != hipSuccess) {  // (the parallel decoder's LDS was refused)
-        (void)hipGetLastError();
-        return VSF_ERR_UNSUPPORTED;
-      }
-      t.jpeg_serial = value != 0;
       break;
     case VSF_OPT_PYRAMID_FEW:
       if (value < 0) return VSF_ERR_INVALID_ARG;
@@ -747,17 +714,12 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
   if (!ctx || !value) return VSF_ERR_INVALID_ARG;
   const VsfTuning& t = ctx->tuning;
   switch (option) {
-    case VSF_OPT_BLUR_MARCH: *value = t.blur_march; break;
     case VSF_OPT_FAST_BOTH_MAX: *value = t.fast_both_max; break;
-    case VSF_OPT_SORT_SERIAL: *value = t.sort_serial; break;
     case VSF_OPT_SELECT_WIDE: *value = t.select_wide; break;
     case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
     case VSF_OPT_PIPE_AFTER_FAST: *value = t.pipe_after_fast; break;
-    case VSF_OPT_MATCH_INT8: *value = t.match_int8; break;
     case VSF_OPT_OBSERVE_THREAD: *value = t.observe_thread; break;
-    case VSF_OPT_FAST_BITS: *value = t.fast_bits; break;
     case VSF_OPT_PIPE_PRIORITY: *value = t.pipe_priority; break;
-    case VSF_OPT_JPEG_SERIAL: *value = t.jpeg_serial; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
     case VSF_OPT_PYRAMID_CHAIN: *value = t.pyramid_chain; break;
     case VSF_OPT_PYRAMID_ROWS: *value = t.pyramid_rows; break;

@@ -41,7 +41,7 @@ vsf_status vsf_tune_fast_resident(vsf_ctx* ctx, const uint8_t* d_imgs, int n_ima
   T.n = n_images;
   T.choice = 0;
   // batches the blur does not run beside have one form only
-  if (!(ctx->blur_overlap && !ctx->tuning.blur_march && n_images >= 32 && ctx->blur_stream && ctx->lanes == 1)) return VSF_OK;
+  if (!(ctx->blur_overlap && n_images >= 32 && ctx->blur_stream && ctx->lanes == 1)) return VSF_OK;
   for (hipEvent_t& e : T.ev)
     if (!e) VSF_HIP(hipEventCreate(&e));
   const VsfImages im{d_imgs, image_stride, row_stride, n_images};
@@ -272,7 +272,7 @@ vsf_status vsf_feature_matches_batch_dev(vsf_ctx* ctx, const uint8_t* d_desc, co
   {
     StageTimer t(ctx, ctx->stream, VSF_STAGE_TAIL, 1);
     vsf_launch_sort_trim(ctx->t_matches, ctx->t_nmatches, n_pairs, (int)K, best_percent, nullptr, ctx->t_sortkeys,
-                         d_pairs, d_npairs, ctx->stream, ctx->tuning.sort_serial != 0, ctx->tuning.lds_limit);
+                         d_pairs, d_npairs, ctx->stream, false, ctx->tuning.lds_limit);
   }
   VSF_STICKY();
   return VSF_OK;

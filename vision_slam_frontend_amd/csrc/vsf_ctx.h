@@ -19,9 +19,7 @@ struct Geometry {
   VsfGeom g{};
   std::vector<VsfLevel> levels;
   std::vector<uint32_t> units;
-  std::vector<uint2> bits_items;  // k_fastbits.hip work items (empty: the geometry does not fit that kernel)
   std::vector<VsfTap> xt, yt;
-  std::vector<uint32_t> blur_tiles;
   // matrix-core blur (k_blur.hip blur_mma_kernel): work units and constant MFMA operands
   std::vector<uint32_t> blur_mma_units, blur_mma_units_small;  // long strips (batches) / short strips (a frame or two)
   std::vector<uint4> blur_tcol, blur_tv;
@@ -32,9 +30,6 @@ struct DevSet {  // device copies of one Geometry + its work buffers
   VsfDev d{};
   VsfLevel* levels = nullptr;
   uint32_t* units = nullptr;
-  uint2* bits_items = nullptr;
-  int n_bits_items = 0;
-  uint32_t* blur_tiles = nullptr;
   uint32_t* blur_mma_units = nullptr;
   uint32_t* blur_mma_units_small = nullptr;
   uint4* blur_tcol = nullptr;
@@ -90,7 +85,6 @@ struct vsf_ctx {
   int pending_hip = 0;  // an error noted during one of THIS context's calls that returned before checking (VsfErrorScope)
   vsfi::Geometry orb, fast;
   vsfi::DevSet dorb, dfast;
-  int gauss[4] = {0, 0, 0, 0};
   // Status words (bit 0: capacity overflow, bit 1: a JPEG stream broke off): word 0 belongs to the context's own stream
   // (batched and host-pointer calls, vsf_sync), words 1..6 to the frames that may be in flight (vsf_observe_submit) --
   // a frame's kernels run on its slot's stream beside another frame's, so each frame sets, copies and clears its own word.

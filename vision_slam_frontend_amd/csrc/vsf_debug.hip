@@ -24,6 +24,18 @@ vsf_status vsf_debug_inject_hip_error(vsf_ctx* ctx, int code) {
   return VSF_OK;
 }
 
+vsf_status vsf_debug_jpeg_serial(vsf_ctx* ctx, int on) {
+  VsfErrorScope scope_(ctx);
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  VSF_HIP(hipStreamSynchronize(ctx->stream));
+  if (!on && vsf_prepare_jpeg_kernels(ctx->tuning.lds_limit) != hipSuccess) {  // (the parallel decoder's LDS was refused)
+    (void)hipGetLastError();
+    return VSF_ERR_UNSUPPORTED;
+  }
+  ctx->tuning.jpeg_serial = on != 0;
+  return VSF_OK;
+}
+
 vsf_status vsf_profile_enable(vsf_ctx* ctx, int on) {
   VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;

@@ -253,10 +253,9 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
   G.g.nwork_half = (int)half_items.size();
   G.units.insert(G.units.end(), half_items.begin(), half_items.end());
   if (G.units.empty()) G.units.push_back(0);
-  if (!(orb && nms && vsf_fast_bits_items(G.levels.data(), nlevels, 4, &G.bits_items))) G.bits_items.clear();
   G.g.lvlkp_entries = std::max(kp_off, 1);
   // resize coefficient tables (host only: the kernel evaluates the same arithmetic in place; built here to check
-  // that a lane's eight x taps fit the 8-byte source window it loads) + blur tiles (ORB only)
+  // that a lane's eight x taps fit the 8-byte source window it loads)
   if (orb) {
     for (int l = 1; l < nlevels; l++) {
       VsfLevel& L = G.levels[l];
@@ -308,26 +307,9 @@ bool build_geometry(const vsf_params& p, bool orb, bool nms, Geometry* out) {
         }
       }
     }
-    for (int l = 0; l < nlevels; l++) {
-      const VsfLevel& L = G.levels[l];
-      // blur work units: (level, 248-column band, 64-row strip), one wave each -- except that a narrow last band
-      // (<= 120 columns) is walked two strips per wave (k_blur.hip: bit 15)
-      const int nb = (L.w + VSF_BLUR_BAND_COLS - 1) / VSF_BLUR_BAND_COLS;
-      const int ns = (L.h + VSF_BLUR_STRIP_ROWS - 1) / VSF_BLUR_STRIP_ROWS;
-      const bool half_last = ns >= 2 && L.w - VSF_BLUR_BAND_COLS * (nb - 1) <= 120;
-      for (int st = 0; st < ns; st++)
-        for (int b = 0; b < nb; b++) {
-          if (half_last && b == nb - 1) {
-            if ((st & 1) == 0) G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | 0x8000u | (uint32_t)st);
-          } else {
-            G.blur_tiles.push_back(((uint32_t)l << 24) | ((uint32_t)b << 16) | (uint32_t)st);
-          }
-        }
-    }
   }
   if (G.xt.empty()) G.xt.push_back(VsfTap{0, 0, 0, 0});
   if (G.yt.empty()) G.yt.push_back(VsfTap{0, 0, 0, 0});
-  if (G.blur_tiles.empty()) G.blur_tiles.push_back(0);
   if (orb) {
     // matrix-core blur: taps must be int8, the row sums 16 bit, bands / steps fit the unit word
     int k4[4];

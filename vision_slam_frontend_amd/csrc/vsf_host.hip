@@ -160,7 +160,7 @@ static vsf_status match_host(vsf_ctx* ctx, const uint8_t* q, int nq, const uint8
                            ctx->stream));
   // m_idx2/m_dist2 are laid out [pair][m_rows][2]; the kernels are given the same row capacity.
   vsf_launch_knn2(ctx->mh_desc, ctx->mh_counts, set_stride, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2,
-                  ctx->stream, ctx->tuning.match_int8 != 0);
+                  ctx->stream);
   if (out) {
     vsf_launch_ratio_compact(ctx->mh_counts, nullptr, nullptr, 1, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
                              ctx->p.ratio_shift, ctx->mh_matches, ctx->mh_nmatches, ctx->d_status, ctx->stream);
@@ -237,7 +237,7 @@ vsf_status vsf_get_matches_multi(vsf_ctx* ctx, const uint8_t* const* q, const in
   // every buffer of this call is laid out with row capacity R: m_idx2 / m_dist2 [S][R][2] (they hold at least
   // m_pairs x m_rows >= S x R entries), mm_matches [S][R]
   vsf_launch_knn2(ctx->mm_desc, ctx->mm_counts, set_stride, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2,
-                  ctx->stream, ctx->tuning.match_int8 != 0);
+                  ctx->stream);
   vsf_launch_ratio_compact(ctx->mm_counts, d_q, d_t, S, R, ctx->m_idx2, ctx->m_dist2, ctx->p.ratio_num,
                            ctx->p.ratio_shift, ctx->mm_matches, ctx->mm_nmatches, ctx->d_status, ctx->stream);
   VSF_STICKY();

@@ -17,8 +17,6 @@
 #define VSF_FAST_HALF_COLS 120   // a last band of at most this many columns is walked two strips per wave (30 lanes x 4)
 #define VSF_FAST_STRIP_ROWS 32
 #define VSF_FAST_RS_STRIDE (VSF_FAST_STRIP_ROWS + 2)  // u16 row-start table per unit (SR + 1 used)
-#define VSF_BLUR_BAND_COLS 248   // output columns per wave of the blur march kernel (62 lanes x 4 px)
-#define VSF_BLUR_STRIP_ROWS 64   // output rows per wave
 #define VSF_BLUR_MMA_ROWS 26     // output rows per step of the matrix-core blur (32 loaded rows - 2 x 3 halo rows)
 #define VSF_BLUR_MMA_STEPS 16    // double steps (52 rows) per unit: a workgroup walks this many blocks down its band pair
 #define VSF_BLUR_MMA_STEPS_SMALL 2  // ... for batches below 32 images
@@ -90,16 +88,12 @@ struct VsfGeom {
 // Per-context launch choices (vsf_set_option / vsf_get_option; the defaults are what the measurements of NOTES.md
 // section 6 settled on).  Nothing in the library reads the environment: a switch is a call on a context.
 struct VsfTuning {
-  int blur_march = 0;      // VSF_OPT_BLUR_MARCH: 1 = round 2's vector-ALU blur kernel instead of the matrix-core one (A/B runs)
   int fast_both_max = 16;  // VSF_OPT_FAST_BOTH_MAX: largest batch (images) whose full and half-wave FAST cells share one launch
-  int sort_serial = 0;     // VSF_OPT_SORT_SERIAL: 1 = sort_trim's one-lane kernel
   int select_wide = 1;     // VSF_OPT_SELECT_WIDE: 1 = a frame or two takes the 1024-thread whole-level selection class
-  int fast_bits = 0;         // VSF_OPT_FAST_BITS: FAST on bit planes (k_fastbits.hip): 0 never, 1 batches of >= 8 images, 2 any batch
-  int match_int8 = 0;        // VSF_OPT_MATCH_INT8: 1 = the int8 form of the matcher (v_mfma_i32_32x32x32_i8) instead of the FP4 one
   int pipe_priority = 0;     // VSF_OPT_PIPE_PRIORITY: stream priority of the pipelined pyramid chain (0 normal, 1 lowest, -1 highest)
   int pipe_after_fast = 1;   // VSF_OPT_PIPE_AFTER_FAST: the pipelined pyramid of call k + 1 starts behind call k's FAST (1) or at once (0)
   int select_big_class = 1;  // VSF_OPT_SELECT_BIG_CLASS: 1 = the widest levels of a batch take the 9 216-entry class
-  int jpeg_serial = 0;     // VSF_OPT_JPEG_SERIAL: 1 = every file through the one-wave-per-image decoder
+  int jpeg_serial = 0;     // 1: every file through the one-wave-per-image decoder (set when the parallel decoder's LDS is refused)
   int pyramid_few = 16;    // VSF_OPT_PYRAMID_FEW: largest batch (images) that takes the slab kernel for every level
   int pyramid_chain = 8;   // VSF_OPT_PYRAMID_CHAIN: levels per slab launch (0: keep the per-level launches)
   int pyramid_rows = 6;    // VSF_OPT_PYRAMID_ROWS: rows of the chain's last level per slab
@@ -151,8 +145,6 @@ hipError_t vsf_prepare_jpeg_kernels(int lds_limit);
 struct VsfDev {
   const VsfLevel* levels;   // [nlevels]
   const uint32_t* units;    // [nwork_full + nwork_half]: level << 24 | band << 16 | (first) strip
-  const uint2* bits_items;  // [n_bits_items] k_fastbits.hip work items, or NULL
-  int n_bits_items;
   uint8_t* pyr;             // [max_images][pyr_bytes]   unblurred levels 1..L-1 (level 0 is the input)
   uint8_t* blur;            // [max_images][pyr_bytes]   blurred levels 0..L-1
   uint32_t* cand;           // [max_images][cand_entries]  per-unit candidate segments (unit-local raster order)
@@ -187,19 +179,10 @@ void vsf_launch_pyramid(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_lev
 // threshold: FAST threshold; nms == 0 keeps every corner (standalone FAST only).
 void vsf_launch_fast(const VsfDev& d, const VsfGeom& g, const VsfImages& im, int threshold, int nms, hipStream_t s,
                      int resident_waves_per_simd = 0, int n_cus = 0, uint32_t* d_cell_counters = nullptr);
-// k_fastbits.hip: the segment test on bit planes + scores only where it fires; same outputs as vsf_launch_fast (NMS on,
-// threshold >= 1).  `d_items` from vsf_fast_bits_items (false: the geometry does not fit).
-#ifdef __cplusplus
-bool vsf_fast_bits_items(const VsfLevel* levels, int nlevels, int chain, std::vector<uint2>* items);
-#endif
-void vsf_launch_fast_bits(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint2* d_items, int nitems,
-                          int threshold, hipStream_t s);
 void vsf_launch_select(const VsfDev& d, const VsfGeom& g, const VsfLevel* h_levels, const VsfImages& im,
                        hipStream_t s);
 void vsf_launch_retain_best_test(uint2* d_data, uint32_t* d_tables, int n, int n_points, int use_lds, int mode,
                                  int* d_out_n, hipStream_t s);
-void vsf_launch_blur(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_tiles, int ntiles,
-                     const int k[4], hipStream_t s);
 // Matrix-core blur (k_blur.hip, round 3): units = level << 24 | band pair << 16 | first double step << 8 | double steps.
 void vsf_launch_blur_mma(const VsfDev& d, const VsfGeom& g, const VsfImages& im, const uint32_t* d_units, int nunits,
                          const uint4* d_tcol, const uint4* d_tv, int bias, hipStream_t s);
@@ -209,7 +192,7 @@ void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int m
                           int32_t* d_counts, hipStream_t s);
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                     hipStream_t s, bool int8_form = false);  // int8_form: round 2's int8 matrix instruction (VSF_OPT_MATCH_INT8)
+                     hipStream_t s);
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
                               int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,

@@ -338,8 +338,7 @@ vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n, bool solo) {
   // ---- every GetFeatureMatches of the batch: one matcher launch, one sort launch (per-pair best_percent) ----
   {
     StageTimer t(ctx, s_tail, VSF_STAGE_KNN2, 1);
-    vsf_launch_knn2(o.sets, o.set_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, o.t_idx2, o.t_dist2, s_tail,
-                    ctx->tuning.match_int8 != 0);
+    vsf_launch_knn2(o.sets, o.set_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, o.t_idx2, o.t_dist2, s_tail);
   }
   {
     StageTimer t(ctx, s_tail, VSF_STAGE_RATIO, 1);
@@ -349,7 +348,7 @@ vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n, bool solo) {
   {
     StageTimer t(ctx, s_tail, VSF_STAGE_TAIL, 3);
     vsf_launch_sort_trim(o.t_matches, o.t_nmatches, n_pairs, Kc, f0.best_percent, M.best_percent, o.t_sortkeys, o.pairs,
-                         o.npairs, s_tail, ctx->tuning.sort_serial != 0, ctx->tuning.lds_limit);
+                         o.npairs, s_tail, false, ctx->tuning.lds_limit);
     // ---- Calculate3DPoints + VisionFeature + UndistortFeaturePoints (cc:437-443): pairs [0, n) are the right -> left ones ----
     vsf_launch_vision_features(o.kpf, counts_f, o.pairs, o.npairs, n, Kc, f0.calib, o.features, nfeat, npoints, s_tail);
     // ---- one compact result per frame, into its slot of the pinned result ring ----

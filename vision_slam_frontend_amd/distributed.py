@@ -411,7 +411,6 @@ class ShardedStereoFrontend:
             tail_params = capi.VsfParams.from_buffer_copy(ctx.params)
             tail_params.max_images = 2
             self.tail_ctx = capi.Context(tail_params, device=ctx.device)
-            self.tail_ctx.set_option(capi.OPT_MATCH_INT8, ctx.get_option(capi.OPT_MATCH_INT8))  # (the tail's matcher in the same form)
             assert self.tail_ctx.params.max_keypoints == ctx.params.max_keypoints
         else:
             self.tail_stream, self.tail_ctx = self.stream, ctx
