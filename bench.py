@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import subprocess
 import os
 import sys
 import time
@@ -500,6 +501,11 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the two short legs on BASELINE's other single-GPU configurations (configs[2] 1920x1080 / 8000 "
+                         "features, configs[4] a temporal window of 8; ~10 s each, child processes of this script)")
+    ap.add_argument("--leg", action="store_true",
+                    help="(internal) this run IS such a leg: the timed steps and the roofline only")
     ap.add_argument("--no-sustained", action="store_true",
                     help="skip the sustained-throughput leg (>= 600 further steps, ~5 s, after the timed region)")
     ap.add_argument("--sustained-steps", type=int, default=700)
@@ -512,6 +518,8 @@ def main() -> int:
     ap.add_argument("--no-gloo-retry", action="store_true",
                     help="bare `--gpus N` form: do not repeat a run whose RCCL set-up failed with the collectives on gloo")
     args = ap.parse_args()
+    if args.leg:
+        args.no_sustained = args.no_observe = args.no_cpu_baseline = args.no_other_configs = True
     cfg = CONFIGS[args.config]
     W = args.width or cfg["width"]
     H = args.height or cfg["height"]
@@ -725,20 +733,30 @@ def main() -> int:
     # roofline figures of the streaming stages use those, the headline value and ms_per_step do not.
     blur_beside = not args.blur_inline and 2 * B >= 32
     inline_stages = None
-    if blur_beside or pipeline:
+    if blur_beside or pipeline or sf.overlap:
+        # Every stage by itself: the blur back on the extraction's stream, no cross-step pyramid, and the host waits for the
+        # GPU after every step, so that neither the previous step's tail nor -- when it rides the tail stream -- the stereo
+        # matcher runs beside the stage being timed (round 5 left the tail beside it: at 10 000 features the pyramid read
+        # 3.25 ms "in line" next to the 6-ms matcher, 1.25 ms at 2000 features for the same work).  Stages the tail
+        # context times (the tail, the matcher when it is the tail's first kernel) are folded in from that context.
         ctx.set_blur_overlap(False)
         ctx.set_pipeline(False)
         inline_steps = 3
         run_step()
         sf.drain()
-        ctx.sync(allow_capacity=True)
-        ctx.profile_enable(True)
+        torch.cuda.synchronize()
+        for c in sf.contexts():
+            c.sync(allow_capacity=True)
+            c.profile_enable(True)
         for _ in range(inline_steps):
             run_step()
-        sf.drain()
-        torch.cuda.synchronize()
-        inline_stages = {k: v[0] / inline_steps for k, v in ctx.profile_read(reset=True).items()}
-        ctx.profile_enable(False)
+            sf.drain()
+            torch.cuda.synchronize()
+        inline_stages = {}
+        for c in sf.contexts():
+            for k, v in c.profile_read(reset=True).items():
+                inline_stages[k] = inline_stages.get(k, 0.0) + v[0] / inline_steps
+            c.profile_enable(False)
         ctx.set_blur_overlap(not args.blur_inline)
         ctx.set_pipeline(pipeline)
     rank_ms = [1e3 * elapsed / args.steps]
@@ -810,11 +828,16 @@ def main() -> int:
         ceilings, valu_rate_all4, ceilings_stale = valu_ceilings()
         concurrent = (["gauss_blur7"] if blur_beside else []) + (["pyramid_resize"] if pipeline else [])
         # the dominant stage by its OWN duration (the in-line pass when stages share the chip in the timed steps)
+        # (a stage the tail context carries -- the stereo matcher as the tail's first kernel -- is looked up there)
+        stages_all = dict(stages)
+        for k, v in (tail_stages or {}).items():
+            if stages_all.get(k, (0.0, 0))[1] == 0:
+                stages_all[k] = v
         if inline_stages:
-            dom = max(inline_stages, key=lambda k: inline_stages[k])
+            dom = max((k for k in inline_stages if stages_all.get(k, (0.0, 0))[1] > 0), key=lambda k: inline_stages[k])
         else:
             dom = max((k for k in stages if k not in concurrent), key=lambda k: stages[k][0])
-        dom_ms, dom_launches = stages[dom]
+        dom_ms, dom_launches = stages_all[dom]
         fast_waves = ctx.get_fast_resident()
         # FAST as resident workgroups shares every SIMD with the blur: its stage time in the timed steps is then a span
         # under contention as well; its own duration comes from the in-line pass
@@ -968,6 +991,36 @@ def main() -> int:
             obs["note"] = ("640x480, frame_life 10, window full; per stereo frame through slam::Frontend (host/slam_frontend.cc); "
                            "pipelined: queue depth 256, <= 128 frames per batch, 3200 steady frames per run")
             out["observe_image"] = obs
+        # BASELINE's other single-GPU configurations, each a short run of this same script in a child process (its own
+        # contexts, tune call, timed steps and in-line pass; the parent's GPU work is over): configs[2] = 1920x1080 / 8000
+        # features, configs[4] = a temporal window of 8 frames (the multi-query matcher launch).
+        out["other_configs"] = None
+        report_stage("other configs")
+        if world == 1 and not args.no_other_configs and args.config == "vga" and args.window == 1 and args.ingest == "hbm":
+            other = {}
+            for name, extra in (("1080p_8000", ["--config", "1080p", "--batch", "64"]), ("window8", ["--window", "8"])):
+                cmd = [sys.executable, str(ROOT / "bench.py"), "--leg", "--steps", "8", "--warmup", "2", "--tune-steps", "4"] + extra
+                t_leg = time.perf_counter()
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    j = json.loads(line[-1]) if line else None
+                except (subprocess.TimeoutExpired, ValueError) as e:
+                    r, j = None, None
+                    other[name] = {"error": repr(e)}
+                if j is not None:
+                    rf = j.get("roofline") or {}
+                    other[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                   "config": {k: j["config"].get(k) for k in ("workload", "frames_per_step_per_gpu", "stereo_match",
+                                                                               "mean_keypoints_per_image", "mean_features_per_frame")},
+                                   "roofline": {"kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"),
+                                                "achieved": rf.get("achieved"), "unit": rf.get("unit"),
+                                                "frac_in_line": (rf.get("in_line") or {}).get("frac")},
+                                   "stages_ms_per_step_in_line": j.get("stages_ms_per_step_in_line"),
+                                   "seconds": time.perf_counter() - t_leg}
+                elif r is not None:
+                    other[name] = {"error": "rc %d: %s" % (r.returncode, (r.stderr or "")[-400:])}
+            out["other_configs"] = other
         report_stage("cpu_baseline leg")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, synth.BASE_SEED)
