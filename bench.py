@@ -111,28 +111,37 @@ def host_cores():
     return max(1, n), how
 
 
-def cpu_baseline(width, height, nfeatures, seed):
+def cpu_baseline(width, height, nfeatures, seed, seconds=15.0, kind="port"):
     """The CPU oracle (a scalar C++ restatement of the OpenCV routines, kind "port": real OpenCV cannot be built here)
-    timed on ALL of this box's host cores, one stereo frame per thread at a time."""
+    timed on ALL of this box's host cores, one stereo frame per thread at a time.  `digest`: sha256 over the keypoints,
+    descriptors and matches of the first frames -- what lets two builds of the oracle be held against each other."""
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import binding as ob
     from vision_slam_frontend_amd import synth
 
-    ob.build()
+    if not os.environ.get("VSF_ORACLE_LIB"):
+        ob.build()
     cores, how = host_cores()
     n_render = min(4 * cores, 64)
     frames = synth.bench_batch(n_render, width, height, seed=seed, n_scenes=min(4, n_render))
 
-    def one(i):
+    def one(i, digest=None):
         a, b = ob.Orb(nfeatures=nfeatures), ob.Orb(nfeatures=nfeatures)
         a.run(frames[i % n_render, 0])
         b.run(frames[i % n_render, 1])
-        _, da = a.result()
-        _, db = b.result()
-        return len(ob.get_matches(da, db))
+        ka, da = a.result()
+        kb, db = b.result()
+        m = ob.get_matches(da, db)
+        if digest is not None:
+            for arr in (ka, da, kb, db, m):
+                digest.update(arr.tobytes())
+        return len(m)
 
-    one(0)  # warm (page in, build tables)
+    h = hashlib.sha256()
+    for i in range(min(4, n_render)):  # warm (page in, build tables) + the digest of four frames
+        one(i, h)
     # A box may show more cores than it grants (a CPU share without a readable cgroup quota): one calibration round on
     # the visible cores measures how many actually ran (process CPU time / wall time); the timed rounds use that many.
     if cores > 1:
@@ -143,19 +152,43 @@ def cpu_baseline(width, height, nfeatures, seed):
         if granted < 0.75 * min(cores, 64):
             cores = max(1, int(granted + 0.5))
             how = "the %d cores this process was granted (measured: CPU time / wall time; the host shows more)" % cores
-    # rounds of one frame per thread until ~15 s of wall time have passed (at least two rounds): bounded whatever the box
+    # rounds of one frame per thread until `seconds` of wall time have passed (at least two rounds): bounded whatever the box
     n, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         while True:
             list(ex.map(one, range(n, n + cores)))
             n += cores
             dt = time.perf_counter() - t0
-            if dt >= 15.0 and n >= 2 * cores:
+            if dt >= seconds and n >= 2 * cores:
                 break
-    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "kind": kind, "digest": h.hexdigest(),
             "sample": "%d synthetic %dx%d stereo frames (%d kp) through the oracle port's extract(L)+extract(R)+GetMatches "
                       "(scalar C++ restatement of OpenCV 3.2, not OpenCV itself), %d threads = %s, %.1f s wall"
                       % (n, width, height, nfeatures, cores, how, dt)}
+
+
+def cpu_baseline_native(width, height, nfeatures, seed, parity_digest):
+    """The same sources built with -O3 -march=native ON THIS HOST (oracle/Makefile `native`: hardware popcount,
+    auto-vectorised loops) and timed the same way in a child process (the oracle's binding holds one library per process);
+    refused unless its outputs equal the parity build's byte for byte."""
+    try:
+        r = subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "native"], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "build failed: " + (r.stderr or r.stdout)[-300:]}
+        env = dict(os.environ, VSF_ORACLE_LIB=str(ROOT / "oracle" / "_native" / "libvsf_oracle_native.so"))
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-child", "--width", str(width), "--height",
+                            str(height), "--nfeatures", str(nfeatures)], capture_output=True, text=True, timeout=300, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "child rc %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+        j = json.loads(line[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
+    if j.get("digest") != parity_digest:
+        return {"error": "outputs differ from the parity build's: not timed as a baseline", "digest": j.get("digest")}
+    j["flags"] = "-O3 -DNDEBUG -march=native -ffp-contract=off (oracle/Makefile native), outputs byte-equal to the parity build"
+    j["kind"] = "port"
+    return j
 
 
 class JpegIngest:
@@ -504,6 +537,8 @@ def main() -> int:
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the two short legs on BASELINE's other single-GPU configurations (configs[2] 1920x1080 / 8000 "
                          "features, configs[4] a temporal window of 8; ~10 s each, child processes of this script)")
+    ap.add_argument("--cpu-baseline-child", action="store_true",
+                    help="(internal) time the oracle library named by VSF_ORACLE_LIB and print the record; no GPU")
     ap.add_argument("--leg", action="store_true",
                     help="(internal) this run IS such a leg: the timed steps and the roofline only")
     ap.add_argument("--no-sustained", action="store_true",
@@ -521,6 +556,11 @@ def main() -> int:
     if args.leg:
         args.no_sustained = args.no_observe = args.no_cpu_baseline = args.no_other_configs = True
     cfg = CONFIGS[args.config]
+    if args.cpu_baseline_child:
+        from vision_slam_frontend_amd import synth as _synth
+        print(json.dumps(cpu_baseline(args.width or cfg["width"], args.height or cfg["height"], args.nfeatures or cfg["nfeatures"],
+                                      _synth.BASE_SEED, seconds=8.0)))
+        return 0
     W = args.width or cfg["width"]
     H = args.height or cfg["height"]
     NF = args.nfeatures or cfg["nfeatures"]
@@ -1024,8 +1064,13 @@ def main() -> int:
         report_stage("cpu_baseline leg")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, synth.BASE_SEED)
+            # ... and the same sources with -march=native: a floor (above) and a fairer figure (here) for what the
+            # reference's -O3 build (CMakeLists.txt:12-14) with OpenCV's SSE2 / parallel_for_ paths would give
+            report_stage("cpu_baseline_native leg")
+            out["cpu_baseline_native"] = cpu_baseline_native(W, H, NF, synth.BASE_SEED, out["cpu_baseline"]["digest"])
         else:
             out["cpu_baseline"] = None
+            out["cpu_baseline_native"] = None
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     report_stage("teardown")
