@@ -18,12 +18,14 @@ extern "C" {
 vsf_status vsf_extract_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride,
                                  size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts) {
   VsfErrorScope scope_(ctx);
-  if (!ctx || !d_kp || !d_desc || !d_counts) return VSF_ERR_INVALID_ARG;
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  InputEventScope input(ctx);
+  if (!d_kp || !d_desc || !d_counts) return VSF_ERR_INVALID_ARG;
   vsf_status st = validate_images(ctx, d_imgs, n_images, image_stride, row_stride);
   if (st != VSF_OK) return st;
   VSF_HIP(hipSetDevice(ctx->device));
   VsfImages im{d_imgs, image_stride, row_stride, n_images};
-  InputEventScope input(ctx);
+  input.wait();
   return extract_async(ctx, im, d_kp, d_desc, d_counts, true);
 }
 
@@ -105,13 +107,15 @@ vsf_status vsf_stereo_batch_dev(vsf_ctx* ctx, const uint8_t* d_imgs, int n_frame
                                 size_t row_stride, vsf_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
                                 vsf_dmatch* d_matches, int32_t* d_nmatches) {
   VsfErrorScope scope_(ctx);
-  if (!ctx || n_frames < 1 || !d_kp || !d_desc || !d_counts || !d_matches || !d_nmatches) return VSF_ERR_INVALID_ARG;
+  if (!ctx) return VSF_ERR_INVALID_ARG;
+  InputEventScope input(ctx);
+  if (n_frames < 1 || !d_kp || !d_desc || !d_counts || !d_matches || !d_nmatches) return VSF_ERR_INVALID_ARG;
   vsf_status st = validate_images(ctx, d_imgs, 2 * n_frames, image_stride, row_stride);
   if (st != VSF_OK) return st;
   VSF_HIP(hipSetDevice(ctx->device));
   st = ensure_match_buffers(ctx, n_frames, ctx->p.max_keypoints);
   if (st != VSF_OK) return st;
-  InputEventScope input(ctx);
+  input.wait();
   const VsfImages im{d_imgs, image_stride, row_stride, 2 * n_frames};
   const size_t set_stride = (size_t)ctx->p.max_keypoints * VSF_DESC_BYTES;
   st = run_chunked(ctx, n_frames, [&](hipStream_t s, int fa, int nf) {

@@ -328,7 +328,11 @@ VsfDev shifted(const VsfDev& d, const VsfGeom& g, int i0);
 // itself in extract_on -- and the event is forgotten when the call returns (one-shot).
 struct InputEventScope {
   vsf_ctx* ctx;
-  explicit InputEventScope(vsf_ctx* c) : ctx(c) {
+  // Built FIRST in the entry point (right behind the null check), so that every way out -- a refusal included -- forgets the
+  // event: a handle left pending would be waited for by some later call, when the caller may long have destroyed or
+  // re-recorded it.  wait() is issued once the arguments have been validated.
+  explicit InputEventScope(vsf_ctx* c) : ctx(c) {}
+  void wait() {
     if (ctx->input_event) vsf_note(hipStreamWaitEvent(ctx->stream, ctx->input_event, 0));
   }
   ~InputEventScope() { ctx->input_event = nullptr; }

@@ -110,9 +110,20 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
     const bool critical = (type[0] & 0x20) == 0;
     const bool crc_ok = (crc32_update(0xFFFFFFFFu, type, (size_t)len + 4) ^ 0xFFFFFFFFu) == be32(data + len);
     pos += 12 + (size_t)len;
+    // png_check_chunk_name: four letters, or png_chunk_error("invalid chunk type"); png_check_chunk_length: anything but IDAT is
+    // at most PNG_USER_CHUNK_MALLOC_MAX = 8 000 000 bytes ("chunk data is too large") -- both before the CRC is looked at
+    for (int k = 0; k < 4; k++)
+      if (!((type[k] >= 'A' && type[k] <= 'Z') || (type[k] >= 'a' && type[k] <= 'z'))) return VSF_ERR_INVALID_ARG;
+    const bool is_idat = std::memcmp(type, "IDAT", 4) == 0;
+    if (!is_idat && len > 8000000u) return VSF_ERR_INVALID_ARG;
+    // the chunk's PLACE counts whatever its CRC says: libpng wants IHDR first ("missing IHDR": the position check of every
+    // handler comes before its CRC check), and any chunk between two IDATs ends the run of IDATs ("Not enough image data" /
+    // "Too many IDATs found" later on), a damaged ancillary one included
+    if (!have_ihdr && std::memcmp(type, "IHDR", 4) != 0) return VSF_ERR_INVALID_ARG;
+    if (have_idat && !is_idat) idat_run_over = true;
     if (!crc_ok) {
       if (critical) return VSF_ERR_INVALID_ARG;  // png_crc_error: png_chunk_error for critical chunks
-      continue;                                  // ancillary: a warning, the chunk is skipped
+      continue;                                  // ancillary: a warning, the chunk's contents are skipped
     }
     if (!have_ihdr) {
       if (std::memcmp(type, "IHDR", 4) != 0 || len != 13) return VSF_ERR_INVALID_ARG;
@@ -153,7 +164,7 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
       continue;
     }
     if (std::memcmp(type, "IHDR", 4) == 0) return VSF_ERR_INVALID_ARG;
-    if (std::memcmp(type, "IDAT", 4) == 0) {
+    if (is_idat) {
       if (idat_run_over) return VSF_ERR_INVALID_ARG;  // (IDAT chunks must follow one another)
       if (ctype == 3 && !have_plte) return VSF_ERR_INVALID_ARG;  // "Missing PLTE before IDAT"
       have_idat = true;
@@ -164,7 +175,6 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
       }
       continue;
     }
-    if (have_idat) idat_run_over = true;
     if (std::memcmp(type, "IEND", 4) == 0) {
       have_iend = true;
       continue;
@@ -227,6 +237,10 @@ vsf_status parse_png(const uint8_t* f, size_t n, int width, int height, DevImage
   }
   if ((hdr[0] & 0x0F) != 8 || (hdr[0] >> 4) > 7 || (hdr[1] & 0x20) != 0 || (((uint32_t)hdr[0] << 8) | hdr[1]) % 31 != 0)
     return VSF_ERR_INVALID_ARG;
+  // libpng inflates with the window the header declares (1 << (CINFO + 8)) and refuses a match that reaches further back
+  // ("invalid distance too far back"); the device kernel's window is the full 32 KiB.  Every encoder in use writes CINFO 7
+  // for an image of this size; a smaller declared window is refused here rather than decoded more leniently than libpng.
+  if ((hdr[0] >> 4) < 7) return VSF_ERR_UNSUPPORTED;
   im->stream_len = (uint32_t)stream_len;
   if (colour) {
     if (unsupported_colourspace || n_iccp > 0 || n_gama > 1 || n_srgb > 1 || (odd_chrm && n_gama + n_srgb > 0)) return VSF_ERR_UNSUPPORTED;
