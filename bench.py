@@ -534,6 +534,9 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-observe", action="store_true",
                     help="skip the drop-in API figures (slam::Frontend::ObserveImage one frame at a time, ~3 s)")
+    ap.add_argument("--no-inline-pass", action="store_true",
+                    help="skip the few untimed steps that give every stage's own duration (counter passes: the run then has "
+                         "exactly warm-up + steps steps, which tools/make_traffic.py divides by)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the two short legs on BASELINE's other single-GPU configurations (configs[2] 1920x1080 / 8000 "
                          "features, configs[4] a temporal window of 8; ~10 s each, child processes of this script)")
@@ -773,7 +776,7 @@ def main() -> int:
     # roofline figures of the streaming stages use those, the headline value and ms_per_step do not.
     blur_beside = not args.blur_inline and 2 * B >= 32
     inline_stages = None
-    if blur_beside or pipeline or sf.overlap:
+    if (blur_beside or pipeline or sf.overlap) and not args.no_inline_pass:
         # Every stage by itself: the blur back on the extraction's stream, no cross-step pyramid, and the host waits for the
         # GPU after every step, so that neither the previous step's tail nor -- when it rides the tail stream -- the stereo
         # matcher runs beside the stage being timed (round 5 left the tail beside it: at 10 000 features the pyramid read

@@ -15,11 +15,11 @@ extra="$@"
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-observe --no-sustained $extra > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_inline" -o bench -- python3 bench.py --no-cpu-baseline --no-observe --no-sustained --blur-inline --no-pipeline $extra > "$out/bench_inline_under_rocprof.json" 2> "$out/stats_inline.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-observe --no-sustained --no-other-configs $extra > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_inline" -o bench -- python3 bench.py --no-cpu-baseline --no-observe --no-sustained --no-other-configs --blur-inline --no-pipeline $extra > "$out/bench_inline_under_rocprof.json" 2> "$out/stats_inline.err"
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE "valu:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES"; do
   pname=${pass%%:*}; counters=${pass#*:}
-  rocprofv3 --pmc $counters --output-format csv -d "$out/$pname" -o pmc -- python3 bench.py --no-cpu-baseline --no-observe --no-sustained --blur-inline --no-pipeline --steps 3 --warmup 1 $extra > "$out/$pname.json" 2> "$out/$pname.err"
+  rocprofv3 --pmc $counters --output-format csv -d "$out/$pname" -o pmc -- python3 bench.py --no-cpu-baseline --no-observe --no-sustained --no-other-configs --no-inline-pass --blur-inline --no-pipeline --steps 3 --warmup 1 $extra > "$out/$pname.json" 2> "$out/$pname.err"
   echo "pmc pass $pname done"
 done
 python3 tools/make_traffic.py "$out/fetch" "$out/write" "$out/valu" $batch $w $h $nf $name
