@@ -191,6 +191,28 @@ def test_queue_depths_equal_the_synchronous_calls(depth, batch, min_batch):
     assert np.isnan(want[18]["threshold"]) and np.isnan(want[19]["threshold"]) and np.isfinite(want[20]["threshold"])
 
 
+def test_queue_at_a_width_that_is_not_a_multiple_of_64(oracle):
+    """328 x 200: the staging pitch (384) differs from the caller's stride, so the rows are staged one by one; the reference's
+    sequence on the oracle frame by frame (synchronous calls), then the same frames through a queue of depth 6 in batches."""
+    from vision_slam_frontend_amd import capi, frontend, synth
+    sc = synth.Scene(328, 200, n_objects=300)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(7)]
+    ctx, calib, sizes = _follow_reference_sequence(oracle, frames, 328, 200, 500, 2)
+    ctx.close()
+    assert min(sizes) > 10
+    bp = float(np.float32(0.3))
+    with capi.Context(capi.default_params(328, 200, max_images=2, nfeatures=500)) as sync_ctx:
+        want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=2) for l, r in frames]
+    padded = [tuple(np.ascontiguousarray(np.pad(im, ((0, 0), (0, 24))))[:, :328] for im in fr) for fr in frames]  # stride 352
+    with capi.Context(capi.default_params(328, 200, max_images=8, nfeatures=500)) as q:
+        q.observe_configure(6, 3, 0)
+        tickets = [q.observe_submit(l, r, calib, best_percent=bp, frame_life=2) for l, r in padded[:6]]
+        got = [q.observe_collect(t, frame_life=2) for t in tickets]
+        got.append(q.observe_stereo(*padded[6], calib, best_percent=bp, frame_life=2))
+    for g, w in zip(got, want):
+        _same_observation(w, g)
+
+
 def test_a_batch_is_cut_where_the_parameters_change():
     """Frames that wait with another best_percent or another calibration than the frame in front of them never share its
     batch; results equal the synchronous calls with the same per-frame parameters."""

@@ -28,7 +28,11 @@ int main(int argc, char** argv) {
   }
   std::fclose(f);
   std::vector<int> nfs;
-  for (int i = 5; i < argc; i++) nfs.push_back(std::atoi(argv[i]));
+  std::vector<std::string> only;  // "+name": run only the modes whose name contains it
+  for (int i = 5; i < argc; i++) {
+    if (argv[i][0] == '+') only.push_back(argv[i] + 1);
+    else nfs.push_back(std::atoi(argv[i]));
+  }
   if (nfs.empty()) nfs = {2000, 10000};
   std::printf("{\"what\": \"slam::Frontend::ObserveImage from C++, %dx%d, frame_life 10 (tools/time_frontend.cc)\", \"results\": {", W, H);
   bool first = true;
@@ -46,6 +50,11 @@ int main(int argc, char** argv) {
                           {"queued_d256_b128_no_thread", true, true, 3232, 256, 128, 0, 0, 0},
                           {"queued", true, true, 3232, 0, 0, 0, 0}};
     for (const Mode& m : modes) {
+      if (!only.empty()) {
+        bool hit = false;
+        for (const std::string& o : only) hit = hit || std::string(m.name).find(o) != std::string::npos;
+        if (!hit) continue;
+      }
       slam::FrontendConfig cfg;
       cfg.orb_nfeatures = nf;
       cfg.image_width = W;

@@ -169,6 +169,106 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const vsf_keypoint* 
   }
 }
 
+// ---- RemoveAmbigStereo of ONE frame as one launch (the synchronous ObserveImage: a batch of one): the three steps above
+// back to back in one workgroup -- residuals into LDS, the ordered mean and the threshold hand-over by one thread, the
+// filter -- with the same float operations in the same order; two dependent launches (~5 us each) fewer in a chain that is
+// nothing but launch latencies.  thr_state: the threshold in force before the frame, advanced to mean + 2 (cc:392-394). ----
+__global__ __launch_bounds__(256) void stereo_one_frame_kernel(const vsf_keypoint* __restrict__ kp,
+                                                               const uint8_t* __restrict__ desc,
+                                                               const vsf_dmatch* __restrict__ matches,
+                                                               const int32_t* __restrict__ nmatches, int max_rows, VsfF9 Fv,
+                                                               int order, float* __restrict__ mean, float* __restrict__ thr,
+                                                               float* __restrict__ thr_state,
+                                                               vsf_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                               int32_t* __restrict__ counts_out,
+                                                               const int32_t* __restrict__ out_sets,
+                                                               int32_t* __restrict__ set_counts) {
+  extern __shared__ __attribute__((aligned(16))) float s_res[];
+  __shared__ int wsum[4];
+  __shared__ int s_base;
+  __shared__ float s_thr;
+  const int n = min(nmatches[0], max_rows);
+  const vsf_keypoint* left = kp;
+  const vsf_keypoint* right = kp + (size_t)max_rows;
+  float Fm[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Fm[i] = Fv.v[i];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const vsf_dmatch dm = matches[i];
+    const float lx = left[dm.queryIdx].x, ly = left[dm.queryIdx].y;
+    const float rx = right[dm.trainIdx].x, ry = right[dm.trainIdx].y;
+    float t[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[j] = dot3(order, lx, Fm[0 * 3 + j], ly, Fm[1 * 3 + j], 1.0f, Fm[2 * 3 + j]);
+    s_res[i] = fabsf(dot3(order, t[0], rx, t[1], ry, t[2], 1.0f));
+  }
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float avg = 0.0f;  // avg_constraint += constraint, in match order
+    int i = 0;
+#pragma unroll 4
+    for (; i + 4 <= n; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(s_res + i);
+      avg += v.x;
+      avg += v.y;
+      avg += v.z;
+      avg += v.w;
+    }
+    for (; i < n; i++) avg += s_res[i];
+    const float m = n > 0 ? avg / (float)n : __uint_as_float(0xFFC00000u);  // (the reference's 0.0f / 0: see above)
+    mean[0] = m;
+    const float th = *thr_state;
+    thr[0] = th;
+    *thr_state = m + 2.0f;
+    s_thr = th;
+  }
+  __syncthreads();
+  const float th = s_thr;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const size_t L = 0, R = (size_t)max_rows;
+  const size_t DL = out_sets ? (size_t)out_sets[0] * max_rows : L, DR = out_sets ? (size_t)out_sets[1] * max_rows : R;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    bool keep = false;
+    vsf_dmatch dm{0, 0, 0, 0.f};
+    if (i < n) {
+      dm = matches[i];
+      keep = s_res[i] <= th;
+    }
+    const uint64_t b = __ballot(keep);
+    const int within = __popcll(b & ((1ull << lane) - 1));
+    if (lane == 0) wsum[wid] = __popcll(b);
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wid; w++) base += wsum[w];
+    if (keep) {
+      const int o = base + within;
+      kp_out[L + o] = kp[L + dm.queryIdx];
+      kp_out[R + o] = kp[R + dm.trainIdx];
+      const uint4* ls = reinterpret_cast<const uint4*>(desc + (L + dm.queryIdx) * VSF_DESC_BYTES);
+      const uint4* rs = reinterpret_cast<const uint4*>(desc + (R + dm.trainIdx) * VSF_DESC_BYTES);
+      uint4* ld = reinterpret_cast<uint4*>(desc_out + (DL + o) * VSF_DESC_BYTES);
+      uint4* rd = reinterpret_cast<uint4*>(desc_out + (DR + o) * VSF_DESC_BYTES);
+      ld[0] = ls[0];
+      ld[1] = ls[1];
+      rd[0] = rs[0];
+      rd[1] = rs[1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counts_out[0] = s_base;
+    counts_out[1] = s_base;
+    if (out_sets) {
+      set_counts[out_sets[0]] = s_base;
+      set_counts[out_sets[1]] = s_base;
+    }
+  }
+}
+
 // ---- GetFeatureMatches: std::sort by distance + cut to int(n * best_percent) ----
 struct SortKey {
   uint32_t dist;  // Hamming distance (DMatch::distance is (float)int, so the order is the integers')
@@ -532,6 +632,20 @@ void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_de
                                    int32_t* d_counts_out, hipStream_t s, const int32_t* d_out_sets, int32_t* d_set_counts) {
   hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, s, d_kp, d_desc, d_matches, d_nmatches,
                      max_rows, d_residual, d_thr, d_kp_out, d_desc_out, d_counts_out, d_out_sets, d_set_counts);
+}
+
+bool vsf_launch_stereo_one_frame(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
+                                 const int32_t* d_nmatches, int max_rows, const float* h_F, int order, float* d_mean,
+                                 float* d_thr, float* d_thr_state, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
+                                 int32_t* d_counts_out, const int32_t* d_out_sets, int32_t* d_set_counts, hipStream_t s) {
+  if (max_rows > 16000) return false;  // (64 KB of LDS without asking for more: the three launches take such a frame)
+  VsfF9 fv;
+  for (int i = 0; i < 9; i++) fv.v[i] = h_F[i];
+  const int lds_rows = (max_rows + 3) & ~3;
+  hipLaunchKernelGGL(stereo_one_frame_kernel, dim3(1), dim3(256), (size_t)lds_rows * sizeof(float), s, d_kp, d_desc, d_matches,
+                     d_nmatches, max_rows, fv, order, d_mean, d_thr, d_thr_state, d_kp_out, d_desc_out, d_counts_out, d_out_sets,
+                     d_set_counts);
+  return true;
 }
 
 void vsf_launch_stereo_filter(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,

@@ -310,22 +310,27 @@ __global__ __launch_bounds__(256) void ratio_compact_kernel(const int32_t* __res
 
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                     hipStream_t s) {
+                     hipStream_t s, int rows_hint) {
   const int qtiles = (max_rows + kWgQueries - 1) / kWgQueries;
   // A batch of 128 stereo pairs brings ~2000 workgroups, two full rounds of the chip at four workgroups per CU, and runs
   // unsplit; with fewer (one pair of one frame at a time) the train sets are split until about that many workgroups exist
   // (each at least eight 32-row tiles) and merged through the packed key pairs.
+  // rows_hint (0: unknown): how many rows the sets are EXPECTED to hold -- the capacity max_rows says nothing about a
+  // filtered frame of a few hundred features, whose whole train set is a handful of tiles: no split, and with it no memset in
+  // front and no finalize launch behind (a wrong hint costs time, never a result).
+  const int rows = rows_hint > 0 ? std::min(rows_hint, max_rows) : max_rows;
+  const int qtiles_full = (rows + kWgQueries - 1) / kWgQueries;
   int nsplit = 1;
-  if ((long)qtiles * n_pairs < 2 * 768) nsplit = (int)std::min<long>(32, 2 * 1024 / ((long)qtiles * n_pairs));
-  nsplit = std::max(1, std::min(nsplit, max_rows / (2 * kSplitAlign)));
+  if ((long)qtiles_full * n_pairs < 2 * 768) nsplit = (int)std::min<long>(32, 2 * 1024 / ((long)qtiles_full * n_pairs));
+  nsplit = std::max(1, std::min(nsplit, rows / (2 * kSplitAlign)));
   if (nsplit <= 1) {
     hipLaunchKernelGGL(knn2_fp4_kernel<false>, dim3(qtiles, n_pairs, 1), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                         d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
     return;
   }
   vsf_note(hipMemsetAsync(d_dist2, 0xFF, (size_t)n_pairs * max_rows * 2 * sizeof(int32_t), s));
   hipLaunchKernelGGL(knn2_fp4_kernel<true>, dim3(qtiles, n_pairs, nsplit), dim3(256), 0, s, d_desc, d_counts, set_stride,
-                       d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
+                     d_q_set, d_t_set, max_rows, d_idx2, d_dist2);
   hipLaunchKernelGGL(knn2_finalize_kernel, dim3((max_rows + 255) / 256, n_pairs, 1), dim3(256), 0, s, d_counts, d_q_set,
                      max_rows, d_idx2, d_dist2);
 }

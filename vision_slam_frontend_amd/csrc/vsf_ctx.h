@@ -180,6 +180,7 @@ struct vsf_ctx {
     int64_t next_collect = 0;  // oldest frame not collected
     int64_t batches = 0;       // batches launched
     int64_t last_submit_ns = 0;  // when the last frame arrived
+    int rows_hint = 0;           // expected rows of a filtered frame (from the collected results; 0: unknown)
     int last_batch = -1;       // slot of the batch launched last
     int64_t stat_frames = 0, stat_max_batch = 0, stat_solo = 0, stat_forced = 0, stat_slot_waits = 0;  // vsf_observe_stats
     int64_t stat_copy_ns = 0, stat_launch_ns = 0, stat_wait_ns = 0;  // host time in staging copies, launches, waits

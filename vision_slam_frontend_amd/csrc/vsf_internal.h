@@ -192,7 +192,7 @@ void vsf_launch_fast_emit(const VsfDev& d, const VsfGeom& g, int n_images, int m
                           int32_t* d_counts, hipStream_t s);
 void vsf_launch_knn2(const uint8_t* d_desc, const int32_t* d_counts, size_t set_stride, const int32_t* d_q_set,
                      const int32_t* d_t_set, int n_pairs, int max_rows, int32_t* d_idx2, int32_t* d_dist2,
-                     hipStream_t s);
+                     hipStream_t s, int rows_hint = 0);  // rows_hint: expected rows per set (0: unknown), speed only
 void vsf_launch_ratio_compact(const int32_t* d_counts, const int32_t* d_q_set, const int32_t* d_t_set, int n_pairs,
                               int max_rows, const int32_t* d_idx2, const int32_t* d_dist2, uint32_t ratio_num,
                               uint32_t ratio_shift, vsf_dmatch* d_matches, int32_t* d_nmatches, int32_t* d_status,
@@ -215,6 +215,12 @@ void vsf_launch_stereo_filter_only(const vsf_keypoint* d_kp, const uint8_t* d_de
                                    const float* d_thr, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
                                    int32_t* d_counts_out, hipStream_t s, const int32_t* d_out_sets = nullptr,
                                    int32_t* d_set_counts = nullptr);
+// RemoveAmbigStereo of one frame in one launch (residuals, ordered mean, threshold hand-over through *d_thr_state, filter);
+// false: the frame's capacity does not fit the kernel's LDS and nothing was launched.
+bool vsf_launch_stereo_one_frame(const vsf_keypoint* d_kp, const uint8_t* d_desc, const vsf_dmatch* d_matches,
+                                 const int32_t* d_nmatches, int max_rows, const float* h_F, int order, float* d_mean,
+                                 float* d_thr, float* d_thr_state, vsf_keypoint* d_kp_out, uint8_t* d_desc_out,
+                                 int32_t* d_counts_out, const int32_t* d_out_sets, int32_t* d_set_counts, hipStream_t s);
 // k_points.hip (SURVEY 8(f) row f2 + the compact gather payload)
 void vsf_launch_stereo_thresholds(const float* d_means, int n, float* d_state, float* d_thr, hipStream_t s);
 void vsf_launch_fill_stereo_sets(int32_t* d_sets, int n_frames, hipStream_t s);  // [0..n): 2f + 1, [n..2n): 2f

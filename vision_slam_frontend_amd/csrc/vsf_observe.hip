@@ -329,16 +329,23 @@ vsf_status launch_batch(vsf_ctx* ctx, int64_t t0, int n, bool solo) {
   int32_t *counts_f = o.ints, *nfeat = o.ints + 2 * o.bmax, *npoints = o.ints + 3 * o.bmax;
   {
     StageTimer t(ctx, s_tail, VSF_STAGE_TAIL, 3);
-    vsf_launch_stereo_residuals(b.kp_raw, b.matches, b.nmatches, n, Kc, nullptr, f0.calib.fundamental, ctx->p.residual_order,
-                                o.residual, means, s_tail);
-    vsf_launch_stereo_thresholds(means, n, thr_state, thr, s_tail);
-    vsf_launch_stereo_filter_only(b.kp_raw, b.desc_raw, b.matches, b.nmatches, n, Kc, o.residual, thr, o.kpf, o.sets, counts_f,
-                                  s_tail, M.out_sets, o.set_counts);
+    // (a lone frame: the three steps in one launch)
+    if (n != 1 || !vsf_launch_stereo_one_frame(b.kp_raw, b.desc_raw, b.matches, b.nmatches, Kc, f0.calib.fundamental,
+                                               ctx->p.residual_order, means, thr, thr_state, o.kpf, o.sets, counts_f,
+                                               M.out_sets, o.set_counts, s_tail)) {
+      vsf_launch_stereo_residuals(b.kp_raw, b.matches, b.nmatches, n, Kc, nullptr, f0.calib.fundamental, ctx->p.residual_order,
+                                  o.residual, means, s_tail);
+      vsf_launch_stereo_thresholds(means, n, thr_state, thr, s_tail);
+      vsf_launch_stereo_filter_only(b.kp_raw, b.desc_raw, b.matches, b.nmatches, n, Kc, o.residual, thr, o.kpf, o.sets,
+                                    counts_f, s_tail, M.out_sets, o.set_counts);
+    }
   }
   // ---- every GetFeatureMatches of the batch: one matcher launch, one sort launch (per-pair best_percent) ----
   {
     StageTimer t(ctx, s_tail, VSF_STAGE_KNN2, 1);
-    vsf_launch_knn2(o.sets, o.set_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, o.t_idx2, o.t_dist2, s_tail);
+    // (rows_hint: what the caller's last collected frames held -- a filtered frame is a few hundred rows of the capacity)
+    vsf_launch_knn2(o.sets, o.set_counts, K * VSF_DESC_BYTES, M.q_set, M.t_set, n_pairs, Kc, o.t_idx2, o.t_dist2, s_tail,
+                    o.rows_hint);
   }
   {
     StageTimer t(ctx, s_tail, VSF_STAGE_RATIO, 1);
@@ -619,6 +626,8 @@ static vsf_status observe_wait(vsf_ctx* ctx, int64_t ticket, const uint8_t** vie
   }
   if (hdr[0] != 0x4F465356u) return VSF_ERR_HIP;
   const_cast<uint32_t*>(hdr)[0] = 0;  // (the slot's next frame must write its own)
+  // the filtered frames' size, for the matcher's launch choice: the largest of the last few frames with room to grow
+  o.rows_hint = std::max((int)hdr[2] * 2 + 64, o.rows_hint - o.rows_hint / 8);
   *view = res;
   *bytes = hdr[3];
   if (st != VSF_OK) return st;
