@@ -1039,7 +1039,8 @@ def main() -> int:
         # features, configs[4] = a temporal window of 8 frames (the multi-query matcher launch).
         out["other_configs"] = None
         report_stage("other configs")
-        if world == 1 and not args.no_other_configs and args.config == "vga" and args.window == 1 and args.ingest == "hbm":
+        if (world == 1 and not args.no_other_configs and args.config == "vga" and args.window == 1 and args.ingest == "hbm"
+                and args.nfeatures is None and args.batch is None):
             other = {}
             for name, extra in (("1080p_8000", ["--config", "1080p", "--batch", "64"]), ("window8", ["--window", "8"])):
                 cmd = [sys.executable, str(ROOT / "bench.py"), "--leg", "--steps", "8", "--warmup", "2", "--tune-steps", "4"] + extra
