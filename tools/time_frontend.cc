@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../vision_slam_frontend_amd/host/slam_frontend.h"
@@ -29,8 +30,12 @@ int main(int argc, char** argv) {
   std::fclose(f);
   std::vector<int> nfs;
   std::vector<std::string> only;  // "+name": run only the modes whose name contains it
+  std::vector<std::pair<int, int>> opts;  // "@option=value": a vsf_option for every context (experiments)
   for (int i = 5; i < argc; i++) {
-    if (argv[i][0] == '+') only.push_back(argv[i] + 1);
+    if (argv[i][0] == '@') {
+      int o = 0, v = 0;
+      if (std::sscanf(argv[i] + 1, "%d=%d", &o, &v) == 2) opts.push_back({o, v});
+    } else if (argv[i][0] == '+') only.push_back(argv[i] + 1);
     else nfs.push_back(std::atoi(argv[i]));
   }
   if (nfs.empty()) nfs = {2000, 10000};
@@ -69,6 +74,7 @@ int main(int argc, char** argv) {
       fe.set_min_batch(m.min_batch);
       fe.set_queue_thread(m.thread != 0);
       fe.set_context_option(VSF_OPT_PYRAMID_TAIL_MIN, m.tail_min);
+      for (const auto& ov : opts) fe.set_context_option(ov.first, ov.second);
       const slam::Quaternionf q(1, 0, 0, 0);
       fe.ObserveOdometry(slam::Vector3f(0, 0, 0), q, 0.0);
       const int warm = 32;
