@@ -173,7 +173,9 @@ typedef enum {
                                 * frames, the thread sends the batches; 0: the caller launches too.  Read when the queue is built */
   VSF_OPT_PYRAMID_TAIL_MIN = 9, /* smallest batch (images) whose one-band pyramid levels are one launch (a workgroup per image)
                                  * even when that fills less than three quarters of the chip; 0: never */
-  VSF_OPT_COUNT = 10
+  VSF_OPT_OBSERVE_COPY_THREAD = 10, /* 1 (default): while frames stream into an ObserveImage queue of depth >= 4 a second host thread
+                                     * takes the right image's staging copy; 0: the caller copies both.  Read when the queue is built */
+  VSF_OPT_COUNT = 11
 } vsf_option;
 vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value);
 vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value);

@@ -41,7 +41,7 @@ EXPORTS = [
 ]
 # vsf_option (include/vsf.h)
 (OPT_FAST_BOTH_MAX, OPT_SELECT_WIDE, OPT_PYRAMID_FEW, OPT_PYRAMID_CHAIN, OPT_PYRAMID_ROWS, OPT_SELECT_BIG_CLASS,
- OPT_PIPE_AFTER_FAST, OPT_PIPE_PRIORITY, OPT_OBSERVE_THREAD, OPT_PYRAMID_TAIL_MIN) = range(10)
+ OPT_PIPE_AFTER_FAST, OPT_PIPE_PRIORITY, OPT_OBSERVE_THREAD, OPT_PYRAMID_TAIL_MIN, OPT_OBSERVE_COPY_THREAD) = range(11)
 STAGE_COUNT = 8
 
 

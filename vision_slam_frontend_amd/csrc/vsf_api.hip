@@ -684,6 +684,7 @@ vsf_status vsf_set_option(vsf_ctx* ctx, int option, int value) {
     case VSF_OPT_SELECT_BIG_CLASS: t.select_big_class = value != 0; break;
     case VSF_OPT_PIPE_AFTER_FAST: t.pipe_after_fast = value != 0; break;
     case VSF_OPT_OBSERVE_THREAD: t.observe_thread = value != 0; break;  // (read when the queue is built)
+    case VSF_OPT_OBSERVE_COPY_THREAD: t.observe_copy_thread = value != 0; break;
     case VSF_OPT_PIPE_PRIORITY:
       if (value < -1 || value > 1) return VSF_ERR_INVALID_ARG;
       t.pipe_priority = value;  // (takes effect with the next vsf_set_pipeline(ctx, 1))
@@ -719,6 +720,7 @@ vsf_status vsf_get_option(const vsf_ctx* ctx, int option, int* value) {
     case VSF_OPT_SELECT_BIG_CLASS: *value = t.select_big_class; break;
     case VSF_OPT_PIPE_AFTER_FAST: *value = t.pipe_after_fast; break;
     case VSF_OPT_OBSERVE_THREAD: *value = t.observe_thread; break;
+    case VSF_OPT_OBSERVE_COPY_THREAD: *value = t.observe_copy_thread; break;
     case VSF_OPT_PIPE_PRIORITY: *value = t.pipe_priority; break;
     case VSF_OPT_PYRAMID_FEW: *value = t.pyramid_few; break;
     case VSF_OPT_PYRAMID_CHAIN: *value = t.pyramid_chain; break;

@@ -126,6 +126,7 @@ struct vsf_ctx {
   // The ObserveImage queue (vsf_observe.hip): frames wait in pinned staging and leave for the GPU in batches.
   static constexpr int kObserveBatchSlots = 4;
   struct ObserveLauncher;    // the queue's lock and its launcher thread
+  struct ObserveCopyHelper;  // a host thread that takes half of a frame's staging copy while frames stream in
   struct ObserveBatchMeta;  // pinned, device-visible: read by the kernels over PCIe (no copy command)
   struct ObserveBatch {     // what one batch's extraction writes and its tail reads
     uint8_t* d_img = nullptr;        // [2 bmax] images at the staging pitch
@@ -175,6 +176,7 @@ struct vsf_ctx {
     std::vector<ObserveFrame> frames;  // [depth]
     hipStream_t copy_stream = nullptr, tail_stream = nullptr;
     ObserveLauncher* launcher = nullptr;
+    ObserveCopyHelper* copy_helper = nullptr;
     int64_t next_ticket = 0;   // tickets issued
     int64_t next_launch = 0;   // first frame still waiting in staging
     int64_t next_collect = 0;  // oldest frame not collected

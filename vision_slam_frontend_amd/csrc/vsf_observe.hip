@@ -35,10 +35,8 @@
 
 using namespace vsfi;
 
-// One row-wise copy of an image into the staging ring (rows at the device pitch): 5-7 us per 640x480 image on one core.
-// (Measured and left out: a second thread that takes the right image while frames stream in -- the copy's share drops from
-// 13 to 7 us per frame and the frame rate does not move: with the launches on their own thread the GPU is what the caller
-// waits for.)
+// One row-wise copy of an image into the staging ring (rows at the device pitch): 5-12 us per 640x480 image on one core,
+// depending on the host (its memory, its neighbours).
 static void stage_image(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t width, int rows) {
   if (dst_pitch == src_pitch) {
     std::memcpy(dst, src, (size_t)(rows - 1) * src_pitch + width);
@@ -46,6 +44,78 @@ static void stage_image(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size
     for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * dst_pitch, src + (size_t)y * src_pitch, width);
   }
 }
+
+// The staging copy is what a queued frame costs its caller once the launches have a thread of their own: 13 us per frame on
+// one box, 23 us on another (the same run: 31.5 k and 28.9 k frames/s -- on the second the caller never waits for the GPU).
+// While frames stream in (the previous one is still in the queue) a helper thread takes the right image: it spins for a job
+// while it is hot and goes to sleep 300 us after the last one, so a caller that submits and collects frame by frame never
+// meets it (a wake-up costs more than the copy saves).  It touches host memory only: no HIP call, no context state.
+struct vsf_ctx::ObserveCopyHelper {
+  struct Job {
+    uint8_t* dst;
+    const uint8_t* src;
+    size_t dst_pitch, src_pitch, width;
+    int rows;
+  };
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<int> state{0};  // 0 no job, 1 job posted, 2 job done
+  std::atomic<bool> hot{false}, stop{false};
+  bool wake = false;
+  Job job{};
+  ObserveCopyHelper() { th = std::thread([this] { run(); }); }
+  ~ObserveCopyHelper() {
+    {
+      std::lock_guard<std::mutex> g(m);
+      stop.store(true);
+    }
+    cv.notify_all();
+    th.join();
+  }
+  void run() {
+    using Clock = std::chrono::steady_clock;
+    while (!stop.load(std::memory_order_acquire)) {
+      hot.store(true, std::memory_order_release);
+      Clock::time_point last = Clock::now();
+      while (!stop.load(std::memory_order_relaxed)) {
+        if (state.load(std::memory_order_acquire) == 1) {
+          stage_image(job.dst, job.dst_pitch, job.src, job.src_pitch, job.width, job.rows);
+          state.store(2, std::memory_order_release);
+          last = Clock::now();
+        } else {
+          __builtin_ia32_pause();
+          if (Clock::now() - last > std::chrono::microseconds(300)) break;
+        }
+      }
+      hot.store(false, std::memory_order_release);
+      std::unique_lock<std::mutex> g(m);
+      // (a job posted between the last look and `hot = false` is still served: the wait's predicate sees it)
+      cv.wait(g, [this] { return stop.load() || wake || state.load(std::memory_order_acquire) == 1; });
+      wake = false;
+    }
+  }
+  // true: the helper took `j` (wait() must follow); false: it sleeps -- woken for the frames behind this one -- and the
+  // caller copies `j` itself.
+  bool post(const Job& j) {
+    if (!hot.load(std::memory_order_acquire)) {
+      {
+        std::lock_guard<std::mutex> g(m);
+        wake = true;
+      }
+      cv.notify_one();
+      return false;
+    }
+    job = j;
+    state.store(1, std::memory_order_release);
+    if (!hot.load(std::memory_order_acquire)) cv.notify_one();  // (it was on its way to sleep: the predicate serves the job)
+    return true;
+  }
+  void wait() {
+    while (state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+    state.store(0, std::memory_order_relaxed);
+  }
+};
 
 // Who launches.  A batch costs the host 0.1 ms (a lone frame) to 0.3 ms (the batched pyramid alone is 50-100 launches):
 // on the caller's thread that was a third of what a queued frame cost.  A queue of depth >= 4 therefore has a LAUNCHER
@@ -114,6 +184,8 @@ void stop_observe_threads(vsf_ctx* ctx) {
     o.launcher->th.join();
     o.launcher->has_thread = false;
   }
+  delete o.copy_helper;
+  o.copy_helper = nullptr;
 }
 
 void free_observe(vsf_ctx* ctx) {
@@ -230,7 +302,9 @@ vsf_status ensure_observe(vsf_ctx* ctx, int frame_life) {
   o.launcher = new (std::nothrow) vsf_ctx::ObserveLauncher();
   if (!o.launcher) return VSF_ERR_INVALID_ARG;
   o.ready = true;
-  // the launcher thread of a deep queue (VSF_OPT_OBSERVE_THREAD; without it the caller launches everything)
+  // the two host threads of a deep queue: VSF_OPT_OBSERVE_THREAD (without it the caller launches everything) and
+  // VSF_OPT_OBSERVE_COPY_THREAD (without it the caller stages both images)
+  if (o.depth >= 4 && ctx->tuning.observe_copy_thread) o.copy_helper = new (std::nothrow) vsf_ctx::ObserveCopyHelper();
   if (o.depth >= 4 && ctx->tuning.observe_thread) {
     o.launcher->has_thread = true;
     o.launcher->th = std::thread(launcher_thread, ctx);
@@ -571,8 +645,14 @@ vsf_status vsf_observe_submit(vsf_ctx* ctx, const uint8_t* left, const uint8_t* 
   // frame has been collected: its upload is long done) ----
   uint8_t* h_img = o.h_img + (size_t)slot * 2 * ctx->st_img_stride;
   const int64_t t_copy = now_ns();
+  const vsf_ctx::ObserveCopyHelper::Job jr{h_img + ctx->st_img_stride, right, ctx->st_img_pitch, stride, (size_t)w, h};
+  // frames are streaming in (the previous one is still in the queue): the helper thread takes the right image
+  const bool helped = o.copy_helper && o.next_ticket > o.next_collect && o.copy_helper->post(jr);
   stage_image(h_img, ctx->st_img_pitch, left, stride, (size_t)w, h);
-  stage_image(h_img + ctx->st_img_stride, ctx->st_img_pitch, right, stride, (size_t)w, h);
+  if (helped)
+    o.copy_helper->wait();
+  else
+    stage_image(jr.dst, jr.dst_pitch, jr.src, jr.src_pitch, jr.width, jr.rows);
   o.stat_copy_ns += now_ns() - t_copy;
   vsf_ctx::ObserveFrame& fr = o.frames[(size_t)slot];
   fr.calib = *calib;

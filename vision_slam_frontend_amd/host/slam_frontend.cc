@@ -264,6 +264,7 @@ bool Frontend::EnsureContext(int width, int height) {
   if (last_status_ != VSF_OK) return false;
   ctx_depth_ = queue_depth();
   last_status_ = vsf_set_option(ctx_, VSF_OPT_OBSERVE_THREAD, queue_thread_ ? 1 : 0);
+  if (last_status_ == VSF_OK) last_status_ = vsf_set_option(ctx_, VSF_OPT_OBSERVE_COPY_THREAD, copy_thread_ ? 1 : 0);
   for (const auto& ov : ctx_options_)
     if (last_status_ == VSF_OK) last_status_ = vsf_set_option(ctx_, ov.first, ov.second);
   if (last_status_ == VSF_OK) last_status_ = vsf_observe_configure(ctx_, ctx_depth_, min_batch_, 0);

@@ -153,8 +153,10 @@ class Frontend {
   // While the GPU is busy, fewer waiting frames than this stay in the queue (0 / 1: whatever waits leaves as soon as fewer
   // than two batches are on the GPU).
   void set_min_batch(int n) { min_batch_ = n < 0 ? 0 : n; }
-  // The queue's launcher thread (VSF_OPT_OBSERVE_THREAD; default on).
+  // The queue's host threads: the launcher (VSF_OPT_OBSERVE_THREAD) and the staging-copy helper
+  // (VSF_OPT_OBSERVE_COPY_THREAD); both on by default.
   void set_queue_thread(bool on) { queue_thread_ = on; }
+  void set_copy_thread(bool on) { copy_thread_ = on; }
   // Any vsf_option of the context (applied when it is created): launch choices only, results never depend on them.
   void set_context_option(int option, int value) { ctx_options_.push_back({option, value}); }
   // vsf_observe_stats of the context (frames, batches, largest batch, ...): how the queue coalesced.
@@ -217,7 +219,7 @@ class Frontend {
   bool fused_;
   bool pipelined_;
   int depth_ = 256, batch_frames_ = 128, min_batch_ = 0;
-  bool queue_thread_ = true;
+  bool queue_thread_ = true, copy_thread_ = true;
   std::vector<std::pair<int, int>> ctx_options_;
   std::vector<PendingFrame> pending_;  // a ring: pending_head_ is the oldest, pending_count_ frames wait
   size_t pending_head_ = 0, pending_count_ = 0;
