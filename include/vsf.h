@@ -372,11 +372,15 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
  * decided (cc:404-409), so nothing in the reference's control flow needs a frame's result before the next frame arrives: a
  * caller may keep up to `depth` frames submitted and not collected.  Frames that wait are COALESCED: they leave for the GPU
  * as one batched extraction + one batched tail (the threshold chain and the temporal window run through the batch in frame
- * order) -- a frame's chain of ~30 launch-bound kernels costs the same whether it carries one frame or thirty.  A batch
- * leaves when the GPU is idle (a lone frame at once: the synchronous call is a batch of one), when `min_batch` frames wait
- * and fewer than `in_flight` batches are on the GPU, when a full batch (max_images / 2 frames, at most `depth`) waits, or
- * when a waiting frame is collected; while the GPU is busy frames accumulate, so the batch size follows the caller's rate.  Results are those of one frame at a time, bit
- * for bit, whatever the batches were (tests/test_gpu_observe.py).
+ * order) -- a frame's chain of ~25 launch-bound kernels costs the same whether it carries one frame or thirty.  A batch
+ * leaves: when the GPU is idle and no frame has arrived for 100 us (a lone frame whose caller collects it leaves at once: the
+ * synchronous call is a batch of one); when `min_batch` frames wait and fewer than `in_flight` batches are on the GPU; when
+ * a full batch (max_images / 2 frames, at most `depth`) waits; or when a waiting frame is collected.  While the GPU is busy
+ * or frames keep arriving, frames accumulate: the batch size follows the caller's rate.  Results are those of one frame at
+ * a time, bit for bit, whatever the batches were (tests/test_gpu_observe.py).  A queue of depth >= 4 owns two host threads
+ * (VSF_OPT_OBSERVE_THREAD: the launcher, so that the caller only stages and collects; VSF_OPT_OBSERVE_COPY_THREAD: half of a
+ * streaming frame's staging copy); every other entry point of the context first sends what waits in the queue, so nothing
+ * ever runs beside the launcher.
  * Tickets are collected in the order they were issued; a submit beyond `depth` uncollected frames returns
  * VSF_ERR_INVALID_ARG.  Consecutive frames with different calibrations or best_percent never share a batch; frame_life
  * changes only while the queue is empty (the window starts over).
@@ -407,6 +411,9 @@ vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_
 /* The same without the copy: *out points at the result inside the context's pinned result ring; it stays valid until `depth`
  * further frames have been submitted (the first word, the magic, reads 0 there). */
 vsf_status vsf_observe_collect_view(vsf_ctx* ctx, int64_t ticket, const uint8_t** out, size_t* out_bytes);
+/* Does not wait and sends nothing: *ready = 1 when the frame's result is there (its collect will not wait), 0 while it still
+ * waits in staging or is on the GPU.  What a caller that books results as they come asks before each collect. */
+vsf_status vsf_observe_poll(vsf_ctx* ctx, int64_t ticket, int* ready);
 vsf_status vsf_observe_reset(vsf_ctx* ctx);
 /* What the queue did since it was built: out[0..n) of { frames launched, batches, largest batch, batches of one frame that
  * ran on one stream, launches forced by a collect or a change of parameters, launches that had to wait for a batch slot,

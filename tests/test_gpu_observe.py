@@ -331,6 +331,33 @@ def test_other_entry_points_beside_a_queue_with_its_launcher_thread():
         ctx.close()  # frames waiting in staging, in flight and uncollected; the launcher thread possibly in a launch
 
 
+def test_a_waiting_frame_leaves_by_itself_and_poll_does_not_wait():
+    """A queue with a launcher thread: a lone frame nobody collects leaves once no frame has arrived for 100 us (an idle GPU
+    takes what waits), and vsf_observe_poll -- which neither waits nor sends anything -- reports it finished a moment later;
+    the collect then finds the synchronous call's bytes."""
+    import time
+    from vision_slam_frontend_amd import capi, frontend
+    frames = _sequence(3)
+    calib = frontend.default_calibration().set("fundamental", F_RECT)
+    bp = float(np.float32(0.3))
+    with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
+        want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
+    with capi.Context(capi.default_params(320, 240, max_images=16, nfeatures=NF)) as ctx:
+        ctx.observe_configure(16, 8, 0)  # (eight frames would have to wait for a busy GPU to take them)
+        got = []
+        for l, r in frames:
+            t = ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE)
+            t0 = time.perf_counter()
+            while not ctx.observe_poll(t):
+                assert time.perf_counter() - t0 < 5.0, "the frame never left the queue"
+                time.sleep(0.0002)
+            got.append(ctx.observe_collect(t, frame_life=LIFE))
+        with pytest.raises(capi.VsfError):
+            ctx.observe_poll(t)  # collected
+    for g, w in zip(got, want):
+        _same_observation(w, g)
+
+
 def test_destroy_with_frames_still_in_flight():
     """vsf_destroy waits for every stream the context launched on -- the slots' streams of frames that were submitted and never
     collected included -- before it frees what their kernels write (device buffers, the pinned result and status words);

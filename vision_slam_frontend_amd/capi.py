@@ -35,7 +35,7 @@ EXPORTS = [
     "vsf_stage_name", "vsf_debug_retain_best", "vsf_debug_sort_trim", "vsf_stereo_residuals_batch_dev", "vsf_stereo_thresholds_dev",
     "vsf_stereo_filter_batch_dev", "vsf_vision_features_batch_dev", "vsf_packed_outputs_capacity",
     "vsf_pack_outputs_dev", "vsf_observe_capacity", "vsf_observe_stereo", "vsf_observe_submit", "vsf_observe_collect", "vsf_observe_reset",
-    "vsf_observe_configure", "vsf_observe_collect_view", "vsf_observe_stats", "vsf_debug_jpeg_serial",
+    "vsf_observe_configure", "vsf_observe_collect_view", "vsf_observe_stats", "vsf_observe_poll", "vsf_debug_jpeg_serial",
     "vsf_jpeg_decode_gray_batch", "vsf_png_decode_gray_batch", "vsf_imdecode_gray_batch", "vsf_tune_fast_resident", "vsf_set_option", "vsf_get_option", "vsf_debug_inject_hip_error", "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_destroy", "vsf_comm_info",
     "vsf_allgather_dev", "vsf_gather_payload_dev", "vsf_reserve", "vsf_set_input_event",
 ]
@@ -152,6 +152,7 @@ def lib() -> C.CDLL:
         L.vsf_observe_collect_view.argtypes = [vp, C.c_int64, C.POINTER(vp), C.POINTER(sz)]
         L.vsf_observe_configure.argtypes = [vp, i32, i32, i32]
         L.vsf_observe_stats.argtypes = [vp, vp, i32]
+        L.vsf_observe_poll.argtypes = [vp, C.c_int64, C.POINTER(i32)]
         L.vsf_observe_stereo.argtypes = [vp, vp, vp, i32, i32, sz, C.POINTER(VsfCalibration), C.c_float, i32, vp, sz,
                                          C.POINTER(sz)]
         L.vsf_observe_reset.argtypes = [vp]
@@ -467,6 +468,12 @@ class Context:
 
     def observe_reset(self):
         self._check(lib().vsf_observe_reset(self._h), "vsf_observe_reset")
+
+    def observe_poll(self, ticket: int) -> bool:
+        """True when the frame's result is there (vsf_observe_poll: does not wait, sends nothing)."""
+        r = C.c_int(0)
+        self._check(lib().vsf_observe_poll(self._h, C.c_int64(ticket), C.byref(r)), "vsf_observe_poll")
+        return bool(r.value)
 
     def observe_configure(self, depth: int = 0, min_batch: int = 0, in_flight: int = 0):
         """The ObserveImage queue (vsf_observe_configure): frames that may wait uncollected, the fewest waiting frames that

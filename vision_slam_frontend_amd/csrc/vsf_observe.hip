@@ -715,6 +715,30 @@ static vsf_status observe_wait(vsf_ctx* ctx, int64_t ticket, const uint8_t** vie
   return hdr[12] != 0 ? VSF_ERR_CAPACITY : VSF_OK;
 }
 
+vsf_status vsf_observe_poll(vsf_ctx* ctx, int64_t ticket, int* ready) {
+  VsfErrorScope scope_(ctx, false);
+  if (!ctx || !ready) return VSF_ERR_INVALID_ARG;
+  *ready = 0;
+  vsf_ctx::Observe& o = ctx->ob;
+  if (!o.ready || ticket < o.next_collect || ticket >= o.next_ticket) return VSF_ERR_INVALID_ARG;
+  const vsf_ctx::ObserveBatch* b = nullptr;
+  {
+    std::lock_guard<std::mutex> g(o.launcher->mu);
+    if (ticket >= o.next_launch) return o.launcher->status;  // it still waits in staging (nothing is forced)
+    b = &o.batch[o.frames[(size_t)(ticket % o.depth)].batch];
+  }
+  VSF_HIP(hipSetDevice(ctx->device));
+  const hipError_t e = hipEventQuery(b->ev_done);
+  if (e == hipSuccess)
+    *ready = 1;
+  else if (e != hipErrorNotReady) {
+    ctx->last_hip = (int)e;
+    return VSF_ERR_HIP;
+  }
+  (void)hipGetLastError();
+  return VSF_OK;
+}
+
 vsf_status vsf_observe_collect(vsf_ctx* ctx, int64_t ticket, uint8_t* out, size_t cap, size_t* out_bytes) {
   VsfErrorScope scope_(ctx, false);
   if (!ctx || !out || !out_bytes) return VSF_ERR_INVALID_ARG;

@@ -576,6 +576,14 @@ bool Frontend::ObserveImageFused(const Image& left_image, const Image& right_ima
   prev_odom_rotation_ = odom_rotation_;
   prev_odom_translation_ = odom_translation_;
   if (!pipelined_) return RetireOldest();
+  // results that are already there are booked now (no waiting, nothing sent early): at a camera's rate the problem stays a
+  // frame or two behind instead of a queue's depth; when frames stream in faster than the GPU serves them this finds nothing
+  // and the queue fills as before
+  while (pending_count_ > 1) {
+    int ready = 0;
+    if (vsf_observe_poll(ctx_, pending_[pending_head_].ticket, &ready) != VSF_OK || !ready) break;
+    if (!RetireOldest()) return false;
+  }
   return true;
 }
 

@@ -139,8 +139,9 @@ class Frontend {
   // frame's features before the next frame arrives.  With pipelining on (fused mode; choose before the first
   // ObserveImage) a call copies its frame into the GPU context's queue (vsf_observe_submit) and returns; frames that wait
   // there leave for the GPU as ONE batched extraction + tail, and a frame's result is collected and booked -- in frame
-  // order, with the odometry of ITS call -- when the queue is full (queue_depth() frames later) or when anything reads
-  // the problem (GetSLAMProblem, GetNumPoses, the accessors below, Flush).  Same nodes, factors and bytes as the
+  // order, with the odometry of ITS call -- as soon as a later call finds it finished, at the latest when the queue is full
+  // (queue_depth() frames later) or when anything reads the problem (GetSLAMProblem, GetNumPoses, the accessors below,
+  // Flush).  Same nodes, factors and bytes as the
   // synchronous mode; a GPU failure then surfaces in last_status() some calls late.
   void set_pipelined(bool on) { pipelined_ = on; }
   // Frames ObserveImage may leave in the queue when pipelined (1..1024, default 256) and the most frames one batch carries
