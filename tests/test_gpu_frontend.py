@@ -263,3 +263,26 @@ def test_queued_observe_image_books_the_synchronous_problem(depth, batch, min_ba
         assert ia == ic and ka.tobytes() == kc.tobytes()
         np.testing.assert_array_equal(da, dc)
     assert [len(n["features"]) for n in a["nodes"]][21:24] == [0, 0, 0] and len(a["nodes"][24]["features"]) > 20
+
+
+def test_a_queued_frontend_is_destroyed_with_frames_in_its_queue():
+    """~Frontend with frames staged, on the GPU and uncollected (launcher thread and copy helper alive): the context stops its
+    threads, waits for its streams and frees what their kernels write; a Frontend created afterwards works."""
+    from vision_slam_frontend_amd import frontend, synth
+    sc = synth.Scene(320, 240, n_objects=400)
+    frames = [(sc.render(f, 0), sc.render(f, 1)) for f in range(12)]
+    q = np.array([1, 0, 0, 0], np.float32)
+    for depth, batch in ((16, 8), (64, 16), (5, 4)):
+        fe = frontend.Frontend(320, 240, nfeatures=600, fundamental=F_RECT, frame_life=3)
+        fe.set_pipelined(True)
+        fe.set_queue(depth, batch, 0)
+        fe.observe_odometry([0, 0, 0], q, 0.0)
+        for f, (l, r) in enumerate(frames):
+            fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)
+            assert fe.observe_image(l, r) is True
+        fe.close()  # nothing was read: frames are still in the queue
+    fe = frontend.Frontend(320, 240, nfeatures=600, fundamental=F_RECT, frame_life=3)
+    fe.observe_odometry([0, 0, 0], q, 0.0)
+    fe.observe_odometry([0.3, 0, 0], q, 1.0)
+    assert fe.observe_image(*frames[0]) is True and fe.num_poses == 1
+    fe.close()
