@@ -80,11 +80,13 @@ int main(int argc, char** argv) {
       const slam::Quaternionf q(1, 0, 0, 0);
       fe.ObserveOdometry(slam::Vector3f(0, 0, 0), q, 0.0);
       const int warm = 32;
+      const bool stages = !only.empty() && argc > 5 && std::string(argv[argc - 1]) == "stages";  // "... +mode stages": per-stage GPU time
       Clock::time_point t0;
       double worst = 0, sum = 0;
       for (int k = 0; k < m.frames; k++) {
         if (k == warm) {
           fe.Flush();
+          if (stages && fe.context()) vsf_profile_enable(fe.context(), 1);
           t0 = Clock::now();
         }
         const uint8_t* l = raw.data() + (size_t)(k % NB) * 2 * W * H;
@@ -109,6 +111,14 @@ int main(int argc, char** argv) {
       fe.Flush();
       const double wall = seconds(t0, Clock::now());
       const int n = m.frames - warm;
+      if (stages && fe.context()) {
+        double ms[VSF_STAGE_COUNT];
+        int64_t launches[VSF_STAGE_COUNT];
+        vsf_profile_read(fe.context(), ms, launches, 1);
+        vsf_profile_enable(fe.context(), 0);
+        for (int i = 0; i < VSF_STAGE_COUNT; i++)
+          std::fprintf(stderr, "%-22s %s %8.2f us per frame (%lld launches)\n", m.name, vsf_stage_name(i), 1e3 * ms[i] / n, (long long)launches[i]);
+      }
       int64_t qs[11];
       fe.queue_stats(qs);
       std::printf("%s\"%s_%d\": {\"frames_per_s\": %.1f, \"observe_image_ms_mean\": %.4f, \"observe_image_ms_max\": %.4f, "

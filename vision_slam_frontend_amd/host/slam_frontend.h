@@ -160,6 +160,9 @@ class Frontend {
   void set_copy_thread(bool on) { copy_thread_ = on; }
   // Any vsf_option of the context (applied when it is created): launch choices only, results never depend on them.
   void set_context_option(int option, int value) { ctx_options_.push_back({option, value}); }
+  // The GPU context behind the object (nullptr before the first image / without image_width): for tools that read its
+  // per-stage timers or queue statistics; whoever calls an entry point on it shares the object's single-caller rule.
+  vsf_ctx* context() const { return ctx_; }
   // vsf_observe_stats of the context (frames, batches, largest batch, ...): how the queue coalesced.
   void queue_stats(int64_t out[11]) const { for (int i = 0; i < 11; i++) out[i] = 0; if (ctx_) vsf_observe_stats(ctx_, out, 11); }
   int queue_depth() const { return pipelined_ ? depth_ : 1; }
