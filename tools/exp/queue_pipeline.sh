@@ -1,5 +1,6 @@
 #!/bin/bash
-# The queue's batches with their pyramid beside the previous batch (VSF_OPT_OBSERVE_PIPELINE = option 11: 0 / 1 / 2) and the
+# RECORD OF AN EXPERIMENT (the option it drives, VSF_OPT_OBSERVE_PIPELINE = 11, existed only for it and is gone again: NOTES.md):
+# the queue's batches with their pyramid beside the previous batch (0 / 1 one chain / 2 two chains) and the
 # chain's start (VSF_OPT_PIPE_AFTER_FAST = option 6: 1 behind the previous FAST / 0 as soon as the upload is there)
 python3 tools/time_frontend.py --dump /tmp/frames.raw 32 > /dev/null
 for rep in 1 2; do for v in "11=0" "11=1" "11=2" "11=1 @6=0" "11=2 @6=0"; do
