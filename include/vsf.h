@@ -169,8 +169,9 @@ typedef enum {
                                 * as its inputs are ready (a step whose FAST shares the chip with a decoder) */
   VSF_OPT_PIPE_PRIORITY = 7,   /* stream priority of the pipelined pyramid chain: 0 normal, 1 lowest, -1 highest; set it before
                                 * vsf_set_pipeline(ctx, 1) */
-  VSF_OPT_OBSERVE_THREAD = 8,  /* 1 (default): an ObserveImage queue of depth >= 4 has a launcher thread -- the caller stages
-                                * frames, the thread sends the batches; 0: the caller launches too.  Read when the queue is built */
+  VSF_OPT_OBSERVE_THREAD = 8,  /* 1: an ObserveImage queue of depth >= 4 gets a launcher thread -- the caller stages frames, the
+                                * thread sends the batches (a host whose launches, 0.1-0.3 ms per batch, are what bounds the
+                                * caller); 0 (default): the caller launches too.  Read when the queue is built */
   VSF_OPT_PYRAMID_TAIL_MIN = 9, /* smallest batch (images) whose one-band pyramid levels are one launch (a workgroup per image)
                                  * even when that fills less than three quarters of the chip; 0: never */
   VSF_OPT_OBSERVE_COPY_THREAD = 10, /* 1 (default): while frames stream into an ObserveImage queue of depth >= 4 a second host thread
@@ -377,10 +378,10 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
  * synchronous call is a batch of one); when `min_batch` frames wait and fewer than `in_flight` batches are on the GPU; when
  * a full batch (max_images / 2 frames, at most `depth`) waits; or when a waiting frame is collected.  While the GPU is busy
  * or frames keep arriving, frames accumulate: the batch size follows the caller's rate.  Results are those of one frame at
- * a time, bit for bit, whatever the batches were (tests/test_gpu_observe.py).  A queue of depth >= 4 owns two host threads
- * (VSF_OPT_OBSERVE_THREAD: the launcher, so that the caller only stages and collects; VSF_OPT_OBSERVE_COPY_THREAD: half of a
- * streaming frame's staging copy); every other entry point of the context first sends what waits in the queue, so nothing
- * ever runs beside the launcher.
+ * a time, bit for bit, whatever the batches were (tests/test_gpu_observe.py).  A queue of depth >= 4 owns a host thread that
+ * takes half of a streaming frame's staging copy (VSF_OPT_OBSERVE_COPY_THREAD; host memory only) and, on request, a launcher
+ * thread (VSF_OPT_OBSERVE_THREAD: the caller then only stages and collects; every other entry point of the context first
+ * sends what waits in the queue, so nothing ever runs beside it).
  * Tickets are collected in the order they were issued; a submit beyond `depth` uncollected frames returns
  * VSF_ERR_INVALID_ARG.  Consecutive frames with different calibrations or best_percent never share a batch; frame_life
  * changes only while the queue is empty (the window starts over).

@@ -311,7 +311,7 @@ def test_options_and_sticky_hip_errors(capi):
     with capi.Context(capi.default_params(w, h, max_images=2 * B, nfeatures=nf)) as ctx:
         defaults = {capi.OPT_FAST_BOTH_MAX: 16, capi.OPT_SELECT_WIDE: 1, capi.OPT_PYRAMID_FEW: 16, capi.OPT_PYRAMID_CHAIN: 8,
                     capi.OPT_PYRAMID_ROWS: 6, capi.OPT_SELECT_BIG_CLASS: 1, capi.OPT_PIPE_AFTER_FAST: 1, capi.OPT_PIPE_PRIORITY: 0,
-                    capi.OPT_OBSERVE_THREAD: 1, capi.OPT_PYRAMID_TAIL_MIN: 0, capi.OPT_OBSERVE_COPY_THREAD: 1}
+                    capi.OPT_OBSERVE_THREAD: 0, capi.OPT_PYRAMID_TAIL_MIN: 0, capi.OPT_OBSERVE_COPY_THREAD: 1}
         for opt, want in defaults.items():
             assert ctx.get_option(opt) == want, opt
         for opt, bad in ((99, 0), (-1, 0), (capi.OPT_PYRAMID_ROWS, 0), (capi.OPT_FAST_BOTH_MAX, -1), (capi.OPT_PYRAMID_CHAIN, 65)):

@@ -276,6 +276,7 @@ def test_a_queued_frontend_is_destroyed_with_frames_in_its_queue():
         fe = frontend.Frontend(320, 240, nfeatures=600, fundamental=F_RECT, frame_life=3)
         fe.set_pipelined(True)
         fe.set_queue(depth, batch, 0)
+        fe.set_queue_threads(launcher=(depth == 64), copy=True)
         fe.observe_odometry([0, 0, 0], q, 0.0)
         for f, (l, r) in enumerate(frames):
             fe.observe_odometry([0.3 * (f + 1), 0, 0], q, 1.0 + f)

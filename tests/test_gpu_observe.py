@@ -161,8 +161,9 @@ def _sequence(n, w=320, h=240):
     return frames
 
 
+@pytest.mark.parametrize("thread", [0, 1])
 @pytest.mark.parametrize("depth,batch,min_batch", [(1, 1, 0), (4, 4, 0), (32, 32, 0), (32, 8, 0), (32, 32, 12), (7, 3, 3)])
-def test_queue_depths_equal_the_synchronous_calls(depth, batch, min_batch):
+def test_queue_depths_equal_the_synchronous_calls(depth, batch, min_batch, thread):
     """The queue at depths 1, 4 and 32 (batches of up to `batch` frames; with min_batch, frames wait for company while the
     GPU is busy): 45 frames submitted as fast as the queue takes them -- so that batches of every size form, cut across the
     window filling, the frames without stereo matches and the NaN thresholds behind them -- return byte for byte what the
@@ -174,6 +175,7 @@ def test_queue_depths_equal_the_synchronous_calls(depth, batch, min_batch):
     with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
         want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
     with capi.Context(capi.default_params(320, 240, max_images=2 * batch, nfeatures=NF)) as ctx:
+        ctx.set_option(capi.OPT_OBSERVE_THREAD, thread)  # (the launcher thread of queues of depth >= 4: off by default)
         ctx.observe_configure(depth, min_batch, 0)
         got, tickets = [], []
         for l, r in frames:
@@ -310,6 +312,7 @@ def test_other_entry_points_beside_a_queue_with_its_launcher_thread():
         want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
         kp_want, desc_want = sync_ctx.extract(frames[5][0])
     with capi.Context(capi.default_params(320, 240, max_images=16, nfeatures=NF)) as ctx:
+        ctx.set_option(capi.OPT_OBSERVE_THREAD, 1)
         ctx.observe_configure(30, 8, 0)
         tickets = []
         for k, (l, r) in enumerate(frames):
@@ -325,6 +328,7 @@ def test_other_entry_points_beside_a_queue_with_its_launcher_thread():
         _same_observation(w, g)
     for _ in range(3):
         ctx = capi.Context(capi.default_params(320, 240, max_images=8, nfeatures=NF))
+        ctx.set_option(capi.OPT_OBSERVE_THREAD, 1)
         ctx.observe_configure(12, 0, 0)
         for l, r in frames[:11]:
             ctx.observe_submit(l, r, calib, best_percent=bp, frame_life=LIFE)
@@ -343,6 +347,7 @@ def test_a_waiting_frame_leaves_by_itself_and_poll_does_not_wait():
     with capi.Context(capi.default_params(320, 240, max_images=2, nfeatures=NF)) as sync_ctx:
         want = [sync_ctx.observe_stereo(l, r, calib, best_percent=bp, frame_life=LIFE) for l, r in frames]
     with capi.Context(capi.default_params(320, 240, max_images=16, nfeatures=NF)) as ctx:
+        ctx.set_option(capi.OPT_OBSERVE_THREAD, 1)
         ctx.observe_configure(16, 8, 0)  # (eight frames would have to wait for a busy GPU to take them)
         got = []
         for l, r in frames:

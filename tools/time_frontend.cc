@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
   std::printf("{\"what\": \"slam::Frontend::ObserveImage from C++, %dx%d, frame_life 10 (tools/time_frontend.cc)\", \"results\": {", W, H);
   bool first = true;
   for (int nf : nfs) {
-    struct Mode { const char* name; bool fused, pipelined; int frames, depth, batch, min_batch, read_every; int thread = 1; int tail_min = 0; int copy_thread = 1; };
+    struct Mode { const char* name; bool fused, pipelined; int frames, depth, batch, min_batch, read_every; int thread = 0; int tail_min = 0; int copy_thread = 1; };
     // read_every 1: the reference's driver unchanged -- GetSLAMProblem after every new node (slam_frontend_main.cc:320-321),
     // which waits for the queue; queued_*: the queue of host/slam_frontend.h at depth / frames per batch / min_batch
     // queued_dD_bB: the queue of host/slam_frontend.h at depth D, B frames per batch at most ("queued": the class's defaults)
@@ -52,8 +52,9 @@ int main(int argc, char** argv) {
                           {"queued_d8_b8", true, true, 832, 8, 8, 0, 0},
                           {"queued_d32_b32", true, true, 1632, 32, 32, 0, 0},
                           {"queued_d128_b64", true, true, 3232, 128, 64, 0, 0},
-                          {"queued_d256_b128_no_thread", true, true, 3232, 256, 128, 0, 0, 0},
-                          {"queued_no_copy_thread", true, true, 3232, 0, 0, 0, 0, 1, 0, 0},
+                          {"queued_d64_b64", true, true, 1632, 64, 64, 0, 0},
+                          {"queued_launcher_thread", true, true, 3232, 0, 0, 0, 0, 1},
+                          {"queued_no_copy_thread", true, true, 3232, 0, 0, 0, 0, 0, 0, 0},
                           {"queued", true, true, 3232, 0, 0, 0, 0}};
     for (const Mode& m : modes) {
       if (!only.empty()) {

@@ -100,7 +100,7 @@ struct VsfTuning {
   int pyramid_tail_min = 0;  // VSF_OPT_PYRAMID_TAIL_MIN: smallest batch (images) whose one-band levels take the image-major kernel whatever
                              // share of the chip it fills (0: only batches that fill three quarters of a round of workgroups)
   int observe_copy_thread = 1;  // VSF_OPT_OBSERVE_COPY_THREAD: a helper thread takes the right image's staging copy while frames stream in
-  int observe_thread = 1;  // VSF_OPT_OBSERVE_THREAD: the launcher thread of an ObserveImage queue of depth >= 4
+  int observe_thread = 0;  // VSF_OPT_OBSERVE_THREAD: 1 = an ObserveImage queue of depth >= 4 gets a launcher thread
   int lds_limit = 0;       // largest dynamic LDS a workgroup may ask for on this device (queried at vsf_create)
 };
 

@@ -50,6 +50,8 @@ def lib() -> C.CDLL:
         L.vsfh_set_frames_in_flight.restype = None
         L.vsfh_set_queue.argtypes = [vp, i32, i32, i32]
         L.vsfh_set_queue.restype = None
+        L.vsfh_set_queue_threads.argtypes = [vp, i32, i32]
+        L.vsfh_set_queue_threads.restype = None
         L.vsfh_time_sequence.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(dbl), C.POINTER(dbl)]
         L.vsfh_time_sequence.restype = dbl
         L.vsfh_left_cam_to_robot.argtypes = [vp, vp, vp]
@@ -103,6 +105,11 @@ class Frontend:
         most (default 128: sizes the context), fewest waiting frames that leave while the GPU is busy (0: half a batch).
         Choose before the first observe_image."""
         lib().vsfh_set_queue(self._h, int(depth), int(batch_frames), int(min_batch))
+
+    def set_queue_threads(self, launcher: bool = False, copy: bool = True):
+        """The queue's host threads (VSF_OPT_OBSERVE_THREAD / VSF_OPT_OBSERVE_COPY_THREAD).  Choose before the first
+        observe_image."""
+        lib().vsfh_set_queue_threads(self._h, int(launcher), int(copy))
 
     def time_sequence(self, frames: np.ndarray, n_frames: int, warm: int = 32, read_every: int = 0):
         """The reference's driver loop in C++ (vsfh_time_sequence) over `frames` [n][2][h][w] taken in turn: returns

@@ -37,6 +37,11 @@ void vsfh_set_queue(void* f, int depth, int batch_frames, int min_batch) {
   fe->set_min_batch(min_batch);
 }
 
+void vsfh_set_queue_threads(void* f, int launcher, int copy) {
+  static_cast<Frontend*>(f)->set_queue_thread(launcher != 0);
+  static_cast<Frontend*>(f)->set_copy_thread(copy != 0);
+}
+
 // The reference's driver loop (slam_frontend_main.cc:271-328) for n_frames stereo frames taken in turn from `frames`
 // (n_src x 2 x h x w bytes): ObserveOdometry (a pose 0.3 m further on: OdomCheck accepts every frame) + ObserveImage per
 // frame, no Python between the calls.  The clock starts at frame `warm` (after a Flush) and stops behind the final Flush.

@@ -147,15 +147,16 @@ class Frontend {
   // Frames ObserveImage may leave in the queue when pipelined (1..1024, default 256) and the most frames one batch carries
   // (default 128; the context's extraction buffers are sized for it: ~25 MB of HBM per 640x480 frame; the queue's staging
   // and result rings are pinned host memory: depth x (two images + vsf_observe_capacity)).  Measured on an MI355X at
-  // 640x480 / 2000 features: depth 32 15 k frames/s, 128 (64 per batch) 27 k, 256 (128 per batch) 32 k.
+  // 640x480 / 2000 features: depth 32 19 k frames/s, 64 25 k, 128 (64 per batch) 28 k, 256 (128 per batch) 32 k.
   void set_queue_depth(int n) { depth_ = n < 1 ? 1 : (n > 1024 ? 1024 : n); }
   void set_frames_in_flight(int n) { set_queue_depth(n); }  // (the name of rounds 3-5)
   void set_batch_frames(int n) { batch_frames_ = n < 1 ? 1 : (n > 256 ? 256 : n); }
   // While the GPU is busy, fewer waiting frames than this stay in the queue (0 / 1: whatever waits leaves as soon as fewer
   // than two batches are on the GPU).
   void set_min_batch(int n) { min_batch_ = n < 0 ? 0 : n; }
-  // The queue's host threads: the launcher (VSF_OPT_OBSERVE_THREAD) and the staging-copy helper
-  // (VSF_OPT_OBSERVE_COPY_THREAD); both on by default.
+  // The queue's host threads: the staging-copy helper (VSF_OPT_OBSERVE_COPY_THREAD, on by default) and the launcher
+  // (VSF_OPT_OBSERVE_THREAD, off by default: with frames gathering into half batches it only pays on a host whose launches
+  // are what bounds the caller, and costs where depth = batch).
   void set_queue_thread(bool on) { queue_thread_ = on; }
   void set_copy_thread(bool on) { copy_thread_ = on; }
   // Any vsf_option of the context (applied when it is created): launch choices only, results never depend on them.
@@ -223,7 +224,7 @@ class Frontend {
   bool fused_;
   bool pipelined_;
   int depth_ = 256, batch_frames_ = 128, min_batch_ = 0;
-  bool queue_thread_ = true, copy_thread_ = true;
+  bool queue_thread_ = false, copy_thread_ = true;
   std::vector<std::pair<int, int>> ctx_options_;
   std::vector<PendingFrame> pending_;  // a ring: pending_head_ is the oldest, pending_count_ frames wait
   size_t pending_head_ = 0, pending_count_ = 0;
