@@ -1,5 +1,5 @@
 """The md5sums host/slam_to_ros.h publishes for the nine vision_slam_frontend messages equal what genmsg's rule gives for the
-committed field lists (host/msg/*.msg), and that rule reproduces the md5sums of geometry_msgs every ROS-1 installation
+committed field lists (tools/ros_md5.py: MESSAGES), and that rule reproduces the md5sums of geometry_msgs every ROS-1 installation
 carries (tools/ros_md5.py)."""
 import re
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""ROS-1 md5sums of the nine vision_slam_frontend messages (vision_slam_frontend_amd/host/msg/*.msg: the field lists of the
-reference's msg/*.msg), by genmsg's rule (gentools.compute_md5_text, what `rosmsg md5` / gendeps print):
+"""ROS-1 md5sums of the nine vision_slam_frontend messages (MESSAGES below: the field lists of the reference's msg/*.msg, the
+wire contract host/slam_to_ros.h serialises), by genmsg's rule (gentools.compute_md5_text, what `rosmsg md5` / gendeps print):
 
     comments and blank lines dropped; constants first as "type name=value"; then one line per field, "type name" for a
     builtin type (array suffix kept) and "<md5 of the sub-message> name" for a message type (array suffix dropped);
@@ -14,9 +14,18 @@ Point = Vector3 = 4a842b65f413084dc2b10fb484ea7f17, Quaternion = a779879fadf0160
     python tools/ros_md5.py --header   prints the constants of host/slam_to_ros.h"""
 import hashlib
 import sys
-from pathlib import Path
 
-MSG_DIR = Path(__file__).resolve().parent.parent / "vision_slam_frontend_amd" / "host" / "msg"
+MESSAGES = {  # message -> its field list, "type name" per line (comments of the .msg files do not enter the md5sum)
+    'CameraExtrinsics': 'float64[3] translation\nfloat64[3] rotation',
+    'CameraIntrinsics': 'float64 fx\nfloat64 fy\nfloat64 cx\nfloat64 cy',
+    'FeatureMatch': 'uint64 id_initial\nuint64 id_current',
+    'OdometryFactor': 'uint64 pose_i\nuint64 pose_j\ngeometry_msgs/Vector3 translation\ngeometry_msgs/Quaternion rotation',
+    'RobotPose': 'geometry_msgs/Vector3 loc\ngeometry_msgs/Quaternion angle',
+    'SLAMNode': 'uint64 id\nfloat64 timestamp\nRobotPose pose\nVisionFeature[] features',
+    'SLAMProblem': 'SLAMNode[] nodes\nVisionFactor[] vision_factors\nOdometryFactor[] odometry_factors',
+    'VisionFactor': 'uint64 pose_initial\nuint64 pose_current\nFeatureMatch[] feature_matches',
+    'VisionFeature': 'uint64 id\ngeometry_msgs/Point pixel\ngeometry_msgs/Point point3d',
+}
 PACKAGE = "vision_slam_frontend"
 BUILTIN = {"bool", "int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64", "string",
            "time", "duration", "char", "byte"}
@@ -36,7 +45,7 @@ def msg_text(full_name: str) -> str:
         return GEOMETRY[full_name]
     pkg, name = full_name.split("/")
     assert pkg == PACKAGE, full_name
-    return (MSG_DIR / (name + ".msg")).read_text()
+    return MESSAGES[name] + "\n"
 
 
 def md5_text(full_name: str) -> str:

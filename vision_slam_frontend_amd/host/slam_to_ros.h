@@ -20,7 +20,7 @@
 // float members widen to float64 exactly as the reference's converters assign them.
 //
 // The md5sums below are what a bag writer puts into its connection headers beside type=vision_slam_frontend/<Name>:
-// computed from the field lists in host/msg/*.msg by genmsg's rule (tools/ros_md5.py, which also reproduces the known
+// computed from the field lists in tools/ros_md5.py by genmsg's rule (the same tool reproduces the known
 // md5sums of geometry_msgs/Point, Vector3 and Quaternion); tests/test_ros_md5.py keeps the two in step.
 #ifndef VSF_HOST_SLAM_TO_ROS_H_
 #define VSF_HOST_SLAM_TO_ROS_H_
