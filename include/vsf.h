@@ -433,8 +433,9 @@ vsf_status vsf_observe_stats(const vsf_ctx* ctx, int64_t* out, int n);
  * The images land at d_dst + i * dst_image_stride (DEVICE memory, rows dst_row_stride apart; base and strides multiples
  * of 4) -- the input of vsf_bayer_bg_to_gray_batch_dev or of the extraction.  The files are copied before the call
  * returns; the decode is asynchronous on the context's stream (one wave per image: run it on a context / stream of its
- * own beside other work).  One exception to "asynchronous": a call whose files do not fit the context's pinned staging and
- * device copies (the first call, or a larger batch than any before) waits for the context's stream while it re-allocates them.  A stream that breaks off inside its entropy-coded data decodes as libjpeg does (zero bits) and
+ * own beside other work).  A call whose files do not fit the context's pinned staging and device copies (the first
+ * call, or a larger batch than any before) allocates anew without waiting for the GPU; what it outgrew is released by the
+ * next vsf_sync.  A stream that breaks off inside its entropy-coded data decodes as libjpeg does (zero bits) and
  * makes the next vsf_sync return VSF_ERR_INVALID_ARG.  PNG files take vsf_png_decode_gray_batch. */
 vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, const size_t* nbytes, int n_images,
                                       int width, int height, uint8_t* d_dst, size_t dst_image_stride,

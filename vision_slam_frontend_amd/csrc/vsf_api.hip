@@ -70,6 +70,8 @@ void free_devset(DevSet* ds) {
 void free_retired(vsf_ctx* ctx) {  // (callers have waited for every stream of the context)
   for (void* p : ctx->retired) hipFree(p);
   ctx->retired.clear();
+  for (void* p : ctx->retired_host) hipHostFree(p);
+  ctx->retired_host.clear();
 }
 
 vsf_status ensure_match_buffers(vsf_ctx* ctx, int pairs, int rows) {
@@ -764,7 +766,7 @@ vsf_status vsf_sync(vsf_ctx* ctx) {
   VsfErrorScope scope_(ctx);
   if (!ctx) return VSF_ERR_INVALID_ARG;
   const vsf_status st = check_status_word(ctx);
-  if (!ctx->retired.empty()) {  // scratch a *_dev call outgrew: nothing can be using it once every stream is idle
+  if (!ctx->retired.empty() || !ctx->retired_host.empty()) {  // scratch a *_dev call outgrew: nothing can be using it once every stream is idle
     sync_all_streams(ctx);
     free_retired(ctx);
   }

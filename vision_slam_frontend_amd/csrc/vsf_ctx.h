@@ -123,6 +123,7 @@ struct vsf_ctx {
   // parks the old one here, because hipFree would wait for the whole device behind the caller's back; released by
   // vsf_sync / vsf_reserve / vsf_destroy, when every stream of the context is known to be idle.
   std::vector<void*> retired;
+  std::vector<void*> retired_host;  // ... and pinned host buffers (the ingest's staging)
   // The ObserveImage queue (vsf_observe.hip): frames wait in pinned staging and leave for the GPU in batches.
   static constexpr int kObserveBatchSlots = 4;
   struct ObserveLauncher;    // the queue's lock and its launcher thread

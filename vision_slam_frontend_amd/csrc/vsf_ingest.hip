@@ -13,6 +13,29 @@
 
 using namespace vsfi;
 
+namespace {
+
+// The pinned staging buffer + its device copy of slot b, grown without waiting for the GPU: the old pair goes to the
+// context's retired lists (freed by vsf_sync / vsf_destroy once every stream is idle).
+vsf_status grow_ingest_staging(vsf_ctx* ctx, int b, size_t cap) {
+  void* host = nullptr;
+  VSF_HIP(hipHostMalloc(&host, cap, hipHostMallocDefault));
+  void* dev = nullptr;
+  if (hipMalloc(&dev, cap) != hipSuccess) {
+    hipHostFree(host);
+    (void)hipGetLastError();
+    return VSF_ERR_HIP;
+  }
+  if (ctx->jp_host[b]) ctx->retired_host.push_back(ctx->jp_host[b]);
+  if (ctx->jp_dev[b]) ctx->retired.push_back(ctx->jp_dev[b]);
+  ctx->jp_host[b] = static_cast<uint8_t*>(host);
+  ctx->jp_dev[b] = static_cast<uint8_t*>(dev);
+  ctx->jp_cap[b] = cap;
+  return VSF_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 vsf_status vsf_bayer_bg_to_gray_batch_dev(vsf_ctx* ctx, const uint8_t* d_src, int n_images, int width, int height,
@@ -58,15 +81,10 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
   ctx->jp_flip ^= 1;
   if (!ctx->jp_copied[b]) VSF_HIP(hipEventCreateWithFlags(&ctx->jp_copied[b], hipEventDisableTiming));
   if (plan.total > ctx->jp_cap[b]) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->jp_host[b]) hipHostFree(ctx->jp_host[b]);
-    hipFree(ctx->jp_dev[b]);
-    ctx->jp_host[b] = ctx->jp_dev[b] = nullptr;
-    ctx->jp_cap[b] = 0;
-    const size_t cap = plan.total + plan.total / 4 + 4096;
-    VSF_HIP(hipHostMalloc((void**)&ctx->jp_host[b], cap, hipHostMallocDefault));
-    VSF_HIP(hipMalloc((void**)&ctx->jp_dev[b], cap));
-    ctx->jp_cap[b] = cap;
+    // (no wait for the GPU: the outgrown pair is retired -- an upload or a decode already queued may still be using it --
+    // and released by the next vsf_sync, like every other scratch a *_dev call outgrows)
+    const vsf_status gs = grow_ingest_staging(ctx, b, plan.total + plan.total / 4 + 4096);
+    if (gs != VSF_OK) return gs;
   } else {
     // the upload of the call before the previous one has left this staging buffer (long ago: the previous call's
     // decode is what may still be running, out of the OTHER buffer)
@@ -79,22 +97,15 @@ vsf_status vsf_jpeg_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* jpeg, 
     const size_t clean_need = plan.n_par > 0 ? vsf_jpeg_clean_bytes(plan.total - plan.off_stream, plan.n_par) : 0,
                  coef_need = (size_t)(plan.n_par + plan.n_prog) * coef_stride + vsf_jpeg_prog_huff_bytes(plan.n_prog_huff);
     // (the expanded Huffman tables of progressive scans live behind the coefficients)
-    if (clean_need > ctx->jp_clean_cap || coef_need > ctx->jp_coef_cap) {
-      VSF_HIP(hipStreamSynchronize(ctx->stream));
-      if (clean_need > ctx->jp_clean_cap) {
-        hipFree(ctx->jp_clean);
-        ctx->jp_clean = nullptr;
-        ctx->jp_clean_cap = 0;
-        VSF_HIP(hipMalloc((void**)&ctx->jp_clean, clean_need + clean_need / 4));
-        ctx->jp_clean_cap = clean_need + clean_need / 4;
-      }
-      if (coef_need > ctx->jp_coef_cap) {
-        hipFree(ctx->jp_coef);
-        ctx->jp_coef = nullptr;
-        ctx->jp_coef_cap = 0;
-        VSF_HIP(hipMalloc((void**)&ctx->jp_coef, coef_need + coef_need / 4));
-        ctx->jp_coef_cap = coef_need + coef_need / 4;
-      }
+    if (clean_need > ctx->jp_clean_cap) {  // (no wait: outgrown buffers are retired)
+      const vsf_status gs = grow_scratch(ctx, ctx->jp_clean, clean_need + clean_need / 4);
+      if (gs != VSF_OK) return gs;
+      ctx->jp_clean_cap = clean_need + clean_need / 4;
+    }
+    if (coef_need > ctx->jp_coef_cap) {
+      const vsf_status gs = grow_scratch(ctx, ctx->jp_coef, coef_need + coef_need / 4);
+      if (gs != VSF_OK) return gs;
+      ctx->jp_coef_cap = coef_need + coef_need / 4;
     }
   }
   vsf_jpeg_fill(plan, jpeg, n_images, ctx->jp_host[b]);  // the one pass over the compressed bytes on the host
@@ -140,15 +151,10 @@ vsf_status vsf_png_decode_gray_batch(vsf_ctx* ctx, const uint8_t* const* png, co
   ctx->jp_flip ^= 1;
   if (!ctx->jp_copied[b]) VSF_HIP(hipEventCreateWithFlags(&ctx->jp_copied[b], hipEventDisableTiming));
   if (plan.total > ctx->jp_cap[b]) {
-    VSF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->jp_host[b]) hipHostFree(ctx->jp_host[b]);
-    hipFree(ctx->jp_dev[b]);
-    ctx->jp_host[b] = ctx->jp_dev[b] = nullptr;
-    ctx->jp_cap[b] = 0;
-    const size_t cap = plan.total + plan.total / 4 + 4096;
-    VSF_HIP(hipHostMalloc((void**)&ctx->jp_host[b], cap, hipHostMallocDefault));
-    VSF_HIP(hipMalloc((void**)&ctx->jp_dev[b], cap));
-    ctx->jp_cap[b] = cap;
+    // (no wait for the GPU: the outgrown pair is retired -- an upload or a decode already queued may still be using it --
+    // and released by the next vsf_sync, like every other scratch a *_dev call outgrows)
+    const vsf_status gs = grow_ingest_staging(ctx, b, plan.total + plan.total / 4 + 4096);
+    if (gs != VSF_OK) return gs;
   } else {
     VSF_HIP(hipEventSynchronize(ctx->jp_copied[b]));  // (the upload of the call before the previous one has left this buffer)
   }
