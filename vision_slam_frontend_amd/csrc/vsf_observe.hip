@@ -10,10 +10,10 @@
 //               result per frame written straight into pinned host memory.
 // A frame's launch-bound chain of ~30 small kernels costs the host 5.4 us per launch and the GPU a launch-to-launch latency
 // per kernel whatever the batch holds, so a batch of n frames costs little more than a batch of one until the chip is full.
-// When a batch leaves: at once when the GPU is idle (a lone frame: the synchronous call is a batch of one); when `min_batch`
-// frames wait (half a batch by default) and fewer than `in_flight` batches are on the GPU; when a whole batch waits; or
-// when somebody collects a frame that still waits.  While the GPU is busy, frames accumulate -- the batch size follows the
-// caller's rate by itself.
+// When a batch leaves (batch_to_launch): when a whole batch waits; when `min_batch` frames wait (half a batch by default) and
+// fewer than `in_flight` batches are on the GPU; when the GPU is idle and no frame has arrived for 100 us; or when somebody
+// collects a frame that still waits (a lone frame: the synchronous call is a batch of one).  While the GPU is busy, frames
+// accumulate -- the batch size follows the caller's rate by itself.
 // The kept frames' filtered descriptors live in a ring of descriptor sets in HBM (frame g in set g % ring); the pair list
 // of a batch addresses them by set index, so a frame matches against frames of earlier batches and of its own alike.
 // Results are those of one frame at a time, bit for bit (tests/test_gpu_observe.py).
@@ -117,13 +117,14 @@ struct vsf_ctx::ObserveCopyHelper {
   }
 };
 
-// Who launches.  A batch costs the host 0.1 ms (a lone frame) to 0.3 ms (the batched pyramid alone is 50-100 launches):
-// on the caller's thread that was a third of what a queued frame cost.  A queue of depth >= 4 therefore has a LAUNCHER
-// thread: the caller stages frames (10 us each) and the thread sends whatever the policy releases, polling the GPU's state
-// while frames wait.  The caller still launches by itself where waiting for the thread would cost more than it saves: when
-// it collects a frame that still waits (the synchronous call: submit, collect), and for every other entry point of the
-// context, which first sends everything that waits (VsfErrorScope -> vsf_ctx_enter), so that nothing else ever runs beside
-// the thread.  `launching` is the baton: whoever holds it is alone inside launch_batch.
+// Who launches.  A batch costs the host 0.1 ms (a lone frame) to 0.4 ms (the batched pyramid alone is 50-100 launches).
+// By default the caller launches, between two submits (4-5 us per frame at 64-128 frames per batch).  With
+// VSF_OPT_OBSERVE_THREAD a queue of depth >= 4 has a LAUNCHER thread instead: the caller stages frames and the thread sends
+// whatever the policy releases, polling the GPU's state while frames wait (measured slower wherever depth == batch size, the
+// same elsewhere: off by default).  The caller still launches by itself where waiting for the thread would cost more than it
+// saves: when it collects a frame that still waits (the synchronous call: submit, collect), and for every other entry
+// point of the context, which first sends everything that waits (VsfErrorScope -> vsf_ctx_enter), so that nothing else ever
+// runs beside the thread.  `launching` is the baton: whoever holds it is alone inside launch_batch.
 struct vsf_ctx::ObserveLauncher {
   std::mutex mu;  // guards next_ticket / next_launch / next_collect, launching, stop, status
   std::condition_variable cv_thread, cv_caller;
