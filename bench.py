@@ -911,11 +911,11 @@ def main() -> int:
         bound = "valu" if valu and valu["frac"] > hbm_frac else "hbm"
         # matcher (K9): pair distances per second of the stereo knn2 launches and the int8 matrix-core rate they imply
         # (a 256-bit distance is 256 int8 multiply-adds on the MFMA pipe = 512 ops)
-        knn_ms, knn_launches = stages.get("hamming_knn2", (0.0, 0))
+        knn_ms, knn_launches = stages_all.get("hamming_knn2", (0.0, 0))
         matcher = None
+        mean_n = float(counts.mean())
+        pairs_per_step = B * mean_n * mean_n  # stereo L->R; the R'->L' and temporal launches are ~1 % of that
         if knn_ms > 0:
-            mean_n = float(counts.mean())
-            pairs_per_step = B * mean_n * mean_n  # stereo L->R; the R'->L' and temporal launches are ~1 % of that
             dps = pairs_per_step * args.steps / (knn_ms * 1e-3)
             peak = MFMA_FP4_PEAK_TOPS
             matcher = {"pair_distances_per_s": dps, "mfma_tops": dps * 512 / 1e12,
@@ -937,6 +937,32 @@ def main() -> int:
                                       "note": "against the measured rate of 4-cycle instructions; FAST by itself issues at "
                                               "its mix ceiling, the other stages wait on latency (NOTES.md section 6)"}
         device_ms = sum(v[0] for k, v in stages.items() if k not in concurrent)
+        roofline = {"bound": "hbm", "limited_by": None if (pmc_stale or not pmc) else bound, "kernel": dom, "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_stale": bool(pmc_stale),
+                    "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
+                    "launches": dom_launches, "shares_the_chip_with": shares,
+                    "in_line": None if not inline_stages else {
+                        "avg_launch_ms": inline_stages[dom] * args.steps / max(dom_launches, 1),
+                        "achieved": alg[dom] / (inline_stages[dom] * 1e-3) / 1e9,
+                        "frac": alg[dom] / (inline_stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "the kernel by itself: 3 untimed steps with every stage back in line on one stream"}}
+        if dom == "hamming_knn2":
+            # the matcher runs on the matrix cores (at nfeatures = 10000 it is the step's longest stage): its roofline is the
+            # dense FP4 MFMA rate -- 512 operations per 256-bit distance -- not HBM, which it leaves idle (the HBM figures stay
+            # beside it as "hbm")
+            ops_per_launch = pairs_per_step * 512 * args.steps / max(dom_launches, 1)
+            tops = ops_per_launch / per_launch_s / 1e12
+            hbm_view = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
+            roofline.update({"bound": "mfma", "achieved": tops, "peak": MFMA_FP4_PEAK_TOPS, "unit": "TFLOP/s",
+                             "frac": tops / MFMA_FP4_PEAK_TOPS, "algorithmic_flops_per_launch": ops_per_launch,
+                             "form": "fp4 (v_mfma_scale_f32_32x32x64_f8f6f4, exact); per launch: the step's stereo pair "
+                                     "distances / its matcher launches", "hbm": hbm_view})
+            del roofline["algorithmic_bytes_per_launch"]
+            if sf.match_on_tail and sf.overlap:  # (its span in the timed steps is a span under contention: see in_line)
+                roofline["shares_the_chip_with"] = ["the next step's extraction (the matcher is the tail stream's first kernel)"]
+            if inline_stages:
+                t_in = pairs_per_step * 512 / (inline_stages[dom] * 1e-3) / 1e12
+                roofline["in_line"].update({"achieved": t_in, "frac": t_in / MFMA_FP4_PEAK_TOPS})
         out = {
             "metric": ("stereo frames/s (640x480, 2000 kp/frame)" if (W, H, NF) == (640, 480, 2000)
                        else "stereo frames/s (%dx%d, %d kp/frame)" % (W, H, NF)) +
@@ -981,15 +1007,7 @@ def main() -> int:
                        "capacity_overflow": bool(overflow_ranks)},
             # "bound" names the roofline this object is measured against (the contract knows "hbm" and "mfma");
             # "limited_by" says what the counters show the kernel is actually limited by (see "roofline_valu")
-            "roofline": {"bound": "hbm", "limited_by": None if (pmc_stale or not pmc) else bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_stale": bool(pmc_stale),
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
-                         "launches": dom_launches, "shares_the_chip_with": shares,
-                         "in_line": None if not inline_stages else {
-                             "avg_launch_ms": inline_stages[dom] * args.steps / max(dom_launches, 1),
-                             "achieved": alg[dom] / (inline_stages[dom] * 1e-3) / 1e9,
-                             "frac": alg[dom] / (inline_stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "the kernel by itself: 3 untimed steps with every stage back in line on one stream"}},
+            "roofline": roofline,
             # self-verification of a multi-GPU run: what the process group says it is, the ranks an all-gather of rank ids
             # saw on that backend, every rank's own step time, the longest any rank's host waited inside a gather
             "rccl": dict(handshake, per_rank_ms_per_step={"min": min(rank_ms), "max": max(rank_ms)},
