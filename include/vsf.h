@@ -399,7 +399,7 @@ vsf_status vsf_pack_outputs_dev(vsf_ctx* ctx, const vsf_vision_feature* d_featur
 size_t vsf_observe_capacity(const vsf_ctx* ctx, int frame_life);
 /* depth: frames that may be submitted and not collected (0: max_images / 2; up to 1024 -- the staging and result rings are
  * pinned host memory, depth x (2 images + vsf_observe_capacity)); a batch holds min(depth, max_images / 2) frames at most.
- * min_batch (0 = half a batch): while the GPU is busy, fewer waiting frames than this do not leave -- an idle GPU takes
+ * min_batch (0 = a whole batch when depth >= two batches, else half the depth): while the GPU is busy, fewer waiting frames than this do not leave -- an idle GPU takes
  * whatever waits, a collect sends everything -- because a batch costs the host ~45 launches whatever it carries.  in_flight (0 = 2, at most 3): batches on the GPU at a time.  Call it before the first submit or while
  * the queue is empty; changing depth rebuilds the queue (window and threshold start over). */
 vsf_status vsf_observe_configure(vsf_ctx* ctx, int depth, int min_batch, int in_flight);

@@ -10,7 +10,7 @@
 //               result per frame written straight into pinned host memory.
 // A frame's launch-bound chain of ~30 small kernels costs the host 5.4 us per launch and the GPU a launch-to-launch latency
 // per kernel whatever the batch holds, so a batch of n frames costs little more than a batch of one until the chip is full.
-// When a batch leaves (batch_to_launch): when a whole batch waits; when `min_batch` frames wait (half a batch by default) and
+// When a batch leaves (batch_to_launch): when a whole batch waits; when `min_batch` frames wait (a whole batch by default while the queue holds two, else half the queue) and
 // fewer than `in_flight` batches are on the GPU; when the GPU is idle and no frame has arrived for 100 us; or when somebody
 // collects a frame that still waits (a lone frame: the synchronous call is a batch of one).  While the GPU is busy, frames
 // accumulate -- the batch size follows the caller's rate by itself.
@@ -475,14 +475,18 @@ int batch_to_launch(vsf_ctx* ctx, bool force) {
   const int pending = (int)(o.next_ticket - o.next_launch);
   if (pending <= 0) return 0;
   if (force || pending >= o.bmax) return std::min(pending, o.bmax);
-  // An idle GPU takes whatever waits.  A busy one is in no hurry: frames wait for company -- half a batch by default --
-  // because a batch costs ~50-100 launches whatever it carries (measured on the caller's thread: batches of 1-8 frames
-  // 14 k frames/s, of 32-64 frames 27 k).
+  // An idle GPU takes whatever waits.  A busy one is in no hurry: frames wait for company because a batch costs ~50-100
+  // launches whatever it carries (measured on the caller's thread: batches of 1-8 frames 14 k frames/s, of 32-64 frames
+  // 27 k).  How much company: in steady state a batch leaves the moment `min_batch` frames wait, so min_batch IS the batch
+  // size -- by default a whole batch when the queue is deep enough for the caller to fill the next one meanwhile (depth >= 2
+  // batches), else half the queue, so that staging and the GPU still overlap (tools/exp/min_batch.sh: depth 64 / 32 per
+  // batch 19.8 -> 25.0 k frames/s against half a batch, 128 / 64 27.9 -> 28.8 k, 256 / 128 32.0 -> 32.4 k; at depth =
+  // batch size half the queue is what it was).
   // ... and "idle" must not be mistaken for "nobody is coming": while frames stream in (the last one arrived less than
   // 100 us ago) even an idle GPU waits for min_batch of them.  Without that a GPU that once ran dry keeps being fed batches of
   // a few frames, each gone before the next has gathered (measured: the same queue at 15 k or 32 k frames/s).
   const int busy = batches_on_gpu(ctx);
-  const int min_batch = ctx->ob_min_batch > 0 ? std::min(ctx->ob_min_batch, o.bmax) : std::max(1, o.bmax / 2);
+  const int min_batch = ctx->ob_min_batch > 0 ? std::min(ctx->ob_min_batch, o.bmax) : std::max(1, std::min(o.bmax, o.depth / 2));
   if (busy < ctx->ob_in_flight && pending >= min_batch) return pending;
   return (busy == 0 && now_ns() - o.last_submit_ns > 100000) ? pending : 0;
 }

@@ -102,7 +102,7 @@ class Frontend:
 
     def set_queue(self, depth: int = 0, batch_frames: int = 0, min_batch: int = 0):
         """The ObserveImage queue of a pipelined Frontend: frames that may wait uncollected (default 256), frames per batch at
-        most (default 128: sizes the context), fewest waiting frames that leave while the GPU is busy (0: half a batch).
+        most (default 128: sizes the context), fewest waiting frames that leave while the GPU is busy (0: a whole batch, or half the depth when that is less).
         Choose before the first observe_image."""
         lib().vsfh_set_queue(self._h, int(depth), int(batch_frames), int(min_batch))
 

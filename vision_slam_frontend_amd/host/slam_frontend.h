@@ -151,11 +151,11 @@ class Frontend {
   void set_queue_depth(int n) { depth_ = n < 1 ? 1 : (n > 1024 ? 1024 : n); }
   void set_frames_in_flight(int n) { set_queue_depth(n); }  // (the name of rounds 3-5)
   void set_batch_frames(int n) { batch_frames_ = n < 1 ? 1 : (n > 256 ? 256 : n); }
-  // While the GPU is busy, fewer waiting frames than this stay in the queue (0 / 1: whatever waits leaves as soon as fewer
-  // than two batches are on the GPU).
+  // While the GPU is busy, fewer waiting frames than this stay in the queue (0: a whole batch, or half the queue's depth
+  // when that is less; 1: whatever waits leaves as soon as fewer than two batches are on the GPU).
   void set_min_batch(int n) { min_batch_ = n < 0 ? 0 : n; }
   // The queue's host threads: the staging-copy helper (VSF_OPT_OBSERVE_COPY_THREAD, on by default) and the launcher
-  // (VSF_OPT_OBSERVE_THREAD, off by default: with frames gathering into half batches it only pays on a host whose launches
+  // (VSF_OPT_OBSERVE_THREAD, off by default: with frames gathering into batches it only pays on a host whose launches
   // are what bounds the caller, and costs where depth = batch).
   void set_queue_thread(bool on) { queue_thread_ = on; }
   void set_copy_thread(bool on) { copy_thread_ = on; }
