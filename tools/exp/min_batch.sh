@@ -1,6 +1,8 @@
 #!/bin/bash
+# RECORD OF AN EXPERIMENT (the modes qx_* of tools/time_frontend.cc existed only for it: NOTES.md): the queue's min_batch
+# at several depths, same box, alternating runs
 python3 tools/time_frontend.py --dump /tmp/frames.raw 32 > /dev/null
-for rep in 1 2; do
+for rep in 1 2 3; do
   tools/time_frontend /tmp/frames.raw 640 480 32 2000 10000 +qx_ 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
