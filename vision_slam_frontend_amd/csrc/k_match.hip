@@ -41,6 +41,12 @@ __device__ inline void merge_top2(uint32_t& m1, uint32_t& m2, uint32_t b1, uint3
 constexpr int kWgQueries = 128;   // 4 waves x 32 queries
 
 __device__ inline int imed3(int a, int b, int c) { return min(max(a, b), max(min(a, b), c)); }  // v_med3_i32
+// v_min3_i32.  `a` goes through an empty asm first: min(a, b) is also a subexpression of imed3(a, b, c), and once the compiler
+// has merged the two it emits two v_min instead of one v_min3 (the asm holds no instruction and touches no matrix result).
+__device__ inline int imin3(int a, int b, int c) {
+  asm("" : "+v"(a));
+  return min(min(a, b), c);
+}
 
 // ---- round 5: the same key out of the FP4 matrix instruction ----
 // v_mfma_scale_f32_32x32x64_f8f6f4 with E2M1 operands takes K = 64 per instruction at the cycles v_mfma_i32_32x32x32_i8
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256, 4) void knn2_fp4_kernel(const uint8_t* __restr
                                                           int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][kTile * kTileStride4];
   // byte of descriptor bits -> dword of eight train-side FP4 codes: the staging of a tile is four table reads per thread
-  // instead of ~20 vector instructions (the fold, 33 instructions per tile, is what the vector ALU is for here:
+  // instead of ~20 vector instructions (the fold, 22 instructions per tile, is what the vector ALU is for here:
   // 0.188 -> 0.173 ms per 256 pairs of 2000 x 2000)
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = 0xEEEEEEEEu ^ fp4_spread8(threadIdx.x);  // (the first barrier below orders it)
@@ -130,7 +136,12 @@ __global__ __launch_bounds__(256, 4) void knn2_fp4_kernel(const uint8_t* __restr
   // compiler's own interleaving is as good; a fold that skips groups of four accumulator registers none of whose keys
   // is below a lane's second best -- v_min3 + v_min + one compare + a wave-uniform branch per group, the eight fold
   // instructions for 20-60 % of the groups -- 0.187 ms, and 0.979 against 0.944 ms per 64 pairs of 10 000 x 10 000: the
-  // branches cost more than the instructions they save.)
+  // branches cost more than the instructions they save.  Round 6: all of a step's LDS traffic issued at its start -- the
+  // next tile's write from registers expanded a step earlier, so that nothing is in flight at the barrier: 0.158 against
+  // 0.152 ms and 0.894 against 0.870 ms; two query tiles per wave, half the LDS reads per distance
+  // (tools/exp/match_wide.patch): equal.  The counters (tools/exp/match_counters.sh, 64 pairs of 10 000 x 10 000): matrix
+  // pipe busy 38 % of the SIMD cycles, vector ALU 50 %, both at once 16 %, the LDS 58 % of the CU's cycles (a third of it
+  // bank conflicts of the table reads): no unit is full, the waves of a SIMD take turns.)
   const int st_row = tid >> 3, st_s = tid & 7;
   auto load_bits = [&](int t0, int c_end) -> uint32_t { return T[(size_t)min(t0 + st_row, c_end - 1) * 8 + st_s]; };
   auto stage = [&](int buf, uint32_t bits) {
@@ -147,12 +158,21 @@ __global__ __launch_bounds__(256, 4) void knn2_fp4_kernel(const uint8_t* __restr
       m1 -= (float)kTile;  // (exact: integers below 2^24; the "none" key stays 1.7e38)
       m2 -= (float)kTile;
       int i1 = __float_as_int(m1), i2 = __float_as_int(m2);
+      // Two keys at a time: the second smallest of {i1, i2, k0, k1} with i1 <= i2 is min(i2, median(i1, k0, k1)) -- either
+      // i2 or the second smallest of the other three -- so a pair costs v_med3 + v_min3 and two pairs share one v_min3 into
+      // i2: five instructions per four keys where one key at a time (v_med3 + v_min) takes eight.
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const bool valid = !check || t0 + (i & 3) + 8 * (i >> 2) + 4 * h < c_end;
-        const int k = valid ? __float_as_int(a[i]) : kKeyNoneBits;
-        i2 = imed3(i1, i2, k);
-        i1 = min(i1, k);
+      for (int i = 0; i < 16; i += 4) {
+        int k[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool valid = !check || t0 + ((i + j) & 3) + 8 * ((i + j) >> 2) + 4 * h < c_end;
+          k[j] = valid ? __float_as_int(a[i + j]) : kKeyNoneBits;
+        }
+        const int ta = imed3(i1, k[0], k[1]), ia = imin3(i1, k[0], k[1]);
+        const int tb = imed3(ia, k[2], k[3]);
+        i1 = imin3(ia, k[2], k[3]);
+        i2 = imin3(i2, ta, tb);
       }
       m1 = __int_as_float(i1);
       m2 = __int_as_float(i2);
