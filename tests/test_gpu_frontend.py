@@ -265,6 +265,26 @@ def test_queued_observe_image_books_the_synchronous_problem(depth, batch, min_ba
     assert [len(n["features"]) for n in a["nodes"]][21:24] == [0, 0, 0] and len(a["nodes"][24]["features"]) > 20
 
 
+@pytest.mark.parametrize("nfeatures", [2000, 10000])
+def test_the_benched_queue_books_the_synchronous_problem(nfeatures):
+    """What bench.py's `observe_image` leg times, held to the synchronous mode byte for byte: 640x480, the reference's window
+    of 10, 2000 features and the reference's own nfeatures = 10000, the class's DEFAULT queue (depth 256, up to 128 frames per
+    batch) fed by the C++ driver loop (vsfh_time_sequence: the reference's ObserveOdometry + ObserveImage per frame, no Python
+    between the calls, so that batches really fill) -- 420 frames, the whole SLAMProblem as ROS wire bytes."""
+    from vision_slam_frontend_amd import frontend, synth
+    sc = synth.Scene(640, 480)
+    frames = np.stack([np.stack([sc.render(f, 0), sc.render(f, 1)]) for f in range(14)])
+    wires = []
+    for pipelined in (False, True):
+        fe = frontend.Frontend(640, 480, nfeatures=nfeatures, fundamental=F_RECT)
+        fe.set_pipelined(pipelined)
+        fps, _, _ = fe.time_sequence(frames, 420, warm=0)
+        assert fps > 0 and fe.num_poses == 420
+        wires.append(fe.serialize_problem())
+        fe.close()
+    assert len(wires[0]) > 1000000 and wires[0] == wires[1]
+
+
 def test_a_queued_frontend_is_destroyed_with_frames_in_its_queue():
     """~Frontend with frames staged, on the GPU and uncollected (launcher thread and copy helper alive): the context stops its
     threads, waits for its streams and frees what their kernels write; a Frontend created afterwards works."""
